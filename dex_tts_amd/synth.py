@@ -1,0 +1,96 @@
+"""Portable synthetic weights and inputs (numpy only, counter-based, bit-reproducible anywhere).
+
+No trained checkpoints exist offline, and the reference's default init zeroes
+every DiT adaLN/final projection and every ``Rezero.g`` (dit.py:404-413, diffusion.py:35), which
+would make the DiT and linear-attention branches dead.  This generator therefore overwrites *all*
+parameters with non-degenerate values derived from a splitmix64 stream keyed by the parameter name,
+so the oracle container (where goldens are made from the real reference) and the GPU box (where the
+HIP path is checked) regenerate identical tensors without shipping ~31 MB of weights.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_GOLDEN = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+
+def _fnv1a64(s: str) -> int:
+    h = 0xCBF29CE484222325
+    for b in s.encode("utf-8"):
+        h ^= b
+        h = (h * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def uniform01(key: str, n: int, seed: int = 0) -> np.ndarray:
+    """n float64 values in [0,1) from splitmix64(fnv1a(key) ^ seed-mix); element i depends only on i."""
+    base = np.uint64((_fnv1a64(key) ^ ((seed * 0xD1342543DE82EF95) & 0xFFFFFFFFFFFFFFFF)) & 0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        z = base + (np.arange(1, n + 1, dtype=np.uint64) * _GOLDEN)
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def symmetric(key: str, shape, scale: float, seed: int = 0) -> np.ndarray:
+    n = int(np.prod(shape)) if len(shape) else 1
+    return ((uniform01(key, n, seed) * 2.0 - 1.0) * scale).astype(np.float32).reshape(shape)
+
+
+def normalish(key: str, shape, seed: int = 0) -> np.ndarray:
+    """Approximately N(0,1): sum of 4 uniforms, variance-normalised (portable, no Box-Muller libm)."""
+    n = int(np.prod(shape))
+    u = sum(uniform01(f"{key}#{j}", n, seed) for j in range(4))
+    return ((u - 2.0) * np.sqrt(3.0)).astype(np.float32).reshape(shape)
+
+
+def make_weights(shapes: dict, seed: int = 0) -> dict:
+    """name -> float32 ndarray for every entry of ``config.param_shapes``.
+
+    >=2-D tensors: U(-a, a) with a = sqrt(3 / fan_in) (unit-gain); GroupNorm scales: 1 + 0.1 u;
+    Rezero gates ``*.fn.g``: 0.4 + 0.1 u; every other 1-D tensor (biases): 0.1 u;
+    ``vit.freq_new_pos_embed``: 0.1 u.
+    """
+    out = {}
+    for name, shape in shapes.items():
+        shape = tuple(shape)
+        if name.endswith("block.1.weight"):
+            w = 1.0 + symmetric(name, shape, 0.1, seed)
+        elif name.endswith(".fn.g"):
+            w = 0.4 + symmetric(name, shape, 0.1, seed)
+        elif name == "vit.freq_new_pos_embed":
+            w = symmetric(name, shape, 0.1, seed)
+        elif len(shape) >= 2:
+            fan_in = int(np.prod(shape[1:]))
+            w = symmetric(name, shape, float(np.sqrt(3.0 / fan_in)), seed)
+        else:
+            w = symmetric(name, shape, 0.1, seed)
+        out[name] = np.ascontiguousarray(w, dtype=np.float32)
+    return out
+
+
+def make_inputs(B: int, T: int, lengths=None, seed: int = 1234, temperature: float = 1.5):
+    """Synthetic (mu, mask, z) of SURVEY §8-d: mel-like prior clipped to [-11.5, 2.5], float mask
+    from lengths, and the latent z = randn / temperature + mu (diffusion.py:227) drawn portably."""
+    mu = np.clip(normalish("mu", (B, 80, T), seed) - 5.0, -11.5, 2.5).astype(np.float32)
+    if lengths is None:
+        lengths = [T] * B
+    lengths = np.asarray(lengths, dtype=np.int64)
+    mask = (np.arange(T)[None, :] < lengths[:, None]).astype(np.float32)[:, None, :]
+    z = (normalish("z", (B, 80, T), seed + 100) / np.float32(temperature) + mu).astype(np.float32)
+    return mu, mask, z, lengths
+
+
+def make_dex_style(B: int, Tr: int, Ts: int, mid: int = 128, n_skips: int = 6, seed: int = 77,
+                   ref_lengths=None, sty_lengths=None):
+    """Synthetic style-encoder outputs for DEX (stand-ins for TIVEncoder skips / TVEncoder tokens,
+    DEX-TTS/model/tts.py:42-51): 6 skips [B,mid,Tr], style tokens [B,mid,Ts], and their lengths."""
+    ref = [normalish(f"ref{j}", (B, mid, Tr), seed) * np.float32(0.7 + 0.1 * j) + np.float32(0.05 * j)
+           for j in range(n_skips)]
+    sty = normalish("sty", (B, mid, Ts), seed)
+    ref_lengths = np.asarray(ref_lengths if ref_lengths is not None else [Tr] * B, dtype=np.int64)
+    sty_lengths = np.asarray(sty_lengths if sty_lengths is not None else [Ts] * B, dtype=np.int64)
+    return ref, ref_lengths, sty.astype(np.float32), sty_lengths
