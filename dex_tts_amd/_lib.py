@@ -1,0 +1,96 @@
+"""ctypes binding of libdexamd.so (C ABI declared in include/dex_amd.h).  No CPU fallback: if the
+library is missing this module raises, and the product path fails loudly."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libdexamd.so")
+
+DEX_OK = 0
+VARIANT = {"gedex": 0, "dex": 1}
+PRECISION = {"fp32": 0, "bf16": 1}
+
+
+class DexConfig(C.Structure):
+    _fields_ = [("variant", C.c_int32), ("n_feats", C.c_int32), ("dim", C.c_int32), ("n_stages", C.c_int32),
+                ("dim_mults", C.c_int32 * 4), ("n_spks", C.c_int32), ("spk_emb_dim", C.c_int32),
+                ("pe_scale", C.c_float),
+                ("dit_patch", C.c_int32), ("dit_stride", C.c_int32), ("dit_hidden", C.c_int32),
+                ("dit_depth", C.c_int32), ("dit_heads", C.c_int32), ("dit_mlp_ratio", C.c_float),
+                ("dit_conv_pos", C.c_int32), ("dit_conv_pos_groups", C.c_int32)]
+
+
+class DexSampleArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("n_steps", C.c_int32),
+                ("z_dev", C.c_void_p), ("mu_dev", C.c_void_p), ("mask_dev", C.c_void_p), ("sigmas_dev", C.c_void_p),
+                ("spk_dev", C.c_void_p),
+                ("ref_skips_dev", C.POINTER(C.c_void_p)), ("n_ref", C.c_int32), ("Tr", C.c_int32),
+                ("sty_dev", C.c_void_p), ("sty_lengths_dev", C.c_void_p), ("Ts", C.c_int32),
+                ("out_dev", C.c_void_p), ("workspace_dev", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("use_graph", C.c_int32)]
+
+
+class DexDenoiseArgs(C.Structure):
+    _fields_ = [("s", DexSampleArgs), ("x_dev", C.c_void_p)]
+
+
+# every symbol include/dex_amd.h declares: (name, restype, argtypes)
+SYMBOLS = [
+    ("dex_ctx_create", C.c_int, [C.POINTER(DexConfig), C.POINTER(C.c_void_p)]),
+    ("dex_ctx_destroy", None, [C.c_void_p]),
+    ("dex_last_error", C.c_char_p, [C.c_void_p]),
+    ("dex_version", C.c_char_p, []),
+    ("dex_ctx_num_weights", C.c_int, [C.c_void_p]),
+    ("dex_ctx_weight_info", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    ("dex_ctx_load_weight", C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    ("dex_ctx_finalize", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("dex_ctx_set_precision", C.c_int, [C.c_void_p, C.c_int]),
+    ("dex_workspace_bytes", C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("dex_sample", C.c_int, [C.c_void_p, C.POINTER(DexSampleArgs), C.c_void_p]),
+    ("dex_denoise_once", C.c_int, [C.c_void_p, C.POINTER(DexDenoiseArgs), C.c_void_p]),
+    ("dex_edm_sigmas", C.c_int, [C.c_int, C.POINTER(C.c_float)]),
+    ("dex_num_taps", C.c_int, [C.c_void_p]),
+    ("dex_tap_name", C.c_char_p, [C.c_void_p, C.c_int]),
+    ("dex_tap_info", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    ("dex_tap_copy", C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("dex_profile_enable", C.c_int, [C.c_void_p, C.c_int]),
+    ("dex_profile_num", C.c_int, [C.c_void_p]),
+    ("dex_profile_get", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_double),
+                                  C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("dex_mel_frames", C.c_int, [C.c_int]),
+    ("dex_mel_from_wav", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+]
+
+_lib = None
+
+
+def load():
+    """dlopen libdexamd.so and type its entry points.  Raises if the library is absent — build it with
+    `python -m dex_tts_amd.build` (hipcc, gfx950)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: the HIP extension is required (python -m dex_tts_amd.build); "
+                           "there is no CPU fallback in the product path")
+    lib = C.CDLL(LIB_PATH)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+def make_config(cfg) -> DexConfig:
+    c = DexConfig()
+    c.variant = VARIANT[cfg.variant]
+    c.n_feats, c.dim, c.n_stages = cfg.n_feats, cfg.dim, len(cfg.dim_mults)
+    for i, m in enumerate(cfg.dim_mults):
+        c.dim_mults[i] = int(m)
+    c.n_spks, c.spk_emb_dim, c.pe_scale = cfg.n_spks, cfg.spk_emb_dim, float(cfg.pe_scale)
+    t = cfg.dit
+    c.dit_patch, c.dit_stride, c.dit_hidden, c.dit_depth, c.dit_heads = t.patch_size, t.stride_size, t.hidden_size, t.depth, t.num_heads
+    c.dit_mlp_ratio, c.dit_conv_pos, c.dit_conv_pos_groups = float(t.mlp_ratio), t.conv_pos, t.conv_pos_groups
+    return c

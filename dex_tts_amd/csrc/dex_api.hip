@@ -1,0 +1,1086 @@
+// dex_api.hip — C ABI of libdexamd.so (include/dex_amd.h): context, weight packing, workspace plan,
+// and the host-side enqueue of one EDM Euler step / the whole sampler.  No torch types; raw device
+// pointers + hipStream_t only.  Reference call chain replaced: GeDEX-TTS/model/diffusion.py:220-229 ->
+// model/edm.py:109-216 -> :88-98 -> diffusion.py:168-207 (+ model/dit.py:485-525, DEX ref_encoder.py).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dex_amd.h"
+#include "kernels.h"
+
+using namespace dex;
+
+namespace {
+
+struct RawW { float* p = nullptr; std::vector<int64_t> shape; long numel = 0; bool loaded = false; };
+struct TD { float* p; int ld; int coff; int C; };          // channels-last activation view
+
+struct ResW { const float *w1, *b1, *g1, *be1, *w2, *b2, *g2, *be2, *wr, *br, *mlp_w, *mlp_b; int cin, cout; };
+struct LinW { const float *wqkv, *wout_raw, *bias_eff, *g; int C; };
+struct DitBlockW { const float *wqkv, *bqkv, *wproj, *bproj, *wfc1, *bfc1, *wfc2, *bfc2, *ada_w, *ada_b; };
+
+struct Prof { std::string name; hipEvent_t a, b; double flops, bytes; };
+struct ProfAgg { std::string name; int calls; double ms, flops, bytes; };
+
+struct Arena {                                             // bump allocator over the caller's workspace
+    char* base = nullptr; size_t off = 0, cap = 0; bool dry = true;
+    void* take(size_t bytes) {
+        off = (off + 255) & ~size_t(255);
+        void* p = dry ? nullptr : (void*)(base + off);
+        off += bytes;
+        return p;
+    }
+    float* f(size_t n) { return (float*)take(n * sizeof(float)); }
+};
+
+}  // namespace
+
+struct DexCtx {
+    DexConfig cfg{};
+    std::string err;
+    std::vector<std::string> keys;
+    std::map<std::string, RawW> raw;
+    std::vector<void*> owned;                              // hipMalloc'ed packed weights
+    bool finalized = false;
+    int precision = DEX_PREC_FP32;
+    // packed weights
+    std::vector<std::vector<ResW>> down_res, up_res;       // [stage][2]
+    std::vector<LinW> down_lin, up_lin;
+    std::vector<const float*> down_ds_w, down_ds_b;        // Downsample
+    std::vector<const float*> up_us_w, up_us_b;            // Upsample: 4 parity matrices back to back
+    const float *fc_w3 = nullptr, *fc_w1 = nullptr;        // first conv packs
+    const float *fin_w = nullptr, *fin_b = nullptr, *fin_g = nullptr, *fin_be = nullptr, *fconv_w = nullptr, *fconv_b = nullptr;
+    const float *pe_dw = nullptr, *pe_db = nullptr, *pe_pw = nullptr, *pe_pb = nullptr, *pos_w = nullptr, *pos_b = nullptr, *freq_pos = nullptr;
+    std::vector<DitBlockW> blocks;
+    const float *fl_w = nullptr, *fl_b = nullptr, *fl_ada_w = nullptr, *fl_ada_b = nullptr;
+    const float *tv_wq_raw = nullptr, *tv_wk = nullptr, *tv_wv = nullptr, *tv_wl = nullptr;
+    // mel front-end constants
+    float *mel_basis = nullptr, *mel_filt = nullptr; void* mel_ws = nullptr; size_t mel_ws_bytes = 0;
+    // taps of the last call
+    struct Tap { std::string name; const float* p; std::vector<int64_t> shape; };
+    std::vector<Tap> taps;
+    // profiling
+    bool prof_on = false;
+    std::vector<Prof> prof;
+    std::vector<ProfAgg> prof_agg;
+    // hipGraph cache of one Euler step
+    hipGraphExec_t graph_exec = nullptr;
+    std::vector<uint64_t> graph_key;
+
+    int fail(int code, const char* fmt, ...) {
+        char buf[512];
+        va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+
+#define HIPCHK(ctx, call)                                                                              \
+    do { hipError_t e_ = (call); if (e_ != hipSuccess)                                                 \
+        return (ctx)->fail(DEX_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+// ================================================================================================
+// parameter inventory (mirrors dex_tts_amd/config.py:param_shapes; validated against the reference
+// state-dict manifests in tests/golden/manifest_*.json by tests/test_cabi.py)
+namespace {
+
+int stage_dim(const DexConfig& c, int i) { return c.dim * c.dim_mults[i]; }
+int in_planes(const DexConfig& c) { return 2 + (c.n_spks > 1 ? 1 : 0); }
+int mid_dim(const DexConfig& c) { return stage_dim(c, c.n_stages - 1); }
+int mid_h(const DexConfig& c) { return c.n_feats >> (c.n_stages - 1); }
+int grid_h(const DexConfig& c) { return mid_h(c) / c.dit_stride; }
+int token_rows(const DexConfig& c) { return (mid_h(c) + 2 * (c.dit_patch / 2) - c.dit_patch) / c.dit_stride + 1; }
+int token_cols(const DexConfig& c, int wmid) {
+    const int p = c.dit_patch, s = c.dit_stride;
+    const int wp = (wmid % p == 0) ? wmid : wmid + (p - wmid % p);
+    return (wp + 2 * (p / 2) - p) / s + 1;
+}
+int mlp_hidden(const DexConfig& c) { return (int)(c.dit_hidden * c.dit_mlp_ratio); }
+
+void add_key(DexCtx* x, const std::string& k, std::vector<int64_t> shape) {
+    x->keys.push_back(k);
+    RawW r; r.shape = std::move(shape); r.numel = 1;
+    for (auto d : r.shape) r.numel *= d;
+    x->raw[k] = r;
+}
+void add_resnet(DexCtx* x, const std::string& p, int cin, int cout, int tdim) {
+    add_key(x, p + ".mlp.1.weight", {cout, tdim}); add_key(x, p + ".mlp.1.bias", {cout});
+    for (int blk = 1; blk <= 2; ++blk) {
+        const std::string q = p + ".block" + std::to_string(blk) + ".block";
+        add_key(x, q + ".0.weight", {cout, blk == 1 ? cin : cout, 3, 3}); add_key(x, q + ".0.bias", {cout});
+        add_key(x, q + ".1.weight", {cout}); add_key(x, q + ".1.bias", {cout});
+    }
+    if (cin != cout) { add_key(x, p + ".res_conv.weight", {cout, cin, 1, 1}); add_key(x, p + ".res_conv.bias", {cout}); }
+}
+void add_linattn(DexCtx* x, const std::string& p, int c) {
+    add_key(x, p + ".fn.g", {1});
+    add_key(x, p + ".fn.fn.to_qkv.weight", {384, c, 1, 1});
+    add_key(x, p + ".fn.fn.to_out.weight", {c, 128, 1, 1});
+    add_key(x, p + ".fn.fn.to_out.bias", {c});
+}
+void build_inventory(DexCtx* x) {
+    const DexConfig& c = x->cfg;
+    const int d = c.dim;
+    add_key(x, "mlp.0.weight", {4 * d, d}); add_key(x, "mlp.0.bias", {4 * d});
+    add_key(x, "mlp.2.weight", {d, 4 * d}); add_key(x, "mlp.2.bias", {d});
+    if (c.variant == DEX_VARIANT_DEX)
+        for (const char* n : {"mlp_adap", "mlp_adap_sty"}) {
+            const std::string s(n);
+            add_key(x, s + ".0.weight", {d, d}); add_key(x, s + ".0.bias", {d});
+            add_key(x, s + ".2.weight", {2 * d, d}); add_key(x, s + ".2.bias", {2 * d});
+        }
+    if (c.n_spks > 1) {
+        const int e = c.spk_emb_dim;
+        add_key(x, "spk_mlp.0.weight", {4 * e, e}); add_key(x, "spk_mlp.0.bias", {4 * e});
+        add_key(x, "spk_mlp.2.weight", {c.n_feats, 4 * e}); add_key(x, "spk_mlp.2.bias", {c.n_feats});
+    }
+    for (int i = 0; i < c.n_stages; ++i) {
+        const int ci = i == 0 ? in_planes(c) : stage_dim(c, i - 1), co = stage_dim(c, i);
+        const std::string p = "downs." + std::to_string(i);
+        add_resnet(x, p + ".0", ci, co, d); add_resnet(x, p + ".1", co, co, d); add_linattn(x, p + ".2", co);
+        if (i < c.n_stages - 1) { add_key(x, p + ".3.conv.weight", {co, co, 3, 3}); add_key(x, p + ".3.conv.bias", {co}); }
+    }
+    const int hid = c.dit_hidden, mid = mid_dim(c), mh = mlp_hidden(c);
+    add_key(x, "vit.freq_new_pos_embed", {1, hid, grid_h(c), 1});
+    add_key(x, "vit.x_embedder.proj.0.weight", {mid, 1, c.dit_patch, c.dit_patch}); add_key(x, "vit.x_embedder.proj.0.bias", {mid});
+    add_key(x, "vit.x_embedder.proj.2.weight", {hid, mid, 1, 1}); add_key(x, "vit.x_embedder.proj.2.bias", {hid});
+    add_key(x, "vit.t_embedder.mlp.0.weight", {hid, 256}); add_key(x, "vit.t_embedder.mlp.0.bias", {hid});
+    add_key(x, "vit.t_embedder.mlp.2.weight", {hid, hid}); add_key(x, "vit.t_embedder.mlp.2.bias", {hid});
+    add_key(x, "vit.pos_conv.0.weight", {hid, hid / c.dit_conv_pos_groups, c.dit_conv_pos, c.dit_conv_pos});
+    add_key(x, "vit.pos_conv.0.bias", {hid});
+    for (int k = 0; k < c.dit_depth; ++k) {
+        const std::string p = "vit.blocks." + std::to_string(k);
+        add_key(x, p + ".attn.qkv.weight", {3 * hid, hid}); add_key(x, p + ".attn.qkv.bias", {3 * hid});
+        add_key(x, p + ".attn.proj.weight", {hid, hid}); add_key(x, p + ".attn.proj.bias", {hid});
+        add_key(x, p + ".mlp.fc1.weight", {mh, hid}); add_key(x, p + ".mlp.fc1.bias", {mh});
+        add_key(x, p + ".mlp.fc2.weight", {hid, mh}); add_key(x, p + ".mlp.fc2.bias", {hid});
+        add_key(x, p + ".adaLN_modulation.1.weight", {6 * hid, hid}); add_key(x, p + ".adaLN_modulation.1.bias", {6 * hid});
+    }
+    const int so = c.dit_stride * c.dit_stride * mid;
+    add_key(x, "vit.final_layer.linear.weight", {so, hid}); add_key(x, "vit.final_layer.linear.bias", {so});
+    add_key(x, "vit.final_layer.adaLN_modulation.1.weight", {2 * hid, hid}); add_key(x, "vit.final_layer.adaLN_modulation.1.bias", {2 * hid});
+    if (c.variant == DEX_VARIANT_DEX) {
+        for (const char* w : {"w_q", "w_k", "w_v", "linear"}) add_key(x, std::string("tv_adaptor.") + w + ".weight", {mid, mid});
+        for (const char* s : {"mean_sap", "std_sap"}) {
+            add_key(x, std::string("tiv_adaptor.") + s + ".W.weight", {1, mid});
+            add_key(x, std::string("tiv_adaptor.") + s + ".W.bias", {1});
+        }
+    }
+    for (int j = 0; j < c.n_stages - 1; ++j) {
+        const int i = c.n_stages - 1 - j;                   // consumes the skip of down stage i
+        const int ci = stage_dim(c, i - 1), co = stage_dim(c, i);
+        const std::string p = "ups." + std::to_string(j);
+        add_resnet(x, p + ".0", co * 2, ci, d); add_resnet(x, p + ".1", ci, ci, d); add_linattn(x, p + ".2", ci);
+        add_key(x, p + ".3.conv.weight", {ci, ci, 4, 4}); add_key(x, p + ".3.conv.bias", {ci});
+    }
+    add_key(x, "final_block.block.0.weight", {d, d, 3, 3}); add_key(x, "final_block.block.0.bias", {d});
+    add_key(x, "final_block.block.1.weight", {d}); add_key(x, "final_block.block.1.bias", {d});
+    add_key(x, "final_conv.weight", {1, d, 1, 1}); add_key(x, "final_conv.bias", {1});
+}
+
+// ConvTranspose2d(4,2,1) -> four 2x2-tap parity sub-convolutions.
+// dst[par = ph*2+pw][(th*2+tw)*Cin + ci][co] = src[ci][co][kh][kw],  kh = (ph ? 0 : 1) + 2*th, kw likewise.
+__global__ void pack_convt_kernel(const float* src, float* dst, int Cin, int Cout) {
+    const long total = 4L * 4 * Cin * Cout;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(i % Cout);
+        const int ci = (int)((i / Cout) % Cin);
+        const int tap = (int)((i / ((long)Cout * Cin)) % 4);
+        const int par = (int)(i / ((long)Cout * Cin * 4));
+        const int ph = par >> 1, pw = par & 1, th = tap >> 1, tw = tap & 1;
+        const int kh = (ph ? 0 : 1) + 2 * th, kw = (pw ? 0 : 1) + 2 * tw;
+        dst[i] = src[(((long)ci * Cout + co) * 4 + kh) * 4 + kw];
+    }
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+const char* dex_version(void) { return "dexamd 0.1 (gfx950)"; }
+
+int dex_ctx_create(const DexConfig* cfg, DexCtx** out) {
+    if (!cfg || !out) return DEX_ERR_ARG;
+    DexCtx* x = new DexCtx();
+    x->cfg = *cfg;
+    const DexConfig& c = x->cfg;
+    *out = x;
+    if (c.n_feats != 80) return x->fail(DEX_ERR_ARG, "n_feats must be 80 (diffusion.py:226 hard-codes it)");
+    if (c.n_stages < 2 || c.n_stages > 4) return x->fail(DEX_ERR_ARG, "n_stages must be in [2,4]");
+    if (c.dim % 64 != 0) return x->fail(DEX_ERR_ARG, "dim must be a multiple of 64");
+    if (c.dit_hidden / c.dit_heads != 128) return x->fail(DEX_ERR_ARG, "DiT head_dim must be 128 (hidden %d heads %d)", c.dit_hidden, c.dit_heads);
+    if (c.dit_hidden % 64 || c.dit_hidden > 512) return x->fail(DEX_ERR_ARG, "dit_hidden must be a multiple of 64, <= 512");
+    if (mlp_hidden(c) % 64) return x->fail(DEX_ERR_ARG, "mlp hidden must be a multiple of 64");
+    if ((c.dit_hidden / c.dit_conv_pos_groups) != 32) return x->fail(DEX_ERR_ARG, "pos-conv must have 32 channels per group");
+    if (c.dit_conv_pos % 2) return x->fail(DEX_ERR_ARG, "conv_pos must be even");
+    if (c.variant == DEX_VARIANT_DEX && mid_dim(c) != 128) return x->fail(DEX_ERR_ARG, "DEX adaptors need mid_dim 128 (attention head_dim)");
+    build_inventory(x);
+    return DEX_OK;
+}
+
+void dex_ctx_destroy(DexCtx* x) {
+    if (!x) return;
+    for (auto& kv : x->raw) if (kv.second.p) hipFree(kv.second.p);
+    for (void* p : x->owned) hipFree(p);
+    if (x->mel_basis) hipFree(x->mel_basis);
+    if (x->mel_filt) hipFree(x->mel_filt);
+    if (x->mel_ws) hipFree(x->mel_ws);
+    if (x->graph_exec) hipGraphExecDestroy(x->graph_exec);
+    for (auto& pr : x->prof) { hipEventDestroy(pr.a); hipEventDestroy(pr.b); }
+    delete x;
+}
+
+const char* dex_last_error(const DexCtx* x) { return x ? x->err.c_str() : "null context"; }
+int dex_ctx_num_weights(const DexCtx* x) { return x ? (int)x->keys.size() : 0; }
+
+int dex_ctx_weight_info(const DexCtx* x, int i, const char** key, int64_t shape[4], int* ndim) {
+    if (!x || i < 0 || i >= (int)x->keys.size()) return DEX_ERR_ARG;
+    const RawW& r = x->raw.at(x->keys[i]);
+    if (key) *key = x->keys[i].c_str();
+    if (ndim) *ndim = (int)r.shape.size();
+    if (shape) for (size_t k = 0; k < r.shape.size(); ++k) shape[k] = r.shape[k];
+    return DEX_OK;
+}
+
+int dex_ctx_load_weight(DexCtx* x, const char* key, const float* w_dev, const int64_t* shape, int ndim) {
+    if (!x || !key || !w_dev) return DEX_ERR_ARG;
+    auto it = x->raw.find(key);
+    if (it == x->raw.end()) return x->fail(DEX_ERR_ARG, "unknown weight key '%s'", key);
+    RawW& r = it->second;
+    if ((int)r.shape.size() != ndim) return x->fail(DEX_ERR_ARG, "weight '%s': expected %d dims, got %d", key, (int)r.shape.size(), ndim);
+    for (int k = 0; k < ndim; ++k)
+        if (r.shape[k] != shape[k]) return x->fail(DEX_ERR_ARG, "weight '%s': dim %d is %lld, expected %lld", key, k, (long long)shape[k], (long long)r.shape[k]);
+    if (!r.p) HIPCHK(x, hipMalloc((void**)&r.p, r.numel * sizeof(float)));
+    HIPCHK(x, hipMemcpy(r.p, w_dev, r.numel * sizeof(float), hipMemcpyDeviceToDevice));
+    r.loaded = true;
+    x->finalized = false;
+    return DEX_OK;
+}
+
+int dex_ctx_set_precision(DexCtx* x, int precision) {
+    if (!x || (precision != DEX_PREC_FP32 && precision != DEX_PREC_BF16)) return DEX_ERR_ARG;
+    if (precision == DEX_PREC_BF16) return x->fail(DEX_ERR_ARG, "bf16 MFMA mode is not built in this version");
+    x->precision = precision;
+    return DEX_OK;
+}
+
+}  // extern "C"
+
+// ================================================================================================
+// weight packing
+namespace {
+
+struct Packer {
+    DexCtx* x; hipStream_t st; int rc = DEX_OK;
+    float* alloc(long n) {
+        float* p = nullptr;
+        if (hipMalloc((void**)&p, n * sizeof(float)) != hipSuccess) { rc = x->fail(DEX_ERR_HIP, "hipMalloc of %ld floats failed", n); return nullptr; }
+        x->owned.push_back(p);
+        return p;
+    }
+    const RawW& R(const std::string& k) { return x->raw.at(k); }
+    const float* raw(const std::string& k) { return R(k).p; }
+    // [d0,d1,d2,d3] -> permuted contiguous copy
+    const float* perm(const std::string& k, int d0, int d1, int d2, int d3, int p0, int p1, int p2, int p3) {
+        float* dst = alloc((long)d0 * d1 * d2 * d3);
+        if (dst) launch_permute4(raw(k), dst, d0, d1, d2, d3, p0, p1, p2, p3, st);
+        return dst;
+    }
+    // conv / linear weight [out, in, kh, kw] -> [(kh*KW+kw)*in + ci][out]
+    const float* kn(const std::string& k) {
+        const auto& s = R(k).shape;
+        const int o = (int)s[0], i = (int)s[1], kh = s.size() > 2 ? (int)s[2] : 1, kw = s.size() > 3 ? (int)s[3] : 1;
+        return perm(k, o, i, kh, kw, 2, 3, 1, 0);
+    }
+    ResW resnet(const std::string& p, int cin, int cout, bool first) {
+        ResW r{};
+        r.cin = cin; r.cout = cout;
+        const std::string b1 = p + ".block1.block", b2 = p + ".block2.block";
+        if (first) {   // [C, planes, 3, 3] -> [planes*9][C]
+            r.w1 = perm(b1 + ".0.weight", cout, cin, 3, 3, 1, 2, 3, 0);
+            r.wr = perm(p + ".res_conv.weight", cout, cin, 1, 1, 1, 2, 3, 0);
+        } else {
+            r.w1 = kn(b1 + ".0.weight");
+            r.wr = (cin != cout) ? kn(p + ".res_conv.weight") : nullptr;
+        }
+        r.br = (cin != cout) ? raw(p + ".res_conv.bias") : nullptr;
+        r.b1 = raw(b1 + ".0.bias"); r.g1 = raw(b1 + ".1.weight"); r.be1 = raw(b1 + ".1.bias");
+        r.w2 = kn(b2 + ".0.weight");
+        r.b2 = raw(b2 + ".0.bias"); r.g2 = raw(b2 + ".1.weight"); r.be2 = raw(b2 + ".1.bias");
+        r.mlp_w = raw(p + ".mlp.1.weight"); r.mlp_b = raw(p + ".mlp.1.bias");
+        return r;
+    }
+    LinW linattn(const std::string& p, int c) {
+        LinW l{};
+        l.C = c;
+        l.wqkv = kn(p + ".fn.fn.to_qkv.weight");
+        l.wout_raw = raw(p + ".fn.fn.to_out.weight");
+        l.g = raw(p + ".fn.g");
+        float* be = alloc(c);
+        if (be) launch_scale_copy(raw(p + ".fn.fn.to_out.bias"), be, c, l.g, st);     // Rezero gate folded into the bias
+        l.bias_eff = be;
+        return l;
+    }
+};
+
+// mel front-end constants (audio/stft.py:26-47,145-147), built on the host in double, rounded like the reference
+void build_mel_constants(std::vector<float>& basis, std::vector<float>& filt) {
+    const int n_fft = 1024, nb = 513, NP = 1152, IM = 576;
+    basis.assign((size_t)n_fft * NP, 0.f);
+    for (int n = 0; n < n_fft; ++n) {
+        const float win = (float)(0.5 - 0.5 * cos(2.0 * M_PI * n / n_fft));         // periodic Hann
+        for (int k = 0; k < nb; ++k) {
+            const double ang = 2.0 * M_PI * (double)(((long)k * n) % n_fft) / n_fft;
+            basis[(size_t)n * NP + k] = (float)cos(ang) * win;
+            basis[(size_t)n * NP + IM + k] = (float)(-sin(ang)) * win;
+        }
+    }
+    // librosa.filters.mel(22050, 1024, 80, 0, 8000), Slaney scale + slaney area normalisation
+    const int n_mels = 80; const double sr = 22050, fmin = 0, fmax = 8000;
+    auto hz2mel = [](double f) { const double fsp = 200.0 / 3; return f >= 1000.0 ? 1000.0 / fsp + log(f / 1000.0) / (log(6.4) / 27.0) : f / fsp; };
+    auto mel2hz = [](double m) { const double fsp = 200.0 / 3, mlm = 1000.0 / fsp; return m >= mlm ? 1000.0 * exp(log(6.4) / 27.0 * (m - mlm)) : fsp * m; };
+    std::vector<double> mf(n_mels + 2);
+    const double m0 = hz2mel(fmin), m1 = hz2mel(fmax);
+    for (int i = 0; i < n_mels + 2; ++i) mf[i] = mel2hz(m0 + (m1 - m0) * i / (n_mels + 1));
+    filt.assign((size_t)n_mels * nb, 0.f);
+    for (int i = 0; i < n_mels; ++i) {
+        const double enorm = 2.0 / (mf[i + 2] - mf[i]);
+        for (int k = 0; k < nb; ++k) {
+            const double fr = (sr / 2.0) * k / (nb - 1);
+            const double lower = (fr - mf[i]) / (mf[i + 1] - mf[i]), upper = (mf[i + 2] - fr) / (mf[i + 2] - mf[i + 1]);
+            const double w = fmax > 0 ? std::max(0.0, std::min(lower, upper)) : 0.0;
+            filt[(size_t)i * nb + k] = (float)(w * enorm);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dex_ctx_finalize(DexCtx* x, dex_stream_t stream) {
+    if (!x) return DEX_ERR_ARG;
+    for (const auto& k : x->keys)
+        if (!x->raw.at(k).loaded) return x->fail(DEX_ERR_STATE, "weight '%s' was never loaded", k.c_str());
+    for (void* p : x->owned) hipFree(p);
+    x->owned.clear();
+    if (x->graph_exec) { hipGraphExecDestroy(x->graph_exec); x->graph_exec = nullptr; x->graph_key.clear(); }
+    const DexConfig& c = x->cfg;
+    hipStream_t st = (hipStream_t)stream;
+    Packer P{x, st};
+    x->down_res.assign(c.n_stages, {}); x->down_lin.clear(); x->down_ds_w.clear(); x->down_ds_b.clear();
+    for (int i = 0; i < c.n_stages; ++i) {
+        const int ci = i == 0 ? in_planes(c) : stage_dim(c, i - 1), co = stage_dim(c, i);
+        const std::string p = "downs." + std::to_string(i);
+        x->down_res[i].push_back(P.resnet(p + ".0", ci, co, i == 0));
+        x->down_res[i].push_back(P.resnet(p + ".1", co, co, false));
+        x->down_lin.push_back(P.linattn(p + ".2", co));
+        if (i < c.n_stages - 1) { x->down_ds_w.push_back(P.kn(p + ".3.conv.weight")); x->down_ds_b.push_back(P.raw(p + ".3.conv.bias")); }
+    }
+    x->up_res.assign(c.n_stages - 1, {}); x->up_lin.clear(); x->up_us_w.clear(); x->up_us_b.clear();
+    for (int j = 0; j < c.n_stages - 1; ++j) {
+        const int i = c.n_stages - 1 - j, ci = stage_dim(c, i - 1), co = stage_dim(c, i);
+        const std::string p = "ups." + std::to_string(j);
+        x->up_res[j].push_back(P.resnet(p + ".0", co * 2, ci, false));
+        x->up_res[j].push_back(P.resnet(p + ".1", ci, ci, false));
+        x->up_lin.push_back(P.linattn(p + ".2", ci));
+        float* wt = P.alloc(16L * ci * ci);
+        if (wt) hipLaunchKernelGGL(pack_convt_kernel, dim3(256), dim3(256), 0, st, P.raw(p + ".3.conv.weight"), wt, ci, ci);
+        x->up_us_w.push_back(wt); x->up_us_b.push_back(P.raw(p + ".3.conv.bias"));
+    }
+    x->fin_w = P.kn("final_block.block.0.weight"); x->fin_b = P.raw("final_block.block.0.bias");
+    x->fin_g = P.raw("final_block.block.1.weight"); x->fin_be = P.raw("final_block.block.1.bias");
+    x->fconv_w = P.raw("final_conv.weight"); x->fconv_b = P.raw("final_conv.bias");
+    const int hid = c.dit_hidden, mid = mid_dim(c), G = c.dit_conv_pos_groups, kp = c.dit_conv_pos;
+    x->pe_dw = P.perm("vit.x_embedder.proj.0.weight", mid, 1, c.dit_patch, c.dit_patch, 2, 3, 1, 0);
+    x->pe_db = P.raw("vit.x_embedder.proj.0.bias");
+    x->pe_pw = P.kn("vit.x_embedder.proj.2.weight"); x->pe_pb = P.raw("vit.x_embedder.proj.2.bias");
+    x->pos_w = P.perm("vit.pos_conv.0.weight", G, hid / G, hid / G, kp * kp, 0, 3, 2, 1);   // [G][tap][ci][n]
+    x->pos_b = P.raw("vit.pos_conv.0.bias");
+    x->freq_pos = P.perm("vit.freq_new_pos_embed", 1, hid, grid_h(c), 1, 0, 2, 3, 1);       // [Hf][hid]
+    x->blocks.clear();
+    for (int k = 0; k < c.dit_depth; ++k) {
+        const std::string p = "vit.blocks." + std::to_string(k);
+        DitBlockW b{};
+        b.wqkv = P.kn(p + ".attn.qkv.weight"); b.bqkv = P.raw(p + ".attn.qkv.bias");
+        b.wproj = P.kn(p + ".attn.proj.weight"); b.bproj = P.raw(p + ".attn.proj.bias");
+        b.wfc1 = P.kn(p + ".mlp.fc1.weight"); b.bfc1 = P.raw(p + ".mlp.fc1.bias");
+        b.wfc2 = P.kn(p + ".mlp.fc2.weight"); b.bfc2 = P.raw(p + ".mlp.fc2.bias");
+        b.ada_w = P.raw(p + ".adaLN_modulation.1.weight"); b.ada_b = P.raw(p + ".adaLN_modulation.1.bias");
+        x->blocks.push_back(b);
+    }
+    x->fl_w = P.kn("vit.final_layer.linear.weight"); x->fl_b = P.raw("vit.final_layer.linear.bias");
+    x->fl_ada_w = P.raw("vit.final_layer.adaLN_modulation.1.weight"); x->fl_ada_b = P.raw("vit.final_layer.adaLN_modulation.1.bias");
+    if (c.variant == DEX_VARIANT_DEX) {
+        x->tv_wq_raw = P.raw("tv_adaptor.w_q.weight");
+        x->tv_wk = P.kn("tv_adaptor.w_k.weight"); x->tv_wv = P.kn("tv_adaptor.w_v.weight"); x->tv_wl = P.kn("tv_adaptor.linear.weight");
+    }
+    if (!x->mel_basis) {
+        std::vector<float> basis, filt;
+        build_mel_constants(basis, filt);
+        HIPCHK(x, hipMalloc((void**)&x->mel_basis, basis.size() * sizeof(float)));
+        HIPCHK(x, hipMalloc((void**)&x->mel_filt, filt.size() * sizeof(float)));
+        HIPCHK(x, hipMemcpy(x->mel_basis, basis.data(), basis.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(x, hipMemcpy(x->mel_filt, filt.data(), filt.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    if (P.rc != DEX_OK) return P.rc;
+    HIPCHK(x, hipStreamSynchronize(st));
+    HIPCHK(x, hipGetLastError());
+    x->finalized = true;
+    return DEX_OK;
+}
+
+// ================================================================================================
+// workspace plan + step enqueue
+namespace {
+
+constexpr int SCAL_STRIDE = 8;
+constexpr int LA_CHUNK = 512;
+constexpr int POS_SPLIT = 8;
+
+struct Dims { int B, T, Tr, Ts, n_steps; };
+
+struct StageBuf {
+    int H, W, C, mask_ws; long npix;
+    float *h1, *a1, *h2, *rbuf, *r0out, *r1out;        // resblock scratch
+    float *qkv, *pm, *ps, *pc, *weff; int nchunks;
+    float* attn_out; int attn_ld, attn_coff;            // where the stage's attention output lives
+    float* ds_out;                                      // Downsample output (down stages except the last)
+};
+
+struct Plan {
+    Dims d;
+    float *sig2, *scal, *t_unet, *t_dit, *tmp_u, *temb, *c_tmp, *c_emb, *fin_mod;
+    std::vector<float*> tadd_down, tadd_up, ada;
+    float *adap_tmp, *t_adap, *t_sty, *tv_k0, *tv_v0, *sap_m, *sap_s, *ref_mean, *ref_std;
+    float *spk_tmp, *spk_plane;
+    int* step; double* stats; long stats_bytes; int n_gn;
+    float* xbuf;
+    std::vector<StageBuf> down, up;
+    std::vector<float*> cat;
+    float *up_out, *hF;
+    int Hm, Wm, Hf, Wt, N;
+    float *pe0, *emb, *pos_part, *tok, *xn, *qkv, *ao, *hmlp, *dbg_tok;
+    float *tv_keys, *tv_K, *tv_V, *tv_q, *tv_ao, *tv_out, *tiv_out, *tv_weff, *tv_beff; double *tv_stats, *tiv_stats;
+    size_t bytes;
+};
+
+void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
+    const DexConfig& c = x->cfg;
+    Arena A; A.base = (char*)ws; A.dry = (ws == nullptr);
+    P.d = d;
+    const int n = d.n_steps, dim = c.dim, hid = c.dit_hidden, mid = mid_dim(c), B = d.B;
+    P.sig2 = A.f(64);
+    P.scal = A.f((size_t)n * SCAL_STRIDE); P.t_unet = A.f((size_t)n * dim); P.t_dit = A.f((size_t)n * 256);
+    P.tmp_u = A.f((size_t)n * 4 * dim); P.temb = A.f((size_t)n * dim);
+    P.c_tmp = A.f((size_t)n * hid); P.c_emb = A.f((size_t)n * hid); P.fin_mod = A.f((size_t)n * 2 * hid);
+    P.tadd_down.clear(); P.tadd_up.clear(); P.ada.clear();
+    for (int i = 0; i < c.n_stages; ++i) for (int r = 0; r < 2; ++r) P.tadd_down.push_back(A.f((size_t)n * stage_dim(c, i)));
+    for (int j = 0; j < c.n_stages - 1; ++j) for (int r = 0; r < 2; ++r) P.tadd_up.push_back(A.f((size_t)n * stage_dim(c, c.n_stages - 2 - j)));
+    for (int k = 0; k < c.dit_depth; ++k) P.ada.push_back(A.f((size_t)n * 6 * hid));
+    P.adap_tmp = P.t_adap = P.t_sty = P.tv_k0 = P.tv_v0 = P.sap_m = P.sap_s = P.ref_mean = P.ref_std = nullptr;
+    if (c.variant == DEX_VARIANT_DEX) {
+        P.adap_tmp = A.f((size_t)n * dim); P.t_adap = A.f((size_t)n * 2 * dim); P.t_sty = A.f((size_t)n * 2 * dim);
+        P.tv_k0 = A.f((size_t)n * mid); P.tv_v0 = A.f((size_t)n * mid);
+        P.sap_m = A.f((size_t)n * B * mid); P.sap_s = A.f((size_t)n * B * mid);
+        P.ref_mean = A.f((size_t)B * 8 * mid); P.ref_std = A.f((size_t)B * 8 * mid);
+    }
+    P.spk_tmp = P.spk_plane = nullptr;
+    if (c.n_spks > 1) { P.spk_tmp = A.f((size_t)B * 4 * c.spk_emb_dim); P.spk_plane = A.f((size_t)B * c.n_feats); }
+    P.step = (int*)A.take(256);
+    P.n_gn = 4 * c.n_stages + 4 * (c.n_stages - 1) + 1;
+    P.stats_bytes = (long)P.n_gn * B * 8 * 2 * sizeof(double);
+    P.stats = (double*)A.take(P.stats_bytes);
+    P.xbuf = A.f((size_t)B * 80 * d.T);
+    P.cat.assign(c.n_stages - 1, nullptr);
+    for (int j = 0; j < c.n_stages - 1; ++j) {
+        const int i = c.n_stages - 1 - j;
+        P.cat[j] = A.f((size_t)B * (c.n_feats >> i) * (d.T >> i) * 2 * stage_dim(c, i));
+    }
+    auto stage = [&](int H, int W, int C, int mws) {
+        StageBuf s{};
+        s.H = H; s.W = W; s.C = C; s.mask_ws = mws; s.npix = (long)H * W;
+        const size_t e = (size_t)B * s.npix;
+        s.h1 = A.f(e * C); s.a1 = A.f(e * C); s.h2 = A.f(e * C); s.rbuf = A.f(e * C); s.r0out = A.f(e * C); s.r1out = A.f(e * C);
+        s.qkv = A.f(e * 384);
+        s.nchunks = (int)((s.npix + LA_CHUNK - 1) / LA_CHUNK);
+        s.pm = A.f((size_t)B * 4 * s.nchunks * 32); s.ps = A.f((size_t)B * 4 * s.nchunks * 32);
+        s.pc = A.f((size_t)B * 4 * s.nchunks * 1024); s.weff = A.f((size_t)B * 128 * C);
+        s.ds_out = nullptr;
+        return s;
+    };
+    P.down.clear(); P.up.clear();
+    for (int i = 0; i < c.n_stages; ++i) {
+        StageBuf s = stage(c.n_feats >> i, d.T >> i, stage_dim(c, i), 1 << i);
+        if (i >= 1) { const int j = c.n_stages - 1 - i; s.attn_out = P.cat[j]; s.attn_ld = 2 * s.C; s.attn_coff = s.C; }
+        else { s.attn_out = A.f((size_t)B * s.npix * s.C); s.attn_ld = s.C; s.attn_coff = 0; }
+        if (i < c.n_stages - 1) s.ds_out = A.f((size_t)B * (s.npix / 4) * s.C);
+        P.down.push_back(s);
+    }
+    for (int j = 0; j < c.n_stages - 1; ++j) {
+        const int i = c.n_stages - 1 - j;
+        StageBuf s = stage(c.n_feats >> i, d.T >> i, stage_dim(c, i - 1), 1 << i);
+        s.attn_out = A.f((size_t)B * s.npix * s.C); s.attn_ld = s.C; s.attn_coff = 0;
+        P.up.push_back(s);
+    }
+    P.up_out = A.f((size_t)B * 80 * d.T * dim);
+    P.hF = A.f((size_t)B * 80 * d.T * dim);
+    P.Hm = mid_h(c); P.Wm = d.T >> (c.n_stages - 1);
+    P.Hf = token_rows(c); P.Wt = token_cols(c, P.Wm); P.N = P.Hf * P.Wt;
+    const size_t tok = (size_t)B * P.N;
+    P.pe0 = A.f(tok * mid); P.emb = A.f(tok * hid); P.pos_part = A.f(tok * hid * POS_SPLIT); P.tok = A.f(tok * hid);
+    P.xn = A.f(tok * hid); P.qkv = A.f(tok * 3 * hid); P.ao = A.f(tok * hid); P.hmlp = A.f(tok * mlp_hidden(c));
+    P.dbg_tok = A.f(tok * hid * (c.dit_depth + 1));
+    P.tv_keys = P.tv_K = P.tv_V = P.tv_q = P.tv_ao = P.tv_out = P.tiv_out = P.tv_weff = P.tv_beff = nullptr;
+    P.tv_stats = P.tiv_stats = nullptr;
+    if (c.variant == DEX_VARIANT_DEX) {
+        const size_t pm = (size_t)B * P.Hm * P.Wm;
+        P.tv_keys = A.f((size_t)B * d.Ts * mid); P.tv_K = A.f((size_t)B * (d.Ts + 1) * mid); P.tv_V = A.f((size_t)B * (d.Ts + 1) * mid);
+        P.tv_q = A.f(pm * mid); P.tv_ao = A.f(pm * mid); P.tv_out = A.f(pm * mid); P.tiv_out = A.f(pm * mid);
+        P.tv_weff = A.f((size_t)B * mid * mid); P.tv_beff = A.f((size_t)B * mid);
+        P.tv_stats = (double*)A.take((size_t)B * mid * 2 * sizeof(double) * 2);
+        P.tiv_stats = A.dry ? nullptr : P.tv_stats + (size_t)B * mid * 2;
+    }
+    P.bytes = (A.off + 255) & ~size_t(255);
+}
+
+struct Runner {
+    DexCtx* x; const Plan& P; hipStream_t st;
+    const float* mask; const float* mu; const float* xcur;
+    const DexSampleArgs* args;
+    bool debug;
+    int gn_idx = 0;
+
+    template <typename F> void run(const char* name, double flops, double bytes, F&& f) {
+        if (x->prof_on) {
+            Prof pr; pr.name = name; pr.flops = flops; pr.bytes = bytes;
+            hipEventCreate(&pr.a); hipEventCreate(&pr.b);
+            hipEventRecord(pr.a, st); f(); hipEventRecord(pr.b, st);
+            x->prof.push_back(pr);
+        } else f();
+    }
+    double* next_stats() { return P.stats + (size_t)(gn_idx++) * P.d.B * 8 * 2; }
+    void tap(const char* name, const float* p, long rows, int C, int ld) {
+        if (!debug) return;
+        DexCtx::Tap t; t.name = name; t.p = p; t.shape = {rows, C, ld};
+        for (auto& o : x->taps) if (o.name == t.name) { o = t; return; }
+        x->taps.push_back(t);
+    }
+
+    IGemmP base_gemm(const float* A, int lda, int acoff, int H, int W, int Cin, const float* Wt, int N, const float* bias,
+                     float* C, int ldc, int ccoff) {
+        IGemmP g{};
+        g.A = A; g.lda = lda; g.a_bstride = (long)H * W * lda; g.a_coff = acoff;
+        g.Hi = H; g.Wi = W; g.Cin = Cin;
+        g.KH = 1; g.KW = 1; g.sh = 1; g.sw = 1; g.off_h = 0; g.off_w = 0; g.step_h = 1; g.step_w = 1;
+        g.Ho = H; g.Wo = W;
+        g.W = Wt; g.w_bstride = 0; g.w_gstride = 0; g.Wbf = nullptr;
+        g.N = N; g.K = Cin; g.ksplit = 1; g.groups = 1;
+        g.bias = bias; g.bias_bstride = 0;
+        g.C = C; g.ldc = ldc; g.c_bstride = (long)H * W * ldc; g.c_sstride = 0; g.c_coff = ccoff;
+        g.OHf = H; g.OWf = W; g.osh = 1; g.osw = 1; g.oh0 = 0; g.ow0 = 0;
+        g.inmask = nullptr; g.inmask_ws = 1; g.outmask = nullptr; g.outmask_ws = 1; g.mask_bstride = P.d.T;
+        g.act = 0; g.gate = nullptr; g.gate_nstride = 1; g.gate_step_stride = 0;
+        g.res = nullptr; g.ldres = 0; g.res_bstride = 0; g.res_coff = 0;
+        g.step = P.step; g.unpatch_s = 0; g.unpatch_C = 0; g.B = P.d.B;
+        return g;
+    }
+    void gemm(const char* name, const IGemmP& g) {
+        const double M = (double)g.Ho * g.Wo * g.B;
+        const double fl = 2.0 * M * g.N * g.groups * g.K;
+        const double by = 4.0 * (M * g.Cin * g.groups + M * g.N * g.groups * g.ksplit + (double)g.K * g.N * g.groups);
+        run(name, fl, by, [&] { launch_igemm(g, x->precision, st); });
+    }
+    void conv3x3(const char* name, const TD& X, int H, int W, int mask_ws, bool inmask, const float* Wt, const float* bias, int Cout, float* out) {
+        IGemmP g = base_gemm(X.p, X.ld, X.coff, H, W, X.C, Wt, Cout, bias, out, Cout, 0);
+        g.KH = 3; g.KW = 3; g.off_h = -1; g.off_w = -1; g.K = 9 * X.C;
+        if (inmask) { g.inmask = mask; g.inmask_ws = mask_ws; }
+        gemm(name, g);
+    }
+    void gn_stats(const float* h, int C, long npix, double* stats) {
+        GnStatsP s{h, C, npix * C, (int)npix, C, 8, stats, P.d.B};
+        run("gn_stats", 3.0 * npix * C * P.d.B, 4.0 * npix * C * P.d.B, [&] { launch_gn_stats(s, st); });
+    }
+    void gn_apply(const float* h, int C, long npix, int W, int mask_ws, const double* stats, const float* gamma, const float* beta,
+                  const float* tadd, const float* res, int ldres, long resb, bool res_under_mask, float* out) {
+        GnApplyP a{};
+        a.X = h; a.ldx = C; a.xb = npix * C; a.Y = out; a.ldy = C; a.yb = npix * C; a.y_coff = 0;
+        a.npix = (int)npix; a.W = W; a.C = C; a.groups = 8; a.stats = stats; a.gamma = gamma; a.beta = beta;
+        a.mask = mask; a.mask_ws = mask_ws; a.mask_bstride = P.d.T;
+        a.tadd = tadd; a.tadd_step_stride = C; a.step = P.step;
+        a.res = res; a.ldres = ldres; a.resb = resb; a.res_under_mask = res_under_mask ? 1 : 0; a.B = P.d.B;
+        run("gn_apply_mish", 12.0 * npix * C * P.d.B, (res ? 12.0 : 8.0) * npix * C * P.d.B, [&] { launch_gn_apply(a, st); });
+    }
+
+    // ResnetBlock (diffusion.py:66-71).  X: unmasked input view; out = block2(...) + res_conv(x*mask) (unmasked).
+    void resblock(const ResW& w, const StageBuf& s, const TD& X, const float* tadd, float* out, bool first_layer) {
+        const long npix = s.npix;
+        const float* resptr; int ldres; long resb; bool under = false;
+        if (first_layer) {
+            FirstConvP f{};
+            f.mu = mu; f.x = xcur; f.spk = P.spk_plane; f.mask = mask; f.B = P.d.B; f.H = s.H; f.T = s.W; f.planes = w.cin; f.C = w.cout;
+            f.W3 = w.w1; f.b3 = w.b1; f.W1 = w.wr; f.b1 = w.br; f.scal = P.scal; f.scal_stride = SCAL_STRIDE; f.step = P.step;
+            f.h1 = s.h1; f.res = s.rbuf;
+            run("first_conv", 2.0 * npix * P.d.B * w.cout * (w.cin * 10), 4.0 * npix * P.d.B * (2 * w.cout + w.cin), [&] { launch_first_conv(f, st); });
+            resptr = s.rbuf; ldres = w.cout; resb = npix * w.cout;
+        } else {
+            conv3x3("conv3x3", X, s.H, s.W, s.mask_ws, true, w.w1, w.b1, w.cout, s.h1);
+            if (w.wr) {
+                IGemmP g = base_gemm(X.p, X.ld, X.coff, s.H, s.W, X.C, w.wr, w.cout, w.br, s.rbuf, w.cout, 0);
+                g.inmask = mask; g.inmask_ws = s.mask_ws;
+                gemm("conv1x1_res", g);
+                resptr = s.rbuf; ldres = w.cout; resb = npix * w.cout;
+            } else {
+                resptr = X.p + X.coff; ldres = X.ld; resb = npix * X.ld; under = true;
+            }
+        }
+        double* st1 = next_stats();
+        gn_stats(s.h1, w.cout, npix, st1);
+        gn_apply(s.h1, w.cout, npix, s.W, s.mask_ws, st1, w.g1, w.be1, tadd, nullptr, 0, 0, false, s.a1);
+        TD A1{s.a1, w.cout, 0, w.cout};
+        conv3x3("conv3x3", A1, s.H, s.W, s.mask_ws, false, w.w2, w.b2, w.cout, s.h2);
+        double* st2 = next_stats();
+        gn_stats(s.h2, w.cout, npix, st2);
+        gn_apply(s.h2, w.cout, npix, s.W, s.mask_ws, st2, w.g2, w.be2, nullptr, resptr, ldres, resb, under, out);
+    }
+
+    // Residual(Rezero(LinearAttention)) (diffusion.py:74-102)
+    void linattn(const LinW& w, const StageBuf& s, const TD& X, float* out, int ldo, int ocoff) {
+        const long npix = s.npix; const int B = P.d.B;
+        IGemmP g = base_gemm(X.p, X.ld, X.coff, s.H, s.W, X.C, w.wqkv, 384, nullptr, s.qkv, 384, 0);
+        gemm("linattn_qkv", g);
+        LinAttnCtxP cp{s.qkv, 384, npix * 384, (int)npix, 4, LA_CHUNK, s.nchunks, s.pm, s.ps, s.pc, B};
+        run("linattn_ctx", 2.0 * npix * 128 * 32 * B, 4.0 * npix * 384 * B, [&] { launch_linattn_ctx(cp, st); });
+        LinAttnCombineP cb{s.pm, s.ps, s.pc, s.nchunks, 4, w.wout_raw, w.g, w.C, s.weff, B};
+        run("linattn_combine", 2.0 * 128 * 32 * w.C * B, 4.0 * s.nchunks * 4 * 1100 * B, [&] { launch_linattn_combine(cb, st); });
+        IGemmP o = base_gemm(s.qkv, 384, 0, s.H, s.W, 128, s.weff, w.C, w.bias_eff, out, ldo, ocoff);
+        o.w_bstride = 128L * w.C;
+        o.res = X.p; o.ldres = X.ld; o.res_coff = X.coff; o.res_bstride = npix * X.ld;
+        gemm("linattn_out", o);
+    }
+
+    // DiTMask.forward (dit.py:485-525): X = bottleneck input view; writes [B,Hm,Wm,mid] into (out, ldo, ocoff)
+    void dit(const TD& X, bool mask_input, int mask_ws, float* out, int ldo, int ocoff) {
+        const DexConfig& c = x->cfg;
+        const int B = P.d.B, hid = c.dit_hidden, mid = mid_dim(c), N = P.N, mh = mlp_hidden(c);
+        DwConvP dw{};
+        dw.X = X.p + X.coff; dw.ldx = X.ld; dw.xb = (long)P.Hm * P.Wm * X.ld; dw.Hi = P.Hm; dw.Wi = P.Wm; dw.C = mid;
+        dw.k = c.dit_patch; dw.s = c.dit_stride; dw.pad = c.dit_patch / 2; dw.Wd = x->pe_dw; dw.bd = x->pe_db;
+        dw.mask = mask_input ? mask : nullptr; dw.mask_ws = mask_ws; dw.mask_bstride = P.d.T;
+        dw.Y = P.pe0; dw.Hf = P.Hf; dw.Wt = P.Wt; dw.B = B;
+        run("patch_dwconv_silu", 2.0 * B * N * mid * c.dit_patch * c.dit_patch, 4.0 * B * (P.Hm * P.Wm + N) * mid, [&] { launch_dwconv_silu(dw, st); });
+        IGemmP pe = base_gemm(P.pe0, mid, 0, P.Hf, P.Wt, mid, x->pe_pw, hid, x->pe_pb, P.emb, hid, 0);
+        gemm("patch_pointwise", pe);
+        // grouped 16x16 pos-conv, split-K partials (bias added in the tail)
+        const int G = c.dit_conv_pos_groups, kp = c.dit_conv_pos, cg = hid / G;
+        IGemmP pc = base_gemm(P.emb, hid, 0, P.Hf, P.Wt, cg, x->pos_w, cg, nullptr, P.pos_part, hid, 0);
+        pc.KH = kp; pc.KW = kp; pc.off_h = -(kp / 2); pc.off_w = -(kp / 2); pc.K = kp * kp * cg;
+        pc.groups = G; pc.w_gstride = (long)kp * kp * cg * cg; pc.ksplit = POS_SPLIT; pc.c_sstride = (long)B * N * hid;
+        gemm("pos_conv", pc);
+        PosFinishP pf{P.pos_part, POS_SPLIT, (long)B * N * hid, x->pos_b, P.emb, x->freq_pos, P.tok, P.Hf, P.Wt, hid, B};
+        run("pos_finish", 20.0 * B * N * hid, 4.0 * B * N * hid * (POS_SPLIT + 2), [&] { launch_pos_finish(pf, st); });
+        if (debug) hipMemcpyAsync(P.dbg_tok, P.tok, (size_t)B * N * hid * 4, hipMemcpyDeviceToDevice, st);
+        tap("tok_in", P.dbg_tok, (long)B * N, hid, hid);
+        const float scale = 1.0f / sqrtf((float)(hid / c.dit_heads));
+        for (int k = 0; k < c.dit_depth; ++k) {
+            const DitBlockW& w = x->blocks[k];
+            const float* ada = P.ada[k];
+            LnModP l1{P.tok, P.xn, N, hid, ada + 0 * hid, ada + 1 * hid, 6L * hid, P.step, B};
+            run("ln_modulate", 8.0 * B * N * hid, 8.0 * B * N * hid, [&] { launch_ln_mod(l1, st); });
+            IGemmP q = base_gemm(P.xn, hid, 0, 1, N, hid, w.wqkv, 3 * hid, w.bqkv, P.qkv, 3 * hid, 0);
+            gemm("dit_qkv", q);
+            AttnP a{};
+            a.Q = P.qkv; a.ldq = 3 * hid; a.qb = (long)N * 3 * hid;
+            a.K = P.qkv + hid; a.ldk = 3 * hid; a.kb = a.qb; a.V = P.qkv + 2 * hid; a.ldv = 3 * hid; a.vb = a.qb;
+            a.O = P.ao; a.ldo = hid; a.ob = (long)N * hid; a.Nq = N; a.Nk = N; a.kv_len = nullptr; a.kv_len_add = 0;
+            a.heads = c.dit_heads; a.scale = scale; a.B = B;
+            run("dit_attention", 4.0 * B * (double)N * N * hid, 4.0 * 4 * B * N * hid, [&] { launch_attention(a, x->precision, st); });
+            IGemmP pr = base_gemm(P.ao, hid, 0, 1, N, hid, w.wproj, hid, w.bproj, P.tok, hid, 0);
+            pr.gate = ada + 2 * hid; pr.gate_nstride = 1; pr.gate_step_stride = 6L * hid;
+            pr.res = P.tok; pr.ldres = hid; pr.res_bstride = (long)N * hid;
+            gemm("dit_proj", pr);
+            LnModP l2{P.tok, P.xn, N, hid, ada + 3 * hid, ada + 4 * hid, 6L * hid, P.step, B};
+            run("ln_modulate", 8.0 * B * N * hid, 8.0 * B * N * hid, [&] { launch_ln_mod(l2, st); });
+            IGemmP f1 = base_gemm(P.xn, hid, 0, 1, N, hid, w.wfc1, mh, w.bfc1, P.hmlp, mh, 0);
+            f1.act = 1;
+            gemm("dit_fc1_gelu", f1);
+            IGemmP f2 = base_gemm(P.hmlp, mh, 0, 1, N, mh, w.wfc2, hid, w.bfc2, P.tok, hid, 0);
+            f2.gate = ada + 5 * hid; f2.gate_nstride = 1; f2.gate_step_stride = 6L * hid;
+            f2.res = P.tok; f2.ldres = hid; f2.res_bstride = (long)N * hid;
+            gemm("dit_fc2", f2);
+            if (debug) {
+                float* dst = P.dbg_tok + (size_t)(k + 1) * B * N * hid;
+                hipMemcpyAsync(dst, P.tok, (size_t)B * N * hid * 4, hipMemcpyDeviceToDevice, st);
+                char nm[32]; snprintf(nm, sizeof nm, "tok_blk%d", k);
+                tap(nm, dst, (long)B * N, hid, hid);
+            }
+        }
+        LnModP lf{P.tok, P.xn, N, hid, P.fin_mod, P.fin_mod + hid, 2L * hid, P.step, B};
+        run("ln_modulate", 8.0 * B * N * hid, 8.0 * B * N * hid, [&] { launch_ln_mod(lf, st); });
+        const int s2c = c.dit_stride * c.dit_stride * mid;
+        IGemmP fl = base_gemm(P.xn, hid, 0, P.Hf, P.Wt, hid, x->fl_w, s2c, x->fl_b, out, ldo, ocoff);
+        fl.unpatch_s = c.dit_stride; fl.unpatch_C = mid; fl.OHf = P.Hm; fl.OWf = P.Wm;
+        fl.c_bstride = (long)P.Hm * P.Wm * ldo;
+        fl.outmask = mask; fl.outmask_ws = mask_ws;
+        gemm("dit_final_unpatchify", fl);
+    }
+
+    // TVAdaptor + TIVAdaptor (ref_encoder.py:154-179,264-273); X is the (unmasked) bottleneck view.
+    void dex_adaptors(const TD& X, int mask_ws) {
+        const DexConfig& c = x->cfg;
+        const int B = P.d.B, mid = mid_dim(c);
+        const long npix = (long)P.Hm * P.Wm;
+        hipMemsetAsync(P.tv_stats, 0, (size_t)B * mid * 2 * sizeof(double) * 2, st);
+        InStatsP is{X.p + X.coff, X.ld, npix * X.ld, (int)npix, mid, P.tv_stats, B, mask, mask_ws, (long)P.d.T, P.Wm};
+        run("in2d_stats", 3.0 * npix * mid * B, 4.0 * npix * mid * B, [&] { launch_in_stats(is, st); });
+        InFoldP fo{P.tv_stats, (int)npix, 1e-5f, x->tv_wq_raw, mid, P.tv_weff, P.tv_beff, B};
+        run("tv_fold_in2d", 2.0 * mid * mid * B, 8.0 * mid * mid * B, [&] { launch_in_fold(fo, st); });
+        IGemmP q = base_gemm(X.p, X.ld, X.coff, P.Hm, P.Wm, mid, P.tv_weff, mid, P.tv_beff, P.tv_q, mid, 0);
+        q.w_bstride = (long)mid * mid; q.bias_bstride = mid; q.inmask = mask; q.inmask_ws = mask_ws;
+        gemm("tv_q", q);
+        TvRow0P r0{P.tv_k0, P.tv_v0, P.step, P.tv_K, P.tv_V, (long)(P.d.Ts + 1) * mid, mid, B};
+        run("tv_time_token", 0, 8.0 * mid * B, [&] { launch_tv_row0(r0, st); });
+        AttnP a{};
+        a.Q = P.tv_q; a.ldq = mid; a.qb = npix * mid; a.K = P.tv_K; a.ldk = mid; a.kb = (long)(P.d.Ts + 1) * mid;
+        a.V = P.tv_V; a.ldv = mid; a.vb = a.kb; a.O = P.tv_ao; a.ldo = mid; a.ob = npix * mid;
+        a.Nq = (int)npix; a.Nk = P.d.Ts + 1; a.kv_len = args->sty_lengths_dev; a.kv_len_add = 1; a.heads = 1;
+        a.scale = 1.0f / sqrtf((float)mid); a.B = B;
+        run("tv_attention", 4.0 * B * (double)npix * (P.d.Ts + 1) * mid, 4.0 * B * (2 * npix + 2 * (P.d.Ts + 1)) * mid, [&] { launch_attention(a, x->precision, st); });
+        IGemmP o = base_gemm(P.tv_ao, mid, 0, P.Hm, P.Wm, mid, x->tv_wl, mid, nullptr, P.tv_out, mid, 0);
+        o.res = X.p; o.ldres = X.ld; o.res_coff = X.coff; o.res_bstride = npix * X.ld;
+        o.outmask = mask; o.outmask_ws = mask_ws;
+        gemm("tv_out", o);
+        tap("tv", P.tv_out, B * npix, mid, mid);
+        InStatsP is2{P.tv_out, mid, npix * mid, (int)npix, mid, P.tiv_stats, B, nullptr, 1, 0, P.Wm};
+        run("in2d_stats", 3.0 * npix * mid * B, 4.0 * npix * mid * B, [&] { launch_in_stats(is2, st); });
+        TivApplyP ta{P.tv_out, mid, npix * mid, P.tiv_out, mid, npix * mid, (int)npix, mid, P.tiv_stats, 1e-5f, P.sap_s, P.sap_m, P.step, B};
+        run("tiv_adain", 2.0 * npix * mid * B, 8.0 * npix * mid * B, [&] { launch_tiv_apply(ta, st); });
+        tap("tiv", P.tiv_out, B * npix, mid, mid);
+    }
+
+    // One EDMPrecond + Euler update (edm.py:88-98,199-208).
+    void step(float* denoised, float* xnext) {
+        const DexConfig& c = x->cfg;
+        const int B = P.d.B, ns = c.n_stages;
+        gn_idx = 0;
+        hipMemsetAsync(P.stats, 0, P.stats_bytes, st);
+        TD cur{nullptr, 0, 0, 0};
+        for (int i = 0; i < ns; ++i) {
+            const StageBuf& s = P.down[i];
+            resblock(x->down_res[i][0], s, cur, P.tadd_down[2 * i], s.r0out, i == 0);
+            TD r0{s.r0out, s.C, 0, s.C};
+            resblock(x->down_res[i][1], s, r0, P.tadd_down[2 * i + 1], s.r1out, false);
+            TD r1{s.r1out, s.C, 0, s.C};
+            linattn(x->down_lin[i], s, r1, s.attn_out, s.attn_ld, s.attn_coff);
+            char nm[16]; snprintf(nm, sizeof nm, "down%d", i);
+            tap(nm, s.attn_out + s.attn_coff, B * s.npix, s.C, s.attn_ld);
+            if (i < ns - 1) {
+                TD a{s.attn_out, s.attn_ld, s.attn_coff, s.C};
+                IGemmP g = base_gemm(a.p, a.ld, a.coff, s.H, s.W, s.C, x->down_ds_w[i], s.C, x->down_ds_b[i], s.ds_out, s.C, 0);
+                g.KH = 3; g.KW = 3; g.sh = 2; g.sw = 2; g.off_h = -1; g.off_w = -1; g.K = 9 * s.C;
+                g.Ho = s.H / 2; g.Wo = s.W / 2; g.OHf = g.Ho; g.OWf = g.Wo; g.c_bstride = (long)g.Ho * g.Wo * s.C;
+                g.inmask = mask; g.inmask_ws = s.mask_ws;
+                gemm("downsample", g);
+                cur = TD{s.ds_out, s.C, 0, s.C};
+            }
+        }
+        const StageBuf& sm = P.down[ns - 1];
+        TD mid_in{sm.attn_out, sm.attn_ld, sm.attn_coff, sm.C};
+        float* dit_dst = P.cat[0];
+        const int dit_ld = 2 * sm.C;
+        if (c.variant == DEX_VARIANT_DEX) {
+            dex_adaptors(mid_in, sm.mask_ws);
+            TD t{P.tiv_out, sm.C, 0, sm.C};
+            dit(t, false, sm.mask_ws, dit_dst, dit_ld, 0);
+        } else {
+            dit(mid_in, true, sm.mask_ws, dit_dst, dit_ld, 0);
+        }
+        tap("dit_out", dit_dst, B * sm.npix, sm.C, dit_ld);
+        for (int j = 0; j < ns - 1; ++j) {
+            const StageBuf& s = P.up[j];
+            const int i = ns - 1 - j;
+            TD X{P.cat[j], 2 * stage_dim(c, i), 0, 2 * stage_dim(c, i)};
+            resblock(x->up_res[j][0], s, X, P.tadd_up[2 * j], s.r0out, false);
+            TD r0{s.r0out, s.C, 0, s.C};
+            resblock(x->up_res[j][1], s, r0, P.tadd_up[2 * j + 1], s.r1out, false);
+            TD r1{s.r1out, s.C, 0, s.C};
+            linattn(x->up_lin[j], s, r1, s.attn_out, s.C, 0);
+            char nm[16]; snprintf(nm, sizeof nm, "up%d", j);
+            tap(nm, s.attn_out, B * s.npix, s.C, s.C);
+            // Upsample = ConvTranspose2d(4,2,1) on x*mask: four parity sub-convolutions with 2x2 taps
+            float* dst; int ldd;
+            if (j < ns - 2) { dst = P.cat[j + 1]; ldd = 2 * stage_dim(c, i - 1); } else { dst = P.up_out; ldd = s.C; }
+            for (int par = 0; par < 4; ++par) {
+                const int ph = par >> 1, pw = par & 1;
+                IGemmP g = base_gemm(s.attn_out, s.C, 0, s.H, s.W, s.C, x->up_us_w[j] + (long)par * 4 * s.C * s.C, s.C, x->up_us_b[j], dst, ldd, 0);
+                g.KH = 2; g.KW = 2; g.step_h = -1; g.step_w = -1; g.off_h = ph; g.off_w = pw; g.K = 4 * s.C;
+                g.OHf = 2 * s.H; g.OWf = 2 * s.W; g.osh = 2; g.osw = 2; g.oh0 = ph; g.ow0 = pw;
+                g.c_bstride = 4L * s.H * s.W * ldd;
+                g.inmask = mask; g.inmask_ws = s.mask_ws;
+                gemm("upsample_convT", g);
+            }
+        }
+        tap("up_out", P.up_out, (long)B * 80 * P.d.T, c.dim, c.dim);
+        TD U{P.up_out, c.dim, 0, c.dim};
+        conv3x3("conv3x3", U, 80, P.d.T, 1, true, x->fin_w, x->fin_b, c.dim, P.hF);
+        double* stf = next_stats();
+        gn_stats(P.hF, c.dim, 80L * P.d.T, stf);
+        FinalP f{};
+        f.X = P.hF; f.xb = 80L * P.d.T * c.dim; f.npix = 80 * P.d.T; f.W = P.d.T; f.C = c.dim; f.groups = 8; f.stats = stf;
+        f.gamma = x->fin_g; f.beta = x->fin_be; f.mask = mask; f.mask_bstride = P.d.T; f.wfc = x->fconv_w; f.bfc = x->fconv_b;
+        f.xcur = xcur; f.denoised = denoised; f.xnext = xnext; f.scal = P.scal; f.scal_stride = SCAL_STRIDE; f.step = P.step; f.B = B;
+        run("final_conv_euler", 14.0 * 80 * P.d.T * c.dim * B, 4.0 * 80 * P.d.T * (c.dim + 3) * B, [&] { launch_final(f, st); });
+    }
+
+    // conditioning tables for every Euler step (depend only on sigma_i)
+    void prepare(const float* sigmas_dev, int n) {
+        const DexConfig& c = x->cfg;
+        const int dim = c.dim, hid = c.dit_hidden, B = P.d.B, mid = mid_dim(c);
+        auto R = [&](const std::string& k) { return x->raw.at(k).p; };
+        auto lin = [&](const float* X, int ldx, int rows, int K, const std::string& w, bool bias, int N, float* Y, int ai, int ao) {
+            SmallLinP s{X, ldx, rows, K, R(w + ".weight"), bias ? R(w + ".bias") : nullptr, N, Y, N, ai, ao};
+            run("cond_mlp", 2.0 * rows * K * N, 4.0 * K * N, [&] { launch_small_linear(s, st); });
+        };
+        CondPrepP cp{sigmas_dev, n, c.pe_scale, dim, P.scal, SCAL_STRIDE, P.t_unet, P.t_dit};
+        run("cond_prep", 0, 0, [&] { launch_cond_prep(cp, st); });
+        lin(P.t_unet, dim, n, dim, "mlp.0", true, 4 * dim, P.tmp_u, 0, 1);
+        lin(P.tmp_u, 4 * dim, n, 4 * dim, "mlp.2", true, dim, P.temb, 0, 0);
+        for (int i = 0; i < c.n_stages; ++i)
+            for (int r = 0; r < 2; ++r)
+                lin(P.temb, dim, n, dim, "downs." + std::to_string(i) + "." + std::to_string(r) + ".mlp.1", true, stage_dim(c, i), P.tadd_down[2 * i + r], 1, 0);
+        for (int j = 0; j < c.n_stages - 1; ++j)
+            for (int r = 0; r < 2; ++r)
+                lin(P.temb, dim, n, dim, "ups." + std::to_string(j) + "." + std::to_string(r) + ".mlp.1", true, stage_dim(c, c.n_stages - 2 - j), P.tadd_up[2 * j + r], 1, 0);
+        lin(P.t_dit, 256, n, 256, "vit.t_embedder.mlp.0", true, hid, P.c_tmp, 0, 2);
+        lin(P.c_tmp, hid, n, hid, "vit.t_embedder.mlp.2", true, hid, P.c_emb, 0, 0);
+        for (int k = 0; k < c.dit_depth; ++k)
+            lin(P.c_emb, hid, n, hid, "vit.blocks." + std::to_string(k) + ".adaLN_modulation.1", true, 6 * hid, P.ada[k], 2, 0);
+        lin(P.c_emb, hid, n, hid, "vit.final_layer.adaLN_modulation.1", true, 2 * hid, P.fin_mod, 2, 0);
+        if (c.n_spks > 1) {
+            lin(args->spk_dev, c.spk_emb_dim, B, c.spk_emb_dim, "spk_mlp.0", true, 4 * c.spk_emb_dim, P.spk_tmp, 0, 1);
+            lin(P.spk_tmp, 4 * c.spk_emb_dim, B, 4 * c.spk_emb_dim, "spk_mlp.2", true, c.n_feats, P.spk_plane, 0, 0);
+        }
+        if (c.variant == DEX_VARIANT_DEX) {
+            lin(P.t_unet, dim, n, dim, "mlp_adap.0", true, dim, P.adap_tmp, 0, 1);
+            lin(P.adap_tmp, dim, n, dim, "mlp_adap.2", true, 2 * dim, P.t_adap, 0, 0);
+            lin(P.t_unet, dim, n, dim, "mlp_adap_sty.0", true, dim, P.adap_tmp, 0, 1);
+            lin(P.adap_tmp, dim, n, dim, "mlp_adap_sty.2", true, 2 * dim, P.t_sty, 0, 0);
+            lin(P.t_sty, mid, n, mid, "tv_adaptor.w_k", false, mid, P.tv_k0, 0, 0);
+            lin(P.t_sty, mid, n, mid, "tv_adaptor.w_v", false, mid, P.tv_v0, 0, 0);
+            const int L = args->n_ref;
+            for (int j = 0; j < L; ++j)
+                run("ref_stats", 0, 4.0 * B * mid * args->Tr, [&] {
+                    launch_row_stats(args->ref_skips_dev[j], B, mid, args->Tr, 1e-5f, P.ref_mean + (long)j * mid, P.ref_std + (long)j * mid, (long)L * mid, st);
+                });
+            SapP sm{P.t_adap, 2 * dim, 0, n, P.ref_mean, L, mid, R("tiv_adaptor.mean_sap.W.weight"), R("tiv_adaptor.mean_sap.W.bias"), P.sap_m, B};
+            SapP ss{P.t_adap, 2 * dim, 0, n, P.ref_std, L, mid, R("tiv_adaptor.std_sap.W.weight"), R("tiv_adaptor.std_sap.W.bias"), P.sap_s, B};
+            run("sap_pool", 0, 0, [&] { launch_sap(sm, st); launch_sap(ss, st); });
+            // style keys/values for the Ts style tokens are step-invariant (rows 1..Ts of K/V)
+            run("sty_transpose", 0, 8.0 * B * mid * args->Ts, [&] { launch_transpose_cl(args->sty_dev, P.tv_keys, B, mid, args->Ts, 0, (long)args->Ts * mid, st); });
+            for (int which = 0; which < 2; ++which) {
+                float* dst = which ? P.tv_V : P.tv_K;
+                IGemmP g = base_gemm(P.tv_keys, mid, 0, 1, args->Ts, mid, which ? x->tv_wv : x->tv_wk, mid, nullptr, dst + mid, mid, 0);
+                g.c_bstride = (long)(args->Ts + 1) * mid;
+                gemm("tv_kv", g);
+            }
+        }
+    }
+};
+
+int validate(DexCtx* x, const DexSampleArgs* a, bool need_z) {
+    if (!x || !a) return DEX_ERR_ARG;
+    if (!x->finalized) return x->fail(DEX_ERR_STATE, "dex_ctx_finalize has not been called");
+    if (a->B < 1 || a->T < 4 || (a->T % 4) != 0) return x->fail(DEX_ERR_ARG, "T (%d) must be a positive multiple of 4 (fix_len_compatibility), B >= 1", a->T);
+    if ((a->T >> (x->cfg.n_stages - 1)) * (1 << (x->cfg.n_stages - 1)) != a->T) return x->fail(DEX_ERR_ARG, "T must be divisible by 2^(n_stages-1)");
+    if (need_z && a->n_steps < 2) return x->fail(DEX_ERR_ARG, "n_steps must be >= 2 (edm.py:157 divides by num_steps - 1)");
+    if (!a->mu_dev || !a->mask_dev || !a->sigmas_dev || !a->out_dev || !a->workspace_dev) return x->fail(DEX_ERR_ARG, "null device pointer");
+    if (need_z && !a->z_dev) return x->fail(DEX_ERR_ARG, "z_dev is null");
+    if (x->cfg.n_spks > 1 && !a->spk_dev) return x->fail(DEX_ERR_ARG, "spk_dev required when n_spks > 1");
+    if (x->cfg.variant == DEX_VARIANT_DEX) {
+        if (!a->ref_skips_dev || !a->sty_dev || !a->sty_lengths_dev || a->Tr < 2 || a->Ts < 1 || a->n_ref < 1 || a->n_ref > 7)
+            return x->fail(DEX_ERR_ARG, "DEX needs ref_skips_dev (1..7 tensors, Tr >= 2), sty_dev, sty_lengths_dev, Ts >= 1");
+        for (int j = 0; j < a->n_ref; ++j) if (!a->ref_skips_dev[j]) return x->fail(DEX_ERR_ARG, "ref_skips_dev[%d] is null", j);
+    }
+    if (((uintptr_t)a->workspace_dev & 255) != 0) return x->fail(DEX_ERR_ARG, "workspace must be 256-byte aligned");
+    return DEX_OK;
+}
+
+__global__ void set_sigma_pair(const float* src, float* dst) { dst[0] = src[0]; dst[1] = 0.f; }
+
+}  // namespace
+
+extern "C" {
+
+size_t dex_workspace_bytes(const DexCtx* x, int B, int T, int Tr, int Ts, int n_steps) {
+    if (!x || B < 1 || T < 4) return 0;
+    Plan P; Dims d{B, T, Tr, Ts, n_steps < 1 ? 1 : n_steps};
+    make_plan(x, d, nullptr, P);
+    return P.bytes;
+}
+
+int dex_edm_sigmas(int n, float* out) {
+    if (n < 2 || !out) return DEX_ERR_ARG;
+    const double a = pow(80.0, 1.0 / 7.0), bq = pow(0.002, 1.0 / 7.0);
+    for (int i = 0; i < n; ++i) {
+        const float frac = (float)i / (float)(n - 1);
+        const float base = (float)a + frac * (float)(bq - a);
+        out[i] = powf(base, 7.0f);
+    }
+    out[n] = 0.f;
+    return DEX_OK;
+}
+
+int dex_denoise_once(DexCtx* x, const DexDenoiseArgs* da, dex_stream_t stream) {
+    if (!da) return DEX_ERR_ARG;
+    const DexSampleArgs* a = &da->s;
+    int rc = validate(x, a, false);
+    if (rc) return rc;
+    if (!da->x_dev) return x->fail(DEX_ERR_ARG, "x_dev is null");
+    hipStream_t st = (hipStream_t)stream;
+    Plan P; Dims d{a->B, a->T, a->Tr, a->Ts, 1};
+    make_plan(x, d, nullptr, P);
+    if (P.bytes > a->workspace_bytes) return x->fail(DEX_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", P.bytes, a->workspace_bytes);
+    make_plan(x, d, a->workspace_dev, P);
+    x->taps.clear();
+    Runner R{x, P, st, a->mask_dev, a->mu_dev, da->x_dev, a, true};
+    hipLaunchKernelGGL(set_sigma_pair, dim3(1), dim3(1), 0, st, a->sigmas_dev, P.sig2);
+    launch_step_reset(P.step, st);
+    R.prepare(P.sig2, 1);
+    R.step(a->out_dev, nullptr);
+    HIPCHK(x, hipGetLastError());
+    return DEX_OK;
+}
+
+int dex_sample(DexCtx* x, const DexSampleArgs* a, dex_stream_t stream) {
+    int rc = validate(x, a, true);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    Plan P; Dims d{a->B, a->T, a->Tr, a->Ts, a->n_steps};
+    make_plan(x, d, nullptr, P);
+    if (P.bytes > a->workspace_bytes) return x->fail(DEX_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", P.bytes, a->workspace_bytes);
+    make_plan(x, d, a->workspace_dev, P);
+    x->taps.clear();
+    if (x->prof_on) { for (auto& pr : x->prof) { hipEventDestroy(pr.a); hipEventDestroy(pr.b); } x->prof.clear(); x->prof_agg.clear(); }
+    Runner R{x, P, st, a->mask_dev, a->mu_dev, P.xbuf, a, false};
+    launch_step_reset(P.step, st);
+    R.prepare(a->sigmas_dev, a->n_steps);
+    // x_0 = z * sigma_0 (edm.py:188-189)
+    R.run("init_scale", 0, 8.0 * a->B * 80 * a->T, [&] { launch_scale_copy(a->z_dev, P.xbuf, (long)a->B * 80 * a->T, P.scal, st); });
+    const bool use_graph = a->use_graph && !x->prof_on;
+    if (use_graph) {
+        std::vector<uint64_t> key = {(uint64_t)a->B, (uint64_t)a->T, (uint64_t)a->Tr, (uint64_t)a->Ts, (uint64_t)a->n_steps, (uint64_t)x->precision,
+                                     (uint64_t)(uintptr_t)a->mu_dev, (uint64_t)(uintptr_t)a->mask_dev, (uint64_t)(uintptr_t)a->workspace_dev,
+                                     (uint64_t)(uintptr_t)a->sty_lengths_dev, (uint64_t)(uintptr_t)st};
+        if (!x->graph_exec || key != x->graph_key) {
+            if (x->graph_exec) { hipGraphExecDestroy(x->graph_exec); x->graph_exec = nullptr; }
+            hipGraph_t graph = nullptr;
+            HIPCHK(x, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            R.step(nullptr, P.xbuf);
+            launch_step_inc(P.step, st);
+            HIPCHK(x, hipStreamEndCapture(st, &graph));
+            HIPCHK(x, hipGraphInstantiate(&x->graph_exec, graph, nullptr, nullptr, 0));
+            hipGraphDestroy(graph);
+            x->graph_key = key;
+        }
+        for (int i = 0; i < a->n_steps; ++i) HIPCHK(x, hipGraphLaunch(x->graph_exec, st));
+    } else {
+        for (int i = 0; i < a->n_steps; ++i) { R.step(nullptr, P.xbuf); launch_step_inc(P.step, st); }
+    }
+    HIPCHK(x, hipMemcpyAsync(a->out_dev, P.xbuf, (size_t)a->B * 80 * a->T * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIPCHK(x, hipGetLastError());
+    return DEX_OK;
+}
+
+// ---- taps ---------------------------------------------------------------------------------------
+int dex_num_taps(const DexCtx* x) { return x ? (int)x->taps.size() : 0; }
+const char* dex_tap_name(const DexCtx* x, int i) { return (x && i >= 0 && i < (int)x->taps.size()) ? x->taps[i].name.c_str() : nullptr; }
+int dex_tap_info(const DexCtx* x, const char* name, int64_t shape[4], int* ndim) {
+    if (!x || !name) return DEX_ERR_ARG;
+    for (const auto& t : x->taps)
+        if (t.name == name) { shape[0] = t.shape[0]; shape[1] = t.shape[1]; if (ndim) *ndim = 2; return DEX_OK; }
+    return DEX_ERR_ARG;
+}
+int dex_tap_copy(DexCtx* x, const char* name, float* dst, size_t dst_bytes, dex_stream_t stream) {
+    if (!x || !name || !dst) return DEX_ERR_ARG;
+    for (const auto& t : x->taps)
+        if (t.name == name) {
+            const size_t rows = (size_t)t.shape[0], C = (size_t)t.shape[1], ld = (size_t)t.shape[2];
+            if (dst_bytes < rows * C * 4) return x->fail(DEX_ERR_ARG, "tap '%s' needs %zu bytes", name, rows * C * 4);
+            HIPCHK(x, hipMemcpy2DAsync(dst, C * 4, t.p, ld * 4, C * 4, rows, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+            return DEX_OK;
+        }
+    return x->fail(DEX_ERR_ARG, "unknown tap '%s'", name);
+}
+
+// ---- profiling ----------------------------------------------------------------------------------
+int dex_profile_enable(DexCtx* x, int on) { if (!x) return DEX_ERR_ARG; x->prof_on = on != 0; return DEX_OK; }
+static void prof_aggregate(DexCtx* x) {
+    if (!x->prof_agg.empty() || x->prof.empty()) return;
+    hipEventSynchronize(x->prof.back().b);
+    std::map<std::string, size_t> idx;
+    for (auto& pr : x->prof) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, pr.a, pr.b);
+        auto it = idx.find(pr.name);
+        if (it == idx.end()) { idx[pr.name] = x->prof_agg.size(); x->prof_agg.push_back({pr.name, 0, 0.0, 0.0, 0.0}); it = idx.find(pr.name); }
+        ProfAgg& g = x->prof_agg[it->second];
+        g.calls += 1; g.ms += ms; g.flops += pr.flops; g.bytes += pr.bytes;
+    }
+}
+int dex_profile_num(const DexCtx* x) { if (!x) return 0; prof_aggregate(const_cast<DexCtx*>(x)); return (int)x->prof_agg.size(); }
+int dex_profile_get(const DexCtx* x, int i, const char** name, int* calls, double* total_ms, double* flops, double* bytes) {
+    if (!x) return DEX_ERR_ARG;
+    prof_aggregate(const_cast<DexCtx*>(x));
+    if (i < 0 || i >= (int)x->prof_agg.size()) return DEX_ERR_ARG;
+    const ProfAgg& g = x->prof_agg[i];
+    if (name) *name = g.name.c_str(); if (calls) *calls = g.calls; if (total_ms) *total_ms = g.ms;
+    if (flops) *flops = g.flops; if (bytes) *bytes = g.bytes;
+    return DEX_OK;
+}
+
+// ---- STFT / mel front-end -------------------------------------------------------------------------
+int dex_mel_frames(int n_samples) { return n_samples / 256 + 1; }
+
+int dex_mel_from_wav(DexCtx* x, const float* wav_dev, int n, float* mel_dev, float* energy_dev, dex_stream_t stream) {
+    if (!x || !wav_dev || !mel_dev || !energy_dev) return DEX_ERR_ARG;
+    if (n < 513) return x->fail(DEX_ERR_ARG, "reflect padding needs at least 513 samples (got %d)", n);
+    hipStream_t st = (hipStream_t)stream;
+    if (!x->mel_basis) {
+        std::vector<float> basis, filt;
+        build_mel_constants(basis, filt);
+        HIPCHK(x, hipMalloc((void**)&x->mel_basis, basis.size() * sizeof(float)));
+        HIPCHK(x, hipMalloc((void**)&x->mel_filt, filt.size() * sizeof(float)));
+        HIPCHK(x, hipMemcpy(x->mel_basis, basis.data(), basis.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(x, hipMemcpy(x->mel_filt, filt.data(), filt.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    const int frames = dex_mel_frames(n), NP = 1152;
+    const size_t pad_len = (size_t)(frames - 1) * 256 + 1024 + 256;
+    const size_t need = (pad_len + (size_t)frames * NP) * sizeof(float) + 512;
+    if (need > x->mel_ws_bytes) {
+        if (x->mel_ws) hipFree(x->mel_ws);
+        HIPCHK(x, hipMalloc(&x->mel_ws, need));
+        x->mel_ws_bytes = need;
+    }
+    float* ypad = (float*)x->mel_ws;
+    float* spec = ypad + ((pad_len + 63) & ~size_t(63));
+    launch_wav_pad(wav_dev, n, 512, ypad, (int)pad_len, st);
+    // frames x 1152 = (frames x 1024 overlapping-row view, row stride = hop) x basis[1024][1152]
+    IGemmP g{};
+    g.A = ypad; g.lda = 256; g.a_bstride = 0; g.a_coff = 0; g.Hi = 1; g.Wi = frames; g.Cin = 1024;
+    g.KH = 1; g.KW = 1; g.sh = 1; g.sw = 1; g.step_h = 1; g.step_w = 1; g.Ho = 1; g.Wo = frames;
+    g.W = x->mel_basis; g.N = NP; g.K = 1024; g.ksplit = 1; g.groups = 1;
+    g.C = spec; g.ldc = NP; g.c_bstride = 0; g.OHf = 1; g.OWf = frames; g.osh = 1; g.osw = 1; g.gate_nstride = 1; g.B = 1;
+    launch_igemm(g, DEX_PREC_FP32, st);
+    MagMelP m{spec, NP, 576, frames, 513, x->mel_filt, 80, mel_dev, energy_dev};
+    launch_magmel(m, st);
+    HIPCHK(x, hipGetLastError());
+    return DEX_OK;
+}
+
+}  // extern "C"

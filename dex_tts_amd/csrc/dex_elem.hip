@@ -1,0 +1,196 @@
+// dex_elem.hip — DEX-TTS style adaptors (DEX-TTS/model/ref_encoder.py:142-179,239-273, model/base.py:67-114)
+// around the shared attention / GEMM kernels: instance-norm statistics, SAP pooling tables, IN2d folded
+// into w_q, AdaIN apply, time-token rows, layout transposes.
+#include "kernels.h"
+
+namespace dex {
+
+// InstanceNorm1D.cal_stats (base.py:72-78): mean and sqrt(unbiased var + eps) over the FULL padded length.
+// One wave per (b, c) row of a [B, C, len] tensor; out[b*out_bstride + c].
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* X, int B, int C, int len, float eps,
+                                                        float* mean, float* sd, long out_bstride) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long)B * C) return;
+    const float* x = X + row * len;
+    double s = 0.0;
+    for (int k = lane; k < len; k += 64) s += (double)x[k];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const double mu = s / len;
+    double q = 0.0;
+    for (int k = lane; k < len; k += 64) { const double d = (double)x[k] - mu; q += d * d; }
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    if (lane == 0) {
+        const int b = (int)(row / C), c = (int)(row % C);
+        mean[(long)b * out_bstride + c] = (float)mu;
+        sd[(long)b * out_bstride + c] = (float)sqrt(q / (double)(len - 1) + (double)eps);
+    }
+}
+void launch_row_stats(const float* X, int B, int C, int len, float eps, float* mean, float* sd, long out_bstride, hipStream_t st) {
+    const long rows = (long)B * C;
+    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, X, B, C, len, eps, mean, sd, out_bstride);
+}
+
+// per-(b,c) sum / sumsq over all pixels (incl. padding), fp64.  grid (chunks, B); C <= 256.
+constexpr int IN_PIX = 256;
+__global__ __launch_bounds__(256) void in_stats_kernel(const InStatsP p) {
+    __shared__ double red[256][2];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int C4 = p.C >> 2;
+    red[tid][0] = 0.0; red[tid][1] = 0.0;
+    __syncthreads();
+    const int cq = tid % C4, prow = tid / C4, rpp = 256 / C4;
+    const int pbeg = blockIdx.x * IN_PIX, pend = min(p.npix, pbeg + IN_PIX);
+    const float* X = p.X + (long)b * p.bstride;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int px = pbeg + prow; px < pend; px += rpp) {
+        float4 v = *reinterpret_cast<const float4*>(X + (long)px * p.ld + cq * 4);
+        if (p.mask) {
+            const float mk = p.mask[(long)b * p.mask_bstride + (px % p.W) * p.mask_ws];
+            v.x *= mk; v.y *= mk; v.z *= mk; v.w *= mk;
+        }
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        q.x = fmaf(v.x, v.x, q.x); q.y = fmaf(v.y, v.y, q.y); q.z = fmaf(v.z, v.z, q.z); q.w = fmaf(v.w, v.w, q.w);
+    }
+    const int c = cq * 4;
+    atomicAdd(&red[c + 0][0], (double)s.x); atomicAdd(&red[c + 0][1], (double)q.x);
+    atomicAdd(&red[c + 1][0], (double)s.y); atomicAdd(&red[c + 1][1], (double)q.y);
+    atomicAdd(&red[c + 2][0], (double)s.z); atomicAdd(&red[c + 2][1], (double)q.z);
+    atomicAdd(&red[c + 3][0], (double)s.w); atomicAdd(&red[c + 3][1], (double)q.w);
+    __syncthreads();
+    if (tid < p.C) {
+        atomicAdd(p.stats + ((long)b * p.C + tid) * 2 + 0, red[tid][0]);
+        atomicAdd(p.stats + ((long)b * p.C + tid) * 2 + 1, red[tid][1]);
+    }
+}
+void launch_in_stats(const InStatsP& p, hipStream_t st) {
+    hipLaunchKernelGGL(in_stats_kernel, dim3((p.npix + IN_PIX - 1) / IN_PIX, p.B), dim3(256), 0, st, p);
+}
+
+__device__ __forceinline__ void in_mean_rstd(const double* stats, long idx, int npix, float eps, float& mean, float& rstd) {
+    const double n = (double)npix;
+    const double mu = stats[idx * 2] / n;
+    double var = (stats[idx * 2 + 1] - n * mu * mu) / (n - 1.0);    // unbiased (torch.var default, base.py:99)
+    var = var < 0.0 ? 0.0 : var;
+    mean = (float)mu;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// SelfAttentionPooling (ref_encoder.py:246-253) for every Euler step: one wave per (step, b).  C <= 256.
+__global__ __launch_bounds__(64) void sap_kernel(const SapP p) {
+    const int lane = threadIdx.x, stepi = blockIdx.x, b = blockIdx.y;
+    const int per = (p.C + 63) / 64;
+    float logit[8], xs[8][4];
+    const float* tt = p.t_tok + (long)stepi * p.t_ld + p.t_coff;
+    for (int l = 0; l <= p.L; ++l) {
+        float a = 0.f;
+        for (int j = 0; j < per; ++j) {
+            const int c = lane + 64 * j;
+            float v = 0.f;
+            if (c < p.C) v = (l == 0) ? tt[c] : p.stats[((long)b * p.L + (l - 1)) * p.C + c];
+            xs[l][j] = v;
+            if (c < p.C) a = fmaf(v, p.w[c], a);
+        }
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        logit[l] = a + p.bias[0];
+    }
+    float mx = logit[0];
+    for (int l = 1; l <= p.L; ++l) mx = fmaxf(mx, logit[l]);
+    float den = 0.f;
+    for (int l = 0; l <= p.L; ++l) { logit[l] = __expf(logit[l] - mx); den += logit[l]; }
+    for (int j = 0; j < per; ++j) {
+        const int c = lane + 64 * j;
+        if (c >= p.C) continue;
+        float o = 0.f;
+        for (int l = 0; l <= p.L; ++l) o = fmaf(xs[l][j], logit[l] / den, o);
+        p.out[((long)stepi * p.B + b) * p.C + c] = o;
+    }
+}
+void launch_sap(const SapP& p, hipStream_t st) {
+    hipLaunchKernelGGL(sap_kernel, dim3(p.nsteps, p.B), dim3(64), 0, st, p);
+}
+
+// TVAdaptor: q = w_q(IN2d(x)) folded into a per-batch weight/bias (ref_encoder.py:166):
+//   Weff[b][k][n] = rstd[b,k] * Wq[n][k];   beff[b][n] = -sum_k mean[b,k] * rstd[b,k] * Wq[n][k]
+__global__ __launch_bounds__(256) void in_fold_kernel(const InFoldP p) {
+    __shared__ float smean[256], srstd[256];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    if (tid < p.C) in_mean_rstd(p.stats, (long)b * p.C + tid, p.npix, p.eps, smean[tid], srstd[tid]);
+    __syncthreads();
+    float* We = p.Weff + (long)b * p.C * p.C;
+    for (int idx = tid; idx < p.C * p.C; idx += 256) {
+        const int k = idx / p.C, n = idx - k * p.C;
+        We[idx] = srstd[k] * p.Wq[(long)n * p.C + k];
+    }
+    if (tid < p.C) {
+        float a = 0.f;
+        for (int k = 0; k < p.C; ++k) a = fmaf(smean[k] * srstd[k], p.Wq[(long)tid * p.C + k], a);
+        p.beff[(long)b * p.C + tid] = -a;
+    }
+}
+void launch_in_fold(const InFoldP& p, hipStream_t st) {
+    hipLaunchKernelGGL(in_fold_kernel, dim3(p.B), dim3(256), 0, st, p);
+}
+
+// TIVAdaptor: y = IN2d(x) * s + m, output NOT masked (ref_encoder.py:271)
+__global__ __launch_bounds__(256) void tiv_apply_kernel(const TivApplyP p) {
+    __shared__ float sa[256], sb[256];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int step = p.step ? *p.step : 0;
+    if (tid < p.C) {
+        float mean, rstd;
+        in_mean_rstd(p.stats, (long)b * p.C + tid, p.npix, p.eps, mean, rstd);
+        const float s = p.s_tab[((long)step * p.B + b) * p.C + tid];
+        const float m = p.m_tab[((long)step * p.B + b) * p.C + tid];
+        sa[tid] = rstd * s;
+        sb[tid] = m - mean * rstd * s;
+    }
+    __syncthreads();
+    const int C4 = p.C >> 2;
+    const long total = (long)p.npix * C4;
+    const float* X = p.X + (long)b * p.xb;
+    float* Y = p.Y + (long)b * p.yb;
+    for (long idx = (long)blockIdx.x * 256 + tid; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % C4) * 4;
+        const long px = idx / C4;
+        const float4 x = *reinterpret_cast<const float4*>(X + px * p.ld + c);
+        float4 y;
+        y.x = fmaf(x.x, sa[c], sb[c]); y.y = fmaf(x.y, sa[c + 1], sb[c + 1]);
+        y.z = fmaf(x.z, sa[c + 2], sb[c + 2]); y.w = fmaf(x.w, sa[c + 3], sb[c + 3]);
+        *reinterpret_cast<float4*>(Y + px * p.ldy + c) = y;
+    }
+}
+void launch_tiv_apply(const TivApplyP& p, hipStream_t st) {
+    const long total = (long)p.npix * (p.C / 4);
+    long blocks = (total + 1023) / 1024; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(tiv_apply_kernel, dim3((unsigned)blocks, p.B), dim3(256), 0, st, p);
+}
+
+__global__ void tv_row0_kernel(const TvRow0P p) {
+    const int b = blockIdx.x, c = threadIdx.x;
+    const int step = p.step ? *p.step : 0;
+    if (c < p.C) {
+        p.K[(long)b * p.kvb + c] = p.k0[(long)step * p.C + c];
+        p.V[(long)b * p.kvb + c] = p.v0[(long)step * p.C + c];
+    }
+}
+void launch_tv_row0(const TvRow0P& p, hipStream_t st) {
+    hipLaunchKernelGGL(tv_row0_kernel, dim3(p.B), dim3(256), 0, st, p);
+}
+
+__global__ void transpose_cl_kernel(const float* src, float* dst, int B, int C, int L, int row_off, long dst_bstride) {
+    const long total = (long)B * C * L;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int l = (int)((i / C) % L);
+        const int b = (int)(i / ((long)C * L));
+        dst[(long)b * dst_bstride + (long)(l + row_off) * C + c] = src[((long)b * C + c) * L + l];
+    }
+}
+void launch_transpose_cl(const float* src, float* dst, int B, int C, int L, int row_off, long dst_bstride, hipStream_t st) {
+    const long total = (long)B * C * L;
+    long blocks = (total + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(transpose_cl_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, B, C, L, row_off, dst_bstride);
+}
+
+}  // namespace dex

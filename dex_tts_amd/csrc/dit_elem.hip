@@ -1,0 +1,120 @@
+// dit_elem.hip — HBM-bound pieces of the DiT bottleneck (dit.py): overlapping depthwise patch-embed conv + SiLU,
+// pos-conv tail (GELU, mean over frequency, add positional terms), LayerNorm + adaLN modulate.
+#include "kernels.h"
+
+namespace dex {
+
+__device__ __forceinline__ float silu_d(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float gelu_d(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// PatchEmbed2D.proj[0..1] (dit.py:57-58): depthwise k x k, stride s, pad k/2; the reference right-pads the
+// width to a multiple of patch_size with zeros first (dit.py:442-445) — identical to treating wi >= Wi as zero.
+// The DiT input is x * mask_mid (diffusion.py:189 Identity on the last stage), applied here on load.
+__global__ __launch_bounds__(256) void dwconv_silu_kernel(const DwConvP p) {
+    const int C4 = p.C >> 2;
+    const long total = (long)p.B * p.Hf * p.Wt * C4;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int cq = (int)(gid % C4);
+    const long tok = gid / C4;
+    const int wt = (int)(tok % p.Wt);
+    const int f = (int)((tok / p.Wt) % p.Hf);
+    const int b = (int)(tok / ((long)p.Wt * p.Hf));
+    const float* X = p.X + (long)b * p.xb;
+    const float* mrow = p.mask ? p.mask + (long)b * p.mask_bstride : nullptr;
+    float4 acc = *reinterpret_cast<const float4*>(p.bd + cq * 4);
+    for (int kh = 0; kh < p.k; ++kh) {
+        const int hi = f * p.s + kh - p.pad;
+        if ((unsigned)hi >= (unsigned)p.Hi) continue;
+        for (int kw = 0; kw < p.k; ++kw) {
+            const int wi = wt * p.s + kw - p.pad;
+            if ((unsigned)wi >= (unsigned)p.Wi) continue;
+            float4 v = *reinterpret_cast<const float4*>(X + ((long)hi * p.Wi + wi) * p.ldx + cq * 4);
+            const float4 w = *reinterpret_cast<const float4*>(p.Wd + (kh * p.k + kw) * p.C + cq * 4);
+            const float mk = mrow ? mrow[wi * p.mask_ws] : 1.f;
+            acc.x = fmaf(v.x * mk, w.x, acc.x); acc.y = fmaf(v.y * mk, w.y, acc.y);
+            acc.z = fmaf(v.z * mk, w.z, acc.z); acc.w = fmaf(v.w * mk, w.w, acc.w);
+        }
+    }
+    acc.x = silu_d(acc.x); acc.y = silu_d(acc.y); acc.z = silu_d(acc.z); acc.w = silu_d(acc.w);
+    *reinterpret_cast<float4*>(p.Y + tok * p.C + cq * 4) = acc;
+}
+void launch_dwconv_silu(const DwConvP& p, hipStream_t st) {
+    const long total = (long)p.B * p.Hf * p.Wt * (p.C / 4);
+    hipLaunchKernelGGL(dwconv_silu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+}
+
+// pos = mean_f GELU(conv + bias)  (dit.py:450-451; SamePad already applied by only computing Hf x Wt outputs);
+// tok[b, f*Wt + w, :] = emb + pos[w] + freq_pos[f]  (dit.py:452-454)
+__global__ __launch_bounds__(256) void pos_finish_kernel(const PosFinishP p) {
+    const int D4 = p.D >> 2;
+    const long total = (long)p.B * p.Wt * D4;
+    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int cq = (int)(gid % D4);
+    const int wt = (int)((gid / D4) % p.Wt);
+    const int b = (int)(gid / ((long)D4 * p.Wt));
+    const float4 bias = *reinterpret_cast<const float4*>(p.bias + cq * 4);
+    float4 pos = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int f = 0; f < p.Hf; ++f) {
+        const long row = ((long)b * p.Hf + f) * p.Wt + wt;
+        float4 a = bias;
+        for (int s = 0; s < p.nsplit; ++s) {
+            const float4 v = *reinterpret_cast<const float4*>(p.part + (long)s * p.split_stride + row * p.D + cq * 4);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        pos.x += gelu_d(a.x); pos.y += gelu_d(a.y); pos.z += gelu_d(a.z); pos.w += gelu_d(a.w);
+    }
+    const float inv = 1.f / (float)p.Hf;
+    pos.x *= inv; pos.y *= inv; pos.z *= inv; pos.w *= inv;
+    for (int f = 0; f < p.Hf; ++f) {
+        const long row = ((long)b * p.Hf + f) * p.Wt + wt;
+        const float4 e = *reinterpret_cast<const float4*>(p.emb + row * p.D + cq * 4);
+        const float4 fp = *reinterpret_cast<const float4*>(p.freq_pos + (long)f * p.D + cq * 4);
+        float4 o;
+        o.x = e.x + pos.x + fp.x; o.y = e.y + pos.y + fp.y; o.z = e.z + pos.z + fp.z; o.w = e.w + pos.w + fp.w;
+        *reinterpret_cast<float4*>(p.tok + row * p.D + cq * 4) = o;
+    }
+}
+void launch_pos_finish(const PosFinishP& p, hipStream_t st) {
+    const long total = (long)p.B * p.Wt * (p.D / 4);
+    hipLaunchKernelGGL(pos_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+}
+
+// LayerNorm (eps 1e-6, biased var, no affine) then x*(1+scale)+shift.  One wave per token, D <= 512, D % 64 == 0.
+__global__ __launch_bounds__(256) void ln_mod_kernel(const LnModP p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long rows = (long)p.B * p.rows_per_batch;
+    if (row >= rows) return;
+    const int step = p.step ? *p.step : 0;
+    const float* x = p.X + row * p.D;
+    const int per = p.D >> 6;
+    float v[8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] = (j < per) ? x[lane + 64 * j] : 0.f; s += v[j]; }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)p.D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float d = (j < per) ? v[j] - mean : 0.f; q = fmaf(d, d, q); }
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)p.D + 1e-6f);
+    const float* sh = p.shift + (long)step * p.step_stride;
+    const float* sc = p.scale + (long)step * p.step_stride;
+    float* y = p.Y + row * p.D;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (j < per) {
+            const int c = lane + 64 * j;
+            y[c] = (v[j] - mean) * rstd * (1.f + sc[c]) + sh[c];
+        }
+    }
+}
+void launch_ln_mod(const LnModP& p, hipStream_t st) {
+    const long rows = (long)p.B * p.rows_per_batch;
+    hipLaunchKernelGGL(ln_mod_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, p);
+}
+
+}  // namespace dex

@@ -1,0 +1,164 @@
+// kernels.h — launch interfaces of the hand-written gfx950 kernels behind libdexamd.so.
+// Activations are channels-last fp32: element (b,h,w,c) at base[b*bstride + (h*W + w)*ld + coff + c].
+// "step" pointers are a device-resident Euler-step counter so one captured hipGraph of a step can be
+// replayed for every step: per-step conditioning tables are indexed as table[step*stride + ...].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dex {
+
+// ------------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution / linear:  C[m, n] = epi( sum_k gather(A)[m,k] * W[k,n] )
+//   m = (ho, wo) in an Ho x Wo grid per batch; k = tap*Cin + c; tap=(kh,kw);
+//   hi = ho*sh + off_h + kh*step_h, wi = wo*sw + off_w + kw*step_w (zero outside [0,Hi)x[0,Wi)).
+//   blockIdx.z = (b*groups + g)*ksplit + s.
+struct IGemmP {
+    const float* A; int lda; long a_bstride; int a_coff;
+    int Hi, Wi, Cin;
+    int KH, KW, sh, sw, off_h, off_w, step_h, step_w;
+    int Ho, Wo;
+    const float* W; long w_bstride; long w_gstride;   // packed [K][N] (per group), optional per-batch
+    const void* Wbf;                                   // bf16 copy, packed [N][K] (K contiguous), or null
+    int N, K, ksplit, groups;
+    const float* bias; long bias_bstride;              // [groups*N] or null; optional per-batch stride
+    float* C; int ldc; long c_bstride; long c_sstride; int c_coff;
+    int OHf, OWf, osh, osw, oh0, ow0;
+    const float* inmask; int inmask_ws;
+    const float* outmask; int outmask_ws;
+    long mask_bstride;
+    int act;                                           // 0 none, 1 GELU(erf)
+    const float* gate; int gate_nstride; long gate_step_stride;
+    const float* res; int ldres; long res_bstride; int res_coff;
+    const int* step;
+    int unpatch_s, unpatch_C;                          // >0: scatter rows (f,w) x cols (p1,p2,c) -> NHWC image
+    int B;
+};
+void launch_igemm(const IGemmP& p, int precision, hipStream_t st);
+
+// First ResnetBlock of the U-Net: 3x3 conv and 1x1 res_conv straight from the stacked input planes
+// (mu, c_in*x[, spk]) * mask  (diffusion.py:171-175,185; edm.py:96).
+struct FirstConvP {
+    const float* mu; const float* x; const float* spk;    // [B,80,T]; spk plane [B,80] or null
+    const float* mask; int B, H, T, planes, C;
+    const float* W3; const float* b3;                     // [planes*9][C], [C]
+    const float* W1; const float* b1;                     // [planes][C], [C]
+    const float* scal; int scal_stride; const int* step;  // per-step scalars; scal[step*stride + 2] = c_in
+    float* h1; float* res;                                // [B,H,T,C] each
+};
+void launch_first_conv(const FirstConvP& p, hipStream_t st);
+
+// GroupNorm statistics: per (b, group) sum / sum-of-squares in fp64 (biased variance later).
+struct GnStatsP { const float* X; int ld; long bstride; int npix; int C; int groups; double* stats; int B; };
+void launch_gn_stats(const GnStatsP& p, hipStream_t st);
+
+// y = mask*(Mish(GN(x)) + tadd[c]) + res   (Block / ResnetBlock tails, diffusion.py:41-50,66-71)
+struct GnApplyP {
+    const float* X; int ldx; long xb;
+    float* Y; int ldy; long yb; int y_coff;
+    int npix, W, C, groups; const double* stats; const float* gamma; const float* beta;
+    const float* mask; int mask_ws; long mask_bstride;
+    const float* tadd; long tadd_step_stride; const int* step;
+    const float* res; int ldres; long resb; int res_under_mask;   // 1: y = mask*(mish + tadd + res)
+    int B;
+};
+void launch_gn_apply(const GnApplyP& p, hipStream_t st);
+
+// final_block tail + final_conv + EDM combine + Euler update (diffusion.py:204-207, edm.py:97,202-208)
+struct FinalP {
+    const float* X; long xb; int npix, W, C, groups; const double* stats; const float* gamma; const float* beta;
+    const float* mask; long mask_bstride;
+    const float* wfc; const float* bfc;                   // final_conv weight [C], bias [1]
+    const float* xcur;                                    // [B,80,T] current sampler state (x_hat)
+    float* denoised;                                      // optional D_x out
+    float* xnext;                                         // optional Euler update out (may alias xcur)
+    const float* scal; int scal_stride; const int* step;
+    int B;
+};
+void launch_final(const FinalP& p, hipStream_t st);
+
+// Linear attention (diffusion.py:82-92): qkv [B,n,3*heads*32]; softmax over positions on k.
+struct LinAttnCtxP { const float* qkv; int ld; long bstride; int n; int heads; int chunk; int nchunks;
+                     float* part_m; float* part_s; float* part_c; int B; };
+void launch_linattn_ctx(const LinAttnCtxP& p, hipStream_t st);
+struct LinAttnCombineP { const float* part_m; const float* part_s; const float* part_c; int nchunks; int heads;
+                         const float* Wout;   // [C][heads*32] reference layout (to_out.weight)
+                         const float* g;      // Rezero scalar
+                         int C; float* Weff;  // [B][heads*32][C] : g * sum_e ctx[d,e] * Wout[c, h*32+e]
+                         int B; };
+void launch_linattn_combine(const LinAttnCombineP& p, hipStream_t st);
+
+// Depthwise patch-embed conv + SiLU (dit.py:57-58), channels-last, zero padding incl. right pad to patch multiple.
+struct DwConvP { const float* X; int ldx; long xb; int Hi, Wi, C; int k, s, pad; const float* Wd; const float* bd;
+                 const float* mask; int mask_ws; long mask_bstride;
+                 float* Y; int Hf, Wt; int B; };
+void launch_dwconv_silu(const DwConvP& p, hipStream_t st);
+
+// pos-conv tail: sum split-K partials + bias -> GELU -> mean over freq -> tokens = emb + pos + freq_pos (dit.py:450-454)
+struct PosFinishP { const float* part; int nsplit; long split_stride; const float* bias; const float* emb;
+                    const float* freq_pos; float* tok; int Hf, Wt, D; int B; };
+void launch_pos_finish(const PosFinishP& p, hipStream_t st);
+
+// LayerNorm(eps 1e-6, no affine) + modulate (dit.py:78-79,288-289,330)
+struct LnModP { const float* X; float* Y; int rows_per_batch; int D; const float* shift; const float* scale;
+                long step_stride; const int* step; int B; };
+void launch_ln_mod(const LnModP& p, hipStream_t st);
+
+// Softmax attention, head_dim 128, no key mask except kv_len (timm Attention core / TVAdaptor core).
+struct AttnP { const float* Q; int ldq; long qb; const float* K; int ldk; long kb; const float* V; int ldv; long vb;
+               float* O; int ldo; long ob; int Nq, Nk; const int* kv_len; int kv_len_add; int heads; float scale; int B; };
+void launch_attention(const AttnP& p, int precision, hipStream_t st);
+
+// y[r, n] = act_out( bias[n] + sum_k act_in(x[r,k]) * W[n,k] )   (tiny conditioning MLPs; W in reference layout)
+struct SmallLinP { const float* X; int ldx; int rows; int K; const float* W; const float* bias; int N;
+                   float* Y; int ldy; int act_in; int act_out; };   // act: 0 none, 1 mish, 2 silu
+void launch_small_linear(const SmallLinP& p, hipStream_t st);
+
+// Per-step EDM scalars + sinusoidal features from the sigma table (edm.py:90-94, diffusion.py:110-117, dit.py:250-254)
+struct CondPrepP { const float* sigmas; int n; float pe_scale; int dim; float* scal; int scal_stride;
+                   float* t_unet; float* t_dit; };
+void launch_cond_prep(const CondPrepP& p, hipStream_t st);
+
+// misc elementwise
+void launch_scale_copy(const float* src, float* dst, long n, const float* scal_ptr, hipStream_t st); // dst = src * *scal_ptr
+void launch_step_reset(int* step, hipStream_t st);
+void launch_step_inc(int* step, hipStream_t st);
+void launch_permute4(const float* src, float* dst, int d0, int d1, int d2, int d3, int p0, int p1, int p2, int p3,
+                     hipStream_t st);   // dst = src.permute(p0..p3).contiguous()
+void launch_f32_to_bf16(const float* src, void* dst, long n, hipStream_t st);
+void launch_spk_plane(const float* spk_out, float* plane, int B, int F, hipStream_t st);
+
+// DEX style adaptors -------------------------------------------------------------------------
+// per-row mean / sqrt(unbiased var + eps) over the last dim (InstanceNorm1D.cal_stats, base.py:72-78)
+void launch_row_stats(const float* X, int B, int C, int len, float eps, float* mean, float* std, long out_bstride, hipStream_t st);
+// per-(b,c) sum / sumsq over pixels (InstanceNorm2D statistics, base.py:95-103), fp64 atomics
+struct InStatsP { const float* X; int ld; long bstride; int npix; int C; double* stats; int B;
+                  const float* mask; int mask_ws; long mask_bstride; int W; };   // optional x*mask on load
+void launch_in_stats(const InStatsP& p, hipStream_t st);
+// SelfAttentionPooling for all steps (ref_encoder.py:246-253): out[step][b][C]
+struct SapP { const float* t_tok; int t_ld; int t_coff; int nsteps; const float* stats; int L; int C;
+              const float* w; const float* bias; float* out; int B; };
+void launch_sap(const SapP& p, hipStream_t st);
+// TV: fold InstanceNorm2D into w_q:  Weff[b][k][n] = rstd[b,k]*Wq[n,k];  beff[b][n] = -sum_k mean*rstd*Wq[n,k]
+struct InFoldP { const double* stats; int npix; float eps; const float* Wq; int C; float* Weff; float* beff; int B; };
+void launch_in_fold(const InFoldP& p, hipStream_t st);
+// TIV: y = IN2d(x)*s + m  (ref_encoder.py:271); s,m indexed [step][b][C]
+struct TivApplyP { const float* X; int ld; long xb; float* Y; int ldy; long yb; int npix; int C; const double* stats;
+                   float eps; const float* s_tab; const float* m_tab; const int* step; int B; };
+void launch_tiv_apply(const TivApplyP& p, hipStream_t st);
+// write per-step time-token rows into K/V row 0 (ref_encoder.py:157)
+struct TvRow0P { const float* k0; const float* v0; const int* step; float* K; float* V; long kvb; int C; int B; };
+void launch_tv_row0(const TvRow0P& p, hipStream_t st);
+// transpose [B,C,L] -> [B, L(+row_off), C]
+void launch_transpose_cl(const float* src, float* dst, int B, int C, int L, int row_off, long dst_bstride, hipStream_t st);
+
+// STFT / mel -------------------------------------------------------------------------------------
+// clip to [-1,1] + reflect-pad n_fft/2 on both sides (stft.py:60-66, tools.py:9)
+void launch_wav_pad(const float* wav, int n, int pad, float* out, int out_len, hipStream_t st);
+// spec [frames][ld] holds re at cols [0,513) and im at cols [im_off, im_off+513) ->
+// mel[j][f] = log(max(sum_k melW[j][k]*|spec|, 1e-5)), energy[f] = ||mag||_2   (stft.py:172-176)
+struct MagMelP { const float* spec; int ld; int im_off; int frames; int nbins; const float* melW; int nmel;
+                 float* mel; float* energy; };
+void launch_magmel(const MagMelP& p, hipStream_t st);
+
+}  // namespace dex

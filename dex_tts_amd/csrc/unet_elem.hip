@@ -1,0 +1,334 @@
+// unet_elem.hip — HBM-bound pieces of the Grad-TTS style U-Net stages (channels-last fp32):
+// first-layer direct convolution, GroupNorm statistics, GN-apply+Mish+mask(+time bias)(+residual),
+// the fused final_block tail + final_conv + EDM combine + Euler update, conditioning tables.
+#include "kernels.h"
+
+namespace dex {
+
+// Mish = x * tanh(softplus(x)) (diffusion.py:8-10; torch softplus threshold 20).
+// tanh(log1p(e)) = n/(n+2) with n = e*(e+2), e = exp(x): one exp, one divide, no cancellation.
+__device__ __forceinline__ float mish_f(float x) {
+    if (x > 20.f) return x;
+    const float e = __expf(x);
+    const float n = e * (e + 2.f);
+    return x * (n / (n + 2.f));
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+
+// ------------------------------------------------------------------------------------------------
+// first conv: one thread = one pixel x 4 output channels.  planes <= 3.
+__global__ __launch_bounds__(256) void first_conv_kernel(const FirstConvP p) {
+    const int C4 = p.C >> 2;
+    const long total = (long)p.B * p.H * p.T * C4;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int cq = (int)(gid % C4);
+    const long pix = gid / C4;
+    const int w = (int)(pix % p.T);
+    const int h = (int)((pix / p.T) % p.H);
+    const int b = (int)(pix / ((long)p.T * p.H));
+    const int step = p.step ? *p.step : 0;
+    const float c_in = p.scal[step * p.scal_stride + 2];
+    const float* mrow = p.mask + (long)b * p.T;
+    const float* pl[3] = {p.mu + (long)b * p.H * p.T, p.x + (long)b * p.H * p.T, nullptr};
+    float4 a3 = *reinterpret_cast<const float4*>(p.b3 + cq * 4);
+    float4 a1 = *reinterpret_cast<const float4*>(p.b1 + cq * 4);
+    for (int q = 0; q < p.planes; ++q) {
+        const float sc = (q == 1) ? c_in : 1.f;
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hi = h + kh - 1;
+            if ((unsigned)hi >= (unsigned)p.H) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+                const int wi = w + kw - 1;
+                if ((unsigned)wi >= (unsigned)p.T) continue;
+                float v;
+                if (q < 2) v = pl[q][(long)hi * p.T + wi] * sc;
+                else v = p.spk[(long)b * p.H + hi];
+                v *= mrow[wi];
+                const float4 wv = *reinterpret_cast<const float4*>(p.W3 + ((q * 9 + kh * 3 + kw) * p.C) + cq * 4);
+                a3.x = fmaf(v, wv.x, a3.x); a3.y = fmaf(v, wv.y, a3.y); a3.z = fmaf(v, wv.z, a3.z); a3.w = fmaf(v, wv.w, a3.w);
+                if (kh == 1 && kw == 1) {
+                    const float4 w1 = *reinterpret_cast<const float4*>(p.W1 + q * p.C + cq * 4);
+                    a1.x = fmaf(v, w1.x, a1.x); a1.y = fmaf(v, w1.y, a1.y); a1.z = fmaf(v, w1.z, a1.z); a1.w = fmaf(v, w1.w, a1.w);
+                }
+            }
+        }
+    }
+    *reinterpret_cast<float4*>(p.h1 + pix * p.C + cq * 4) = a3;
+    *reinterpret_cast<float4*>(p.res + pix * p.C + cq * 4) = a1;
+}
+void launch_first_conv(const FirstConvP& p, hipStream_t st) {
+    const long total = (long)p.B * p.H * p.T * (p.C / 4);
+    hipLaunchKernelGGL(first_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// GroupNorm statistics: grid (chunks, B); each block reduces GN_PIX pixels x C channels into
+// per-group (sum, sumsq), block-combined in LDS (fp64), then one fp64 atomic pair per group.
+constexpr int GN_PIX = 256;
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GnStatsP p) {
+    __shared__ double red[32][2];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int C4 = p.C >> 2, cpg = p.C / p.groups;
+    if (tid < 32) { red[tid][0] = 0.0; red[tid][1] = 0.0; }
+    __syncthreads();
+    const int cq = tid % C4, prow = tid / C4, rpp = 256 / C4;
+    const int pbeg = blockIdx.x * GN_PIX;
+    const int pend = min(p.npix, pbeg + GN_PIX);
+    const float* X = p.X + (long)b * p.bstride;
+    float s = 0.f, ss = 0.f;
+    for (int px = pbeg + prow; px < pend; px += rpp) {
+        const float4 v = *reinterpret_cast<const float4*>(X + (long)px * p.ld + cq * 4);
+        s += (v.x + v.y) + (v.z + v.w);
+        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+    const int g = (cq * 4) / cpg;
+    atomicAdd(&red[g][0], (double)s);
+    atomicAdd(&red[g][1], (double)ss);
+    __syncthreads();
+    if (tid < p.groups * 2) {
+        const int gg = tid >> 1, k = tid & 1;
+        atomicAdd(p.stats + ((long)b * p.groups + gg) * 2 + k, red[gg][k]);
+    }
+}
+void launch_gn_stats(const GnStatsP& p, hipStream_t st) {
+    dim3 grid((p.npix + GN_PIX - 1) / GN_PIX, p.B);
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(256), 0, st, p);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnApplyP p) {
+    __shared__ float smean[32], srstd[32];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int C4 = p.C >> 2, cpg = p.C / p.groups;
+    if (tid < p.groups) {
+        const double n = (double)p.npix * cpg;
+        const double mean = p.stats[((long)b * p.groups + tid) * 2] / n;
+        double var = p.stats[((long)b * p.groups + tid) * 2 + 1] / n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        smean[tid] = (float)mean;
+        srstd[tid] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+    __syncthreads();
+    const int step = p.step ? *p.step : 0;
+    const long total = (long)p.npix * C4;
+    const float* X = p.X + (long)b * p.xb;
+    float* Y = p.Y + (long)b * p.yb + p.y_coff;
+    const float* R = p.res ? p.res + (long)b * p.resb : nullptr;
+    const float* mrow = p.mask + (long)b * p.mask_bstride;
+    for (long idx = (long)blockIdx.x * 256 + tid; idx < total; idx += (long)gridDim.x * 256) {
+        const int cq = (int)(idx % C4);
+        const long px = idx / C4;
+        const int w = (int)(px % p.W);
+        const int c = cq * 4, g = c / cpg;
+        const float mean = smean[g], rstd = srstd[g];
+        const float4 x = *reinterpret_cast<const float4*>(X + px * p.ldx + c);
+        const float4 ga = *reinterpret_cast<const float4*>(p.gamma + c);
+        const float4 be = *reinterpret_cast<const float4*>(p.beta + c);
+        float4 y;
+        y.x = mish_f((x.x - mean) * rstd * ga.x + be.x);
+        y.y = mish_f((x.y - mean) * rstd * ga.y + be.y);
+        y.z = mish_f((x.z - mean) * rstd * ga.z + be.z);
+        y.w = mish_f((x.w - mean) * rstd * ga.w + be.w);
+        if (p.tadd) {
+            const float4 t = *reinterpret_cast<const float4*>(p.tadd + (long)step * p.tadd_step_stride + c);
+            y.x += t.x; y.y += t.y; y.z += t.z; y.w += t.w;
+        }
+        const float mk = mrow[w * p.mask_ws];
+        if (R && p.res_under_mask) {      // identity shortcut: h + (x * mask)
+            const float4 r = *reinterpret_cast<const float4*>(R + px * p.ldres + c);
+            y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
+        }
+        y.x *= mk; y.y *= mk; y.z *= mk; y.w *= mk;
+        if (R && !p.res_under_mask) {     // res_conv(x * mask): bias survives in padded columns
+            const float4 r = *reinterpret_cast<const float4*>(R + px * p.ldres + c);
+            y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
+        }
+        *reinterpret_cast<float4*>(Y + px * p.ldy + c) = y;
+    }
+}
+void launch_gn_apply(const GnApplyP& p, hipStream_t st) {
+    const long total = (long)p.npix * (p.C / 4);
+    long blocks = (total + 256 * 4 - 1) / (256 * 4);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)blocks, p.B), dim3(256), 0, st, p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// final: per pixel  f = mask * (b + sum_c w[c] * mask * Mish(GN(x)[c]));  D = c_skip*x + c_out*f;
+//        x_next = x + (t_next - t)/t * (x - D).          scal row: [sigma, sigma_next, c_in, c_skip, c_out, c_noise]
+// 16 lanes cooperate on one pixel (C = 64 -> one float4 each; C = 128 -> two).
+__global__ __launch_bounds__(256) void final_kernel(const FinalP p) {
+    __shared__ float smean[32], srstd[32];
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int cpg = p.C / p.groups;
+    if (tid < p.groups) {
+        const double n = (double)p.npix * cpg;
+        const double mean = p.stats[((long)b * p.groups + tid) * 2] / n;
+        double var = p.stats[((long)b * p.groups + tid) * 2 + 1] / n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        smean[tid] = (float)mean;
+        srstd[tid] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+    __syncthreads();
+    const int step = p.step ? *p.step : 0;
+    const float* sc = p.scal + (long)step * p.scal_stride;
+    const float sigma = sc[0], sigma_next = sc[1], c_skip = sc[3], c_out = sc[4];
+    const float* X = p.X + (long)b * p.xb;
+    const float* mrow = p.mask + (long)b * p.mask_bstride;
+    const int sub = tid & 15;
+    for (long px = (long)blockIdx.x * 16 + (tid >> 4); px < p.npix; px += (long)gridDim.x * 16) {
+        const int w = (int)(px % p.W);
+        const float mk = mrow[w];
+        float acc = 0.f;
+        for (int c = sub * 4; c < p.C; c += 64) {
+            const int g = c / cpg;
+            const float mean = smean[g], rstd = srstd[g];
+            const float4 x = *reinterpret_cast<const float4*>(X + px * p.C + c);
+            const float4 ga = *reinterpret_cast<const float4*>(p.gamma + c);
+            const float4 be = *reinterpret_cast<const float4*>(p.beta + c);
+            const float4 wv = *reinterpret_cast<const float4*>(p.wfc + c);
+            acc = fmaf(mish_f((x.x - mean) * rstd * ga.x + be.x), wv.x, acc);
+            acc = fmaf(mish_f((x.y - mean) * rstd * ga.y + be.y), wv.y, acc);
+            acc = fmaf(mish_f((x.z - mean) * rstd * ga.z + be.z), wv.z, acc);
+            acc = fmaf(mish_f((x.w - mean) * rstd * ga.w + be.w), wv.w, acc);
+        }
+        acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 8);
+        if (sub == 0) {
+            const float f = (acc * mk + p.bfc[0]) * mk;
+            const long o = (long)b * p.npix + px;            // [B,80,T] has the same (h*T + w) linear order
+            const float xc = p.xcur[o];
+            const float D = c_skip * xc + c_out * f;
+            if (p.denoised) p.denoised[o] = D;
+            if (p.xnext) {
+                const float inv = 1.f / sigma;
+                const float d = inv * xc - inv * D;
+                p.xnext[o] = xc + (sigma_next - sigma) * d;
+            }
+        }
+    }
+}
+void launch_final(const FinalP& p, hipStream_t st) {
+    long blocks = (p.npix + 15) / 16;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(final_kernel, dim3((unsigned)blocks, p.B), dim3(256), 0, st, p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Conditioning prep: thread i = Euler step i.  fp32 math in the reference's op order
+// (edm.py:90-94; SinusoidalPosEmb diffusion.py:110-117; timestep_embedding dit.py:250-254).
+__global__ void cond_prep_kernel(const CondPrepP p) {
+    const int i = blockIdx.x;
+    const int k = threadIdx.x;
+    const float sigma = p.sigmas[i], sigma_next = p.sigmas[i + 1];
+    const float sd = 0.5f;
+    const float c_noise = logf(sigma) / 4.f;
+    if (k == 0) {
+        float* sc = p.scal + (long)i * p.scal_stride;
+        const float s2 = sigma * sigma + sd * sd;
+        sc[0] = sigma; sc[1] = sigma_next;
+        sc[2] = 1.f / sqrtf(s2);                 // c_in
+        sc[3] = (sd * sd) / s2;                  // c_skip
+        sc[4] = sigma * sd / sqrtf(s2);          // c_out
+        sc[5] = c_noise;
+    }
+    const int half = p.dim / 2;
+    if (k < half) {
+        const float e = (float)(log(10000.0) / (double)(half - 1));   // python double -> fp32 scalar
+        const float f = expf((float)k * -e);
+        const float a = p.pe_scale * c_noise * f;
+        p.t_unet[(long)i * p.dim + k] = sinf(a);
+        p.t_unet[(long)i * p.dim + half + k] = cosf(a);
+    }
+    if (k < 128) {
+        const float f = expf((float)(-log(10000.0)) * (float)k / 128.f);
+        const float a = c_noise * f;
+        p.t_dit[(long)i * 256 + k] = cosf(a);
+        p.t_dit[(long)i * 256 + 128 + k] = sinf(a);
+    }
+}
+void launch_cond_prep(const CondPrepP& p, hipStream_t st) {
+    hipLaunchKernelGGL(cond_prep_kernel, dim3(p.n), dim3(128), 0, st, p);
+}
+
+// tiny conditioning MLPs: one wave per output feature n, looping over rows (Euler steps).
+__global__ __launch_bounds__(256) void small_linear_kernel(const SmallLinP p) {
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= p.N) return;
+    const float* w = p.W + (long)wave * p.K;
+    const float bias = p.bias ? p.bias[wave] : 0.f;
+    for (int r = 0; r < p.rows; ++r) {
+        const float* x = p.X + (long)r * p.ldx;
+        float acc = 0.f;
+        for (int k = lane; k < p.K; k += 64) {
+            float v = x[k];
+            if (p.act_in == 1) v = mish_f(v); else if (p.act_in == 2) v = silu_f(v);
+            acc = fmaf(v, w[k], acc);
+        }
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) {
+            float y = acc + bias;
+            if (p.act_out == 1) y = mish_f(y); else if (p.act_out == 2) y = silu_f(y);
+            p.Y[(long)r * p.ldy + wave] = y;
+        }
+    }
+}
+void launch_small_linear(const SmallLinP& p, hipStream_t st) {
+    hipLaunchKernelGGL(small_linear_kernel, dim3((p.N * 64 + 255) / 256), dim3(256), 0, st, p);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void scale_copy_kernel(const float* src, float* dst, long n, const float* scal) {
+    const float s = scal ? *scal : 1.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = src[i] * s;
+}
+void launch_scale_copy(const float* src, float* dst, long n, const float* scal_ptr, hipStream_t st) {
+    long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(scale_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, n, scal_ptr);
+}
+__global__ void step_reset_kernel(int* s) { *s = 0; }
+__global__ void step_inc_kernel(int* s) { *s = *s + 1; }
+void launch_step_reset(int* step, hipStream_t st) { hipLaunchKernelGGL(step_reset_kernel, dim3(1), dim3(1), 0, st, step); }
+void launch_step_inc(int* step, hipStream_t st) { hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, step); }
+
+__global__ void permute4_kernel(const float* src, float* dst, int d0, int d1, int d2, int d3, int p0, int p1, int p2, int p3) {
+    const long n = (long)d0 * d1 * d2 * d3;
+    const int sd[4] = {d0, d1, d2, d3};
+    const long ss[4] = {(long)d1 * d2 * d3, (long)d2 * d3, (long)d3, 1};
+    const int pm[4] = {p0, p1, p2, p3};
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        long rem = i, off = 0;
+        for (int a = 3; a >= 0; --a) {
+            const int dim = sd[pm[a]];
+            const int idx = (int)(rem % dim);
+            rem /= dim;
+            off += idx * ss[pm[a]];
+        }
+        dst[i] = src[off];
+    }
+}
+void launch_permute4(const float* src, float* dst, int d0, int d1, int d2, int d3, int p0, int p1, int p2, int p3, hipStream_t st) {
+    const long n = (long)d0 * d1 * d2 * d3;
+    long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(permute4_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, d0, d1, d2, d3, p0, p1, p2, p3);
+}
+
+__global__ void f32_to_bf16_kernel(const float* src, unsigned short* dst, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        unsigned u = __float_as_uint(src[i]);
+        u += 0x7FFFu + ((u >> 16) & 1u);          // round to nearest even
+        dst[i] = (unsigned short)(u >> 16);
+    }
+}
+void launch_f32_to_bf16(const float* src, void* dst, long n, hipStream_t st) {
+    long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, (unsigned short*)dst, n);
+}
+
+// speaker plane: the reference repeats spk_mlp(spk) [B,80] along time (diffusion.py:173-175); we keep [B,80].
+void launch_spk_plane(const float* spk_out, float* plane, int B, int F, hipStream_t st) {
+    launch_scale_copy(spk_out, plane, (long)B * F, nullptr, st);
+}
+
+}  // namespace dex

@@ -1,0 +1,161 @@
+"""Drop-in replacement for the reference ``model.diffusion.Diffusion`` inference path.
+
+Same constructor arguments, same ``forward`` signatures, same checkpoint keys (every denoiser tensor
+appears under ``denoise_fn.*`` and ``precond_model.model.*`` — reference diffusion.py:213-214), same
+RNG draws.  All arithmetic of ``forward(..., infer=True)`` runs in libdexamd.so (hand-written gfx950
+kernels); PyTorch only owns the tensors and the stream.
+
+    GeDEX: Diffusion.forward(x, mask, mu, n_timesteps, spk, infer, temperature, mask_ratio)
+           — GeDEX-TTS/model/diffusion.py:220-229
+    DEX:   Diffusion.forward(x, mask, mu, ref, ref_lengths, sty, sty_lengths, n_timesteps, spk, infer,
+           temperature, mask_ratio) — DEX-TTS/model/diffusion.py:250-259
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+import torch.nn as nn
+
+from .config import DiTConfig, ScoreNetConfig, param_shapes
+from .engine import ScoreNetEngine
+
+
+class _Params(nn.Module):
+    """Parameter container reproducing the reference's module-tree names (no forward)."""
+
+    def __init__(self):
+        super().__init__()
+
+
+def _build_tree(shapes: Dict[str, tuple]) -> _Params:
+    root = _Params()
+    for key, shape in shapes.items():
+        parts = key.split(".")
+        node = root
+        for name in parts[:-1]:
+            if name not in node._modules:
+                node.add_module(name, _Params())
+            node = node._modules[name]
+        zero = (key.endswith(".fn.g") or ".adaLN_modulation.1." in key or key.startswith("vit.final_layer.linear")
+                or key == "vit.freq_new_pos_embed" or key.endswith(".bias"))
+        if zero:      # reference zero-inits (dit.py:404-413, diffusion.py:35); biases start at 0 here
+            t = torch.zeros(shape)
+        elif key.endswith("block.1.weight"):
+            t = torch.ones(shape)
+        else:
+            fan_in = int(math.prod(shape[1:])) if len(shape) > 1 else int(shape[0])
+            t = torch.empty(shape).uniform_(-1.0, 1.0) * (1.0 / math.sqrt(max(fan_in, 1)))
+        node.register_parameter(parts[-1], nn.Parameter(t, requires_grad=False))
+    return root
+
+
+class _Precond(nn.Module):
+    """Holds ``model`` so that state_dict exposes ``precond_model.model.*`` (edm.py:74-86)."""
+
+    def __init__(self, model: nn.Module, sigma_data: float = 0.5):
+        super().__init__()
+        self.model = model
+        self.sigma_min, self.sigma_max, self.sigma_data = 0, float("inf"), sigma_data
+
+
+def _cfg_get(obj, name, default):
+    if isinstance(obj, dict):
+        return obj.get(name, default)
+    return getattr(obj, name, default)
+
+
+class Diffusion(nn.Module):
+    def __init__(self, n_feats, dim, dit_cfg, loss_type="base", precond="edm", model_type="dit", dim_mults=(1, 2),
+                 n_spks=1, spk_emb_dim=64, pe_scale=1000, variant="gedex"):
+        super().__init__()
+        if model_type != "dit" or precond != "edm":
+            raise ValueError("only model_type='dit' / precond='edm' exist in the reference configs")
+        d = DiTConfig()
+        dit = DiTConfig(**{k: _cfg_get(dit_cfg, k, getattr(d, k)) for k in DiTConfig.__dataclass_fields__})
+        self.cfg = ScoreNetConfig(variant=variant, n_feats=n_feats, dim=dim, dim_mults=tuple(dim_mults),
+                                  n_spks=n_spks if n_spks is not None else 1, spk_emb_dim=spk_emb_dim,
+                                  pe_scale=float(pe_scale), dit=dit)
+        self.loss_type = loss_type
+        self.denoise_fn = _build_tree(param_shapes(self.cfg))
+        self.precond_model = _Precond(self.denoise_fn)
+        self.loss_fn = None                      # EDMLoss is training-only (edm.py:22-68): out of scope
+        self.precision = "fp32"
+        self.use_graph = False
+        self.rng_parity = True                   # replay the reference's per-step randn_like draws (edm.py:196)
+        self._engine = None
+        self._engine_key = None
+        if variant == "dex":
+            self.sampler = lambda z, mask, mu, ref, ref_lengths, sty, sty_lengths, spk, steps: self._sample(
+                z, mask, mu, steps, spk, ref, sty, sty_lengths)
+        else:
+            self.sampler = lambda z, mask, mu, spk, steps: self._sample(z, mask, mu, steps, spk)
+
+    # ---- engine management ---------------------------------------------------------------------
+    def _weights(self):
+        return {k: v for k, v in self.denoise_fn.state_dict().items()}
+
+    def engine(self, device: torch.device) -> ScoreNetEngine:
+        params = list(self.denoise_fn.parameters())
+        key = (str(device), tuple(p._version for p in params), tuple(p.data_ptr() for p in params), self.precision)
+        if self._engine is None or self._engine.device != device:
+            self._engine = ScoreNetEngine(self.cfg, device)
+            self._engine_key = None
+        if key != self._engine_key:
+            self._engine.load_weights(self._weights())
+            self._engine.set_precision(self.precision)
+            self._engine_key = key
+        return self._engine
+
+    def _sample(self, z, mask, mu, steps, spk=None, ref=None, sty=None, sty_lengths=None):
+        eng = self.engine(z.device)
+        return eng.sample(z, mask, mu, int(steps), spk=spk, ref=ref, sty=sty, sty_lengths=sty_lengths,
+                          use_graph=self.use_graph)
+
+    def _advance_rng(self, like: torch.Tensor, n: int):
+        """The reference draws ``randn_like(x_cur)`` once per Euler step and multiplies it by 0
+        (edm.py:196); only the generator state matters.  Advance the Philox offset by the same amount."""
+        if not self.rng_parity or n <= 0:
+            return
+        gen = torch.cuda.default_generators[like.device.index if like.device.index is not None else torch.cuda.current_device()]
+        try:
+            o0 = gen.get_offset()
+            torch.randn_like(like)
+            step = gen.get_offset() - o0
+            if n > 1:
+                gen.set_offset(o0 + n * step)
+        except Exception:
+            for _ in range(n - 1):
+                torch.randn_like(like)
+
+    # ---- reference call surface ----------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, x, mask, mu, *args, n_timesteps=1, spk=None, infer=False, temperature=1.0, mask_ratio=0, **kw):
+        names = ["ref", "ref_lengths", "sty", "sty_lengths"] if self.cfg.variant == "dex" else []
+        names += ["n_timesteps", "spk", "infer", "temperature", "mask_ratio"]
+        vals = {"n_timesteps": n_timesteps, "spk": spk, "infer": infer, "temperature": temperature, "mask_ratio": mask_ratio}
+        vals.update(kw)
+        if len(args) > len(names):
+            raise TypeError("too many positional arguments")
+        for n, v in zip(names, args):
+            vals[n] = v
+        if not vals["infer"]:
+            raise NotImplementedError("the training-loss branch (EDMLoss, edm.py:22-68) is out of scope of the "
+                                      "MI355X sampler; use the reference module for training")
+        shape = (mu.shape[0], 80, mu.shape[2])
+        z = torch.randn(shape, device=x.device) / vals["temperature"] + mu            # diffusion.py:227
+        if self.cfg.variant == "dex":
+            out = self.sampler(z, mask, mu, vals["ref"], vals["ref_lengths"], vals["sty"], vals["sty_lengths"],
+                               vals["spk"], vals["n_timesteps"])
+        else:
+            out = self.sampler(z, mask, mu, vals["spk"], vals["n_timesteps"])
+        self._advance_rng(z, int(vals["n_timesteps"]))
+        return out
+
+
+def from_config(cfg: ScoreNetConfig) -> Diffusion:
+    t = cfg.dit
+    dit = {k: getattr(t, k) for k in DiTConfig.__dataclass_fields__}
+    return Diffusion(cfg.n_feats, cfg.dim, dit, dim_mults=cfg.dim_mults, n_spks=cfg.n_spks,
+                     spk_emb_dim=cfg.spk_emb_dim, pe_scale=cfg.pe_scale, variant=cfg.variant)

@@ -1,0 +1,188 @@
+"""Host-side owner of one libdexamd context: device memory and streams come from PyTorch-ROCm
+(plumbing), all arithmetic of the sampler runs in the HIP library."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional
+
+import torch
+
+from . import _lib
+from .config import ScoreNetConfig, param_shapes
+
+
+def edm_sigmas(n_steps: int) -> torch.Tensor:
+    """t_0..t_{N-1}, t_N = 0 with the reference's exact fp32 expression (edm.py:141,157,184-185)."""
+    if n_steps < 2:
+        raise ValueError("n_timesteps must be >= 2 (the reference divides by num_steps - 1, edm.py:157)")
+    sigma_min, sigma_max, rho = 0.002, 80, 7
+    idx = torch.arange(n_steps)
+    s = (sigma_max ** (1 / rho) + idx / (n_steps - 1) * (sigma_min ** (1 / rho) - sigma_max ** (1 / rho))) ** rho
+    return torch.cat([s.to(torch.float32), torch.zeros(1)])
+
+
+class ScoreNetEngine:
+    def __init__(self, cfg: ScoreNetConfig, device: torch.device):
+        if device.type != "cuda":
+            raise RuntimeError("dex_tts_amd runs on an AMD GPU (torch device 'cuda' on ROCm); no CPU path exists")
+        self.lib = _lib.load()
+        self.cfg, self.device = cfg, device
+        self.shapes = param_shapes(cfg)
+        ccfg = _lib.make_config(cfg)
+        h = C.c_void_p()
+        rc = self.lib.dex_ctx_create(C.byref(ccfg), C.byref(h))
+        self.h = h
+        self._check(rc)
+        self._ws: Optional[torch.Tensor] = None
+        self._keep: list = []
+        self.loaded_version = None
+
+    # ---------------------------------------------------------------------------------------
+    def _check(self, rc: int):
+        if rc != 0:
+            msg = self.lib.dex_last_error(self.h)
+            raise RuntimeError(f"libdexamd error {rc}: {msg.decode() if msg else '?'}")
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None) and self.h.value:
+                self.lib.dex_ctx_destroy(self.h)
+                self.h = C.c_void_p()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_precision(self, name: str):
+        self._check(self.lib.dex_ctx_set_precision(self.h, _lib.PRECISION[name]))
+
+    def load_weights(self, weights: Dict[str, torch.Tensor]):
+        """weights: state-dict entries relative to ``denoise_fn.`` in the reference layout."""
+        with torch.cuda.device(self.device):
+            for key, shape in self.shapes.items():
+                if key not in weights:
+                    raise KeyError(f"missing weight {key}")
+                w = weights[key].detach().to(device=self.device, dtype=torch.float32).contiguous()
+                if tuple(w.shape) != tuple(shape):
+                    raise ValueError(f"{key}: shape {tuple(w.shape)} != {tuple(shape)}")
+                shp = (C.c_int64 * 4)(*([int(s) for s in shape] + [0] * (4 - len(shape))))
+                self._check(self.lib.dex_ctx_load_weight(self.h, key.encode(), C.c_void_p(w.data_ptr()), shp, len(shape)))
+            torch.cuda.synchronize(self.device)
+            self._check(self.lib.dex_ctx_finalize(self.h, self._stream()))
+
+    def workspace(self, B, T, Tr, Ts, n_steps) -> torch.Tensor:
+        need = int(self.lib.dex_workspace_bytes(self.h, B, T, Tr, Ts, n_steps))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need + 256, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    # ---------------------------------------------------------------------------------------
+    def _fill_args(self, a: _lib.DexSampleArgs, mu, mask, sigmas, out, n_steps, spk, ref, sty, sty_lengths, use_graph):
+        B, F, T = mu.shape
+        if F != 80:
+            raise ValueError("mel dimension must be 80")
+        if T % 4 != 0:
+            raise ValueError(f"T={T} must be a multiple of 4 (fix_len_compatibility)")
+        Tr = Ts = 0
+        keep = [mu, mask, sigmas, out]
+        a.B, a.T, a.n_steps = B, T, n_steps
+        a.mu_dev, a.mask_dev, a.sigmas_dev, a.out_dev = mu.data_ptr(), mask.data_ptr(), sigmas.data_ptr(), out.data_ptr()
+        a.spk_dev = None
+        if spk is not None and self.cfg.n_spks > 1:
+            spk = spk.to(device=self.device, dtype=torch.float32).contiguous()
+            keep.append(spk); a.spk_dev = spk.data_ptr()
+        a.ref_skips_dev, a.n_ref, a.Tr, a.sty_dev, a.sty_lengths_dev, a.Ts = None, 0, 0, None, None, 0
+        if self.cfg.variant == "dex":
+            ref = [r.to(device=self.device, dtype=torch.float32).contiguous() for r in ref]
+            sty = sty.to(device=self.device, dtype=torch.float32).contiguous()
+            sl = sty_lengths.to(device=self.device, dtype=torch.int32).contiguous()
+            if any(r.shape[0] != B for r in ref) or sty.shape[0] != B or sl.shape[0] != B:
+                raise ValueError("DEX style tensors must have the batch size of mu")
+            Tr, Ts = ref[0].shape[-1], sty.shape[-1]
+            arr = (C.c_void_p * len(ref))(*[r.data_ptr() for r in ref])
+            keep += ref + [sty, sl, arr]
+            a.ref_skips_dev, a.n_ref, a.Tr = C.cast(arr, C.POINTER(C.c_void_p)), len(ref), Tr
+            a.sty_dev, a.sty_lengths_dev, a.Ts = sty.data_ptr(), sl.data_ptr(), Ts
+        ws = self.workspace(B, T, Tr, Ts, max(n_steps, 1))
+        base = (ws.data_ptr() + 255) // 256 * 256
+        a.workspace_dev, a.workspace_bytes = base, ws.numel() - (base - ws.data_ptr())
+        a.use_graph = 1 if use_graph else 0
+        return keep
+
+    @staticmethod
+    def _prep_mask(mask, B, T, device):
+        m = mask.to(device=device, dtype=torch.float32).reshape(B, T).contiguous()
+        return m
+
+    def sample(self, z, mask, mu, n_steps, spk=None, ref=None, sty=None, sty_lengths=None, use_graph=False):
+        """ablation_sampler(euler, edm, linear, none) for latent z — edm.py:109-216.  Asynchronous."""
+        with torch.cuda.device(self.device):
+            mu = mu.to(device=self.device, dtype=torch.float32).contiguous()
+            z = z.to(device=self.device, dtype=torch.float32).contiguous()
+            B, _, T = mu.shape
+            mask = self._prep_mask(mask, B, T, self.device)
+            sig = edm_sigmas(n_steps).to(self.device)
+            out = torch.empty_like(mu)
+            a = _lib.DexSampleArgs()
+            keep = self._fill_args(a, mu, mask, sig, out, n_steps, spk, ref, sty, sty_lengths, use_graph)
+            a.z_dev = z.data_ptr()
+            self._check(self.lib.dex_sample(self.h, C.byref(a), self._stream()))
+            self._keep = keep + [z]           # keep inputs alive until the stream work is enqueued & consumed
+            return out
+
+    def denoise_once(self, x, sigma: float, mask, mu, spk=None, ref=None, sty=None, sty_lengths=None):
+        """One EDMPrecond.forward (edm.py:88-98); also records debug taps."""
+        with torch.cuda.device(self.device):
+            mu = mu.to(device=self.device, dtype=torch.float32).contiguous()
+            x = x.to(device=self.device, dtype=torch.float32).contiguous()
+            B, _, T = mu.shape
+            mask = self._prep_mask(mask, B, T, self.device)
+            sig = torch.tensor([float(sigma), 0.0], dtype=torch.float32).to(self.device)
+            out = torch.empty_like(mu)
+            d = _lib.DexDenoiseArgs()
+            keep = self._fill_args(d.s, mu, mask, sig, out, 1, spk, ref, sty, sty_lengths, False)
+            d.x_dev = x.data_ptr()
+            self._check(self.lib.dex_denoise_once(self.h, C.byref(d), self._stream()))
+            self._keep = keep + [x]
+            return out
+
+    def taps(self) -> Dict[str, torch.Tensor]:
+        """Named intermediates of the last denoise_once call, each [rows, C] (channels-last)."""
+        out = {}
+        with torch.cuda.device(self.device):
+            for i in range(self.lib.dex_num_taps(self.h)):
+                name = self.lib.dex_tap_name(self.h, i)
+                shp = (C.c_int64 * 4)()
+                nd = C.c_int()
+                self._check(self.lib.dex_tap_info(self.h, name, shp, C.byref(nd)))
+                t = torch.empty(int(shp[0]), int(shp[1]), dtype=torch.float32, device=self.device)
+                self._check(self.lib.dex_tap_copy(self.h, name, C.c_void_p(t.data_ptr()), t.numel() * 4, self._stream()))
+                out[name.decode()] = t
+            torch.cuda.synchronize(self.device)
+        return out
+
+    # profiling --------------------------------------------------------------------------------
+    def profile(self, on: bool):
+        self._check(self.lib.dex_profile_enable(self.h, 1 if on else 0))
+
+    def profile_rows(self) -> List[dict]:
+        rows = []
+        for i in range(self.lib.dex_profile_num(self.h)):
+            name = C.c_char_p(); calls = C.c_int(); ms = C.c_double(); fl = C.c_double(); by = C.c_double()
+            self._check(self.lib.dex_profile_get(self.h, i, C.byref(name), C.byref(calls), C.byref(ms), C.byref(fl), C.byref(by)))
+            rows.append({"name": name.value.decode(), "calls": calls.value, "ms": ms.value, "flops": fl.value, "bytes": by.value})
+        return rows
+
+    # mel front-end ----------------------------------------------------------------------------
+    def mel_from_wav(self, wav: torch.Tensor):
+        with torch.cuda.device(self.device):
+            wav = wav.to(device=self.device, dtype=torch.float32).contiguous().reshape(-1)
+            n = wav.numel()
+            frames = self.lib.dex_mel_frames(n)
+            mel = torch.empty(80, frames, dtype=torch.float32, device=self.device)
+            energy = torch.empty(frames, dtype=torch.float32, device=self.device)
+            self._check(self.lib.dex_mel_from_wav(self.h, wav.data_ptr(), n, mel.data_ptr(), energy.data_ptr(), self._stream()))
+            self._keep = [wav]
+            return mel, energy

@@ -1,0 +1,130 @@
+/*
+ * dex_amd.h — C ABI of libdexamd.so: MI355X (gfx950) reverse-diffusion sampler for DEX-TTS / GeDEX-TTS.
+ *
+ * Drop-in boundary for the reference's Diffusion.forward(..., infer=True) hot path
+ *   GeDEX-TTS/model/diffusion.py:220-229, DEX-TTS/model/diffusion.py:250-259
+ *   -> ablation_sampler (euler/edm/linear/none)   GeDEX-TTS/model/edm.py:109-216 (DEX :104-211)
+ *   -> EDMPrecond.forward                          model/edm.py:88-98
+ *   -> DiffusionDenoiser.forward (+DiTMask, TV/TIV adaptors)
+ *                                                  GeDEX diffusion.py:168-207, DEX :190-236, model/dit.py:485-525,
+ *                                                  DEX-TTS/model/ref_encoder.py:142-179,255-273
+ * and for the STFT/mel front-end audio/tools.py:8-15 -> audio/stft.py:159-178,52-81.
+ *
+ * Conventions: every pointer named *_dev is a DEVICE pointer (HBM) to contiguous fp32 unless stated;
+ * all work is enqueued asynchronously on the caller's HIP stream; the library never synchronises the
+ * stream inside dex_sample/dex_denoise_once.  Functions return 0 on success and a negative DexStatus
+ * otherwise; nothing throws across the ABI; dex_last_error() gives the message.
+ * Ownership: the caller owns inputs, outputs and the workspace; the library owns the context, its
+ * packed weight copies (hipMalloc at dex_ctx_finalize) and captured hipGraphs.
+ */
+#ifndef DEX_AMD_H
+#define DEX_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct DexCtx DexCtx;
+typedef void* dex_stream_t; /* hipStream_t */
+
+typedef enum {
+    DEX_OK = 0,
+    DEX_ERR_ARG = -1,      /* bad argument / shape (e.g. T % 4 != 0, unknown key, wrong weight shape) */
+    DEX_ERR_STATE = -2,    /* call order (weights missing, not finalized) */
+    DEX_ERR_HIP = -3,      /* a HIP runtime call failed */
+    DEX_ERR_WORKSPACE = -4 /* workspace too small */
+} DexStatus;
+
+typedef enum { DEX_VARIANT_GEDEX = 0, DEX_VARIANT_DEX = 1 } DexVariant;
+typedef enum { DEX_PREC_FP32 = 0, DEX_PREC_BF16 = 1 } DexPrecision;
+
+/* Mirrors Diffusion(**cfg.decoder, dit_cfg=cfg.dit): GeDEX diffusion.py:210, dit.py:339-356. */
+typedef struct {
+    int32_t variant;        /* DexVariant */
+    int32_t n_feats;        /* 80 (hard-coded at diffusion.py:226) */
+    int32_t dim;            /* decoder.dim (64) */
+    int32_t n_stages;       /* len(dim_mults) (2) */
+    int32_t dim_mults[4];
+    int32_t n_spks;         /* >1 adds the speaker plane (GeDEX-VCTK) */
+    int32_t spk_emb_dim;
+    float   pe_scale;       /* 1000 */
+    int32_t dit_patch, dit_stride, dit_hidden, dit_depth, dit_heads;
+    float   dit_mlp_ratio;
+    int32_t dit_conv_pos, dit_conv_pos_groups;
+} DexConfig;
+
+/* One Diffusion.forward(infer=True) call == ablation_sampler with a given latent z. */
+typedef struct {
+    int32_t B, T;               /* batch, padded mel frames (T % 4 == 0, model/utils.py:13-17) */
+    int32_t n_steps;            /* n_timesteps >= 2 */
+    const float* z_dev;         /* [B,80,T] latent = randn/temperature + mu (diffusion.py:227); drawn by the caller */
+    const float* mu_dev;        /* [B,80,T] */
+    const float* mask_dev;      /* [B,T]   float 0/1 (reference shape [B,1,T]) */
+    const float* sigmas_dev;    /* [n_steps+1] fp32 noise levels t_0..t_{N-1}, t_N=0 (edm.py:157,184-185) */
+    const float* spk_dev;       /* [B,spk_emb_dim] or NULL */
+    /* DEX only (NULL/0 otherwise): */
+    const float* const* ref_skips_dev; /* HOST array of 6 device pointers, each [B,mid,Tr] */
+    int32_t n_ref, Tr;
+    const float* sty_dev;       /* [B,mid,Ts] */
+    const int32_t* sty_lengths_dev; /* [B] int32 */
+    int32_t Ts;
+    float* out_dev;             /* [B,80,T] x_N (unmasked, like edm.py:216) */
+    void*  workspace_dev;       /* >= dex_workspace_bytes(...) bytes, 256-B aligned */
+    size_t workspace_bytes;
+    int32_t use_graph;          /* 1: replay a cached hipGraph of one Euler step */
+} DexSampleArgs;
+
+/* One EDMPrecond.forward call (edm.py:88-98): out = c_skip*x + c_out*F(c_in*x, mask, mu, ln(sigma)/4). */
+typedef struct {
+    DexSampleArgs s;            /* z_dev is ignored; n_steps ignored; sigmas_dev[0] = sigma */
+    const float* x_dev;         /* [B,80,T] */
+} DexDenoiseArgs;
+
+int  dex_ctx_create(const DexConfig* cfg, DexCtx** out);
+void dex_ctx_destroy(DexCtx* ctx);
+const char* dex_last_error(const DexCtx* ctx);
+const char* dex_version(void);
+
+/* Number of state-dict tensors the context expects, and the i-th key (relative to "denoise_fn.") + shape. */
+int  dex_ctx_num_weights(const DexCtx* ctx);
+int  dex_ctx_weight_info(const DexCtx* ctx, int i, const char** key, int64_t shape[4], int* ndim);
+/* Hand over one tensor in the REFERENCE layout (fp32, contiguous, device memory). The pointer must stay
+ * valid until dex_ctx_finalize returns. */
+int  dex_ctx_load_weight(DexCtx* ctx, const char* key, const float* w_dev, const int64_t* shape, int ndim);
+/* Pack all weights into kernel layouts (library-owned HBM); synchronises the stream once. */
+int  dex_ctx_finalize(DexCtx* ctx, dex_stream_t stream);
+int  dex_ctx_set_precision(DexCtx* ctx, int precision /* DexPrecision */);
+
+size_t dex_workspace_bytes(const DexCtx* ctx, int B, int T, int Tr, int Ts, int n_steps);
+int  dex_sample(DexCtx* ctx, const DexSampleArgs* args, dex_stream_t stream);
+int  dex_denoise_once(DexCtx* ctx, const DexDenoiseArgs* args, dex_stream_t stream);
+
+/* EDM rho=7 schedule in fp32 on the host (edm.py:157): writes n_steps+1 values, last one 0. */
+int  dex_edm_sigmas(int n_steps, float* sigmas_host);
+
+/* Debug taps: copy a named intermediate of the LAST dex_denoise_once/dex_sample call out of the
+ * workspace (device->device, async on stream).  Names: see dex_tap_name(i).  Layout NHWC fp32. */
+int  dex_num_taps(const DexCtx* ctx);
+const char* dex_tap_name(const DexCtx* ctx, int i);
+int  dex_tap_info(const DexCtx* ctx, const char* name, int64_t shape[4], int* ndim);
+int  dex_tap_copy(DexCtx* ctx, const char* name, float* dst_dev, size_t dst_bytes, dex_stream_t stream);
+
+/* Per-kernel timing of the last dex_sample with profiling enabled (HIP events on the launch stream). */
+int  dex_profile_enable(DexCtx* ctx, int on);
+int  dex_profile_num(const DexCtx* ctx);
+int  dex_profile_get(const DexCtx* ctx, int i, const char** name, int* calls, double* total_ms,
+                     double* flops, double* bytes);
+
+/* STFT/mel front-end (audio/tools.py:8-15): wav [L] fp32 in [-1,1] (clipped here) -> mel [80,frames],
+ * energy [frames]; frames = L/256 + 1.  n_fft=1024, hop=256, 80 mels, 22050 Hz, fmin 0, fmax 8000. */
+int  dex_mel_frames(int n_samples);
+int  dex_mel_from_wav(DexCtx* ctx, const float* wav_dev, int n_samples, float* mel_dev, float* energy_dev,
+                      dex_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEX_AMD_H */

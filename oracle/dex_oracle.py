@@ -146,13 +146,17 @@ def dit_patchify(W, cfg, x: Tensor):
     return e.flatten(2).transpose(1, 2), w, hh, ww
 
 
-def dit_forward(W, cfg, x: Tensor, mask_mid: Tensor, t: Tensor) -> Tensor:
+def dit_forward(W, cfg, x: Tensor, mask_mid: Tensor, t: Tensor, taps: Optional[dict] = None) -> Tensor:
     """DiTMask.forward, eval / mask_ratio=0 / use_decoder=False path — dit.py:485-525."""
     td = cfg.dit
     tok, w_orig, hh, ww = dit_patchify(W, cfg, x)
     c = linear(W, "vit.t_embedder.mlp.2", F.silu(linear(W, "vit.t_embedder.mlp.0", sinusoid_dit(t, 256))))
+    if taps is not None:
+        taps["tok_in"] = tok
     for k in range(td.depth):
         tok = dit_block(W, f"vit.blocks.{k}", tok, c, td.num_heads)
+        if taps is not None:
+            taps[f"tok_blk{k}"] = tok
     mod = linear(W, "vit.final_layer.adaLN_modulation.1", F.silu(c))
     shift, scale = mod.chunk(2, dim=1)
     tok = linear(W, "vit.final_layer.linear", modulate(layer_norm_noaffine(tok), shift, scale))
@@ -260,7 +264,7 @@ def denoiser_forward(W, cfg, x: Tensor, mask: Tensor, mu: Tensor, t: Tensor, spk
             taps["tiv"] = h
     if taps is not None:
         taps["dit_in"] = h
-    h = dit_forward(W, cfg, h, mm, t)
+    h = dit_forward(W, cfg, h, mm, t, taps)
     if taps is not None:
         taps["dit_out"] = h
     for j in range(n_stage - 1):
@@ -273,6 +277,8 @@ def denoiser_forward(W, cfg, x: Tensor, mask: Tensor, mu: Tensor, t: Tensor, spk
             taps[f"up{j}"] = h
         h = F.conv_transpose2d(h * mu_, W[f"ups.{j}.3.conv.weight"], W[f"ups.{j}.3.conv.bias"],
                                stride=2, padding=1)
+    if taps is not None:
+        taps["up_out"] = h
     h = block(W, "final_block", h, m, g)
     out = F.conv2d(h * m, W["final_conv.weight"], W["final_conv.bias"])
     return (out * m).squeeze(1)

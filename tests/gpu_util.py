@@ -1,0 +1,101 @@
+"""Helpers shared by the GPU parity tests and tests/diag_gpu.py: build an engine on cuda:0 with the
+portable synthetic weights, run the CPU oracle on the same inputs, compare outputs and stage taps."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from dex_tts_amd import config as C, synth  # noqa: E402
+from oracle import dex_oracle as O  # noqa: E402
+
+_ENG = {}
+
+
+def engine_for(name):
+    """One engine (HIP context + packed synthetic weights) per preset, cached for the session."""
+    from dex_tts_amd.engine import ScoreNetEngine
+    if name not in _ENG:
+        cfg = C.PRESETS[name]()
+        eng = ScoreNetEngine(cfg, torch.device("cuda", 0))
+        w = synth.make_weights(C.param_shapes(cfg))
+        eng.load_weights({k: torch.from_numpy(v) for k, v in w.items()})
+        _ENG[name] = (cfg, eng, w)
+    return _ENG[name]
+
+
+def make_case(cfg, B, T, lengths=None, Tr=40, Ts=40, sty_lengths=None, seed=1234):
+    mu, mask, z, lengths = synth.make_inputs(B, T, lengths, seed=seed)
+    case = {"mu": mu, "mask": mask, "z": z, "eps": synth.normalish("eps", (B, 80, T), seed + 5)}
+    if cfg.variant == "dex":
+        ref, rl, sty, sl = synth.make_dex_style(B, Tr, Ts, cfg.mid_dim, sty_lengths=sty_lengths)
+        case.update(ref=np.stack(ref), ref_lengths=rl, sty=sty, sty_lengths=sl)
+    if cfg.n_spks > 1:
+        case["spk"] = synth.normalish("spk", (B, cfg.spk_emb_dim), 9)
+    return case
+
+
+def oracle_kwargs(case, dtype=torch.float32):
+    kw = {}
+    if "ref" in case:
+        kw["ref"] = [torch.from_numpy(r).to(dtype) for r in case["ref"]]
+        kw["sty"] = torch.from_numpy(case["sty"]).to(dtype)
+        kw["sty_lengths"] = torch.from_numpy(np.asarray(case["sty_lengths"]))
+    if "spk" in case:
+        kw["spk"] = torch.from_numpy(case["spk"]).to(dtype)
+    return kw
+
+
+def engine_kwargs(case):
+    kw = {}
+    if "ref" in case:
+        kw["ref"] = [torch.from_numpy(r) for r in case["ref"]]
+        kw["sty"] = torch.from_numpy(case["sty"])
+        kw["sty_lengths"] = torch.from_numpy(np.asarray(case["sty_lengths"]))
+    if "spk" in case:
+        kw["spk"] = torch.from_numpy(case["spk"])
+    return kw
+
+
+def nhwc_rows(t: torch.Tensor) -> np.ndarray:
+    if t.dim() == 4:
+        return t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).numpy()
+    return t.reshape(-1, t.shape[-1]).numpy()
+
+
+def run_precond(name, case, sigma, dtype=torch.float32, with_taps=True):
+    """Returns (gpu_out, oracle_out, {tap: (max_abs_err, max_abs_ref)})."""
+    cfg, eng, w = engine_for(name)
+    W = O.as_torch(w, dtype)
+    mu, mask, eps = (torch.from_numpy(case[k]) for k in ("mu", "mask", "eps"))
+    x = mu + float(sigma) * eps
+    got = eng.denoise_once(x, sigma, mask, mu, **engine_kwargs(case))
+    gtaps = eng.taps() if with_taps else {}
+    got = got.cpu().numpy()
+    taps = {} if with_taps else None
+    ref = O.edm_precond(W, cfg, x.to(dtype), torch.tensor(float(sigma), dtype=dtype), mask.to(dtype), mu.to(dtype),
+                        taps=taps, **oracle_kwargs(case, dtype)).to(torch.float32).numpy()
+    terr = {}
+    if with_taps:
+        for k, v in gtaps.items():
+            if k in taps:
+                r = nhwc_rows(taps[k].to(torch.float32))
+                g = v.cpu().numpy()
+                if r.shape != g.shape:
+                    terr[k] = (float("inf"), float(np.abs(r).max()))
+                else:
+                    terr[k] = (float(np.abs(g - r).max()), float(np.abs(r).max()))
+    return got, ref, terr
+
+
+def run_sampler(name, case, n_steps, use_graph=False):
+    cfg, eng, w = engine_for(name)
+    W = O.as_torch(w, torch.float32)
+    mu, mask, z = (torch.from_numpy(case[k]) for k in ("mu", "mask", "z"))
+    got = eng.sample(z, mask, mu, n_steps, use_graph=use_graph, **engine_kwargs(case)).cpu().numpy()
+    ref = O.diffusion_infer(W, cfg, mask, mu, n_steps, z, **oracle_kwargs(case)).numpy()
+    return got, ref

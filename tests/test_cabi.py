@@ -1,0 +1,81 @@
+"""CPU: the C-ABI shared library loads, exports every symbol include/dex_amd.h declares, and its
+host-side logic (parameter inventory, workspace plan, sigma schedule, argument validation) is sane.
+No compute entry point is called without a GPU."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from dex_tts_amd import _lib, config as Cfg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(_lib.LIB_PATH):
+        from dex_tts_amd import build
+        build.build(verbose=False)
+    return _lib.load()
+
+
+def test_header_symbols_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "dex_amd.h")).read()
+    declared = set(re.findall(r"\b(dex_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    bound = {n for n, _, _ in _lib.SYMBOLS}
+    assert declared == bound, (declared ^ bound)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b"gfx950" in lib.dex_version()
+
+
+@pytest.mark.parametrize("preset", ["gedex_lj", "gedex_vctk", "dex_vctk"])
+def test_inventory_matches_reference_state_dict(lib, preset):
+    cfg = Cfg.PRESETS[preset]()
+    cc = _lib.make_config(cfg)
+    h = C.c_void_p()
+    assert lib.dex_ctx_create(C.byref(cc), C.byref(h)) == 0, lib.dex_last_error(h)
+    got = {}
+    for i in range(lib.dex_ctx_num_weights(h)):
+        key = C.c_char_p(); shp = (C.c_int64 * 4)(); nd = C.c_int()
+        assert lib.dex_ctx_weight_info(h, i, C.byref(key), shp, C.byref(nd)) == 0
+        got[key.value.decode()] = tuple(shp[k] for k in range(nd.value))
+    want = {k: tuple(v) for k, v in Cfg.param_shapes(cfg).items()}      # itself pinned to the reference manifests
+    assert got == want
+    ws = lib.dex_workspace_bytes(h, 1, 512, 348, 348, 50)
+    assert 50e6 < ws < 2e9
+    assert lib.dex_workspace_bytes(h, 32, 512, 348, 348, 50) > 20 * ws // 2
+    lib.dex_ctx_destroy(h)
+
+
+def test_bad_config_rejected(lib):
+    cfg = Cfg.gedex_lj()
+    cfg.dit.num_heads = 4                  # head_dim 64: unsupported by the attention kernel
+    cc = _lib.make_config(cfg)
+    h = C.c_void_p()
+    assert lib.dex_ctx_create(C.byref(cc), C.byref(h)) == -1
+    assert b"head_dim" in lib.dex_last_error(h)
+    lib.dex_ctx_destroy(h)
+
+
+def test_host_sigma_schedule(lib, golden_dir):
+    g = dict(np.load(os.path.join(golden_dir, "sigma_tables.npz")))
+    for k, v in g.items():
+        n = int(k[1:])
+        out = (C.c_float * (n + 1))()
+        assert lib.dex_edm_sigmas(n, out) == 0
+        s = np.frombuffer(out, dtype=np.float32)
+        assert s[-1] == 0.0
+        np.testing.assert_allclose(s[:-1], v, rtol=3e-7)
+    assert lib.dex_edm_sigmas(1, (C.c_float * 2)()) == -1
+
+
+def test_product_path_has_no_oracle_or_cpu_fallback():
+    pkg = os.path.join(ROOT, "dex_tts_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "import oracle" not in src and "from oracle" not in src, fn
