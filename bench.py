@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""bench.py — mel-frames/s of the reverse-diffusion hot path (Diffusion.forward(infer=True) == EDM Euler
+sampler) on MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE full sampler call (n_timesteps Euler steps) over one batch of synthetic utterances.
+Default workload = BASELINE.json configs[1]: GeDEX-LJ, B=1, T=512 mel frames, n_timesteps=50.
+For N>1 every rank samples its own shard of independent utterances (weak scaling, no data-path collective)
+and the finished mels are all-gathered over RCCL inside the timed region (the path's one exchange step).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from dex_tts_amd import config as C, synth  # noqa: E402
+
+WORKLOADS = {
+    # name: (preset, B, T, n_timesteps, Tr/Ts)
+    "gedex_b1": ("gedex_lj", 1, 512, 50, 0),
+    "gedex_b1_t800": ("gedex_lj", 1, 800, 50, 0),
+    "gedex_b32": ("gedex_lj", 32, 512, 50, 0),
+    "dex_b1": ("dex_vctk", 1, 512, 50, 348),
+    "dex_b32": ("dex_vctk", 32, 256, 50, 348),
+    "gedex_long": ("gedex_lj", 1, 4000, 50, 0),
+}
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0
+
+
+def make_inputs(cfg, B, T, TrTs, device, rank):
+    lengths = None if B == 1 else [int(T * (0.6 + 0.4 * ((7 * i + 3 * rank) % 11) / 10.0)) for i in range(B)]
+    mu, mask, z, _ = synth.make_inputs(B, T, lengths, seed=1234 + rank)
+    kw = {}
+    if cfg.variant == "dex":
+        ref, rl, sty, sl = synth.make_dex_style(B, TrTs, TrTs, cfg.mid_dim)
+        kw = dict(ref=[torch.from_numpy(r).to(device) for r in ref], sty=torch.from_numpy(sty).to(device),
+                  sty_lengths=torch.from_numpy(sl).to(device))
+    t = lambda a: torch.from_numpy(a).to(device)
+    valid = int(mask.sum())
+    return t(mu), t(mask), t(z), kw, valid
+
+
+def cpu_baseline(cfg, weights, B, T, n_timesteps, TrTs):
+    """Oracle (CPU restatement of the reference, torch ops on the host cores) on a bounded sample:
+    a 3-step sampler of the same workload, scaled to n_timesteps."""
+    from oracle import dex_oracle as O
+    W = O.as_torch(weights)
+    mu, mask, z, _ = synth.make_inputs(B, T, None, seed=1234)
+    kw = {}
+    if cfg.variant == "dex":
+        ref, rl, sty, sl = synth.make_dex_style(B, TrTs, TrTs, cfg.mid_dim)
+        kw = dict(ref=[torch.from_numpy(r) for r in ref], sty=torch.from_numpy(sty), sty_lengths=torch.from_numpy(sl))
+    mu, mask, z = map(torch.from_numpy, (mu, mask, z))
+    nsub = 3
+    with torch.no_grad():
+        O.diffusion_infer(W, cfg, mask, mu, 2, z, **kw)            # warm-up (oneDNN primitive caches)
+        t0 = time.perf_counter()
+        O.diffusion_infer(W, cfg, mask, mu, nsub, z, **kw)
+        dt = time.perf_counter() - t0
+    per_step = dt / nsub
+    frames_s = B * T / (per_step * n_timesteps)
+    return {"value": round(frames_s, 2), "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{nsub} of {n_timesteps} Euler steps of the same workload (B={B}, T={T}), scaled x{n_timesteps}/{nsub}; "
+                      f"{per_step * 1e3:.1f} ms/Euler-step on {torch.get_num_threads()} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="gedex_b1", choices=sorted(WORKLOADS))
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    preset, B, T, n_steps, TrTs = WORKLOADS[args.workload]
+    cfg = C.PRESETS[preset]()
+    from dex_tts_amd.engine import ScoreNetEngine
+    weights = synth.make_weights(C.param_shapes(cfg))
+    eng = ScoreNetEngine(cfg, device)
+    eng.load_weights({k: torch.from_numpy(v) for k, v in weights.items()})
+    eng.set_precision(args.precision)
+    mu, mask, z, kw, valid = make_inputs(cfg, B, T, TrTs, device, rank)
+    use_graph = not args.no_graph
+    stream = torch.cuda.Stream(device)
+    gathered = torch.empty(world * B, 80, T, device=device) if world > 1 else None
+
+    def one_call():
+        out = eng.sample(z, mask, mu, n_steps, use_graph=use_graph, **kw)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out)
+        return out
+
+    with torch.cuda.stream(stream):
+        for _ in range(args.warmup):
+            one_call()
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = one_call()
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        v = torch.tensor([float(valid)], device=device, dtype=torch.float64)
+        dist.all_reduce(v)
+        valid_total = int(v.item())
+    else:
+        valid_total = valid
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        dtype = "f32" if args.precision == "fp32" else "bf16"
+        ms_per_step = dt / args.steps * 1e3
+        frames_s = valid_total * args.steps / dt
+        audio_s = valid_total * 256 / 22050.0
+        res = {
+            "metric": "mel-frames/s at n_timesteps=50, 80-ch mel (sampler only); RTF",
+            "value": round(frames_s, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": dtype, "data": "synthetic (portable random weights with zero-inits overridden; mel-like mu; mask from lengths)",
+            "config": {"workload": f"{args.workload}: {preset} B={B}/GPU T={T} n_timesteps={n_steps}"
+                                   + (f" Tr=Ts={TrTs}" if TrTs else "") + " (BASELINE.json configs[1])" * (args.workload == "gedex_b1"),
+                       "global_batch": B * world, "frames": T, "n_timesteps": n_steps, "hipgraph": use_graph,
+                       "parallelism": f"{world} independent replicas, utterance-sharded; RCCL all-gather of finished mels"},
+            "rtf": round((dt / args.steps) / audio_s, 6),
+            "ms_per_euler_step": round(ms_per_step / n_steps, 4),
+        }
+        if world == 1 and not args.no_profile:
+            # per-kernel HIP-event timing on the launch stream (eager launches, same work)
+            eng.profile(True)
+            with torch.cuda.stream(stream):
+                eng.sample(z, mask, mu, n_steps, use_graph=False, **kw)
+                torch.cuda.synchronize(device)
+            rows = sorted(eng.profile_rows(), key=lambda r: -r["ms"])
+            eng.profile(False)
+            tot = sum(r["ms"] for r in rows)
+            kern = []
+            for r in rows[:8]:
+                tf = r["flops"] / (r["ms"] * 1e-3) / 1e12
+                gb = r["bytes"] / (r["ms"] * 1e-3) / 1e9
+                kern.append({"kernel": r["name"], "calls": r["calls"], "avg_us": round(r["ms"] / r["calls"] * 1e3, 2),
+                             "share": round(r["ms"] / tot, 3), "TFLOP/s": round(tf, 2), "GB/s": round(gb, 1)})
+            dom = rows[0]
+            mfma_bound = dom["name"] in ("conv3x3", "dit_attention", "tv_attention", "pos_conv", "linattn_qkv", "downsample",
+                                         "upsample_convT", "dit_qkv", "dit_fc1_gelu", "dit_fc2", "dit_proj", "linattn_out")
+            if mfma_bound:
+                ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+                res["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dtype],
+                                   "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[dtype], 4), "traffic": None,
+                                   "avg_launch_us": round(dom["ms"] / dom["calls"] * 1e3, 2), "launches": dom["calls"]}
+            else:
+                ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+                res["roofline"] = {"kernel": dom["name"], "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
+                                   "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+                                   "avg_launch_us": round(dom["ms"] / dom["calls"] * 1e3, 2), "launches": dom["calls"]}
+            att = [r for r in rows if r["name"] == "dit_attention"]
+            if att:
+                a = att[0]
+                ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
+                res["roofline_attention"] = {"kernel": "dit_attention", "bound": "mfma", "achieved": round(ach, 2),
+                                             "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[dtype], 4),
+                                             "avg_launch_us": round(a["ms"] / a["calls"] * 1e3, 2)}
+            res["kernels"] = kern
+            res["eager_event_total_ms"] = round(tot, 2)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, weights, B, T, n_steps, TrTs)
+            res["gpu_over_cpu"] = round(frames_s / res["cpu_baseline"]["value"], 1)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -980,12 +980,15 @@ int dex_sample(DexCtx* x, const DexSampleArgs* a, dex_stream_t stream) {
         if (!x->graph_exec || key != x->graph_key) {
             if (x->graph_exec) { hipGraphExecDestroy(x->graph_exec); x->graph_exec = nullptr; }
             hipGraph_t graph = nullptr;
+            if (st == nullptr) return x->fail(DEX_ERR_ARG, "use_graph needs a non-default stream (the legacy null stream cannot be captured)");
             HIPCHK(x, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             R.step(nullptr, P.xbuf);
             launch_step_inc(P.step, st);
-            HIPCHK(x, hipStreamEndCapture(st, &graph));
-            HIPCHK(x, hipGraphInstantiate(&x->graph_exec, graph, nullptr, nullptr, 0));
+            hipError_t ec = hipStreamEndCapture(st, &graph);          // always leave capture mode
+            if (ec != hipSuccess || !graph) return x->fail(DEX_ERR_HIP, "stream capture failed: %s", hipGetErrorString(ec));
+            ec = hipGraphInstantiate(&x->graph_exec, graph, nullptr, nullptr, 0);
             hipGraphDestroy(graph);
+            if (ec != hipSuccess) { x->graph_exec = nullptr; return x->fail(DEX_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ec)); }
             x->graph_key = key;
         }
         for (int i = 0; i < a->n_steps; ++i) HIPCHK(x, hipGraphLaunch(x->graph_exec, st));

@@ -35,6 +35,7 @@ class ScoreNetEngine:
         self._check(rc)
         self._ws: Optional[torch.Tensor] = None
         self._keep: list = []
+        self._side = None
         self.loaded_version = None
 
     # ---------------------------------------------------------------------------------------
@@ -128,7 +129,18 @@ class ScoreNetEngine:
             a = _lib.DexSampleArgs()
             keep = self._fill_args(a, mu, mask, sig, out, n_steps, spk, ref, sty, sty_lengths, use_graph)
             a.z_dev = z.data_ptr()
-            self._check(self.lib.dex_sample(self.h, C.byref(a), self._stream()))
+            cur = torch.cuda.current_stream(self.device)
+            if use_graph and cur.cuda_stream == 0:
+                # the legacy default stream cannot be captured: replay on a private stream, ordered
+                # after / before the caller's stream
+                if self._side is None:
+                    self._side = torch.cuda.Stream(self.device)
+                self._side.wait_stream(cur)
+                with torch.cuda.stream(self._side):
+                    self._check(self.lib.dex_sample(self.h, C.byref(a), self._stream()))
+                cur.wait_stream(self._side)
+            else:
+                self._check(self.lib.dex_sample(self.h, C.byref(a), self._stream()))
             self._keep = keep + [z]           # keep inputs alive until the stream work is enqueued & consumed
             return out
 

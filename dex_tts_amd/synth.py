@@ -50,7 +50,8 @@ def normalish(key: str, shape, seed: int = 0) -> np.ndarray:
 def make_weights(shapes: dict, seed: int = 0) -> dict:
     """name -> float32 ndarray for every entry of ``config.param_shapes``.
 
-    >=2-D tensors: U(-a, a) with a = sqrt(3 / fan_in) (unit-gain); GroupNorm scales: 1 + 0.1 u;
+    >=2-D tensors: U(-a, a) with a = gain*sqrt(3 / fan_in) (gain 1, or 0.35 on the paths no norm follows);
+    GroupNorm scales: 1 + 0.1 u;
     Rezero gates ``*.fn.g``: 0.4 + 0.1 u; every other 1-D tensor (biases): 0.1 u;
     ``vit.freq_new_pos_embed``: 0.1 u.
     """
@@ -65,7 +66,10 @@ def make_weights(shapes: dict, seed: int = 0) -> dict:
             w = symmetric(name, shape, 0.1, seed)
         elif len(shape) >= 2:
             fan_in = int(np.prod(shape[1:]))
-            w = symmetric(name, shape, float(np.sqrt(3.0 / fan_in)), seed)
+            gain = 1.0
+            if name.endswith("to_qkv.weight") or name.endswith("res_conv.weight") or ".3.conv.weight" in name:
+                gain = 0.35        # keeps q/k/v and the un-normalised shortcut / resampling paths O(1)
+            w = symmetric(name, shape, gain * float(np.sqrt(3.0 / fan_in)), seed)
         else:
             w = symmetric(name, shape, 0.1, seed)
         out[name] = np.ascontiguousarray(w, dtype=np.float32)
