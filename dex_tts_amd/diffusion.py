@@ -159,3 +159,22 @@ def from_config(cfg: ScoreNetConfig) -> Diffusion:
     dit = {k: getattr(t, k) for k in DiTConfig.__dataclass_fields__}
     return Diffusion(cfg.n_feats, cfg.dim, dit, dim_mults=cfg.dim_mults, n_spks=cfg.n_spks,
                      spk_emb_dim=cfg.spk_emb_dim, pe_scale=cfg.pe_scale, variant=cfg.variant)
+
+
+class GeDEXDiffusion(Diffusion):
+    """Exact constructor surface of GeDEX-TTS/model/diffusion.py:210."""
+
+    def __init__(self, n_feats, dim, dit_cfg, loss_type="base", precond="edm", model_type="dit", dim_mults=(1, 2),
+                 n_spks=1, spk_emb_dim=64, pe_scale=1000):
+        super().__init__(n_feats, dim, dit_cfg, loss_type, precond, model_type, dim_mults, n_spks, spk_emb_dim,
+                         pe_scale, variant="gedex")
+
+
+class DEXDiffusion(Diffusion):
+    """Exact constructor surface of DEX-TTS/model/diffusion.py:239 (its default model_type is 'vit', which
+    builds no bottleneck at all in the reference; every shipped config passes 'dit')."""
+
+    def __init__(self, n_feats, dim, dit_cfg, loss_type="base", precond="edm", model_type="dit", dim_mults=(1, 2),
+                 n_spks=1, spk_emb_dim=64, pe_scale=1000):
+        super().__init__(n_feats, dim, dit_cfg, loss_type, precond, model_type, dim_mults, n_spks, spk_emb_dim,
+                         pe_scale, variant="dex")
