@@ -4,6 +4,5 @@
 #include <cstdlib>
 #include "kernels.h"
 namespace dex {
-void launch_igemm_bf16(const IGemmP&, hipStream_t) { fprintf(stderr, "dexamd: bf16 igemm not built\n"); abort(); }
 void launch_attention_bf16(const AttnP&, hipStream_t) { fprintf(stderr, "dexamd: bf16 attention not built\n"); abort(); }
 }  // namespace dex

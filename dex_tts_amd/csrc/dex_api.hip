@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -48,6 +49,7 @@ struct DexCtx {
     std::vector<std::string> keys;
     std::map<std::string, RawW> raw;
     std::vector<void*> owned;                              // hipMalloc'ed packed weights
+    std::map<const float*, const void*> bf16_of;           // fp32 [K][N] pack -> bf16 [N][K] twin
     bool finalized = false;
     int precision = DEX_PREC_FP32;
     // packed weights
@@ -185,6 +187,17 @@ void build_inventory(DexCtx* x) {
     add_key(x, "final_conv.weight", {1, d, 1, 1}); add_key(x, "final_conv.bias", {1});
 }
 
+// fp32 [K][N] -> bf16 [N][K] (round-to-nearest-even)
+__global__ void pack_bf16_nk_kernel(const float* src, unsigned short* dst, int K, int N) {
+    const long total = (long)K * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K), n = (int)(i / K);
+        unsigned u = __float_as_uint(src[(long)k * N + n]);
+        u += 0x7FFFu + ((u >> 16) & 1u);
+        dst[i] = (unsigned short)(u >> 16);
+    }
+}
+
 // ConvTranspose2d(4,2,1) -> four 2x2-tap parity sub-convolutions.
 // dst[par = ph*2+pw][(th*2+tw)*Cin + ci][co] = src[ci][co][kh][kw],  kh = (ph ? 0 : 1) + 2*th, kw likewise.
 __global__ void pack_convt_kernel(const float* src, float* dst, int Cin, int Cout) {
@@ -267,7 +280,6 @@ int dex_ctx_load_weight(DexCtx* x, const char* key, const float* w_dev, const in
 
 int dex_ctx_set_precision(DexCtx* x, int precision) {
     if (!x || (precision != DEX_PREC_FP32 && precision != DEX_PREC_BF16)) return DEX_ERR_ARG;
-    if (precision == DEX_PREC_BF16) return x->fail(DEX_ERR_ARG, "bf16 MFMA mode is not built in this version");
     x->precision = precision;
     return DEX_OK;
 }
@@ -286,6 +298,16 @@ struct Packer {
         x->owned.push_back(p);
         return p;
     }
+    // bf16 [N][K] twins of `count` consecutive fp32 [K][N] matrices starting at p
+    void twin(const float* p, int count, int K, int N) {
+        if (!p) return;
+        unsigned short* d = (unsigned short*)alloc(((long)count * K * N + 1) / 2);
+        if (!d) return;
+        for (int c = 0; c < count; ++c) {
+            hipLaunchKernelGGL(pack_bf16_nk_kernel, dim3(256), dim3(256), 0, st, p + (long)c * K * N, d + (long)c * K * N, K, N);
+            x->bf16_of[p + (long)c * K * N] = d + (long)c * K * N;
+        }
+    }
     const RawW& R(const std::string& k) { return x->raw.at(k); }
     const float* raw(const std::string& k) { return R(k).p; }
     // [d0,d1,d2,d3] -> permuted contiguous copy
@@ -298,7 +320,9 @@ struct Packer {
     const float* kn(const std::string& k) {
         const auto& s = R(k).shape;
         const int o = (int)s[0], i = (int)s[1], kh = s.size() > 2 ? (int)s[2] : 1, kw = s.size() > 3 ? (int)s[3] : 1;
-        return perm(k, o, i, kh, kw, 2, 3, 1, 0);
+        const float* f = perm(k, o, i, kh, kw, 2, 3, 1, 0);
+        twin(f, 1, i * kh * kw, o);
+        return f;
     }
     ResW resnet(const std::string& p, int cin, int cout, bool first) {
         ResW r{};
@@ -370,6 +394,7 @@ extern "C" int dex_ctx_finalize(DexCtx* x, dex_stream_t stream) {
         if (!x->raw.at(k).loaded) return x->fail(DEX_ERR_STATE, "weight '%s' was never loaded", k.c_str());
     for (void* p : x->owned) hipFree(p);
     x->owned.clear();
+    x->bf16_of.clear();
     if (x->graph_exec) { hipGraphExecDestroy(x->graph_exec); x->graph_exec = nullptr; x->graph_key.clear(); }
     const DexConfig& c = x->cfg;
     hipStream_t st = (hipStream_t)stream;
@@ -391,7 +416,10 @@ extern "C" int dex_ctx_finalize(DexCtx* x, dex_stream_t stream) {
         x->up_res[j].push_back(P.resnet(p + ".1", ci, ci, false));
         x->up_lin.push_back(P.linattn(p + ".2", ci));
         float* wt = P.alloc(16L * ci * ci);
-        if (wt) hipLaunchKernelGGL(pack_convt_kernel, dim3(256), dim3(256), 0, st, P.raw(p + ".3.conv.weight"), wt, ci, ci);
+        if (wt) {
+            hipLaunchKernelGGL(pack_convt_kernel, dim3(256), dim3(256), 0, st, P.raw(p + ".3.conv.weight"), wt, ci, ci);
+            P.twin(wt, 4, 4 * ci, ci);
+        }
         x->up_us_w.push_back(wt); x->up_us_b.push_back(P.raw(p + ".3.conv.bias"));
     }
     x->fin_w = P.kn("final_block.block.0.weight"); x->fin_b = P.raw("final_block.block.0.bias");
@@ -402,6 +430,7 @@ extern "C" int dex_ctx_finalize(DexCtx* x, dex_stream_t stream) {
     x->pe_db = P.raw("vit.x_embedder.proj.0.bias");
     x->pe_pw = P.kn("vit.x_embedder.proj.2.weight"); x->pe_pb = P.raw("vit.x_embedder.proj.2.bias");
     x->pos_w = P.perm("vit.pos_conv.0.weight", G, hid / G, hid / G, kp * kp, 0, 3, 2, 1);   // [G][tap][ci][n]
+    P.twin(x->pos_w, G, kp * kp * (hid / G), hid / G);
     x->pos_b = P.raw("vit.pos_conv.0.bias");
     x->freq_pos = P.perm("vit.freq_new_pos_embed", 1, hid, grid_h(c), 1, 0, 2, 3, 1);       // [Hf][hid]
     x->blocks.clear();
@@ -495,7 +524,7 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
     if (c.n_spks > 1) { P.spk_tmp = A.f((size_t)B * 4 * c.spk_emb_dim); P.spk_plane = A.f((size_t)B * c.n_feats); }
     P.step = (int*)A.take(256);
     P.n_gn = 4 * c.n_stages + 4 * (c.n_stages - 1) + 1;
-    P.stats_bytes = (long)P.n_gn * B * 8 * 2 * sizeof(double);
+    P.stats_bytes = (long)P.n_gn * B * 8 * GN_SLOTS * 2 * sizeof(double);
     P.stats = (double*)A.take(P.stats_bytes);
     P.xbuf = A.f((size_t)B * 80 * d.T);
     P.cat.assign(c.n_stages - 1, nullptr);
@@ -565,7 +594,7 @@ struct Runner {
             x->prof.push_back(pr);
         } else f();
     }
-    double* next_stats() { return P.stats + (size_t)(gn_idx++) * P.d.B * 8 * 2; }
+    double* next_stats() { return P.stats + (size_t)(gn_idx++) * P.d.B * 8 * GN_SLOTS * 2; }
     void tap(const char* name, const float* p, long rows, int C, int ld) {
         if (!debug) return;
         DexCtx::Tap t; t.name = name; t.p = p; t.shape = {rows, C, ld};
@@ -580,7 +609,8 @@ struct Runner {
         g.Hi = H; g.Wi = W; g.Cin = Cin;
         g.KH = 1; g.KW = 1; g.sh = 1; g.sw = 1; g.off_h = 0; g.off_w = 0; g.step_h = 1; g.step_w = 1;
         g.Ho = H; g.Wo = W;
-        g.W = Wt; g.w_bstride = 0; g.w_gstride = 0; g.Wbf = nullptr;
+        g.W = Wt; g.w_bstride = 0; g.w_gstride = 0;
+        { auto it = x->bf16_of.find(Wt); g.Wbf = (it != x->bf16_of.end()) ? it->second : nullptr; }
         g.N = N; g.K = Cin; g.ksplit = 1; g.groups = 1;
         g.bias = bias; g.bias_bstride = 0;
         g.C = C; g.ldc = ldc; g.c_bstride = (long)H * W * ldc; g.c_sstride = 0; g.c_coff = ccoff;
@@ -597,10 +627,12 @@ struct Runner {
         const double by = 4.0 * (M * g.Cin * g.groups + M * g.N * g.groups * g.ksplit + (double)g.K * g.N * g.groups);
         run(name, fl, by, [&] { launch_igemm(g, x->precision, st); });
     }
-    void conv3x3(const char* name, const TD& X, int H, int W, int mask_ws, bool inmask, const float* Wt, const float* bias, int Cout, float* out) {
+    void conv3x3(const char* name, const TD& X, int H, int W, int mask_ws, bool inmask, const float* Wt, const float* bias, int Cout, float* out,
+                 double* gn = nullptr) {
         IGemmP g = base_gemm(X.p, X.ld, X.coff, H, W, X.C, Wt, Cout, bias, out, Cout, 0);
         g.KH = 3; g.KW = 3; g.off_h = -1; g.off_w = -1; g.K = 9 * X.C;
         if (inmask) { g.inmask = mask; g.inmask_ws = mask_ws; }
+        g.gn_stats = gn; g.gn_groups = 8; g.gn_cpg = Cout / 8;
         gemm(name, g);
     }
     void gn_stats(const float* h, int C, long npix, double* stats) {
@@ -622,6 +654,7 @@ struct Runner {
     void resblock(const ResW& w, const StageBuf& s, const TD& X, const float* tadd, float* out, bool first_layer) {
         const long npix = s.npix;
         const float* resptr; int ldres; long resb; bool under = false;
+        double* st1 = nullptr;
         if (first_layer) {
             FirstConvP f{};
             f.mu = mu; f.x = xcur; f.spk = P.spk_plane; f.mask = mask; f.B = P.d.B; f.H = s.H; f.T = s.W; f.planes = w.cin; f.C = w.cout;
@@ -630,7 +663,8 @@ struct Runner {
             run("first_conv", 2.0 * npix * P.d.B * w.cout * (w.cin * 10), 4.0 * npix * P.d.B * (2 * w.cout + w.cin), [&] { launch_first_conv(f, st); });
             resptr = s.rbuf; ldres = w.cout; resb = npix * w.cout;
         } else {
-            conv3x3("conv3x3", X, s.H, s.W, s.mask_ws, true, w.w1, w.b1, w.cout, s.h1);
+            st1 = next_stats();
+            conv3x3("conv3x3", X, s.H, s.W, s.mask_ws, true, w.w1, w.b1, w.cout, s.h1, st1);
             if (w.wr) {
                 IGemmP g = base_gemm(X.p, X.ld, X.coff, s.H, s.W, X.C, w.wr, w.cout, w.br, s.rbuf, w.cout, 0);
                 g.inmask = mask; g.inmask_ws = s.mask_ws;
@@ -640,13 +674,11 @@ struct Runner {
                 resptr = X.p + X.coff; ldres = X.ld; resb = npix * X.ld; under = true;
             }
         }
-        double* st1 = next_stats();
-        gn_stats(s.h1, w.cout, npix, st1);
+        if (!st1) { st1 = next_stats(); gn_stats(s.h1, w.cout, npix, st1); }
         gn_apply(s.h1, w.cout, npix, s.W, s.mask_ws, st1, w.g1, w.be1, tadd, nullptr, 0, 0, false, s.a1);
         TD A1{s.a1, w.cout, 0, w.cout};
-        conv3x3("conv3x3", A1, s.H, s.W, s.mask_ws, false, w.w2, w.b2, w.cout, s.h2);
         double* st2 = next_stats();
-        gn_stats(s.h2, w.cout, npix, st2);
+        conv3x3("conv3x3", A1, s.H, s.W, s.mask_ws, false, w.w2, w.b2, w.cout, s.h2, st2);
         gn_apply(s.h2, w.cout, npix, s.W, s.mask_ws, st2, w.g2, w.be2, nullptr, resptr, ldres, resb, under, out);
     }
 
@@ -700,7 +732,7 @@ struct Runner {
             a.K = P.qkv + hid; a.ldk = 3 * hid; a.kb = a.qb; a.V = P.qkv + 2 * hid; a.ldv = 3 * hid; a.vb = a.qb;
             a.O = P.ao; a.ldo = hid; a.ob = (long)N * hid; a.Nq = N; a.Nk = N; a.kv_len = nullptr; a.kv_len_add = 0;
             a.heads = c.dit_heads; a.scale = scale; a.B = B;
-            run("dit_attention", 4.0 * B * (double)N * N * hid, 4.0 * 4 * B * N * hid, [&] { launch_attention(a, x->precision, st); });
+            run("dit_attention", 4.0 * B * (double)N * N * hid, 4.0 * 4 * B * N * hid, [&] { launch_attention(a, DEX_PREC_FP32, st); });
             IGemmP pr = base_gemm(P.ao, hid, 0, 1, N, hid, w.wproj, hid, w.bproj, P.tok, hid, 0);
             pr.gate = ada + 2 * hid; pr.gate_nstride = 1; pr.gate_step_stride = 6L * hid;
             pr.res = P.tok; pr.ldres = hid; pr.res_bstride = (long)N * hid;
@@ -751,7 +783,7 @@ struct Runner {
         a.V = P.tv_V; a.ldv = mid; a.vb = a.kb; a.O = P.tv_ao; a.ldo = mid; a.ob = npix * mid;
         a.Nq = (int)npix; a.Nk = P.d.Ts + 1; a.kv_len = args->sty_lengths_dev; a.kv_len_add = 1; a.heads = 1;
         a.scale = 1.0f / sqrtf((float)mid); a.B = B;
-        run("tv_attention", 4.0 * B * (double)npix * (P.d.Ts + 1) * mid, 4.0 * B * (2 * npix + 2 * (P.d.Ts + 1)) * mid, [&] { launch_attention(a, x->precision, st); });
+        run("tv_attention", 4.0 * B * (double)npix * (P.d.Ts + 1) * mid, 4.0 * B * (2 * npix + 2 * (P.d.Ts + 1)) * mid, [&] { launch_attention(a, DEX_PREC_FP32, st); });
         IGemmP o = base_gemm(P.tv_ao, mid, 0, P.Hm, P.Wm, mid, x->tv_wl, mid, nullptr, P.tv_out, mid, 0);
         o.res = X.p; o.ldres = X.ld; o.res_coff = X.coff; o.res_bstride = npix * X.ld;
         o.outmask = mask; o.outmask_ws = mask_ws;
@@ -828,9 +860,8 @@ struct Runner {
         }
         tap("up_out", P.up_out, (long)B * 80 * P.d.T, c.dim, c.dim);
         TD U{P.up_out, c.dim, 0, c.dim};
-        conv3x3("conv3x3", U, 80, P.d.T, 1, true, x->fin_w, x->fin_b, c.dim, P.hF);
         double* stf = next_stats();
-        gn_stats(P.hF, c.dim, 80L * P.d.T, stf);
+        conv3x3("conv3x3", U, 80, P.d.T, 1, true, x->fin_w, x->fin_b, c.dim, P.hF, stf);
         FinalP f{};
         f.X = P.hF; f.xb = 80L * P.d.T * c.dim; f.npix = 80 * P.d.T; f.W = P.d.T; f.C = c.dim; f.groups = 8; f.stats = stf;
         f.gamma = x->fin_g; f.beta = x->fin_be; f.mask = mask; f.mask_bstride = P.d.T; f.wfc = x->fconv_w; f.bfc = x->fconv_b;

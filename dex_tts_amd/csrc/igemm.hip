@@ -10,12 +10,10 @@
 // 256 threads = 4 waves; each wave owns MT 32x32 accumulator tiles.  Register-staged prefetch of the next
 // K tile overlaps the global gather with the MFMA chain.
 #include "kernels.h"
+#include "igemm_epilogue.h"
 
 namespace dex {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 template <int BM, int BN>
 __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
@@ -115,48 +113,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
         }
     }
 
-    // ---- epilogue: bias -> act -> gate -> (+res) -> mask -> store --------------------------------
-    const int n = n0 + wn * 32 + i;              // column within the group
-    const int ng = g * p.N + n;                  // global output channel
-    const int step = p.step ? *p.step : 0;
-    const float bias = p.bias ? p.bias[(long)b * p.bias_bstride + ng] : 0.f;
-    const float gate = p.gate ? p.gate[(long)step * p.gate_step_stride + (long)ng * p.gate_nstride] : 1.f;
-    const float* omask = p.outmask ? p.outmask + (long)b * p.mask_bstride : nullptr;
-    float* Cb = p.C + (long)b * p.c_bstride + (long)s * p.c_sstride + p.c_coff;
-    const float* Rb = p.res ? p.res + (long)b * p.res_bstride + p.res_coff : nullptr;
-    int up_c = 0, up_p1 = 0, up_p2 = 0;
-    if (p.unpatch_s > 0) {
-        const int pp = ng / p.unpatch_C;
-        up_c = ng - pp * p.unpatch_C;
-        up_p1 = pp / p.unpatch_s;
-        up_p2 = pp - up_p1 * p.unpatch_s;
-    }
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wm * (MT * 32) + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const int m = m0 + row;
-            if (m >= M) continue;
-            const int ho = m / p.Wo, wo = m - ho * p.Wo;
-            float v = acc[t][r] + bias;
-            if (p.act == 1) v = gelu_erf(v);
-            v *= gate;
-            if (p.unpatch_s > 0) {
-                const int oh = ho * p.unpatch_s + up_p1, ow = wo * p.unpatch_s + up_p2;
-                if (oh < p.OHf && ow < p.OWf) {
-                    if (omask) v *= omask[ow * p.outmask_ws];
-                    Cb[((long)oh * p.OWf + ow) * p.ldc + up_c] = v;
-                }
-            } else {
-                const int oh = ho * p.osh + p.oh0, ow = wo * p.osw + p.ow0;
-                const long opix = (long)oh * p.OWf + ow;
-                if (Rb) v += Rb[opix * p.ldres + ng];
-                if (omask) v *= omask[ow * p.outmask_ws];
-                Cb[opix * p.ldc + ng] = v;
-            }
-        }
-    }
+    igemm_epilogue<MT>(p, acc, m0, n0, wm * (MT * 32), wn * 32, lane, b, g, s, M);
 }
 
 void launch_igemm_bf16(const IGemmP& p, hipStream_t st);   // igemm_bf16.hip

@@ -1,0 +1,141 @@
+// igemm_bf16.hip — implicit-GEMM convolution / linear with bf16 operands on v_mfma_f32_32x32x16_bf16
+// (fp32 accumulate, fp32 activations in HBM converted to bf16 while staging; weights pre-packed bf16 [N][K]).
+// Same gather semantics and the same epilogue as igemm.hip.  LDS tiles are row-major [rows][BK+8] bf16:
+// the 16-byte pad makes every ds_read_b128 / ds_write_b128 lane group hit 64 distinct banks.
+#include "kernels.h"
+#include "igemm_epilogue.h"
+
+namespace dex {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+    // round-to-nearest-even, two fp32 -> one dword of 2 x bf16
+    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
+    a += 0x7FFFu + ((a >> 16) & 1u);
+    b += 0x7FFFu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xFFFF0000u);
+}
+
+template <int BM, int BN, int BK>
+__global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemmP p) {
+    constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (WM * 32);
+    constexpr int TPR = BK / 8;                 // threads per tile row (8 elements each)
+    constexpr int RPP = 256 / TPR;              // rows per pass
+    constexpr int AP = BM / RPP;                // A passes
+    constexpr int BP = (BN + RPP - 1) / RPP;    // B passes
+    constexpr int LDS_LD = BK + 8;              // bf16 elements per LDS row
+    static_assert(MT >= 1 && AP >= 1, "tile");
+    __shared__ __attribute__((aligned(16))) u16 As[BM * LDS_LD];
+    __shared__ __attribute__((aligned(16))) u16 Bs[BN * LDS_LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int z = blockIdx.z;
+    const int s = z % p.ksplit;
+    const int g = (z / p.ksplit) % p.groups;
+    const int b = z / (p.ksplit * p.groups);
+    const int M = p.Ho * p.Wo;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int Kper = p.K / p.ksplit, kbeg = s * Kper, nkt = Kper / BK;
+
+    const float* Ab = p.A + (long)b * p.a_bstride + p.a_coff + g * p.Cin;
+    const float* mrow = p.inmask ? p.inmask + (long)b * p.mask_bstride : nullptr;
+    const int trow = tid / TPR, tk8 = (tid % TPR) * 8;
+    int bh[AP], bw[AP];
+    bool mv[AP];
+#pragma unroll
+    for (int j = 0; j < AP; ++j) {
+        const int m = m0 + trow + RPP * j;
+        mv[j] = m < M;
+        const int ho = m / p.Wo, wo = m - ho * p.Wo;
+        bh[j] = ho * p.sh + p.off_h;
+        bw[j] = wo * p.sw + p.off_w;
+    }
+    // bf16 weights [N][K] (per group / per batch strides are in elements of the fp32 [K][N] pack: same count)
+    const u16* Wb = reinterpret_cast<const u16*>(p.Wbf) + (long)b * p.w_bstride + (long)g * p.w_gstride;
+
+    uint4 ra[AP];
+    uint4 rb0 = make_uint4(0, 0, 0, 0), rb1 = rb0;
+    static_assert(BP <= 2, "B passes");
+    f32x16 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int kt = -1; kt < nkt; ++kt) {
+        if (kt >= 0) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < AP; ++j)
+                *reinterpret_cast<uint4*>(As + (trow + RPP * j) * LDS_LD + tk8) = ra[j];
+            if (BN >= RPP || trow < BN) *reinterpret_cast<uint4*>(Bs + trow * LDS_LD + tk8) = rb0;
+            if constexpr (BP > 1) *reinterpret_cast<uint4*>(Bs + (trow + RPP) * LDS_LD + tk8) = rb1;
+            __syncthreads();
+        }
+        if (kt + 1 < nkt) {
+            const int k0 = kbeg + (kt + 1) * BK;
+            const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+            for (int j = 0; j < AP; ++j) {
+                const int hi = bh[j] + kh * p.step_h, wi = bw[j] + kw * p.step_w;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (mv[j] && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi) {
+                    const float* src = Ab + ((long)hi * p.Wi + wi) * p.lda + c0 + tk8;
+                    float4 f0 = *reinterpret_cast<const float4*>(src);
+                    float4 f1 = *reinterpret_cast<const float4*>(src + 4);
+                    if (mrow) {
+                        const float mk = mrow[wi * p.inmask_ws];
+                        f0.x *= mk; f0.y *= mk; f0.z *= mk; f0.w *= mk; f1.x *= mk; f1.y *= mk; f1.z *= mk; f1.w *= mk;
+                    }
+                    v.x = pack_bf16(f0.x, f0.y); v.y = pack_bf16(f0.z, f0.w);
+                    v.z = pack_bf16(f1.x, f1.y); v.w = pack_bf16(f1.z, f1.w);
+                }
+                ra[j] = v;
+            }
+            if (BN >= RPP || trow < BN) rb0 = *reinterpret_cast<const uint4*>(Wb + (long)(n0 + trow) * p.K + k0 + tk8);
+            if constexpr (BP > 1) rb1 = *reinterpret_cast<const uint4*>(Wb + (long)(n0 + trow + RPP) * p.K + k0 + tk8);
+        }
+        if (kt >= 0) {
+            const u16* ap = As + (wm * (MT * 32) + i) * LDS_LD + hh * 8;
+            const u16* bp = Bs + (wn * 32 + i) * LDS_LD + hh * 8;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bp + ks * 16);
+#pragma unroll
+                for (int t = 0; t < MT; ++t) {
+                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(ap + t * 32 * LDS_LD + ks * 16);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    igemm_epilogue<MT>(p, acc, m0, n0, wm * (MT * 32), wn * 32, lane, b, g, s, M);
+}
+
+void launch_igemm_bf16(const IGemmP& p, hipStream_t st) {
+    const int M = p.Ho * p.Wo;
+    const int zdim = p.B * p.groups * p.ksplit;
+    const bool k64 = (p.Cin % 64 == 0) && ((p.K / p.ksplit) % 64 == 0);
+    if (p.N % 64 == 0) {
+        const long blocks128 = (long)((M + 127) / 128) * (p.N / 64) * zdim;
+        if (blocks128 < 1024) {
+            dim3 grid((M + 63) / 64, p.N / 64, zdim);
+            if (k64) hipLaunchKernelGGL((igemm_bf16_kernel<64, 64, 64>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((igemm_bf16_kernel<64, 64, 32>), grid, dim3(256), 0, st, p);
+        } else {
+            dim3 grid((M + 127) / 128, p.N / 64, zdim);
+            if (k64) hipLaunchKernelGGL((igemm_bf16_kernel<128, 64, 64>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((igemm_bf16_kernel<128, 64, 32>), grid, dim3(256), 0, st, p);
+        }
+    } else {
+        dim3 grid((M + 127) / 128, p.N / 32, zdim);
+        hipLaunchKernelGGL((igemm_bf16_kernel<128, 32, 32>), grid, dim3(256), 0, st, p);
+    }
+}
+
+}  // namespace dex

@@ -1,0 +1,78 @@
+// igemm_epilogue.h — shared epilogue of the implicit-GEMM kernels (fp32 and bf16 MFMA variants).
+// Accumulator layout of a 32x32 MFMA tile (dtype-independent on gfx950):
+//   col = lane & 31,  row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5),  r in [0,16).
+// bias -> [GroupNorm partial statistics of the raw conv output] -> act -> adaLN gate -> +residual -> mask -> store
+#pragma once
+#include "kernels.h"
+
+namespace dex {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// rows [row0, row0 + MT*32) x cols [col0, col0+32) of the block tile belong to this wave.
+template <int MT>
+__device__ __forceinline__ void igemm_epilogue(const IGemmP& p, f32x16 (&acc)[MT], int m0, int n0, int row0, int col0,
+                                               int lane, int b, int g, int s, int M) {
+    const int i = lane & 31, hh = lane >> 5;
+    const int n = n0 + col0 + i;                 // column within the group
+    const int ng = g * p.N + n;                  // global output channel
+    const int step = p.step ? *p.step : 0;
+    const float bias = p.bias ? p.bias[(long)b * p.bias_bstride + ng] : 0.f;
+    const float gate = p.gate ? p.gate[(long)step * p.gate_step_stride + (long)ng * p.gate_nstride] : 1.f;
+    const float* omask = p.outmask ? p.outmask + (long)b * p.mask_bstride : nullptr;
+    float* Cb = p.C + (long)b * p.c_bstride + (long)s * p.c_sstride + p.c_coff;
+    const float* Rb = p.res ? p.res + (long)b * p.res_bstride + p.res_coff : nullptr;
+    int up_c = 0, up_p1 = 0, up_p2 = 0;
+    if (p.unpatch_s > 0) {
+        const int pp = ng / p.unpatch_C;
+        up_c = ng - pp * p.unpatch_C;
+        up_p1 = pp / p.unpatch_s;
+        up_p2 = pp - up_p1 * p.unpatch_s;
+    }
+    float gs = 0.f, gss = 0.f;                   // GroupNorm partials of this lane's column
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const int m = m0 + row;
+            if (m >= M) continue;
+            const int ho = m / p.Wo, wo = m - ho * p.Wo;
+            float v = acc[t][r] + bias;
+            gs += v; gss = fmaf(v, v, gss);
+            if (p.act == 1) v = gelu_erf(v);
+            v *= gate;
+            if (p.unpatch_s > 0) {
+                const int oh = ho * p.unpatch_s + up_p1, ow = wo * p.unpatch_s + up_p2;
+                if (oh < p.OHf && ow < p.OWf) {
+                    if (omask) v *= omask[ow * p.outmask_ws];
+                    Cb[((long)oh * p.OWf + ow) * p.ldc + up_c] = v;
+                }
+            } else {
+                const int oh = ho * p.osh + p.oh0, ow = wo * p.osw + p.ow0;
+                const long opix = (long)oh * p.OWf + ow;
+                if (Rb) v += Rb[opix * p.ldres + ng];
+                if (omask) v *= omask[ow * p.outmask_ws];
+                Cb[opix * p.ldc + ng] = v;
+            }
+        }
+    }
+    if (p.gn_stats) {
+        // channels-per-group cpg in {8,16,32}: reduce over the cpg lanes of a group and over both half-waves,
+        // then ONE fp64 atomic pair per group per wave into slot (blockIdx.x % GN_SLOTS) — slots spread the
+        // same-address atomic traffic; the consumer sums the slots.
+        const int cpg = p.gn_cpg;
+        for (int o = 1; o < cpg; o <<= 1) { gs += __shfl_xor(gs, o); gss += __shfl_xor(gss, o); }
+        gs += __shfl_xor(gs, 32); gss += __shfl_xor(gss, 32);
+        if (hh == 0 && (i & (cpg - 1)) == 0) {
+            const int grp = ng / cpg;
+            double* dst = p.gn_stats + (((long)b * p.gn_groups + grp) * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * 2;
+            atomicAdd(dst, (double)gs);
+            atomicAdd(dst + 1, (double)gss);
+        }
+    }
+}
+
+}  // namespace dex

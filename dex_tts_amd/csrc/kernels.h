@@ -8,6 +8,8 @@
 
 namespace dex {
 
+constexpr int GN_SLOTS = 16;   // GroupNorm statistics are accumulated into [B][groups][GN_SLOTS][2] fp64 (atomic spreading)
+
 // ------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution / linear:  C[m, n] = epi( sum_k gather(A)[m,k] * W[k,n] )
 //   m = (ho, wo) in an Ho x Wo grid per batch; k = tap*Cin + c; tap=(kh,kw);
@@ -32,6 +34,7 @@ struct IGemmP {
     const float* res; int ldres; long res_bstride; int res_coff;
     const int* step;
     int unpatch_s, unpatch_C;                          // >0: scatter rows (f,w) x cols (p1,p2,c) -> NHWC image
+    double* gn_stats; int gn_groups, gn_cpg;           // fused GroupNorm partial statistics of (acc + bias), or null
     int B;
 };
 void launch_igemm(const IGemmP& p, int precision, hipStream_t st);

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnStatsP p) {
     __syncthreads();
     if (tid < p.groups * 2) {
         const int gg = tid >> 1, k = tid & 1;
-        atomicAdd(p.stats + ((long)b * p.groups + gg) * 2 + k, red[gg][k]);
+        atomicAdd(p.stats + (((long)b * p.groups + gg) * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * 2 + k, red[gg][k]);
     }
 }
 void launch_gn_stats(const GnStatsP& p, hipStream_t st) {
@@ -103,8 +103,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnApplyP p) {
     const int C4 = p.C >> 2, cpg = p.C / p.groups;
     if (tid < p.groups) {
         const double n = (double)p.npix * cpg;
-        const double mean = p.stats[((long)b * p.groups + tid) * 2] / n;
-        double var = p.stats[((long)b * p.groups + tid) * 2 + 1] / n - mean * mean;
+        double s1 = 0.0, s2 = 0.0;
+        for (int sl = 0; sl < GN_SLOTS; ++sl) {
+            s1 += p.stats[(((long)b * p.groups + tid) * GN_SLOTS + sl) * 2];
+            s2 += p.stats[(((long)b * p.groups + tid) * GN_SLOTS + sl) * 2 + 1];
+        }
+        const double mean = s1 / n;
+        double var = s2 / n - mean * mean;
         var = var < 0.0 ? 0.0 : var;
         smean[tid] = (float)mean;
         srstd[tid] = (float)(1.0 / sqrt(var + 1e-5));
@@ -165,8 +170,13 @@ __global__ __launch_bounds__(256) void final_kernel(const FinalP p) {
     const int cpg = p.C / p.groups;
     if (tid < p.groups) {
         const double n = (double)p.npix * cpg;
-        const double mean = p.stats[((long)b * p.groups + tid) * 2] / n;
-        double var = p.stats[((long)b * p.groups + tid) * 2 + 1] / n - mean * mean;
+        double s1 = 0.0, s2 = 0.0;
+        for (int sl = 0; sl < GN_SLOTS; ++sl) {
+            s1 += p.stats[(((long)b * p.groups + tid) * GN_SLOTS + sl) * 2];
+            s2 += p.stats[(((long)b * p.groups + tid) * GN_SLOTS + sl) * 2 + 1];
+        }
+        const double mean = s1 / n;
+        double var = s2 / n - mean * mean;
         var = var < 0.0 ? 0.0 : var;
         smean[tid] = (float)mean;
         srstd[tid] = (float)(1.0 / sqrt(var + 1e-5));
