@@ -59,7 +59,7 @@ __global__ __launch_bounds__(NW * 64) void attn_f32_kernel(const AttnP p) {
         const int k0 = kt * 32;
         // ---- stage K tile transposed: kT[d][key].  Per instruction a 32-lane half covers 4 keys x 32 d
         // (128-B coalesced rows); LDS bank = (d + key) % 32 = ((i&7)*4 + q + (i>>3)) % 32 -> conflict-free.
-#pragma unroll 4
+#pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int key = (it >> 2) * 8 + hh * 4 + (i >> 3);
             const int dd = (it & 3) * 32 + (i & 7) * 4;

@@ -2,6 +2,10 @@
 // Accumulator layout of a 32x32 MFMA tile (dtype-independent on gfx950):
 //   col = lane & 31,  row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5),  r in [0,16).
 // bias -> [GroupNorm partial statistics of the raw conv output] -> act -> adaLN gate -> +residual -> mask -> store
+//
+// Written in phases per 32x32 tile (indices, then ALL residual/mask loads with clamped addresses, then math,
+// then predicated stores) so the 16 dependent global loads of a lane are in flight together instead of
+// serialising behind per-element branches.
 #pragma once
 #include "kernels.h"
 
@@ -24,39 +28,57 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmP& p, f32x16 (&acc)[MT
     const float* omask = p.outmask ? p.outmask + (long)b * p.mask_bstride : nullptr;
     float* Cb = p.C + (long)b * p.c_bstride + (long)s * p.c_sstride + p.c_coff;
     const float* Rb = p.res ? p.res + (long)b * p.res_bstride + p.res_coff : nullptr;
+    const bool unp = p.unpatch_s > 0;
     int up_c = 0, up_p1 = 0, up_p2 = 0;
-    if (p.unpatch_s > 0) {
+    if (unp) {
         const int pp = ng / p.unpatch_C;
         up_c = ng - pp * p.unpatch_C;
         up_p1 = pp / p.unpatch_s;
         up_p2 = pp - up_p1 * p.unpatch_s;
     }
+    const int col_out = unp ? up_c : ng;
     float gs = 0.f, gss = 0.f;                   // GroupNorm partials of this lane's column
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
+        int opix[16], ow_[16];
+        bool ok[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = row0 + t * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
             const int m = m0 + row;
-            if (m >= M) continue;
-            const int ho = m / p.Wo, wo = m - ho * p.Wo;
+            bool v = m < M;
+            const int mm = v ? m : 0;
+            const int ho = mm / p.Wo, wo = mm - ho * p.Wo;
+            int oh, ow;
+            if (unp) { oh = ho * p.unpatch_s + up_p1; ow = wo * p.unpatch_s + up_p2; v = v && oh < p.OHf && ow < p.OWf; }
+            else { oh = ho * p.osh + p.oh0; ow = wo * p.osw + p.ow0; }
+            ok[r] = v;
+            opix[r] = v ? oh * p.OWf + ow : 0;
+            ow_[r] = v ? ow : 0;
+        }
+        float rv[16], mk[16];
+        if (Rb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = Rb[(long)opix[r] * p.ldres + ng];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+        }
+        if (omask) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mk[r] = omask[ow_[r] * p.outmask_ws];
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mk[r] = 1.f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
             float v = acc[t][r] + bias;
-            gs += v; gss = fmaf(v, v, gss);
+            const float vs = ok[r] ? v : 0.f;
+            gs += vs; gss = fmaf(vs, vs, gss);
             if (p.act == 1) v = gelu_erf(v);
-            v *= gate;
-            if (p.unpatch_s > 0) {
-                const int oh = ho * p.unpatch_s + up_p1, ow = wo * p.unpatch_s + up_p2;
-                if (oh < p.OHf && ow < p.OWf) {
-                    if (omask) v *= omask[ow * p.outmask_ws];
-                    Cb[((long)oh * p.OWf + ow) * p.ldc + up_c] = v;
-                }
-            } else {
-                const int oh = ho * p.osh + p.oh0, ow = wo * p.osw + p.ow0;
-                const long opix = (long)oh * p.OWf + ow;
-                if (Rb) v += Rb[opix * p.ldres + ng];
-                if (omask) v *= omask[ow * p.outmask_ws];
-                Cb[opix * p.ldc + ng] = v;
-            }
+            v = (v * gate + rv[r]) * mk[r];
+            if (ok[r]) Cb[(long)opix[r] * p.ldc + col_out] = v;
         }
     }
     if (p.gn_stats) {
