@@ -470,7 +470,7 @@ extern "C" int dex_ctx_finalize(DexCtx* x, dex_stream_t stream) {
 namespace {
 
 constexpr int SCAL_STRIDE = 8;
-constexpr int LA_CHUNK = 128;   // == LA_POS in linattn.hip
+constexpr int LA_CHUNK = 512;   // == LA_POS * LA_SUBT in linattn.hip
 constexpr int POS_SPLIT = 8;
 
 struct Dims { int B, T, Tr, Ts, n_steps; };

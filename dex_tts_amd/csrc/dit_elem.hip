@@ -10,6 +10,7 @@ __device__ __forceinline__ float gelu_d(float x) { return 0.5f * x * (1.0f + erf
 // PatchEmbed2D.proj[0..1] (dit.py:57-58): depthwise k x k, stride s, pad k/2; the reference right-pads the
 // width to a multiple of patch_size with zeros first (dit.py:442-445) — identical to treating wi >= Wi as zero.
 // The DiT input is x * mask_mid (diffusion.py:189 Identity on the last stage), applied here on load.
+template <int KS>
 __global__ __launch_bounds__(256) void dwconv_silu_kernel(const DwConvP p) {
     const int C4 = p.C >> 2;
     const long total = (long)p.B * p.Hf * p.Wt * C4;
@@ -23,15 +24,18 @@ __global__ __launch_bounds__(256) void dwconv_silu_kernel(const DwConvP p) {
     const float* X = p.X + (long)b * p.xb;
     const float* mrow = p.mask ? p.mask + (long)b * p.mask_bstride : nullptr;
     float4 acc = *reinterpret_cast<const float4*>(p.bd + cq * 4);
-    for (int kh = 0; kh < p.k; ++kh) {
+#pragma unroll
+    for (int kh = 0; kh < KS; ++kh) {
         const int hi = f * p.s + kh - p.pad;
-        if ((unsigned)hi >= (unsigned)p.Hi) continue;
-        for (int kw = 0; kw < p.k; ++kw) {
+#pragma unroll
+        for (int kw = 0; kw < KS; ++kw) {
             const int wi = wt * p.s + kw - p.pad;
-            if ((unsigned)wi >= (unsigned)p.Wi) continue;
-            float4 v = *reinterpret_cast<const float4*>(X + ((long)hi * p.Wi + wi) * p.ldx + cq * 4);
-            const float4 w = *reinterpret_cast<const float4*>(p.Wd + (kh * p.k + kw) * p.C + cq * 4);
-            const float mk = mrow ? mrow[wi * p.mask_ws] : 1.f;
+            const bool inb = (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
+            const int hc = inb ? hi : 0, wc = inb ? wi : 0;              // clamped: loads are unconditional
+            float4 v = *reinterpret_cast<const float4*>(X + ((long)hc * p.Wi + wc) * p.ldx + cq * 4);
+            const float4 w = *reinterpret_cast<const float4*>(p.Wd + (kh * KS + kw) * p.C + cq * 4);
+            float mk = mrow ? mrow[wc * p.mask_ws] : 1.f;
+            mk = inb ? mk : 0.f;
             acc.x = fmaf(v.x * mk, w.x, acc.x); acc.y = fmaf(v.y * mk, w.y, acc.y);
             acc.z = fmaf(v.z * mk, w.z, acc.z); acc.w = fmaf(v.w * mk, w.w, acc.w);
         }
@@ -41,44 +45,60 @@ __global__ __launch_bounds__(256) void dwconv_silu_kernel(const DwConvP p) {
 }
 void launch_dwconv_silu(const DwConvP& p, hipStream_t st) {
     const long total = (long)p.B * p.Hf * p.Wt * (p.C / 4);
-    hipLaunchKernelGGL(dwconv_silu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (p.k == 7) hipLaunchKernelGGL(dwconv_silu_kernel<7>, grid, dim3(256), 0, st, p);
+    else if (p.k == 3) hipLaunchKernelGGL(dwconv_silu_kernel<3>, grid, dim3(256), 0, st, p);
+    else if (p.k == 15) hipLaunchKernelGGL(dwconv_silu_kernel<15>, grid, dim3(256), 0, st, p);
 }
 
 // pos = mean_f GELU(conv + bias)  (dit.py:450-451; SamePad already applied by only computing Hf x Wt outputs);
 // tok[b, f*Wt + w, :] = emb + pos[w] + freq_pos[f]  (dit.py:452-454)
+// One workgroup per (b, w): thread = (channel quad cq, frequency lane fl of 4); all split-K partial loads of a
+// thread are independent; the mean over frequency is an LDS reduction over the 4 frequency lanes.
 __global__ __launch_bounds__(256) void pos_finish_kernel(const PosFinishP p) {
+    __shared__ float4 red[4][64];
+    const int tid = threadIdx.x, wt = blockIdx.x, b = blockIdx.y;
     const int D4 = p.D >> 2;
-    const long total = (long)p.B * p.Wt * D4;
-    const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-    if (gid >= total) return;
-    const int cq = (int)(gid % D4);
-    const int wt = (int)((gid / D4) % p.Wt);
-    const int b = (int)(gid / ((long)D4 * p.Wt));
-    const float4 bias = *reinterpret_cast<const float4*>(p.bias + cq * 4);
-    float4 pos = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int f = 0; f < p.Hf; ++f) {
-        const long row = ((long)b * p.Hf + f) * p.Wt + wt;
-        float4 a = bias;
-        for (int s = 0; s < p.nsplit; ++s) {
-            const float4 v = *reinterpret_cast<const float4*>(p.part + (long)s * p.split_stride + row * p.D + cq * 4);
-            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    for (int c0 = 0; c0 < D4; c0 += 64) {
+        const int cq = c0 + (tid & 63), fl = tid >> 6;
+        const bool act = cq < D4;
+        float4 part = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (act) {
+            const float4 bias = *reinterpret_cast<const float4*>(p.bias + cq * 4);
+            for (int f = fl; f < p.Hf; f += 4) {
+                const long row = ((long)b * p.Hf + f) * p.Wt + wt;
+                float4 a = bias;
+#pragma unroll 8
+                for (int s = 0; s < p.nsplit; ++s) {
+                    const float4 v = *reinterpret_cast<const float4*>(p.part + (long)s * p.split_stride + row * p.D + cq * 4);
+                    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+                }
+                part.x += gelu_d(a.x); part.y += gelu_d(a.y); part.z += gelu_d(a.z); part.w += gelu_d(a.w);
+            }
         }
-        pos.x += gelu_d(a.x); pos.y += gelu_d(a.y); pos.z += gelu_d(a.z); pos.w += gelu_d(a.w);
-    }
-    const float inv = 1.f / (float)p.Hf;
-    pos.x *= inv; pos.y *= inv; pos.z *= inv; pos.w *= inv;
-    for (int f = 0; f < p.Hf; ++f) {
-        const long row = ((long)b * p.Hf + f) * p.Wt + wt;
-        const float4 e = *reinterpret_cast<const float4*>(p.emb + row * p.D + cq * 4);
-        const float4 fp = *reinterpret_cast<const float4*>(p.freq_pos + (long)f * p.D + cq * 4);
-        float4 o;
-        o.x = e.x + pos.x + fp.x; o.y = e.y + pos.y + fp.y; o.z = e.z + pos.z + fp.z; o.w = e.w + pos.w + fp.w;
-        *reinterpret_cast<float4*>(p.tok + row * p.D + cq * 4) = o;
+        __syncthreads();
+        red[fl][tid & 63] = part;
+        __syncthreads();
+        if (act) {
+            const float inv = 1.f / (float)p.Hf;
+            float4 pos;
+            pos.x = (red[0][tid & 63].x + red[1][tid & 63].x + red[2][tid & 63].x + red[3][tid & 63].x) * inv;
+            pos.y = (red[0][tid & 63].y + red[1][tid & 63].y + red[2][tid & 63].y + red[3][tid & 63].y) * inv;
+            pos.z = (red[0][tid & 63].z + red[1][tid & 63].z + red[2][tid & 63].z + red[3][tid & 63].z) * inv;
+            pos.w = (red[0][tid & 63].w + red[1][tid & 63].w + red[2][tid & 63].w + red[3][tid & 63].w) * inv;
+            for (int f = fl; f < p.Hf; f += 4) {
+                const long row = ((long)b * p.Hf + f) * p.Wt + wt;
+                const float4 e = *reinterpret_cast<const float4*>(p.emb + row * p.D + cq * 4);
+                const float4 fp = *reinterpret_cast<const float4*>(p.freq_pos + (long)f * p.D + cq * 4);
+                float4 o;
+                o.x = e.x + pos.x + fp.x; o.y = e.y + pos.y + fp.y; o.z = e.z + pos.z + fp.z; o.w = e.w + pos.w + fp.w;
+                *reinterpret_cast<float4*>(p.tok + row * p.D + cq * 4) = o;
+            }
+        }
     }
 }
 void launch_pos_finish(const PosFinishP& p, hipStream_t st) {
-    const long total = (long)p.B * p.Wt * (p.D / 4);
-    hipLaunchKernelGGL(pos_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(pos_finish_kernel, dim3(p.Wt, p.B), dim3(256), 0, st, p);
 }
 
 // LayerNorm (eps 1e-6, biased var, no affine) then x*(1+scale)+shift.  One wave per token, D <= 512, D % 64 == 0.

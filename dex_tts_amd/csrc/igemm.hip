@@ -36,7 +36,11 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
     const int g = (z / p.ksplit) % p.groups;
     const int b = z / (p.ksplit * p.groups);
     const int M = p.Ho * p.Wo;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch), each XCD has a private L2, and
+    // neighbouring pixel tiles share their 3x3 halo -> give every XCD one contiguous range of tiles.
+    int mtile = blockIdx.x;
+    if ((gridDim.x & 7) == 0) mtile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int m0 = mtile * BM, n0 = blockIdx.y * BN;
     const int Kper = p.K / p.ksplit, kbeg = s * Kper, nkt = Kper / BK;
 
     const float* Ab = p.A + (long)b * p.a_bstride + p.a_coff + g * p.Cin;

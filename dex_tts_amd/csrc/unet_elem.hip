@@ -15,8 +15,28 @@ __device__ __forceinline__ float mish_f(float x) {
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
 
+
+// mean / rstd of each GroupNorm group from the slot-spread fp64 partials: thread (g = tid/16, slot = tid%16)
+// loads one (sum, sumsq) pair, 16-lane shuffle reduce — one global round trip instead of 16 serial ones.
+__device__ __forceinline__ void gn_mean_rstd(const double* stats, int b, int groups, double n, float* smean, float* srstd, int tid) {
+    if (tid < groups * GN_SLOTS) {
+        const int g = tid / GN_SLOTS;
+        const double* src = stats + (((long)b * groups + g) * GN_SLOTS + (tid % GN_SLOTS)) * 2;
+        double s1 = src[0], s2 = src[1];
+        for (int o = 1; o < GN_SLOTS; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        if ((tid % GN_SLOTS) == 0) {
+            const double mean = s1 / n;
+            double var = s2 / n - mean * mean;
+            var = var < 0.0 ? 0.0 : var;
+            smean[g] = (float)mean;
+            srstd[g] = (float)(1.0 / sqrt(var + 1e-5));
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // first conv: one thread = one pixel x 4 output channels.  planes <= 3.
+template <int PLANES>
 __global__ __launch_bounds__(256) void first_conv_kernel(const FirstConvP p) {
     const int C4 = p.C >> 2;
     const long total = (long)p.B * p.H * p.T * C4;
@@ -33,18 +53,22 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const FirstConvP p) {
     const float* pl[3] = {p.mu + (long)b * p.H * p.T, p.x + (long)b * p.H * p.T, nullptr};
     float4 a3 = *reinterpret_cast<const float4*>(p.b3 + cq * 4);
     float4 a1 = *reinterpret_cast<const float4*>(p.b1 + cq * 4);
-    for (int q = 0; q < p.planes; ++q) {
+#pragma unroll
+    for (int q = 0; q < PLANES; ++q) {
         const float sc = (q == 1) ? c_in : 1.f;
+#pragma unroll
         for (int kh = 0; kh < 3; ++kh) {
             const int hi = h + kh - 1;
-            if ((unsigned)hi >= (unsigned)p.H) continue;
+#pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
                 const int wi = w + kw - 1;
-                if ((unsigned)wi >= (unsigned)p.T) continue;
+                const bool inb = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.T;
+                const int hc = inb ? hi : h, wc = inb ? wi : w;          // clamped, always-valid address
                 float v;
-                if (q < 2) v = pl[q][(long)hi * p.T + wi] * sc;
-                else v = p.spk[(long)b * p.H + hi];
-                v *= mrow[wi];
+                if (q < 2) v = pl[q][(long)hc * p.T + wc] * sc;
+                else v = p.spk[(long)b * p.H + hc];
+                v *= mrow[wc];
+                v = inb ? v : 0.f;
                 const float4 wv = *reinterpret_cast<const float4*>(p.W3 + ((q * 9 + kh * 3 + kw) * p.C) + cq * 4);
                 a3.x = fmaf(v, wv.x, a3.x); a3.y = fmaf(v, wv.y, a3.y); a3.z = fmaf(v, wv.z, a3.z); a3.w = fmaf(v, wv.w, a3.w);
                 if (kh == 1 && kw == 1) {
@@ -59,7 +83,8 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const FirstConvP p) {
 }
 void launch_first_conv(const FirstConvP& p, hipStream_t st) {
     const long total = (long)p.B * p.H * p.T * (p.C / 4);
-    hipLaunchKernelGGL(first_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    if (p.planes == 3) hipLaunchKernelGGL(first_conv_kernel<3>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(first_conv_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -101,19 +126,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnApplyP p) {
     __shared__ float smean[32], srstd[32];
     const int tid = threadIdx.x, b = blockIdx.y;
     const int C4 = p.C >> 2, cpg = p.C / p.groups;
-    if (tid < p.groups) {
-        const double n = (double)p.npix * cpg;
-        double s1 = 0.0, s2 = 0.0;
-        for (int sl = 0; sl < GN_SLOTS; ++sl) {
-            s1 += p.stats[(((long)b * p.groups + tid) * GN_SLOTS + sl) * 2];
-            s2 += p.stats[(((long)b * p.groups + tid) * GN_SLOTS + sl) * 2 + 1];
-        }
-        const double mean = s1 / n;
-        double var = s2 / n - mean * mean;
-        var = var < 0.0 ? 0.0 : var;
-        smean[tid] = (float)mean;
-        srstd[tid] = (float)(1.0 / sqrt(var + 1e-5));
-    }
+    gn_mean_rstd(p.stats, b, p.groups, (double)p.npix * cpg, smean, srstd, tid);
     __syncthreads();
     const int step = p.step ? *p.step : 0;
     const long total = (long)p.npix * C4;
@@ -168,19 +181,7 @@ __global__ __launch_bounds__(256) void final_kernel(const FinalP p) {
     __shared__ float smean[32], srstd[32];
     const int tid = threadIdx.x, b = blockIdx.y;
     const int cpg = p.C / p.groups;
-    if (tid < p.groups) {
-        const double n = (double)p.npix * cpg;
-        double s1 = 0.0, s2 = 0.0;
-        for (int sl = 0; sl < GN_SLOTS; ++sl) {
-            s1 += p.stats[(((long)b * p.groups + tid) * GN_SLOTS + sl) * 2];
-            s2 += p.stats[(((long)b * p.groups + tid) * GN_SLOTS + sl) * 2 + 1];
-        }
-        const double mean = s1 / n;
-        double var = s2 / n - mean * mean;
-        var = var < 0.0 ? 0.0 : var;
-        smean[tid] = (float)mean;
-        srstd[tid] = (float)(1.0 / sqrt(var + 1e-5));
-    }
+    gn_mean_rstd(p.stats, b, p.groups, (double)p.npix * cpg, smean, srstd, tid);
     __syncthreads();
     const int step = p.step ? *p.step : 0;
     const float* sc = p.scal + (long)step * p.scal_stride;
@@ -262,30 +263,39 @@ void launch_cond_prep(const CondPrepP& p, hipStream_t st) {
     hipLaunchKernelGGL(cond_prep_kernel, dim3(p.n), dim3(128), 0, st, p);
 }
 
-// tiny conditioning MLPs: one wave per output feature n, looping over rows (Euler steps).
+// tiny conditioning MLPs: one wave per (output feature n, group of 8 rows); the 8 row loads are independent.
 __global__ __launch_bounds__(256) void small_linear_kernel(const SmallLinP p) {
     const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (wave >= p.N) return;
     const float* w = p.W + (long)wave * p.K;
     const float bias = p.bias ? p.bias[wave] : 0.f;
-    for (int r = 0; r < p.rows; ++r) {
-        const float* x = p.X + (long)r * p.ldx;
-        float acc = 0.f;
-        for (int k = lane; k < p.K; k += 64) {
-            float v = x[k];
+    const int r0 = blockIdx.y * 8;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int k = lane; k < p.K; k += 64) {
+        const float wk = w[k];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = min(r0 + j, p.rows - 1);
+            float v = p.X[(long)r * p.ldx + k];
             if (p.act_in == 1) v = mish_f(v); else if (p.act_in == 2) v = silu_f(v);
-            acc = fmaf(v, w[k], acc);
+            acc[j] = fmaf(v, wk, acc[j]);
         }
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
-        if (lane == 0) {
-            float y = acc + bias;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float a = acc[j];
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+        if (lane == 0 && r0 + j < p.rows) {
+            float y = a + bias;
             if (p.act_out == 1) y = mish_f(y); else if (p.act_out == 2) y = silu_f(y);
-            p.Y[(long)r * p.ldy + wave] = y;
+            p.Y[(long)(r0 + j) * p.ldy + wave] = y;
         }
     }
 }
 void launch_small_linear(const SmallLinP& p, hipStream_t st) {
-    hipLaunchKernelGGL(small_linear_kernel, dim3((p.N * 64 + 255) / 256), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(small_linear_kernel, dim3((p.N * 64 + 255) / 256, (p.rows + 7) / 8), dim3(256), 0, st, p);
 }
 
 // ------------------------------------------------------------------------------------------------
