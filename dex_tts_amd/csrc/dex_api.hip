@@ -627,8 +627,23 @@ struct Runner {
         const double by = 4.0 * (M * g.Cin * g.groups + M * g.N * g.groups * g.ksplit + (double)g.K * g.N * g.groups);
         run(name, fl, by, [&] { launch_igemm(g, x->precision, st); });
     }
+    // Block conv (diffusion.py:44).  pro != null fuses the producer's GN-apply + Mish + time bias into the load
+    // (bf16 patch kernel only).
+    struct Pro { const double* stats; const float *gamma, *beta, *tadd; };
+    bool fast_conv(int cin, int cout) const { return x->precision == DEX_PREC_BF16 && conv3x3_bf16_supported(cin, cout); }
     void conv3x3(const char* name, const TD& X, int H, int W, int mask_ws, bool inmask, const float* Wt, const float* bias, int Cout, float* out,
-                 double* gn = nullptr) {
+                 double* gn = nullptr, const Pro* pro = nullptr) {
+        auto it = x->bf16_of.find(Wt);
+        if (fast_conv(X.C, Cout) && it != x->bf16_of.end()) {
+            Conv3P c{};
+            c.X = X.p; c.ldx = X.ld; c.x_coff = X.coff; c.H = H; c.W = W; c.Cin = X.C; c.Cout = Cout;
+            c.Wbf = it->second; c.bias = bias; c.Y = out; c.mask = mask; c.mask_ws = mask_ws; c.mask_bstride = P.d.T;
+            if (pro) { c.pro_stats = pro->stats; c.pro_gamma = pro->gamma; c.pro_beta = pro->beta; c.pro_tadd = pro->tadd; }
+            c.step = P.step; c.gn_stats = gn; c.B = P.d.B;
+            const double M = (double)H * W * P.d.B;
+            run(name, 2.0 * M * Cout * 9 * X.C, 4.0 * M * (X.C + Cout) + 2.0 * 9 * X.C * Cout, [&] { launch_conv3x3_bf16(c, st); });
+            return;
+        }
         IGemmP g = base_gemm(X.p, X.ld, X.coff, H, W, X.C, Wt, Cout, bias, out, Cout, 0);
         g.KH = 3; g.KW = 3; g.off_h = -1; g.off_w = -1; g.K = 9 * X.C;
         if (inmask) { g.inmask = mask; g.inmask_ws = mask_ws; }
@@ -675,10 +690,17 @@ struct Runner {
             }
         }
         if (!st1) { st1 = next_stats(); gn_stats(s.h1, w.cout, npix, st1); }
-        gn_apply(s.h1, w.cout, npix, s.W, s.mask_ws, st1, w.g1, w.be1, tadd, nullptr, 0, 0, false, s.a1);
-        TD A1{s.a1, w.cout, 0, w.cout};
         double* st2 = next_stats();
-        conv3x3("conv3x3", A1, s.H, s.W, s.mask_ws, false, w.w2, w.b2, w.cout, s.h2, st2);
+        if (fast_conv(w.cout, w.cout)) {
+            // block1's GN-apply + Mish + time bias + mask is applied while block2's conv stages its input patch
+            Pro pro{st1, w.g1, w.be1, tadd};
+            TD H1{s.h1, w.cout, 0, w.cout};
+            conv3x3("conv3x3", H1, s.H, s.W, s.mask_ws, true, w.w2, w.b2, w.cout, s.h2, st2, &pro);
+        } else {
+            gn_apply(s.h1, w.cout, npix, s.W, s.mask_ws, st1, w.g1, w.be1, tadd, nullptr, 0, 0, false, s.a1);
+            TD A1{s.a1, w.cout, 0, w.cout};
+            conv3x3("conv3x3", A1, s.H, s.W, s.mask_ws, false, w.w2, w.b2, w.cout, s.h2, st2);
+        }
         gn_apply(s.h2, w.cout, npix, s.W, s.mask_ws, st2, w.g2, w.be2, nullptr, resptr, ldres, resb, under, out);
     }
 

@@ -39,6 +39,18 @@ struct IGemmP {
 };
 void launch_igemm(const IGemmP& p, int precision, hipStream_t st);
 
+// Patch-staged 3x3/s1/p1 Block convolution on bf16 MFMA (conv3x3_bf16.hip).  Input transform while staging:
+// x*mask, or mask*(Mish(GroupNorm(x)) + tadd[step]) when pro_stats != null (the fused tail of block1).
+struct Conv3P {
+    const float* X; int ldx; int x_coff; int H, W, Cin, Cout;
+    const void* Wbf; const float* bias; float* Y;            // bf16 [Cout][9*Cin]; Y is [B,H,W,Cout] contiguous
+    const float* mask; int mask_ws; long mask_bstride;
+    const double* pro_stats; const float* pro_gamma; const float* pro_beta; const float* pro_tadd;
+    const int* step; double* gn_stats; int B;
+};
+bool conv3x3_bf16_supported(int Cin, int Cout);
+void launch_conv3x3_bf16(const Conv3P& p, hipStream_t st);
+
 // First ResnetBlock of the U-Net: 3x3 conv and 1x1 res_conv straight from the stacked input planes
 // (mu, c_in*x[, spk]) * mask  (diffusion.py:171-175,185; edm.py:96).
 struct FirstConvP {
