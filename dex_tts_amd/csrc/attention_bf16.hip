@@ -1,0 +1,307 @@
+// attention_bf16.hip — softmax attention core on v_mfma_f32_32x32x16_bf16 (fp32 Q/K/V in HBM, converted to
+// bf16 while staging; fp32 scores, softmax state and accumulation).  head_dim 128.
+//
+// Transposed flash formulation (every per-query quantity lane-local, no cross-lane traffic for P):
+//     S^T = K Q^T    A = K rows [key][d] from LDS (16-B reads), B = Q^T fragments kept in registers (pre-scaled)
+//     O^T = V^T P^T  A = V^T from LDS laid out [d][pos(key)], B = P^T = the S^T accumulator registers packed
+//                    to bf16 — the contraction order over keys is the accumulator order, so V^T is stored with
+//                    key bits 2 and 3 swapped (pos(key)) and P needs no shuffle at all.
+// C-layout of a 32x32 tile: col = lane&31 (query), row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+//
+// Two workgroup shapes:
+//   SPLIT=false: 4 waves = 4 query tiles (128 queries) sharing double-buffered K/V tiles of 64 keys
+//                (one barrier per tile, next tile prefetched into registers during the MFMAs);
+//   SPLIT=true : NW waves share ONE 32-query tile and split the keys (wave-private 32-key tiles, partial
+//                (m, l, O) merged through LDS) — keeps small token counts (N=650 at B=1) spread over the chip.
+#include "kernels.h"
+
+namespace dex {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned short u16;
+constexpr int AHD = 128;
+constexpr int K_LD = AHD + 8;             // bf16 elements per K row in LDS (272 B)
+
+__device__ __forceinline__ unsigned at_pack(float lo, float hi) {
+    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
+    a += 0x7FFFu + ((a >> 16) & 1u);
+    b += 0x7FFFu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xFFFF0000u);
+}
+__device__ __forceinline__ int key_pos(int k) { return (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1); }
+
+union Frag { uint4 u; bf16x8 v; };
+
+// Stage KT keys starting at k0 (rows clamped to Nk-1; masked later through the scores) with GS cooperating
+// threads (index t): K -> kS[key][K_LD], V -> vT[d][KT+8] (transposed, key positions permuted).
+template <int KT, int GS>
+struct Stager {
+    static constexpr int KI = KT * AHD / 8 / GS;          // K items (8 consecutive d of one key) per thread
+    static constexpr int VI = (KT / 2) * (AHD / 4) / GS;  // V items (key pair x 4 consecutive d) per thread
+    float4 kr[KI][2];
+    float4 vr[VI][2];
+    __device__ __forceinline__ void load(const float* Kb, int ldk, const float* Vb, int ldv, int k0, int Nk, int t) {
+#pragma unroll
+        for (int j = 0; j < KI; ++j) {
+            const int it = t + GS * j;
+            const int key = it / (AHD / 8), d8 = (it % (AHD / 8)) * 8;
+            const float* src = Kb + (long)min(k0 + key, Nk - 1) * ldk + d8;
+            kr[j][0] = *reinterpret_cast<const float4*>(src);
+            kr[j][1] = *reinterpret_cast<const float4*>(src + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < VI; ++j) {
+            const int it = t + GS * j;
+            const int kp = it / (AHD / 4), d4 = (it % (AHD / 4)) * 4;
+            vr[j][0] = *reinterpret_cast<const float4*>(Vb + (long)min(k0 + 2 * kp, Nk - 1) * ldv + d4);
+            vr[j][1] = *reinterpret_cast<const float4*>(Vb + (long)min(k0 + 2 * kp + 1, Nk - 1) * ldv + d4);
+        }
+    }
+    __device__ __forceinline__ void store(u16* kS, u16* vT, int t) {
+        constexpr int V_LD = KT + 8;
+#pragma unroll
+        for (int j = 0; j < KI; ++j) {
+            const int it = t + GS * j;
+            const int key = it / (AHD / 8), d8 = (it % (AHD / 8)) * 8;
+            uint4 u;
+            u.x = at_pack(kr[j][0].x, kr[j][0].y); u.y = at_pack(kr[j][0].z, kr[j][0].w);
+            u.z = at_pack(kr[j][1].x, kr[j][1].y); u.w = at_pack(kr[j][1].z, kr[j][1].w);
+            *reinterpret_cast<uint4*>(kS + key * K_LD + d8) = u;
+        }
+#pragma unroll
+        for (int j = 0; j < VI; ++j) {
+            const int it = t + GS * j;
+            const int kp = it / (AHD / 4), d4 = (it % (AHD / 4)) * 4;
+            unsigned* dst = reinterpret_cast<unsigned*>(vT + key_pos(2 * kp));      // even position: dword aligned
+            dst[((d4 + 0) * V_LD) >> 1] = at_pack(vr[j][0].x, vr[j][1].x);
+            dst[((d4 + 1) * V_LD) >> 1] = at_pack(vr[j][0].y, vr[j][1].y);
+            dst[((d4 + 2) * V_LD) >> 1] = at_pack(vr[j][0].z, vr[j][1].z);
+            dst[((d4 + 3) * V_LD) >> 1] = at_pack(vr[j][0].w, vr[j][1].w);
+        }
+    }
+};
+
+// One KV tile of KT keys for one wave's 32 queries: scores, online softmax, P.V.
+template <int KT>
+__device__ __forceinline__ void attn_tile(const u16* kS, const u16* vT, const Frag (&qf)[8], f32x16 (&o)[4],
+                                          float& m_run, float& l_run, int k0, int Nk, int lane) {
+    constexpr int V_LD = KT + 8, NS = KT / 32;
+    const int i = lane & 31, hh = lane >> 5;
+    f32x16 s[NS];
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[st][r] = 0.f;
+        const u16* ka = kS + (st * 32 + i) * K_LD + hh * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            Frag a; a.u = *reinterpret_cast<const uint4*>(ka + ks * 16);
+            s[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, qf[ks].v, s[st], 0, 0, 0);
+        }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int st = 0; st < NS; ++st)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (key >= Nk) s[st][r] = -INFINITY;
+            mx = fmaxf(mx, s[st][r]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __expf(m_run - m_new);
+    float psum = 0.f;
+#pragma unroll
+    for (int st = 0; st < NS; ++st)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[st][r] = __expf(s[st][r] - m_new); psum += s[st][r]; }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+#pragma unroll
+    for (int st = 0; st < NS; ++st)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            Frag pb;
+            pb.u.x = at_pack(s[st][8 * k2 + 0], s[st][8 * k2 + 1]); pb.u.y = at_pack(s[st][8 * k2 + 2], s[st][8 * k2 + 3]);
+            pb.u.z = at_pack(s[st][8 * k2 + 4], s[st][8 * k2 + 5]); pb.u.w = at_pack(s[st][8 * k2 + 6], s[st][8 * k2 + 7]);
+            const u16* va = vT + i * V_LD + (st * 2 + k2) * 16 + hh * 8;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                Frag a; a.u = *reinterpret_cast<const uint4*>(va + t * 32 * V_LD);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, pb.v, o[t], 0, 0, 0);
+            }
+        }
+}
+
+__device__ __forceinline__ void load_q(Frag (&qf)[8], const float* Qb, int ldq, int qrow, int Nq, float scale, int hh) {
+    const bool ok = qrow < Nq;
+    const float* qp = Qb + (long)(ok ? qrow : 0) * ldq + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        float4 a = *reinterpret_cast<const float4*>(qp + ks * 16);
+        float4 c = *reinterpret_cast<const float4*>(qp + ks * 16 + 4);
+        if (!ok) { a = make_float4(0.f, 0.f, 0.f, 0.f); c = a; }
+        qf[ks].u.x = at_pack(a.x * scale, a.y * scale); qf[ks].u.y = at_pack(a.z * scale, a.w * scale);
+        qf[ks].u.z = at_pack(c.x * scale, c.y * scale); qf[ks].u.w = at_pack(c.z * scale, c.w * scale);
+    }
+}
+
+// ---- SPLIT=false: 4 waves, 4 query tiles, shared K/V tiles of 64 keys ---------------------------------
+__global__ __launch_bounds__(256) void attn_bf16_shared_kernel(const AttnP p) {
+    constexpr int KT = 64, V_LD = KT + 8;
+    constexpr int KBUF = KT * K_LD, VBUF = AHD * V_LD;
+    extern __shared__ __attribute__((aligned(16))) u16 smem_b[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int q0 = blockIdx.x * 128 + wave * 32, h = blockIdx.y, b = blockIdx.z;
+    int Nk = p.Nk;
+    if (p.kv_len) Nk = min(p.Nk, p.kv_len[b] + p.kv_len_add);
+    const float* Qb = p.Q + (long)b * p.qb + h * AHD;
+    const float* Kb = p.K + (long)b * p.kb + h * AHD;
+    const float* Vb = p.V + (long)b * p.vb + h * AHD;
+    Frag qf[8];
+    load_q(qf, Qb, p.ldq, q0 + i, p.Nq, p.scale, hh);
+    f32x16 o[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int ntiles = (Nk + KT - 1) / KT;
+    Stager<KT, 256> sg;
+    sg.load(Kb, p.ldk, Vb, p.ldv, 0, Nk, tid);
+    sg.store(smem_b, smem_b + 2 * KBUF, tid);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();                                   // tile kt visible; buffer (kt+1)&1 free
+        const int cur = kt & 1;
+        if (kt + 1 < ntiles) sg.load(Kb, p.ldk, Vb, p.ldv, (kt + 1) * KT, Nk, tid);
+        attn_tile<KT>(smem_b + cur * KBUF, smem_b + 2 * KBUF + cur * VBUF, qf, o, m_run, l_run, kt * KT, Nk, lane);
+        if (kt + 1 < ntiles) sg.store(smem_b + (cur ^ 1) * KBUF, smem_b + 2 * KBUF + (cur ^ 1) * VBUF, tid);
+    }
+    l_run += __shfl_xor(l_run, 32);
+    const int qrow = q0 + i;
+    if (qrow < p.Nq) {
+        const float inv = 1.f / l_run;
+        float* op = p.O + (long)b * p.ob + (long)qrow * p.ldo + h * AHD;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq)
+                *reinterpret_cast<float4*>(op + t * 32 + 8 * rq + 4 * hh) =
+                    make_float4(o[t][rq * 4 + 0] * inv, o[t][rq * 4 + 1] * inv, o[t][rq * 4 + 2] * inv, o[t][rq * 4 + 3] * inv);
+    }
+}
+
+// ---- SPLIT=true: NW waves share one 32-query tile and split the keys ----------------------------------
+constexpr int SP_KT = 32;
+constexpr int SP_WAVE_U16 = SP_KT * K_LD + AHD * (SP_KT + 8);   // 4352 + 5120 = 9472 u16 = 18944 B >= 32*132*4
+constexpr int SP_O_LD = 132;
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bf16_split_kernel(const AttnP p) {
+    extern __shared__ __attribute__((aligned(16))) u16 smem_b[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+    u16* kS = smem_b + wave * SP_WAVE_U16;
+    u16* vT = kS + SP_KT * K_LD;
+    float* stat = reinterpret_cast<float*>(smem_b + NW * SP_WAVE_U16);     // [NW][2][32]
+    int Nk = p.Nk;
+    if (p.kv_len) Nk = min(p.Nk, p.kv_len[b] + p.kv_len_add);
+    const float* Qb = p.Q + (long)b * p.qb + h * AHD;
+    const float* Kb = p.K + (long)b * p.kb + h * AHD;
+    const float* Vb = p.V + (long)b * p.vb + h * AHD;
+    Frag qf[8];
+    load_q(qf, Qb, p.ldq, q0 + i, p.Nq, p.scale, hh);
+    f32x16 o[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int ntiles = (Nk + SP_KT - 1) / SP_KT;
+    for (int kt = wave; kt < ntiles; kt += NW) {
+        Stager<SP_KT, 64> sg;
+        sg.load(Kb, p.ldk, Vb, p.ldv, kt * SP_KT, Nk, lane);
+        sg.store(kS, vT, lane);
+        __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): wave-private tile written
+        __builtin_amdgcn_wave_barrier();
+        attn_tile<SP_KT>(kS, vT, qf, o, m_run, l_run, kt * SP_KT, Nk, lane);
+        __builtin_amdgcn_wave_barrier();
+    }
+    l_run += __shfl_xor(l_run, 32);
+    __syncthreads();
+    float* oS = reinterpret_cast<float*>(smem_b + wave * SP_WAVE_U16);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq)
+            *reinterpret_cast<float4*>(oS + i * SP_O_LD + t * 32 + 8 * rq + 4 * hh) =
+                make_float4(o[t][rq * 4 + 0], o[t][rq * 4 + 1], o[t][rq * 4 + 2], o[t][rq * 4 + 3]);
+    if (hh == 0) { stat[(wave * 2 + 0) * 32 + i] = m_run; stat[(wave * 2 + 1) * 32 + i] = l_run; }
+    __syncthreads();
+    const int d4 = (tid & 31) * 4;
+    for (int q = tid >> 5; q < 32; q += NW * 2) {
+        if (q0 + q >= p.Nq) continue;
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) M = fmaxf(M, stat[(w * 2) * 32 + q]);
+        float L = 0.f;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const float mw = stat[(w * 2) * 32 + q];
+            const float f = (mw == -INFINITY) ? 0.f : __expf(mw - M);
+            L += f * stat[(w * 2 + 1) * 32 + q];
+            const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(smem_b + w * SP_WAVE_U16) + q * SP_O_LD + d4);
+            acc.x = fmaf(f, v.x, acc.x); acc.y = fmaf(f, v.y, acc.y); acc.z = fmaf(f, v.z, acc.z); acc.w = fmaf(f, v.w, acc.w);
+        }
+        const float inv = 1.f / L;
+        float* op = p.O + (long)b * p.ob + (long)(q0 + q) * p.ldo + h * AHD + d4;
+        *reinterpret_cast<float4*>(op) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+    }
+}
+
+template <int NW>
+static void launch_split(const AttnP& p, hipStream_t st) {
+    const size_t lds = (size_t)NW * SP_WAVE_U16 * sizeof(u16) + NW * 64 * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf16_split_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    dim3 grid((p.Nq + 31) / 32, p.heads, p.B);
+    hipLaunchKernelGGL((attn_bf16_split_kernel<NW>), grid, dim3(NW * 64), lds, st, p);
+}
+
+void launch_attention_bf16(const AttnP& p, hipStream_t st) {
+    const long blocks128 = (long)((p.Nq + 127) / 128) * p.heads * p.B;
+    if (blocks128 >= 256) {
+        constexpr int KT = 64;
+        const size_t lds = (size_t)(2 * KT * K_LD + 2 * AHD * (KT + 8)) * sizeof(u16);
+        static bool attr = false;
+        if (!attr) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf16_shared_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr = true;
+        }
+        dim3 grid((p.Nq + 127) / 128, p.heads, p.B);
+        hipLaunchKernelGGL(attn_bf16_shared_kernel, grid, dim3(256), lds, st, p);
+        return;
+    }
+    const long blocks32 = (long)((p.Nq + 31) / 32) * p.heads * p.B;
+    const int ntiles = (p.Nk + SP_KT - 1) / SP_KT;
+    int nw = 8;
+    if (blocks32 * 4 >= 1024 || ntiles < 8) nw = 4;
+    if (blocks32 * 2 >= 2048 || ntiles < 4) nw = 2;
+    if (nw == 8) launch_split<8>(p, st);
+    else if (nw == 4) launch_split<4>(p, st);
+    else launch_split<2>(p, st);
+}
+
+}  // namespace dex

@@ -754,7 +754,7 @@ struct Runner {
             a.K = P.qkv + hid; a.ldk = 3 * hid; a.kb = a.qb; a.V = P.qkv + 2 * hid; a.ldv = 3 * hid; a.vb = a.qb;
             a.O = P.ao; a.ldo = hid; a.ob = (long)N * hid; a.Nq = N; a.Nk = N; a.kv_len = nullptr; a.kv_len_add = 0;
             a.heads = c.dit_heads; a.scale = scale; a.B = B;
-            run("dit_attention", 4.0 * B * (double)N * N * hid, 4.0 * 4 * B * N * hid, [&] { launch_attention(a, DEX_PREC_FP32, st); });
+            run("dit_attention", 4.0 * B * (double)N * N * hid, 4.0 * 4 * B * N * hid, [&] { launch_attention(a, x->precision, st); });
             IGemmP pr = base_gemm(P.ao, hid, 0, 1, N, hid, w.wproj, hid, w.bproj, P.tok, hid, 0);
             pr.gate = ada + 2 * hid; pr.gate_nstride = 1; pr.gate_step_stride = 6L * hid;
             pr.res = P.tok; pr.ldres = hid; pr.res_bstride = (long)N * hid;
@@ -805,7 +805,7 @@ struct Runner {
         a.V = P.tv_V; a.ldv = mid; a.vb = a.kb; a.O = P.tv_ao; a.ldo = mid; a.ob = npix * mid;
         a.Nq = (int)npix; a.Nk = P.d.Ts + 1; a.kv_len = args->sty_lengths_dev; a.kv_len_add = 1; a.heads = 1;
         a.scale = 1.0f / sqrtf((float)mid); a.B = B;
-        run("tv_attention", 4.0 * B * (double)npix * (P.d.Ts + 1) * mid, 4.0 * B * (2 * npix + 2 * (P.d.Ts + 1)) * mid, [&] { launch_attention(a, DEX_PREC_FP32, st); });
+        run("tv_attention", 4.0 * B * (double)npix * (P.d.Ts + 1) * mid, 4.0 * B * (2 * npix + 2 * (P.d.Ts + 1)) * mid, [&] { launch_attention(a, x->precision, st); });
         IGemmP o = base_gemm(P.tv_ao, mid, 0, P.Hm, P.Wm, mid, x->tv_wl, mid, nullptr, P.tv_out, mid, 0);
         o.res = X.p; o.ldres = X.ld; o.res_coff = X.coff; o.res_bstride = npix * X.ld;
         o.outmask = mask; o.outmask_ws = mask_ws;
