@@ -1,13 +1,19 @@
 // conv3x3_bf16.hip — 3x3 / stride 1 / pad 1 convolution of the U-Net Block (diffusion.py:41-50) as a
 // patch-staged direct convolution on v_mfma_f32_32x32x16_bf16 (fp32 accumulate, fp32 tensors in HBM).
 //
-// A workgroup owns TH rows x 32 columns of output pixels and ALL output channels.  The (TH+2) x 34 input
-// patch is staged ONCE in LDS as bf16 (1.6x halo overhead instead of the 9x re-gather of an im2col GEMM), with
-// the producer's tail fused into the staging:  x*mask   or   mask*(Mish(GroupNorm(x)) + time_bias)
-// (diffusion.py:49,67-69) so the activated tensor of block1 never exists in HBM.  Per-tap weight slices
-// [Cout][CC] stream through a double-buffered LDS tile.  LDS rows are padded by 16 B so every ds_read_b128 /
-// ds_write_b128 lane group covers 64 distinct banks.  Epilogue: +bias, fused GroupNorm partial statistics
-// (fp64 atomics, slot-spread), fp32 channels-last store (128-B rows).
+// A workgroup owns TH rows x 32 columns of output pixels.  The (TH+2) x 34 input patch is staged ONCE in LDS
+// as bf16 (1.6x halo overhead instead of the 9x re-gather of an im2col GEMM), with the producer's tail fused
+// into the staging:  x*mask   or   mask*(Mish(GroupNorm(x)) + time_bias)   (diffusion.py:49,67-69), so the
+// activated tensor of block1 never exists in HBM.  Two weight schedules:
+//   RESIDENT  (few workgroups, B=1): a workgroup owns a slice of NSL output channels and keeps ALL nine taps of
+//             its weights in LDS; every global load of the kernel is issued up front and the 9-tap MFMA chain
+//             runs without a single barrier — at one workgroup per CU dependent global round trips are the
+//             only cost that matters (measured: 9 streamed taps = 9 exposed round trips).
+//   STREAMED  (many workgroups, big batches): per-tap weight slices [Cout][CC] stream through a double-buffered
+//             LDS tile (small LDS footprint, 3 workgroups per CU).
+// LDS rows are padded by 16 B so every ds_read_b128 / ds_write_b128 lane group covers 64 distinct banks.
+// Epilogue: +bias, GroupNorm partial statistics (workgroup-combined, one fp32 atomic pair per group into a
+// slot-spread buffer), fp32 channels-last store (128-B rows).
 #include "kernels.h"
 
 namespace dex {
@@ -22,25 +28,121 @@ __device__ __forceinline__ unsigned cv_pack_bf16(float lo, float hi) {
     b += 0x7FFFu + ((b >> 16) & 1u);
     return (a >> 16) | (b & 0xFFFF0000u);
 }
-__device__ __forceinline__ float cv_mish(float x) {
-    if (x > 20.f) return x;
-    const float e = __expf(x);
+__device__ __forceinline__ float cv_mish(float x) {           // branch-free: tanh(softplus(x)) == 1 to fp32 for x > 20
+    const float e = __expf(fminf(x, 20.f));
     const float n = e * (e + 2.f);
     return x * (n / (n + 2.f));
 }
 
-// CC: channels per staged chunk (Cin = nchunk*CC), COUT: output channels, TH: tile rows (waves: TH x (4/TH))
+// mean / rstd of the producer's GroupNorm from the slot-spread fp32 partials (8 groups x GN_SLOTS == 256 threads)
+__device__ __forceinline__ void cv_gn_coeffs(const Conv3P& p, int b, int tid, float* smean, float* srstd) {
+    const int g = tid / GN_SLOTS;
+    const float* src = p.pro_stats + (((long)b * 8 + g) * GN_SLOTS + (tid % GN_SLOTS)) * 2;
+    double s1 = (double)src[0], s2 = (double)src[1];
+    for (int o = 1; o < GN_SLOTS; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if ((tid % GN_SLOTS) == 0) {
+        const double n = (double)p.H * p.W * (p.Cin / 8);
+        const double mean = s1 / n;
+        double var = s2 / n - mean * mean;
+        var = var < 0.0 ? 0.0 : var;
+        smean[g] = (float)mean;
+        srstd[g] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+}
+
+// Stage the (TH+2) x 34 x CC input patch chunk [cbase, cbase+CC) into LDS as bf16 (8 channels per item).
+template <int CC, int TH>
+__device__ __forceinline__ void cv_stage_patch(const Conv3P& p, const float* X, const float* mrow, u16* patch, int h0, int w0,
+                                               int cbase, int step, const float* smean, const float* srstd, int tid) {
+    constexpr int PW = 34, PH = TH + 2, LDP = CC + 8;
+    constexpr int ITEMS = PH * PW * (CC / 8);
+#pragma unroll 4
+    for (int it = tid; it < ITEMS; it += 256) {
+        const int c8 = (it % (CC / 8)) * 8;
+        const int px = it / (CC / 8);
+        const int pw = px % PW, ph = px / PW;
+        const int hi = h0 + ph - 1, wi = w0 + pw - 1;
+        const bool inb = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        const int hc = inb ? hi : 0, wc = inb ? wi : 0;          // clamped: every load is unconditional
+        const float* src = X + ((long)hc * p.W + wc) * p.ldx + cbase + c8;
+        float4 f0 = *reinterpret_cast<const float4*>(src);
+        float4 f1 = *reinterpret_cast<const float4*>(src + 4);
+        float mk = mrow[wc * p.mask_ws];
+        mk = inb ? mk : 0.f;
+        if (p.pro_stats) {
+            const int c = cbase + c8;
+            const int g = c / (p.Cin / 8);
+            const float mean = smean[g], rstd = srstd[g];
+            const float4 ga0 = *reinterpret_cast<const float4*>(p.pro_gamma + c), ga1 = *reinterpret_cast<const float4*>(p.pro_gamma + c + 4);
+            const float4 be0 = *reinterpret_cast<const float4*>(p.pro_beta + c), be1 = *reinterpret_cast<const float4*>(p.pro_beta + c + 4);
+            const float* ta = p.pro_tadd + (long)step * p.Cin + c;
+            const float4 t0 = *reinterpret_cast<const float4*>(ta), t1 = *reinterpret_cast<const float4*>(ta + 4);
+            f0.x = cv_mish((f0.x - mean) * rstd * ga0.x + be0.x) + t0.x; f0.y = cv_mish((f0.y - mean) * rstd * ga0.y + be0.y) + t0.y;
+            f0.z = cv_mish((f0.z - mean) * rstd * ga0.z + be0.z) + t0.z; f0.w = cv_mish((f0.w - mean) * rstd * ga0.w + be0.w) + t0.w;
+            f1.x = cv_mish((f1.x - mean) * rstd * ga1.x + be1.x) + t1.x; f1.y = cv_mish((f1.y - mean) * rstd * ga1.y + be1.y) + t1.y;
+            f1.z = cv_mish((f1.z - mean) * rstd * ga1.z + be1.z) + t1.z; f1.w = cv_mish((f1.w - mean) * rstd * ga1.w + be1.w) + t1.w;
+        }
+        f0.x *= mk; f0.y *= mk; f0.z *= mk; f0.w *= mk; f1.x *= mk; f1.y *= mk; f1.z *= mk; f1.w *= mk;
+        uint4 v;
+        v.x = cv_pack_bf16(f0.x, f0.y); v.y = cv_pack_bf16(f0.z, f0.w);
+        v.z = cv_pack_bf16(f1.x, f1.y); v.w = cv_pack_bf16(f1.z, f1.w);
+        *reinterpret_cast<uint4*>(patch + px * LDP + c8) = v;
+    }
+}
+
+// Epilogue of one wave: NT 32x32 tiles; rows = pixels (w0 + row) of image row ho, cols = channels nbase + t*32 + i.
+// GroupNorm partials are combined across the workgroup's waves in LDS (gnred[8][2]) before the atomics.
+template <int NT, int COUT>
+__device__ __forceinline__ void cv_epilogue(const Conv3P& p, f32x16 (&acc)[NT], int b, int ho, int w0, int nbase, int lane, int tid,
+                                            float* gnred) {
+    const int i = lane & 31, hh = lane >> 5;
+    float* Y = p.Y + (long)b * p.H * p.W * COUT;
+    constexpr int cpg = COUT / 8;
+    if (p.gn_stats) { if (tid < 16) gnred[tid] = 0.f; __syncthreads(); }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int n = nbase + t * 32 + i;
+        const float bias = p.bias[n];
+        float gs = 0.f, gss = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int wo = w0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const bool ok = ho < p.H && wo < p.W;
+            const float v = acc[t][r] + bias;
+            const float vs = ok ? v : 0.f;
+            gs += vs; gss = fmaf(vs, vs, gss);
+            if (ok) Y[((long)ho * p.W + wo) * COUT + n] = v;
+        }
+        if (p.gn_stats) {
+            for (int o = 1; o < cpg; o <<= 1) { gs += __shfl_xor(gs, o); gss += __shfl_xor(gss, o); }
+            gs += __shfl_xor(gs, 32); gss += __shfl_xor(gss, 32);
+            if (hh == 0 && (i & (cpg - 1)) == 0) { atomicAdd(&gnred[(n / cpg) * 2], gs); atomicAdd(&gnred[(n / cpg) * 2 + 1], gss); }
+        }
+    }
+    if (p.gn_stats) {
+        __syncthreads();
+        if (tid < 16) {
+            const float v = gnred[tid];
+            if (v != 0.f) {
+                const int slot = (blockIdx.x + blockIdx.y * gridDim.x) % GN_SLOTS;
+                atomicAdd(p.gn_stats + (((long)b * 8 + (tid >> 1)) * GN_SLOTS + slot) * 2 + (tid & 1), v);
+            }
+        }
+    }
+}
+
+// ---- STREAMED weights: CC channels per chunk, all COUT channels, TH rows (waves: TH x (4/TH)) -----------------
 template <int CC, int COUT, int TH>
 __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
     constexpr int PW = 34, PH = TH + 2;
-    constexpr int LDP = CC + 8;                       // bf16 elements per patch pixel / weight row
-    constexpr int WN = 4 / TH;                        // wave columns (split of the output channels)
-    constexpr int NT = COUT / 32 / WN;                // 32-wide n-tiles per wave
+    constexpr int LDP = CC + 8;
+    constexpr int WN = 4 / TH;
+    constexpr int NT = COUT / 32 / WN;
     static_assert(NT >= 1, "tile");
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* patch = smem;                                // [PH*PW][LDP]
     u16* wbuf = smem + PH * PW * LDP;                 // [2][COUT][LDP]
-    __shared__ float smean[8], srstd[8];
+    __shared__ float smean[8], srstd[8], gnred[16];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
@@ -51,24 +153,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
     const float* mrow = p.mask + (long)b * p.mask_bstride;
     const u16* Wg = reinterpret_cast<const u16*>(p.Wbf);     // [COUT][9*Cin]
     const int K = 9 * p.Cin;
-
-    if (p.pro_stats) {                                       // GroupNorm mean / rstd of the producer
-        if (tid < 8 * GN_SLOTS) {
-            const int g = tid / GN_SLOTS;
-            const double* src = p.pro_stats + (((long)b * 8 + g) * GN_SLOTS + (tid % GN_SLOTS)) * 2;
-            double s1 = src[0], s2 = src[1];
-            for (int o = 1; o < GN_SLOTS; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-            if ((tid % GN_SLOTS) == 0) {
-                const double n = (double)p.H * p.W * (p.Cin / 8);
-                const double mean = s1 / n;
-                double var = s2 / n - mean * mean;
-                var = var < 0.0 ? 0.0 : var;
-                smean[g] = (float)mean;
-                srstd[g] = (float)(1.0 / sqrt(var + 1e-5));
-            }
-        }
-        __syncthreads();
-    }
+    if (p.pro_stats) { cv_gn_coeffs(p, b, tid, smean, srstd); __syncthreads(); }
 
     f32x16 acc[NT];
 #pragma unroll
@@ -76,55 +161,18 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    constexpr int WPT = COUT * CC / 8 / 256;          // uint4 weight loads per thread per tap
+    constexpr int WPT = COUT * CC / 8 / 256;
     static_assert(WPT >= 1, "weights per thread");
     const int nchunk = p.Cin / CC;
     for (int ch = 0; ch < nchunk; ++ch) {
         const int cbase = ch * CC;
         __syncthreads();                              // previous chunk fully consumed
-        // ---- stage the input patch chunk: PH*PW pixels x CC channels, 8 channels per thread-item
-        constexpr int ITEMS = PH * PW * (CC / 8);
-#pragma unroll 4
-        for (int it = tid; it < ITEMS; it += 256) {
-            const int c8 = (it % (CC / 8)) * 8;
-            const int px = it / (CC / 8);
-            const int pw = px % PW, ph = px / PW;
-            const int hi = h0 + ph - 1, wi = w0 + pw - 1;
-            const bool inb = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            const int hc = inb ? hi : 0, wc = inb ? wi : 0;          // clamped: every load is unconditional
-            const float* src = X + ((long)hc * p.W + wc) * p.ldx + cbase + c8;
-            float4 f0 = *reinterpret_cast<const float4*>(src);
-            float4 f1 = *reinterpret_cast<const float4*>(src + 4);
-            float mk = mrow[wc * p.mask_ws];
-            mk = inb ? mk : 0.f;
-            if (p.pro_stats) {
-                const int c = cbase + c8;
-                const int g = c / (p.Cin / 8);
-                const float mean = smean[g], rstd = srstd[g];
-                const float4 ga0 = *reinterpret_cast<const float4*>(p.pro_gamma + c), ga1 = *reinterpret_cast<const float4*>(p.pro_gamma + c + 4);
-                const float4 be0 = *reinterpret_cast<const float4*>(p.pro_beta + c), be1 = *reinterpret_cast<const float4*>(p.pro_beta + c + 4);
-                const float* ta = p.pro_tadd + (long)step * p.Cin + c;
-                const float4 t0 = *reinterpret_cast<const float4*>(ta), t1 = *reinterpret_cast<const float4*>(ta + 4);
-                f0.x = cv_mish((f0.x - mean) * rstd * ga0.x + be0.x) + t0.x; f0.y = cv_mish((f0.y - mean) * rstd * ga0.y + be0.y) + t0.y;
-                f0.z = cv_mish((f0.z - mean) * rstd * ga0.z + be0.z) + t0.z; f0.w = cv_mish((f0.w - mean) * rstd * ga0.w + be0.w) + t0.w;
-                f1.x = cv_mish((f1.x - mean) * rstd * ga1.x + be1.x) + t1.x; f1.y = cv_mish((f1.y - mean) * rstd * ga1.y + be1.y) + t1.y;
-                f1.z = cv_mish((f1.z - mean) * rstd * ga1.z + be1.z) + t1.z; f1.w = cv_mish((f1.w - mean) * rstd * ga1.w + be1.w) + t1.w;
-            }
-            f0.x *= mk; f0.y *= mk; f0.z *= mk; f0.w *= mk; f1.x *= mk; f1.y *= mk; f1.z *= mk; f1.w *= mk;
-            uint4 v;
-            v.x = cv_pack_bf16(f0.x, f0.y); v.y = cv_pack_bf16(f0.z, f0.w);
-            v.z = cv_pack_bf16(f1.x, f1.y); v.w = cv_pack_bf16(f1.z, f1.w);
-            *reinterpret_cast<uint4*>(patch + px * LDP + c8) = v;
-        }
-        // ---- taps: weights of tap t live in wbuf[t&1]; tap t+1 is fetched into registers before the MFMAs of
-        // tap t and written to the other buffer after them (one barrier per tap).
-        {
+        cv_stage_patch<CC, TH>(p, X, mrow, patch, h0, w0, cbase, step, smean, srstd, tid);
 #pragma unroll
-            for (int j = 0; j < WPT; ++j) {
-                const int it = tid + 256 * j;
-                const int n = it / (CC / 8), c8 = (it % (CC / 8)) * 8;
-                *reinterpret_cast<uint4*>(wbuf + n * LDP + c8) = *reinterpret_cast<const uint4*>(Wg + (long)n * K + cbase + c8);
-            }
+        for (int j = 0; j < WPT; ++j) {
+            const int it = tid + 256 * j;
+            const int n = it / (CC / 8), c8 = (it % (CC / 8)) * 8;
+            *reinterpret_cast<uint4*>(wbuf + n * LDP + c8) = *reinterpret_cast<const uint4*>(Wg + (long)n * K + cbase + c8);
         }
         for (int tap = 0; tap < 9; ++tap) {
             __syncthreads();                          // patch + this tap's weights visible; the other buffer is free
@@ -161,36 +209,83 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
             }
         }
     }
+    cv_epilogue<NT, COUT>(p, acc, b, h0 + wrow, w0, wcol * NT * 32, lane, tid, gnred);
+}
 
-    // ---- epilogue: rows of the 32x32 tile = pixels (w0 + row) of image row h0 + wrow; cols = channels
-    const int ho = h0 + wrow;
-    float* Y = p.Y + (long)b * p.H * p.W * COUT;
+// ---- RESIDENT weights: a workgroup owns output channels [slice*NSL, +NSL) and all nine taps of them ------------
+// grid.z = b * (COUT/NSL) + slice.
+template <int CC, int COUT, int NSL, int TH>
+__global__ __launch_bounds__(256) void conv3x3_bf16_res_kernel(const Conv3P p) {
+    constexpr int PW = 34, PH = TH + 2;
+    constexpr int LDP = CC + 8;
+    constexpr int WN = 4 / TH;
+    constexpr int NT = NSL / 32 / WN;
+    constexpr int NSLICE = COUT / NSL;
+    static_assert(NT >= 1, "tile");
+    extern __shared__ __attribute__((aligned(16))) u16 smem[];
+    u16* patch = smem;                                // [PH*PW][LDP]
+    u16* wres = smem + PH * PW * LDP;                 // [9][NSL][LDP]
+    __shared__ float smean[8], srstd[8], gnred[16];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int wrow = wave % TH, wcol = wave / TH;
+    const int w0 = blockIdx.x * 32, h0 = blockIdx.y * TH;
+    const int b = blockIdx.z / NSLICE, slice = blockIdx.z % NSLICE;
+    const int step = p.step ? *p.step : 0;
+    const float* X = p.X + (long)b * p.H * p.W * p.ldx + p.x_coff;
+    const float* mrow = p.mask + (long)b * p.mask_bstride;
+    const int K = 9 * p.Cin;
+    const u16* Wg = reinterpret_cast<const u16*>(p.Wbf) + (long)slice * NSL * K;   // rows of this slice
+
+    f32x16 acc[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int n = (wcol * NT + t) * 32 + i;
-        const float bias = p.bias[n];
-        float gs = 0.f, gss = 0.f;
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int wo = w0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const bool ok = ho < p.H && wo < p.W;
-            const float v = acc[t][r] + bias;
-            const float vs = ok ? v : 0.f;
-            gs += vs; gss = fmaf(vs, vs, gss);
-            if (ok) Y[((long)ho * p.W + wo) * COUT + n] = v;
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    constexpr int WITEMS = 9 * NSL * (CC / 8);
+    constexpr int WPT = (WITEMS + 255) / 256;
+    const int nchunk = p.Cin / CC;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int cbase = ch * CC;
+        if (ch > 0) __syncthreads();                  // previous chunk fully consumed
+        // all weight loads of the chunk first (independent of everything), then the patch
+        uint4 wr[WPT];
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            const int it = min(tid + 256 * j, WITEMS - 1);
+            const int c8 = (it % (CC / 8)) * 8, n = (it / (CC / 8)) % NSL, tap = it / ((CC / 8) * NSL);
+            wr[j] = *reinterpret_cast<const uint4*>(Wg + (long)n * K + (long)tap * p.Cin + cbase + c8);
         }
-        if (p.gn_stats) {
-            constexpr int cpg = COUT / 8;
-            for (int o = 1; o < cpg; o <<= 1) { gs += __shfl_xor(gs, o); gss += __shfl_xor(gss, o); }
-            gs += __shfl_xor(gs, 32); gss += __shfl_xor(gss, 32);
-            if (hh == 0 && (i & (cpg - 1)) == 0) {
-                const int slot = (blockIdx.x + blockIdx.y * gridDim.x) % GN_SLOTS;
-                double* dst = p.gn_stats + (((long)b * 8 + n / cpg) * GN_SLOTS + slot) * 2;
-                atomicAdd(dst, (double)gs);
-                atomicAdd(dst + 1, (double)gss);
+        if (ch == 0 && p.pro_stats) { cv_gn_coeffs(p, b, tid, smean, srstd); __syncthreads(); }
+        cv_stage_patch<CC, TH>(p, X, mrow, patch, h0, w0, cbase, step, smean, srstd, tid);
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            const int it = tid + 256 * j;
+            if (it < WITEMS) {
+                const int c8 = (it % (CC / 8)) * 8, n = (it / (CC / 8)) % NSL, tap = it / ((CC / 8) * NSL);
+                *reinterpret_cast<uint4*>(wres + (tap * NSL + n) * LDP + c8) = wr[j];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int kh = tap / 3, kw = tap - kh * 3;
+            const u16* ap = patch + ((wrow + kh) * PW + i + kw) * LDP + hh * 8;
+            const u16* bp = wres + (tap * NSL + wcol * NT * 32 + i) * LDP + hh * 8;
+#pragma unroll
+            for (int ks = 0; ks < CC / 16; ++ks) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(ap + ks * 16);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bp + t * 32 * LDP + ks * 16);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
+                }
             }
         }
     }
+    cv_epilogue<NT, COUT>(p, acc, b, h0 + wrow, w0, slice * NSL + wcol * NT * 32, lane, tid, gnred);
 }
 
 template <int CC, int COUT, int TH>
@@ -205,19 +300,37 @@ static void launch_c3(const Conv3P& p, hipStream_t st) {
     dim3 grid((p.W + 31) / 32, (p.H + TH - 1) / TH, p.B);
     hipLaunchKernelGGL((conv3x3_bf16_kernel<CC, COUT, TH>), grid, dim3(256), lds, st, p);
 }
+template <int CC, int COUT, int NSL, int TH>
+static void launch_c3r(const Conv3P& p, hipStream_t st) {
+    constexpr int LDP = CC + 8;
+    const size_t lds = ((size_t)(TH + 2) * 34 * LDP + 9 * NSL * LDP) * sizeof(u16);
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_res_kernel<CC, COUT, NSL, TH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    dim3 grid((p.W + 31) / 32, (p.H + TH - 1) / TH, p.B * (COUT / NSL));
+    hipLaunchKernelGGL((conv3x3_bf16_res_kernel<CC, COUT, NSL, TH>), grid, dim3(256), lds, st, p);
+}
 
 bool conv3x3_bf16_supported(int Cin, int Cout) {
     return (Cin == 64 || Cin == 128 || Cin == 256) && (Cout == 64 || Cout == 128);
 }
 
 void launch_conv3x3_bf16(const Conv3P& p, hipStream_t st) {
-    // few tiles (half resolution at B=1): 2-row tiles double the workgroup count
     const long tiles4 = (long)((p.W + 31) / 32) * ((p.H + 3) / 4) * p.B;
+    if (tiles4 * (p.Cin >= 128 ? p.Cout / 32 : 1) <= 1536) {
+        // latency regime: resident weights, every load issued up front
+        if (p.Cin == 64 && p.Cout == 64) { tiles4 < 192 ? launch_c3r<64, 64, 64, 2>(p, st) : launch_c3r<64, 64, 64, 4>(p, st); }
+        else if (p.Cin == 64 && p.Cout == 128) { tiles4 < 192 ? launch_c3r<64, 128, 64, 2>(p, st) : launch_c3r<64, 128, 64, 4>(p, st); }
+        else if (p.Cout == 128) launch_c3r<128, 128, 32, 4>(p, st);     // Cin 128 (or 256 in two chunks)
+        else launch_c3r<128, 64, 32, 4>(p, st);                         // Cin 128 / 256 -> 64
+        return;
+    }
     const bool small = tiles4 < 256;
     if (p.Cout == 64) {
         if (p.Cin == 64) { small ? launch_c3<64, 64, 2>(p, st) : launch_c3<64, 64, 4>(p, st); }
-        else if (p.Cin == 128) { small ? launch_c3<128, 64, 2>(p, st) : launch_c3<128, 64, 4>(p, st); }
-        else { small ? launch_c3<128, 64, 2>(p, st) : launch_c3<128, 64, 4>(p, st); }          // Cin 256: two chunks
+        else { small ? launch_c3<128, 64, 2>(p, st) : launch_c3<128, 64, 4>(p, st); }          // Cin 128 / 256 (two chunks)
     } else {
         if (p.Cin == 64) { small ? launch_c3<64, 128, 2>(p, st) : launch_c3<64, 128, 4>(p, st); }
         else { small ? launch_c3<128, 128, 2>(p, st) : launch_c3<128, 128, 4>(p, st); }

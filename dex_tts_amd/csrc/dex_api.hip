@@ -489,7 +489,7 @@ struct Plan {
     std::vector<float*> tadd_down, tadd_up, ada;
     float *adap_tmp, *t_adap, *t_sty, *tv_k0, *tv_v0, *sap_m, *sap_s, *ref_mean, *ref_std;
     float *spk_tmp, *spk_plane;
-    int* step; double* stats; long stats_bytes; int n_gn;
+    int* step; float* stats; long stats_bytes; int n_gn;
     float* xbuf;
     std::vector<StageBuf> down, up;
     std::vector<float*> cat;
@@ -524,8 +524,8 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
     if (c.n_spks > 1) { P.spk_tmp = A.f((size_t)B * 4 * c.spk_emb_dim); P.spk_plane = A.f((size_t)B * c.n_feats); }
     P.step = (int*)A.take(256);
     P.n_gn = 4 * c.n_stages + 4 * (c.n_stages - 1) + 1;
-    P.stats_bytes = (long)P.n_gn * B * 8 * GN_SLOTS * 2 * sizeof(double);
-    P.stats = (double*)A.take(P.stats_bytes);
+    P.stats_bytes = (long)P.n_gn * B * 8 * GN_SLOTS * 2 * sizeof(float);
+    P.stats = (float*)A.take(P.stats_bytes);
     P.xbuf = A.f((size_t)B * 80 * d.T);
     P.cat.assign(c.n_stages - 1, nullptr);
     for (int j = 0; j < c.n_stages - 1; ++j) {
@@ -594,7 +594,7 @@ struct Runner {
             x->prof.push_back(pr);
         } else f();
     }
-    double* next_stats() { return P.stats + (size_t)(gn_idx++) * P.d.B * 8 * GN_SLOTS * 2; }
+    float* next_stats() { return P.stats + (size_t)(gn_idx++) * P.d.B * 8 * GN_SLOTS * 2; }
     void tap(const char* name, const float* p, long rows, int C, int ld) {
         if (!debug) return;
         DexCtx::Tap t; t.name = name; t.p = p; t.shape = {rows, C, ld};
@@ -629,10 +629,10 @@ struct Runner {
     }
     // Block conv (diffusion.py:44).  pro != null fuses the producer's GN-apply + Mish + time bias into the load
     // (bf16 patch kernel only).
-    struct Pro { const double* stats; const float *gamma, *beta, *tadd; };
+    struct Pro { const float* stats; const float *gamma, *beta, *tadd; };
     bool fast_conv(int cin, int cout) const { return x->precision == DEX_PREC_BF16 && conv3x3_bf16_supported(cin, cout); }
     void conv3x3(const char* name, const TD& X, int H, int W, int mask_ws, bool inmask, const float* Wt, const float* bias, int Cout, float* out,
-                 double* gn = nullptr, const Pro* pro = nullptr) {
+                 float* gn = nullptr, const Pro* pro = nullptr) {
         auto it = x->bf16_of.find(Wt);
         if (fast_conv(X.C, Cout) && it != x->bf16_of.end()) {
             Conv3P c{};
@@ -650,11 +650,11 @@ struct Runner {
         g.gn_stats = gn; g.gn_groups = 8; g.gn_cpg = Cout / 8;
         gemm(name, g);
     }
-    void gn_stats(const float* h, int C, long npix, double* stats) {
+    void gn_stats(const float* h, int C, long npix, float* stats) {
         GnStatsP s{h, C, npix * C, (int)npix, C, 8, stats, P.d.B};
         run("gn_stats", 3.0 * npix * C * P.d.B, 4.0 * npix * C * P.d.B, [&] { launch_gn_stats(s, st); });
     }
-    void gn_apply(const float* h, int C, long npix, int W, int mask_ws, const double* stats, const float* gamma, const float* beta,
+    void gn_apply(const float* h, int C, long npix, int W, int mask_ws, const float* stats, const float* gamma, const float* beta,
                   const float* tadd, const float* res, int ldres, long resb, bool res_under_mask, float* out) {
         GnApplyP a{};
         a.X = h; a.ldx = C; a.xb = npix * C; a.Y = out; a.ldy = C; a.yb = npix * C; a.y_coff = 0;
@@ -669,7 +669,7 @@ struct Runner {
     void resblock(const ResW& w, const StageBuf& s, const TD& X, const float* tadd, float* out, bool first_layer) {
         const long npix = s.npix;
         const float* resptr; int ldres; long resb; bool under = false;
-        double* st1 = nullptr;
+        float* st1 = nullptr;
         if (first_layer) {
             FirstConvP f{};
             f.mu = mu; f.x = xcur; f.spk = P.spk_plane; f.mask = mask; f.B = P.d.B; f.H = s.H; f.T = s.W; f.planes = w.cin; f.C = w.cout;
@@ -690,7 +690,7 @@ struct Runner {
             }
         }
         if (!st1) { st1 = next_stats(); gn_stats(s.h1, w.cout, npix, st1); }
-        double* st2 = next_stats();
+        float* st2 = next_stats();
         if (fast_conv(w.cout, w.cout)) {
             // block1's GN-apply + Mish + time bias + mask is applied while block2's conv stages its input patch
             Pro pro{st1, w.g1, w.be1, tadd};
@@ -882,7 +882,7 @@ struct Runner {
         }
         tap("up_out", P.up_out, (long)B * 80 * P.d.T, c.dim, c.dim);
         TD U{P.up_out, c.dim, 0, c.dim};
-        double* stf = next_stats();
+        float* stf = next_stats();
         conv3x3("conv3x3", U, 80, P.d.T, 1, true, x->fin_w, x->fin_b, c.dim, P.hF, stf);
         FinalP f{};
         f.X = P.hF; f.xb = 80L * P.d.T * c.dim; f.npix = 80 * P.d.T; f.W = P.d.T; f.C = c.dim; f.groups = 8; f.stats = stf;

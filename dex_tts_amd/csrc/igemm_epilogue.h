@@ -83,16 +83,16 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmP& p, f32x16 (&acc)[MT
     }
     if (p.gn_stats) {
         // channels-per-group cpg in {8,16,32}: reduce over the cpg lanes of a group and over both half-waves,
-        // then ONE fp64 atomic pair per group per wave into slot (blockIdx.x % GN_SLOTS) — slots spread the
-        // same-address atomic traffic; the consumer sums the slots.
+        // then ONE fp32 atomic pair per group per wave into slot (blockIdx.x % GN_SLOTS) — slots spread the
+        // same-address atomic traffic; the consumer sums the slots in fp64.
         const int cpg = p.gn_cpg;
         for (int o = 1; o < cpg; o <<= 1) { gs += __shfl_xor(gs, o); gss += __shfl_xor(gss, o); }
         gs += __shfl_xor(gs, 32); gss += __shfl_xor(gss, 32);
         if (hh == 0 && (i & (cpg - 1)) == 0) {
             const int grp = ng / cpg;
-            double* dst = p.gn_stats + (((long)b * p.gn_groups + grp) * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * 2;
-            atomicAdd(dst, (double)gs);
-            atomicAdd(dst + 1, (double)gss);
+            float* dst = p.gn_stats + (((long)b * p.gn_groups + grp) * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * 2;
+            atomicAdd(dst, gs);
+            atomicAdd(dst + 1, gss);
         }
     }
 }

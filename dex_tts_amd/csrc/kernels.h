@@ -8,7 +8,8 @@
 
 namespace dex {
 
-constexpr int GN_SLOTS = 16;   // GroupNorm statistics are accumulated into [B][groups][GN_SLOTS][2] fp64 (atomic spreading)
+constexpr int GN_SLOTS = 32;   // GroupNorm statistics: [B][groups][GN_SLOTS][2] fp32 partial sums (native L2 atomics,
+                                // spread over slots; fp64 atomics measured ~170 ns each on one address); consumers sum the slots in fp64
 
 // ------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution / linear:  C[m, n] = epi( sum_k gather(A)[m,k] * W[k,n] )
@@ -34,7 +35,7 @@ struct IGemmP {
     const float* res; int ldres; long res_bstride; int res_coff;
     const int* step;
     int unpatch_s, unpatch_C;                          // >0: scatter rows (f,w) x cols (p1,p2,c) -> NHWC image
-    double* gn_stats; int gn_groups, gn_cpg;           // fused GroupNorm partial statistics of (acc + bias), or null
+    float* gn_stats; int gn_groups, gn_cpg;            // fused GroupNorm partial statistics of (acc + bias), or null
     int B;
 };
 void launch_igemm(const IGemmP& p, int precision, hipStream_t st);
@@ -45,8 +46,9 @@ struct Conv3P {
     const float* X; int ldx; int x_coff; int H, W, Cin, Cout;
     const void* Wbf; const float* bias; float* Y;            // bf16 [Cout][9*Cin]; Y is [B,H,W,Cout] contiguous
     const float* mask; int mask_ws; long mask_bstride;
-    const double* pro_stats; const float* pro_gamma; const float* pro_beta; const float* pro_tadd;
-    const int* step; double* gn_stats; int B;
+    const float* pro_stats; const float* pro_gamma; const float* pro_beta; const float* pro_tadd;
+    const int* step; float* gn_stats; int B;
+    long long* dbg;                                          // optional phase timestamps (tools/kbench)
 };
 bool conv3x3_bf16_supported(int Cin, int Cout);
 void launch_conv3x3_bf16(const Conv3P& p, hipStream_t st);
@@ -64,14 +66,14 @@ struct FirstConvP {
 void launch_first_conv(const FirstConvP& p, hipStream_t st);
 
 // GroupNorm statistics: per (b, group) sum / sum-of-squares in fp64 (biased variance later).
-struct GnStatsP { const float* X; int ld; long bstride; int npix; int C; int groups; double* stats; int B; };
+struct GnStatsP { const float* X; int ld; long bstride; int npix; int C; int groups; float* stats; int B; };
 void launch_gn_stats(const GnStatsP& p, hipStream_t st);
 
 // y = mask*(Mish(GN(x)) + tadd[c]) + res   (Block / ResnetBlock tails, diffusion.py:41-50,66-71)
 struct GnApplyP {
     const float* X; int ldx; long xb;
     float* Y; int ldy; long yb; int y_coff;
-    int npix, W, C, groups; const double* stats; const float* gamma; const float* beta;
+    int npix, W, C, groups; const float* stats; const float* gamma; const float* beta;
     const float* mask; int mask_ws; long mask_bstride;
     const float* tadd; long tadd_step_stride; const int* step;
     const float* res; int ldres; long resb; int res_under_mask;   // 1: y = mask*(mish + tadd + res)
@@ -81,7 +83,7 @@ void launch_gn_apply(const GnApplyP& p, hipStream_t st);
 
 // final_block tail + final_conv + EDM combine + Euler update (diffusion.py:204-207, edm.py:97,202-208)
 struct FinalP {
-    const float* X; long xb; int npix, W, C, groups; const double* stats; const float* gamma; const float* beta;
+    const float* X; long xb; int npix, W, C, groups; const float* stats; const float* gamma; const float* beta;
     const float* mask; long mask_bstride;
     const float* wfc; const float* bfc;                   // final_conv weight [C], bias [1]
     const float* xcur;                                    // [B,80,T] current sampler state (x_hat)

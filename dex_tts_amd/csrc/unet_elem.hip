@@ -17,12 +17,12 @@ __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x))
 
 
 // mean / rstd of each GroupNorm group from the slot-spread fp64 partials: thread (g = tid/16, slot = tid%16)
-// loads one (sum, sumsq) pair, 16-lane shuffle reduce — one global round trip instead of 16 serial ones.
-__device__ __forceinline__ void gn_mean_rstd(const double* stats, int b, int groups, double n, float* smean, float* srstd, int tid) {
+// loads one (sum, sumsq) pair, GN_SLOTS-lane shuffle reduce — one global round trip instead of 16 serial ones.
+__device__ __forceinline__ void gn_mean_rstd(const float* stats, int b, int groups, double n, float* smean, float* srstd, int tid) {
     if (tid < groups * GN_SLOTS) {
         const int g = tid / GN_SLOTS;
-        const double* src = stats + (((long)b * groups + g) * GN_SLOTS + (tid % GN_SLOTS)) * 2;
-        double s1 = src[0], s2 = src[1];
+        const float* src = stats + (((long)b * groups + g) * GN_SLOTS + (tid % GN_SLOTS)) * 2;
+        double s1 = (double)src[0], s2 = (double)src[1];
         for (int o = 1; o < GN_SLOTS; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
         if ((tid % GN_SLOTS) == 0) {
             const double mean = s1 / n;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnStatsP p) {
     __syncthreads();
     if (tid < p.groups * 2) {
         const int gg = tid >> 1, k = tid & 1;
-        atomicAdd(p.stats + (((long)b * p.groups + gg) * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * 2 + k, red[gg][k]);
+        atomicAdd(p.stats + (((long)b * p.groups + gg) * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * 2 + k, (float)red[gg][k]);
     }
 }
 void launch_gn_stats(const GnStatsP& p, hipStream_t st) {

@@ -1,0 +1,84 @@
+// kbench: isolated timing of libdexamd kernels (steady state, back-to-back launches of the same kernel).
+//   hipcc --offload-arch=gfx950 -O3 -I dex_tts_amd/csrc tools/kbench.hip -L dex_tts_amd/lib -ldexamd -Wl,-rpath,$PWD/dex_tts_amd/lib -o tools/kbench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <functional>
+#include <algorithm>
+#include "kernels.h"
+using namespace dex;
+
+static float* dalloc(size_t n, float val = 0.01f) {
+    float* p; hipMalloc(&p, n * 4);
+    std::vector<float> h(n);
+    for (size_t i = 0; i < n; ++i) h[i] = val * (float)((i * 2654435761u) % 1000) / 1000.f - val * 0.5f;
+    hipMemcpy(p, h.data(), n * 4, hipMemcpyHostToDevice);
+    return p;
+}
+static void timeit(const char* name, int iters, double flops, double bytes, std::function<void()> f) {
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    for (int i = 0; i < 3; ++i) f();
+    hipDeviceSynchronize();
+    hipEventRecord(a, 0);
+    for (int i = 0; i < iters; ++i) f();
+    hipEventRecord(b, 0); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    const double us = ms * 1e3 / iters;
+    printf("%-44s %8.2f us  %8.2f TF/s %8.1f GB/s\n", name, us, flops / us * 1e-6, bytes / us * 1e-3);
+}
+
+int main() {
+    const int B = 1, T = 512;
+    // ---- attention N=650 (GeDEX) and N=2580 (DEX)
+    for (int N : {650, 2580}) {
+        float* qkv = dalloc((size_t)B * N * 768, 1.0f);
+        float* o = dalloc((size_t)B * N * 256);
+        AttnP a{}; a.Q = qkv; a.ldq = 768; a.qb = (long)N * 768; a.K = qkv + 256; a.ldk = 768; a.kb = a.qb; a.V = qkv + 512; a.ldv = 768; a.vb = a.qb;
+        a.O = o; a.ldo = 256; a.ob = (long)N * 256; a.Nq = N; a.Nk = N; a.heads = 2; a.scale = 0.088f; a.B = B;
+        char nm[64];
+        snprintf(nm, 64, "attention fp32 N=%d", N); timeit(nm, 50, 4.0 * N * N * 256, 16.0 * N * 256, [&] { launch_attention(a, 0, 0); });
+        snprintf(nm, 64, "attention bf16 N=%d", N); timeit(nm, 50, 4.0 * N * N * 256, 16.0 * N * 256, [&] { launch_attention(a, 1, 0); });
+    }
+    // ---- conv3x3 64->64 @80x512 and 128->128 @40x256 (bf16 patch kernel and fp32 igemm)
+    struct CS { int H, W, Cin, Cout; };
+    for (CS c : {CS{80, 512, 64, 64}, CS{40, 256, 128, 128}, CS{40, 256, 256, 64}}) {
+        const long npix = (long)c.H * c.W;
+        float* x = dalloc(B * npix * c.Cin, 1.0f); float* y = dalloc(B * npix * c.Cout);
+        float* w = dalloc(9L * c.Cin * c.Cout, 0.1f); float* bias = dalloc(c.Cout);
+        unsigned short* wb; hipMalloc(&wb, 9L * c.Cin * c.Cout * 2); hipMemset(wb, 0, 9L * c.Cin * c.Cout * 2);
+        float* mask = dalloc(B * T, 0.f); hipMemset(mask, 0, 4); // values irrelevant
+        float* st; hipMalloc(&st, 8 * 64 * 2 * 8 * B); hipMemset(st, 0, 8 * 64 * 2 * 8 * B);
+        Conv3P p{}; p.X = x; p.ldx = c.Cin; p.H = c.H; p.W = c.W; p.Cin = c.Cin; p.Cout = c.Cout; p.Wbf = wb; p.bias = bias; p.Y = y;
+        p.mask = mask; p.mask_ws = 512 / c.W; p.mask_bstride = T; p.gn_stats = st; p.B = B;
+        char nm[80];
+        const double fl = 2.0 * npix * c.Cout * 9 * c.Cin, by = 4.0 * npix * (c.Cin + c.Cout);
+        snprintf(nm, 80, "conv3x3 bf16 patch %d->%d @%dx%d", c.Cin, c.Cout, c.H, c.W); timeit(nm, 50, fl, by, [&] { launch_conv3x3_bf16(p, 0); });
+        p.gn_stats = nullptr;
+        snprintf(nm, 80, "  .. same, no GN atomics"); timeit(nm, 50, fl, by, [&] { launch_conv3x3_bf16(p, 0); });
+        p.gn_stats = st;
+        IGemmP g{}; g.A = x; g.lda = c.Cin; g.a_bstride = npix * c.Cin; g.Hi = c.H; g.Wi = c.W; g.Cin = c.Cin; g.KH = 3; g.KW = 3; g.sh = g.sw = 1; g.off_h = g.off_w = -1;
+        g.step_h = g.step_w = 1; g.Ho = c.H; g.Wo = c.W; g.W = w; g.Wbf = wb; g.N = c.Cout; g.K = 9 * c.Cin; g.ksplit = 1; g.groups = 1; g.bias = bias;
+        g.C = y; g.ldc = c.Cout; g.c_bstride = npix * c.Cout; g.OHf = c.H; g.OWf = c.W; g.osh = g.osw = 1; g.gate_nstride = 1; g.B = B; g.mask_bstride = T;
+        g.gn_stats = st; g.gn_groups = 8; g.gn_cpg = c.Cout / 8;
+        snprintf(nm, 80, "conv3x3 bf16 igemm %d->%d @%dx%d", c.Cin, c.Cout, c.H, c.W); timeit(nm, 50, fl, by, [&] { launch_igemm(g, 1, 0); });
+        snprintf(nm, 80, "conv3x3 fp32 igemm %d->%d @%dx%d", c.Cin, c.Cout, c.H, c.W); timeit(nm, 50, fl, by, [&] { launch_igemm(g, 0, 0); });
+    }
+    // ---- DiT linear M=650 K=256 N=768 / K=512 N=256
+    struct LS { int M, K, N; };
+    for (LS l : {LS{650, 256, 768}, LS{650, 512, 256}, LS{650, 256, 512}, LS{40960, 64, 384}}) {
+        float* x = dalloc((size_t)l.M * l.K, 1.0f); float* y = dalloc((size_t)l.M * l.N); float* w = dalloc((size_t)l.K * l.N, 0.1f);
+        unsigned short* wb; hipMalloc(&wb, (size_t)l.K * l.N * 2); hipMemset(wb, 0, (size_t)l.K * l.N * 2);
+        IGemmP g{}; g.A = x; g.lda = l.K; g.a_bstride = (long)l.M * l.K; g.Hi = 1; g.Wi = l.M; g.Cin = l.K; g.KH = g.KW = 1; g.sh = g.sw = 1; g.step_h = g.step_w = 1;
+        g.Ho = 1; g.Wo = l.M; g.W = w; g.Wbf = wb; g.N = l.N; g.K = l.K; g.ksplit = 1; g.groups = 1; g.C = y; g.ldc = l.N; g.c_bstride = (long)l.M * l.N;
+        g.OHf = 1; g.OWf = l.M; g.osh = g.osw = 1; g.gate_nstride = 1; g.B = 1;
+        char nm[80];
+        const double fl = 2.0 * l.M * l.K * l.N, by = 4.0 * (l.M * l.K + l.M * l.N + l.K * l.N);
+        snprintf(nm, 80, "linear bf16 M=%d K=%d N=%d", l.M, l.K, l.N); timeit(nm, 50, fl, by, [&] { launch_igemm(g, 1, 0); });
+        snprintf(nm, 80, "linear fp32 M=%d K=%d N=%d", l.M, l.K, l.N); timeit(nm, 50, fl, by, [&] { launch_igemm(g, 0, 0); });
+    }
+    // ---- trivial kernel floor
+    int* stp; hipMalloc(&stp, 4);
+    timeit("step_inc (launch floor)", 200, 0, 0, [&] { launch_step_inc(stp, 0); });
+    return 0;
+}
