@@ -131,28 +131,35 @@ __device__ __forceinline__ void cv_epilogue(const Conv3P& p, f32x16 (&acc)[NT], 
     }
 }
 
-// ---- STREAMED weights: CC channels per chunk, all COUT channels, TH rows (waves: TH x (4/TH)) -----------------
-template <int CC, int COUT, int TH>
+// CC channels per chunk, output-channel slice [slice*NSL, +NSL) of COUT, TH rows (waves: TH x (4/TH)).
+// grid.z = b * (COUT/NSL) + slice.
+template <int CC, int COUT, int NSL, int TH>
 __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
     constexpr int PW = 34, PH = TH + 2;
     constexpr int LDP = CC + 8;
     constexpr int WN = 4 / TH;
-    constexpr int NT = COUT / 32 / WN;
+    constexpr int NT = NSL / 32 / WN;
+    constexpr int NSLICE = COUT / NSL;
     static_assert(NT >= 1, "tile");
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* patch = smem;                                // [PH*PW][LDP]
-    u16* wbuf = smem + PH * PW * LDP;                 // [2][COUT][LDP]
+    u16* wbuf = smem + PH * PW * LDP;                 // [2][NSL][LDP]
     __shared__ float smean[8], srstd[8], gnred[16];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
     const int wrow = wave % TH, wcol = wave / TH;
-    const int w0 = blockIdx.x * 32, h0 = blockIdx.y * TH, b = blockIdx.z;
+    const int w0 = blockIdx.x * 32, h0 = blockIdx.y * TH;
+    const int b = blockIdx.z / NSLICE, slice = blockIdx.z % NSLICE;
     const int step = p.step ? *p.step : 0;
     const float* X = p.X + (long)b * p.H * p.W * p.ldx + p.x_coff;
     const float* mrow = p.mask + (long)b * p.mask_bstride;
-    const u16* Wg = reinterpret_cast<const u16*>(p.Wbf);     // [COUT][9*Cin]
     const int K = 9 * p.Cin;
+    const u16* Wg = reinterpret_cast<const u16*>(p.Wbf) + (long)slice * NSL * K;     // [COUT][9*Cin], rows of this slice
+#ifdef DEX_TIMING
+    long long tst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    tst[7] = wall_clock64();
+#endif
     if (p.pro_stats) { cv_gn_coeffs(p, b, tid, smean, srstd); __syncthreads(); }
 
     f32x16 acc[NT];
@@ -161,7 +168,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    constexpr int WPT = COUT * CC / 8 / 256;
+    constexpr int WPT = NSL * CC / 8 / 256;
     static_assert(WPT >= 1, "weights per thread");
     const int nchunk = p.Cin / CC;
     for (int ch = 0; ch < nchunk; ++ch) {
@@ -175,8 +182,14 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
             *reinterpret_cast<uint4*>(wbuf + n * LDP + c8) = *reinterpret_cast<const uint4*>(Wg + (long)n * K + cbase + c8);
         }
         for (int tap = 0; tap < 9; ++tap) {
+#ifdef DEX_TIMING
+            if (tap == 1) tst[0] = wall_clock64();
+#endif
             __syncthreads();                          // patch + this tap's weights visible; the other buffer is free
-            const u16* wb = wbuf + (tap & 1) * COUT * LDP;
+#ifdef DEX_TIMING
+            if (tap == 1) tst[1] = wall_clock64();
+#endif
+            const u16* wb = wbuf + (tap & 1) * NSL * LDP;
             uint4 wnext[WPT];
             if (tap + 1 < 9) {
 #pragma unroll
@@ -186,6 +199,9 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
                     wnext[j] = *reinterpret_cast<const uint4*>(Wg + (long)n * K + (long)(tap + 1) * p.Cin + cbase + c8);
                 }
             }
+#ifdef DEX_TIMING
+            if (tap == 1) tst[2] = wall_clock64();
+#endif
             const int kh = tap / 3, kw = tap - kh * 3;
             const u16* ap = patch + ((wrow + kh) * PW + i + kw) * LDP + hh * 8;
             const u16* bp = wb + (wcol * NT * 32 + i) * LDP + hh * 8;
@@ -198,8 +214,11 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
                 }
             }
+#ifdef DEX_TIMING
+            if (tap == 1) { asm volatile("s_nop 0" :: "v"(acc[0][0])); tst[3] = wall_clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tst[4] = wall_clock64(); }
+#endif
             if (tap + 1 < 9) {
-                u16* wn = wbuf + ((tap + 1) & 1) * COUT * LDP;
+                u16* wn = wbuf + ((tap + 1) & 1) * NSL * LDP;
 #pragma unroll
                 for (int j = 0; j < WPT; ++j) {
                     const int it = tid + 256 * j;
@@ -209,108 +228,26 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
             }
         }
     }
-    cv_epilogue<NT, COUT>(p, acc, b, h0 + wrow, w0, wcol * NT * 32, lane, tid, gnred);
-}
-
-// ---- RESIDENT weights: a workgroup owns output channels [slice*NSL, +NSL) and all nine taps of them ------------
-// grid.z = b * (COUT/NSL) + slice.
-template <int CC, int COUT, int NSL, int TH>
-__global__ __launch_bounds__(256) void conv3x3_bf16_res_kernel(const Conv3P p) {
-    constexpr int PW = 34, PH = TH + 2;
-    constexpr int LDP = CC + 8;
-    constexpr int WN = 4 / TH;
-    constexpr int NT = NSL / 32 / WN;
-    constexpr int NSLICE = COUT / NSL;
-    static_assert(NT >= 1, "tile");
-    extern __shared__ __attribute__((aligned(16))) u16 smem[];
-    u16* patch = smem;                                // [PH*PW][LDP]
-    u16* wres = smem + PH * PW * LDP;                 // [9][NSL][LDP]
-    __shared__ float smean[8], srstd[8], gnred[16];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = lane & 31, hh = lane >> 5;
-    const int wrow = wave % TH, wcol = wave / TH;
-    const int w0 = blockIdx.x * 32, h0 = blockIdx.y * TH;
-    const int b = blockIdx.z / NSLICE, slice = blockIdx.z % NSLICE;
-    const int step = p.step ? *p.step : 0;
-    const float* X = p.X + (long)b * p.H * p.W * p.ldx + p.x_coff;
-    const float* mrow = p.mask + (long)b * p.mask_bstride;
-    const int K = 9 * p.Cin;
-    const u16* Wg = reinterpret_cast<const u16*>(p.Wbf) + (long)slice * NSL * K;   // rows of this slice
-
-    f32x16 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-    constexpr int WITEMS = 9 * NSL * (CC / 8);
-    constexpr int WPT = (WITEMS + 255) / 256;
-    const int nchunk = p.Cin / CC;
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const int cbase = ch * CC;
-        if (ch > 0) __syncthreads();                  // previous chunk fully consumed
-        // all weight loads of the chunk first (independent of everything), then the patch
-        uint4 wr[WPT];
-#pragma unroll
-        for (int j = 0; j < WPT; ++j) {
-            const int it = min(tid + 256 * j, WITEMS - 1);
-            const int c8 = (it % (CC / 8)) * 8, n = (it / (CC / 8)) % NSL, tap = it / ((CC / 8) * NSL);
-            wr[j] = *reinterpret_cast<const uint4*>(Wg + (long)n * K + (long)tap * p.Cin + cbase + c8);
-        }
-        if (ch == 0 && p.pro_stats) { cv_gn_coeffs(p, b, tid, smean, srstd); __syncthreads(); }
-        cv_stage_patch<CC, TH>(p, X, mrow, patch, h0, w0, cbase, step, smean, srstd, tid);
-#pragma unroll
-        for (int j = 0; j < WPT; ++j) {
-            const int it = tid + 256 * j;
-            if (it < WITEMS) {
-                const int c8 = (it % (CC / 8)) * 8, n = (it / (CC / 8)) % NSL, tap = it / ((CC / 8) * NSL);
-                *reinterpret_cast<uint4*>(wres + (tap * NSL + n) * LDP + c8) = wr[j];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int kh = tap / 3, kw = tap - kh * 3;
-            const u16* ap = patch + ((wrow + kh) * PW + i + kw) * LDP + hh * 8;
-            const u16* bp = wres + (tap * NSL + wcol * NT * 32 + i) * LDP + hh * 8;
-#pragma unroll
-            for (int ks = 0; ks < CC / 16; ++ks) {
-                const bf16x8 af = *reinterpret_cast<const bf16x8*>(ap + ks * 16);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bp + t * 32 * LDP + ks * 16);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
-                }
-            }
-        }
-    }
+#ifdef DEX_TIMING
+    tst[5] = wall_clock64();
+#endif
     cv_epilogue<NT, COUT>(p, acc, b, h0 + wrow, w0, slice * NSL + wcol * NT * 32, lane, tid, gnred);
+#ifdef DEX_TIMING
+    if (p.dbg && tid == 0) { tst[6] = wall_clock64(); long long* d = p.dbg + ((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 8; for (int k = 0; k < 8; ++k) d[k] = tst[k]; }
+#endif
 }
 
-template <int CC, int COUT, int TH>
+template <int CC, int COUT, int NSL, int TH>
 static void launch_c3(const Conv3P& p, hipStream_t st) {
     constexpr int LDP = CC + 8;
-    const size_t lds = ((size_t)(TH + 2) * 34 * LDP + 2 * COUT * LDP) * sizeof(u16);
+    const size_t lds = ((size_t)(TH + 2) * 34 * LDP + 2 * NSL * LDP) * sizeof(u16);
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<CC, COUT, TH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
-    dim3 grid((p.W + 31) / 32, (p.H + TH - 1) / TH, p.B);
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<CC, COUT, TH>), grid, dim3(256), lds, st, p);
-}
-template <int CC, int COUT, int NSL, int TH>
-static void launch_c3r(const Conv3P& p, hipStream_t st) {
-    constexpr int LDP = CC + 8;
-    const size_t lds = ((size_t)(TH + 2) * 34 * LDP + 9 * NSL * LDP) * sizeof(u16);
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_res_kernel<CC, COUT, NSL, TH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<CC, COUT, NSL, TH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     dim3 grid((p.W + 31) / 32, (p.H + TH - 1) / TH, p.B * (COUT / NSL));
-    hipLaunchKernelGGL((conv3x3_bf16_res_kernel<CC, COUT, NSL, TH>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<CC, COUT, NSL, TH>), grid, dim3(256), lds, st, p);
 }
 
 bool conv3x3_bf16_supported(int Cin, int Cout) {
@@ -318,22 +255,16 @@ bool conv3x3_bf16_supported(int Cin, int Cout) {
 }
 
 void launch_conv3x3_bf16(const Conv3P& p, hipStream_t st) {
+    // few tiles (half resolution at small batch): 2-row tiles and 64-channel output slices put more, lighter
+    // workgroups on the chip (per-tap weight traffic per workgroup halves, two workgroups fit per CU)
     const long tiles4 = (long)((p.W + 31) / 32) * ((p.H + 3) / 4) * p.B;
-    if (tiles4 * (p.Cin >= 128 ? p.Cout / 32 : 1) <= 1536) {
-        // latency regime: resident weights, every load issued up front
-        if (p.Cin == 64 && p.Cout == 64) { tiles4 < 192 ? launch_c3r<64, 64, 64, 2>(p, st) : launch_c3r<64, 64, 64, 4>(p, st); }
-        else if (p.Cin == 64 && p.Cout == 128) { tiles4 < 192 ? launch_c3r<64, 128, 64, 2>(p, st) : launch_c3r<64, 128, 64, 4>(p, st); }
-        else if (p.Cout == 128) launch_c3r<128, 128, 32, 4>(p, st);     // Cin 128 (or 256 in two chunks)
-        else launch_c3r<128, 64, 32, 4>(p, st);                         // Cin 128 / 256 -> 64
-        return;
-    }
     const bool small = tiles4 < 256;
     if (p.Cout == 64) {
-        if (p.Cin == 64) { small ? launch_c3<64, 64, 2>(p, st) : launch_c3<64, 64, 4>(p, st); }
-        else { small ? launch_c3<128, 64, 2>(p, st) : launch_c3<128, 64, 4>(p, st); }          // Cin 128 / 256 (two chunks)
+        if (p.Cin == 64) { small ? launch_c3<64, 64, 64, 2>(p, st) : launch_c3<64, 64, 64, 4>(p, st); }
+        else { small ? launch_c3<128, 64, 64, 2>(p, st) : launch_c3<128, 64, 64, 4>(p, st); }      // Cin 128 / 256 (two chunks)
     } else {
-        if (p.Cin == 64) { small ? launch_c3<64, 128, 2>(p, st) : launch_c3<64, 128, 4>(p, st); }
-        else { small ? launch_c3<128, 128, 2>(p, st) : launch_c3<128, 128, 4>(p, st); }
+        if (p.Cin == 64) { small ? launch_c3<64, 128, 64, 2>(p, st) : launch_c3<64, 128, 128, 4>(p, st); }
+        else { small ? launch_c3<128, 128, 64, 2>(p, st) : launch_c3<128, 128, 128, 4>(p, st); }
     }
 }
 

@@ -57,6 +57,19 @@ int main() {
         p.gn_stats = nullptr;
         snprintf(nm, 80, "  .. same, no GN atomics"); timeit(nm, 50, fl, by, [&] { launch_conv3x3_bf16(p, 0); });
         p.gn_stats = st;
+#ifdef DEX_TIMING
+        {
+            long long* dbg; hipMalloc(&dbg, 4096 * 8 * 8); hipMemset(dbg, 0, 4096 * 8 * 8);
+            p.dbg = dbg; launch_conv3x3_bf16(p, 0); hipDeviceSynchronize(); p.dbg = nullptr;
+            std::vector<long long> h(4096 * 8); hipMemcpy(h.data(), dbg, 4096 * 8 * 8, hipMemcpyDeviceToHost);
+            int nb = 0; long long t0 = 1LL << 62, te = 0;
+            for (int bl = 0; bl < 4096; ++bl) if (h[bl * 8 + 7]) { nb++; t0 = std::min(t0, h[bl * 8 + 7]); te = std::max(te, h[bl * 8 + 6]); }
+            printf("   blocks=%d span=%lld (10ns)\n", nb, te - t0);
+            for (int bl : {0, nb / 2, nb - 1}) { long long* d = &h[bl * 8];
+                printf("   blk %4d: start+%lld  [tap1] pre-barrier@%lld barrier=%lld issue=%lld mfma=%lld vmwait=%lld | to-epilogue@%lld epi=%lld\n", bl, d[7] - t0,
+                       d[0] - d[7], d[1] - d[0], d[2] - d[1], d[3] - d[2], d[4] - d[3], d[5] - d[7], d[6] - d[5]); }
+        }
+#endif
         IGemmP g{}; g.A = x; g.lda = c.Cin; g.a_bstride = npix * c.Cin; g.Hi = c.H; g.Wi = c.W; g.Cin = c.Cin; g.KH = 3; g.KW = 3; g.sh = g.sw = 1; g.off_h = g.off_w = -1;
         g.step_h = g.step_w = 1; g.Ho = c.H; g.Wo = c.W; g.W = w; g.Wbf = wb; g.N = c.Cout; g.K = 9 * c.Cin; g.ksplit = 1; g.groups = 1; g.bias = bias;
         g.C = y; g.ldc = c.Cout; g.c_bstride = npix * c.Cout; g.OHf = c.H; g.OWf = c.W; g.osh = g.osw = 1; g.gate_nstride = 1; g.B = B; g.mask_bstride = T;
