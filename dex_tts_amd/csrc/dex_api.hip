@@ -745,9 +745,13 @@ struct Runner {
         for (int k = 0; k < c.dit_depth; ++k) {
             const DitBlockW& w = x->blocks[k];
             const float* ada = P.ada[k];
-            LnModP l1{P.tok, P.xn, N, hid, ada + 0 * hid, ada + 1 * hid, 6L * hid, P.step, B};
-            run("ln_modulate", 8.0 * B * N * hid, 8.0 * B * N * hid, [&] { launch_ln_mod(l1, st); });
-            IGemmP q = base_gemm(P.xn, hid, 0, 1, N, hid, w.wqkv, 3 * hid, w.bqkv, P.qkv, 3 * hid, 0);
+            const bool fuse_ln = x->precision == DEX_PREC_BF16;      // LayerNorm+modulate inside the GEMM's A staging
+            IGemmP q = base_gemm(fuse_ln ? P.tok : P.xn, hid, 0, 1, N, hid, w.wqkv, 3 * hid, w.bqkv, P.qkv, 3 * hid, 0);
+            if (fuse_ln) { q.ln_shift = ada + 0 * hid; q.ln_scale = ada + 1 * hid; q.ln_step_stride = 6L * hid; }
+            else {
+                LnModP l1{P.tok, P.xn, N, hid, ada + 0 * hid, ada + 1 * hid, 6L * hid, P.step, B};
+                run("ln_modulate", 8.0 * B * N * hid, 8.0 * B * N * hid, [&] { launch_ln_mod(l1, st); });
+            }
             gemm("dit_qkv", q);
             AttnP a{};
             a.Q = P.qkv; a.ldq = 3 * hid; a.qb = (long)N * 3 * hid;
@@ -759,9 +763,12 @@ struct Runner {
             pr.gate = ada + 2 * hid; pr.gate_nstride = 1; pr.gate_step_stride = 6L * hid;
             pr.res = P.tok; pr.ldres = hid; pr.res_bstride = (long)N * hid;
             gemm("dit_proj", pr);
-            LnModP l2{P.tok, P.xn, N, hid, ada + 3 * hid, ada + 4 * hid, 6L * hid, P.step, B};
-            run("ln_modulate", 8.0 * B * N * hid, 8.0 * B * N * hid, [&] { launch_ln_mod(l2, st); });
-            IGemmP f1 = base_gemm(P.xn, hid, 0, 1, N, hid, w.wfc1, mh, w.bfc1, P.hmlp, mh, 0);
+            IGemmP f1 = base_gemm(fuse_ln ? P.tok : P.xn, hid, 0, 1, N, hid, w.wfc1, mh, w.bfc1, P.hmlp, mh, 0);
+            if (fuse_ln) { f1.ln_shift = ada + 3 * hid; f1.ln_scale = ada + 4 * hid; f1.ln_step_stride = 6L * hid; }
+            else {
+                LnModP l2{P.tok, P.xn, N, hid, ada + 3 * hid, ada + 4 * hid, 6L * hid, P.step, B};
+                run("ln_modulate", 8.0 * B * N * hid, 8.0 * B * N * hid, [&] { launch_ln_mod(l2, st); });
+            }
             f1.act = 1;
             gemm("dit_fc1_gelu", f1);
             IGemmP f2 = base_gemm(P.hmlp, mh, 0, 1, N, mh, w.wfc2, hid, w.bfc2, P.tok, hid, 0);
@@ -775,10 +782,14 @@ struct Runner {
                 tap(nm, dst, (long)B * N, hid, hid);
             }
         }
-        LnModP lf{P.tok, P.xn, N, hid, P.fin_mod, P.fin_mod + hid, 2L * hid, P.step, B};
-        run("ln_modulate", 8.0 * B * N * hid, 8.0 * B * N * hid, [&] { launch_ln_mod(lf, st); });
+        const bool fuse_lnf = x->precision == DEX_PREC_BF16;
         const int s2c = c.dit_stride * c.dit_stride * mid;
-        IGemmP fl = base_gemm(P.xn, hid, 0, P.Hf, P.Wt, hid, x->fl_w, s2c, x->fl_b, out, ldo, ocoff);
+        IGemmP fl = base_gemm(fuse_lnf ? P.tok : P.xn, hid, 0, P.Hf, P.Wt, hid, x->fl_w, s2c, x->fl_b, out, ldo, ocoff);
+        if (fuse_lnf) { fl.ln_shift = P.fin_mod; fl.ln_scale = P.fin_mod + hid; fl.ln_step_stride = 2L * hid; }
+        else {
+            LnModP lf{P.tok, P.xn, N, hid, P.fin_mod, P.fin_mod + hid, 2L * hid, P.step, B};
+            run("ln_modulate", 8.0 * B * N * hid, 8.0 * B * N * hid, [&] { launch_ln_mod(lf, st); });
+        }
         fl.unpatch_s = c.dit_stride; fl.unpatch_C = mid; fl.OHf = P.Hm; fl.OWf = P.Wm;
         fl.c_bstride = (long)P.Hm * P.Wm * ldo;
         fl.outmask = mask; fl.outmask_ws = mask_ws;

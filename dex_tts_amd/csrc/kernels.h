@@ -36,6 +36,8 @@ struct IGemmP {
     const int* step;
     int unpatch_s, unpatch_C;                          // >0: scatter rows (f,w) x cols (p1,p2,c) -> NHWC image
     float* gn_stats; int gn_groups, gn_cpg;            // fused GroupNorm partial statistics of (acc + bias), or null
+    const float* ln_shift; const float* ln_scale; long ln_step_stride;   // fused LayerNorm(eps 1e-6)+modulate on the A rows
+                                                       // (single-shot bf16 kernel only; needs K == Cin == row length)
     int B;
 };
 void launch_igemm(const IGemmP& p, int precision, hipStream_t st);
