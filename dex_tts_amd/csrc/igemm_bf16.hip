@@ -125,12 +125,14 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemmP p) {
 // workgroup makes ONE global round trip before its MFMA chain instead of one per K tile (at B=1 the DiT linears
 // are pure latency: 4-8 exposed round trips at ~1.2 us each).  Optional fused prologue on the A rows:
 // LayerNorm(eps 1e-6, no affine) + adaLN modulate (dit.py:78-79,288-289) when the row IS the K extent.
-template <int BM, int BN>
+template <int BM, int BN, int K>
 __global__ __launch_bounds__(256) void igemm_bf16_ss_kernel(const IGemmP p) {
     constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (WM * 32);
-    static_assert(MT >= 1, "tile");
+    constexpr int LDS_LD = K + 8, KC = K / 8;               // KC: 8-element chunks per row (power of two <= 64)
+    constexpr int AIT = BM * KC / 256, BIT = BN * KC / 256; // items per thread
+    constexpr int ABATCH = AIT > 8 ? 8 : AIT;               // A items in flight per batch (2 float4 each)
+    static_assert(MT >= 1 && AIT >= 1 && BIT >= 1, "tile");
     extern __shared__ __attribute__((aligned(16))) u16 smem_ss[];
-    const int K = p.K, LDS_LD = K + 8, KC = K / 8;          // KC: 8-element chunks per row
     u16* As = smem_ss;
     u16* Bs = smem_ss + BM * LDS_LD;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -143,51 +145,76 @@ __global__ __launch_bounds__(256) void igemm_bf16_ss_kernel(const IGemmP p) {
     const float* mrow = p.inmask ? p.inmask + (long)b * p.mask_bstride : nullptr;
     const u16* Wb = reinterpret_cast<const u16*>(p.Wbf) + (long)b * p.w_bstride;
     const int step = p.step ? *p.step : 0;
-
-    // B tile first (independent of everything)
-    for (int it = tid; it < BN * KC; it += 256) {
-        const int n = it / KC, c8 = (it - n * KC) * 8;
-        *reinterpret_cast<uint4*>(Bs + n * LDS_LD + c8) = *reinterpret_cast<const uint4*>(Wb + (long)(n0 + n) * K + c8);
-    }
-    // A tile: item = (row, 8-element chunk)
     const float* lsh = p.ln_shift ? p.ln_shift + (long)step * p.ln_step_stride : nullptr;
     const float* lsc = p.ln_scale ? p.ln_scale + (long)step * p.ln_step_stride : nullptr;
-#pragma unroll 4
-    for (int it = tid; it < BM * KC; it += 256) {
-        const int row = it / KC, k8 = (it - row * KC) * 8;
-        const int m = m0 + row;
-        const int tap = k8 / p.Cin, c0 = k8 - tap * p.Cin;
-        const int kh = tap / p.KW, kw = tap - kh * p.KW;
-        const int mm = m < M ? m : 0;
-        const int ho = mm / p.Wo, wo = mm - ho * p.Wo;
-        const int hi = ho * p.sh + p.off_h + kh * p.step_h, wi = wo * p.sw + p.off_w + kw * p.step_w;
-        const bool ok = m < M && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
-        const int hc = ok ? hi : 0, wc = ok ? wi : 0;
-        const float* src = Ab + ((long)hc * p.Wi + wc) * p.lda + c0;
-        float4 f0 = *reinterpret_cast<const float4*>(src);
-        float4 f1 = *reinterpret_cast<const float4*>(src + 4);
-        float mk = mrow ? mrow[wc * p.inmask_ws] : 1.f;
-        mk = ok ? mk : 0.f;
-        if (lsh) {
-            // row statistics over the KC lanes that share this row (KC is a power of two <= 64, lanes contiguous)
-            float s = (f0.x + f0.y) + (f0.z + f0.w) + (f1.x + f1.y) + (f1.z + f1.w);
-            for (int o = 1; o < KC; o <<= 1) s += __shfl_xor(s, o);
-            const float mean = s / (float)K;
-            f0.x -= mean; f0.y -= mean; f0.z -= mean; f0.w -= mean; f1.x -= mean; f1.y -= mean; f1.z -= mean; f1.w -= mean;
-            float q = f0.x * f0.x + f0.y * f0.y + f0.z * f0.z + f0.w * f0.w + f1.x * f1.x + f1.y * f1.y + f1.z * f1.z + f1.w * f1.w;
-            for (int o = 1; o < KC; o <<= 1) q += __shfl_xor(q, o);
-            const float rstd = rsqrtf(q / (float)K + 1e-6f);
-            const float4 sc0 = *reinterpret_cast<const float4*>(lsc + k8), sc1 = *reinterpret_cast<const float4*>(lsc + k8 + 4);
-            const float4 sh0 = *reinterpret_cast<const float4*>(lsh + k8), sh1 = *reinterpret_cast<const float4*>(lsh + k8 + 4);
-            f0.x = f0.x * rstd * (1.f + sc0.x) + sh0.x; f0.y = f0.y * rstd * (1.f + sc0.y) + sh0.y;
-            f0.z = f0.z * rstd * (1.f + sc0.z) + sh0.z; f0.w = f0.w * rstd * (1.f + sc0.w) + sh0.w;
-            f1.x = f1.x * rstd * (1.f + sc1.x) + sh1.x; f1.y = f1.y * rstd * (1.f + sc1.y) + sh1.y;
-            f1.z = f1.z * rstd * (1.f + sc1.z) + sh1.z; f1.w = f1.w * rstd * (1.f + sc1.w) + sh1.w;
+
+    // ---- issue: all B loads, then the first batch of A loads (everything in flight together)
+    uint4 br[BIT];
+#pragma unroll
+    for (int j = 0; j < BIT; ++j) {
+        const int it = tid + 256 * j;
+        const int n = it / KC, c8 = (it % KC) * 8;
+        br[j] = *reinterpret_cast<const uint4*>(Wb + (long)(n0 + n) * K + c8);
+    }
+#pragma unroll
+    for (int a0 = 0; a0 < AIT; a0 += ABATCH) {
+        float4 f0[ABATCH], f1[ABATCH];
+        float mk[ABATCH];
+#pragma unroll
+        for (int j = 0; j < ABATCH; ++j) {
+            const int it = tid + 256 * (a0 + j);
+            const int row = it / KC, k8 = (it % KC) * 8;
+            const int m = m0 + row;
+            const int tap = k8 / p.Cin, c0 = k8 - tap * p.Cin;
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+            const int mm = m < M ? m : 0;
+            const int ho = mm / p.Wo, wo = mm - ho * p.Wo;
+            const int hi = ho * p.sh + p.off_h + kh * p.step_h, wi = wo * p.sw + p.off_w + kw * p.step_w;
+            const bool ok = m < M && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
+            const int hc = ok ? hi : 0, wc = ok ? wi : 0;
+            const float* src = Ab + ((long)hc * p.Wi + wc) * p.lda + c0;
+            f0[j] = *reinterpret_cast<const float4*>(src);
+            f1[j] = *reinterpret_cast<const float4*>(src + 4);
+            const float mv = mrow ? mrow[wc * p.inmask_ws] : 1.f;
+            mk[j] = ok ? mv : 0.f;
         }
-        uint4 v;
-        v.x = pack_bf16(f0.x * mk, f0.y * mk); v.y = pack_bf16(f0.z * mk, f0.w * mk);
-        v.z = pack_bf16(f1.x * mk, f1.y * mk); v.w = pack_bf16(f1.z * mk, f1.w * mk);
-        *reinterpret_cast<uint4*>(As + row * LDS_LD + k8) = v;
+        if (a0 == 0) {
+#pragma unroll
+            for (int j = 0; j < BIT; ++j) {
+                const int it = tid + 256 * j;
+                const int n = it / KC, c8 = (it % KC) * 8;
+                *reinterpret_cast<uint4*>(Bs + n * LDS_LD + c8) = br[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < ABATCH; ++j) {
+            const int it = tid + 256 * (a0 + j);
+            const int row = it / KC, k8 = (it % KC) * 8;
+            float4 a = f0[j], c = f1[j];
+            if (lsh) {
+                // row statistics over the KC lanes that share this row (lanes contiguous, KC a power of two)
+                float s = (a.x + a.y) + (a.z + a.w) + (c.x + c.y) + (c.z + c.w);
+#pragma unroll
+                for (int o = 1; o < KC; o <<= 1) s += __shfl_xor(s, o);
+                const float mean = s * (1.f / (float)K);
+                a.x -= mean; a.y -= mean; a.z -= mean; a.w -= mean; c.x -= mean; c.y -= mean; c.z -= mean; c.w -= mean;
+                float q = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
+#pragma unroll
+                for (int o = 1; o < KC; o <<= 1) q += __shfl_xor(q, o);
+                const float rstd = rsqrtf(q * (1.f / (float)K) + 1e-6f);
+                const float4 sc0 = *reinterpret_cast<const float4*>(lsc + k8), sc1 = *reinterpret_cast<const float4*>(lsc + k8 + 4);
+                const float4 sh0 = *reinterpret_cast<const float4*>(lsh + k8), sh1 = *reinterpret_cast<const float4*>(lsh + k8 + 4);
+                a.x = a.x * rstd * (1.f + sc0.x) + sh0.x; a.y = a.y * rstd * (1.f + sc0.y) + sh0.y;
+                a.z = a.z * rstd * (1.f + sc0.z) + sh0.z; a.w = a.w * rstd * (1.f + sc0.w) + sh0.w;
+                c.x = c.x * rstd * (1.f + sc1.x) + sh1.x; c.y = c.y * rstd * (1.f + sc1.y) + sh1.y;
+                c.z = c.z * rstd * (1.f + sc1.z) + sh1.z; c.w = c.w * rstd * (1.f + sc1.w) + sh1.w;
+            }
+            const float m_ = mk[j];
+            uint4 v;
+            v.x = pack_bf16(a.x * m_, a.y * m_); v.y = pack_bf16(a.z * m_, a.w * m_);
+            v.z = pack_bf16(c.x * m_, c.y * m_); v.w = pack_bf16(c.z * m_, c.w * m_);
+            *reinterpret_cast<uint4*>(As + row * LDS_LD + k8) = v;
+        }
     }
     __syncthreads();
     f32x16 acc[MT];
@@ -197,7 +224,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_ss_kernel(const IGemmP p) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     const u16* ap = As + (wm * (MT * 32) + i) * LDS_LD + hh * 8;
     const u16* bp = Bs + (wn * 32 + i) * LDS_LD + hh * 8;
-#pragma unroll 4
+#pragma unroll
     for (int ks = 0; ks < K / 16; ++ks) {
         const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bp + ks * 16);
 #pragma unroll
@@ -209,10 +236,21 @@ __global__ __launch_bounds__(256) void igemm_bf16_ss_kernel(const IGemmP p) {
     igemm_epilogue<MT>(p, acc, m0, n0, wm * (MT * 32), wn * 32, lane, b, 0, 0, M);
 }
 
+template <int K>
+static void launch_ss(const IGemmP& p, hipStream_t st) {
+    const size_t lds = (size_t)(64 + 64) * (K + 8) * sizeof(u16);
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_ss_kernel<64, 64, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    dim3 grid((p.Ho * p.Wo + 63) / 64, p.N / 64, p.B);
+    hipLaunchKernelGGL((igemm_bf16_ss_kernel<64, 64, K>), grid, dim3(256), lds, st, p);
+}
+
 static bool ss_eligible(const IGemmP& p) {
-    if (p.ksplit != 1 || p.groups != 1 || p.K > 512 || (p.K % 64) != 0 || (p.N % 64) != 0) return false;
-    const int kc = p.K / 8;
-    if (kc & (kc - 1)) return false;                                  // row-sharing lanes must be a power of two
+    if (p.ksplit != 1 || p.groups != 1 || (p.N % 64) != 0) return false;
+    if (p.K != 64 && p.K != 128 && p.K != 256 && p.K != 512) return false;
     const long blocks = (long)((p.Ho * p.Wo + 63) / 64) * (p.N / 64) * p.B;
     return blocks <= 4096 || p.ln_shift != nullptr;
 }
@@ -220,14 +258,10 @@ static bool ss_eligible(const IGemmP& p) {
 void launch_igemm_bf16(const IGemmP& p, hipStream_t st) {
     const int M = p.Ho * p.Wo;
     if (ss_eligible(p)) {
-        const size_t lds = (size_t)(64 + 64) * (p.K + 8) * sizeof(u16);
-        static bool attr = false;
-        if (!attr) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_ss_kernel<64, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-            attr = true;
-        }
-        dim3 grid((M + 63) / 64, p.N / 64, p.B);
-        hipLaunchKernelGGL((igemm_bf16_ss_kernel<64, 64>), grid, dim3(256), lds, st, p);
+        if (p.K == 64) launch_ss<64>(p, st);
+        else if (p.K == 128) launch_ss<128>(p, st);
+        else if (p.K == 256) launch_ss<256>(p, st);
+        else launch_ss<512>(p, st);
         return;
     }
     const int zdim = p.B * p.groups * p.ksplit;
