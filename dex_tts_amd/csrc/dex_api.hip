@@ -24,7 +24,7 @@ struct RawW { float* p = nullptr; std::vector<int64_t> shape; long numel = 0; bo
 struct TD { float* p; int ld; int coff; int C; };          // channels-last activation view
 
 struct ResW { const float *w1, *b1, *g1, *be1, *w2, *b2, *g2, *be2, *wr, *br, *mlp_w, *mlp_b; int cin, cout; };
-struct LinW { const float *wqkv, *wout_raw, *bias_eff, *g; int C; };
+struct LinW { const float *wqkv, *wqkv_raw, *wout_raw, *bias_eff, *g; const void* wkv_bf16; int C; };
 struct DitBlockW { const float *wqkv, *bqkv, *wproj, *bproj, *wfc1, *bfc1, *wfc2, *bfc2, *ada_w, *ada_b; };
 
 struct Prof { std::string name; hipEvent_t a, b; double flops, bytes; };
@@ -346,7 +346,13 @@ struct Packer {
         LinW l{};
         l.C = c;
         l.wqkv = kn(p + ".fn.fn.to_qkv.weight");
+        l.wqkv_raw = raw(p + ".fn.fn.to_qkv.weight");                 // [384][C]: rows q | k | v
         l.wout_raw = raw(p + ".fn.fn.to_out.weight");
+        {   // bf16 copy of the k|v rows in their native [N][K] layout (B operand of the fused kernel)
+            unsigned short* kvb = (unsigned short*)alloc((256L * c + 1) / 2);
+            if (kvb) launch_f32_to_bf16(l.wqkv_raw + 128L * c, kvb, 256L * c, st);
+            l.wkv_bf16 = kvb;
+        }
         l.g = raw(p + ".fn.g");
         float* be = alloc(c);
         if (be) launch_scale_copy(raw(p + ".fn.fn.to_out.bias"), be, c, l.g, st);     // Rezero gate folded into the bias
@@ -478,7 +484,7 @@ struct Dims { int B, T, Tr, Ts, n_steps; };
 struct StageBuf {
     int H, W, C, mask_ws; long npix;
     float *h1, *a1, *h2, *rbuf, *r0out, *r1out;        // resblock scratch
-    float *qkv, *pm, *ps, *pc, *weff; int nchunks;
+    float *qkv, *pm, *ps, *pc, *weff, *ctxn; void* mbf; int nchunks, nblk_fused;
     float* attn_out; int attn_ld, attn_coff;            // where the stage's attention output lives
     float* ds_out;                                      // Downsample output (down stages except the last)
 };
@@ -539,8 +545,10 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
         s.h1 = A.f(e * C); s.a1 = A.f(e * C); s.h2 = A.f(e * C); s.rbuf = A.f(e * C); s.r0out = A.f(e * C); s.r1out = A.f(e * C);
         s.qkv = A.f(e * 384);
         s.nchunks = (int)((s.npix + LA_CHUNK - 1) / LA_CHUNK);
-        s.pm = A.f((size_t)B * 4 * s.nchunks * 32); s.ps = A.f((size_t)B * 4 * s.nchunks * 32);
-        s.pc = A.f((size_t)B * 4 * s.nchunks * 1024); s.weff = A.f((size_t)B * 128 * C);
+        s.nblk_fused = (int)((s.npix + 127) / 128);             // fused bf16 path: one partial per 128-pixel workgroup
+        s.pm = A.f((size_t)B * 4 * s.nblk_fused * 32); s.ps = A.f((size_t)B * 4 * s.nblk_fused * 32);
+        s.pc = A.f((size_t)B * 4 * s.nblk_fused * 1024); s.weff = A.f((size_t)B * 128 * C);
+        s.ctxn = A.f((size_t)B * 4096); s.mbf = A.take((size_t)B * C * C * 2);
         s.ds_out = nullptr;
         return s;
     };
@@ -707,6 +715,23 @@ struct Runner {
     // Residual(Rezero(LinearAttention)) (diffusion.py:74-102)
     void linattn(const LinW& w, const StageBuf& s, const TD& X, float* out, int ldo, int ocoff) {
         const long npix = s.npix; const int B = P.d.B;
+        if (x->precision == DEX_PREC_BF16 && (X.C == 64 || X.C == 128)) {
+            // fused: y = x + M_b x + g*b  with  M_b = g Wout blockdiag(ctx^T) Wq   (linattn_fused.hip)
+            int nsub = 1;
+            while (nsub < 4 && (npix + 128 * nsub - 1) / (128 * nsub) * B > 1024) nsub *= 2;
+            const int nblk = (int)((npix + 128L * nsub - 1) / (128L * nsub));
+            LinKvCtxP k{X.p, X.ld, X.coff, npix * X.ld, (int)npix, X.C, w.wkv_bf16, nsub, nblk, s.pm, s.ps, s.pc, B};
+            run("linattn_kvctx", 2.0 * npix * B * (256.0 * X.C + 128 * 32), 4.0 * npix * X.C * B, [&] { launch_linattn_kvctx(k, st); });
+            LinMergeP mg{s.pm, s.ps, s.pc, nblk, s.ctxn, B};
+            run("linattn_merge", 0, 4.0 * nblk * 4 * 1088 * B, [&] { launch_linattn_merge(mg, st); });
+            LinFoldP fo{s.ctxn, w.wqkv_raw, w.wout_raw, w.g, X.C, s.weff, s.mbf, B};
+            run("linattn_fold", 2.0 * (128.0 * 32 * X.C + 128.0 * X.C * X.C) * B, 0, [&] { launch_linattn_fold(fo, st); });
+            IGemmP o = base_gemm(X.p, X.ld, X.coff, s.H, s.W, X.C, s.weff, w.C, w.bias_eff, out, ldo, ocoff);
+            o.Wbf = s.mbf; o.w_bstride = (long)X.C * X.C;
+            o.res = X.p; o.ldres = X.ld; o.res_coff = X.coff; o.res_bstride = npix * X.ld;
+            gemm("linattn_out", o);
+            return;
+        }
         IGemmP g = base_gemm(X.p, X.ld, X.coff, s.H, s.W, X.C, w.wqkv, 384, nullptr, s.qkv, 384, 0);
         gemm("linattn_qkv", g);
         LinAttnCtxP cp{s.qkv, 384, npix * 384, (int)npix, 4, LA_CHUNK, s.nchunks, s.pm, s.ps, s.pc, B};

@@ -1,0 +1,220 @@
+// linattn_fused.hip — LinearAttention (diffusion.py:74-92) without ever materialising q, k or v (bf16-MFMA mode).
+//
+// Algebra: q enters linearly (out[e,n] = sum_d ctx[d,e] q[d,n], q = Wq x), so the whole Residual(Rezero(
+// LinearAttention)) collapses to   y = x + M_b x + g*b_out   with a per-utterance C x C matrix
+//     M_b = g * Wout * blockdiag_h(ctx_h^T) * Wq,      ctx_h[d,e] = sum_n softmax_n(k)[d,n] v[e,n].
+// Kernel 1 (this file) streams x once: per 32-pixel sub-tile a wave computes k and v (8 tiles of 32x32) with
+// v_mfma_f32_32x32x16_bf16, keeps an online per-channel max, and accumulates ctx^T with a SECOND MFMA whose A
+// and B operands are the k/v accumulator registers themselves (C-layout: lane = channel, registers = pixels ->
+// exactly the A[e][px] / B[px][d] fragment shape; both use the same pixel order, so no shuffle and no LDS).
+// Kernel 2 merges the workgroup partials (flash-style) into normalised ctx; kernel 3 folds ctx, Wq, Wout and g
+// into M_b (fp32 [ci][co] and bf16 [co][ci]); the tail is one GEMM with K = C and a residual.
+// HBM traffic per call: x read twice + y written, instead of writing q,k,v (6x the size of x) and re-reading them.
+#include "kernels.h"
+
+namespace dex {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned short u16;
+union LFrag { uint4 u; bf16x8 v; };
+
+__device__ __forceinline__ unsigned la_pack(float lo, float hi) {
+    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
+    a += 0x7FFFu + ((a >> 16) & 1u);
+    b += 0x7FFFu + ((b >> 16) & 1u);
+    return (a >> 16) | (b & 0xFFFF0000u);
+}
+
+// grid (nblk, B); 256 threads; each wave owns `nsub` consecutive 32-pixel sub-tiles.
+// part_m/part_s: [B][4][nblk][32], part_c: [B][4][nblk][32 d][32 e]   (same layout linattn_combine reads)
+template <int C>
+__global__ __launch_bounds__(256) void linattn_kvctx_kernel(const LinKvCtxP p) {
+    constexpr int LDW = C + 8, KS = C / 16;
+    extern __shared__ __attribute__((aligned(16))) u16 smem_la[];
+    u16* Ws = smem_la;                                       // [256][LDW]  rows: k(4x32) then v(4x32)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int blk = blockIdx.x, b = blockIdx.y;
+    const u16* Wg = reinterpret_cast<const u16*>(p.Wkv);     // bf16 [256][C]
+    for (int it = tid; it < 256 * (C / 8); it += 256) {
+        const int n = it / (C / 8), c8 = (it % (C / 8)) * 8;
+        *reinterpret_cast<uint4*>(Ws + n * LDW + c8) = *reinterpret_cast<const uint4*>(Wg + (long)n * C + c8);
+    }
+    const float* X = p.X + (long)b * p.xb + p.x_coff;
+    const int px_base = (blk * 4 + wave) * p.nsub * 32;
+
+    f32x16 ctxT[4];
+    float m_run[4], s_run[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        m_run[h] = -INFINITY; s_run[h] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ctxT[h][r] = 0.f;
+    }
+    __syncthreads();
+    for (int sub = 0; sub < p.nsub; ++sub) {
+        const int px0 = px_base + sub * 32;
+        if (px0 >= p.npix) break;
+        // A fragments of x: lane (pixel i, half hh) holds x[px][ks*16 + hh*8 .. +8]
+        const int pxr = min(px0 + i, p.npix - 1);
+        const float* xr = X + (long)pxr * p.ldx + hh * 8;
+        LFrag af[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float4 a = *reinterpret_cast<const float4*>(xr + ks * 16);
+            const float4 c = *reinterpret_cast<const float4*>(xr + ks * 16 + 4);
+            af[ks].u.x = la_pack(a.x, a.y); af[ks].u.y = la_pack(a.z, a.w);
+            af[ks].u.z = la_pack(c.x, c.y); af[ks].u.w = la_pack(c.z, c.w);
+        }
+        f32x16 kv[8];
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) kv[nt][r] = 0.f;
+            const u16* bp = Ws + (nt * 32 + i) * LDW + hh * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                LFrag bf; bf.u = *reinterpret_cast<const uint4*>(bp + ks * 16);
+                kv[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks].v, bf.v, kv[nt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            // column (channel d = lane&31) max over the 32 pixels of the sub-tile
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int px = px0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (px >= p.npix) kv[h][r] = -INFINITY;
+                mx = fmaxf(mx, kv[h][r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float mn = fmaxf(m_run[h], mx);
+            const float alpha = __expf(m_run[h] - mn);
+            m_run[h] = mn;
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { kv[h][r] = __expf(kv[h][r] - mn); ps += kv[h][r]; }
+            s_run[h] = s_run[h] * alpha + ps;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ctxT[h][r] *= alpha;
+            // ctx^T[e][d] += sum_px v[px][e] * p[px][d]   (A = v tile regs, B = p tile regs, same pixel order)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                LFrag va, pb;
+                va.u.x = la_pack(kv[4 + h][8 * k2 + 0], kv[4 + h][8 * k2 + 1]); va.u.y = la_pack(kv[4 + h][8 * k2 + 2], kv[4 + h][8 * k2 + 3]);
+                va.u.z = la_pack(kv[4 + h][8 * k2 + 4], kv[4 + h][8 * k2 + 5]); va.u.w = la_pack(kv[4 + h][8 * k2 + 6], kv[4 + h][8 * k2 + 7]);
+                pb.u.x = la_pack(kv[h][8 * k2 + 0], kv[h][8 * k2 + 1]); pb.u.y = la_pack(kv[h][8 * k2 + 2], kv[h][8 * k2 + 3]);
+                pb.u.z = la_pack(kv[h][8 * k2 + 4], kv[h][8 * k2 + 5]); pb.u.w = la_pack(kv[h][8 * k2 + 6], kv[h][8 * k2 + 7]);
+                ctxT[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va.v, pb.v, ctxT[h], 0, 0, 0);
+            }
+        }
+    }
+    // ---- merge the 4 waves of the workgroup through LDS, write one partial per head
+    __syncthreads();                                          // weights no longer needed
+    float* mS = reinterpret_cast<float*>(smem_la);            // [4 waves][4 heads][32 d][33]  ctx as [d][e]
+    float* mm = mS + 4 * 4 * 32 * 33;                         // [4][4][32] m
+    float* ms = mm + 4 * 4 * 32;                              // [4][4][32] s
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const float st = s_run[h] + __shfl_xor(s_run[h], 32);
+        float* dst = mS + ((wave * 4 + h) * 32 + i) * 33;     // row d = lane&31
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(r & 3) + 8 * (r >> 2) + 4 * hh] = ctxT[h][r];   // column e
+        if (hh == 0) { mm[(wave * 4 + h) * 32 + i] = m_run[h]; ms[(wave * 4 + h) * 32 + i] = st; }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 4 * 1024; idx += 256) {
+        const int h = idx >> 10, d = (idx >> 5) & 31, e = idx & 31;
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) M = fmaxf(M, mm[(w * 4 + h) * 32 + d]);
+        float acc = 0.f, s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float mw = mm[(w * 4 + h) * 32 + d];
+            const float f = (mw == -INFINITY) ? 0.f : __expf(mw - M);
+            acc = fmaf(f, mS[((w * 4 + h) * 32 + d) * 33 + e], acc);
+            s = fmaf(f, ms[(w * 4 + h) * 32 + d], s);
+        }
+        const long pidx = ((long)b * 4 + h) * p.nblk + blk;
+        p.part_c[pidx * 1024 + d * 32 + e] = acc;
+        if (e == 0) { p.part_m[pidx * 32 + d] = M; p.part_s[pidx * 32 + d] = s; }
+    }
+}
+
+void launch_linattn_kvctx(const LinKvCtxP& p, hipStream_t st) {
+    const size_t lds_w = (size_t)256 * (p.C + 8) * sizeof(u16);
+    const size_t lds_m = (size_t)(4 * 4 * 32 * 33 + 2 * 4 * 4 * 32) * sizeof(float);
+    const size_t lds = lds_w > lds_m ? lds_w : lds_m;
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_kvctx_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_kvctx_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr = true;
+    }
+    dim3 grid(p.nblk, p.B);
+    if (p.C == 64) hipLaunchKernelGGL(linattn_kvctx_kernel<64>, grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL(linattn_kvctx_kernel<128>, grid, dim3(256), lds, st, p);
+}
+
+// grid (4 heads, B, 4 d-slices): merge the workgroup partials -> normalised ctx[b][h][d][e]
+__global__ __launch_bounds__(256) void linattn_merge_kernel(const LinMergeP p) {
+    const int tid = threadIdx.x, h = blockIdx.x, b = blockIdx.y, ds = blockIdx.z;
+    const long pbase = ((long)b * 4 + h) * p.nblk;
+    const int dlr = tid >> 5, e = tid & 31, d = ds * 8 + dlr;
+    float m = -INFINITY;
+#pragma unroll 8
+    for (int c = 0; c < p.nblk; ++c) m = fmaxf(m, p.part_m[(pbase + c) * 32 + d]);
+    float acc = 0.f, s = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < p.nblk; ++c) {
+        const float w = __expf(p.part_m[(pbase + c) * 32 + d] - m);
+        acc = fmaf(w, p.part_c[(pbase + c) * 1024 + d * 32 + e], acc);
+        s = fmaf(w, p.part_s[(pbase + c) * 32 + d], s);
+    }
+    p.ctx[(((long)b * 4 + h) * 32 + d) * 32 + e] = acc / s;
+}
+void launch_linattn_merge(const LinMergeP& p, hipStream_t st) {
+    hipLaunchKernelGGL(linattn_merge_kernel, dim3(4, p.B, 4), dim3(256), 0, st, p);
+}
+
+// grid (B): M_b = g * Wout * blockdiag(ctx^T) * Wq  ->  Mt fp32 [ci][co]  and  Mbf bf16 [co][ci]
+//   T[h*32+e][ci] = sum_d ctx[h][d][e] * Wq[h*32+d][ci];   M[co][ci] = g * sum_{he} Wout[co][he] * T[he][ci]
+__global__ __launch_bounds__(256) void linattn_fold_kernel(const LinFoldP p) {
+    extern __shared__ float smem_f[];
+    const int C = p.C, tid = threadIdx.x, b = blockIdx.x;
+    float* T = smem_f;                      // [128][C+1]
+    float* cs = T + 128 * (C + 1);          // [4][32][33] ctx
+    for (int idx = tid; idx < 4096; idx += 256) cs[(idx >> 5) * 33 + (idx & 31)] = p.ctx[(long)b * 4096 + idx];
+    __syncthreads();
+    for (int idx = tid; idx < 128 * C; idx += 256) {
+        const int he = idx / C, ci = idx - he * C, h = he >> 5, e = he & 31;
+        float a = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < 32; ++d) a = fmaf(cs[(h * 32 + d) * 33 + e], p.Wq[(long)(h * 32 + d) * C + ci], a);
+        T[he * (C + 1) + ci] = a;
+    }
+    __syncthreads();
+    const float g = p.g[0];
+    for (int idx = tid; idx < C * C; idx += 256) {
+        const int co = idx / C, ci = idx - co * C;
+        float a = 0.f;
+#pragma unroll 8
+        for (int he = 0; he < 128; ++he) a = fmaf(p.Wout[(long)co * 128 + he], T[he * (C + 1) + ci], a);
+        a *= g;
+        p.Mt[(long)b * C * C + (long)ci * C + co] = a;
+        unsigned u = __float_as_uint(a);
+        u += 0x7FFFu + ((u >> 16) & 1u);
+        reinterpret_cast<u16*>(p.Mbf)[(long)b * C * C + (long)co * C + ci] = (u16)(u >> 16);
+    }
+}
+void launch_linattn_fold(const LinFoldP& p, hipStream_t st) {
+    const size_t lds = (size_t)(128 * (p.C + 1) + 4 * 32 * 33) * sizeof(float);
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_fold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
+    hipLaunchKernelGGL(linattn_fold_kernel, dim3(p.B), dim3(256), lds, st, p);
+}
+
+}  // namespace dex
