@@ -159,51 +159,72 @@ void launch_linattn_kvctx(const LinKvCtxP& p, hipStream_t st) {
     else hipLaunchKernelGGL(linattn_kvctx_kernel<128>, grid, dim3(256), lds, st, p);
 }
 
-// grid (4 heads, B, 4 d-slices): merge the workgroup partials -> normalised ctx[b][h][d][e]
+// grid (4 heads, B, 32 rows d): merge the workgroup partials of ONE context row -> normalised ctx[b][h][d][:].
+// thread = (column e = tid%32, partial lane pl = tid/32): 8 lanes stride the partial list with independent loads.
 __global__ __launch_bounds__(256) void linattn_merge_kernel(const LinMergeP p) {
-    const int tid = threadIdx.x, h = blockIdx.x, b = blockIdx.y, ds = blockIdx.z;
+    __shared__ float redm[8], reda[8][32], reds[8];
+    const int tid = threadIdx.x, h = blockIdx.x, b = blockIdx.y, d = blockIdx.z;
     const long pbase = ((long)b * 4 + h) * p.nblk;
-    const int dlr = tid >> 5, e = tid & 31, d = ds * 8 + dlr;
+    const int e = tid & 31, pl = tid >> 5;
     float m = -INFINITY;
 #pragma unroll 8
-    for (int c = 0; c < p.nblk; ++c) m = fmaxf(m, p.part_m[(pbase + c) * 32 + d]);
+    for (int c = pl; c < p.nblk; c += 8) m = fmaxf(m, p.part_m[(pbase + c) * 32 + d]);
+    if (e == 0) redm[pl] = m;
+    __syncthreads();
+    m = redm[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) m = fmaxf(m, redm[k]);
     float acc = 0.f, s = 0.f;
 #pragma unroll 8
-    for (int c = 0; c < p.nblk; ++c) {
+    for (int c = pl; c < p.nblk; c += 8) {
         const float w = __expf(p.part_m[(pbase + c) * 32 + d] - m);
         acc = fmaf(w, p.part_c[(pbase + c) * 1024 + d * 32 + e], acc);
         s = fmaf(w, p.part_s[(pbase + c) * 32 + d], s);
     }
-    p.ctx[(((long)b * 4 + h) * 32 + d) * 32 + e] = acc / s;
+    reda[pl][e] = acc;
+    if (e == 0) reds[pl] = s;
+    __syncthreads();
+    if (pl == 0) {
+        float a = 0.f, ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a += reda[k][e]; ss += reds[k]; }
+        p.ctx[(((long)b * 4 + h) * 32 + d) * 32 + e] = a / ss;
+    }
 }
 void launch_linattn_merge(const LinMergeP& p, hipStream_t st) {
-    hipLaunchKernelGGL(linattn_merge_kernel, dim3(4, p.B, 4), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(linattn_merge_kernel, dim3(4, p.B, 32), dim3(256), 0, st, p);
 }
 
-// grid (B): M_b = g * Wout * blockdiag(ctx^T) * Wq  ->  Mt fp32 [ci][co]  and  Mbf bf16 [co][ci]
+// grid (C/16 column slabs, B): M_b = g * Wout * blockdiag(ctx^T) * Wq for 16 input columns ci:
 //   T[h*32+e][ci] = sum_d ctx[h][d][e] * Wq[h*32+d][ci];   M[co][ci] = g * sum_{he} Wout[co][he] * T[he][ci]
+// written as Mt fp32 [ci][co] and Mbf bf16 [co][ci].  Everything is staged in LDS with bulk coalesced loads first.
 __global__ __launch_bounds__(256) void linattn_fold_kernel(const LinFoldP p) {
     extern __shared__ float smem_f[];
-    const int C = p.C, tid = threadIdx.x, b = blockIdx.x;
-    float* T = smem_f;                      // [128][C+1]
-    float* cs = T + 128 * (C + 1);          // [4][32][33] ctx
+    const int C = p.C, tid = threadIdx.x, b = blockIdx.y, ci0 = blockIdx.x * 16;
+    float* cs = smem_f;                     // [4][32][33] ctx
+    float* wq = cs + 4 * 32 * 33;           // [128][17]   Wq[:, ci0:ci0+16]
+    float* T = wq + 128 * 17;               // [128][17]
+    float* wo = T + 128 * 17;               // [C][129]    Wout
     for (int idx = tid; idx < 4096; idx += 256) cs[(idx >> 5) * 33 + (idx & 31)] = p.ctx[(long)b * 4096 + idx];
+    for (int idx = tid; idx < 128 * 16; idx += 256) wq[(idx >> 4) * 17 + (idx & 15)] = p.Wq[(long)(idx >> 4) * C + ci0 + (idx & 15)];
+    for (int idx = tid; idx < C * 128; idx += 256) wo[(idx >> 7) * 129 + (idx & 127)] = p.Wout[idx];
     __syncthreads();
-    for (int idx = tid; idx < 128 * C; idx += 256) {
-        const int he = idx / C, ci = idx - he * C, h = he >> 5, e = he & 31;
+    for (int idx = tid; idx < 128 * 16; idx += 256) {
+        const int he = idx >> 4, cl = idx & 15, h = he >> 5, e = he & 31;
         float a = 0.f;
-#pragma unroll 8
-        for (int d = 0; d < 32; ++d) a = fmaf(cs[(h * 32 + d) * 33 + e], p.Wq[(long)(h * 32 + d) * C + ci], a);
-        T[he * (C + 1) + ci] = a;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) a = fmaf(cs[(h * 32 + d) * 33 + e], wq[(h * 32 + d) * 17 + cl], a);
+        T[he * 17 + cl] = a;
     }
     __syncthreads();
     const float g = p.g[0];
-    for (int idx = tid; idx < C * C; idx += 256) {
-        const int co = idx / C, ci = idx - co * C;
+    for (int idx = tid; idx < C * 16; idx += 256) {
+        const int co = idx >> 4, cl = idx & 15;
         float a = 0.f;
-#pragma unroll 8
-        for (int he = 0; he < 128; ++he) a = fmaf(p.Wout[(long)co * 128 + he], T[he * (C + 1) + ci], a);
+#pragma unroll 16
+        for (int he = 0; he < 128; ++he) a = fmaf(wo[co * 129 + he], T[he * 17 + cl], a);
         a *= g;
+        const int ci = ci0 + cl;
         p.Mt[(long)b * C * C + (long)ci * C + co] = a;
         unsigned u = __float_as_uint(a);
         u += 0x7FFFu + ((u >> 16) & 1u);
@@ -211,10 +232,10 @@ __global__ __launch_bounds__(256) void linattn_fold_kernel(const LinFoldP p) {
     }
 }
 void launch_linattn_fold(const LinFoldP& p, hipStream_t st) {
-    const size_t lds = (size_t)(128 * (p.C + 1) + 4 * 32 * 33) * sizeof(float);
+    const size_t lds = (size_t)(4 * 32 * 33 + 2 * 128 * 17 + p.C * 129) * sizeof(float);
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_fold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
-    hipLaunchKernelGGL(linattn_fold_kernel, dim3(p.B), dim3(256), lds, st, p);
+    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_fold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024); attr = true; }
+    hipLaunchKernelGGL(linattn_fold_kernel, dim3(p.C / 16, p.B), dim3(256), lds, st, p);
 }
 
 }  // namespace dex
