@@ -18,6 +18,10 @@ import os
 import sys
 import time
 
+# kernel arguments in device memory: shaves ~0.7 us off every launch of this launch-bound workload (must be set
+# before the HIP runtime initialises)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -63,11 +67,20 @@ def cpu_baseline(cfg, weights, B, T, n_timesteps, TrTs):
         kw = dict(ref=[torch.from_numpy(r) for r in ref], sty=torch.from_numpy(sty), sty_lengths=torch.from_numpy(sl))
     mu, mask, z = map(torch.from_numpy, (mu, mask, z))
     nsub = 3
+    all_cores = torch.get_num_threads()
+    best = None
     with torch.no_grad():
-        O.diffusion_infer(W, cfg, mask, mu, 2, z, **kw)            # warm-up (oneDNN primitive caches)
-        t0 = time.perf_counter()
-        O.diffusion_infer(W, cfg, mask, mu, nsub, z, **kw)
-        dt = time.perf_counter() - t0
+        # oversubscribed hosts run this small-tensor workload slower on all cores: take the better of two settings
+        for nt in sorted({all_cores, min(all_cores, 16)}):
+            torch.set_num_threads(nt)
+            O.diffusion_infer(W, cfg, mask, mu, 2, z, **kw)        # warm-up (oneDNN primitive caches)
+            t0 = time.perf_counter()
+            O.diffusion_infer(W, cfg, mask, mu, nsub, z, **kw)
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, nt)
+    dt, nt = best
+    torch.set_num_threads(nt)
     per_step = dt / nsub
     frames_s = B * T / (per_step * n_timesteps)
     return {"value": round(frames_s, 2), "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
@@ -81,8 +94,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="gedex_b1", choices=sorted(WORKLOADS))
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"])
-    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16"])
+    ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per Euler step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -109,7 +122,7 @@ def main():
     eng.load_weights({k: torch.from_numpy(v) for k, v in weights.items()})
     eng.set_precision(args.precision)
     mu, mask, z, kw, valid = make_inputs(cfg, B, T, TrTs, device, rank)
-    use_graph = not args.no_graph
+    use_graph = args.graph
     stream = torch.cuda.Stream(device)
     gathered = torch.empty(world * B, 80, T, device=device) if world > 1 else None
 
@@ -199,6 +212,30 @@ def main():
                                              "avg_launch_us": round(a["ms"] / a["calls"] * 1e3, 2)}
             res["kernels"] = kern
             res["eager_event_total_ms"] = round(tot, 2)
+        if world == 1 and not args.no_profile and args.precision == "bf16":
+            # companion number in the exact-fp32 MFMA mode (parity mode of the tests)
+            eng.set_precision("fp32")
+            with torch.cuda.stream(stream):
+                eng.sample(z, mask, mu, n_steps, **kw)
+                torch.cuda.synchronize(device)
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    eng.sample(z, mask, mu, n_steps, **kw)
+                torch.cuda.synchronize(device)
+                dt32 = (time.perf_counter() - t0) / 2
+            eng.profile(True)
+            with torch.cuda.stream(stream):
+                eng.sample(z, mask, mu, n_steps, **kw)
+                torch.cuda.synchronize(device)
+            r32 = sorted(eng.profile_rows(), key=lambda r: -r["ms"])
+            eng.profile(False)
+            eng.set_precision("bf16")
+            d32 = r32[0]
+            a32 = d32["flops"] / (d32["ms"] * 1e-3) / 1e12
+            res["fp32_mode"] = {"value": round(valid * 1.0 / dt32, 1), "unit": "mel-frames/s", "ms_per_step": round(dt32 * 1e3, 3),
+                                "roofline": {"kernel": d32["name"], "bound": "mfma", "achieved": round(a32, 2), "peak": PEAK_TFLOPS["f32"],
+                                             "unit": "TFLOP/s", "frac": round(a32 / PEAK_TFLOPS["f32"], 4),
+                                             "avg_launch_us": round(d32["ms"] / d32["calls"] * 1e3, 2)}}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, weights, B, T, n_steps, TrTs)
             res["gpu_over_cpu"] = round(frames_s / res["cpu_baseline"]["value"], 1)
