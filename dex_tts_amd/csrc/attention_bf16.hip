@@ -14,6 +14,7 @@
 //   SPLIT=true : NW waves share ONE 32-query tile and split the keys (wave-private 32-key tiles, partial
 //                (m, l, O) merged through LDS) — keeps small token counts (N=650 at B=1) spread over the chip.
 #include "kernels.h"
+#include "bf16_util.h"
 
 namespace dex {
 
@@ -23,12 +24,6 @@ typedef unsigned short u16;
 constexpr int AHD = 128;
 constexpr int K_LD = AHD + 8;             // bf16 elements per K row in LDS (272 B)
 
-__device__ __forceinline__ unsigned at_pack(float lo, float hi) {
-    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
-    a += 0x7FFFu + ((a >> 16) & 1u);
-    b += 0x7FFFu + ((b >> 16) & 1u);
-    return (a >> 16) | (b & 0xFFFF0000u);
-}
 __device__ __forceinline__ int key_pos(int k) { return (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1); }
 
 union Frag { uint4 u; bf16x8 v; };
@@ -41,6 +36,11 @@ struct Stager {
     static constexpr int VI = (KT / 2) * (AHD / 4) / GS;  // V items (key pair x 4 consecutive d) per thread
     float4 kr[KI][2];
     float4 vr[VI][2];
+    // V item -> (key pair, 4 channels): consecutive threads walk the 128 channels of one key pair (coalesced
+    // 512-B rows).  The transposed LDS dword writes of a wave then collide 16-way; a key-pair-major map is
+    // conflict-free but measured slower (uncoalesced 64-B row segments cost more than the LDS replays).
+    static __device__ __forceinline__ int v_kp(int it) { return it / (AHD / 4); }
+    static __device__ __forceinline__ int v_d4(int it) { return (it % (AHD / 4)) * 4; }
     __device__ __forceinline__ void load(const float* Kb, int ldk, const float* Vb, int ldv, int k0, int Nk, int t) {
 #pragma unroll
         for (int j = 0; j < KI; ++j) {
@@ -52,8 +52,7 @@ struct Stager {
         }
 #pragma unroll
         for (int j = 0; j < VI; ++j) {
-            const int it = t + GS * j;
-            const int kp = it / (AHD / 4), d4 = (it % (AHD / 4)) * 4;
+            const int kp = v_kp(t + GS * j), d4 = v_d4(t + GS * j);
             vr[j][0] = *reinterpret_cast<const float4*>(Vb + (long)min(k0 + 2 * kp, Nk - 1) * ldv + d4);
             vr[j][1] = *reinterpret_cast<const float4*>(Vb + (long)min(k0 + 2 * kp + 1, Nk - 1) * ldv + d4);
         }
@@ -65,19 +64,18 @@ struct Stager {
             const int it = t + GS * j;
             const int key = it / (AHD / 8), d8 = (it % (AHD / 8)) * 8;
             uint4 u;
-            u.x = at_pack(kr[j][0].x, kr[j][0].y); u.y = at_pack(kr[j][0].z, kr[j][0].w);
-            u.z = at_pack(kr[j][1].x, kr[j][1].y); u.w = at_pack(kr[j][1].z, kr[j][1].w);
+            u.x = pack2_bf16_asm(kr[j][0].x, kr[j][0].y); u.y = pack2_bf16_asm(kr[j][0].z, kr[j][0].w);
+            u.z = pack2_bf16_asm(kr[j][1].x, kr[j][1].y); u.w = pack2_bf16_asm(kr[j][1].z, kr[j][1].w);
             *reinterpret_cast<uint4*>(kS + key * K_LD + d8) = u;
         }
 #pragma unroll
         for (int j = 0; j < VI; ++j) {
-            const int it = t + GS * j;
-            const int kp = it / (AHD / 4), d4 = (it % (AHD / 4)) * 4;
+            const int kp = v_kp(t + GS * j), d4 = v_d4(t + GS * j);
             unsigned* dst = reinterpret_cast<unsigned*>(vT + key_pos(2 * kp));      // even position: dword aligned
-            dst[((d4 + 0) * V_LD) >> 1] = at_pack(vr[j][0].x, vr[j][1].x);
-            dst[((d4 + 1) * V_LD) >> 1] = at_pack(vr[j][0].y, vr[j][1].y);
-            dst[((d4 + 2) * V_LD) >> 1] = at_pack(vr[j][0].z, vr[j][1].z);
-            dst[((d4 + 3) * V_LD) >> 1] = at_pack(vr[j][0].w, vr[j][1].w);
+            dst[((d4 + 0) * V_LD) >> 1] = pack2_bf16_asm(vr[j][0].x, vr[j][1].x);
+            dst[((d4 + 1) * V_LD) >> 1] = pack2_bf16_asm(vr[j][0].y, vr[j][1].y);
+            dst[((d4 + 2) * V_LD) >> 1] = pack2_bf16_asm(vr[j][0].z, vr[j][1].z);
+            dst[((d4 + 3) * V_LD) >> 1] = pack2_bf16_asm(vr[j][0].w, vr[j][1].w);
         }
     }
 };
@@ -128,8 +126,8 @@ __device__ __forceinline__ void attn_tile(const u16* kS, const u16* vT, const Fr
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
             Frag pb;
-            pb.u.x = at_pack(s[st][8 * k2 + 0], s[st][8 * k2 + 1]); pb.u.y = at_pack(s[st][8 * k2 + 2], s[st][8 * k2 + 3]);
-            pb.u.z = at_pack(s[st][8 * k2 + 4], s[st][8 * k2 + 5]); pb.u.w = at_pack(s[st][8 * k2 + 6], s[st][8 * k2 + 7]);
+            pb.u.x = pack2_bf16_asm(s[st][8 * k2 + 0], s[st][8 * k2 + 1]); pb.u.y = pack2_bf16_asm(s[st][8 * k2 + 2], s[st][8 * k2 + 3]);
+            pb.u.z = pack2_bf16_asm(s[st][8 * k2 + 4], s[st][8 * k2 + 5]); pb.u.w = pack2_bf16_asm(s[st][8 * k2 + 6], s[st][8 * k2 + 7]);
             const u16* va = vT + i * V_LD + (st * 2 + k2) * 16 + hh * 8;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -147,8 +145,8 @@ __device__ __forceinline__ void load_q(Frag (&qf)[8], const float* Qb, int ldq, 
         float4 a = *reinterpret_cast<const float4*>(qp + ks * 16);
         float4 c = *reinterpret_cast<const float4*>(qp + ks * 16 + 4);
         if (!ok) { a = make_float4(0.f, 0.f, 0.f, 0.f); c = a; }
-        qf[ks].u.x = at_pack(a.x * scale, a.y * scale); qf[ks].u.y = at_pack(a.z * scale, a.w * scale);
-        qf[ks].u.z = at_pack(c.x * scale, c.y * scale); qf[ks].u.w = at_pack(c.z * scale, c.w * scale);
+        qf[ks].u.x = pack2_bf16_asm(a.x * scale, a.y * scale); qf[ks].u.y = pack2_bf16_asm(a.z * scale, a.w * scale);
+        qf[ks].u.z = pack2_bf16_asm(c.x * scale, c.y * scale); qf[ks].u.w = pack2_bf16_asm(c.z * scale, c.w * scale);
     }
 }
 

@@ -15,6 +15,7 @@
 // Epilogue: +bias, GroupNorm partial statistics (workgroup-combined, one fp32 atomic pair per group into a
 // slot-spread buffer), fp32 channels-last store (128-B rows).
 #include "kernels.h"
+#include "bf16_util.h"
 
 namespace dex {
 
@@ -22,12 +23,6 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned short u16;
 
-__device__ __forceinline__ unsigned cv_pack_bf16(float lo, float hi) {
-    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
-    a += 0x7FFFu + ((a >> 16) & 1u);
-    b += 0x7FFFu + ((b >> 16) & 1u);
-    return (a >> 16) | (b & 0xFFFF0000u);
-}
 __device__ __forceinline__ float cv_mish(float x) {           // branch-free: tanh(softplus(x)) == 1 to fp32 for x > 20
     const float e = __expf(fminf(x, 20.f));
     const float n = e * (e + 2.f);
@@ -84,8 +79,8 @@ __device__ __forceinline__ void cv_stage_patch(const Conv3P& p, const float* X, 
         }
         f0.x *= mk; f0.y *= mk; f0.z *= mk; f0.w *= mk; f1.x *= mk; f1.y *= mk; f1.z *= mk; f1.w *= mk;
         uint4 v;
-        v.x = cv_pack_bf16(f0.x, f0.y); v.y = cv_pack_bf16(f0.z, f0.w);
-        v.z = cv_pack_bf16(f1.x, f1.y); v.w = cv_pack_bf16(f1.z, f1.w);
+        v.x = pack2_bf16(f0.x, f0.y); v.y = pack2_bf16(f0.z, f0.w);
+        v.z = pack2_bf16(f1.x, f1.y); v.w = pack2_bf16(f1.z, f1.w);
         *reinterpret_cast<uint4*>(patch + px * LDP + c8) = v;
     }
 }

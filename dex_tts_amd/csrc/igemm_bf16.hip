@@ -3,6 +3,7 @@
 // Same gather semantics and the same epilogue as igemm.hip.  LDS tiles are row-major [rows][BK+8] bf16:
 // the 16-byte pad makes every ds_read_b128 / ds_write_b128 lane group hit 64 distinct banks.
 #include "kernels.h"
+#include "bf16_util.h"
 #include "igemm_epilogue.h"
 
 namespace dex {
@@ -10,13 +11,6 @@ namespace dex {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
-__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
-    // round-to-nearest-even, two fp32 -> one dword of 2 x bf16
-    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
-    a += 0x7FFFu + ((a >> 16) & 1u);
-    b += 0x7FFFu + ((b >> 16) & 1u);
-    return (a >> 16) | (b & 0xFFFF0000u);
-}
 
 template <int BM, int BN, int BK>
 __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemmP p) {
@@ -96,8 +90,8 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemmP p) {
                         const float mk = mrow[wi * p.inmask_ws];
                         f0.x *= mk; f0.y *= mk; f0.z *= mk; f0.w *= mk; f1.x *= mk; f1.y *= mk; f1.z *= mk; f1.w *= mk;
                     }
-                    v.x = pack_bf16(f0.x, f0.y); v.y = pack_bf16(f0.z, f0.w);
-                    v.z = pack_bf16(f1.x, f1.y); v.w = pack_bf16(f1.z, f1.w);
+                    v.x = pack2_bf16(f0.x, f0.y); v.y = pack2_bf16(f0.z, f0.w);
+                    v.z = pack2_bf16(f1.x, f1.y); v.w = pack2_bf16(f1.z, f1.w);
                 }
                 ra[j] = v;
             }
@@ -211,8 +205,8 @@ __global__ __launch_bounds__(256) void igemm_bf16_ss_kernel(const IGemmP p) {
             }
             const float m_ = mk[j];
             uint4 v;
-            v.x = pack_bf16(a.x * m_, a.y * m_); v.y = pack_bf16(a.z * m_, a.w * m_);
-            v.z = pack_bf16(c.x * m_, c.y * m_); v.w = pack_bf16(c.z * m_, c.w * m_);
+            v.x = pack2_bf16(a.x * m_, a.y * m_); v.y = pack2_bf16(a.z * m_, a.w * m_);
+            v.z = pack2_bf16(c.x * m_, c.y * m_); v.w = pack2_bf16(c.z * m_, c.w * m_);
             *reinterpret_cast<uint4*>(As + row * LDS_LD + k8) = v;
         }
     }

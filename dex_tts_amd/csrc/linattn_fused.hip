@@ -11,6 +11,7 @@
 // into M_b (fp32 [ci][co] and bf16 [co][ci]); the tail is one GEMM with K = C and a residual.
 // HBM traffic per call: x read twice + y written, instead of writing q,k,v (6x the size of x) and re-reading them.
 #include "kernels.h"
+#include "bf16_util.h"
 
 namespace dex {
 
@@ -19,12 +20,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned short u16;
 union LFrag { uint4 u; bf16x8 v; };
 
-__device__ __forceinline__ unsigned la_pack(float lo, float hi) {
-    unsigned a = __float_as_uint(lo), b = __float_as_uint(hi);
-    a += 0x7FFFu + ((a >> 16) & 1u);
-    b += 0x7FFFu + ((b >> 16) & 1u);
-    return (a >> 16) | (b & 0xFFFF0000u);
-}
 
 // grid (nblk, B); 256 threads; each wave owns `nsub` consecutive 32-pixel sub-tiles.
 // part_m/part_s: [B][4][nblk][32], part_c: [B][4][nblk][32 d][32 e]   (same layout linattn_combine reads)
@@ -64,8 +59,8 @@ __global__ __launch_bounds__(256) void linattn_kvctx_kernel(const LinKvCtxP p) {
         for (int ks = 0; ks < KS; ++ks) {
             const float4 a = *reinterpret_cast<const float4*>(xr + ks * 16);
             const float4 c = *reinterpret_cast<const float4*>(xr + ks * 16 + 4);
-            af[ks].u.x = la_pack(a.x, a.y); af[ks].u.y = la_pack(a.z, a.w);
-            af[ks].u.z = la_pack(c.x, c.y); af[ks].u.w = la_pack(c.z, c.w);
+            af[ks].u.x = pack2_bf16(a.x, a.y); af[ks].u.y = pack2_bf16(a.z, a.w);
+            af[ks].u.z = pack2_bf16(c.x, c.y); af[ks].u.w = pack2_bf16(c.z, c.w);
         }
         f32x16 kv[8];
 #pragma unroll
@@ -103,10 +98,10 @@ __global__ __launch_bounds__(256) void linattn_kvctx_kernel(const LinKvCtxP p) {
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
                 LFrag va, pb;
-                va.u.x = la_pack(kv[4 + h][8 * k2 + 0], kv[4 + h][8 * k2 + 1]); va.u.y = la_pack(kv[4 + h][8 * k2 + 2], kv[4 + h][8 * k2 + 3]);
-                va.u.z = la_pack(kv[4 + h][8 * k2 + 4], kv[4 + h][8 * k2 + 5]); va.u.w = la_pack(kv[4 + h][8 * k2 + 6], kv[4 + h][8 * k2 + 7]);
-                pb.u.x = la_pack(kv[h][8 * k2 + 0], kv[h][8 * k2 + 1]); pb.u.y = la_pack(kv[h][8 * k2 + 2], kv[h][8 * k2 + 3]);
-                pb.u.z = la_pack(kv[h][8 * k2 + 4], kv[h][8 * k2 + 5]); pb.u.w = la_pack(kv[h][8 * k2 + 6], kv[h][8 * k2 + 7]);
+                va.u.x = pack2_bf16(kv[4 + h][8 * k2 + 0], kv[4 + h][8 * k2 + 1]); va.u.y = pack2_bf16(kv[4 + h][8 * k2 + 2], kv[4 + h][8 * k2 + 3]);
+                va.u.z = pack2_bf16(kv[4 + h][8 * k2 + 4], kv[4 + h][8 * k2 + 5]); va.u.w = pack2_bf16(kv[4 + h][8 * k2 + 6], kv[4 + h][8 * k2 + 7]);
+                pb.u.x = pack2_bf16(kv[h][8 * k2 + 0], kv[h][8 * k2 + 1]); pb.u.y = pack2_bf16(kv[h][8 * k2 + 2], kv[h][8 * k2 + 3]);
+                pb.u.z = pack2_bf16(kv[h][8 * k2 + 4], kv[h][8 * k2 + 5]); pb.u.w = pack2_bf16(kv[h][8 * k2 + 6], kv[h][8 * k2 + 7]);
                 ctxT[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va.v, pb.v, ctxT[h], 0, 0, 0);
             }
         }
