@@ -495,7 +495,7 @@ struct Plan {
     std::vector<float*> tadd_down, tadd_up, ada;
     float *adap_tmp, *t_adap, *t_sty, *tv_k0, *tv_v0, *sap_m, *sap_s, *ref_mean, *ref_std;
     float *spk_tmp, *spk_plane;
-    int* step; float* stats; long stats_bytes; int n_gn;
+    int* step; int* step_tab; float* stats; long stats_bytes; int n_gn;   // stats: two arenas (Euler-step parity)
     float* xbuf;
     std::vector<StageBuf> down, up;
     std::vector<float*> cat;
@@ -529,9 +529,10 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
     P.spk_tmp = P.spk_plane = nullptr;
     if (c.n_spks > 1) { P.spk_tmp = A.f((size_t)B * 4 * c.spk_emb_dim); P.spk_plane = A.f((size_t)B * c.n_feats); }
     P.step = (int*)A.take(256);
+    P.step_tab = (int*)A.take((size_t)(n + 1) * sizeof(int));
     P.n_gn = 4 * c.n_stages + 4 * (c.n_stages - 1) + 1;
     P.stats_bytes = (long)P.n_gn * B * 8 * GN_SLOTS * 2 * sizeof(float);
-    P.stats = (float*)A.take(P.stats_bytes);
+    P.stats = (float*)A.take(2 * P.stats_bytes);
     P.xbuf = A.f((size_t)B * 80 * d.T);
     P.cat.assign(c.n_stages - 1, nullptr);
     for (int j = 0; j < c.n_stages - 1; ++j) {
@@ -593,6 +594,9 @@ struct Runner {
     const DexSampleArgs* args;
     bool debug;
     int gn_idx = 0;
+    const int* sp = nullptr;        // device pointer to the current Euler-step index
+    float* stats_base = nullptr;    // statistics arena of this step
+    float* stats_other = nullptr;   // arena to clear for the next step (eager mode), or null
 
     template <typename F> void run(const char* name, double flops, double bytes, F&& f) {
         if (x->prof_on) {
@@ -602,7 +606,7 @@ struct Runner {
             x->prof.push_back(pr);
         } else f();
     }
-    float* next_stats() { return P.stats + (size_t)(gn_idx++) * P.d.B * 8 * GN_SLOTS * 2; }
+    float* next_stats() { return stats_base + (size_t)(gn_idx++) * P.d.B * 8 * GN_SLOTS * 2; }
     void tap(const char* name, const float* p, long rows, int C, int ld) {
         if (!debug) return;
         DexCtx::Tap t; t.name = name; t.p = p; t.shape = {rows, C, ld};
@@ -626,7 +630,7 @@ struct Runner {
         g.inmask = nullptr; g.inmask_ws = 1; g.outmask = nullptr; g.outmask_ws = 1; g.mask_bstride = P.d.T;
         g.act = 0; g.gate = nullptr; g.gate_nstride = 1; g.gate_step_stride = 0;
         g.res = nullptr; g.ldres = 0; g.res_bstride = 0; g.res_coff = 0;
-        g.step = P.step; g.unpatch_s = 0; g.unpatch_C = 0; g.B = P.d.B;
+        g.step = sp; g.unpatch_s = 0; g.unpatch_C = 0; g.B = P.d.B;
         return g;
     }
     void gemm(const char* name, const IGemmP& g) {
@@ -647,7 +651,7 @@ struct Runner {
             c.X = X.p; c.ldx = X.ld; c.x_coff = X.coff; c.H = H; c.W = W; c.Cin = X.C; c.Cout = Cout;
             c.Wbf = it->second; c.bias = bias; c.Y = out; c.mask = mask; c.mask_ws = mask_ws; c.mask_bstride = P.d.T;
             if (pro) { c.pro_stats = pro->stats; c.pro_gamma = pro->gamma; c.pro_beta = pro->beta; c.pro_tadd = pro->tadd; }
-            c.step = P.step; c.gn_stats = gn; c.B = P.d.B;
+            c.step = sp; c.gn_stats = gn; c.B = P.d.B;
             const double M = (double)H * W * P.d.B;
             run(name, 2.0 * M * Cout * 9 * X.C, 4.0 * M * (X.C + Cout) + 2.0 * 9 * X.C * Cout, [&] { launch_conv3x3_bf16(c, st); });
             return;
@@ -668,7 +672,7 @@ struct Runner {
         a.X = h; a.ldx = C; a.xb = npix * C; a.Y = out; a.ldy = C; a.yb = npix * C; a.y_coff = 0;
         a.npix = (int)npix; a.W = W; a.C = C; a.groups = 8; a.stats = stats; a.gamma = gamma; a.beta = beta;
         a.mask = mask; a.mask_ws = mask_ws; a.mask_bstride = P.d.T;
-        a.tadd = tadd; a.tadd_step_stride = C; a.step = P.step;
+        a.tadd = tadd; a.tadd_step_stride = C; a.step = sp;
         a.res = res; a.ldres = ldres; a.resb = resb; a.res_under_mask = res_under_mask ? 1 : 0; a.B = P.d.B;
         run("gn_apply_mish", 12.0 * npix * C * P.d.B, (res ? 12.0 : 8.0) * npix * C * P.d.B, [&] { launch_gn_apply(a, st); });
     }
@@ -681,8 +685,9 @@ struct Runner {
         if (first_layer) {
             FirstConvP f{};
             f.mu = mu; f.x = xcur; f.spk = P.spk_plane; f.mask = mask; f.B = P.d.B; f.H = s.H; f.T = s.W; f.planes = w.cin; f.C = w.cout;
-            f.W3 = w.w1; f.b3 = w.b1; f.W1 = w.wr; f.b1 = w.br; f.scal = P.scal; f.scal_stride = SCAL_STRIDE; f.step = P.step;
+            f.W3 = w.w1; f.b3 = w.b1; f.W1 = w.wr; f.b1 = w.br; f.scal = P.scal; f.scal_stride = SCAL_STRIDE; f.step = sp;
             f.h1 = s.h1; f.res = s.rbuf;
+            st1 = next_stats(); f.gn_stats = st1;
             run("first_conv", 2.0 * npix * P.d.B * w.cout * (w.cin * 10), 4.0 * npix * P.d.B * (2 * w.cout + w.cin), [&] { launch_first_conv(f, st); });
             resptr = s.rbuf; ldres = w.cout; resb = npix * w.cout;
         } else {
@@ -774,7 +779,7 @@ struct Runner {
             IGemmP q = base_gemm(fuse_ln ? P.tok : P.xn, hid, 0, 1, N, hid, w.wqkv, 3 * hid, w.bqkv, P.qkv, 3 * hid, 0);
             if (fuse_ln) { q.ln_shift = ada + 0 * hid; q.ln_scale = ada + 1 * hid; q.ln_step_stride = 6L * hid; }
             else {
-                LnModP l1{P.tok, P.xn, N, hid, ada + 0 * hid, ada + 1 * hid, 6L * hid, P.step, B};
+                LnModP l1{P.tok, P.xn, N, hid, ada + 0 * hid, ada + 1 * hid, 6L * hid, sp, B};
                 run("ln_modulate", 8.0 * B * N * hid, 8.0 * B * N * hid, [&] { launch_ln_mod(l1, st); });
             }
             gemm("dit_qkv", q);
@@ -791,7 +796,7 @@ struct Runner {
             IGemmP f1 = base_gemm(fuse_ln ? P.tok : P.xn, hid, 0, 1, N, hid, w.wfc1, mh, w.bfc1, P.hmlp, mh, 0);
             if (fuse_ln) { f1.ln_shift = ada + 3 * hid; f1.ln_scale = ada + 4 * hid; f1.ln_step_stride = 6L * hid; }
             else {
-                LnModP l2{P.tok, P.xn, N, hid, ada + 3 * hid, ada + 4 * hid, 6L * hid, P.step, B};
+                LnModP l2{P.tok, P.xn, N, hid, ada + 3 * hid, ada + 4 * hid, 6L * hid, sp, B};
                 run("ln_modulate", 8.0 * B * N * hid, 8.0 * B * N * hid, [&] { launch_ln_mod(l2, st); });
             }
             f1.act = 1;
@@ -812,7 +817,7 @@ struct Runner {
         IGemmP fl = base_gemm(fuse_lnf ? P.tok : P.xn, hid, 0, P.Hf, P.Wt, hid, x->fl_w, s2c, x->fl_b, out, ldo, ocoff);
         if (fuse_lnf) { fl.ln_shift = P.fin_mod; fl.ln_scale = P.fin_mod + hid; fl.ln_step_stride = 2L * hid; }
         else {
-            LnModP lf{P.tok, P.xn, N, hid, P.fin_mod, P.fin_mod + hid, 2L * hid, P.step, B};
+            LnModP lf{P.tok, P.xn, N, hid, P.fin_mod, P.fin_mod + hid, 2L * hid, sp, B};
             run("ln_modulate", 8.0 * B * N * hid, 8.0 * B * N * hid, [&] { launch_ln_mod(lf, st); });
         }
         fl.unpatch_s = c.dit_stride; fl.unpatch_C = mid; fl.OHf = P.Hm; fl.OWf = P.Wm;
@@ -834,7 +839,7 @@ struct Runner {
         IGemmP q = base_gemm(X.p, X.ld, X.coff, P.Hm, P.Wm, mid, P.tv_weff, mid, P.tv_beff, P.tv_q, mid, 0);
         q.w_bstride = (long)mid * mid; q.bias_bstride = mid; q.inmask = mask; q.inmask_ws = mask_ws;
         gemm("tv_q", q);
-        TvRow0P r0{P.tv_k0, P.tv_v0, P.step, P.tv_K, P.tv_V, (long)(P.d.Ts + 1) * mid, mid, B};
+        TvRow0P r0{P.tv_k0, P.tv_v0, sp, P.tv_K, P.tv_V, (long)(P.d.Ts + 1) * mid, mid, B};
         run("tv_time_token", 0, 8.0 * mid * B, [&] { launch_tv_row0(r0, st); });
         AttnP a{};
         a.Q = P.tv_q; a.ldq = mid; a.qb = npix * mid; a.K = P.tv_K; a.ldk = mid; a.kb = (long)(P.d.Ts + 1) * mid;
@@ -849,7 +854,7 @@ struct Runner {
         tap("tv", P.tv_out, B * npix, mid, mid);
         InStatsP is2{P.tv_out, mid, npix * mid, (int)npix, mid, P.tiv_stats, B, nullptr, 1, 0, P.Wm};
         run("in2d_stats", 3.0 * npix * mid * B, 4.0 * npix * mid * B, [&] { launch_in_stats(is2, st); });
-        TivApplyP ta{P.tv_out, mid, npix * mid, P.tiv_out, mid, npix * mid, (int)npix, mid, P.tiv_stats, 1e-5f, P.sap_s, P.sap_m, P.step, B};
+        TivApplyP ta{P.tv_out, mid, npix * mid, P.tiv_out, mid, npix * mid, (int)npix, mid, P.tiv_stats, 1e-5f, P.sap_s, P.sap_m, sp, B};
         run("tiv_adain", 2.0 * npix * mid * B, 8.0 * npix * mid * B, [&] { launch_tiv_apply(ta, st); });
         tap("tiv", P.tiv_out, B * npix, mid, mid);
     }
@@ -859,7 +864,7 @@ struct Runner {
         const DexConfig& c = x->cfg;
         const int B = P.d.B, ns = c.n_stages;
         gn_idx = 0;
-        hipMemsetAsync(P.stats, 0, P.stats_bytes, st);
+        if (!stats_other) hipMemsetAsync(stats_base, 0, P.stats_bytes, st);   // graph mode / single call: clear in place
         TD cur{nullptr, 0, 0, 0};
         for (int i = 0; i < ns; ++i) {
             const StageBuf& s = P.down[i];
@@ -906,11 +911,10 @@ struct Runner {
             // Upsample = ConvTranspose2d(4,2,1) on x*mask: four parity sub-convolutions with 2x2 taps
             float* dst; int ldd;
             if (j < ns - 2) { dst = P.cat[j + 1]; ldd = 2 * stage_dim(c, i - 1); } else { dst = P.up_out; ldd = s.C; }
-            for (int par = 0; par < 4; ++par) {
-                const int ph = par >> 1, pw = par & 1;
-                IGemmP g = base_gemm(s.attn_out, s.C, 0, s.H, s.W, s.C, x->up_us_w[j] + (long)par * 4 * s.C * s.C, s.C, x->up_us_b[j], dst, ldd, 0);
-                g.KH = 2; g.KW = 2; g.step_h = -1; g.step_w = -1; g.off_h = ph; g.off_w = pw; g.K = 4 * s.C;
-                g.OHf = 2 * s.H; g.OWf = 2 * s.W; g.osh = 2; g.osw = 2; g.oh0 = ph; g.ow0 = pw;
+            {
+                IGemmP g = base_gemm(s.attn_out, s.C, 0, s.H, s.W, s.C, x->up_us_w[j], s.C, x->up_us_b[j], dst, ldd, 0);
+                g.KH = 2; g.KW = 2; g.step_h = -1; g.step_w = -1; g.K = 4 * s.C; g.parity = 1;
+                g.OHf = 2 * s.H; g.OWf = 2 * s.W; g.osh = 2; g.osw = 2;
                 g.c_bstride = 4L * s.H * s.W * ldd;
                 g.inmask = mask; g.inmask_ws = s.mask_ws;
                 gemm("upsample_convT", g);
@@ -923,7 +927,8 @@ struct Runner {
         FinalP f{};
         f.X = P.hF; f.xb = 80L * P.d.T * c.dim; f.npix = 80 * P.d.T; f.W = P.d.T; f.C = c.dim; f.groups = 8; f.stats = stf;
         f.gamma = x->fin_g; f.beta = x->fin_be; f.mask = mask; f.mask_bstride = P.d.T; f.wfc = x->fconv_w; f.bfc = x->fconv_b;
-        f.xcur = xcur; f.denoised = denoised; f.xnext = xnext; f.scal = P.scal; f.scal_stride = SCAL_STRIDE; f.step = P.step; f.B = B;
+        f.xcur = xcur; f.denoised = denoised; f.xnext = xnext; f.scal = P.scal; f.scal_stride = SCAL_STRIDE; f.step = sp; f.B = B;
+        f.zero_ptr = stats_other; f.zero_n = P.stats_bytes / (long)sizeof(float);
         run("final_conv_euler", 14.0 * 80 * P.d.T * c.dim * B, 4.0 * 80 * P.d.T * (c.dim + 3) * B, [&] { launch_final(f, st); });
     }
 
@@ -1038,6 +1043,7 @@ int dex_denoise_once(DexCtx* x, const DexDenoiseArgs* da, dex_stream_t stream) {
     make_plan(x, d, a->workspace_dev, P);
     x->taps.clear();
     Runner R{x, P, st, a->mask_dev, a->mu_dev, da->x_dev, a, true};
+    R.sp = P.step; R.stats_base = P.stats; R.stats_other = nullptr;
     hipLaunchKernelGGL(set_sigma_pair, dim3(1), dim3(1), 0, st, a->sigmas_dev, P.sig2);
     launch_step_reset(P.step, st);
     R.prepare(P.sig2, 1);
@@ -1057,7 +1063,9 @@ int dex_sample(DexCtx* x, const DexSampleArgs* a, dex_stream_t stream) {
     x->taps.clear();
     if (x->prof_on) { for (auto& pr : x->prof) { hipEventDestroy(pr.a); hipEventDestroy(pr.b); } x->prof.clear(); x->prof_agg.clear(); }
     Runner R{x, P, st, a->mask_dev, a->mu_dev, P.xbuf, a, false};
+    R.sp = P.step; R.stats_base = P.stats; R.stats_other = nullptr;
     launch_step_reset(P.step, st);
+    launch_iota(P.step_tab, a->n_steps, st);
     R.prepare(a->sigmas_dev, a->n_steps);
     // x_0 = z * sigma_0 (edm.py:188-189)
     R.run("init_scale", 0, 8.0 * a->B * 80 * a->T, [&] { launch_scale_copy(a->z_dev, P.xbuf, (long)a->B * 80 * a->T, P.scal, st); });
@@ -1082,7 +1090,14 @@ int dex_sample(DexCtx* x, const DexSampleArgs* a, dex_stream_t stream) {
         }
         for (int i = 0; i < a->n_steps; ++i) HIPCHK(x, hipGraphLaunch(x->graph_exec, st));
     } else {
-        for (int i = 0; i < a->n_steps; ++i) { R.step(nullptr, P.xbuf); launch_step_inc(P.step, st); }
+        // eager: the step index comes from a device table (no increment kernel) and the GroupNorm statistics
+        // alternate between two arenas; each step's last kernel clears the arena of the next step
+        float* arena[2] = {P.stats, P.stats + P.stats_bytes / (long)sizeof(float)};
+        hipMemsetAsync(P.stats, 0, 2 * P.stats_bytes, st);
+        for (int i = 0; i < a->n_steps; ++i) {
+            R.sp = P.step_tab + i; R.stats_base = arena[i & 1]; R.stats_other = arena[(i + 1) & 1];
+            R.step(nullptr, P.xbuf);
+        }
     }
     HIPCHK(x, hipMemcpyAsync(a->out_dev, P.xbuf, (size_t)a->B * 80 * a->T * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIPCHK(x, hipGetLastError());

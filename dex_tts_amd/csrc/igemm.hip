@@ -31,10 +31,13 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const int z = blockIdx.z;
+    int z = blockIdx.z, par = 0;
+    if (p.parity) { par = z & 3; z >>= 2; }
     const int s = z % p.ksplit;
     const int g = (z / p.ksplit) % p.groups;
     const int b = z / (p.ksplit * p.groups);
+    const int off_h = p.parity ? (par >> 1) : p.off_h, off_w = p.parity ? (par & 1) : p.off_w;
+    const int oh0 = p.parity ? (par >> 1) : p.oh0, ow0 = p.parity ? (par & 1) : p.ow0;
     const int M = p.Ho * p.Wo;
     // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch), each XCD has a private L2, and
     // neighbouring pixel tiles share their 3x3 halo -> give every XCD one contiguous range of tiles.
@@ -53,11 +56,11 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
         int m = m0 + arow + 32 * j;
         mv[j] = m < M;
         int ho = m / p.Wo, wo = m - ho * p.Wo;
-        bh[j] = ho * p.sh + p.off_h;
-        bw[j] = wo * p.sw + p.off_w;
+        bh[j] = ho * p.sh + off_h;
+        bw[j] = wo * p.sw + off_w;
     }
     const int brow = tid / BTR, bc4 = (tid % BTR) * 4;
-    const float* Wb = p.W + (long)b * p.w_bstride + (long)g * p.w_gstride + n0 + bc4;
+    const float* Wb = p.W + (long)b * p.w_bstride + (long)g * p.w_gstride + (long)par * p.K * p.N + n0 + bc4;
 
     float4 ra[AP];
     float4 rb0 = make_float4(0.f, 0.f, 0.f, 0.f), rb1 = rb0;
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
         }
     }
 
-    igemm_epilogue<MT>(p, acc, m0, n0, wm * (MT * 32), wn * 32, lane, b, g, s, M);
+    igemm_epilogue<MT>(p, acc, m0, n0, wm * (MT * 32), wn * 32, lane, b, g, s, M, oh0, ow0);
 }
 
 void launch_igemm_bf16(const IGemmP& p, hipStream_t st);   // igemm_bf16.hip
@@ -125,7 +128,7 @@ void launch_igemm_bf16(const IGemmP& p, hipStream_t st);   // igemm_bf16.hip
 void launch_igemm(const IGemmP& p, int precision, hipStream_t st) {
     if (precision == 1 && p.Wbf != nullptr) { launch_igemm_bf16(p, st); return; }
     const int M = p.Ho * p.Wo;
-    const int zdim = p.B * p.groups * p.ksplit;
+    const int zdim = p.B * p.groups * p.ksplit * (p.parity ? 4 : 1);
     if (p.N % 64 == 0) {
         // small-M problems (DiT tokens at B=1) use the 64-row tile to put more workgroups on the chip
         const long blocks128 = (long)((M + 127) / 128) * (p.N / 64) * zdim;

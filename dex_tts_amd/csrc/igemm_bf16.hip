@@ -27,10 +27,13 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemmP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const int z = blockIdx.z;
+    int z = blockIdx.z, par = 0;
+    if (p.parity) { par = z & 3; z >>= 2; }
     const int s = z % p.ksplit;
     const int g = (z / p.ksplit) % p.groups;
     const int b = z / (p.ksplit * p.groups);
+    const int off_h = p.parity ? (par >> 1) : p.off_h, off_w = p.parity ? (par & 1) : p.off_w;
+    const int oh0 = p.parity ? (par >> 1) : p.oh0, ow0 = p.parity ? (par & 1) : p.ow0;
     const int M = p.Ho * p.Wo;
     // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch), each XCD has a private L2, and
     // neighbouring pixel tiles share their 3x3 halo -> give every XCD one contiguous range of tiles.
@@ -49,11 +52,11 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemmP p) {
         const int m = m0 + trow + RPP * j;
         mv[j] = m < M;
         const int ho = m / p.Wo, wo = m - ho * p.Wo;
-        bh[j] = ho * p.sh + p.off_h;
-        bw[j] = wo * p.sw + p.off_w;
+        bh[j] = ho * p.sh + off_h;
+        bw[j] = wo * p.sw + off_w;
     }
     // bf16 weights [N][K] (per group / per batch strides are in elements of the fp32 [K][N] pack: same count)
-    const u16* Wb = reinterpret_cast<const u16*>(p.Wbf) + (long)b * p.w_bstride + (long)g * p.w_gstride;
+    const u16* Wb = reinterpret_cast<const u16*>(p.Wbf) + (long)b * p.w_bstride + (long)g * p.w_gstride + (long)par * p.K * p.N;
 
     uint4 ra[AP];
     uint4 rb0 = make_uint4(0, 0, 0, 0), rb1 = rb0;
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemmP p) {
             }
         }
     }
-    igemm_epilogue<MT>(p, acc, m0, n0, wm * (MT * 32), wn * 32, lane, b, g, s, M);
+    igemm_epilogue<MT>(p, acc, m0, n0, wm * (MT * 32), wn * 32, lane, b, g, s, M, oh0, ow0);
 }
 
 // ---- single-shot variant (K <= 512): the whole K extent of the A and B tiles is staged at once, so a
@@ -132,12 +135,15 @@ __global__ __launch_bounds__(256) void igemm_bf16_ss_kernel(const IGemmP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const int b = blockIdx.z;
+    int b = blockIdx.z, par = 0;
+    if (p.parity) { par = b & 3; b >>= 2; }
+    const int off_h = p.parity ? (par >> 1) : p.off_h, off_w = p.parity ? (par & 1) : p.off_w;
+    const int oh0 = p.parity ? (par >> 1) : p.oh0, ow0 = p.parity ? (par & 1) : p.ow0;
     const int M = p.Ho * p.Wo;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const float* Ab = p.A + (long)b * p.a_bstride + p.a_coff;
     const float* mrow = p.inmask ? p.inmask + (long)b * p.mask_bstride : nullptr;
-    const u16* Wb = reinterpret_cast<const u16*>(p.Wbf) + (long)b * p.w_bstride;
+    const u16* Wb = reinterpret_cast<const u16*>(p.Wbf) + (long)b * p.w_bstride + (long)par * K * p.N;
     const int step = p.step ? *p.step : 0;
     const float* lsh = p.ln_shift ? p.ln_shift + (long)step * p.ln_step_stride : nullptr;
     const float* lsc = p.ln_scale ? p.ln_scale + (long)step * p.ln_step_stride : nullptr;
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_ss_kernel(const IGemmP p) {
             const int kh = tap / p.KW, kw = tap - kh * p.KW;
             const int mm = m < M ? m : 0;
             const int ho = mm / p.Wo, wo = mm - ho * p.Wo;
-            const int hi = ho * p.sh + p.off_h + kh * p.step_h, wi = wo * p.sw + p.off_w + kw * p.step_w;
+            const int hi = ho * p.sh + off_h + kh * p.step_h, wi = wo * p.sw + off_w + kw * p.step_w;
             const bool ok = m < M && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
             const int hc = ok ? hi : 0, wc = ok ? wi : 0;
             const float* src = Ab + ((long)hc * p.Wi + wc) * p.lda + c0;
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_ss_kernel(const IGemmP p) {
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
         }
     }
-    igemm_epilogue<MT>(p, acc, m0, n0, wm * (MT * 32), wn * 32, lane, b, 0, 0, M);
+    igemm_epilogue<MT>(p, acc, m0, n0, wm * (MT * 32), wn * 32, lane, b, 0, 0, M, oh0, ow0);
 }
 
 template <int K>
@@ -238,7 +244,7 @@ static void launch_ss(const IGemmP& p, hipStream_t st) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_ss_kernel<64, 64, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    dim3 grid((p.Ho * p.Wo + 63) / 64, p.N / 64, p.B);
+    dim3 grid((p.Ho * p.Wo + 63) / 64, p.N / 64, p.B * (p.parity ? 4 : 1));
     hipLaunchKernelGGL((igemm_bf16_ss_kernel<64, 64, K>), grid, dim3(256), lds, st, p);
 }
 
@@ -258,7 +264,7 @@ void launch_igemm_bf16(const IGemmP& p, hipStream_t st) {
         else launch_ss<512>(p, st);
         return;
     }
-    const int zdim = p.B * p.groups * p.ksplit;
+    const int zdim = p.B * p.groups * p.ksplit * (p.parity ? 4 : 1);
     const bool k64 = (p.Cin % 64 == 0) && ((p.K / p.ksplit) % 64 == 0);
     if (p.N % 64 == 0) {
         const long blocks128 = (long)((M + 127) / 128) * (p.N / 64) * zdim;

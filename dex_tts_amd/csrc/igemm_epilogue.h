@@ -18,7 +18,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // rows [row0, row0 + MT*32) x cols [col0, col0+32) of the block tile belong to this wave.
 template <int MT>
 __device__ __forceinline__ void igemm_epilogue(const IGemmP& p, f32x16 (&acc)[MT], int m0, int n0, int row0, int col0,
-                                               int lane, int b, int g, int s, int M) {
+                                               int lane, int b, int g, int s, int M, int oh0, int ow0) {
     const int i = lane & 31, hh = lane >> 5;
     const int n = n0 + col0 + i;                 // column within the group
     const int ng = g * p.N + n;                  // global output channel
@@ -51,7 +51,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmP& p, f32x16 (&acc)[MT
             const int ho = mm / p.Wo, wo = mm - ho * p.Wo;
             int oh, ow;
             if (unp) { oh = ho * p.unpatch_s + up_p1; ow = wo * p.unpatch_s + up_p2; v = v && oh < p.OHf && ow < p.OWf; }
-            else { oh = ho * p.osh + p.oh0; ow = wo * p.osw + p.ow0; }
+            else { oh = ho * p.osh + oh0; ow = wo * p.osw + ow0; }
             ok[r] = v;
             opix[r] = v ? oh * p.OWf + ow : 0;
             ow_[r] = v ? ow : 0;

@@ -35,6 +35,8 @@ struct IGemmP {
     const float* res; int ldres; long res_bstride; int res_coff;
     const int* step;
     int unpatch_s, unpatch_C;                          // >0: scatter rows (f,w) x cols (p1,p2,c) -> NHWC image
+    int parity;                                        // 1: blockIdx.z = b*4 + (ph*2+pw): ConvTranspose2d(4,2,1) as four 2x2-tap
+                                                       // sub-convolutions in ONE launch (off/oh0/ow0 = parity, weights += par*K*N)
     float* gn_stats; int gn_groups, gn_cpg;            // fused GroupNorm partial statistics of (acc + bias), or null
     const float* ln_shift; const float* ln_scale; long ln_step_stride;   // fused LayerNorm(eps 1e-6)+modulate on the A rows
                                                        // (single-shot bf16 kernel only; needs K == Cin == row length)
@@ -64,6 +66,7 @@ struct FirstConvP {
     const float* W1; const float* b1;                     // [planes][C], [C]
     const float* scal; int scal_stride; const int* step;  // per-step scalars; scal[step*stride + 2] = c_in
     float* h1; float* res;                                // [B,H,T,C] each
+    float* gn_stats;                                      // fused GroupNorm partials of h1 (8 groups, slot-spread) or null
 };
 void launch_first_conv(const FirstConvP& p, hipStream_t st);
 
@@ -92,6 +95,7 @@ struct FinalP {
     float* denoised;                                      // optional D_x out
     float* xnext;                                         // optional Euler update out (may alias xcur)
     const float* scal; int scal_stride; const int* step;
+    float* zero_ptr; long zero_n;                         // optional: clear the OTHER parity's GroupNorm statistics arena
     int B;
 };
 void launch_final(const FinalP& p, hipStream_t st);
@@ -151,6 +155,7 @@ void launch_cond_prep(const CondPrepP& p, hipStream_t st);
 void launch_scale_copy(const float* src, float* dst, long n, const float* scal_ptr, hipStream_t st); // dst = src * *scal_ptr
 void launch_step_reset(int* step, hipStream_t st);
 void launch_step_inc(int* step, hipStream_t st);
+void launch_iota(int* dst, int n, hipStream_t st);
 void launch_permute4(const float* src, float* dst, int d0, int d1, int d2, int d3, int p0, int p1, int p2, int p3,
                      hipStream_t st);   // dst = src.permute(p0..p3).contiguous()
 void launch_f32_to_bf16(const float* src, void* dst, long n, hipStream_t st);

@@ -80,6 +80,17 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const FirstConvP p) {
     }
     *reinterpret_cast<float4*>(p.h1 + pix * p.C + cq * 4) = a3;
     *reinterpret_cast<float4*>(p.res + pix * p.C + cq * 4) = a1;
+    if (p.gn_stats) {          // workgroup-combined GroupNorm partials of h1 (8 groups), one atomic pair per group
+        __shared__ float red[16];
+        if (threadIdx.x < 16) red[threadIdx.x] = 0.f;
+        __syncthreads();
+        const int g = (cq * 4) / (p.C / 8);
+        atomicAdd(&red[g * 2], (a3.x + a3.y) + (a3.z + a3.w));
+        atomicAdd(&red[g * 2 + 1], (a3.x * a3.x + a3.y * a3.y) + (a3.z * a3.z + a3.w * a3.w));
+        __syncthreads();
+        if (threadIdx.x < 16)
+            atomicAdd(p.gn_stats + (((long)b * 8 + (threadIdx.x >> 1)) * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * 2 + (threadIdx.x & 1), red[threadIdx.x]);
+    }
 }
 void launch_first_conv(const FirstConvP& p, hipStream_t st) {
     const long total = (long)p.B * p.H * p.T * (p.C / 4);
@@ -219,6 +230,10 @@ __global__ __launch_bounds__(256) void final_kernel(const FinalP p) {
             }
         }
     }
+    if (p.zero_ptr) {          // clear the statistics arena the NEXT Euler step accumulates into (other parity)
+        const long nthreads = (long)gridDim.x * gridDim.y * 256;
+        for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < p.zero_n; i += nthreads) p.zero_ptr[i] = 0.f;
+    }
 }
 void launch_final(const FinalP& p, hipStream_t st) {
     long blocks = (p.npix + 15) / 16;
@@ -307,6 +322,8 @@ void launch_scale_copy(const float* src, float* dst, long n, const float* scal_p
     long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(scale_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, n, scal_ptr);
 }
+__global__ void iota_kernel(int* d, int n) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) d[i] = i; }
+void launch_iota(int* dst, int n, hipStream_t st) { hipLaunchKernelGGL(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dst, n); }
 __global__ void step_reset_kernel(int* s) { *s = 0; }
 __global__ void step_inc_kernel(int* s) { *s = *s + 1; }
 void launch_step_reset(int* step, hipStream_t st) { hipLaunchKernelGGL(step_reset_kernel, dim3(1), dim3(1), 0, st, step); }
