@@ -98,6 +98,10 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per Euler step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N>1 (nccl == RCCL over xGMI; gloo only for single-GPU smoke tests)")
+    ap.add_argument("--all-on-device0", action="store_true",
+                    help="testing aid: every rank uses cuda:0 (exercises the N>1 code path on a 1-GPU box; use with --backend gloo)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -107,12 +111,17 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
+    if args.all_on_device0:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     preset, B, T, n_steps, TrTs = WORKLOADS[args.workload]
     cfg = C.PRESETS[preset]()
@@ -124,12 +133,13 @@ def main():
     mu, mask, z, kw, valid = make_inputs(cfg, B, T, TrTs, device, rank)
     use_graph = args.graph
     stream = torch.cuda.Stream(device)
-    gathered = torch.empty(world * B, 80, T, device=device) if world > 1 else None
+    gdev = device if args.backend == "nccl" else torch.device("cpu")
+    gathered = torch.empty(world * B, 80, T, device=gdev) if world > 1 else None
 
     def one_call():
         out = eng.sample(z, mask, mu, n_steps, use_graph=use_graph, **kw)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, out)
+        if world > 1:       # the path's one exchange step: finished mels of every shard
+            dist.all_gather_into_tensor(gathered, out if args.backend == "nccl" else out.cpu())
         return out
 
     with torch.cuda.stream(stream):
@@ -148,10 +158,10 @@ def main():
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device=gdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        v = torch.tensor([float(valid)], device=device, dtype=torch.float64)
+        v = torch.tensor([float(valid)], device=gdev, dtype=torch.float64)
         dist.all_reduce(v)
         valid_total = int(v.item())
     else:
