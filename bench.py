@@ -246,6 +246,37 @@ def main():
                                 "roofline": {"kernel": d32["name"], "bound": "mfma", "achieved": round(a32, 2), "peak": PEAK_TFLOPS["f32"],
                                              "unit": "TFLOP/s", "frac": round(a32 / PEAK_TFLOPS["f32"], 4),
                                              "avg_launch_us": round(d32["ms"] / d32["calls"] * 1e3, 2)}}
+        if world == 1 and not args.no_profile and args.workload == "gedex_b1":
+            # The B=1 headline workload is launch/latency-bound (67 dependent launches of a few us per Euler step), so
+            # its roofline fractions say little about the kernels.  Same kernels in the bandwidth/MFMA regime:
+            # one B=32 sampler call per precision, event-timed per kernel class.
+            p32, B32, T32, n32, _ = WORKLOADS["gedex_b32"]
+            mu2, mask2, z2, kw2, valid2 = make_inputs(cfg, B32, T32, 0, device, 0)
+            scale = {}
+            for prec, key in (("bf16", "bf16"), ("fp32", "f32")):
+                eng.set_precision(prec)
+                with torch.cuda.stream(stream):
+                    eng.sample(z2, mask2, mu2, 2, **kw2)
+                    torch.cuda.synchronize(device)
+                    t0 = time.perf_counter()
+                    eng.sample(z2, mask2, mu2, n32, **kw2)
+                    torch.cuda.synchronize(device)
+                    dtb = time.perf_counter() - t0
+                    eng.profile(True)
+                    eng.sample(z2, mask2, mu2, 4, **kw2)
+                    torch.cuda.synchronize(device)
+                rb = {r["name"]: r for r in eng.profile_rows()}
+                eng.profile(False)
+                ent = {"value": round(valid2 / dtb, 1), "unit": "mel-frames/s", "workload": f"gedex_lj B={B32} T={T32} n_timesteps={n32}"}
+                for kname in ("conv3x3", "dit_attention"):
+                    if kname in rb:
+                        r = rb[kname]
+                        tf = r["flops"] / (r["ms"] * 1e-3) / 1e12
+                        ent[kname] = {"achieved": round(tf, 1), "peak": PEAK_TFLOPS[key], "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS[key], 4),
+                                      "avg_launch_us": round(r["ms"] / r["calls"] * 1e3, 1)}
+                scale[prec] = ent
+            eng.set_precision(args.precision)
+            res["roofline_batch32"] = scale
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, weights, B, T, n_steps, TrTs)
             res["gpu_over_cpu"] = round(frames_s / res["cpu_baseline"]["value"], 1)
