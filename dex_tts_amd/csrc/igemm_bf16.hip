@@ -12,7 +12,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
 
-template <int BM, int BN, int BK>
+// PT: the 8-element chunk of every thread resolves its own tap (k -> (kh,kw,c)); needed when Cin < BK, e.g. the
+// grouped 16x16 pos-conv (Cin = 32 per group) with BK = 128: 8 K iterations instead of 32 exposed round trips.
+template <int BM, int BN, int BK, bool PT = false>
 __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemmP p) {
     constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (WM * 32);
     constexpr int TPR = BK / 8;                 // threads per tile row (8 elements each)
@@ -79,14 +81,15 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemmP p) {
         }
         if (kt + 1 < nkt) {
             const int k0 = kbeg + (kt + 1) * BK;
-            const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;
+            const int kthr = PT ? k0 + tk8 : k0;                     // tap resolution per thread or per tile
+            const int tap = kthr / p.Cin, c0 = kthr - tap * p.Cin + (PT ? 0 : tk8);
             const int kh = tap / p.KW, kw = tap - kh * p.KW;
 #pragma unroll
             for (int j = 0; j < AP; ++j) {
                 const int hi = bh[j] + kh * p.step_h, wi = bw[j] + kw * p.step_w;
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (mv[j] && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi) {
-                    const float* src = Ab + ((long)hi * p.Wi + wi) * p.lda + c0 + tk8;
+                    const float* src = Ab + ((long)hi * p.Wi + wi) * p.lda + c0;
                     float4 f0 = *reinterpret_cast<const float4*>(src);
                     float4 f1 = *reinterpret_cast<const float4*>(src + 4);
                     if (mrow) {
@@ -279,7 +282,8 @@ void launch_igemm_bf16(const IGemmP& p, hipStream_t st) {
         }
     } else {
         dim3 grid((M + 127) / 128, p.N / 32, zdim);
-        hipLaunchKernelGGL((igemm_bf16_kernel<128, 32, 32>), grid, dim3(256), 0, st, p);
+        if ((p.K / p.ksplit) % 128 == 0 && p.Cin % 8 == 0) hipLaunchKernelGGL((igemm_bf16_kernel<128, 32, 128, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((igemm_bf16_kernel<128, 32, 32>), grid, dim3(256), 0, st, p);
     }
 }
 

@@ -32,9 +32,18 @@ __global__ __launch_bounds__(256) void linattn_kvctx_kernel(const LinKvCtxP p) {
     const int i = lane & 31, hh = lane >> 5;
     const int blk = blockIdx.x, b = blockIdx.y;
     const u16* Wg = reinterpret_cast<const u16*>(p.Wkv);     // bf16 [256][C]
-    for (int it = tid; it < 256 * (C / 8); it += 256) {
-        const int n = it / (C / 8), c8 = (it % (C / 8)) * 8;
-        *reinterpret_cast<uint4*>(Ws + n * LDW + c8) = *reinterpret_cast<const uint4*>(Wg + (long)n * C + c8);
+    {   // all weight loads in flight together, then the LDS stores (a load->store loop serialises 8-16 round trips)
+        uint4 wr[C / 8];
+#pragma unroll
+        for (int j = 0; j < C / 8; ++j) {
+            const int it = tid + 256 * j;
+            wr[j] = *reinterpret_cast<const uint4*>(Wg + (long)(it / (C / 8)) * C + (it % (C / 8)) * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < C / 8; ++j) {
+            const int it = tid + 256 * j;
+            *reinterpret_cast<uint4*>(Ws + (it / (C / 8)) * LDW + (it % (C / 8)) * 8) = wr[j];
+        }
     }
     const float* X = p.X + (long)b * p.xb + p.x_coff;
     const int px_base = (blk * 4 + wave) * p.nsub * 32;
@@ -200,9 +209,27 @@ __global__ __launch_bounds__(256) void linattn_fold_kernel(const LinFoldP p) {
     float* wq = cs + 4 * 32 * 33;           // [128][17]   Wq[:, ci0:ci0+16]
     float* T = wq + 128 * 17;               // [128][17]
     float* wo = T + 128 * 17;               // [C][129]    Wout
-    for (int idx = tid; idx < 4096; idx += 256) cs[(idx >> 5) * 33 + (idx & 31)] = p.ctx[(long)b * 4096 + idx];
-    for (int idx = tid; idx < 128 * 16; idx += 256) wq[(idx >> 4) * 17 + (idx & 15)] = p.Wq[(long)(idx >> 4) * C + ci0 + (idx & 15)];
-    for (int idx = tid; idx < C * 128; idx += 256) wo[(idx >> 7) * 129 + (idx & 127)] = p.Wout[idx];
+    {   // bulk loads first (registers), LDS stores after: one global round trip for the whole staging
+        float c_[16], q_[8];
+        float4 o_[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) c_[j] = p.ctx[(long)b * 4096 + tid + 256 * j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int idx = tid + 256 * j; q_[j] = p.Wq[(long)(idx >> 4) * C + ci0 + (idx & 15)]; }
+        const int nwo = C * 32 / 256;                       // float4 items per thread (8 for C=64, 16 for C=128)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) if (j < nwo) o_[j] = *reinterpret_cast<const float4*>(p.Wout + (long)(tid + 256 * j) * 4);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) { const int idx = tid + 256 * j; cs[(idx >> 5) * 33 + (idx & 31)] = c_[j]; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int idx = tid + 256 * j; wq[(idx >> 4) * 17 + (idx & 15)] = q_[j]; }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) if (j < nwo) {
+            const int idx = (tid + 256 * j) * 4;
+            float* d = wo + (idx >> 7) * 129 + (idx & 127);
+            d[0] = o_[j].x; d[1] = o_[j].y; d[2] = o_[j].z; d[3] = o_[j].w;
+        }
+    }
     __syncthreads();
     for (int idx = tid; idx < 128 * 16; idx += 256) {
         const int he = idx >> 4, cl = idx & 15, h = he >> 5, e = he & 31;
