@@ -295,7 +295,7 @@ void launch_attention_bf16(const AttnP& p, hipStream_t st) {
     const long blocks32 = (long)((p.Nq + 31) / 32) * p.heads * p.B;
     const int ntiles = (p.Nk + SP_KT - 1) / SP_KT;
     int nw = 8;
-    if (blocks32 * 4 >= 1024 || ntiles < 8) nw = 4;
+    if (blocks32 * 4 >= 2048 || ntiles < 8) nw = 4;
     if (blocks32 * 2 >= 2048 || ntiles < 4) nw = 2;
     if (nw == 8) launch_split<8>(p, st);
     else if (nw == 4) launch_split<4>(p, st);

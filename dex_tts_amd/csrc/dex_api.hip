@@ -50,6 +50,7 @@ struct DexCtx {
     std::map<std::string, RawW> raw;
     std::vector<void*> owned;                              // hipMalloc'ed packed weights
     std::map<const float*, const void*> bf16_of;           // fp32 [K][N] pack -> bf16 [N][K] twin
+    std::map<const float*, const void*> frag_of;           // fp32 [K][N] pack -> bf16 MFMA-fragment-order twin (DiT row chain)
     bool finalized = false;
     int precision = DEX_PREC_FP32;
     // packed weights
@@ -308,6 +309,13 @@ struct Packer {
             x->bf16_of[p + (long)c * K * N] = d + (long)c * K * N;
         }
     }
+    void frag(const float* p, int K, int N) {
+        if (!p) return;
+        void* d = alloc(((long)K * N + 1) / 2);
+        if (!d) return;
+        launch_pack_bf16_frag(p, d, K, N, st);
+        x->frag_of[p] = d;
+    }
     const RawW& R(const std::string& k) { return x->raw.at(k); }
     const float* raw(const std::string& k) { return R(k).p; }
     // [d0,d1,d2,d3] -> permuted contiguous copy
@@ -400,7 +408,7 @@ extern "C" int dex_ctx_finalize(DexCtx* x, dex_stream_t stream) {
         if (!x->raw.at(k).loaded) return x->fail(DEX_ERR_STATE, "weight '%s' was never loaded", k.c_str());
     for (void* p : x->owned) hipFree(p);
     x->owned.clear();
-    x->bf16_of.clear();
+    x->bf16_of.clear(); x->frag_of.clear();
     if (x->graph_exec) { hipGraphExecDestroy(x->graph_exec); x->graph_exec = nullptr; x->graph_key.clear(); }
     const DexConfig& c = x->cfg;
     hipStream_t st = (hipStream_t)stream;
@@ -448,6 +456,9 @@ extern "C" int dex_ctx_finalize(DexCtx* x, dex_stream_t stream) {
         b.wfc1 = P.kn(p + ".mlp.fc1.weight"); b.bfc1 = P.raw(p + ".mlp.fc1.bias");
         b.wfc2 = P.kn(p + ".mlp.fc2.weight"); b.bfc2 = P.raw(p + ".mlp.fc2.bias");
         b.ada_w = P.raw(p + ".adaLN_modulation.1.weight"); b.ada_b = P.raw(p + ".adaLN_modulation.1.bias");
+        if (dit_rowchain_supported(hid, mlp_hidden(c))) {
+            P.frag(b.wqkv, hid, 3 * hid); P.frag(b.wproj, hid, hid); P.frag(b.wfc1, hid, mlp_hidden(c)); P.frag(b.wfc2, mlp_hidden(c), hid);
+        }
         x->blocks.push_back(b);
     }
     x->fl_w = P.kn("vit.final_layer.linear.weight"); x->fl_b = P.raw("vit.final_layer.linear.bias");
@@ -772,23 +783,47 @@ struct Runner {
         if (debug) hipMemcpyAsync(P.dbg_tok, P.tok, (size_t)B * N * hid * 4, hipMemcpyDeviceToDevice, st);
         tap("tok_in", P.dbg_tok, (long)B * N, hid, hid);
         const float scale = 1.0f / sqrtf((float)(hid / c.dit_heads));
+        const bool chain = x->precision == DEX_PREC_BF16 && dit_rowchain_supported(hid, mh) && x->frag_of.count(x->blocks[0].wproj);
         for (int k = 0; k < c.dit_depth; ++k) {
             const DitBlockW& w = x->blocks[k];
             const float* ada = P.ada[k];
             const bool fuse_ln = x->precision == DEX_PREC_BF16;      // LayerNorm+modulate inside the GEMM's A staging
-            IGemmP q = base_gemm(fuse_ln ? P.tok : P.xn, hid, 0, 1, N, hid, w.wqkv, 3 * hid, w.bqkv, P.qkv, 3 * hid, 0);
-            if (fuse_ln) { q.ln_shift = ada + 0 * hid; q.ln_scale = ada + 1 * hid; q.ln_step_stride = 6L * hid; }
-            else {
-                LnModP l1{P.tok, P.xn, N, hid, ada + 0 * hid, ada + 1 * hid, 6L * hid, sp, B};
-                run("ln_modulate", 8.0 * B * N * hid, 8.0 * B * N * hid, [&] { launch_ln_mod(l1, st); });
+            if (!chain || k == 0) {                                  // (chained: block k-1's launch already wrote qkv)
+                IGemmP q = base_gemm(fuse_ln ? P.tok : P.xn, hid, 0, 1, N, hid, w.wqkv, 3 * hid, w.bqkv, P.qkv, 3 * hid, 0);
+                if (fuse_ln) { q.ln_shift = ada + 0 * hid; q.ln_scale = ada + 1 * hid; q.ln_step_stride = 6L * hid; }
+                else {
+                    LnModP l1{P.tok, P.xn, N, hid, ada + 0 * hid, ada + 1 * hid, 6L * hid, sp, B};
+                    run("ln_modulate", 8.0 * B * N * hid, 8.0 * B * N * hid, [&] { launch_ln_mod(l1, st); });
+                }
+                gemm("dit_qkv", q);
             }
-            gemm("dit_qkv", q);
             AttnP a{};
             a.Q = P.qkv; a.ldq = 3 * hid; a.qb = (long)N * 3 * hid;
             a.K = P.qkv + hid; a.ldk = 3 * hid; a.kb = a.qb; a.V = P.qkv + 2 * hid; a.ldv = 3 * hid; a.vb = a.qb;
             a.O = P.ao; a.ldo = hid; a.ob = (long)N * hid; a.Nq = N; a.Nk = N; a.kv_len = nullptr; a.kv_len_add = 0;
             a.heads = c.dit_heads; a.scale = scale; a.B = B;
             run("dit_attention", 4.0 * B * (double)N * N * hid, 4.0 * 4 * B * N * hid, [&] { launch_attention(a, x->precision, st); });
+            if (chain) {
+                const bool last = k + 1 == c.dit_depth;
+                DitChainP ch{};
+                ch.O = P.ao; ch.X = P.tok; ch.Wp = x->frag_of.at(w.wproj); ch.W1 = x->frag_of.at(w.wfc1); ch.W2 = x->frag_of.at(w.wfc2);
+                ch.bp = w.bproj; ch.b1 = w.bfc1; ch.b2 = w.bfc2; ch.ada = ada; ch.step = sp; ch.M = B * N; ch.QKV = P.qkv;
+                if (!last) {
+                    const DitBlockW& wn = x->blocks[k + 1];
+                    ch.Wq = x->frag_of.at(wn.wqkv); ch.bq = wn.bqkv;
+                    ch.next_shift = P.ada[k + 1]; ch.next_scale = P.ada[k + 1] + hid; ch.next_step_stride = 6L * hid;
+                }
+                const double M = (double)B * N;
+                const double wel = (double)hid * hid + 2.0 * hid * mh + (last ? 0.0 : 3.0 * hid * hid);
+                run("dit_rowchain", 2.0 * M * wel, 4.0 * M * hid * (last ? 3 : 6) + 2.0 * wel, [&] { launch_dit_rowchain(ch, st); });
+                if (debug) {
+                    float* dst = P.dbg_tok + (size_t)(k + 1) * B * N * hid;
+                    hipMemcpyAsync(dst, P.tok, (size_t)B * N * hid * 4, hipMemcpyDeviceToDevice, st);
+                    char nm[32]; snprintf(nm, sizeof nm, "tok_blk%d", k);
+                    tap(nm, dst, (long)B * N, hid, hid);
+                }
+                continue;
+            }
             IGemmP pr = base_gemm(P.ao, hid, 0, 1, N, hid, w.wproj, hid, w.bproj, P.tok, hid, 0);
             pr.gate = ada + 2 * hid; pr.gate_nstride = 1; pr.gate_step_stride = 6L * hid;
             pr.res = P.tok; pr.ldres = hid; pr.res_bstride = (long)N * hid;

@@ -1,0 +1,243 @@
+// dit_rowchain.hip — everything of a DiT block that is row-local, in ONE launch (bf16-MFMA mode).
+//
+// After the attention core, the rest of a DiTBlock (reference model/dit.py:73-84) touches one token row at a time:
+//     x1  = x  + gate_msa * (O Wproj + b)                        attention projection + gated residual
+//     h   = GELU(modulate(LN(x1), shift_mlp, scale_mlp) W1 + b1) Mlp.fc1
+//     x2  = x1 + gate_mlp * (h W2 + b2)                          Mlp.fc2 + gated residual
+//     qkv = modulate(LN(x2), shift_msa', scale_msa') Wqkv' + b'  the NEXT block's qkv projection
+// At B=1 (650 token rows) these four GEMMs are pure latency — separately they cost 4 launches of 7-13 us each for
+// ~0.3 GFLOP.  Here a workgroup of 8 waves owns a 32-row tile and walks the whole chain with the activations in
+// LDS (bf16 MFMA A operands, fp32 residual stream); each wave owns 32-column slices of every weight matrix and
+// streams them from L2 straight into MFMA B-operand registers.  Weights are host-packed in fragment order
+// (`pack_bf16_frag_kernel`: one 1-KB contiguous read per wave per K-step of 16) and double-buffered one 16-KB
+// tile ahead, across stage boundaries — weights never depend on the data.
+//
+// Accumulator layout (32x32x16 bf16): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+#include "bf16_util.h"
+
+namespace dex {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+namespace {
+
+constexpr int RC_H = 256, RC_MLP = 512, RC_ROWS = 32, RC_NW = 8;
+constexpr int A_LD = RC_H + 8;       // bf16 elements; row stride 528 B: b128 reads of 16 rows hit 64 distinct banks
+constexpr int H_LD = RC_MLP + 8;
+constexpr int X_LD = RC_H + 4;       // floats
+constexpr size_t RC_LDS = (size_t)RC_ROWS * (A_LD + H_LD) * sizeof(u16) + (size_t)RC_ROWS * X_LD * sizeof(float);
+
+__device__ __forceinline__ float gelu_erf_rc(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// one weight tile = 32 output columns x 256 K = 16 K-steps x (64 lanes x 16 B)
+__device__ __forceinline__ void wload(uint4 (&w)[16], const void* W, int ksteps_total, int nt, int ks0, int lane) {
+    const uint4* src = reinterpret_cast<const uint4*>(W) + ((long)nt * ksteps_total + ks0) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) w[j] = src[j * 64];
+}
+__device__ __forceinline__ void mma16(f32x16& acc, const uint4 (&w)[16], const u16* a_lane) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(a_lane + j * 16);
+        const bf16x8 bf = __builtin_bit_cast(bf16x8, w[j]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+    }
+}
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+
+// LayerNorm(eps 1e-6, no affine) + modulate of the 32 fp32 rows in X1 -> bf16 A tile.  16 threads per row, each
+// owning four float4 at columns q*64 + seg*4 (64 contiguous floats per 16 lanes: conflict-free).
+__device__ __forceinline__ void ln_to_A(const float* X1, u16* As, const float* shift, const float* scale, int tid) {
+    const int row = tid >> 4, seg = tid & 15;
+    const float* xr = X1 + row * X_LD + seg * 4;
+    float4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(xr + q * 64);
+    float4 sc[4], sh[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        sc[q] = *reinterpret_cast<const float4*>(scale + q * 64 + seg * 4);
+        sh[q] = *reinterpret_cast<const float4*>(shift + q * 64 + seg * 4);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.f / RC_H);
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        v[q].x -= mean; v[q].y -= mean; v[q].z -= mean; v[q].w -= mean;
+        ss += v[q].x * v[q].x + v[q].y * v[q].y + v[q].z * v[q].z + v[q].w * v[q].w;
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o);
+    const float rstd = rsqrtf(ss * (1.f / RC_H) + 1e-6f);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint2 o;
+        o.x = pack2_bf16(v[q].x * rstd * (1.f + sc[q].x) + sh[q].x, v[q].y * rstd * (1.f + sc[q].y) + sh[q].y);
+        o.y = pack2_bf16(v[q].z * rstd * (1.f + sc[q].z) + sh[q].z, v[q].w * rstd * (1.f + sc[q].w) + sh[q].w);
+        *reinterpret_cast<uint2*>(As + row * A_LD + q * 64 + seg * 4) = o;
+    }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChainP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_rc[];
+    u16* As = reinterpret_cast<u16*>(smem_rc);                 // [32][A_LD]  bf16 A operand (O, then LN outputs)
+    u16* Hs = As + RC_ROWS * A_LD;                             // [32][H_LD]  bf16 GELU(fc1)
+    float* X1 = reinterpret_cast<float*>(Hs + RC_ROWS * H_LD); // [32][X_LD]  fp32 residual stream
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int m0 = blockIdx.x * RC_ROWS, M = p.M;
+    const int step = p.step ? *p.step : 0;
+    const float* ada = p.ada + (long)step * 6 * RC_H;
+    const bool has_q = p.next_shift != nullptr;
+
+    uint4 wa[16], wb[16];
+    wload(wa, p.Wp, 16, wave, 0, lane);
+    // residual rows of this lane's output column + the attention output tile
+    const int col = wave * 32 + i;
+    float xres[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = min(m0 + (r & 3) + 8 * (r >> 2) + 4 * hh, M - 1);
+        xres[r] = p.X[(long)m * RC_H + col];
+    }
+    {
+        const int row = tid >> 4, seg = tid & 15;
+        const float* src = p.O + (long)min(m0 + row, M - 1) * RC_H + seg * 4;
+        float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(src + q * 64);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint2 o;
+            o.x = pack2_bf16(v[q].x, v[q].y); o.y = pack2_bf16(v[q].z, v[q].w);
+            *reinterpret_cast<uint2*>(As + row * A_LD + q * 64 + seg * 4) = o;
+        }
+    }
+    const float b_p = p.bp[col], g_msa = ada[2 * RC_H + col];
+    const float b_1a = p.b1[col], b_1b = p.b1[col + 256];
+    const float b_2 = p.b2[col], g_mlp = ada[5 * RC_H + col];
+    __syncthreads();
+
+    // ---- x1 = x + gate_msa * (O Wproj + b)
+    wload(wb, p.W1, 16, wave, 0, lane);
+    const u16* a_lane = As + i * A_LD + hh * 8;
+    const u16* h_lane = Hs + i * H_LD + hh * 8;
+    f32x16 acc = zero16();
+    mma16(acc, wa, a_lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        X1[row * X_LD + col] = xres[r] + g_msa * (acc[r] + b_p);
+    }
+    __syncthreads();
+    ln_to_A(X1, As, ada + 3 * RC_H, ada + 4 * RC_H, tid);
+    __syncthreads();
+
+    // ---- h = GELU(A W1 + b1): column tiles `wave` and `wave + 8`
+    wload(wa, p.W1, 16, wave + 8, 0, lane);
+    acc = zero16();
+    mma16(acc, wb, a_lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        Hs[row * H_LD + col] = (u16)(pack2_bf16(gelu_erf_rc(acc[r] + b_1a), 0.f) & 0xffffu);
+    }
+    wload(wb, p.W2, 32, wave, 0, lane);
+    acc = zero16();
+    mma16(acc, wa, a_lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        Hs[row * H_LD + col + 256] = (u16)(pack2_bf16(gelu_erf_rc(acc[r] + b_1b), 0.f) & 0xffffu);
+    }
+    __syncthreads();
+
+    // ---- x2 = x1 + gate_mlp * (h W2 + b2)
+    wload(wa, p.W2, 32, wave, 16, lane);
+    acc = zero16();
+    mma16(acc, wb, h_lane);
+    if (has_q) wload(wb, p.Wq, 16, wave, 0, lane);
+    mma16(acc, wa, h_lane + 256);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const float x2 = X1[row * X_LD + col] + g_mlp * (acc[r] + b_2);
+        X1[row * X_LD + col] = x2;
+        if (m0 + row < M) p.X[(long)(m0 + row) * RC_H + col] = x2;
+    }
+    if (!has_q) return;
+    __syncthreads();
+    ln_to_A(X1, As, p.next_shift + (long)step * p.next_step_stride, p.next_scale + (long)step * p.next_step_stride, tid);
+    __syncthreads();
+
+    // ---- qkv of the next block: column tiles wave, wave+8, wave+16
+    const float bq0 = p.bq[col], bq1 = p.bq[col + 256], bq2 = p.bq[col + 512];
+    wload(wa, p.Wq, 16, wave + 8, 0, lane);
+    acc = zero16();
+    mma16(acc, wb, a_lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (m0 + row < M) p.QKV[(long)(m0 + row) * (3 * RC_H) + col] = acc[r] + bq0;
+    }
+    wload(wb, p.Wq, 16, wave + 16, 0, lane);
+    acc = zero16();
+    mma16(acc, wa, a_lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (m0 + row < M) p.QKV[(long)(m0 + row) * (3 * RC_H) + col + 256] = acc[r] + bq1;
+    }
+    acc = zero16();
+    mma16(acc, wb, a_lane);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (m0 + row < M) p.QKV[(long)(m0 + row) * (3 * RC_H) + col + 512] = acc[r] + bq2;
+    }
+}
+
+bool dit_rowchain_supported(int hidden, int mlp_hidden) { return hidden == RC_H && mlp_hidden == RC_MLP; }
+
+void launch_dit_rowchain(const DitChainP& p, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&dit_rowchain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC_LDS);
+        attr = true;
+    }
+    hipLaunchKernelGGL(dit_rowchain_kernel, dim3((p.M + RC_ROWS - 1) / RC_ROWS), dim3(RC_NW * 64), RC_LDS, st, p);
+}
+
+// fp32 [K][N] -> bf16 in MFMA B-fragment order: dst[((nt * K/16 + ks) * 64 + lane) * 8 + j] =
+// W[k = ks*16 + (lane >> 5)*8 + j][n = nt*32 + (lane & 31)]
+__global__ void pack_bf16_frag_kernel(const float* __restrict__ src, u16* __restrict__ dst, int K, int N) {
+    const long total = (long)K * N;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(o & 7), lane = (int)((o >> 3) & 63);
+        const long t = o >> 9;
+        const int ks = (int)(t % (K / 16)), nt = (int)(t / (K / 16));
+        const int k = ks * 16 + (lane >> 5) * 8 + j, n = nt * 32 + (lane & 31);
+        dst[o] = (u16)(pack2_bf16(src[(long)k * N + n], 0.f) & 0xffffu);
+    }
+}
+void launch_pack_bf16_frag(const float* src, void* dst, int K, int N, hipStream_t st) {
+    hipLaunchKernelGGL(pack_bf16_frag_kernel, dim3(256), dim3(256), 0, st, src, reinterpret_cast<u16*>(dst), K, N);
+}
+
+}  // namespace dex

@@ -136,6 +136,16 @@ struct LnModP { const float* X; float* Y; int rows_per_batch; int D; const float
                 long step_stride; const int* step; int B; };
 void launch_ln_mod(const LnModP& p, hipStream_t st);
 
+// Row-local remainder of a DiT block + the next block's qkv projection in one launch (dit_rowchain.hip; bf16 mode,
+// hidden 256 / mlp 512).  Weights are bf16 in MFMA fragment order (launch_pack_bf16_frag).
+struct DitChainP { const float* O; float* X; const void *Wp, *W1, *W2, *Wq; const float *bp, *b1, *b2, *bq;
+                   const float* ada;                       // this block's [n_steps][6*hidden] adaLN table
+                   const float *next_shift, *next_scale; long next_step_stride;   // null: no qkv stage (last block)
+                   float* QKV; const int* step; int M; };
+bool dit_rowchain_supported(int hidden, int mlp_hidden);
+void launch_dit_rowchain(const DitChainP& p, hipStream_t st);
+void launch_pack_bf16_frag(const float* src, void* dst, int K, int N, hipStream_t st);
+
 // Softmax attention, head_dim 128, no key mask except kv_len (timm Attention core / TVAdaptor core).
 struct AttnP { const float* Q; int ldq; long qb; const float* K; int ldk; long kb; const float* V; int ldv; long vb;
                float* O; int ldo; long ob; int Nq, Nk; const int* kv_len; int kv_len_add; int heads; float scale; int B; };

@@ -28,8 +28,60 @@ static void timeit(const char* name, int iters, double flops, double bytes, std:
     printf("%-44s %8.2f us  %8.2f TF/s %8.1f GB/s\n", name, us, flops / us * 1e-6, bytes / us * 1e-3);
 }
 
+// ---- pure-register MFMA chains: the practical matrix-core ceiling on this part (clock under load included)
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+template <int WPS>
+__global__ __launch_bounds__(256 * WPS) void mfma_f32_probe(float* out, int iters) {
+    f32x16_t a0 = {}, a1 = {}, a2 = {}, a3 = {};
+    float x = threadIdx.x * 1e-6f, y = 1.0f + threadIdx.x * 1e-7f;
+    for (int i = 0; i < iters; ++i) {
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_32x32x2f32(x, y, a3, 0, 0, 0);
+    }
+    float s = 0; for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
+    if (s == 123.456f) out[0] = s;
+}
+template <int WPS>
+__global__ __launch_bounds__(256 * WPS) void mfma_bf16_probe(float* out, int iters) {
+    f32x16_t a0 = {}, a1 = {}, a2 = {}, a3 = {};
+    bf16x8_t x, y;
+    for (int j = 0; j < 8; ++j) { x[j] = (__bf16)(threadIdx.x * 1e-3f); y[j] = (__bf16)1.0f; }
+    for (int i = 0; i < iters; ++i) {
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a1, 0, 0, 0);
+        a2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a2, 0, 0, 0);
+        a3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, a3, 0, 0, 0);
+    }
+    float s = 0; for (int r = 0; r < 16; ++r) s += a0[r] + a1[r] + a2[r] + a3[r];
+    if (s == 123.456f) out[0] = s;
+}
+
 int main() {
+    {
+        float* o; hipMalloc(&o, 4);
+        const int it = 4096;
+        const double wf32 = 4.0 * it * 2.0 * 32 * 32 * 2, wbf = 4.0 * it * 2.0 * 32 * 32 * 16;
+        timeit("MFMA probe fp32 32x32x2  1 wave/SIMD", 5, wf32 * 1024 * 4, 0, [&] { hipLaunchKernelGGL(mfma_f32_probe<1>, dim3(1024), dim3(256), 0, 0, o, it); });
+        timeit("MFMA probe fp32 32x32x2  2 waves/SIMD", 5, wf32 * 1024 * 8, 0, [&] { hipLaunchKernelGGL(mfma_f32_probe<2>, dim3(1024), dim3(512), 0, 0, o, it); });
+        timeit("MFMA probe bf16 32x32x16 1 wave/SIMD", 5, wbf * 1024 * 4, 0, [&] { hipLaunchKernelGGL(mfma_bf16_probe<1>, dim3(1024), dim3(256), 0, 0, o, it); });
+        timeit("MFMA probe bf16 32x32x16 2 waves/SIMD", 5, wbf * 1024 * 8, 0, [&] { hipLaunchKernelGGL(mfma_bf16_probe<2>, dim3(1024), dim3(512), 0, 0, o, it); });
+    }
     const int B = 1, T = 512;
+    // ---- attention at scale: B=32 N=1300 (DEX-VCTK T=256) and B=1 N=5010 (long form)
+    for (int cfg = 0; cfg < 2; ++cfg) {
+        const int Bb = cfg == 0 ? 32 : 1, N = cfg == 0 ? 1300 : 5010;
+        float* qkv = dalloc((size_t)Bb * N * 768, 1.0f);
+        float* o = dalloc((size_t)Bb * N * 256);
+        AttnP a{}; a.Q = qkv; a.ldq = 768; a.qb = (long)N * 768; a.K = qkv + 256; a.ldk = 768; a.kb = a.qb; a.V = qkv + 512; a.ldv = 768; a.vb = a.qb;
+        a.O = o; a.ldo = 256; a.ob = (long)N * 256; a.Nq = N; a.Nk = N; a.heads = 2; a.scale = 0.088f; a.B = Bb;
+        char nm[64];
+        snprintf(nm, 64, "attention fp32 B=%d N=%d", Bb, N); timeit(nm, 10, 4.0 * Bb * N * (double)N * 256, 16.0 * Bb * N * 256, [&] { launch_attention(a, 0, 0); });
+        snprintf(nm, 64, "attention bf16 B=%d N=%d", Bb, N); timeit(nm, 10, 4.0 * Bb * N * (double)N * 256, 16.0 * Bb * N * 256, [&] { launch_attention(a, 1, 0); });
+        hipFree(qkv); hipFree(o);
+    }
     // ---- attention N=650 (GeDEX) and N=2580 (DEX)
     for (int N : {650, 2580}) {
         float* qkv = dalloc((size_t)B * N * 768, 1.0f);
