@@ -24,7 +24,7 @@ struct RawW { float* p = nullptr; std::vector<int64_t> shape; long numel = 0; bo
 struct TD { float* p; int ld; int coff; int C; };          // channels-last activation view
 
 struct ResW { const float *w1, *b1, *g1, *be1, *w2, *b2, *g2, *be2, *wr, *br, *mlp_w, *mlp_b; int cin, cout; };
-struct LinW { const float *wqkv, *wqkv_raw, *wout_raw, *bias_eff, *g; const void* wkv_bf16; int C; };
+struct LinW { const float *wqkv, *wqkv_raw, *wout_raw, *bias_eff, *g; const void *wq_bf16, *wkv_bf16; int C; };
 struct DitBlockW { const float *wqkv, *bqkv, *wproj, *bproj, *wfc1, *bfc1, *wfc2, *bfc2, *ada_w, *ada_b; };
 
 struct Prof { std::string name; hipEvent_t a, b; double flops, bytes; };
@@ -356,10 +356,10 @@ struct Packer {
         l.wqkv = kn(p + ".fn.fn.to_qkv.weight");
         l.wqkv_raw = raw(p + ".fn.fn.to_qkv.weight");                 // [384][C]: rows q | k | v
         l.wout_raw = raw(p + ".fn.fn.to_out.weight");
-        {   // bf16 copy of the k|v rows in their native [N][K] layout (B operand of the fused kernel)
-            unsigned short* kvb = (unsigned short*)alloc((256L * c + 1) / 2);
-            if (kvb) launch_f32_to_bf16(l.wqkv_raw + 128L * c, kvb, 256L * c, st);
-            l.wkv_bf16 = kvb;
+        {   // bf16 copy of the q | k | v rows in their native [N][K] layout (MFMA operands of the fused kernels)
+            unsigned short* qb = (unsigned short*)alloc((384L * c + 1) / 2);
+            if (qb) launch_f32_to_bf16(l.wqkv_raw, qb, 384L * c, st);
+            l.wq_bf16 = qb; l.wkv_bf16 = qb ? qb + 128L * c : nullptr;
         }
         l.g = raw(p + ".fn.g");
         float* be = alloc(c);
@@ -560,7 +560,7 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
         s.nblk_fused = (int)((s.npix + 127) / 128);             // fused bf16 path: one partial per 128-pixel workgroup
         s.pm = A.f((size_t)B * 4 * s.nblk_fused * 32); s.ps = A.f((size_t)B * 4 * s.nblk_fused * 32);
         s.pc = A.f((size_t)B * 4 * s.nblk_fused * 1024); s.weff = A.f((size_t)B * 128 * C);
-        s.ctxn = A.f((size_t)B * 4096); s.mbf = A.take((size_t)B * C * C * 2);
+        s.ctxn = A.f((size_t)B * 4096); s.mbf = A.take((size_t)B * C * 128 * 2);
         s.ds_out = nullptr;
         return s;
     };
@@ -732,20 +732,16 @@ struct Runner {
     void linattn(const LinW& w, const StageBuf& s, const TD& X, float* out, int ldo, int ocoff) {
         const long npix = s.npix; const int B = P.d.B;
         if (x->precision == DEX_PREC_BF16 && (X.C == 64 || X.C == 128)) {
-            // fused: y = x + M_b x + g*b  with  M_b = g Wout blockdiag(ctx^T) Wq   (linattn_fused.hip)
+            // fused: y = x + W2 (Wq x) + g*b  with  W2 = g Wout blockdiag(ctx^T)   (linattn_fused.hip)
             int nsub = 1;
             while (nsub < 4 && (npix + 128 * nsub - 1) / (128 * nsub) * B > 1024) nsub *= 2;
             const int nblk = (int)((npix + 128L * nsub - 1) / (128L * nsub));
             LinKvCtxP k{X.p, X.ld, X.coff, npix * X.ld, (int)npix, X.C, w.wkv_bf16, nsub, nblk, s.pm, s.ps, s.pc, B};
             run("linattn_kvctx", 2.0 * npix * B * (256.0 * X.C + 128 * 32), 4.0 * npix * X.C * B, [&] { launch_linattn_kvctx(k, st); });
-            LinMergeP mg{s.pm, s.ps, s.pc, nblk, s.ctxn, B};
-            run("linattn_merge", 0, 4.0 * nblk * 4 * 1088 * B, [&] { launch_linattn_merge(mg, st); });
-            LinFoldP fo{s.ctxn, w.wqkv_raw, w.wout_raw, w.g, X.C, s.weff, s.mbf, B};
-            run("linattn_fold", 2.0 * (128.0 * 32 * X.C + 128.0 * X.C * X.C) * B, 0, [&] { launch_linattn_fold(fo, st); });
-            IGemmP o = base_gemm(X.p, X.ld, X.coff, s.H, s.W, X.C, s.weff, w.C, w.bias_eff, out, ldo, ocoff);
-            o.Wbf = s.mbf; o.w_bstride = (long)X.C * X.C;
-            o.res = X.p; o.ldres = X.ld; o.res_coff = X.coff; o.res_bstride = npix * X.ld;
-            gemm("linattn_out", o);
+            LinMergeP mg{s.pm, s.ps, s.pc, nblk, w.wout_raw, w.g, X.C, s.mbf, B};
+            run("linattn_merge", 2.0 * 128 * 32 * X.C * B, 4.0 * nblk * 4 * 1088 * B, [&] { launch_linattn_merge(mg, st); });
+            LinOut2P o{X.p, X.ld, X.coff, npix * X.ld, (int)npix, X.C, w.wq_bf16, s.mbf, w.bias_eff, out, ldo, ocoff, npix * ldo, B};
+            run("linattn_out", 4.0 * npix * B * 128.0 * X.C, 8.0 * npix * X.C * B, [&] { launch_linattn_out2(o, st); });
             return;
         }
         IGemmP g = base_gemm(X.p, X.ld, X.coff, s.H, s.W, X.C, w.wqkv, 384, nullptr, s.qkv, 384, 0);

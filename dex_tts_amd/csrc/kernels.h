@@ -115,10 +115,12 @@ void launch_linattn_combine(const LinAttnCombineP& p, hipStream_t st);
 struct LinKvCtxP { const float* X; int ldx; int x_coff; long xb; int npix; int C; const void* Wkv; int nsub; int nblk;
                    float* part_m; float* part_s; float* part_c; int B; };
 void launch_linattn_kvctx(const LinKvCtxP& p, hipStream_t st);
-struct LinMergeP { const float* part_m; const float* part_s; const float* part_c; int nblk; float* ctx; int B; };
+struct LinMergeP { const float* part_m; const float* part_s; const float* part_c; int nblk;
+                   const float* Wout; const float* g; int C; void* W2; int B; };       // Wout fp32 [C][128]
 void launch_linattn_merge(const LinMergeP& p, hipStream_t st);
-struct LinFoldP { const float* ctx; const float* Wq; const float* Wout; const float* g; int C; float* Mt; void* Mbf; int B; };
-void launch_linattn_fold(const LinFoldP& p, hipStream_t st);
+struct LinOut2P { const float* X; int ldx; int x_coff; long xb; int npix; int C; const void* Wq; const void* W2;
+                  const float* bias; float* Y; int ldy; int y_coff; long yb; int B; }; // Wq bf16 [128][C]
+void launch_linattn_out2(const LinOut2P& p, hipStream_t st);
 
 // Depthwise patch-embed conv + SiLU (dit.py:57-58), channels-last, zero padding incl. right pad to patch multiple.
 struct DwConvP { const float* X; int ldx; long xb; int Hi, Wi, C; int k, s, pad; const float* Wd; const float* bd;

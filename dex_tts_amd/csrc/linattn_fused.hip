@@ -7,8 +7,9 @@
 // v_mfma_f32_32x32x16_bf16, keeps an online per-channel max, and accumulates ctx^T with a SECOND MFMA whose A
 // and B operands are the k/v accumulator registers themselves (C-layout: lane = channel, registers = pixels ->
 // exactly the A[e][px] / B[px][d] fragment shape; both use the same pixel order, so no shuffle and no LDS).
-// Kernel 2 merges the workgroup partials (flash-style) into normalised ctx; kernel 3 folds ctx, Wq, Wout and g
-// into M_b (fp32 [ci][co] and bf16 [co][ci]); the tail is one GEMM with K = C and a residual.
+// Kernel 2 merges the workgroup partials (flash-style) into normalised ctx and folds it with Wout and g into
+// W2 = g Wout blockdiag(ctx^T) (C x 128, bf16); kernel 3 is the tail  y = x + W2 (Wq x) + g b  (two chained MFMA
+// GEMMs per 32-pixel wave tile, M_b itself is never formed).
 // HBM traffic per call: x read twice + y written, instead of writing q,k,v (6x the size of x) and re-reading them.
 #include "kernels.h"
 #include "bf16_util.h"
@@ -56,20 +57,35 @@ __global__ __launch_bounds__(256) void linattn_kvctx_kernel(const LinKvCtxP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) ctxT[h][r] = 0.f;
     }
+    // x rows of the first sub-tile go out before the barrier (beside the weight loads); later sub-tiles are
+    // prefetched one iteration ahead
+    float4 xa[KS], xc[KS];
+    {
+        const float* xr = X + (long)min(px_base + i, p.npix - 1) * p.ldx + hh * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            xa[ks] = *reinterpret_cast<const float4*>(xr + ks * 16);
+            xc[ks] = *reinterpret_cast<const float4*>(xr + ks * 16 + 4);
+        }
+    }
     __syncthreads();
     for (int sub = 0; sub < p.nsub; ++sub) {
         const int px0 = px_base + sub * 32;
         if (px0 >= p.npix) break;
         // A fragments of x: lane (pixel i, half hh) holds x[px][ks*16 + hh*8 .. +8]
-        const int pxr = min(px0 + i, p.npix - 1);
-        const float* xr = X + (long)pxr * p.ldx + hh * 8;
         LFrag af[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            const float4 a = *reinterpret_cast<const float4*>(xr + ks * 16);
-            const float4 c = *reinterpret_cast<const float4*>(xr + ks * 16 + 4);
-            af[ks].u.x = pack2_bf16(a.x, a.y); af[ks].u.y = pack2_bf16(a.z, a.w);
-            af[ks].u.z = pack2_bf16(c.x, c.y); af[ks].u.w = pack2_bf16(c.z, c.w);
+            af[ks].u.x = pack2_bf16(xa[ks].x, xa[ks].y); af[ks].u.y = pack2_bf16(xa[ks].z, xa[ks].w);
+            af[ks].u.z = pack2_bf16(xc[ks].x, xc[ks].y); af[ks].u.w = pack2_bf16(xc[ks].z, xc[ks].w);
+        }
+        if (sub + 1 < p.nsub) {
+            const float* xr = X + (long)min(px0 + 32 + i, p.npix - 1) * p.ldx + hh * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                xa[ks] = *reinterpret_cast<const float4*>(xr + ks * 16);
+                xc[ks] = *reinterpret_cast<const float4*>(xr + ks * 16 + 4);
+            }
         }
         f32x16 kv[8];
 #pragma unroll
@@ -163,11 +179,22 @@ void launch_linattn_kvctx(const LinKvCtxP& p, hipStream_t st) {
     else hipLaunchKernelGGL(linattn_kvctx_kernel<128>, grid, dim3(256), lds, st, p);
 }
 
-// grid (4 heads, B, 32 rows d): merge the workgroup partials of ONE context row -> normalised ctx[b][h][d][:].
+// grid (4 heads, B, 32 rows d): merge the workgroup partials of ONE context row -> normalised ctx[b][h][d][:], then
+// fold it with the output projection:  W2[co][h*32+d] = g * sum_e Wout[co][h*32+e] * ctx[h][d][e]   (one column of
+// W2 = g * Wout * blockdiag(ctx^T) per workgroup).  W2 is written as bf16 in the A-fragment order the tail kernel
+// consumes: he index permuted to the accumulator row order of the q^T tiles (see linattn_out2_kernel).
 // thread = (column e = tid%32, partial lane pl = tid/32): 8 lanes stride the partial list with independent loads.
 __global__ __launch_bounds__(256) void linattn_merge_kernel(const LinMergeP p) {
-    __shared__ float redm[8], reda[8][32], reds[8];
+    __shared__ float redm[8], reda[8][32], reds[8], cvec[32];
     const int tid = threadIdx.x, h = blockIdx.x, b = blockIdx.y, d = blockIdx.z;
+    const int C = p.C;
+    // this thread's Wout row slice (co = tid): 32 floats, in flight under the partial merge
+    float4 wo[8];
+    if (tid < C) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wo[j] = *reinterpret_cast<const float4*>(p.Wout + (long)tid * 128 + h * 32 + j * 4);
+    }
+    const float g = p.g[0];
     const long pbase = ((long)b * 4 + h) * p.nblk;
     const int e = tid & 31, pl = tid >> 5;
     float m = -INFINITY;
@@ -192,72 +219,119 @@ __global__ __launch_bounds__(256) void linattn_merge_kernel(const LinMergeP p) {
         float a = 0.f, ss = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) { a += reda[k][e]; ss += reds[k]; }
-        p.ctx[(((long)b * 4 + h) * 32 + d) * 32 + e] = a / ss;
+        cvec[e] = a / ss;
+    }
+    __syncthreads();
+    if (tid < C) {
+        float a = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            a = fmaf(wo[j].x, cvec[j * 4 + 0], a); a = fmaf(wo[j].y, cvec[j * 4 + 1], a);
+            a = fmaf(wo[j].z, cvec[j * 4 + 2], a); a = fmaf(wo[j].w, cvec[j * 4 + 3], a);
+        }
+        a *= g;
+        // fragment slot of (co = tid, he = h*32 + d):  d = (j&3) + 8*(2*ksl + (j>>2)) + 4*hh
+        const int co = tid, hh = (d >> 2) & 1, j = (d & 3) + 4 * ((d >> 3) & 1), ks = 2 * h + (d >> 4);
+        const long dst = ((((long)b * (C / 32) + (co >> 5)) * 8 + ks) * 64 + hh * 32 + (co & 31)) * 8 + j;
+        reinterpret_cast<u16*>(p.W2)[dst] = (u16)(pack2_bf16(a, 0.f) & 0xffffu);
     }
 }
 void launch_linattn_merge(const LinMergeP& p, hipStream_t st) {
     hipLaunchKernelGGL(linattn_merge_kernel, dim3(4, p.B, 32), dim3(256), 0, st, p);
 }
 
-// grid (C/16 column slabs, B): M_b = g * Wout * blockdiag(ctx^T) * Wq for 16 input columns ci:
-//   T[h*32+e][ci] = sum_d ctx[h][d][e] * Wq[h*32+d][ci];   M[co][ci] = g * sum_{he} Wout[co][he] * T[he][ci]
-// written as Mt fp32 [ci][co] and Mbf bf16 [co][ci].  Everything is staged in LDS with bulk coalesced loads first.
-__global__ __launch_bounds__(256) void linattn_fold_kernel(const LinFoldP p) {
-    extern __shared__ float smem_f[];
-    const int C = p.C, tid = threadIdx.x, b = blockIdx.y, ci0 = blockIdx.x * 16;
-    float* cs = smem_f;                     // [4][32][33] ctx
-    float* wq = cs + 4 * 32 * 33;           // [128][17]   Wq[:, ci0:ci0+16]
-    float* T = wq + 128 * 17;               // [128][17]
-    float* wo = T + 128 * 17;               // [C][129]    Wout
-    {   // bulk loads first (registers), LDS stores after: one global round trip for the whole staging
-        float c_[16], q_[8];
-        float4 o_[16];
+// Tail: y = x + W2 (Wq x) + g*b per pixel, as two chained MFMA GEMMs computed TRANSPOSED so that no operand ever
+// needs a layout change:  q^T[he][px] = Wq[he][:] . x[px][:]  (A = Wq rows, B = x rows),  then
+// y^T[co][px] = sum_he W2[co][he] q^T[he][px]  (A = W2, B = the q^T accumulators re-used in place: a lane already
+// holds, for its pixel column, 8 he values per K-step — in accumulator row order, which is why W2 is stored with
+// that permutation).  Each wave owns 32 pixels end to end: no LDS, no barrier, every global load issued up front.
+// grid (ceil(npix/128), B), 256 threads.
+template <int C>
+__global__ __launch_bounds__(256) void linattn_out2_kernel(const LinOut2P p) {
+    constexpr int KS1 = C / 16, CT = C / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.y;
+    const int px0 = (blockIdx.x * 4 + wave) * 32;
+    if (px0 >= p.npix) return;
+    const float* X = p.X + (long)b * p.xb + p.x_coff;
+    const int px = min(px0 + i, p.npix - 1);
+    // B fragments of GEMM1: lane (pixel column i, half hh) holds x[px][ks*16 + hh*8 .. +8]
+    const float* xr = X + (long)px * p.ldx + hh * 8;
+    float4 xa[KS1], xc[KS1];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) c_[j] = p.ctx[(long)b * 4096 + tid + 256 * j];
+    for (int ks = 0; ks < KS1; ++ks) {
+        xa[ks] = *reinterpret_cast<const float4*>(xr + ks * 16);
+        xc[ks] = *reinterpret_cast<const float4*>(xr + ks * 16 + 4);
+    }
+    // A fragments of GEMM2 (all of W2 for this utterance: CT x 8 K-steps)
+    const uint4* w2 = reinterpret_cast<const uint4*>(p.W2) + (long)b * CT * 8 * 64 + lane;
+    uint4 w2f[CT][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const int idx = tid + 256 * j; q_[j] = p.Wq[(long)(idx >> 4) * C + ci0 + (idx & 15)]; }
-        const int nwo = C * 32 / 256;                       // float4 items per thread (8 for C=64, 16 for C=128)
+    for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int j = 0; j < 16; ++j) if (j < nwo) o_[j] = *reinterpret_cast<const float4*>(p.Wout + (long)(tid + 256 * j) * 4);
+        for (int ks = 0; ks < 8; ++ks) w2f[ct][ks] = w2[(ct * 8 + ks) * 64];
+    LFrag xf[KS1];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) { const int idx = tid + 256 * j; cs[(idx >> 5) * 33 + (idx & 31)] = c_[j]; }
+    for (int ks = 0; ks < KS1; ++ks) {
+        xf[ks].u.x = pack2_bf16(xa[ks].x, xa[ks].y); xf[ks].u.y = pack2_bf16(xa[ks].z, xa[ks].w);
+        xf[ks].u.z = pack2_bf16(xc[ks].x, xc[ks].y); xf[ks].u.w = pack2_bf16(xc[ks].z, xc[ks].w);
+    }
+    // ---- GEMM1: q^T, four 32-row he tiles; converted to bf16 B fragments tile by tile
+    const u16* wq = reinterpret_cast<const u16*>(p.Wq) + (long)i * C + hh * 8;      // bf16 [128][C]
+    LFrag qf[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const int idx = tid + 256 * j; wq[(idx >> 4) * 17 + (idx & 15)] = q_[j]; }
+    for (int t = 0; t < 4; ++t) {
+        f32x16 q;
 #pragma unroll
-        for (int j = 0; j < 16; ++j) if (j < nwo) {
-            const int idx = (tid + 256 * j) * 4;
-            float* d = wo + (idx >> 7) * 129 + (idx & 127);
-            d[0] = o_[j].x; d[1] = o_[j].y; d[2] = o_[j].z; d[3] = o_[j].w;
+        for (int r = 0; r < 16; ++r) q[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            LFrag af; af.u = *reinterpret_cast<const uint4*>(wq + (long)t * 32 * C + ks * 16);
+            q = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.v, xf[ks].v, q, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            qf[t * 2 + k2].u.x = pack2_bf16(q[8 * k2 + 0], q[8 * k2 + 1]); qf[t * 2 + k2].u.y = pack2_bf16(q[8 * k2 + 2], q[8 * k2 + 3]);
+            qf[t * 2 + k2].u.z = pack2_bf16(q[8 * k2 + 4], q[8 * k2 + 5]); qf[t * 2 + k2].u.w = pack2_bf16(q[8 * k2 + 6], q[8 * k2 + 7]);
         }
     }
-    __syncthreads();
-    for (int idx = tid; idx < 128 * 16; idx += 256) {
-        const int he = idx >> 4, cl = idx & 15, h = he >> 5, e = he & 31;
-        float a = 0.f;
+    // ---- GEMM2 + epilogue: rows co = ct*32 + (r&3) + 8*(r>>2) + 4*hh  ->  4 consecutive channels per register quad
+    float* Y = p.Y + (long)b * p.yb + p.y_coff;
+    const bool ok = px0 + i < p.npix;
 #pragma unroll
-        for (int d = 0; d < 32; ++d) a = fmaf(cs[(h * 32 + d) * 33 + e], wq[(h * 32 + d) * 17 + cl], a);
-        T[he * 17 + cl] = a;
-    }
-    __syncthreads();
-    const float g = p.g[0];
-    for (int idx = tid; idx < C * 16; idx += 256) {
-        const int co = idx >> 4, cl = idx & 15;
-        float a = 0.f;
-#pragma unroll 16
-        for (int he = 0; he < 128; ++he) a = fmaf(wo[co * 129 + he], T[he * 17 + cl], a);
-        a *= g;
-        const int ci = ci0 + cl;
-        p.Mt[(long)b * C * C + (long)ci * C + co] = a;
-        unsigned u = __float_as_uint(a);
-        u += 0x7FFFu + ((u >> 16) & 1u);
-        reinterpret_cast<u16*>(p.Mbf)[(long)b * C * C + (long)co * C + ci] = (u16)(u >> 16);
+    for (int ct = 0; ct < CT; ++ct) {
+        f32x16 y;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] = 0.f;
+        float4 res[4], bia[4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int co = ct * 32 + 8 * g4 + 4 * hh;
+            res[g4] = *reinterpret_cast<const float4*>(X + (long)px * p.ldx + co);
+            bia[g4] = *reinterpret_cast<const float4*>(p.bias + co);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            LFrag af; af.u = w2f[ct][ks];
+            y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.v, qf[ks].v, y, 0, 0, 0);
+        }
+        if (ok) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int co = ct * 32 + 8 * g4 + 4 * hh;
+                float4 o;
+                o.x = y[g4 * 4 + 0] + res[g4].x + bia[g4].x; o.y = y[g4 * 4 + 1] + res[g4].y + bia[g4].y;
+                o.z = y[g4 * 4 + 2] + res[g4].z + bia[g4].z; o.w = y[g4 * 4 + 3] + res[g4].w + bia[g4].w;
+                *reinterpret_cast<float4*>(Y + (long)(px0 + i) * p.ldy + co) = o;
+            }
+        }
     }
 }
-void launch_linattn_fold(const LinFoldP& p, hipStream_t st) {
-    const size_t lds = (size_t)(4 * 32 * 33 + 2 * 128 * 17 + p.C * 129) * sizeof(float);
-    static bool attr = false;
-    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_fold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024); attr = true; }
-    hipLaunchKernelGGL(linattn_fold_kernel, dim3(p.C / 16, p.B), dim3(256), lds, st, p);
+void launch_linattn_out2(const LinOut2P& p, hipStream_t st) {
+    dim3 grid((p.npix + 127) / 128, p.B);
+    if (p.C == 64) hipLaunchKernelGGL(linattn_out2_kernel<64>, grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(linattn_out2_kernel<128>, grid, dim3(256), 0, st, p);
 }
 
 }  // namespace dex
