@@ -91,8 +91,8 @@ def cpu_baseline(cfg, weights, B, T, n_timesteps, TrTs):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="gedex_b1", choices=sorted(WORKLOADS))
     ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16"])
     ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per Euler step")
@@ -195,7 +195,7 @@ def main():
             eng.profile(False)
             tot = sum(r["ms"] for r in rows)
             kern = []
-            for r in rows[:8]:
+            for r in rows[:int(os.environ.get("DEX_BENCH_TOPK", "8"))]:
                 tf = r["flops"] / (r["ms"] * 1e-3) / 1e12
                 gb = r["bytes"] / (r["ms"] * 1e-3) / 1e9
                 kern.append({"kernel": r["name"], "calls": r["calls"], "avg_us": round(r["ms"] / r["calls"] * 1e3, 2),

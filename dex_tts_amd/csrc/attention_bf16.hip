@@ -138,15 +138,22 @@ __device__ __forceinline__ void attn_tile(const u16* kS, const u16* vT, const Fr
 }
 
 __device__ __forceinline__ void load_q(Frag (&qf)[8], const float* Qb, int ldq, int qrow, int Nq, float scale, int hh) {
-    const bool ok = qrow < Nq;
-    const float* qp = Qb + (long)(ok ? qrow : 0) * ldq + hh * 8;
+    // branch-free (row clamped, out-of-range rows scaled to zero): all 16 loads issue back to back
+    const float sc = qrow < Nq ? scale : 0.f;
+    const float* qp = Qb + (long)min(qrow, Nq - 1) * ldq + hh * 8;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        float4 a = *reinterpret_cast<const float4*>(qp + ks * 16);
-        float4 c = *reinterpret_cast<const float4*>(qp + ks * 16 + 4);
-        if (!ok) { a = make_float4(0.f, 0.f, 0.f, 0.f); c = a; }
-        qf[ks].u.x = pack2_bf16_asm(a.x * scale, a.y * scale); qf[ks].u.y = pack2_bf16_asm(a.z * scale, a.w * scale);
-        qf[ks].u.z = pack2_bf16_asm(c.x * scale, c.y * scale); qf[ks].u.w = pack2_bf16_asm(c.z * scale, c.w * scale);
+    for (int k0 = 0; k0 < 8; k0 += 4) {          // two batches of 8 loads: 32 staging VGPRs instead of 64
+        float4 a[4], c[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            a[ks] = *reinterpret_cast<const float4*>(qp + (k0 + ks) * 16);
+            c[ks] = *reinterpret_cast<const float4*>(qp + (k0 + ks) * 16 + 4);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qf[k0 + ks].u.x = pack2_bf16_asm(a[ks].x * sc, a[ks].y * sc); qf[k0 + ks].u.y = pack2_bf16_asm(a[ks].z * sc, a[ks].w * sc);
+            qf[k0 + ks].u.z = pack2_bf16_asm(c[ks].x * sc, c[ks].y * sc); qf[k0 + ks].u.w = pack2_bf16_asm(c[ks].z * sc, c[ks].w * sc);
+        }
     }
 }
 
@@ -206,7 +213,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_split_kernel(const AttnP p)
     extern __shared__ __attribute__((aligned(16))) u16 smem_b[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
-    const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+    const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+    const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z / ksplit, sp = blockIdx.z % ksplit;
     u16* kS = smem_b + wave * SP_WAVE_U16;
     u16* vT = kS + SP_KT * K_LD;
     float* stat = reinterpret_cast<float*>(smem_b + NW * SP_WAVE_U16);     // [NW][2][32]
@@ -215,26 +223,54 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_split_kernel(const AttnP p)
     const float* Qb = p.Q + (long)b * p.qb + h * AHD;
     const float* Kb = p.K + (long)b * p.kb + h * AHD;
     const float* Vb = p.V + (long)b * p.vb + h * AHD;
+#ifdef DEX_TIMING
+    long long tst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    tst[0] = wall_clock64();
+#endif
     Frag qf[8];
     load_q(qf, Qb, p.ldq, q0 + i, p.Nq, p.scale, hh);
+    const int ntiles = (Nk + SP_KT - 1) / SP_KT;
+    const int t_lo = (int)((long)ntiles * sp / ksplit), t_hi = (int)((long)ntiles * (sp + 1) / ksplit);
     f32x16 o[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
-    const int ntiles = (Nk + SP_KT - 1) / SP_KT;
-    for (int kt = wave; kt < ntiles; kt += NW) {
+    if constexpr (NW >= 8) {
+        // 2 waves per SIMD leave 256 VGPRs: no room for a second tile's fp32 staging registers
+        for (int kt = t_lo + wave; kt < t_hi; kt += NW) {
+            Stager<SP_KT, 64> sg;
+            sg.load(Kb, p.ldk, Vb, p.ldv, kt * SP_KT, Nk, lane);
+            sg.store(kS, vT, lane);
+            __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): wave-private tile written
+            __builtin_amdgcn_wave_barrier();
+            attn_tile<SP_KT>(kS, vT, qf, o, m_run, l_run, kt * SP_KT, Nk, lane);
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        int kt = t_lo + wave;
         Stager<SP_KT, 64> sg;
-        sg.load(Kb, p.ldk, Vb, p.ldv, kt * SP_KT, Nk, lane);
-        sg.store(kS, vT, lane);
-        __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0): wave-private tile written
-        __builtin_amdgcn_wave_barrier();
-        attn_tile<SP_KT>(kS, vT, qf, o, m_run, l_run, kt * SP_KT, Nk, lane);
-        __builtin_amdgcn_wave_barrier();
+        if (kt < t_hi) sg.load(Kb, p.ldk, Vb, p.ldv, kt * SP_KT, Nk, lane);
+        while (kt < t_hi) {
+            sg.store(kS, vT, lane);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            const int kn = kt + NW;
+            if (kn < t_hi) sg.load(Kb, p.ldk, Vb, p.ldv, kn * SP_KT, Nk, lane);   // next tile in flight under the MFMAs
+            attn_tile<SP_KT>(kS, vT, qf, o, m_run, l_run, kt * SP_KT, Nk, lane);
+            __builtin_amdgcn_wave_barrier();
+            kt = kn;
+        }
     }
     l_run += __shfl_xor(l_run, 32);
+#ifdef DEX_TIMING
+    asm volatile("s_nop 0" :: "v"(o[0][0]), "v"(o[3][15])); tst[4] = wall_clock64();
+#endif
     __syncthreads();
+#ifdef DEX_TIMING
+    tst[5] = wall_clock64();
+#endif
     float* oS = reinterpret_cast<float*>(smem_b + wave * SP_WAVE_U16);
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -260,10 +296,21 @@ __global__ __launch_bounds__(NW * 64) void attn_bf16_split_kernel(const AttnP p)
             const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(smem_b + w * SP_WAVE_U16) + q * SP_O_LD + d4);
             acc.x = fmaf(f, v.x, acc.x); acc.y = fmaf(f, v.y, acc.y); acc.z = fmaf(f, v.z, acc.z); acc.w = fmaf(f, v.w, acc.w);
         }
-        const float inv = 1.f / L;
-        float* op = p.O + (long)b * p.ob + (long)(q0 + q) * p.ldo + h * AHD + d4;
+        const float inv = L > 0.f ? 1.f / L : 0.f;
+        float* op = p.O + (long)sp * p.o_sstride + (long)b * p.ob + (long)(q0 + q) * p.ldo + h * AHD + d4;
         *reinterpret_cast<float4*>(op) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+        if (ksplit > 1 && d4 == 0) {
+            float* ml = p.ml + ((((long)sp * p.B + b) * p.heads + h) * p.Nq + q0 + q) * 2;
+            ml[0] = M; ml[1] = L;
+        }
     }
+#ifdef DEX_TIMING
+    if (p.dbg && lane == 0 && (wave == 0 || wave == NW - 1)) {
+        tst[6] = wall_clock64();
+        long long* d = p.dbg + (((long)blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z)) * 2 + (wave ? 1 : 0)) * 8;
+        for (int k = 0; k < 8; ++k) d[k] = tst[k];
+    }
+#endif
 }
 
 template <int NW>
@@ -274,13 +321,13 @@ static void launch_split(const AttnP& p, hipStream_t st) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf16_split_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    dim3 grid((p.Nq + 31) / 32, p.heads, p.B);
+    dim3 grid((p.Nq + 31) / 32, p.heads, p.B * (p.ksplit > 1 ? p.ksplit : 1));
     hipLaunchKernelGGL((attn_bf16_split_kernel<NW>), grid, dim3(NW * 64), lds, st, p);
 }
 
 void launch_attention_bf16(const AttnP& p, hipStream_t st) {
     const long blocks128 = (long)((p.Nq + 127) / 128) * p.heads * p.B;
-    if (blocks128 >= 256) {
+    if (blocks128 >= 256 && p.ksplit <= 1) {
         constexpr int KT = 64;
         const size_t lds = (size_t)(2 * KT * K_LD + 2 * AHD * (KT + 8)) * sizeof(u16);
         static bool attr = false;
@@ -293,7 +340,7 @@ void launch_attention_bf16(const AttnP& p, hipStream_t st) {
         return;
     }
     const long blocks32 = (long)((p.Nq + 31) / 32) * p.heads * p.B;
-    const int ntiles = (p.Nk + SP_KT - 1) / SP_KT;
+    const int ntiles = ((p.Nk + SP_KT - 1) / SP_KT + (p.ksplit > 1 ? p.ksplit - 1 : 0)) / (p.ksplit > 1 ? p.ksplit : 1);
     int nw = 8;
     if (blocks32 * 4 >= 2048 || ntiles < 8) nw = 4;
     if (blocks32 * 2 >= 2048 || ntiles < 4) nw = 2;

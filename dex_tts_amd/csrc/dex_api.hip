@@ -24,6 +24,7 @@ struct RawW { float* p = nullptr; std::vector<int64_t> shape; long numel = 0; bo
 struct TD { float* p; int ld; int coff; int C; };          // channels-last activation view
 
 struct ResW { const float *w1, *b1, *g1, *be1, *w2, *b2, *g2, *be2, *wr, *br, *mlp_w, *mlp_b; int cin, cout; };
+constexpr int ATT_KSPLIT_MAX = 4;     // key-split attention partials kept per token (dit_rowchain.hip merges them)
 struct LinW { const float *wqkv, *wqkv_raw, *wout_raw, *bias_eff, *g; const void *wq_bf16, *wkv_bf16; int C; };
 struct DitBlockW { const float *wqkv, *bqkv, *wproj, *bproj, *wfc1, *bfc1, *wfc2, *bfc2, *ada_w, *ada_b; };
 
@@ -512,7 +513,8 @@ struct Plan {
     std::vector<float*> cat;
     float *up_out, *hF;
     int Hm, Wm, Hf, Wt, N;
-    float *pe0, *emb, *pos_part, *tok, *xn, *qkv, *ao, *hmlp, *dbg_tok;
+    float *pe0, *emb, *pos_part, *tok, *xn, *qkv, *ao, *att_ml, *hmlp, *dbg_tok;
+    void *qh, *kh, *vt; int Npad; size_t vt_bytes;          // bf16 attention operands of the row-chain path
     float *tv_keys, *tv_K, *tv_V, *tv_q, *tv_ao, *tv_out, *tiv_out, *tv_weff, *tv_beff; double *tv_stats, *tiv_stats;
     size_t bytes;
 };
@@ -584,7 +586,9 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
     P.Hf = token_rows(c); P.Wt = token_cols(c, P.Wm); P.N = P.Hf * P.Wt;
     const size_t tok = (size_t)B * P.N;
     P.pe0 = A.f(tok * mid); P.emb = A.f(tok * hid); P.pos_part = A.f(tok * hid * POS_SPLIT); P.tok = A.f(tok * hid);
-    P.xn = A.f(tok * hid); P.qkv = A.f(tok * 3 * hid); P.ao = A.f(tok * hid); P.hmlp = A.f(tok * mlp_hidden(c));
+    P.xn = A.f(tok * hid); P.qkv = A.f(tok * 3 * hid); P.ao = A.f(tok * hid * ATT_KSPLIT_MAX); P.att_ml = A.f(tok * c.dit_heads * 2 * ATT_KSPLIT_MAX);
+    P.Npad = (P.N + 31) / 32 * 32; P.vt_bytes = (size_t)B * hid * P.Npad * 2;
+    P.qh = A.take(tok * hid * 2); P.kh = A.take(tok * hid * 2); P.vt = A.take(P.vt_bytes); P.hmlp = A.f(tok * mlp_hidden(c));
     P.dbg_tok = A.f(tok * hid * (c.dit_depth + 1));
     P.tv_keys = P.tv_K = P.tv_V = P.tv_q = P.tv_ao = P.tv_out = P.tiv_out = P.tv_weff = P.tv_beff = nullptr;
     P.tv_stats = P.tiv_stats = nullptr;
@@ -779,12 +783,23 @@ struct Runner {
         if (debug) hipMemcpyAsync(P.dbg_tok, P.tok, (size_t)B * N * hid * 4, hipMemcpyDeviceToDevice, st);
         tap("tok_in", P.dbg_tok, (long)B * N, hid, hid);
         const float scale = 1.0f / sqrtf((float)(hid / c.dit_heads));
-        const bool chain = x->precision == DEX_PREC_BF16 && dit_rowchain_supported(hid, mh) && x->frag_of.count(x->blocks[0].wproj);
+        const bool chain = x->precision == DEX_PREC_BF16 && dit_rowchain_supported(hid, mh) && c.dit_heads == 2 && x->frag_of.count(x->blocks[0].wproj);
         for (int k = 0; k < c.dit_depth; ++k) {
             const DitBlockW& w = x->blocks[k];
             const float* ada = P.ada[k];
             const bool fuse_ln = x->precision == DEX_PREC_BF16;      // LayerNorm+modulate inside the GEMM's A staging
-            if (!chain || k == 0) {                                  // (chained: block k-1's launch already wrote qkv)
+            DitChainP ch{};
+            if (chain) {
+                ch.ksplit = 0; ch.heads = c.dit_heads; ch.rows_per_batch = N; ch.X = P.tok; ch.ada = ada; ch.step = sp; ch.M = B * N;
+                ch.Qh = P.qh; ch.Kh = P.kh; ch.Vt = P.vt; ch.Npad = P.Npad; ch.qscale = scale;
+            }
+            if (chain && k == 0) {                                   // first block: LN + modulate + qkv only
+                ch.qkv_only = 1; ch.Wq = x->frag_of.at(w.wqkv); ch.bq = w.bqkv;
+                ch.next_shift = ada; ch.next_scale = ada + hid; ch.next_step_stride = 6L * hid;
+                run("dit_qkv", 2.0 * B * N * 3.0 * hid * hid, 4.0 * B * N * hid + 2.0 * B * N * 3 * hid, [&] { launch_dit_rowchain(ch, st); });
+                ch.qkv_only = 0; ch.Wq = nullptr; ch.bq = nullptr; ch.next_shift = ch.next_scale = nullptr;
+            }
+            if (!chain) {
                 IGemmP q = base_gemm(fuse_ln ? P.tok : P.xn, hid, 0, 1, N, hid, w.wqkv, 3 * hid, w.bqkv, P.qkv, 3 * hid, 0);
                 if (fuse_ln) { q.ln_shift = ada + 0 * hid; q.ln_scale = ada + 1 * hid; q.ln_step_stride = 6L * hid; }
                 else {
@@ -793,17 +808,18 @@ struct Runner {
                 }
                 gemm("dit_qkv", q);
             }
-            AttnP a{};
-            a.Q = P.qkv; a.ldq = 3 * hid; a.qb = (long)N * 3 * hid;
-            a.K = P.qkv + hid; a.ldk = 3 * hid; a.kb = a.qb; a.V = P.qkv + 2 * hid; a.ldv = 3 * hid; a.vb = a.qb;
-            a.O = P.ao; a.ldo = hid; a.ob = (long)N * hid; a.Nq = N; a.Nk = N; a.kv_len = nullptr; a.kv_len_add = 0;
-            a.heads = c.dit_heads; a.scale = scale; a.B = B;
-            run("dit_attention", 4.0 * B * (double)N * N * hid, 4.0 * 4 * B * N * hid, [&] { launch_attention(a, x->precision, st); });
             if (chain) {
+                // few workgroups (small batch): split the keys over up to 4 workgroups per query tile so a wave sees
+                // one or two key tiles (one global round trip); the row-chain kernel merges the partials on load
+                const long blocks = (long)((N + 31) / 32) * 2 * B;
+                const int ntiles = (N + 31) / 32;
+                const int ks = (int)std::max<long>(1, std::min<long>(std::min<long>(768 / blocks, (ntiles + 7) / 8), ATT_KSPLIT_MAX));
+                AttnDirectP ad{P.qh, P.kh, P.vt, N, P.Npad, B, P.ao, (long)B * N * hid, ks > 1 ? P.att_ml : nullptr, ks, nullptr};
+                run("dit_attention", 4.0 * B * (double)N * N * hid, 2.0 * 3 * B * N * hid + 4.0 * B * N * hid * ks, [&] { launch_attention_direct(ad, st); });
                 const bool last = k + 1 == c.dit_depth;
-                DitChainP ch{};
-                ch.O = P.ao; ch.X = P.tok; ch.Wp = x->frag_of.at(w.wproj); ch.W1 = x->frag_of.at(w.wfc1); ch.W2 = x->frag_of.at(w.wfc2);
-                ch.bp = w.bproj; ch.b1 = w.bfc1; ch.b2 = w.bfc2; ch.ada = ada; ch.step = sp; ch.M = B * N; ch.QKV = P.qkv;
+                ch.O = P.ao; ch.ksplit = ks; ch.o_sstride = ad.o_sstride; ch.ml = P.att_ml;
+                ch.Wp = x->frag_of.at(w.wproj); ch.W1 = x->frag_of.at(w.wfc1); ch.W2 = x->frag_of.at(w.wfc2);
+                ch.bp = w.bproj; ch.b1 = w.bfc1; ch.b2 = w.bfc2;
                 if (!last) {
                     const DitBlockW& wn = x->blocks[k + 1];
                     ch.Wq = x->frag_of.at(wn.wqkv); ch.bq = wn.bqkv;
@@ -820,6 +836,12 @@ struct Runner {
                 }
                 continue;
             }
+            AttnP a{};
+            a.Q = P.qkv; a.ldq = 3 * hid; a.qb = (long)N * 3 * hid;
+            a.K = P.qkv + hid; a.ldk = 3 * hid; a.kb = a.qb; a.V = P.qkv + 2 * hid; a.ldv = 3 * hid; a.vb = a.qb;
+            a.O = P.ao; a.ldo = hid; a.ob = (long)N * hid; a.Nq = N; a.Nk = N; a.kv_len = nullptr; a.kv_len_add = 0;
+            a.heads = c.dit_heads; a.scale = scale; a.B = B;
+            run("dit_attention", 4.0 * B * (double)N * N * hid, 4.0 * 4 * B * N * hid, [&] { launch_attention(a, x->precision, st); });
             IGemmP pr = base_gemm(P.ao, hid, 0, 1, N, hid, w.wproj, hid, w.bproj, P.tok, hid, 0);
             pr.gate = ada + 2 * hid; pr.gate_nstride = 1; pr.gate_step_stride = 6L * hid;
             pr.res = P.tok; pr.ldres = hid; pr.res_bstride = (long)N * hid;
@@ -972,6 +994,7 @@ struct Runner {
             SmallLinP s{X, ldx, rows, K, R(w + ".weight"), bias ? R(w + ".bias") : nullptr, N, Y, N, ai, ao};
             run("cond_mlp", 2.0 * rows * K * N, 4.0 * K * N, [&] { launch_small_linear(s, st); });
         };
+        hipMemsetAsync(P.vt, 0, P.vt_bytes, st);      // key padding of the transposed V operand (attention_direct.hip)
         CondPrepP cp{sigmas_dev, n, c.pe_scale, dim, P.scal, SCAL_STRIDE, P.t_unet, P.t_dit};
         run("cond_prep", 0, 0, [&] { launch_cond_prep(cp, st); });
         lin(P.t_unet, dim, n, dim, "mlp.0", true, 4 * dim, P.tmp_u, 0, 1);

@@ -29,9 +29,18 @@ constexpr int RC_H = 256, RC_MLP = 512, RC_ROWS = 32, RC_NW = 8;
 constexpr int A_LD = RC_H + 8;       // bf16 elements; row stride 528 B: b128 reads of 16 rows hit 64 distinct banks
 constexpr int H_LD = RC_MLP + 8;
 constexpr int X_LD = RC_H + 4;       // floats
-constexpr size_t RC_LDS = (size_t)RC_ROWS * (A_LD + H_LD) * sizeof(u16) + (size_t)RC_ROWS * X_LD * sizeof(float);
+constexpr size_t RC_LDS = (size_t)RC_ROWS * (A_LD + H_LD) * sizeof(u16) + (size_t)RC_ROWS * X_LD * sizeof(float) + 4 * RC_H * sizeof(float);
 
-__device__ __forceinline__ float gelu_erf_rc(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the bf16 rounding the value
+// gets next): ~15 VALU ops instead of the ~45 of libm erff, 32 of them per lane in the fc1 epilogue
+__device__ __forceinline__ float gelu_erf_rc(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    float pl = fmaf(1.061405429f, t, -1.453152027f);
+    pl = fmaf(pl, t, 1.421413741f); pl = fmaf(pl, t, -0.284496736f); pl = fmaf(pl, t, 0.254829592f);
+    const float er = 1.0f - pl * t * __expf(-z * z);           // erf(|x|/sqrt2)
+    return 0.5f * x * (1.0f + copysignf(er, x));
+}
 
 // one weight tile = 32 output columns x 256 K = 16 K-steps x (64 lanes x 16 B)
 __device__ __forceinline__ void wload(uint4 (&w)[16], const void* W, int ksteps_total, int nt, int ks0, int lane) {
@@ -92,6 +101,29 @@ __device__ __forceinline__ void ln_to_A(const float* X1, u16* As, const float* s
     }
 }
 
+// One 32x32 tile of the next block's qkv projection -> the attention kernel's operand layouts (attention_direct.hip):
+//   q (pre-scaled) and k: bf16 [B][2 heads][N][128];   v: transposed bf16 [B][2][128][Npad], key index with bits 2/3
+//   swapped inside each 32-key block (the order in which a P^T accumulator lane holds its keys).
+__device__ __forceinline__ void store_qkv_tile(const DitChainP& p, const f32x16& acc, int nt, float bias, int m0, int lane) {
+    const int i = lane & 31, hh = lane >> 5;
+    const int kind = nt >> 3, head = (nt >> 2) & 1, d = (nt & 3) * 32 + i;
+    const int N = p.rows_per_batch;
+    const int b0 = m0 / N, n0 = m0 - b0 * N;
+    u16* Qh = reinterpret_cast<u16*>(p.Qh); u16* Kh = reinterpret_cast<u16*>(p.Kh); u16* Vt = reinterpret_cast<u16*>(p.Vt);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (m0 + row >= p.M) continue;
+        int n = n0 + row, b = b0;
+        if (n >= N) { n -= N; ++b; }
+        const float v = acc[r] + bias;
+        const long hb = (long)b * 2 + head;
+        if (kind == 0) Qh[(hb * N + n) * 128 + d] = (u16)(pack2_bf16(v * p.qscale, 0.f) & 0xffffu);
+        else if (kind == 1) Kh[(hb * N + n) * 128 + d] = (u16)(pack2_bf16(v, 0.f) & 0xffffu);
+        else Vt[(hb * 128 + d) * p.Npad + ((n & ~12) | ((n & 4) << 1) | ((n & 8) >> 1))] = (u16)(pack2_bf16(v, 0.f) & 0xffffu);
+    }
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChainP p) {
@@ -99,6 +131,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
     u16* As = reinterpret_cast<u16*>(smem_rc);                 // [32][A_LD]  bf16 A operand (O, then LN outputs)
     u16* Hs = As + RC_ROWS * A_LD;                             // [32][H_LD]  bf16 GELU(fc1)
     float* X1 = reinterpret_cast<float*>(Hs + RC_ROWS * H_LD); // [32][X_LD]  fp32 residual stream
+    float* LNp = X1 + RC_ROWS * X_LD;                          // [4][256]   shift_mlp, scale_mlp, next shift, next scale
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
     const int m0 = blockIdx.x * RC_ROWS, M = p.M;
@@ -106,10 +139,32 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
     const float* ada = p.ada + (long)step * 6 * RC_H;
     const bool has_q = p.next_shift != nullptr;
 
+#ifdef DEX_TIMING
+    long long tst[10] = {0,0,0,0,0,0,0,0,0,0};
+    tst[0] = wall_clock64();
+#endif
+    {   // both LayerNorm parameter sets -> LDS now (a dependent L2 round trip inside each LN otherwise)
+        const int which = tid >> 7, c2 = (tid & 127) * 2;       // 512 threads x 2 floats = 4 x 256
+        const float* src = which == 0 ? ada + 3 * RC_H : which == 1 ? ada + 4 * RC_H
+                         : which == 2 ? (has_q ? p.next_shift + (long)step * p.next_step_stride : ada)
+                                      : (has_q ? p.next_scale + (long)step * p.next_step_stride : ada);
+        *reinterpret_cast<float2*>(LNp + which * RC_H + c2) = *reinterpret_cast<const float2*>(src + c2);
+    }
     uint4 wa[16], wb[16];
+    const int col = wave * 32 + i;
+    const u16* a_lane = As + i * A_LD + hh * 8;
+    const u16* h_lane = Hs + i * H_LD + hh * 8;
+    f32x16 acc;
+    if (p.qkv_only) {
+        // first block: just LN + modulate + qkv of the incoming token rows
+        wload(wb, p.Wq, 16, wave, 0, lane);
+        const int row = tid >> 4, seg = tid & 15;
+        const float* src = p.X + (long)min(m0 + row, M - 1) * RC_H + seg * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(X1 + row * X_LD + q * 64 + seg * 4) = *reinterpret_cast<const float4*>(src + q * 64);
+    } else {
     wload(wa, p.Wp, 16, wave, 0, lane);
     // residual rows of this lane's output column + the attention output tile
-    const int col = wave * 32 + i;
     float xres[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -118,10 +173,54 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
     }
     {
         const int row = tid >> 4, seg = tid & 15;
-        const float* src = p.O + (long)min(m0 + row, M - 1) * RC_H + seg * 4;
+        const int m = min(m0 + row, M - 1);
+        const float* src = p.O + (long)m * RC_H + seg * 4;
         float4 v[4];
+        if (p.ksplit <= 1) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(src + q * 64);
+            for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(src + q * 64);
+        } else {
+            // merge the key-split attention partials: O = sum_s w_s O_s / sum_s w_s,  w_s = l_s exp(m_s - max m)
+            // (column block q belongs to head q / 2: head_dim 128)
+            const int bb = m / p.rows_per_batch, n = m - bb * p.rows_per_batch;
+            const int nbat = M / p.rows_per_batch;
+            float4 pv[4][4];
+            float2 st[4][2];
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_) {
+                if (s_ < p.ksplit) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) pv[s_][q] = *reinterpret_cast<const float4*>(src + (long)s_ * p.o_sstride + q * 64);
+#pragma unroll
+                    for (int hd = 0; hd < 2; ++hd)
+                        st[s_][hd] = *reinterpret_cast<const float2*>(p.ml + ((((long)s_ * nbat + bb) * p.heads + hd) * p.rows_per_batch + n) * 2);
+                }
+            }
+#pragma unroll
+            for (int hd = 0; hd < 2; ++hd) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) if (s_ < p.ksplit) mx = fmaxf(mx, st[s_][hd].x);
+                float wsum = 0.f, w[4];
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    w[s_] = 0.f;
+                    if (s_ < p.ksplit) { w[s_] = st[s_][hd].y * __expf(st[s_][hd].x - mx); wsum += w[s_]; }
+                }
+                const float inv = 1.f / wsum;
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    const int q = hd * 2 + qq;
+                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_) if (s_ < p.ksplit) {
+                        a.x = fmaf(w[s_], pv[s_][q].x, a.x); a.y = fmaf(w[s_], pv[s_][q].y, a.y);
+                        a.z = fmaf(w[s_], pv[s_][q].z, a.z); a.w = fmaf(w[s_], pv[s_][q].w, a.w);
+                    }
+                    v[q] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+                }
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             uint2 o;
@@ -133,12 +232,13 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
     const float b_1a = p.b1[col], b_1b = p.b1[col + 256];
     const float b_2 = p.b2[col], g_mlp = ada[5 * RC_H + col];
     __syncthreads();
+#ifdef DEX_TIMING
+    tst[1] = wall_clock64();
+#endif
 
     // ---- x1 = x + gate_msa * (O Wproj + b)
     wload(wb, p.W1, 16, wave, 0, lane);
-    const u16* a_lane = As + i * A_LD + hh * 8;
-    const u16* h_lane = Hs + i * H_LD + hh * 8;
-    f32x16 acc = zero16();
+    acc = zero16();
     mma16(acc, wa, a_lane);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -146,8 +246,15 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
         X1[row * X_LD + col] = xres[r] + g_msa * (acc[r] + b_p);
     }
     __syncthreads();
-    ln_to_A(X1, As, ada + 3 * RC_H, ada + 4 * RC_H, tid);
+#ifdef DEX_TIMING
+    tst[2] = wall_clock64();
+#endif
+    ln_to_A(X1, As, LNp, LNp + RC_H, tid);
     __syncthreads();
+#ifdef DEX_TIMING
+    tst[3] = wall_clock64();
+#endif
+
 
     // ---- h = GELU(A W1 + b1): column tiles `wave` and `wave + 8`
     wload(wa, p.W1, 16, wave + 8, 0, lane);
@@ -167,6 +274,9 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
         Hs[row * H_LD + col + 256] = (u16)(pack2_bf16(gelu_erf_rc(acc[r] + b_1b), 0.f) & 0xffffu);
     }
     __syncthreads();
+#ifdef DEX_TIMING
+    tst[4] = wall_clock64();
+#endif
 
     // ---- x2 = x1 + gate_mlp * (h W2 + b2)
     wload(wa, p.W2, 32, wave, 16, lane);
@@ -182,35 +292,35 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
         if (m0 + row < M) p.X[(long)(m0 + row) * RC_H + col] = x2;
     }
     if (!has_q) return;
+    }   // !qkv_only
     __syncthreads();
-    ln_to_A(X1, As, p.next_shift + (long)step * p.next_step_stride, p.next_scale + (long)step * p.next_step_stride, tid);
+#ifdef DEX_TIMING
+    tst[5] = wall_clock64();
+#endif
+
+    ln_to_A(X1, As, LNp + 2 * RC_H, LNp + 3 * RC_H, tid);
     __syncthreads();
 
-    // ---- qkv of the next block: column tiles wave, wave+8, wave+16
+
+#ifdef DEX_TIMING
+    tst[6] = wall_clock64();
+#endif
+    // ---- qkv of the next block: column tiles wave (q), wave+8 (k), wave+16 (v)
     const float bq0 = p.bq[col], bq1 = p.bq[col + 256], bq2 = p.bq[col + 512];
     wload(wa, p.Wq, 16, wave + 8, 0, lane);
     acc = zero16();
     mma16(acc, wb, a_lane);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (m0 + row < M) p.QKV[(long)(m0 + row) * (3 * RC_H) + col] = acc[r] + bq0;
-    }
+    store_qkv_tile(p, acc, wave, bq0, m0, lane);
     wload(wb, p.Wq, 16, wave + 16, 0, lane);
     acc = zero16();
     mma16(acc, wa, a_lane);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (m0 + row < M) p.QKV[(long)(m0 + row) * (3 * RC_H) + col + 256] = acc[r] + bq1;
-    }
+    store_qkv_tile(p, acc, wave + 8, bq1, m0, lane);
     acc = zero16();
     mma16(acc, wb, a_lane);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (m0 + row < M) p.QKV[(long)(m0 + row) * (3 * RC_H) + col + 512] = acc[r] + bq2;
-    }
+    store_qkv_tile(p, acc, wave + 16, bq2, m0, lane);
+#ifdef DEX_TIMING
+    if (p.dbg && tid == 0) { tst[7] = wall_clock64(); for (int k = 0; k < 8; ++k) p.dbg[blockIdx.x * 8 + k] = tst[k]; }
+#endif
 }
 
 bool dit_rowchain_supported(int hidden, int mlp_hidden) { return hidden == RC_H && mlp_hidden == RC_MLP; }

@@ -140,17 +140,29 @@ void launch_ln_mod(const LnModP& p, hipStream_t st);
 
 // Row-local remainder of a DiT block + the next block's qkv projection in one launch (dit_rowchain.hip; bf16 mode,
 // hidden 256 / mlp 512).  Weights are bf16 in MFMA fragment order (launch_pack_bf16_frag).
-struct DitChainP { const float* O; float* X; const void *Wp, *W1, *W2, *Wq; const float *bp, *b1, *b2, *bq;
+struct DitChainP { const float* O; int ksplit; long o_sstride; const float* ml; int heads; int rows_per_batch;   // attention partials
+                   float* X; const void *Wp, *W1, *W2, *Wq; const float *bp, *b1, *b2, *bq;
                    const float* ada;                       // this block's [n_steps][6*hidden] adaLN table
                    const float *next_shift, *next_scale; long next_step_stride;   // null: no qkv stage (last block)
-                   float* QKV; const int* step; int M; };
+                   void *Qh, *Kh, *Vt; int Npad; float qscale;          // bf16 head-major q,k and transposed v (attention_direct.hip)
+                   int qkv_only;                                        // 1: only LN+modulate+qkv of X (first block)
+                   const int* step; int M; long long* dbg; };
 bool dit_rowchain_supported(int hidden, int mlp_hidden);
+// Softmax attention on the row chain's bf16 operands (2 heads x 128): no staging, K / V^T / Q fragments are read
+// straight from global memory.  O: fp32 [ksplit][B][N][256] partials + ml (merged by the next row chain launch).
+struct AttnDirectP { const void *Qh, *Kh, *Vt; int N, Npad, B; float* O; long o_sstride; float* ml; int ksplit; long long* dbg; };
+void launch_attention_direct(const AttnDirectP& p, hipStream_t st);
 void launch_dit_rowchain(const DitChainP& p, hipStream_t st);
 void launch_pack_bf16_frag(const float* src, void* dst, int K, int N, hipStream_t st);
 
 // Softmax attention, head_dim 128, no key mask except kv_len (timm Attention core / TVAdaptor core).
 struct AttnP { const float* Q; int ldq; long qb; const float* K; int ldk; long kb; const float* V; int ldv; long vb;
-               float* O; int ldo; long ob; int Nq, Nk; const int* kv_len; int kv_len_add; int heads; float scale; int B; };
+               float* O; int ldo; long ob; int Nq, Nk; const int* kv_len; int kv_len_add; int heads; float scale; int B;
+               // key-split partials (bf16 split kernel only; 0/1 = off): split s handles a contiguous range of key
+               // tiles, writes its normalised O to O + s*o_sstride and (running max, row sum) to
+               // ml[((s*B + b)*heads + h)*Nq + q][2]; the consumer merges (dit_rowchain.hip)
+               int ksplit; long o_sstride; float* ml;
+               long long* dbg; };                            // DEX_TIMING builds only
 void launch_attention(const AttnP& p, int precision, hipStream_t st);
 
 // y[r, n] = act_out( bias[n] + sum_k act_in(x[r,k]) * W[n,k] )   (tiny conditioning MLPs; W in reference layout)

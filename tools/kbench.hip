@@ -91,6 +91,24 @@ int main() {
         char nm[64];
         snprintf(nm, 64, "attention fp32 N=%d", N); timeit(nm, 50, 4.0 * N * N * 256, 16.0 * N * 256, [&] { launch_attention(a, 0, 0); });
         snprintf(nm, 64, "attention bf16 N=%d", N); timeit(nm, 50, 4.0 * N * N * 256, 16.0 * N * 256, [&] { launch_attention(a, 1, 0); });
+        float* o4 = dalloc((size_t)B * N * 256 * 4); float* ml = dalloc((size_t)B * N * 16);
+        a.O = o4; a.ksplit = N == 650 ? 3 : 4; a.o_sstride = (long)B * N * 256; a.ml = ml;
+        snprintf(nm, 64, "attention bf16 N=%d ksplit=%d", N, a.ksplit); timeit(nm, 50, 4.0 * N * N * 256, 16.0 * N * 256, [&] { launch_attention(a, 1, 0); });
+#ifdef DEX_TIMING
+        {
+            const int nb = ((N + 31) / 32) * 2 * a.ksplit;
+            long long* dbg; hipMalloc(&dbg, nb * 16 * 8); hipMemset(dbg, 0, nb * 16 * 8);
+            a.dbg = dbg; launch_attention(a, 1, 0); hipDeviceSynchronize(); a.dbg = nullptr;
+            std::vector<long long> h(nb * 16); hipMemcpy(h.data(), dbg, nb * 16 * 8, hipMemcpyDeviceToHost);
+            long long t0 = 1LL << 62, te = 0;
+            for (int bl = 0; bl < nb * 2; ++bl) if (h[bl * 8]) { t0 = std::min(t0, h[bl * 8]); te = std::max(te, h[bl * 8 + 6]); }
+            printf("   blocks=%d span=%lld (10ns)\n", nb, te - t0);
+            for (int bl : {0, 1, nb, nb + 1, 2 * nb - 2, 2 * nb - 1}) { long long* d = &h[bl * 8];
+                printf("   blk %4d w%d: start+%lld  loads+q=%lld stage=%lld tile(s)=%lld barrier=%lld merge+store=%lld\n", bl / 2, bl & 1, d[0] - t0,
+                       d[1] - d[0], d[3] - d[1], d[4] - d[3], d[5] - d[4], d[6] - d[5]); }
+        }
+#endif
+        a.ksplit = 0; a.O = o;
     }
     // ---- conv3x3 64->64 @80x512 and 128->128 @40x256 (bf16 patch kernel and fp32 igemm)
     struct CS { int H, W, Cin, Cout; };
@@ -141,6 +159,36 @@ int main() {
         const double fl = 2.0 * l.M * l.K * l.N, by = 4.0 * (l.M * l.K + l.M * l.N + l.K * l.N);
         snprintf(nm, 80, "linear bf16 M=%d K=%d N=%d", l.M, l.K, l.N); timeit(nm, 50, fl, by, [&] { launch_igemm(g, 1, 0); });
         snprintf(nm, 80, "linear fp32 M=%d K=%d N=%d", l.M, l.K, l.N); timeit(nm, 50, fl, by, [&] { launch_igemm(g, 0, 0); });
+    }
+    // ---- DiT row chain (M=650): weights hot in L2 (back-to-back) vs evicted by a 64 MB sweep between launches
+    {
+        const int M = 650;
+        float* O = dalloc((size_t)M * 256 * 4, 1.0f); float* X = dalloc((size_t)M * 256, 1.0f); float* ml = dalloc((size_t)M * 16, 1.0f);
+        unsigned short *Wp, *W1, *W2, *Wq, *qh, *kh, *vt;
+        hipMalloc(&Wp, 256 * 256 * 2); hipMalloc(&W1, 256 * 512 * 2); hipMalloc(&W2, 512 * 256 * 2); hipMalloc(&Wq, 256 * 768 * 2);
+        hipMemset(Wp, 0, 256 * 256 * 2); hipMemset(W1, 0, 256 * 512 * 2); hipMemset(W2, 0, 512 * 256 * 2); hipMemset(Wq, 0, 256 * 768 * 2);
+        hipMalloc(&qh, M * 256 * 2); hipMalloc(&kh, M * 256 * 2); hipMalloc(&vt, 672 * 256 * 2);
+        float* bias = dalloc(768, 0.1f); float* ada = dalloc(6 * 256, 0.1f);
+        DitChainP c{}; c.O = O; c.ksplit = 3; c.o_sstride = (long)M * 256; c.ml = ml; c.heads = 2; c.rows_per_batch = M; c.X = X;
+        c.Wp = Wp; c.W1 = W1; c.W2 = W2; c.Wq = Wq; c.bp = bias; c.b1 = bias; c.b2 = bias; c.bq = bias; c.ada = ada;
+        c.next_shift = ada; c.next_scale = ada + 256; c.next_step_stride = 0; c.Qh = qh; c.Kh = kh; c.Vt = vt; c.Npad = 672; c.qscale = 0.088f; c.M = M;
+        const double wel = 256.0 * 256 + 2.0 * 256 * 512 + 3.0 * 256 * 256;
+        timeit("dit_rowchain M=650 (weights hot)", 50, 2.0 * M * wel, 2.0 * wel, [&] { launch_dit_rowchain(c, 0); });
+#ifdef DEX_TIMING
+        {
+            long long* dbg; hipMalloc(&dbg, 32 * 8 * 8); hipMemset(dbg, 0, 32 * 8 * 8);
+            c.dbg = dbg; launch_dit_rowchain(c, 0); hipDeviceSynchronize(); c.dbg = nullptr;
+            std::vector<long long> h(32 * 8); hipMemcpy(h.data(), dbg, 32 * 8 * 8, hipMemcpyDeviceToHost);
+            for (int bl : {0, 10, 20}) { long long* d = &h[bl * 8];
+                printf("   blk %2d: stageO=%lld S1=%lld LN1=%lld S2=%lld S3=%lld LN2=%lld S4=%lld total=%lld (10ns)\n", bl,
+                       d[1] - d[0], d[2] - d[1], d[3] - d[2], d[4] - d[3], d[5] - d[4], d[6] - d[5], d[7] - d[6], d[7] - d[0]); }
+        }
+#endif
+        float* big = dalloc(16 << 20, 1.0f); float* big2 = dalloc(16 << 20, 1.0f);
+        timeit("  64 MB d2d copy alone", 20, 0, 128e6, [&] { hipMemcpyAsync(big2, big, 64 << 20, hipMemcpyDeviceToDevice, 0); });
+        timeit("  copy + dit_rowchain (weights cold)", 20, 2.0 * M * wel, 2.0 * wel, [&] { hipMemcpyAsync(big2, big, 64 << 20, hipMemcpyDeviceToDevice, 0); launch_dit_rowchain(c, 0); });
+        c.qkv_only = 1;
+        timeit("dit_rowchain qkv-only (hot)", 50, 2.0 * M * 3 * 256 * 256, 0, [&] { launch_dit_rowchain(c, 0); });
     }
     // ---- trivial kernel floor
     int* stp; hipMalloc(&stp, 4);
