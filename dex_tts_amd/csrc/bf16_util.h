@@ -23,4 +23,30 @@ __device__ __forceinline__ unsigned pack2_bf16_asm(float lo, float hi) {
     return r;
 }
 
+// (lo*m, hi*m) -> packed bf16 as ONE volatile asm block.  For register rings of raw fp32 loads: any plain C++ op on
+// a loaded value (a mask multiply, a select, the vector convert) is pure, so the compiler hoists it to right behind
+// the load to shorten live ranges — and with it the s_waitcnt, which turns a 3-deep prefetch ring back into
+// load -> wait -> compute.  A volatile asm stays where it is written (below the barrier that precedes the LDS store).
+__device__ __forceinline__ unsigned pack2_mul_bf16_pinned(float lo, float hi, float m) {
+    unsigned r; float a, b;
+    asm volatile("v_mul_f32 %1, %3, %5\n\tv_mul_f32 %2, %4, %5\n\tv_cvt_pk_bf16_f32 %0, %1, %2"
+                 : "=v"(r), "=&v"(a), "=&v"(b) : "v"(lo), "v"(hi), "v"(m));
+    return r;
+}
+__device__ __forceinline__ float mul_pinned(float x, float y) {
+    float r;
+    asm volatile("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a full workgroup-scope fence, which the
+// compiler implements as s_waitcnt vmcnt(0): every global load still in flight (a prefetched weight tile, the next
+// K tile of a register ring) is waited for at EVERY barrier, which serialises software pipelines.  Use this one
+// when the data exchanged across the barrier lives in LDS.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 }  // namespace dex

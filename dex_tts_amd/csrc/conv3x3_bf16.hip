@@ -22,6 +22,7 @@ namespace dex {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned short u16;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: register rings of HIP's uint4 struct defeat SROA
 
 __device__ __forceinline__ float cv_mish(float x) {           // branch-free: tanh(softplus(x)) == 1 to fp32 for x > 20
     const float e = __expf(fminf(x, 20.f));
@@ -42,46 +43,6 @@ __device__ __forceinline__ void cv_gn_coeffs(const Conv3P& p, int b, int tid, fl
         var = var < 0.0 ? 0.0 : var;
         smean[g] = (float)mean;
         srstd[g] = (float)(1.0 / sqrt(var + 1e-5));
-    }
-}
-
-// Stage the (TH+2) x 34 x CC input patch chunk [cbase, cbase+CC) into LDS as bf16 (8 channels per item).
-template <int CC, int TH>
-__device__ __forceinline__ void cv_stage_patch(const Conv3P& p, const float* X, const float* mrow, u16* patch, int h0, int w0,
-                                               int cbase, int step, const float* smean, const float* srstd, int tid) {
-    constexpr int PW = 34, PH = TH + 2, LDP = CC + 8;
-    constexpr int ITEMS = PH * PW * (CC / 8);
-#pragma unroll 4
-    for (int it = tid; it < ITEMS; it += 256) {
-        const int c8 = (it % (CC / 8)) * 8;
-        const int px = it / (CC / 8);
-        const int pw = px % PW, ph = px / PW;
-        const int hi = h0 + ph - 1, wi = w0 + pw - 1;
-        const bool inb = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-        const int hc = inb ? hi : 0, wc = inb ? wi : 0;          // clamped: every load is unconditional
-        const float* src = X + ((long)hc * p.W + wc) * p.ldx + cbase + c8;
-        float4 f0 = *reinterpret_cast<const float4*>(src);
-        float4 f1 = *reinterpret_cast<const float4*>(src + 4);
-        float mk = mrow[wc * p.mask_ws];
-        mk = inb ? mk : 0.f;
-        if (p.pro_stats) {
-            const int c = cbase + c8;
-            const int g = c / (p.Cin / 8);
-            const float mean = smean[g], rstd = srstd[g];
-            const float4 ga0 = *reinterpret_cast<const float4*>(p.pro_gamma + c), ga1 = *reinterpret_cast<const float4*>(p.pro_gamma + c + 4);
-            const float4 be0 = *reinterpret_cast<const float4*>(p.pro_beta + c), be1 = *reinterpret_cast<const float4*>(p.pro_beta + c + 4);
-            const float* ta = p.pro_tadd + (long)step * p.Cin + c;
-            const float4 t0 = *reinterpret_cast<const float4*>(ta), t1 = *reinterpret_cast<const float4*>(ta + 4);
-            f0.x = cv_mish((f0.x - mean) * rstd * ga0.x + be0.x) + t0.x; f0.y = cv_mish((f0.y - mean) * rstd * ga0.y + be0.y) + t0.y;
-            f0.z = cv_mish((f0.z - mean) * rstd * ga0.z + be0.z) + t0.z; f0.w = cv_mish((f0.w - mean) * rstd * ga0.w + be0.w) + t0.w;
-            f1.x = cv_mish((f1.x - mean) * rstd * ga1.x + be1.x) + t1.x; f1.y = cv_mish((f1.y - mean) * rstd * ga1.y + be1.y) + t1.y;
-            f1.z = cv_mish((f1.z - mean) * rstd * ga1.z + be1.z) + t1.z; f1.w = cv_mish((f1.w - mean) * rstd * ga1.w + be1.w) + t1.w;
-        }
-        f0.x *= mk; f0.y *= mk; f0.z *= mk; f0.w *= mk; f1.x *= mk; f1.y *= mk; f1.z *= mk; f1.w *= mk;
-        uint4 v;
-        v.x = pack2_bf16(f0.x, f0.y); v.y = pack2_bf16(f0.z, f0.w);
-        v.z = pack2_bf16(f1.x, f1.y); v.w = pack2_bf16(f1.z, f1.w);
-        *reinterpret_cast<uint4*>(patch + px * LDP + c8) = v;
     }
 }
 
@@ -135,7 +96,11 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
     constexpr int WN = 4 / TH;
     constexpr int NT = NSL / 32 / WN;
     constexpr int NSLICE = COUT / NSL;
-    static_assert(NT >= 1, "tile");
+    constexpr int ITEMS = PH * PW * (CC / 8);            // 8-channel patch items
+    constexpr int NI = (ITEMS + 255) / 256;              // per thread
+    constexpr int WPT = NSL * CC / 8 / 256;              // weight items (16 B) per thread per tap
+    constexpr int RING = 3;                              // taps of weights in flight ahead of the MFMAs
+    static_assert(NT >= 1 && WPT >= 1, "tile");
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* patch = smem;                                // [PH*PW][LDP]
     u16* wbuf = smem + PH * PW * LDP;                 // [2][NSL][LDP]
@@ -151,11 +116,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
     const float* mrow = p.mask + (long)b * p.mask_bstride;
     const int K = 9 * p.Cin;
     const u16* Wg = reinterpret_cast<const u16*>(p.Wbf) + (long)slice * NSL * K;     // [COUT][9*Cin], rows of this slice
-#ifdef DEX_TIMING
-    long long tst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    tst[7] = wall_clock64();
-#endif
-    if (p.pro_stats) { cv_gn_coeffs(p, b, tid, smean, srstd); __syncthreads(); }
+    const bool pro = p.pro_stats != nullptr;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -163,40 +124,91 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    constexpr int WPT = NSL * CC / 8 / 256;
-    static_assert(WPT >= 1, "weights per thread");
+    // weight item j of this thread: output channel wn[j], 8 input channels at wc8[j] (same for every tap)
+    int wofs[WPT], wlds[WPT];
+#pragma unroll
+    for (int j = 0; j < WPT; ++j) {
+        const int it = tid + 256 * j;
+        const int n = it / (CC / 8), c8 = (it % (CC / 8)) * 8;
+        wofs[j] = n * K + c8;
+        wlds[j] = n * LDP + c8;
+    }
+    const int pc8 = (tid % (CC / 8)) * 8;             // 256 % (CC/8) == 0: a thread's patch items share one channel chunk
+
     const int nchunk = p.Cin / CC;
     for (int ch = 0; ch < nchunk; ++ch) {
         const int cbase = ch * CC;
-        __syncthreads();                              // previous chunk fully consumed
-        cv_stage_patch<CC, TH>(p, X, mrow, patch, h0, w0, cbase, step, smean, srstd, tid);
+        // ---- every global load of the chunk's first round goes out back to back: weights of taps 0..RING, the patch
+        u32x4 w0r[WPT], wr[RING][WPT];
 #pragma unroll
-        for (int j = 0; j < WPT; ++j) {
-            const int it = tid + 256 * j;
-            const int n = it / (CC / 8), c8 = (it % (CC / 8)) * 8;
-            *reinterpret_cast<uint4*>(wbuf + n * LDP + c8) = *reinterpret_cast<const uint4*>(Wg + (long)n * K + cbase + c8);
+        for (int j = 0; j < WPT; ++j) w0r[j] = *reinterpret_cast<const u32x4*>(Wg + wofs[j] + cbase);
+#pragma unroll
+        for (int s = 0; s < RING; ++s)
+#pragma unroll
+            for (int j = 0; j < WPT; ++j) wr[s][j] = *reinterpret_cast<const u32x4*>(Wg + wofs[j] + (long)(s + 1) * p.Cin + cbase);
+        float4 pf0[NI], pf1[NI];
+        float pmk[NI];
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            const int it = min(tid + 256 * q, ITEMS - 1);
+            const int px = it / (CC / 8);
+            const int pw = px % PW, ph = px / PW;
+            const int hi = h0 + ph - 1, wi = w0 + pw - 1;
+            const bool inb = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const int hc = inb ? hi : 0, wc = inb ? wi : 0;          // clamped: every load is unconditional
+            const float* src = X + ((long)hc * p.W + wc) * p.ldx + cbase + pc8;
+            pf0[q] = *reinterpret_cast<const float4*>(src);
+            pf1[q] = *reinterpret_cast<const float4*>(src + 4);
+            const float mk = mrow[wc * p.mask_ws];
+            pmk[q] = inb ? mk : 0.f;
         }
-        for (int tap = 0; tap < 9; ++tap) {
-#ifdef DEX_TIMING
-            if (tap == 1) tst[0] = wall_clock64();
-#endif
-            __syncthreads();                          // patch + this tap's weights visible; the other buffer is free
-#ifdef DEX_TIMING
-            if (tap == 1) tst[1] = wall_clock64();
-#endif
-            const u16* wb = wbuf + (tap & 1) * NSL * LDP;
-            uint4 wnext[WPT];
-            if (tap + 1 < 9) {
+        float4 ga0, ga1, be0, be1, t0, t1;
+        float mean = 0.f, rstd = 1.f;
+        if (pro) {
+            const int c = cbase + pc8;
+            ga0 = *reinterpret_cast<const float4*>(p.pro_gamma + c); ga1 = *reinterpret_cast<const float4*>(p.pro_gamma + c + 4);
+            be0 = *reinterpret_cast<const float4*>(p.pro_beta + c); be1 = *reinterpret_cast<const float4*>(p.pro_beta + c + 4);
+            const float* ta = p.pro_tadd + (long)step * p.Cin + c;
+            t0 = *reinterpret_cast<const float4*>(ta); t1 = *reinterpret_cast<const float4*>(ta + 4);
+            if (ch == 0) cv_gn_coeffs(p, b, tid, smean, srstd);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        lds_barrier();                                // GN coefficients visible; previous chunk's MFMAs done with patch/wbuf
+        if (pro) { const int g = (cbase + pc8) / (p.Cin / 8); mean = smean[g]; rstd = srstd[g]; }
 #pragma unroll
-                for (int j = 0; j < WPT; ++j) {
-                    const int it = tid + 256 * j;
-                    const int n = it / (CC / 8), c8 = (it % (CC / 8)) * 8;
-                    wnext[j] = *reinterpret_cast<const uint4*>(Wg + (long)n * K + (long)(tap + 1) * p.Cin + cbase + c8);
-                }
+        for (int j = 0; j < WPT; ++j) *reinterpret_cast<u32x4*>(wbuf + wlds[j]) = w0r[j];
+#pragma unroll
+        for (int q = 0; q < NI; ++q) {
+            float4 f0 = pf0[q], f1 = pf1[q];
+            if (pro) {
+                f0.x = cv_mish((f0.x - mean) * rstd * ga0.x + be0.x) + t0.x; f0.y = cv_mish((f0.y - mean) * rstd * ga0.y + be0.y) + t0.y;
+                f0.z = cv_mish((f0.z - mean) * rstd * ga0.z + be0.z) + t0.z; f0.w = cv_mish((f0.w - mean) * rstd * ga0.w + be0.w) + t0.w;
+                f1.x = cv_mish((f1.x - mean) * rstd * ga1.x + be1.x) + t1.x; f1.y = cv_mish((f1.y - mean) * rstd * ga1.y + be1.y) + t1.y;
+                f1.z = cv_mish((f1.z - mean) * rstd * ga1.z + be1.z) + t1.z; f1.w = cv_mish((f1.w - mean) * rstd * ga1.w + be1.w) + t1.w;
             }
-#ifdef DEX_TIMING
-            if (tap == 1) tst[2] = wall_clock64();
-#endif
+            const float mk = pmk[q];
+            uint4 v;
+            v.x = pack2_bf16(f0.x * mk, f0.y * mk); v.y = pack2_bf16(f0.z * mk, f0.w * mk);
+            v.z = pack2_bf16(f1.x * mk, f1.y * mk); v.w = pack2_bf16(f1.z * mk, f1.w * mk);
+            const int it = tid + 256 * q;
+            if (it < ITEMS) *reinterpret_cast<uint4*>(patch + (it / (CC / 8)) * LDP + pc8) = v;
+        }
+        // ---- nine taps; tap t's weights sit in wbuf[t & 1], taps t+1 .. t+RING are in registers / in flight
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            lds_barrier();                            // wbuf[tap & 1] (and the patch) visible; wbuf[(tap+1) & 1] is free
+            if (tap + 1 < 9) {
+                u16* wn = wbuf + ((tap + 1) & 1) * NSL * LDP;
+#pragma unroll
+                for (int j = 0; j < WPT; ++j) *reinterpret_cast<u32x4*>(wn + wlds[j]) = wr[tap % RING][j];
+                if (tap + 1 + RING < 9) {
+#pragma unroll
+                    for (int j = 0; j < WPT; ++j)
+                        wr[tap % RING][j] = *reinterpret_cast<const u32x4*>(Wg + wofs[j] + (long)(tap + 1 + RING) * p.Cin + cbase);
+                }
+                __builtin_amdgcn_sched_barrier(0);    // the refill loads issue before the MFMAs, not dripped between them
+            }
+            const u16* wb = wbuf + (tap & 1) * NSL * LDP;
             const int kh = tap / 3, kw = tap - kh * 3;
             const u16* ap = patch + ((wrow + kh) * PW + i + kw) * LDP + hh * 8;
             const u16* bp = wb + (wcol * NT * 32 + i) * LDP + hh * 8;
@@ -209,27 +221,9 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
                 }
             }
-#ifdef DEX_TIMING
-            if (tap == 1) { asm volatile("s_nop 0" :: "v"(acc[0][0])); tst[3] = wall_clock64(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tst[4] = wall_clock64(); }
-#endif
-            if (tap + 1 < 9) {
-                u16* wn = wbuf + ((tap + 1) & 1) * NSL * LDP;
-#pragma unroll
-                for (int j = 0; j < WPT; ++j) {
-                    const int it = tid + 256 * j;
-                    const int n = it / (CC / 8), c8 = (it % (CC / 8)) * 8;
-                    *reinterpret_cast<uint4*>(wn + n * LDP + c8) = wnext[j];
-                }
-            }
         }
     }
-#ifdef DEX_TIMING
-    tst[5] = wall_clock64();
-#endif
     cv_epilogue<NT, COUT>(p, acc, b, h0 + wrow, w0, slice * NSL + wcol * NT * 32, lane, tid, gnred);
-#ifdef DEX_TIMING
-    if (p.dbg && tid == 0) { tst[6] = wall_clock64(); long long* d = p.dbg + ((long)blockIdx.x + (long)gridDim.x * blockIdx.y) * 8; for (int k = 0; k < 8; ++k) d[k] = tst[k]; }
-#endif
 }
 
 template <int CC, int COUT, int NSL, int TH>

@@ -47,6 +47,7 @@ __device__ __forceinline__ void wload(uint4 (&w)[16], const void* W, int ksteps_
     const uint4* src = reinterpret_cast<const uint4*>(W) + ((long)nt * ksteps_total + ks0) * 64 + lane;
 #pragma unroll
     for (int j = 0; j < 16; ++j) w[j] = src[j * 64];
+    __builtin_amdgcn_sched_barrier(0);     // all 16 loads issue HERE (the scheduler otherwise drips them into the MFMA chain below)
 }
 __device__ __forceinline__ void mma16(f32x16& acc, const uint4 (&w)[16], const u16* a_lane) {
 #pragma unroll
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
     const float b_p = p.bp[col], g_msa = ada[2 * RC_H + col];
     const float b_1a = p.b1[col], b_1b = p.b1[col + 256];
     const float b_2 = p.b2[col], g_mlp = ada[5 * RC_H + col];
-    __syncthreads();
+    lds_barrier();
 #ifdef DEX_TIMING
     tst[1] = wall_clock64();
 #endif
@@ -245,12 +246,12 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
         const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
         X1[row * X_LD + col] = xres[r] + g_msa * (acc[r] + b_p);
     }
-    __syncthreads();
+    lds_barrier();
 #ifdef DEX_TIMING
     tst[2] = wall_clock64();
 #endif
     ln_to_A(X1, As, LNp, LNp + RC_H, tid);
-    __syncthreads();
+    lds_barrier();
 #ifdef DEX_TIMING
     tst[3] = wall_clock64();
 #endif
@@ -273,7 +274,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
         const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
         Hs[row * H_LD + col + 256] = (u16)(pack2_bf16(gelu_erf_rc(acc[r] + b_1b), 0.f) & 0xffffu);
     }
-    __syncthreads();
+    lds_barrier();
 #ifdef DEX_TIMING
     tst[4] = wall_clock64();
 #endif
@@ -293,13 +294,13 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
     }
     if (!has_q) return;
     }   // !qkv_only
-    __syncthreads();
+    lds_barrier();
 #ifdef DEX_TIMING
     tst[5] = wall_clock64();
 #endif
 
     ln_to_A(X1, As, LNp + 2 * RC_H, LNp + 3 * RC_H, tid);
-    __syncthreads();
+    lds_barrier();
 
 
 #ifdef DEX_TIMING

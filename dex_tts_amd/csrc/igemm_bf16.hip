@@ -12,10 +12,39 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
 
+// one K tile of global loads into a register slot: raw fp32 activations (addresses clamped, validity folded into
+// the mask factor) and bf16 weights; nothing here waits on memory
+template <int BN, int BK, bool PT, int AP, int RPP, int BP>
+__device__ __forceinline__ void igemm_load_tile(const IGemmP& p, float4 (&fa)[AP][2], float (&fm)[AP], float (&fo)[AP], uint4& rb0, uint4& rb1, int k0, bool live, int tk8, int trow,
+                                                const int (&bh)[AP], const int (&bw)[AP], unsigned mvbits,
+                                                const float* Ab, const float* mrow, int mws, const u16* Wb, int n0) {
+    const int kthr = PT ? k0 + tk8 : k0;                     // tap resolution per thread or per tile
+    const int tap = kthr / p.Cin, c0 = kthr - tap * p.Cin + (PT ? 0 : tk8);
+    const int kh = tap / p.KW, kw = tap - kh * p.KW;
+#pragma unroll
+    for (int j = 0; j < AP; ++j) {
+        const int hi = bh[j] + kh * p.step_h, wi = bw[j] + kw * p.step_w;
+        const bool ok = ((mvbits >> j) & 1u) && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
+        const int hc = ok ? hi : 0, wc = ok ? wi : 0;
+        const float* src = Ab + ((long)hc * p.Wi + wc) * p.lda + c0;
+        fa[j][0] = *reinterpret_cast<const float4*>(src);
+        fa[j][1] = *reinterpret_cast<const float4*>(src + 4);
+        fm[j] = mrow[wc * mws];                // raw mask value (a dummy in-bounds load when there is no mask): NO op on it here
+        fo[j] = (ok && live) ? 1.f : 0.f;      // validity from indices only; tiles past the K range (ring padding) give exact zeros
+    }
+    if (BN >= RPP || trow < BN) rb0 = *reinterpret_cast<const uint4*>(Wb + (long)(n0 + trow) * p.K + k0 + tk8);
+    if constexpr (BP > 1) rb1 = *reinterpret_cast<const uint4*>(Wb + (long)(n0 + trow + RPP) * p.K + k0 + tk8);
+}
+
 // PT: the 8-element chunk of every thread resolves its own tap (k -> (kh,kw,c)); needed when Cin < BK, e.g. the
 // grouped 16x16 pos-conv (Cin = 32 per group) with BK = 128: 8 K iterations instead of 32 exposed round trips.
-template <int BM, int BN, int BK, bool PT = false>
-__global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemmP p) {
+// D: K tiles of global loads kept in flight ahead of the MFMAs (raw fp32 in registers, converted when they are
+// stored to LDS).  At B=1 a K tile is ~0.1 us of MFMA behind a ~1.3 us round trip: D=3 cuts the exposed trips 3x.
+// NKT > 0: the K-tile count is a compile-time constant and the ring loop is fully unrolled — only in straight-line
+// code does the compiler keep exact vmcnt(N) waits (inside a loop it falls back to vmcnt(0) at every LDS store,
+// which serialises the ring: measured 19 -> 24.5 us on the stride-2 downsample conv before unrolling).
+template <int BM, int BN, int BK, bool PT = false, int D = 1, int NKT = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void igemm_bf16_kernel(const IGemmP p) {
     constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (WM * 32);
     constexpr int TPR = BK / 8;                 // threads per tile row (8 elements each)
     constexpr int RPP = 256 / TPR;              // rows per pass
@@ -42,17 +71,21 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemmP p) {
     int mtile = blockIdx.x;
     if ((gridDim.x & 7) == 0) mtile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int m0 = mtile * BM, n0 = blockIdx.y * BN;
-    const int Kper = p.K / p.ksplit, kbeg = s * Kper, nkt = Kper / BK;
+    const int Kper = p.K / p.ksplit, kbeg = s * Kper, nkt = NKT ? NKT : Kper / BK;
 
     const float* Ab = p.A + (long)b * p.a_bstride + p.a_coff + g * p.Cin;
-    const float* mrow = p.inmask ? p.inmask + (long)b * p.mask_bstride : nullptr;
+    // both arms are kernel-argument (global) pointers: a select against a __device__ constant would degrade the
+    // mask loads to FLAT, and an outstanding FLAT load forces vmcnt(0) waits everywhere
+    const float* mrow = p.inmask ? p.inmask + (long)b * p.mask_bstride : p.A;
+    const int mws = p.inmask ? p.inmask_ws : 0;
+    const bool has_mask = p.inmask != nullptr;
     const int trow = tid / TPR, tk8 = (tid % TPR) * 8;
     int bh[AP], bw[AP];
-    bool mv[AP];
+    unsigned mvbits = 0;
 #pragma unroll
     for (int j = 0; j < AP; ++j) {
         const int m = m0 + trow + RPP * j;
-        mv[j] = m < M;
+        mvbits |= (m < M ? 1u : 0u) << j;
         const int ho = m / p.Wo, wo = m - ho * p.Wo;
         bh[j] = ho * p.sh + off_h;
         bw[j] = wo * p.sw + off_w;
@@ -60,8 +93,11 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemmP p) {
     // bf16 weights [N][K] (per group / per batch strides are in elements of the fp32 [K][N] pack: same count)
     const u16* Wb = reinterpret_cast<const u16*>(p.Wbf) + (long)b * p.w_bstride + (long)g * p.w_gstride + (long)par * p.K * p.N;
 
-    uint4 ra[AP];
-    uint4 rb0 = make_uint4(0, 0, 0, 0), rb1 = rb0;
+    float4 fa[D][AP][2];
+    float fm[D][AP], fo[D][AP];
+    uint4 rb0[D], rb1[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { rb0[d] = make_uint4(0, 0, 0, 0); rb1[d] = rb0[d]; }
     static_assert(BP <= 2, "B passes");
     f32x16 acc[MT];
 #pragma unroll
@@ -69,42 +105,35 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IGemmP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    for (int kt = -1; kt < nkt; ++kt) {
-        if (kt >= 0) {
-            __syncthreads();
+    // The ring runs over ceil(nkt / D) * D tiles with NO data-dependent control flow (tiles past the end re-read the
+    // last tile with a zero mask): the waitcnt bookkeeping stays exact (vmcnt = loads of the D-1 younger tiles)
+    // instead of collapsing to vmcnt(0) at every conditional.
+    const int nkt_pad = (nkt + D - 1) / D * D;
 #pragma unroll
-            for (int j = 0; j < AP; ++j)
-                *reinterpret_cast<uint4*>(As + (trow + RPP * j) * LDS_LD + tk8) = ra[j];
-            if (BN >= RPP || trow < BN) *reinterpret_cast<uint4*>(Bs + trow * LDS_LD + tk8) = rb0;
-            if constexpr (BP > 1) *reinterpret_cast<uint4*>(Bs + (trow + RPP) * LDS_LD + tk8) = rb1;
-            __syncthreads();
-        }
-        if (kt + 1 < nkt) {
-            const int k0 = kbeg + (kt + 1) * BK;
-            const int kthr = PT ? k0 + tk8 : k0;                     // tap resolution per thread or per tile
-            const int tap = kthr / p.Cin, c0 = kthr - tap * p.Cin + (PT ? 0 : tk8);
-            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+    for (int d = 0; d < D; ++d)
+        igemm_load_tile<BN, BK, PT, AP, RPP, BP>(p, fa[d], fm[d], fo[d], rb0[d], rb1[d], kbeg + min(d, nkt - 1) * BK, d < nkt, tk8, trow, bh, bw, mvbits, Ab, mrow, mws, Wb, n0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll(NKT ? (NKT + D - 1) / D : 1)
+    for (int kt0 = 0; kt0 < nkt_pad; kt0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int kt = kt0 + d;
+            lds_barrier();                  // previous tile's MFMAs are done with the LDS tiles
+            __builtin_amdgcn_sched_barrier(0);     // keep the conversion (and its vmcnt wait) of this slot below the barrier
 #pragma unroll
             for (int j = 0; j < AP; ++j) {
-                const int hi = bh[j] + kh * p.step_h, wi = bw[j] + kw * p.step_w;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (mv[j] && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi) {
-                    const float* src = Ab + ((long)hi * p.Wi + wi) * p.lda + c0;
-                    float4 f0 = *reinterpret_cast<const float4*>(src);
-                    float4 f1 = *reinterpret_cast<const float4*>(src + 4);
-                    if (mrow) {
-                        const float mk = mrow[wi * p.inmask_ws];
-                        f0.x *= mk; f0.y *= mk; f0.z *= mk; f0.w *= mk; f1.x *= mk; f1.y *= mk; f1.z *= mk; f1.w *= mk;
-                    }
-                    v.x = pack2_bf16(f0.x, f0.y); v.y = pack2_bf16(f0.z, f0.w);
-                    v.z = pack2_bf16(f1.x, f1.y); v.w = pack2_bf16(f1.z, f1.w);
-                }
-                ra[j] = v;
+                const float mk = has_mask ? mul_pinned(fm[d][j], fo[d][j]) : fo[d][j];
+                const float4 f0 = fa[d][j][0], f1 = fa[d][j][1];
+                uint4 v;
+                v.x = pack2_mul_bf16_pinned(f0.x, f0.y, mk); v.y = pack2_mul_bf16_pinned(f0.z, f0.w, mk);
+                v.z = pack2_mul_bf16_pinned(f1.x, f1.y, mk); v.w = pack2_mul_bf16_pinned(f1.z, f1.w, mk);
+                *reinterpret_cast<uint4*>(As + (trow + RPP * j) * LDS_LD + tk8) = v;
             }
-            if (BN >= RPP || trow < BN) rb0 = *reinterpret_cast<const uint4*>(Wb + (long)(n0 + trow) * p.K + k0 + tk8);
-            if constexpr (BP > 1) rb1 = *reinterpret_cast<const uint4*>(Wb + (long)(n0 + trow + RPP) * p.K + k0 + tk8);
-        }
-        if (kt >= 0) {
+            if (BN >= RPP || trow < BN) *reinterpret_cast<uint4*>(Bs + trow * LDS_LD + tk8) = rb0[d];
+            if constexpr (BP > 1) *reinterpret_cast<uint4*>(Bs + (trow + RPP) * LDS_LD + tk8) = rb1[d];
+            lds_barrier();
+            igemm_load_tile<BN, BK, PT, AP, RPP, BP>(p, fa[d], fm[d], fo[d], rb0[d], rb1[d], kbeg + min(kt + D, nkt - 1) * BK, kt + D < nkt, tk8, trow, bh, bw, mvbits, Ab, mrow, mws, Wb, n0);
+            __builtin_amdgcn_sched_barrier(0);     // the scheduler otherwise sinks these loads down to their first use
             const u16* ap = As + (wm * (MT * 32) + i) * LDS_LD + hh * 8;
             const u16* bp = Bs + (wn * 32 + i) * LDS_LD + hh * 8;
 #pragma unroll
@@ -273,7 +302,8 @@ void launch_igemm_bf16(const IGemmP& p, hipStream_t st) {
         const long blocks128 = (long)((M + 127) / 128) * (p.N / 64) * zdim;
         if (blocks128 < 1024) {
             dim3 grid((M + 63) / 64, p.N / 64, zdim);
-            if (k64) hipLaunchKernelGGL((igemm_bf16_kernel<64, 64, 64>), grid, dim3(256), 0, st, p);
+            if (k64 && p.K / p.ksplit == 576) hipLaunchKernelGGL((igemm_bf16_kernel<64, 64, 64, false, 3, 9>), grid, dim3(256), 0, st, p);   // 3x3 x 64ch
+            else if (k64) hipLaunchKernelGGL((igemm_bf16_kernel<64, 64, 64>), grid, dim3(256), 0, st, p);
             else hipLaunchKernelGGL((igemm_bf16_kernel<64, 64, 32>), grid, dim3(256), 0, st, p);
         } else {
             dim3 grid((M + 127) / 128, p.N / 64, zdim);
@@ -282,7 +312,8 @@ void launch_igemm_bf16(const IGemmP& p, hipStream_t st) {
         }
     } else {
         dim3 grid((M + 127) / 128, p.N / 32, zdim);
-        if ((p.K / p.ksplit) % 128 == 0 && p.Cin % 8 == 0) hipLaunchKernelGGL((igemm_bf16_kernel<128, 32, 128, true>), grid, dim3(256), 0, st, p);
+        if (p.K / p.ksplit == 1024 && p.Cin % 8 == 0) hipLaunchKernelGGL((igemm_bf16_kernel<128, 32, 128, true, 2, 8>), grid, dim3(256), 0, st, p);   // pos-conv split
+        else if ((p.K / p.ksplit) % 128 == 0 && p.Cin % 8 == 0) hipLaunchKernelGGL((igemm_bf16_kernel<128, 32, 128, true>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((igemm_bf16_kernel<128, 32, 32>), grid, dim3(256), 0, st, p);
     }
 }

@@ -35,67 +35,111 @@ __device__ __forceinline__ void gn_mean_rstd(const float* stats, int b, int grou
 }
 
 // ------------------------------------------------------------------------------------------------
-// first conv: one thread = one pixel x 4 output channels.  planes <= 3.
+// first conv (C == 64): one thread = one pixel x 16 output channels; the 3x3 and 1x1 weights sit in LDS (5-8 KB,
+// broadcast reads), so the 18-27 input taps of a pixel are loaded by 4 threads instead of 16 and the GroupNorm
+// partials are reduced by shuffles before they touch LDS (the per-thread LDS atomics of the first version were a
+// 32-way serialisation).  planes <= 3.
 template <int PLANES>
 __global__ __launch_bounds__(256) void first_conv_kernel(const FirstConvP p) {
-    const int C4 = p.C >> 2;
-    const long total = (long)p.B * p.H * p.T * C4;
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= total) return;
-    const int cq = (int)(gid % C4);
-    const long pix = gid / C4;
+    constexpr int C = 64;
+    __shared__ __attribute__((aligned(16))) float w3s[PLANES * 9 * C];
+    __shared__ __attribute__((aligned(16))) float w1s[PLANES * C];
+    __shared__ float red[16];
+    const int tid = threadIdx.x;
+    for (int k = tid; k < PLANES * 9 * C; k += 256) w3s[k] = p.W3[k];
+    for (int k = tid; k < PLANES * C; k += 256) w1s[k] = p.W1[k];
+    if (tid < 16) red[tid] = 0.f;
+    const long npix = (long)p.B * p.H * p.T;
+    const long pix_raw = (long)blockIdx.x * 64 + (tid >> 2);
+    const bool live = pix_raw < npix;
+    const long pix = live ? pix_raw : npix - 1;
+    const int cq = tid & 3;                                   // channels [cq*16, cq*16+16)
     const int w = (int)(pix % p.T);
     const int h = (int)((pix / p.T) % p.H);
     const int b = (int)(pix / ((long)p.T * p.H));
     const int step = p.step ? *p.step : 0;
     const float c_in = p.scal[step * p.scal_stride + 2];
     const float* mrow = p.mask + (long)b * p.T;
-    const float* pl[3] = {p.mu + (long)b * p.H * p.T, p.x + (long)b * p.H * p.T, nullptr};
-    float4 a3 = *reinterpret_cast<const float4*>(p.b3 + cq * 4);
-    float4 a1 = *reinterpret_cast<const float4*>(p.b1 + cq * 4);
+    const float* pl[2] = {p.mu + (long)b * p.H * p.T, p.x + (long)b * p.H * p.T};
+    float v[PLANES][9];
 #pragma unroll
-    for (int q = 0; q < PLANES; ++q) {
-        const float sc = (q == 1) ? c_in : 1.f;
+    for (int kh = 0; kh < 3; ++kh) {
+        const int hi = h + kh - 1;
 #pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-            const int hi = h + kh - 1;
+        for (int kw = 0; kw < 3; ++kw) {
+            const int wi = w + kw - 1;
+            const bool inb = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.T;
+            const int hc = inb ? hi : h, wc = inb ? wi : w;          // clamped, always-valid address
+            const float mk = inb ? mrow[wc] : 0.f;
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) {
-                const int wi = w + kw - 1;
-                const bool inb = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.T;
-                const int hc = inb ? hi : h, wc = inb ? wi : w;          // clamped, always-valid address
-                float v;
-                if (q < 2) v = pl[q][(long)hc * p.T + wc] * sc;
-                else v = p.spk[(long)b * p.H + hc];
-                v *= mrow[wc];
-                v = inb ? v : 0.f;
-                const float4 wv = *reinterpret_cast<const float4*>(p.W3 + ((q * 9 + kh * 3 + kw) * p.C) + cq * 4);
-                a3.x = fmaf(v, wv.x, a3.x); a3.y = fmaf(v, wv.y, a3.y); a3.z = fmaf(v, wv.z, a3.z); a3.w = fmaf(v, wv.w, a3.w);
-                if (kh == 1 && kw == 1) {
-                    const float4 w1 = *reinterpret_cast<const float4*>(p.W1 + q * p.C + cq * 4);
-                    a1.x = fmaf(v, w1.x, a1.x); a1.y = fmaf(v, w1.y, a1.y); a1.z = fmaf(v, w1.z, a1.z); a1.w = fmaf(v, w1.w, a1.w);
-                }
+            for (int q = 0; q < PLANES; ++q) {
+                float t;
+                if (q < 2) t = pl[q][(long)hc * p.T + wc] * ((q == 1) ? c_in : 1.f);
+                else t = p.spk[(long)b * p.H + hc];
+                v[q][kh * 3 + kw] = t * mk;
             }
         }
     }
-    *reinterpret_cast<float4*>(p.h1 + pix * p.C + cq * 4) = a3;
-    *reinterpret_cast<float4*>(p.res + pix * p.C + cq * 4) = a1;
-    if (p.gn_stats) {          // workgroup-combined GroupNorm partials of h1 (8 groups), one atomic pair per group
-        __shared__ float red[16];
-        if (threadIdx.x < 16) red[threadIdx.x] = 0.f;
+    float4 a3[4], a1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        a3[j] = *reinterpret_cast<const float4*>(p.b3 + cq * 16 + j * 4);
+        a1[j] = *reinterpret_cast<const float4*>(p.b1 + cq * 16 + j * 4);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PLANES; ++q) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float x = v[q][t];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 wv = *reinterpret_cast<const float4*>(w3s + (q * 9 + t) * C + cq * 16 + j * 4);
+                a3[j].x = fmaf(x, wv.x, a3[j].x); a3[j].y = fmaf(x, wv.y, a3[j].y); a3[j].z = fmaf(x, wv.z, a3[j].z); a3[j].w = fmaf(x, wv.w, a3[j].w);
+            }
+        }
+        const float xc = v[q][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 w1 = *reinterpret_cast<const float4*>(w1s + q * C + cq * 16 + j * 4);
+            a1[j].x = fmaf(xc, w1.x, a1[j].x); a1[j].y = fmaf(xc, w1.y, a1[j].y); a1[j].z = fmaf(xc, w1.z, a1[j].z); a1[j].w = fmaf(xc, w1.w, a1[j].w);
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<float4*>(p.h1 + pix * C + cq * 16 + j * 4) = a3[j];
+            *reinterpret_cast<float4*>(p.res + pix * C + cq * 16 + j * 4) = a1[j];
+        }
+    }
+    if (p.gn_stats) {          // GroupNorm partials of h1: 8 channels per group -> this thread feeds groups 2cq, 2cq+1
+        float gs[2], gq[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const float4 u = a3[2 * g], t = a3[2 * g + 1];
+            gs[g] = live ? ((u.x + u.y) + (u.z + u.w)) + ((t.x + t.y) + (t.z + t.w)) : 0.f;
+            gq[g] = live ? ((u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w)) + ((t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w)) : 0.f;
+        }
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) { gs[g] += __shfl_xor(gs[g], o); gq[g] += __shfl_xor(gq[g], o); }
+        }
+        if ((tid & 63) < 4) {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) { atomicAdd(&red[(2 * cq + g) * 2], gs[g]); atomicAdd(&red[(2 * cq + g) * 2 + 1], gq[g]); }
+        }
         __syncthreads();
-        const int g = (cq * 4) / (p.C / 8);
-        atomicAdd(&red[g * 2], (a3.x + a3.y) + (a3.z + a3.w));
-        atomicAdd(&red[g * 2 + 1], (a3.x * a3.x + a3.y * a3.y) + (a3.z * a3.z + a3.w * a3.w));
-        __syncthreads();
-        if (threadIdx.x < 16)
-            atomicAdd(p.gn_stats + (((long)b * 8 + (threadIdx.x >> 1)) * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * 2 + (threadIdx.x & 1), red[threadIdx.x]);
+        // a 64-pixel block never straddles two utterances when H*T is a multiple of 64 (T is)
+        if (tid < 16)
+            atomicAdd(p.gn_stats + (((long)b * 8 + (tid >> 1)) * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * 2 + (tid & 1), red[tid]);
     }
 }
 void launch_first_conv(const FirstConvP& p, hipStream_t st) {
-    const long total = (long)p.B * p.H * p.T * (p.C / 4);
-    if (p.planes == 3) hipLaunchKernelGGL(first_conv_kernel<3>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(first_conv_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    const long npix = (long)p.B * p.H * p.T;
+    const unsigned blocks = (unsigned)((npix + 63) / 64);
+    if (p.planes == 3) hipLaunchKernelGGL(first_conv_kernel<3>, dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(first_conv_kernel<2>, dim3(blocks), dim3(256), 0, st, p);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -59,7 +59,32 @@ __global__ __launch_bounds__(256 * WPS) void mfma_bf16_probe(float* out, int ite
     if (s == 123.456f) out[0] = s;
 }
 
+// ---- per-CU L2 streaming ceiling: NB workgroups of 512 threads each read the same `bytes` (hot in L2), 16 B per lane,
+// UNR independent loads in flight per wave
+template <int UNR>
+__global__ __launch_bounds__(512) void l2_stream_probe(const uint4* src, long n16, unsigned* out) {
+    const int tid = threadIdx.x;
+    uint4 acc = make_uint4(0, 0, 0, 0);
+    for (long i = tid; i < n16; i += 512 * UNR) {
+        uint4 v[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) v[u] = src[min(i + 512L * u, n16 - 1)];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) { acc.x ^= v[u].x; acc.y ^= v[u].y; acc.z ^= v[u].z; acc.w ^= v[u].w; }
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = acc.x;
+}
+
 int main() {
+    {
+        const long bytes = 1441792;   // the row chain's weights per workgroup
+        uint4* src; hipMalloc(&src, bytes); hipMemset(src, 1, bytes); unsigned* o; hipMalloc(&o, 4);
+        for (int nb : {1, 21, 84, 256}) {
+            char nm[80];
+            snprintf(nm, 80, "L2 stream 1.4 MB per wg, %d wgs, 8 loads/wave", nb); timeit(nm, 20, 0, (double)bytes * nb, [&] { hipLaunchKernelGGL(l2_stream_probe<8>, dim3(nb), dim3(512), 0, 0, src, bytes / 16, o); });
+            snprintf(nm, 80, "L2 stream 1.4 MB per wg, %d wgs, 32 loads/wave", nb); timeit(nm, 20, 0, (double)bytes * nb, [&] { hipLaunchKernelGGL(l2_stream_probe<32>, dim3(nb), dim3(512), 0, 0, src, bytes / 16, o); });
+        }
+    }
     {
         float* o; hipMalloc(&o, 4);
         const int it = 4096;
@@ -127,19 +152,6 @@ int main() {
         p.gn_stats = nullptr;
         snprintf(nm, 80, "  .. same, no GN atomics"); timeit(nm, 50, fl, by, [&] { launch_conv3x3_bf16(p, 0); });
         p.gn_stats = st;
-#ifdef DEX_TIMING
-        {
-            long long* dbg; hipMalloc(&dbg, 4096 * 8 * 8); hipMemset(dbg, 0, 4096 * 8 * 8);
-            p.dbg = dbg; launch_conv3x3_bf16(p, 0); hipDeviceSynchronize(); p.dbg = nullptr;
-            std::vector<long long> h(4096 * 8); hipMemcpy(h.data(), dbg, 4096 * 8 * 8, hipMemcpyDeviceToHost);
-            int nb = 0; long long t0 = 1LL << 62, te = 0;
-            for (int bl = 0; bl < 4096; ++bl) if (h[bl * 8 + 7]) { nb++; t0 = std::min(t0, h[bl * 8 + 7]); te = std::max(te, h[bl * 8 + 6]); }
-            printf("   blocks=%d span=%lld (10ns)\n", nb, te - t0);
-            for (int bl : {0, nb / 2, nb - 1}) { long long* d = &h[bl * 8];
-                printf("   blk %4d: start+%lld  [tap1] pre-barrier@%lld barrier=%lld issue=%lld mfma=%lld vmwait=%lld | to-epilogue@%lld epi=%lld\n", bl, d[7] - t0,
-                       d[0] - d[7], d[1] - d[0], d[2] - d[1], d[3] - d[2], d[4] - d[3], d[5] - d[7], d[6] - d[5]); }
-        }
-#endif
         IGemmP g{}; g.A = x; g.lda = c.Cin; g.a_bstride = npix * c.Cin; g.Hi = c.H; g.Wi = c.W; g.Cin = c.Cin; g.KH = 3; g.KW = 3; g.sh = g.sw = 1; g.off_h = g.off_w = -1;
         g.step_h = g.step_w = 1; g.Ho = c.H; g.Wo = c.W; g.W = w; g.Wbf = wb; g.N = c.Cout; g.K = 9 * c.Cin; g.ksplit = 1; g.groups = 1; g.bias = bias;
         g.C = y; g.ldc = c.Cout; g.c_bstride = npix * c.Cout; g.OHf = c.H; g.OWf = c.W; g.osh = g.osw = 1; g.gate_nstride = 1; g.B = B; g.mask_bstride = T;
@@ -159,6 +171,22 @@ int main() {
         const double fl = 2.0 * l.M * l.K * l.N, by = 4.0 * (l.M * l.K + l.M * l.N + l.K * l.N);
         snprintf(nm, 80, "linear bf16 M=%d K=%d N=%d", l.M, l.K, l.N); timeit(nm, 50, fl, by, [&] { launch_igemm(g, 1, 0); });
         snprintf(nm, 80, "linear fp32 M=%d K=%d N=%d", l.M, l.K, l.N); timeit(nm, 50, fl, by, [&] { launch_igemm(g, 0, 0); });
+    }
+    // ---- linear-attention context pass + merge at 80x512 (C=64): pixels per workgroup trade-off
+    {
+        const int npix = 40960, C = 64;
+        float* x = dalloc((size_t)npix * C, 1.0f);
+        unsigned short* wkv; hipMalloc(&wkv, 256 * C * 2); hipMemset(wkv, 0, 256 * C * 2);
+        float* pm = dalloc(4 * 320 * 32); float* ps = dalloc(4 * 320 * 32, 1.0f); float* pc = dalloc(4 * 320 * 1024);
+        float* wout = dalloc(C * 128, 0.1f); float* g = dalloc(1, 1.0f); void* w2; hipMalloc(&w2, C * 128 * 2);
+        for (int nsub : {1, 2, 4}) {
+            const int nblk = (npix + 128 * nsub - 1) / (128 * nsub);
+            LinKvCtxP k{x, C, 0, (long)npix * C, npix, C, wkv, nsub, nblk, pm, ps, pc, 1};
+            LinMergeP mg{pm, ps, pc, nblk, wout, g, C, w2, 1};
+            char nm[80];
+            snprintf(nm, 80, "linattn kvctx 80x512 nsub=%d (%d wgs)", nsub, nblk); timeit(nm, 50, 2.0 * npix * (256.0 * C + 128 * 32), 4.0 * npix * C, [&] { launch_linattn_kvctx(k, 0); });
+            snprintf(nm, 80, "linattn merge nblk=%d", nblk); timeit(nm, 50, 0, 4.0 * nblk * 4 * 1088, [&] { launch_linattn_merge(mg, 0); });
+        }
     }
     // ---- DiT row chain (M=650): weights hot in L2 (back-to-back) vs evicted by a 64 MB sweep between launches
     {
