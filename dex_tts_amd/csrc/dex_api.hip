@@ -693,7 +693,9 @@ struct Runner {
     }
 
     // ResnetBlock (diffusion.py:66-71).  X: unmasked input view; out = block2(...) + res_conv(x*mask) (unmasked).
-    void resblock(const ResW& w, const StageBuf& s, const TD& X, const float* tadd, float* out, bool first_layer) {
+    // tail != null: the final GN-apply + Mish + shortcut is NOT launched; its operands are recorded in *tail and the
+    // consumer (linattn_kvctx) applies it while loading and writes `out`.
+    void resblock(const ResW& w, const StageBuf& s, const TD& X, const float* tadd, float* out, bool first_layer, LinKvCtxP* tail = nullptr) {
         const long npix = s.npix;
         const float* resptr; int ldres; long resb; bool under = false;
         float* st1 = nullptr;
@@ -729,11 +731,18 @@ struct Runner {
             TD A1{s.a1, w.cout, 0, w.cout};
             conv3x3("conv3x3", A1, s.H, s.W, s.mask_ws, false, w.w2, w.b2, w.cout, s.h2, st2);
         }
+        if (tail) {
+            tail->H2 = s.h2; tail->gn_stats = st2; tail->gamma = w.g2; tail->beta = w.be2;
+            tail->res = resptr; tail->ldres = ldres; tail->resb = resb; tail->res_under_mask = under ? 1 : 0;
+            tail->mask = mask; tail->mask_ws = s.mask_ws; tail->mask_bstride = P.d.T; tail->W = s.W; tail->Xout = out;
+            return;
+        }
         gn_apply(s.h2, w.cout, npix, s.W, s.mask_ws, st2, w.g2, w.be2, nullptr, resptr, ldres, resb, under, out);
     }
 
     // Residual(Rezero(LinearAttention)) (diffusion.py:74-102)
-    void linattn(const LinW& w, const StageBuf& s, const TD& X, float* out, int ldo, int ocoff) {
+    bool linattn_fused(int C) const { return x->precision == DEX_PREC_BF16 && (C == 64 || C == 128); }
+    void linattn(const LinW& w, const StageBuf& s, const TD& X, float* out, int ldo, int ocoff, const LinKvCtxP* tail = nullptr) {
         const long npix = s.npix; const int B = P.d.B;
         if (x->precision == DEX_PREC_BF16 && (X.C == 64 || X.C == 128)) {
             // fused: y = x + W2 (Wq x) + g*b  with  W2 = g Wout blockdiag(ctx^T)   (linattn_fused.hip)
@@ -741,8 +750,11 @@ struct Runner {
             // measured at 80x512, B=1: 320 / 160 / 80 workgroups -> context 19.9 / 13.7 / 19.4 us, merge 8.7 / 6.1 / 4.7 us
             while (nsub < 4 && (npix + 128 * nsub - 1) / (128 * nsub) * B > 192) nsub *= 2;
             const int nblk = (int)((npix + 128L * nsub - 1) / (128L * nsub));
-            LinKvCtxP k{X.p, X.ld, X.coff, npix * X.ld, (int)npix, X.C, w.wkv_bf16, nsub, nblk, s.pm, s.ps, s.pc, B};
-            run("linattn_kvctx", 2.0 * npix * B * (256.0 * X.C + 128 * 32), 4.0 * npix * X.C * B, [&] { launch_linattn_kvctx(k, st); });
+            LinKvCtxP k{};
+            if (tail) k = *tail;
+            k.X = X.p; k.ldx = X.ld; k.x_coff = X.coff; k.xb = npix * X.ld; k.npix = (int)npix; k.C = X.C; k.Wkv = w.wkv_bf16;
+            k.nsub = nsub; k.nblk = nblk; k.part_m = s.pm; k.part_s = s.ps; k.part_c = s.pc; k.B = B;
+            run("linattn_kvctx", 2.0 * npix * B * (256.0 * X.C + 128 * 32), (tail ? 12.0 : 4.0) * npix * X.C * B, [&] { launch_linattn_kvctx(k, st); });
             LinMergeP mg{s.pm, s.ps, s.pc, nblk, w.wout_raw, w.g, X.C, s.mbf, B};
             run("linattn_merge", 2.0 * 128 * 32 * X.C * B, 4.0 * nblk * 4 * 1088 * B, [&] { launch_linattn_merge(mg, st); });
             LinOut2P o{X.p, X.ld, X.coff, npix * X.ld, (int)npix, X.C, w.wq_bf16, s.mbf, w.bias_eff, out, ldo, ocoff, npix * ldo, B};
@@ -924,9 +936,11 @@ struct Runner {
             const StageBuf& s = P.down[i];
             resblock(x->down_res[i][0], s, cur, P.tadd_down[2 * i], s.r0out, i == 0);
             TD r0{s.r0out, s.C, 0, s.C};
-            resblock(x->down_res[i][1], s, r0, P.tadd_down[2 * i + 1], s.r1out, false);
+            LinKvCtxP tail{};
+            const bool defer = linattn_fused(s.C);
+            resblock(x->down_res[i][1], s, r0, P.tadd_down[2 * i + 1], s.r1out, false, defer ? &tail : nullptr);
             TD r1{s.r1out, s.C, 0, s.C};
-            linattn(x->down_lin[i], s, r1, s.attn_out, s.attn_ld, s.attn_coff);
+            linattn(x->down_lin[i], s, r1, s.attn_out, s.attn_ld, s.attn_coff, defer ? &tail : nullptr);
             char nm[16]; snprintf(nm, sizeof nm, "down%d", i);
             tap(nm, s.attn_out + s.attn_coff, B * s.npix, s.C, s.attn_ld);
             if (i < ns - 1) {
@@ -957,9 +971,11 @@ struct Runner {
             TD X{P.cat[j], 2 * stage_dim(c, i), 0, 2 * stage_dim(c, i)};
             resblock(x->up_res[j][0], s, X, P.tadd_up[2 * j], s.r0out, false);
             TD r0{s.r0out, s.C, 0, s.C};
-            resblock(x->up_res[j][1], s, r0, P.tadd_up[2 * j + 1], s.r1out, false);
+            LinKvCtxP tail{};
+            const bool defer = linattn_fused(s.C);
+            resblock(x->up_res[j][1], s, r0, P.tadd_up[2 * j + 1], s.r1out, false, defer ? &tail : nullptr);
             TD r1{s.r1out, s.C, 0, s.C};
-            linattn(x->up_lin[j], s, r1, s.attn_out, s.C, 0);
+            linattn(x->up_lin[j], s, r1, s.attn_out, s.C, 0, defer ? &tail : nullptr);
             char nm[16]; snprintf(nm, sizeof nm, "up%d", j);
             tap(nm, s.attn_out, B * s.npix, s.C, s.C);
             // Upsample = ConvTranspose2d(4,2,1) on x*mask: four parity sub-convolutions with 2x2 taps

@@ -113,7 +113,13 @@ void launch_linattn_combine(const LinAttnCombineP& p, hipStream_t st);
 
 // Fused linear attention for the bf16 mode (linattn_fused.hip): k/v + online softmax + ctx without q,k,v in HBM
 struct LinKvCtxP { const float* X; int ldx; int x_coff; long xb; int npix; int C; const void* Wkv; int nsub; int nblk;
-                   float* part_m; float* part_s; float* part_c; int B; };
+                   float* part_m; float* part_s; float* part_c; int B;
+                   // optional fused tail of the preceding ResnetBlock (H2 != null): x = mask*(Mish(GN(H2)) [+ res]) [+ res]
+                   // is computed while the tile is loaded, written to Xout ([npix][C]) for the later consumers, and X is
+                   // not read (diffusion.py:49,67-71).  gn_stats: slot-spread partials of H2; W/mask_ws: mask column map.
+                   const float* H2; const float* gn_stats; const float* gamma; const float* beta;
+                   const float* res; int ldres; long resb; int res_under_mask;
+                   const float* mask; int mask_ws; long mask_bstride; int W; float* Xout; };
 void launch_linattn_kvctx(const LinKvCtxP& p, hipStream_t st);
 struct LinMergeP { const float* part_m; const float* part_s; const float* part_c; int nblk;
                    const float* Wout; const float* g; int C; void* W2; int B; };       // Wout fp32 [C][128]

@@ -24,7 +24,7 @@ union LFrag { uint4 u; bf16x8 v; };
 
 // grid (nblk, B); 256 threads; each wave owns `nsub` consecutive 32-pixel sub-tiles.
 // part_m/part_s: [B][4][nblk][32], part_c: [B][4][nblk][32 d][32 e]   (same layout linattn_combine reads)
-template <int C>
+template <int C, bool PRO>
 __global__ __launch_bounds__(256) void linattn_kvctx_kernel(const LinKvCtxP p) {
     constexpr int LDW = C + 8, KS = C / 16;
     extern __shared__ __attribute__((aligned(16))) u16 smem_la[];
@@ -46,7 +46,10 @@ __global__ __launch_bounds__(256) void linattn_kvctx_kernel(const LinKvCtxP p) {
             *reinterpret_cast<uint4*>(Ws + (it / (C / 8)) * LDW + (it % (C / 8)) * 8) = wr[j];
         }
     }
-    const float* X = p.X + (long)b * p.xb + p.x_coff;
+    const float* X = PRO ? p.H2 + (long)b * p.npix * C : p.X + (long)b * p.xb + p.x_coff;
+    const int ldx = PRO ? C : p.ldx;
+    const float* R = (PRO && p.res) ? p.res + (long)b * p.resb : nullptr;
+    const float* mrow = PRO ? p.mask + (long)b * p.mask_bstride : nullptr;
     const int px_base = (blk * 4 + wave) * p.nsub * 32;
 
     f32x16 ctxT[4];
@@ -58,20 +61,88 @@ __global__ __launch_bounds__(256) void linattn_kvctx_kernel(const LinKvCtxP p) {
         for (int r = 0; r < 16; ++r) ctxT[h][r] = 0.f;
     }
     // x rows of the first sub-tile go out before the barrier (beside the weight loads); later sub-tiles are
-    // prefetched one iteration ahead
-    float4 xa[KS], xc[KS];
+    // prefetched one iteration ahead.  PRO: the rows are the raw conv output + the residual, turned into x below.
+    float4 xa[KS], xc[KS], ra[PRO ? KS : 1], rc[PRO ? KS : 1];
+    float mkv = 1.f;
     {
-        const float* xr = X + (long)min(px_base + i, p.npix - 1) * p.ldx + hh * 8;
+        const int pxr = min(px_base + i, p.npix - 1);
+        const float* xr = X + (long)pxr * ldx + hh * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             xa[ks] = *reinterpret_cast<const float4*>(xr + ks * 16);
             xc[ks] = *reinterpret_cast<const float4*>(xr + ks * 16 + 4);
         }
+        if constexpr (PRO) {
+            if (R) {
+                const float* rr = R + (long)pxr * p.ldres + hh * 8;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    ra[ks] = *reinterpret_cast<const float4*>(rr + ks * 16);
+                    rc[ks] = *reinterpret_cast<const float4*>(rr + ks * 16 + 4);
+                }
+            }
+            mkv = mrow[(pxr % p.W) * p.mask_ws];
+        }
+    }
+    __shared__ float smean[8], srstd[8];
+    __shared__ __attribute__((aligned(16))) float gsc_s[PRO ? C : 4], gsh_s[PRO ? C : 4];   // GroupNorm folded to x*gsc + gsh per channel
+    if constexpr (PRO) {
+        {   // 8 groups x GN_SLOTS partials == 256 threads
+            const int g = tid / GN_SLOTS;
+            const float* src = p.gn_stats + (((long)b * 8 + g) * GN_SLOTS + (tid % GN_SLOTS)) * 2;
+            double s1 = (double)src[0], s2 = (double)src[1];
+            for (int o = 1; o < GN_SLOTS; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+            if ((tid % GN_SLOTS) == 0) {
+                const double n = (double)p.npix * (C / 8);
+                const double mean = s1 / n;
+                double var = s2 / n - mean * mean;
+                var = var < 0.0 ? 0.0 : var;
+                smean[g] = (float)mean;
+                srstd[g] = (float)(1.0 / sqrt(var + 1e-5));
+            }
+        }
     }
     __syncthreads();
+    if constexpr (PRO) {
+        if (tid < C) {
+            const float ga = p.gamma[tid] * srstd[tid / (C / 8)];
+            gsc_s[tid] = ga;
+            gsh_s[tid] = p.beta[tid] - smean[tid / (C / 8)] * ga;
+        }
+        __syncthreads();
+    }
     for (int sub = 0; sub < p.nsub; ++sub) {
         const int px0 = px_base + sub * 32;
         if (px0 >= p.npix) break;
+        if constexpr (PRO) {
+            // x = mask * (Mish(GN(h2)) + r)   (identity shortcut)   or   mask * Mish(GN(h2)) + r   (res_conv shortcut)
+            const bool under = p.res_under_mask != 0;
+            const bool live = px0 + i < p.npix;
+            float* xo = p.Xout + ((long)b * p.npix + min(px0 + i, p.npix - 1)) * C + hh * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                float v[8] = {xa[ks].x, xa[ks].y, xa[ks].z, xa[ks].w, xc[ks].x, xc[ks].y, xc[ks].z, xc[ks].w};
+                float r_[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                const float4 sc0 = *reinterpret_cast<const float4*>(gsc_s + ks * 16 + hh * 8), sc1 = *reinterpret_cast<const float4*>(gsc_s + ks * 16 + hh * 8 + 4);
+                const float4 sh0 = *reinterpret_cast<const float4*>(gsh_s + ks * 16 + hh * 8), sh1 = *reinterpret_cast<const float4*>(gsh_s + ks * 16 + hh * 8 + 4);
+                const float gsc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
+                const float gsh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
+                if (R) { r_[0] = ra[ks].x; r_[1] = ra[ks].y; r_[2] = ra[ks].z; r_[3] = ra[ks].w; r_[4] = rc[ks].x; r_[5] = rc[ks].y; r_[6] = rc[ks].z; r_[7] = rc[ks].w; }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float t = fmaf(v[j], gsc[j], gsh[j]);
+                    const float e = __expf(fminf(t, 20.f));
+                    const float n = e * (e + 2.f);
+                    const float y = t * (n / (n + 2.f));                 // Mish
+                    v[j] = under ? (y + r_[j]) * mkv : fmaf(y, mkv, r_[j]);
+                }
+                xa[ks] = make_float4(v[0], v[1], v[2], v[3]); xc[ks] = make_float4(v[4], v[5], v[6], v[7]);
+                if (live) {
+                    *reinterpret_cast<float4*>(xo + ks * 16) = xa[ks];
+                    *reinterpret_cast<float4*>(xo + ks * 16 + 4) = xc[ks];
+                }
+            }
+        }
         // A fragments of x: lane (pixel i, half hh) holds x[px][ks*16 + hh*8 .. +8]
         LFrag af[KS];
 #pragma unroll
@@ -80,11 +151,23 @@ __global__ __launch_bounds__(256) void linattn_kvctx_kernel(const LinKvCtxP p) {
             af[ks].u.z = pack2_bf16(xc[ks].x, xc[ks].y); af[ks].u.w = pack2_bf16(xc[ks].z, xc[ks].w);
         }
         if (sub + 1 < p.nsub) {
-            const float* xr = X + (long)min(px0 + 32 + i, p.npix - 1) * p.ldx + hh * 8;
+            const int pxr = min(px0 + 32 + i, p.npix - 1);
+            const float* xr = X + (long)pxr * ldx + hh * 8;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 xa[ks] = *reinterpret_cast<const float4*>(xr + ks * 16);
                 xc[ks] = *reinterpret_cast<const float4*>(xr + ks * 16 + 4);
+            }
+            if constexpr (PRO) {
+                if (R) {
+                    const float* rr = R + (long)pxr * p.ldres + hh * 8;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        ra[ks] = *reinterpret_cast<const float4*>(rr + ks * 16);
+                        rc[ks] = *reinterpret_cast<const float4*>(rr + ks * 16 + 4);
+                    }
+                }
+                mkv = mrow[(pxr % p.W) * p.mask_ws];
             }
         }
         f32x16 kv[8];
@@ -170,13 +253,21 @@ void launch_linattn_kvctx(const LinKvCtxP& p, hipStream_t st) {
     const size_t lds = lds_w > lds_m ? lds_w : lds_m;
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_kvctx_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_kvctx_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_kvctx_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_kvctx_kernel<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_kvctx_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_kvctx_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr = true;
     }
     dim3 grid(p.nblk, p.B);
-    if (p.C == 64) hipLaunchKernelGGL(linattn_kvctx_kernel<64>, grid, dim3(256), lds, st, p);
-    else hipLaunchKernelGGL(linattn_kvctx_kernel<128>, grid, dim3(256), lds, st, p);
+    const bool pro = p.H2 != nullptr;
+    if (p.C == 64) {
+        if (pro) hipLaunchKernelGGL((linattn_kvctx_kernel<64, true>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((linattn_kvctx_kernel<64, false>), grid, dim3(256), lds, st, p);
+    } else {
+        if (pro) hipLaunchKernelGGL((linattn_kvctx_kernel<128, true>), grid, dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((linattn_kvctx_kernel<128, false>), grid, dim3(256), lds, st, p);
+    }
 }
 
 // grid (4 heads, B, 32 rows d): merge the workgroup partials of ONE context row -> normalised ctx[b][h][d][:], then
