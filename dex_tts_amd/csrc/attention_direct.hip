@@ -1,9 +1,12 @@
 // attention_direct.hip — softmax attention of the DiT blocks (timm Attention core, reference model/dit.py:73-76)
 // on operands the producer already laid out for the matrix cores (bf16-MFMA mode, 2 heads x 128).
 //
-// The row-chain kernel (dit_rowchain.hip) writes q (pre-scaled), k as bf16 [B][2][N][128] and v TRANSPOSED as bf16
-// [B][2][128][Npad] with the key index bits 2/3 swapped inside each 32-key block.  With those layouts every MFMA
-// operand of the transposed flash formulation is one 16-byte global load per lane:
+// The row-chain kernel (dit_rowchain.hip) writes q (pre-scaled), k and v^T as bf16 in MFMA FRAGMENT order per
+// (batch, head): q/k as [32-row tile][K-step ks][lane = hh*32 + row][8 d], v^T as [32-key tile][d tile t][K-step k2]
+// [lane = hh*32 + d][8 key positions], key positions with index bits 2/3 swapped inside each 32-key block.  Every
+// MFMA operand of the transposed flash formulation is then one 16-byte load per lane and every wave-level load
+// instruction reads 1 KB of CONTIGUOUS memory (the first version used row-major q/k: each instruction touched 32
+// rows x 32 B and L1 lines were evicted between the 4 instructions that share them):
 //     S^T[key][query] = K Q^T      A = K rows  (lane = key,  8 consecutive d)     B = Q rows (lane = query)
 //     O^T[d][query]  += V^T P^T    A = V^T rows (lane = d,   8 consecutive key positions)
 //                                  B = P^T, taken from the S^T accumulator registers in place: a lane holds keys
@@ -37,9 +40,9 @@ __global__ __launch_bounds__(NWD * 64) void attn_direct_kernel(const AttnDirectP
     const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z / ksplit, sp = blockIdx.z % ksplit;
     const int N = p.N;
     const long hb = (long)b * 2 + h;
-    const u16* Qg = reinterpret_cast<const u16*>(p.Qh) + hb * N * HD;
-    const u16* Kg = reinterpret_cast<const u16*>(p.Kh) + hb * N * HD;
-    const u16* Vg = reinterpret_cast<const u16*>(p.Vt) + hb * HD * p.Npad;
+    const uint4* Qg = reinterpret_cast<const uint4*>(p.Qh) + hb * p.Npad * (HD / 8) + lane;    // fragment-tiled: [tile][ks][lane]
+    const uint4* Kg = reinterpret_cast<const uint4*>(p.Kh) + hb * p.Npad * (HD / 8) + lane;
+    const uint4* Vg = reinterpret_cast<const uint4*>(p.Vt) + hb * p.Npad * (HD / 8) + lane;    // [tile][t][k2][lane]
 #ifdef DEX_TIMING
     long long tst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     tst[0] = wall_clock64();
@@ -51,19 +54,19 @@ __global__ __launch_bounds__(NWD * 64) void attn_direct_kernel(const AttnDirectP
     // all first-round loads back to back: Q fragments, then this wave's first K and V^T tiles
     DFrag qf[8], kf[8], vf[4][2];
     {
-        const u16* qp = Qg + (long)min(q0 + i, N - 1) * HD + hh * 8;
+        const uint4* qp = Qg + (long)(q0 >> 5) * 8 * 64;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) qf[ks].u = *reinterpret_cast<const uint4*>(qp + ks * 16);
+        for (int ks = 0; ks < 8; ++ks) qf[ks].u = qp[ks * 64];
     }
     if (kt < t_hi) {
-        const u16* kp = Kg + (long)min(kt * 32 + i, N - 1) * HD + hh * 8;
+        const uint4* kp = Kg + (long)kt * 8 * 64;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) kf[ks].u = *reinterpret_cast<const uint4*>(kp + ks * 16);
-        const u16* vp = Vg + (long)i * p.Npad + kt * 32 + hh * 8;
+        for (int ks = 0; ks < 8; ++ks) kf[ks].u = kp[ks * 64];
+        const uint4* vp = Vg + (long)kt * 8 * 64;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int k2 = 0; k2 < 2; ++k2) vf[t][k2].u = *reinterpret_cast<const uint4*>(vp + (long)t * 32 * p.Npad + k2 * 16);
+            for (int k2 = 0; k2 < 2; ++k2) vf[t][k2].u = vp[(t * 2 + k2) * 64];
     }
     f32x16 o[4];
 #pragma unroll
@@ -82,9 +85,9 @@ __global__ __launch_bounds__(NWD * 64) void attn_direct_kernel(const AttnDirectP
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks].v, qf[ks].v, s, 0, 0, 0);
         if (kn < t_hi) {                                   // next K tile into the registers just consumed
-            const u16* kp = Kg + (long)min(kn * 32 + i, N - 1) * HD + hh * 8;
+            const uint4* kp = Kg + (long)kn * 8 * 64;
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) kf[ks].u = *reinterpret_cast<const uint4*>(kp + ks * 16);
+            for (int ks = 0; ks < 8; ++ks) kf[ks].u = kp[ks * 64];
         }
         float mx = -INFINITY;
 #pragma unroll
@@ -114,11 +117,11 @@ __global__ __launch_bounds__(NWD * 64) void attn_direct_kernel(const AttnDirectP
             for (int t = 0; t < 4; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[t][k2].v, pb.v, o[t], 0, 0, 0);
         }
         if (kn < t_hi) {                                   // next V^T tile
-            const u16* vp = Vg + (long)i * p.Npad + kn * 32 + hh * 8;
+            const uint4* vp = Vg + (long)kn * 8 * 64;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int k2 = 0; k2 < 2; ++k2) vf[t][k2].u = *reinterpret_cast<const uint4*>(vp + (long)t * 32 * p.Npad + k2 * 16);
+                for (int k2 = 0; k2 < 2; ++k2) vf[t][k2].u = vp[(t * 2 + k2) * 64];
         }
         kt = kn;
     }
@@ -174,12 +177,114 @@ __global__ __launch_bounds__(NWD * 64) void attn_direct_kernel(const AttnDirectP
 #endif
 }
 
+// ---- batch regime: 4 waves = 4 consecutive 32-query tiles of one (batch, head), each walking ALL key tiles (no key
+// split, no partial merge).  The K and V^T tiles are shared through a double-buffered LDS image that keeps the
+// fragment order of the global layout: the cooperative copy is 1 KB-contiguous both ways and every ds_read_b128 of a
+// wave is conflict-free.  The running-max rescale of O is skipped (wave-uniform test) whenever no lane's maximum moved.
+__global__ __launch_bounds__(256) void attn_direct_full_kernel(const AttnDirectP p) {
+    __shared__ __attribute__((aligned(16))) uint4 kvS[2][1024];        // [buf][K: ks*64+lane | 512 + V: (t*2+k2)*64+lane]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int N = p.N;
+    const int ntiles = (N + 31) / 32;
+    const int qt = min(blockIdx.x * 4 + wave, ntiles - 1);            // surplus waves shadow the last tile (no store)
+    const bool live_wave = blockIdx.x * 4 + wave < ntiles;
+    const int q0 = qt * 32;
+    const long hb = (long)b * 2 + h;
+    const uint4* Qg = reinterpret_cast<const uint4*>(p.Qh) + hb * p.Npad * (HD / 8) + lane;
+    const uint4* Kt = reinterpret_cast<const uint4*>(p.Kh) + hb * p.Npad * (HD / 8) + tid;   // cooperative copy: thread-linear
+    const uint4* Vt = reinterpret_cast<const uint4*>(p.Vt) + hb * p.Npad * (HD / 8) + tid;
+    DFrag qf[8];
+    {
+        const uint4* qp = Qg + (long)qt * 8 * 64;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) qf[ks].u = qp[ks * 64];
+    }
+    uint4 g0 = Kt[0], g1 = Kt[256], g2 = Vt[0], g3 = Vt[256];
+    f32x16 o[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    kvS[0][tid] = g0; kvS[0][tid + 256] = g1; kvS[0][tid + 512] = g2; kvS[0][tid + 768] = g3;
+    lds_barrier();
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int k0 = kt * 32, kn = kt + 1;
+        const uint4* cur = kvS[kt & 1];
+        if (kn < ntiles) { g0 = Kt[(long)kn * 512]; g1 = Kt[(long)kn * 512 + 256]; g2 = Vt[(long)kn * 512]; g3 = Vt[(long)kn * 512 + 256]; }
+        f32x16 s;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            DFrag kf; kf.u = cur[ks * 64 + lane];
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf.v, qf[ks].v, s, 0, 0, 0);
+        }
+        float mx = -INFINITY;
+        if (k0 + 32 > N) {                                 // only the last tile has keys to mask
+#pragma unroll
+            for (int r = 0; r < 16; ++r) if (k0 + (r & 3) + 8 * (r >> 2) + 4 * hh >= N) s[r] = -INFINITY;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0) {           // some lane's running maximum moves: rescale
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __expf(m_run - m_new);
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        }
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = __expf(s[r] - m_run); psum += s[r]; }
+        l_run += psum;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            DFrag pb;
+            pb.u.x = pack2_bf16(s[8 * k2 + 0], s[8 * k2 + 1]); pb.u.y = pack2_bf16(s[8 * k2 + 2], s[8 * k2 + 3]);
+            pb.u.z = pack2_bf16(s[8 * k2 + 4], s[8 * k2 + 5]); pb.u.w = pack2_bf16(s[8 * k2 + 6], s[8 * k2 + 7]);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                DFrag vf; vf.u = cur[512 + (t * 2 + k2) * 64 + lane];
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pb.v, o[t], 0, 0, 0);
+            }
+        }
+        if (kn < ntiles) {
+            uint4* nxt = kvS[kn & 1];
+            nxt[tid] = g0; nxt[tid + 256] = g1; nxt[tid + 512] = g2; nxt[tid + 768] = g3;
+        }
+        lds_barrier();                                     // next buffer visible; everyone is done with `cur`
+    }
+    l_run += __shfl_xor(l_run, 32);
+    if (live_wave && q0 + i < N) {
+        const float inv = 1.f / l_run;
+        float* op = p.O + ((long)b * N + q0 + i) * (2 * HD) + h * HD + 4 * hh;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq)
+                *reinterpret_cast<float4*>(op + t * 32 + 8 * rq) =
+                    make_float4(o[t][rq * 4 + 0] * inv, o[t][rq * 4 + 1] * inv, o[t][rq * 4 + 2] * inv, o[t][rq * 4 + 3] * inv);
+    }
+}
+
 void launch_attention_direct(const AttnDirectP& p, hipStream_t st) {
     const size_t lds = (size_t)(NWD * 32 * O_LD + NWD * 64) * sizeof(float);
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_direct_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
+    }
+    if (p.ksplit <= 1 && (long)((p.N + 31) / 32) * 2 * p.B >= 1024) {
+        dim3 grid(((p.N + 31) / 32 + 3) / 4, 2, p.B);
+        hipLaunchKernelGGL(attn_direct_full_kernel, grid, dim3(256), 0, st, p);
+        return;
     }
     dim3 grid((p.N + 31) / 32, 2, p.B * (p.ksplit > 1 ? p.ksplit : 1));
     hipLaunchKernelGGL(attn_direct_kernel, grid, dim3(NWD * 64), lds, st, p);

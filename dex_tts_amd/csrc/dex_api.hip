@@ -588,7 +588,8 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
     P.pe0 = A.f(tok * mid); P.emb = A.f(tok * hid); P.pos_part = A.f(tok * hid * POS_SPLIT); P.tok = A.f(tok * hid);
     P.xn = A.f(tok * hid); P.qkv = A.f(tok * 3 * hid); P.ao = A.f(tok * hid * ATT_KSPLIT_MAX); P.att_ml = A.f(tok * c.dit_heads * 2 * ATT_KSPLIT_MAX);
     P.Npad = (P.N + 31) / 32 * 32; P.vt_bytes = (size_t)B * hid * P.Npad * 2;
-    P.qh = A.take(tok * hid * 2); P.kh = A.take(tok * hid * 2); P.vt = A.take(P.vt_bytes); P.hmlp = A.f(tok * mlp_hidden(c));
+    P.qh = A.take(P.vt_bytes); P.kh = A.take(P.vt_bytes); P.vt = A.take(P.vt_bytes);    // all three padded to Npad rows
+    P.hmlp = A.f(tok * mlp_hidden(c));
     P.dbg_tok = A.f(tok * hid * (c.dit_depth + 1));
     P.tv_keys = P.tv_K = P.tv_V = P.tv_q = P.tv_ao = P.tv_out = P.tiv_out = P.tv_weff = P.tv_beff = nullptr;
     P.tv_stats = P.tiv_stats = nullptr;

@@ -103,8 +103,9 @@ __device__ __forceinline__ void ln_to_A(const float* X1, u16* As, const float* s
 }
 
 // One 32x32 tile of the next block's qkv projection -> the attention kernel's operand layouts (attention_direct.hip):
-//   q (pre-scaled) and k: bf16 [B][2 heads][N][128];   v: transposed bf16 [B][2][128][Npad], key index with bits 2/3
-//   swapped inside each 32-key block (the order in which a P^T accumulator lane holds its keys).
+//   q (pre-scaled), k and v^T as bf16 in MFMA fragment order per (batch, head), rows padded to Npad (see
+//   attention_direct.hip); v^T key positions have index bits 2/3 swapped inside each 32-key block (the order in
+//   which a P^T accumulator lane holds its keys).
 __device__ __forceinline__ void store_qkv_tile(const DitChainP& p, const f32x16& acc, int nt, float bias, int m0, int lane) {
     const int i = lane & 31, hh = lane >> 5;
     const int kind = nt >> 3, head = (nt >> 2) & 1, d = (nt & 3) * 32 + i;
@@ -118,10 +119,16 @@ __device__ __forceinline__ void store_qkv_tile(const DitChainP& p, const f32x16&
         int n = n0 + row, b = b0;
         if (n >= N) { n -= N; ++b; }
         const float v = acc[r] + bias;
-        const long hb = (long)b * 2 + head;
-        if (kind == 0) Qh[(hb * N + n) * 128 + d] = (u16)(pack2_bf16(v * p.qscale, 0.f) & 0xffffu);
-        else if (kind == 1) Kh[(hb * N + n) * 128 + d] = (u16)(pack2_bf16(v, 0.f) & 0xffffu);
-        else Vt[(hb * 128 + d) * p.Npad + ((n & ~12) | ((n & 4) << 1) | ((n & 8) >> 1))] = (u16)(pack2_bf16(v, 0.f) & 0xffffu);
+        const long hb = ((long)b * 2 + head) * p.Npad * 128;
+        if (kind < 2) {       // q / k: [tile n/32][ks = d/16][lane = (d/8 & 1)*32 + n%32][d%8]
+            const long o = hb + ((((long)(n >> 5) * 8 + (d >> 4)) * 64 + ((d >> 3) & 1) * 32 + (n & 31)) << 3) + (d & 7);
+            if (kind == 0) Qh[o] = (u16)(pack2_bf16(v * p.qscale, 0.f) & 0xffffu);
+            else Kh[o] = (u16)(pack2_bf16(v, 0.f) & 0xffffu);
+        } else {              // v^T: [tile pos/32][t = d/32][k2 = pos/16 & 1][lane = (pos/8 & 1)*32 + d%32][pos%8]
+            const int pos = (n & ~12) | ((n & 4) << 1) | ((n & 8) >> 1);
+            const long o = hb + (((((long)(pos >> 5) * 4 + (d >> 5)) * 2 + ((pos >> 4) & 1)) * 64 + ((pos >> 3) & 1) * 32 + (d & 31)) << 3) + (pos & 7);
+            Vt[o] = (u16)(pack2_bf16(v, 0.f) & 0xffffu);
+        }
     }
 }
 

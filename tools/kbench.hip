@@ -172,6 +172,22 @@ int main() {
         snprintf(nm, 80, "linear bf16 M=%d K=%d N=%d", l.M, l.K, l.N); timeit(nm, 50, fl, by, [&] { launch_igemm(g, 1, 0); });
         snprintf(nm, 80, "linear fp32 M=%d K=%d N=%d", l.M, l.K, l.N); timeit(nm, 50, fl, by, [&] { launch_igemm(g, 0, 0); });
     }
+    // ---- DiT attention on fragment-tiled bf16 operands: batch regime (shared-KV kernel) and key-split regime
+    {
+        struct AC { int B, N, ks; };
+        for (AC c : {AC{32, 1300, 1}, AC{32, 650, 1}, AC{1, 650, 3}, AC{1, 2580, 4}}) {
+            const int Npad = (c.N + 31) / 32 * 32;
+            const size_t el = (size_t)c.B * 2 * Npad * 128;
+            unsigned short *q, *k, *v; hipMalloc(&q, el * 2); hipMalloc(&k, el * 2); hipMalloc(&v, el * 2);
+            std::vector<unsigned short> hbuf(el);
+            for (size_t i = 0; i < el; ++i) hbuf[i] = (unsigned short)(0x3c00 + ((i * 2654435761u) >> 20 & 0x1ff) - ((i & 1) ? 0 : 0x8000));   // ~ +-0.01..0.03
+            hipMemcpy(q, hbuf.data(), el * 2, hipMemcpyHostToDevice); hipMemcpy(k, hbuf.data(), el * 2, hipMemcpyHostToDevice); hipMemcpy(v, hbuf.data(), el * 2, hipMemcpyHostToDevice);
+            float* O = dalloc((size_t)c.B * c.N * 256 * c.ks); float* ml = dalloc((size_t)c.B * c.N * 4 * c.ks + 16);
+            AttnDirectP a{q, k, v, c.N, Npad, c.B, O, (long)c.B * c.N * 256, c.ks > 1 ? ml : nullptr, c.ks, nullptr};
+            char nm[80]; snprintf(nm, 80, "attention direct bf16 B=%d N=%d ksplit=%d", c.B, c.N, c.ks);
+            timeit(nm, 20, 4.0 * c.B * c.N * (double)c.N * 256, 2.0 * 3 * el + 4.0 * c.B * c.N * 256 * c.ks, [&] { launch_attention_direct(a, 0); });
+        }
+    }
     // ---- linear-attention context pass + merge at 80x512 (C=64): pixels per workgroup trade-off
     {
         const int npix = 40960, C = 64;
@@ -195,7 +211,7 @@ int main() {
         unsigned short *Wp, *W1, *W2, *Wq, *qh, *kh, *vt;
         hipMalloc(&Wp, 256 * 256 * 2); hipMalloc(&W1, 256 * 512 * 2); hipMalloc(&W2, 512 * 256 * 2); hipMalloc(&Wq, 256 * 768 * 2);
         hipMemset(Wp, 0, 256 * 256 * 2); hipMemset(W1, 0, 256 * 512 * 2); hipMemset(W2, 0, 512 * 256 * 2); hipMemset(Wq, 0, 256 * 768 * 2);
-        hipMalloc(&qh, M * 256 * 2); hipMalloc(&kh, M * 256 * 2); hipMalloc(&vt, 672 * 256 * 2);
+        hipMalloc(&qh, 672 * 256 * 2); hipMalloc(&kh, 672 * 256 * 2); hipMalloc(&vt, 672 * 256 * 2);
         float* bias = dalloc(768, 0.1f); float* ada = dalloc(6 * 256, 0.1f);
         DitChainP c{}; c.O = O; c.ksplit = 3; c.o_sstride = (long)M * 256; c.ml = ml; c.heads = 2; c.rows_per_batch = M; c.X = X;
         c.Wp = Wp; c.W1 = W1; c.W2 = W2; c.Wq = Wq; c.bp = bias; c.b1 = bias; c.b2 = bias; c.bq = bias; c.ada = ada;
