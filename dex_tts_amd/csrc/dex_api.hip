@@ -805,7 +805,8 @@ struct Runner {
             DitChainP ch{};
             if (chain) {
                 ch.ksplit = 0; ch.heads = c.dit_heads; ch.rows_per_batch = N; ch.X = P.tok; ch.ada = ada; ch.step = sp; ch.M = B * N;
-                ch.Qh = P.qh; ch.Kh = P.kh; ch.Vt = P.vt; ch.Npad = P.Npad; ch.qscale = scale;
+                ch.Qh = P.qh; ch.Kh = P.kh; ch.Vt = P.vt; ch.Npad = P.Npad;
+                ch.qscale = scale * 1.4426950408889634f;      // log2(e) folded in: the attention kernels use exp2
             }
             if (chain && k == 0) {                                   // first block: LN + modulate + qkv only
                 ch.qkv_only = 1; ch.Wq = x->frag_of.at(w.wqkv); ch.bq = w.bqkv;

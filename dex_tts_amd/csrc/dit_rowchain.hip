@@ -188,7 +188,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(src + q * 64);
         } else {
-            // merge the key-split attention partials: O = sum_s w_s O_s / sum_s w_s,  w_s = l_s exp(m_s - max m)
+            // merge the key-split attention partials: O = sum_s w_s O_s / sum_s w_s,  w_s = l_s 2^(m_s - max m)
             // (column block q belongs to head q / 2: head_dim 128)
             const int bb = m / p.rows_per_batch, n = m - bb * p.rows_per_batch;
             const int nbat = M / p.rows_per_batch;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
 #pragma unroll
                 for (int s_ = 0; s_ < 4; ++s_) {
                     w[s_] = 0.f;
-                    if (s_ < p.ksplit) { w[s_] = st[s_][hd].y * __expf(st[s_][hd].x - mx); wsum += w[s_]; }
+                    if (s_ < p.ksplit) { w[s_] = st[s_][hd].y * exp2f(st[s_][hd].x - mx); wsum += w[s_]; }   // log2-domain maxima
                 }
                 const float inv = 1.f / wsum;
 #pragma unroll

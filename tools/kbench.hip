@@ -186,6 +186,16 @@ int main() {
             AttnDirectP a{q, k, v, c.N, Npad, c.B, O, (long)c.B * c.N * 256, c.ks > 1 ? ml : nullptr, c.ks, nullptr};
             char nm[80]; snprintf(nm, 80, "attention direct bf16 B=%d N=%d ksplit=%d", c.B, c.N, c.ks);
             timeit(nm, 20, 4.0 * c.B * c.N * (double)c.N * 256, 2.0 * 3 * el + 4.0 * c.B * c.N * 256 * c.ks, [&] { launch_attention_direct(a, 0); });
+#ifdef DEX_TIMING
+            if (c.ks == 1) {
+                const int nb = ((c.N + 31) / 32 + 3) / 4 * 2 * c.B;
+                long long* dbg; hipMalloc(&dbg, nb * 64); hipMemset(dbg, 0, nb * 64);
+                a.dbg = dbg; launch_attention_direct(a, 0); hipDeviceSynchronize(); a.dbg = nullptr;
+                std::vector<long long> h(nb * 8); hipMemcpy(h.data(), dbg, nb * 64, hipMemcpyDeviceToHost);
+                for (int bl : {0, nb / 2, nb - 1}) { long long* d = &h[bl * 8];
+                    printf("   wg %4d: S^T=%lld softmax=%lld PV=%lld copy+barrier=%lld total=%lld cycles, wall=%lld x10ns -> %.2f GHz\n", bl, d[0], d[1], d[2], d[3], d[4], d[5], d[4] / (d[5] * 10.0)); }
+            }
+#endif
         }
     }
     // ---- linear-attention context pass + merge at 80x512 (C=64): pixels per workgroup trade-off
