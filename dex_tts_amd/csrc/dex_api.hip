@@ -62,6 +62,7 @@ struct DexCtx {
     const float *fc_w3 = nullptr, *fc_w1 = nullptr;        // first conv packs
     const float *fin_w = nullptr, *fin_b = nullptr, *fin_g = nullptr, *fin_be = nullptr, *fconv_w = nullptr, *fconv_b = nullptr;
     const float *pe_dw = nullptr, *pe_db = nullptr, *pe_pw = nullptr, *pe_pb = nullptr, *pos_w = nullptr, *pos_b = nullptr, *freq_pos = nullptr;
+    const void* pos_wfrag = nullptr;                        // pos-conv weights in MFMA fragment order (pos_conv.hip)
     std::vector<DitBlockW> blocks;
     const float *fl_w = nullptr, *fl_b = nullptr, *fl_ada_w = nullptr, *fl_ada_b = nullptr;
     const float *tv_wq_raw = nullptr, *tv_wk = nullptr, *tv_wv = nullptr, *tv_wl = nullptr;
@@ -446,6 +447,13 @@ extern "C" int dex_ctx_finalize(DexCtx* x, dex_stream_t stream) {
     x->pe_pw = P.kn("vit.x_embedder.proj.2.weight"); x->pe_pb = P.raw("vit.x_embedder.proj.2.bias");
     x->pos_w = P.perm("vit.pos_conv.0.weight", G, hid / G, hid / G, kp * kp, 0, 3, 2, 1);   // [G][tap][ci][n]
     P.twin(x->pos_w, G, kp * kp * (hid / G), hid / G);
+    x->pos_wfrag = nullptr;
+    if (pos_conv_direct_supported(hid, G, kp, token_rows(c))) {
+        const long kn_ = (long)kp * kp * (hid / G) * (hid / G);
+        unsigned short* wf = (unsigned short*)P.alloc((G * kn_ + 1) / 2);
+        if (wf) for (int g = 0; g < G; ++g) launch_pack_bf16_frag(x->pos_w + g * kn_, wf + g * kn_, kp * kp * (hid / G), hid / G, st);
+        x->pos_wfrag = wf;
+    }
     x->pos_b = P.raw("vit.pos_conv.0.bias");
     x->freq_pos = P.perm("vit.freq_new_pos_embed", 1, hid, grid_h(c), 1, 0, 2, 3, 1);       // [Hf][hid]
     x->blocks.clear();
@@ -788,12 +796,19 @@ struct Runner {
         gemm("patch_pointwise", pe);
         // grouped 16x16 pos-conv, split-K partials (bias added in the tail)
         const int G = c.dit_conv_pos_groups, kp = c.dit_conv_pos, cg = hid / G;
-        IGemmP pc = base_gemm(P.emb, hid, 0, P.Hf, P.Wt, cg, x->pos_w, cg, nullptr, P.pos_part, hid, 0);
-        pc.KH = kp; pc.KW = kp; pc.off_h = -(kp / 2); pc.off_w = -(kp / 2); pc.K = kp * kp * cg;
-        pc.groups = G; pc.w_gstride = (long)kp * kp * cg * cg; pc.ksplit = POS_SPLIT; pc.c_sstride = (long)B * N * hid;
-        gemm("pos_conv", pc);
-        PosFinishP pf{P.pos_part, POS_SPLIT, (long)B * N * hid, x->pos_b, P.emb, x->freq_pos, P.tok, P.Hf, P.Wt, hid, B};
-        run("pos_finish", 20.0 * B * N * hid, 4.0 * B * N * hid * (POS_SPLIT + 2), [&] { launch_pos_finish(pf, st); });
+        int nsplit = POS_SPLIT;
+        if (x->precision == DEX_PREC_BF16 && x->pos_wfrag) {
+            PosConvP pcd{P.emb, x->pos_wfrag, P.pos_part, P.Hf, P.Wt, hid, G, B};
+            run("pos_conv", 2.0 * B * N * (double)kp * kp * cg * hid, 8.0 * B * N * hid + 2.0 * kp * kp * cg * hid, [&] { launch_pos_conv_direct(pcd, st); });
+            nsplit = 1;
+        } else {
+            IGemmP pc = base_gemm(P.emb, hid, 0, P.Hf, P.Wt, cg, x->pos_w, cg, nullptr, P.pos_part, hid, 0);
+            pc.KH = kp; pc.KW = kp; pc.off_h = -(kp / 2); pc.off_w = -(kp / 2); pc.K = kp * kp * cg;
+            pc.groups = G; pc.w_gstride = (long)kp * kp * cg * cg; pc.ksplit = POS_SPLIT; pc.c_sstride = (long)B * N * hid;
+            gemm("pos_conv", pc);
+        }
+        PosFinishP pf{P.pos_part, nsplit, (long)B * N * hid, x->pos_b, P.emb, x->freq_pos, P.tok, P.Hf, P.Wt, hid, B};
+        run("pos_finish", 20.0 * B * N * hid, 4.0 * B * N * hid * (nsplit + 2), [&] { launch_pos_finish(pf, st); });
         if (debug) hipMemcpyAsync(P.dbg_tok, P.tok, (size_t)B * N * hid * 4, hipMemcpyDeviceToDevice, st);
         tap("tok_in", P.dbg_tok, (long)B * N, hid, hid);
         const float scale = 1.0f / sqrtf((float)(hid / c.dit_heads));

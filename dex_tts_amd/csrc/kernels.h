@@ -135,6 +135,12 @@ struct DwConvP { const float* X; int ldx; long xb; int Hi, Wi, C; int k, s, pad;
 void launch_dwconv_silu(const DwConvP& p, hipStream_t st);
 
 // pos-conv tail: sum split-K partials + bias -> GELU -> mean over freq -> tokens = emb + pos + freq_pos (dit.py:450-454)
+// Direct grouped 16x16 positional convolution (pos_conv.hip): X = patch embedding [B][Hf][Wt][hid] fp32, Wf = bf16
+// weights in MFMA fragment order per group ([g][tap][ks][lane][8], launch_pack_bf16_frag of each group's [K][32]
+// matrix), Y = raw convolution sums [B][Hf*Wt][hid].
+struct PosConvP { const float* X; const void* Wf; float* Y; int Hf, Wt, hid, G, B; };
+bool pos_conv_direct_supported(int hid, int groups, int kernel, int Hf);
+void launch_pos_conv_direct(const PosConvP& p, hipStream_t st);
 struct PosFinishP { const float* part; int nsplit; long split_stride; const float* bias; const float* emb;
                     const float* freq_pos; float* tok; int Hf, Wt, D; int B; };
 void launch_pos_finish(const PosFinishP& p, hipStream_t st);
