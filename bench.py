@@ -88,6 +88,25 @@ def cpu_baseline(cfg, weights, B, T, n_timesteps, TrTs):
                       f"{per_step * 1e3:.1f} ms/Euler-step on {torch.get_num_threads()} threads"}
 
 
+def roof(r, dtype_key):
+    """Roofline entry of one kernel class from its event-timed profile row.  The binding roof is the one that takes
+    longer for the kernel's ALGORITHMIC work: flops / MFMA peak  vs  bytes / HBM peak."""
+    sec = r["ms"] * 1e-3
+    t_mfma = r["flops"] / (PEAK_TFLOPS[dtype_key] * 1e12)
+    t_hbm = r["bytes"] / (PEAK_HBM_GBS * 1e9)
+    ent = {"kernel": r["name"], "avg_launch_us": round(r["ms"] / r["calls"] * 1e3, 2),
+           "mfma_TFLOP/s": round(r["flops"] / sec / 1e12, 2), "hbm_GB/s": round(r["bytes"] / sec / 1e9, 1), "traffic": None}
+    if t_mfma >= t_hbm:
+        ach = r["flops"] / sec / 1e12
+        ent.update({"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dtype_key], "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_TFLOPS[dtype_key], 4)})
+    else:
+        ach = r["bytes"] / sec / 1e9
+        ent.update({"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(ach / PEAK_HBM_GBS, 4)})
+    return ent
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,26 +219,11 @@ def main():
                 gb = r["bytes"] / (r["ms"] * 1e-3) / 1e9
                 kern.append({"kernel": r["name"], "calls": r["calls"], "avg_us": round(r["ms"] / r["calls"] * 1e3, 2),
                              "share": round(r["ms"] / tot, 3), "TFLOP/s": round(tf, 2), "GB/s": round(gb, 1)})
-            dom = rows[0]
-            mfma_bound = dom["name"] in ("conv3x3", "dit_attention", "tv_attention", "pos_conv", "linattn_qkv", "downsample",
-                                         "upsample_convT", "dit_qkv", "dit_fc1_gelu", "dit_fc2", "dit_proj", "linattn_out")
-            if mfma_bound:
-                ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-                res["roofline"] = {"kernel": dom["name"], "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dtype],
-                                   "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[dtype], 4), "traffic": None,
-                                   "avg_launch_us": round(dom["ms"] / dom["calls"] * 1e3, 2), "launches": dom["calls"]}
-            else:
-                ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-                res["roofline"] = {"kernel": dom["name"], "bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS,
-                                   "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
-                                   "avg_launch_us": round(dom["ms"] / dom["calls"] * 1e3, 2), "launches": dom["calls"]}
+            res["roofline"] = roof(rows[0], dtype)
+            res["roofline"]["launches"] = rows[0]["calls"]
             att = [r for r in rows if r["name"] == "dit_attention"]
             if att:
-                a = att[0]
-                ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
-                res["roofline_attention"] = {"kernel": "dit_attention", "bound": "mfma", "achieved": round(ach, 2),
-                                             "peak": PEAK_TFLOPS[dtype], "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS[dtype], 4),
-                                             "avg_launch_us": round(a["ms"] / a["calls"] * 1e3, 2)}
+                res["roofline_attention"] = roof(att[0], dtype)
             res["kernels"] = kern
             res["eager_event_total_ms"] = round(tot, 2)
         if world == 1 and not args.no_profile and args.precision == "bf16":
@@ -240,14 +244,10 @@ def main():
             r32 = sorted(eng.profile_rows(), key=lambda r: -r["ms"])
             eng.profile(False)
             eng.set_precision("bf16")
-            d32 = r32[0]
-            a32 = d32["flops"] / (d32["ms"] * 1e-3) / 1e12
             res["fp32_mode"] = {"value": round(valid * 1.0 / dt32, 1), "unit": "mel-frames/s", "ms_per_step": round(dt32 * 1e3, 3),
-                                "roofline": {"kernel": d32["name"], "bound": "mfma", "achieved": round(a32, 2), "peak": PEAK_TFLOPS["f32"],
-                                             "unit": "TFLOP/s", "frac": round(a32 / PEAK_TFLOPS["f32"], 4),
-                                             "avg_launch_us": round(d32["ms"] / d32["calls"] * 1e3, 2)}}
+                                "roofline": roof(r32[0], "f32")}
         if world == 1 and not args.no_profile and args.workload == "gedex_b1":
-            # The B=1 headline workload is launch/latency-bound (67 dependent launches of a few us per Euler step), so
+            # The B=1 headline workload is launch/latency-bound (~47 dependent launches of a few us per Euler step), so
             # its roofline fractions say little about the kernels.  Same kernels in the bandwidth/MFMA regime:
             # one B=32 sampler call per precision, event-timed per kernel class.
             p32, B32, T32, n32, _ = WORKLOADS["gedex_b32"]
@@ -256,7 +256,7 @@ def main():
             for prec, key in (("bf16", "bf16"), ("fp32", "f32")):
                 eng.set_precision(prec)
                 with torch.cuda.stream(stream):
-                    eng.sample(z2, mask2, mu2, 2, **kw2)
+                    eng.sample(z2, mask2, mu2, n32, **kw2)      # full warm-up call (plan, conditioning tables, clocks)
                     torch.cuda.synchronize(device)
                     t0 = time.perf_counter()
                     eng.sample(z2, mask2, mu2, n32, **kw2)
@@ -268,12 +268,9 @@ def main():
                 rb = {r["name"]: r for r in eng.profile_rows()}
                 eng.profile(False)
                 ent = {"value": round(valid2 / dtb, 1), "unit": "mel-frames/s", "workload": f"gedex_lj B={B32} T={T32} n_timesteps={n32}"}
-                for kname in ("conv3x3", "dit_attention"):
+                for kname in ("conv3x3", "dit_attention", "dit_rowchain", "pos_conv"):
                     if kname in rb:
-                        r = rb[kname]
-                        tf = r["flops"] / (r["ms"] * 1e-3) / 1e12
-                        ent[kname] = {"achieved": round(tf, 1), "peak": PEAK_TFLOPS[key], "unit": "TFLOP/s", "frac": round(tf / PEAK_TFLOPS[key], 4),
-                                      "avg_launch_us": round(r["ms"] / r["calls"] * 1e3, 1)}
+                        ent[kname] = roof(rb[kname], key)
                 scale[prec] = ent
             eng.set_precision(args.precision)
             res["roofline_batch32"] = scale

@@ -99,7 +99,9 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
     constexpr int ITEMS = PH * PW * (CC / 8);            // 8-channel patch items
     constexpr int NI = (ITEMS + 255) / 256;              // per thread
     constexpr int WPT = NSL * CC / 8 / 256;              // weight items (16 B) per thread per tap
-    constexpr int RING = 3;                              // taps of weights in flight ahead of the MFMAs
+    constexpr int RING = CC == 128 ? 2 : 3;              // taps of weights in flight ahead of the MFMAs
+    constexpr int NPASS = CC == 128 ? 2 : 1;             // patch staging passes: 128-channel chunks would need >256 registers in one
+    constexpr int NIP = (NI + NPASS - 1) / NPASS;        // (1 workgroup per CU instead of 2: measured 16 -> 22 us at 40x256)
     static_assert(NT >= 1 && WPT >= 1, "tile");
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* patch = smem;                                // [PH*PW][LDP]
@@ -146,22 +148,6 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
         for (int s = 0; s < RING; ++s)
 #pragma unroll
             for (int j = 0; j < WPT; ++j) wr[s][j] = *reinterpret_cast<const u32x4*>(Wg + wofs[j] + (long)(s + 1) * p.Cin + cbase);
-        float4 pf0[NI], pf1[NI];
-        float pmk[NI];
-#pragma unroll
-        for (int q = 0; q < NI; ++q) {
-            const int it = min(tid + 256 * q, ITEMS - 1);
-            const int px = it / (CC / 8);
-            const int pw = px % PW, ph = px / PW;
-            const int hi = h0 + ph - 1, wi = w0 + pw - 1;
-            const bool inb = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-            const int hc = inb ? hi : 0, wc = inb ? wi : 0;          // clamped: every load is unconditional
-            const float* src = X + ((long)hc * p.W + wc) * p.ldx + cbase + pc8;
-            pf0[q] = *reinterpret_cast<const float4*>(src);
-            pf1[q] = *reinterpret_cast<const float4*>(src + 4);
-            const float mk = mrow[wc * p.mask_ws];
-            pmk[q] = inb ? mk : 0.f;
-        }
         float4 ga0, ga1, be0, be1, t0, t1;
         float mean = 0.f, rstd = 1.f;
         if (pro) {
@@ -170,28 +156,49 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
             be0 = *reinterpret_cast<const float4*>(p.pro_beta + c); be1 = *reinterpret_cast<const float4*>(p.pro_beta + c + 4);
             const float* ta = p.pro_tadd + (long)step * p.Cin + c;
             t0 = *reinterpret_cast<const float4*>(ta); t1 = *reinterpret_cast<const float4*>(ta + 4);
-            if (ch == 0) cv_gn_coeffs(p, b, tid, smean, srstd);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        lds_barrier();                                // GN coefficients visible; previous chunk's MFMAs done with patch/wbuf
-        if (pro) { const int g = (cbase + pc8) / (p.Cin / 8); mean = smean[g]; rstd = srstd[g]; }
 #pragma unroll
-        for (int j = 0; j < WPT; ++j) *reinterpret_cast<u32x4*>(wbuf + wlds[j]) = w0r[j];
+        for (int ps = 0; ps < NPASS; ++ps) {
+            float4 pf0[NIP], pf1[NIP];
+            float pmk[NIP];
 #pragma unroll
-        for (int q = 0; q < NI; ++q) {
-            float4 f0 = pf0[q], f1 = pf1[q];
-            if (pro) {
-                f0.x = cv_mish((f0.x - mean) * rstd * ga0.x + be0.x) + t0.x; f0.y = cv_mish((f0.y - mean) * rstd * ga0.y + be0.y) + t0.y;
-                f0.z = cv_mish((f0.z - mean) * rstd * ga0.z + be0.z) + t0.z; f0.w = cv_mish((f0.w - mean) * rstd * ga0.w + be0.w) + t0.w;
-                f1.x = cv_mish((f1.x - mean) * rstd * ga1.x + be1.x) + t1.x; f1.y = cv_mish((f1.y - mean) * rstd * ga1.y + be1.y) + t1.y;
-                f1.z = cv_mish((f1.z - mean) * rstd * ga1.z + be1.z) + t1.z; f1.w = cv_mish((f1.w - mean) * rstd * ga1.w + be1.w) + t1.w;
+            for (int q = 0; q < NIP; ++q) {
+                const int it = min(tid + 256 * (ps * NIP + q), ITEMS - 1);
+                const int px = it / (CC / 8);
+                const int pw = px % PW, ph = px / PW;
+                const int hi = h0 + ph - 1, wi = w0 + pw - 1;
+                const bool inb = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                const int hc = inb ? hi : 0, wc = inb ? wi : 0;          // clamped: every load is unconditional
+                const float* src = X + ((long)hc * p.W + wc) * p.ldx + cbase + pc8;
+                pf0[q] = *reinterpret_cast<const float4*>(src);
+                pf1[q] = *reinterpret_cast<const float4*>(src + 4);
+                const float mk = mrow[wc * p.mask_ws];
+                pmk[q] = inb ? mk : 0.f;
             }
-            const float mk = pmk[q];
-            uint4 v;
-            v.x = pack2_bf16(f0.x * mk, f0.y * mk); v.y = pack2_bf16(f0.z * mk, f0.w * mk);
-            v.z = pack2_bf16(f1.x * mk, f1.y * mk); v.w = pack2_bf16(f1.z * mk, f1.w * mk);
-            const int it = tid + 256 * q;
-            if (it < ITEMS) *reinterpret_cast<uint4*>(patch + (it / (CC / 8)) * LDP + pc8) = v;
+            if (ps == 0) {
+                if (pro && ch == 0) cv_gn_coeffs(p, b, tid, smean, srstd);
+                __builtin_amdgcn_sched_barrier(0);
+                lds_barrier();                            // GN coefficients visible; previous chunk's MFMAs done with patch/wbuf
+                if (pro) { const int g = (cbase + pc8) / (p.Cin / 8); mean = smean[g]; rstd = srstd[g]; }
+#pragma unroll
+                for (int j = 0; j < WPT; ++j) *reinterpret_cast<u32x4*>(wbuf + wlds[j]) = w0r[j];
+            }
+#pragma unroll
+            for (int q = 0; q < NIP; ++q) {
+                float4 f0 = pf0[q], f1 = pf1[q];
+                if (pro) {
+                    f0.x = cv_mish((f0.x - mean) * rstd * ga0.x + be0.x) + t0.x; f0.y = cv_mish((f0.y - mean) * rstd * ga0.y + be0.y) + t0.y;
+                    f0.z = cv_mish((f0.z - mean) * rstd * ga0.z + be0.z) + t0.z; f0.w = cv_mish((f0.w - mean) * rstd * ga0.w + be0.w) + t0.w;
+                    f1.x = cv_mish((f1.x - mean) * rstd * ga1.x + be1.x) + t1.x; f1.y = cv_mish((f1.y - mean) * rstd * ga1.y + be1.y) + t1.y;
+                    f1.z = cv_mish((f1.z - mean) * rstd * ga1.z + be1.z) + t1.z; f1.w = cv_mish((f1.w - mean) * rstd * ga1.w + be1.w) + t1.w;
+                }
+                const float mk = pmk[q];
+                uint4 v;
+                v.x = pack2_bf16(f0.x * mk, f0.y * mk); v.y = pack2_bf16(f0.z * mk, f0.w * mk);
+                v.z = pack2_bf16(f1.x * mk, f1.y * mk); v.w = pack2_bf16(f1.z * mk, f1.w * mk);
+                const int it = tid + 256 * (ps * NIP + q);
+                if (it < ITEMS) *reinterpret_cast<uint4*>(patch + (it / (CC / 8)) * LDP + pc8) = v;
+            }
         }
         // ---- nine taps; tap t's weights sit in wbuf[t & 1], taps t+1 .. t+RING are in registers / in flight
 #pragma unroll
@@ -247,7 +254,7 @@ void launch_conv3x3_bf16(const Conv3P& p, hipStream_t st) {
     // few tiles (half resolution at small batch): 2-row tiles and 64-channel output slices put more, lighter
     // workgroups on the chip (per-tap weight traffic per workgroup halves, two workgroups fit per CU)
     const long tiles4 = (long)((p.W + 31) / 32) * ((p.H + 3) / 4) * p.B;
-    const bool small = tiles4 < 256;
+    const bool small = tiles4 < 256;       // (at B=32 the 4-row tiles win despite one workgroup per CU: 189 vs 218 us)
     if (p.Cout == 64) {
         if (p.Cin == 64) { small ? launch_c3<64, 64, 64, 2>(p, st) : launch_c3<64, 64, 64, 4>(p, st); }
         else { small ? launch_c3<128, 64, 64, 2>(p, st) : launch_c3<128, 64, 64, 4>(p, st); }      // Cin 128 / 256 (two chunks)
