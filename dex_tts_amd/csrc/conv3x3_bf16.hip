@@ -55,19 +55,32 @@ __device__ __forceinline__ void cv_epilogue(const Conv3P& p, f32x16 (&acc)[NT], 
     float* Y = p.Y + (long)b * p.H * p.W * COUT;
     constexpr int cpg = COUT / 8;
     if (p.gn_stats) { if (tid < 16) gnred[tid] = 0.f; __syncthreads(); }
+    // one 64-bit base per lane; the 16 rows of a tile are compile-time offsets from it (the first version rebuilt a
+    // 64-bit address and a bounds predicate per element).  Full tiles (the common case: W % 32 == 0) store unpredicated.
+    const bool full = ho < p.H && w0 + 32 <= p.W;
+    float* yl = Y + ((long)ho * p.W + w0 + 4 * hh) * COUT + nbase + i;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int n = nbase + t * 32 + i;
         const float bias = p.bias[n];
         float gs = 0.f, gss = 0.f;
+        if (full) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int wo = w0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const bool ok = ho < p.H && wo < p.W;
-            const float v = acc[t][r] + bias;
-            const float vs = ok ? v : 0.f;
-            gs += vs; gss = fmaf(vs, vs, gss);
-            if (ok) Y[((long)ho * p.W + wo) * COUT + n] = v;
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[t][r] + bias;
+                gs += v; gss = fmaf(v, v, gss);
+                yl[((r & 3) + 8 * (r >> 2)) * COUT + t * 32] = v;
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int wo = w0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const bool ok = ho < p.H && wo < p.W;
+                const float v = acc[t][r] + bias;
+                const float vs = ok ? v : 0.f;
+                gs += vs; gss = fmaf(vs, vs, gss);
+                if (ok) yl[((r & 3) + 8 * (r >> 2)) * COUT + t * 32] = v;
+            }
         }
         if (p.gn_stats) {
             for (int o = 1; o < cpg; o <<= 1) { gs += __shfl_xor(gs, o); gss += __shfl_xor(gss, o); }

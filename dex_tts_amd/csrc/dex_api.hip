@@ -819,7 +819,7 @@ struct Runner {
             const bool fuse_ln = x->precision == DEX_PREC_BF16;      // LayerNorm+modulate inside the GEMM's A staging
             DitChainP ch{};
             if (chain) {
-                ch.ksplit = 0; ch.heads = c.dit_heads; ch.rows_per_batch = N; ch.X = P.tok; ch.ada = ada; ch.step = sp; ch.M = B * N;
+                ch.ksplit = 0; ch.heads = c.dit_heads; ch.rows_per_batch = N; ch.X = P.tok; ch.ada = ada; ch.step = sp; ch.M = B * N; ch.B = B;
                 ch.Qh = P.qh; ch.Kh = P.kh; ch.Vt = P.vt; ch.Npad = P.Npad;
                 ch.qscale = scale * 1.4426950408889634f;      // log2(e) folded in: the attention kernels use exp2
             }

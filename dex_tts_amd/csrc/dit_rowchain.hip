@@ -49,19 +49,28 @@ __device__ __forceinline__ void wload(uint4 (&w)[16], const void* W, int ksteps_
     for (int j = 0; j < 16; ++j) w[j] = src[j * 64];
     __builtin_amdgcn_sched_barrier(0);     // all 16 loads issue HERE (the scheduler otherwise drips them into the MFMA chain below)
 }
-__device__ __forceinline__ void mma16(f32x16& acc, const uint4 (&w)[16], const u16* a_lane) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        const bf16x8 af = *reinterpret_cast<const bf16x8*>(a_lane + j * 16);
-        const bf16x8 bf = __builtin_bit_cast(bf16x8, w[j]);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
-    }
-}
 __device__ __forceinline__ f32x16 zero16() {
     f32x16 z;
 #pragma unroll
     for (int r = 0; r < 16; ++r) z[r] = 0.f;
     return z;
+}
+
+// acc += A(32 rows x 256 K, bf16 in LDS) x W(16 register fragments).  The A fragments are read from LDS in two
+// batches of 8 (all ds_read_b128 of a batch in flight together, 32 VGPRs) instead of one right before each MFMA,
+// which exposed an LDS latency per link of the dependent MFMA chain.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void mma16(f32x16& acc, const uint4 (&w)[16], const u16* a_lane) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        u32x4 a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = *reinterpret_cast<const u32x4*>(a_lane + (h * 8 + j) * 16);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[j]), __builtin_bit_cast(bf16x8, w[h * 8 + j]), acc, 0, 0, 0);
+    }
 }
 
 // LayerNorm(eps 1e-6, no affine) + modulate of the 32 fp32 rows in X1 -> bf16 A tile.  16 threads per row, each
@@ -106,30 +115,52 @@ __device__ __forceinline__ void ln_to_A(const float* X1, u16* As, const float* s
 //   q (pre-scaled), k and v^T as bf16 in MFMA fragment order per (batch, head), rows padded to Npad (see
 //   attention_direct.hip); v^T key positions have index bits 2/3 swapped inside each 32-key block (the order in
 //   which a P^T accumulator lane holds its keys).
-__device__ __forceinline__ void store_qkv_tile(const DitChainP& p, const f32x16& acc, int nt, float bias, int m0, int lane) {
+// `scr` is a wave-private LDS scratch of 32 x QK_LD bf16.  Row tiles never cross an utterance (the grid is per batch
+// element) and start at a multiple of 32 tokens, so a tile is exactly one 32-row block of the fragment layouts and
+// every global store is a full 16-byte chunk: 2 per lane instead of 16 scattered 2-byte stores (which cost 1.4 us
+// per tile, measured).  Rows past N land in the padding rows of the operand buffers (finite duplicates; masked /
+// multiplied by exact zeros in the attention kernel).
+constexpr int QK_LD = 40;
+__device__ __forceinline__ void store_qkv_tile(const DitChainP& p, const f32x16& acc, int nt, float bias, int b, int n0, int lane, u16* scr) {
     const int i = lane & 31, hh = lane >> 5;
-    const int kind = nt >> 3, head = (nt >> 2) & 1, d = (nt & 3) * 32 + i;
-    const int N = p.rows_per_batch;
-    const int b0 = m0 / N, n0 = m0 - b0 * N;
-    u16* Qh = reinterpret_cast<u16*>(p.Qh); u16* Kh = reinterpret_cast<u16*>(p.Kh); u16* Vt = reinterpret_cast<u16*>(p.Vt);
+    const int kind = nt >> 3, head = (nt >> 2) & 1, d0 = (nt & 3) * 32;
+    const float sc = kind == 0 ? p.qscale : 1.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (m0 + row >= p.M) continue;
-        int n = n0 + row, b = b0;
-        if (n >= N) { n -= N; ++b; }
-        const float v = acc[r] + bias;
-        const long hb = ((long)b * 2 + head) * p.Npad * 128;
-        if (kind < 2) {       // q / k: [tile n/32][ks = d/16][lane = (d/8 & 1)*32 + n%32][d%8]
-            const long o = hb + ((((long)(n >> 5) * 8 + (d >> 4)) * 64 + ((d >> 3) & 1) * 32 + (n & 31)) << 3) + (d & 7);
-            if (kind == 0) Qh[o] = (u16)(pack2_bf16(v * p.qscale, 0.f) & 0xffffu);
-            else Kh[o] = (u16)(pack2_bf16(v, 0.f) & 0xffffu);
-        } else {              // v^T: [tile pos/32][t = d/32][k2 = pos/16 & 1][lane = (pos/8 & 1)*32 + d%32][pos%8]
-            const int pos = (n & ~12) | ((n & 4) << 1) | ((n & 8) >> 1);
-            const long o = hb + (((((long)(pos >> 5) * 4 + (d >> 5)) * 2 + ((pos >> 4) & 1)) * 64 + ((pos >> 3) & 1) * 32 + (d & 31)) << 3) + (pos & 7);
-            Vt[o] = (u16)(pack2_bf16(v, 0.f) & 0xffffu);
+        scr[row * QK_LD + i] = (u16)(pack2_bf16((acc[r] + bias) * sc, 0.f) & 0xffffu);
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): this wave's scratch writes landed
+    __builtin_amdgcn_wave_barrier();
+    u16* base = (kind == 0 ? reinterpret_cast<u16*>(p.Qh) : kind == 1 ? reinterpret_cast<u16*>(p.Kh) : reinterpret_cast<u16*>(p.Vt))
+                + ((long)b * 2 + head) * p.Npad * 128 + (long)(n0 >> 5) * 4096;
+    if (kind < 2) {
+        // q / k: [tile][ks = d/16][lane = (d/8 & 1)*32 + row][8 d]: chunk (row, c8) -> 8 consecutive d
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int id = lane + 64 * c, row = id >> 2, c8 = id & 3;
+            const uint4 v = *reinterpret_cast<const uint4*>(scr + row * QK_LD + c8 * 8);
+            const int d = d0 + c8 * 8;
+            *reinterpret_cast<uint4*>(base + (((d >> 4) * 64 + ((d >> 3) & 1) * 32 + row) << 3)) = v;
+        }
+    } else {
+        // v^T: [tile][t = d/32][k2 = pos/16 & 1][lane = (pos/8 & 1)*32 + d%32][8 positions], position = row with bits 2/3
+        // swapped: chunk (d, position group pg) gathers rows swz(pg*8 + j)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int id = lane + 64 * c, dl = id & 31, pg = id >> 5;
+            unsigned w[4];
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) {
+                const int p0 = pg * 8 + 2 * j2, p1 = p0 + 1;
+                const int r0 = (p0 & ~12) | ((p0 & 4) << 1) | ((p0 & 8) >> 1), r1 = (p1 & ~12) | ((p1 & 4) << 1) | ((p1 & 8) >> 1);
+                w[j2] = (unsigned)scr[r0 * QK_LD + dl] | ((unsigned)scr[r1 * QK_LD + dl] << 16);
+            }
+            const int t = d0 >> 5;
+            *reinterpret_cast<uint4*>(base + (((t * 2 + (pg >> 1)) * 64 + (pg & 1) * 32 + dl) << 3)) = make_uint4(w[0], w[1], w[2], w[3]);
         }
     }
+    __builtin_amdgcn_wave_barrier();                     // scratch is reused by the next tile
 }
 
 }  // namespace
@@ -142,7 +173,10 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
     float* LNp = X1 + RC_ROWS * X_LD;                          // [4][256]   shift_mlp, scale_mlp, next shift, next scale
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
-    const int m0 = blockIdx.x * RC_ROWS, M = p.M;
+    // row tiles are per batch element (never across utterances): tile t of element b covers tokens [32 t, 32 t + 32)
+    const int N = p.rows_per_batch, tpb = (N + RC_ROWS - 1) / RC_ROWS;
+    const int b = blockIdx.x / tpb, n0 = (blockIdx.x - b * tpb) * RC_ROWS;
+    const long mb = (long)b * N;                               // first global row of this batch element
     const int step = p.step ? *p.step : 0;
     const float* ada = p.ada + (long)step * 6 * RC_H;
     const bool has_q = p.next_shift != nullptr;
@@ -167,7 +201,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
         // first block: just LN + modulate + qkv of the incoming token rows
         wload(wb, p.Wq, 16, wave, 0, lane);
         const int row = tid >> 4, seg = tid & 15;
-        const float* src = p.X + (long)min(m0 + row, M - 1) * RC_H + seg * 4;
+        const float* src = p.X + (mb + min(n0 + row, N - 1)) * RC_H + seg * 4;
 #pragma unroll
         for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(X1 + row * X_LD + q * 64 + seg * 4) = *reinterpret_cast<const float4*>(src + q * 64);
     } else {
@@ -176,13 +210,13 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
     float xres[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int m = min(m0 + (r & 3) + 8 * (r >> 2) + 4 * hh, M - 1);
-        xres[r] = p.X[(long)m * RC_H + col];
+        const int nn = min(n0 + (r & 3) + 8 * (r >> 2) + 4 * hh, N - 1);
+        xres[r] = p.X[(mb + nn) * RC_H + col];
     }
     {
         const int row = tid >> 4, seg = tid & 15;
-        const int m = min(m0 + row, M - 1);
-        const float* src = p.O + (long)m * RC_H + seg * 4;
+        const int n = min(n0 + row, N - 1);
+        const float* src = p.O + (mb + n) * RC_H + seg * 4;
         float4 v[4];
         if (p.ksplit <= 1) {
 #pragma unroll
@@ -190,8 +224,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
         } else {
             // merge the key-split attention partials: O = sum_s w_s O_s / sum_s w_s,  w_s = l_s 2^(m_s - max m)
             // (column block q belongs to head q / 2: head_dim 128)
-            const int bb = m / p.rows_per_batch, n = m - bb * p.rows_per_batch;
-            const int nbat = M / p.rows_per_batch;
+            const int bb = b, nbat = p.B;
             float4 pv[4][4];
             float2 st[4][2];
 #pragma unroll
@@ -297,7 +330,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
         const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
         const float x2 = X1[row * X_LD + col] + g_mlp * (acc[r] + b_2);
         X1[row * X_LD + col] = x2;
-        if (m0 + row < M) p.X[(long)(m0 + row) * RC_H + col] = x2;
+        if (n0 + row < N) p.X[(mb + n0 + row) * RC_H + col] = x2;
     }
     if (!has_q) return;
     }   // !qkv_only
@@ -316,16 +349,29 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
     // ---- qkv of the next block: column tiles wave (q), wave+8 (k), wave+16 (v)
     const float bq0 = p.bq[col], bq1 = p.bq[col + 256], bq2 = p.bq[col + 512];
     wload(wa, p.Wq, 16, wave + 8, 0, lane);
+#ifdef DEX_TIMING
+    long long u0 = wall_clock64();
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");       // wb (this tile's weights) landed; wa still in flight
+    long long u1 = wall_clock64();
+#endif
     acc = zero16();
     mma16(acc, wb, a_lane);
-    store_qkv_tile(p, acc, wave, bq0, m0, lane);
+#ifdef DEX_TIMING
+    asm volatile("s_nop 0" :: "v"(acc[0]), "v"(acc[15])); long long u2 = wall_clock64();
+#endif
+    u16* scr = Hs + wave * (RC_ROWS * QK_LD);              // H is dead here (and unused in qkv-only mode)
+    store_qkv_tile(p, acc, wave, bq0, b, n0, lane, scr);
+#ifdef DEX_TIMING
+    long long u3 = wall_clock64();
+    if (p.dbg && tid == 0) { p.dbg[256 + blockIdx.x * 4 + 0] = u1 - u0; p.dbg[256 + blockIdx.x * 4 + 1] = u2 - u1; p.dbg[256 + blockIdx.x * 4 + 2] = u3 - u2; }
+#endif
     wload(wb, p.Wq, 16, wave + 16, 0, lane);
     acc = zero16();
     mma16(acc, wa, a_lane);
-    store_qkv_tile(p, acc, wave + 8, bq1, m0, lane);
+    store_qkv_tile(p, acc, wave + 8, bq1, b, n0, lane, scr);
     acc = zero16();
     mma16(acc, wb, a_lane);
-    store_qkv_tile(p, acc, wave + 16, bq2, m0, lane);
+    store_qkv_tile(p, acc, wave + 16, bq2, b, n0, lane, scr);
 #ifdef DEX_TIMING
     if (p.dbg && tid == 0) { tst[7] = wall_clock64(); for (int k = 0; k < 8; ++k) p.dbg[blockIdx.x * 8 + k] = tst[k]; }
 #endif
@@ -339,7 +385,7 @@ void launch_dit_rowchain(const DitChainP& p, hipStream_t st) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&dit_rowchain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC_LDS);
         attr = true;
     }
-    hipLaunchKernelGGL(dit_rowchain_kernel, dim3((p.M + RC_ROWS - 1) / RC_ROWS), dim3(RC_NW * 64), RC_LDS, st, p);
+    hipLaunchKernelGGL(dit_rowchain_kernel, dim3(p.B * ((p.rows_per_batch + RC_ROWS - 1) / RC_ROWS)), dim3(RC_NW * 64), RC_LDS, st, p);
 }
 
 // fp32 [K][N] -> bf16 in MFMA B-fragment order: dst[((nt * K/16 + ks) * 64 + lane) * 8 + j] =

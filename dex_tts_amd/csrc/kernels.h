@@ -158,7 +158,7 @@ struct DitChainP { const float* O; int ksplit; long o_sstride; const float* ml; 
                    const float *next_shift, *next_scale; long next_step_stride;   // null: no qkv stage (last block)
                    void *Qh, *Kh, *Vt; int Npad; float qscale;          // bf16 head-major q,k and transposed v (attention_direct.hip)
                    int qkv_only;                                        // 1: only LN+modulate+qkv of X (first block)
-                   const int* step; int M; long long* dbg; };
+                   const int* step; int M; int B; long long* dbg; };   // M = B * rows_per_batch
 bool dit_rowchain_supported(int hidden, int mlp_hidden);
 // Softmax attention on the row chain's bf16 operands (2 heads x 128): no staging, K / V^T / Q fragments are read
 // straight from global memory.  O: fp32 [ksplit][B][N][256] partials + ml (merged by the next row chain launch).

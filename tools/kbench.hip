@@ -225,17 +225,18 @@ int main() {
         float* bias = dalloc(768, 0.1f); float* ada = dalloc(6 * 256, 0.1f);
         DitChainP c{}; c.O = O; c.ksplit = 3; c.o_sstride = (long)M * 256; c.ml = ml; c.heads = 2; c.rows_per_batch = M; c.X = X;
         c.Wp = Wp; c.W1 = W1; c.W2 = W2; c.Wq = Wq; c.bp = bias; c.b1 = bias; c.b2 = bias; c.bq = bias; c.ada = ada;
-        c.next_shift = ada; c.next_scale = ada + 256; c.next_step_stride = 0; c.Qh = qh; c.Kh = kh; c.Vt = vt; c.Npad = 672; c.qscale = 0.088f; c.M = M;
+        c.next_shift = ada; c.next_scale = ada + 256; c.next_step_stride = 0; c.Qh = qh; c.Kh = kh; c.Vt = vt; c.Npad = 672; c.qscale = 0.088f; c.M = M; c.B = 1;
         const double wel = 256.0 * 256 + 2.0 * 256 * 512 + 3.0 * 256 * 256;
         timeit("dit_rowchain M=650 (weights hot)", 50, 2.0 * M * wel, 2.0 * wel, [&] { launch_dit_rowchain(c, 0); });
 #ifdef DEX_TIMING
         {
-            long long* dbg; hipMalloc(&dbg, 32 * 8 * 8); hipMemset(dbg, 0, 32 * 8 * 8);
+            long long* dbg; hipMalloc(&dbg, 512 * 8); hipMemset(dbg, 0, 512 * 8);
             c.dbg = dbg; launch_dit_rowchain(c, 0); hipDeviceSynchronize(); c.dbg = nullptr;
-            std::vector<long long> h(32 * 8); hipMemcpy(h.data(), dbg, 32 * 8 * 8, hipMemcpyDeviceToHost);
+            std::vector<long long> h(512); hipMemcpy(h.data(), dbg, 512 * 8, hipMemcpyDeviceToHost);
             for (int bl : {0, 10, 20}) { long long* d = &h[bl * 8];
                 printf("   blk %2d: stageO=%lld S1=%lld LN1=%lld S2=%lld S3=%lld LN2=%lld S4=%lld total=%lld (10ns)\n", bl,
-                       d[1] - d[0], d[2] - d[1], d[3] - d[2], d[4] - d[3], d[5] - d[4], d[6] - d[5], d[7] - d[6], d[7] - d[0]); }
+                       d[1] - d[0], d[2] - d[1], d[3] - d[2], d[4] - d[3], d[5] - d[4], d[6] - d[5], d[7] - d[6], d[7] - d[0]);
+                printf("            first qkv tile: weights wait=%lld  A reads+16 MFMA=%lld  store_qkv_tile=%lld (10ns)\n", h[256 + bl * 4], h[256 + bl * 4 + 1], h[256 + bl * 4 + 2]); }
         }
 #endif
         float* big = dalloc(16 << 20, 1.0f); float* big2 = dalloc(16 << 20, 1.0f);
