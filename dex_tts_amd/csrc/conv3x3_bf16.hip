@@ -102,7 +102,7 @@ __device__ __forceinline__ void cv_epilogue(const Conv3P& p, f32x16 (&acc)[NT], 
 
 // CC channels per chunk, output-channel slice [slice*NSL, +NSL) of COUT, TH rows (waves: TH x (4/TH)).
 // grid.z = b * (COUT/NSL) + slice.
-template <int CC, int COUT, int NSL, int TH>
+template <int CC, int COUT, int NSL, int TH, bool PRO2 = false>
 __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
     constexpr int PW = 34, PH = TH + 2;
     constexpr int LDP = CC + 8;
@@ -112,8 +112,8 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
     constexpr int ITEMS = PH * PW * (CC / 8);            // 8-channel patch items
     constexpr int NI = (ITEMS + 255) / 256;              // per thread
     constexpr int WPT = NSL * CC / 8 / 256;              // weight items (16 B) per thread per tap
-    constexpr int RING = CC == 128 ? 2 : 3;              // taps of weights in flight ahead of the MFMAs
-    constexpr int NPASS = CC == 128 ? 2 : 1;             // patch staging passes: 128-channel chunks would need >256 registers in one
+    constexpr int RING = CC == 128 ? (PRO2 ? 1 : 2) : 3;  // taps of weights in flight ahead of the MFMAs
+    constexpr int NPASS = CC == 128 ? (PRO2 ? 5 : 2) : (PRO2 ? 3 : 1);   // patch staging passes: 128-channel chunks (or two source tensors) would need >256 registers in one
     constexpr int NIP = (NI + NPASS - 1) / NPASS;        // (1 workgroup per CU instead of 2: measured 16 -> 22 us at 40x256)
     static_assert(NT >= 1 && WPT >= 1, "tile");
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
@@ -167,13 +167,16 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
             const int c = cbase + pc8;
             ga0 = *reinterpret_cast<const float4*>(p.pro_gamma + c); ga1 = *reinterpret_cast<const float4*>(p.pro_gamma + c + 4);
             be0 = *reinterpret_cast<const float4*>(p.pro_beta + c); be1 = *reinterpret_cast<const float4*>(p.pro_beta + c + 4);
-            const float* ta = p.pro_tadd + (long)step * p.Cin + c;
-            t0 = *reinterpret_cast<const float4*>(ta); t1 = *reinterpret_cast<const float4*>(ta + 4);
+            if (p.pro_tadd) {
+                const float* ta = p.pro_tadd + (long)step * p.Cin + c;
+                t0 = *reinterpret_cast<const float4*>(ta); t1 = *reinterpret_cast<const float4*>(ta + 4);
+            } else { t0 = make_float4(0.f, 0.f, 0.f, 0.f); t1 = t0; }
         }
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
-            float4 pf0[NIP], pf1[NIP];
+            float4 pf0[NIP], pf1[NIP], rf0[PRO2 ? NIP : 1], rf1[PRO2 ? NIP : 1];
             float pmk[NIP];
+            bool pin[NIP];
 #pragma unroll
             for (int q = 0; q < NIP; ++q) {
                 const int it = min(tid + 256 * (ps * NIP + q), ITEMS - 1);
@@ -185,8 +188,14 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
                 const float* src = X + ((long)hc * p.W + wc) * p.ldx + cbase + pc8;
                 pf0[q] = *reinterpret_cast<const float4*>(src);
                 pf1[q] = *reinterpret_cast<const float4*>(src + 4);
+                if constexpr (PRO2) {
+                    const float* rs = p.pro_res + ((long)b * p.H * p.W + (long)hc * p.W + wc) * p.Cin + cbase + pc8;
+                    rf0[q] = *reinterpret_cast<const float4*>(rs);
+                    rf1[q] = *reinterpret_cast<const float4*>(rs + 4);
+                }
                 const float mk = mrow[wc * p.mask_ws];
                 pmk[q] = inb ? mk : 0.f;
+                pin[q] = inb;
             }
             if (ps == 0) {
                 if (pro && ch == 0) cv_gn_coeffs(p, b, tid, smean, srstd);
@@ -206,10 +215,21 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
                     f1.z = cv_mish((f1.z - mean) * rstd * ga1.z + be1.z) + t1.z; f1.w = cv_mish((f1.w - mean) * rstd * ga1.w + be1.w) + t1.w;
                 }
                 const float mk = pmk[q];
+                const int it = tid + 256 * (ps * NIP + q);
+                if constexpr (PRO2) {
+                    // x = mask * Mish(GN(h2)) + res: the value the un-fused gn_apply kernel wrote; the conv then sees x * mask
+                    f0.x = fmaf(f0.x, mk, rf0[q].x); f0.y = fmaf(f0.y, mk, rf0[q].y); f0.z = fmaf(f0.z, mk, rf0[q].z); f0.w = fmaf(f0.w, mk, rf0[q].w);
+                    f1.x = fmaf(f1.x, mk, rf1[q].x); f1.y = fmaf(f1.y, mk, rf1[q].y); f1.z = fmaf(f1.z, mk, rf1[q].z); f1.w = fmaf(f1.w, mk, rf1[q].w);
+                    const int px_ = it / (CC / 8), pw_ = px_ % PW, ph_ = px_ / PW;
+                    if (slice == 0 && it < ITEMS && pin[q] && ph_ >= 1 && ph_ <= TH && pw_ >= 1 && pw_ <= 32) {
+                        float* xo = p.pro_xout + ((long)b * p.H * p.W + (long)(h0 + ph_ - 1) * p.W + (w0 + pw_ - 1)) * p.Cin + cbase + pc8;
+                        *reinterpret_cast<float4*>(xo) = f0;
+                        *reinterpret_cast<float4*>(xo + 4) = f1;
+                    }
+                }
                 uint4 v;
                 v.x = pack2_bf16(f0.x * mk, f0.y * mk); v.y = pack2_bf16(f0.z * mk, f0.w * mk);
                 v.z = pack2_bf16(f1.x * mk, f1.y * mk); v.w = pack2_bf16(f1.z * mk, f1.w * mk);
-                const int it = tid + 256 * (ps * NIP + q);
                 if (it < ITEMS) *reinterpret_cast<uint4*>(patch + (it / (CC / 8)) * LDP + pc8) = v;
             }
         }
@@ -246,19 +266,20 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
     cv_epilogue<NT, COUT>(p, acc, b, h0 + wrow, w0, slice * NSL + wcol * NT * 32, lane, tid, gnred);
 }
 
-template <int CC, int COUT, int NSL, int TH>
+template <int CC, int COUT, int NSL, int TH, bool PRO2 = false>
 static void launch_c3(const Conv3P& p, hipStream_t st) {
     constexpr int LDP = CC + 8;
     const size_t lds = ((size_t)(TH + 2) * 34 * LDP + 2 * NSL * LDP) * sizeof(u16);
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<CC, COUT, NSL, TH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<CC, COUT, NSL, TH, PRO2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     dim3 grid((p.W + 31) / 32, (p.H + TH - 1) / TH, p.B * (COUT / NSL));
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<CC, COUT, NSL, TH>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<CC, COUT, NSL, TH, PRO2>), grid, dim3(256), lds, st, p);
 }
 
+bool conv3x3_bf16_tail_supported(int C) { return C == 64 || C == 128; }
 bool conv3x3_bf16_supported(int Cin, int Cout) {
     return (Cin == 64 || Cin == 128 || Cin == 256) && (Cout == 64 || Cout == 128);
 }
@@ -268,6 +289,11 @@ void launch_conv3x3_bf16(const Conv3P& p, hipStream_t st) {
     // workgroups on the chip (per-tap weight traffic per workgroup halves, two workgroups fit per CU)
     const long tiles4 = (long)((p.W + 31) / 32) * ((p.H + 3) / 4) * p.B;
     const bool small = tiles4 < 256;       // (at B=32 the 4-row tiles win despite one workgroup per CU: 189 vs 218 us)
+    if (p.pro_res) {      // fused ResnetBlock tail in front: only the Cin == Cout shapes of the second block's first conv
+        if (p.Cin == 64 && p.Cout == 64) { small ? launch_c3<64, 64, 64, 2, true>(p, st) : launch_c3<64, 64, 64, 4, true>(p, st); }
+        else { small ? launch_c3<128, 128, 64, 2, true>(p, st) : launch_c3<128, 128, 128, 4, true>(p, st); }
+        return;
+    }
     if (p.Cout == 64) {
         if (p.Cin == 64) { small ? launch_c3<64, 64, 64, 2>(p, st) : launch_c3<64, 64, 64, 4>(p, st); }
         else { small ? launch_c3<128, 64, 64, 2>(p, st) : launch_c3<128, 64, 64, 4>(p, st); }      // Cin 128 / 256 (two chunks)

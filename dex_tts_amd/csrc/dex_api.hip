@@ -665,7 +665,7 @@ struct Runner {
     }
     // Block conv (diffusion.py:44).  pro != null fuses the producer's GN-apply + Mish + time bias into the load
     // (bf16 patch kernel only).
-    struct Pro { const float* stats; const float *gamma, *beta, *tadd; };
+    struct Pro { const float* stats; const float *gamma, *beta, *tadd; const float* res = nullptr; float* xout = nullptr; };
     bool fast_conv(int cin, int cout) const { return x->precision == DEX_PREC_BF16 && conv3x3_bf16_supported(cin, cout); }
     void conv3x3(const char* name, const TD& X, int H, int W, int mask_ws, bool inmask, const float* Wt, const float* bias, int Cout, float* out,
                  float* gn = nullptr, const Pro* pro = nullptr) {
@@ -674,7 +674,7 @@ struct Runner {
             Conv3P c{};
             c.X = X.p; c.ldx = X.ld; c.x_coff = X.coff; c.H = H; c.W = W; c.Cin = X.C; c.Cout = Cout;
             c.Wbf = it->second; c.bias = bias; c.Y = out; c.mask = mask; c.mask_ws = mask_ws; c.mask_bstride = P.d.T;
-            if (pro) { c.pro_stats = pro->stats; c.pro_gamma = pro->gamma; c.pro_beta = pro->beta; c.pro_tadd = pro->tadd; }
+            if (pro) { c.pro_stats = pro->stats; c.pro_gamma = pro->gamma; c.pro_beta = pro->beta; c.pro_tadd = pro->tadd; c.pro_res = pro->res; c.pro_xout = pro->xout; }
             c.step = sp; c.gn_stats = gn; c.B = P.d.B;
             const double M = (double)H * W * P.d.B;
             run(name, 2.0 * M * Cout * 9 * X.C, 4.0 * M * (X.C + Cout) + 2.0 * 9 * X.C * Cout, [&] { launch_conv3x3_bf16(c, st); });
@@ -704,7 +704,11 @@ struct Runner {
     // ResnetBlock (diffusion.py:66-71).  X: unmasked input view; out = block2(...) + res_conv(x*mask) (unmasked).
     // tail != null: the final GN-apply + Mish + shortcut is NOT launched; its operands are recorded in *tail and the
     // consumer (linattn_kvctx) applies it while loading and writes `out`.
-    void resblock(const ResW& w, const StageBuf& s, const TD& X, const float* tadd, float* out, bool first_layer, LinKvCtxP* tail = nullptr) {
+    // head != null: X (= the previous ResnetBlock's output) has NOT been materialised; *head describes its tail
+    // (raw conv output + GN + res_conv shortcut) and this block's first conv applies it while staging and writes X.
+    // ctail != null: same deferral for THIS block's output towards the next block's first conv.
+    void resblock(const ResW& w, const StageBuf& s, const TD& X, const float* tadd, float* out, bool first_layer, LinKvCtxP* tail = nullptr,
+                  const Pro* head = nullptr, Pro* ctail = nullptr) {
         const long npix = s.npix;
         const float* resptr; int ldres; long resb; bool under = false;
         float* st1 = nullptr;
@@ -718,7 +722,12 @@ struct Runner {
             resptr = s.rbuf; ldres = w.cout; resb = npix * w.cout;
         } else {
             st1 = next_stats();
-            conv3x3("conv3x3", X, s.H, s.W, s.mask_ws, true, w.w1, w.b1, w.cout, s.h1, st1);
+            if (head) {
+                TD H2{s.h2, X.C, 0, X.C};                  // previous block's raw conv2 output
+                conv3x3("conv3x3", H2, s.H, s.W, s.mask_ws, true, w.w1, w.b1, w.cout, s.h1, st1, head);
+            } else {
+                conv3x3("conv3x3", X, s.H, s.W, s.mask_ws, true, w.w1, w.b1, w.cout, s.h1, st1);
+            }
             if (w.wr) {
                 IGemmP g = base_gemm(X.p, X.ld, X.coff, s.H, s.W, X.C, w.wr, w.cout, w.br, s.rbuf, w.cout, 0);
                 g.inmask = mask; g.inmask_ws = s.mask_ws;
@@ -739,6 +748,10 @@ struct Runner {
             gn_apply(s.h1, w.cout, npix, s.W, s.mask_ws, st1, w.g1, w.be1, tadd, nullptr, 0, 0, false, s.a1);
             TD A1{s.a1, w.cout, 0, w.cout};
             conv3x3("conv3x3", A1, s.H, s.W, s.mask_ws, false, w.w2, w.b2, w.cout, s.h2, st2);
+        }
+        if (ctail) {       // res_conv shortcut only (resptr is a dense [npix][cout] buffer, added outside the mask)
+            ctail->stats = st2; ctail->gamma = w.g2; ctail->beta = w.be2; ctail->tadd = nullptr; ctail->res = resptr; ctail->xout = out;
+            return;
         }
         if (tail) {
             tail->H2 = s.h2; tail->gn_stats = st2; tail->gamma = w.g2; tail->beta = w.be2;
@@ -951,11 +964,16 @@ struct Runner {
         TD cur{nullptr, 0, 0, 0};
         for (int i = 0; i < ns; ++i) {
             const StageBuf& s = P.down[i];
-            resblock(x->down_res[i][0], s, cur, P.tadd_down[2 * i], s.r0out, i == 0);
+            // block 0's tail (GN-apply + Mish + res_conv shortcut) rides in block 1's first conv when that conv has the
+            // fused form (bf16 mode, 64/128 channels, block 0 has a res_conv)
+            Pro t0{};
+            const bool defer0 = x->precision == DEX_PREC_BF16 && conv3x3_bf16_tail_supported(s.C) && fast_conv(s.C, s.C) &&
+                                (i == 0 || x->down_res[i][0].wr != nullptr);
+            resblock(x->down_res[i][0], s, cur, P.tadd_down[2 * i], s.r0out, i == 0, nullptr, nullptr, defer0 ? &t0 : nullptr);
             TD r0{s.r0out, s.C, 0, s.C};
             LinKvCtxP tail{};
             const bool defer = linattn_fused(s.C);
-            resblock(x->down_res[i][1], s, r0, P.tadd_down[2 * i + 1], s.r1out, false, defer ? &tail : nullptr);
+            resblock(x->down_res[i][1], s, r0, P.tadd_down[2 * i + 1], s.r1out, false, defer ? &tail : nullptr, defer0 ? &t0 : nullptr);
             TD r1{s.r1out, s.C, 0, s.C};
             linattn(x->down_lin[i], s, r1, s.attn_out, s.attn_ld, s.attn_coff, defer ? &tail : nullptr);
             char nm[16]; snprintf(nm, sizeof nm, "down%d", i);
@@ -986,11 +1004,14 @@ struct Runner {
             const StageBuf& s = P.up[j];
             const int i = ns - 1 - j;
             TD X{P.cat[j], 2 * stage_dim(c, i), 0, 2 * stage_dim(c, i)};
-            resblock(x->up_res[j][0], s, X, P.tadd_up[2 * j], s.r0out, false);
+            Pro t0{};
+            const bool defer0 = x->precision == DEX_PREC_BF16 && conv3x3_bf16_tail_supported(s.C) && fast_conv(s.C, s.C) &&
+                                x->up_res[j][0].wr != nullptr;
+            resblock(x->up_res[j][0], s, X, P.tadd_up[2 * j], s.r0out, false, nullptr, nullptr, defer0 ? &t0 : nullptr);
             TD r0{s.r0out, s.C, 0, s.C};
             LinKvCtxP tail{};
             const bool defer = linattn_fused(s.C);
-            resblock(x->up_res[j][1], s, r0, P.tadd_up[2 * j + 1], s.r1out, false, defer ? &tail : nullptr);
+            resblock(x->up_res[j][1], s, r0, P.tadd_up[2 * j + 1], s.r1out, false, defer ? &tail : nullptr, defer0 ? &t0 : nullptr);
             TD r1{s.r1out, s.C, 0, s.C};
             linattn(x->up_lin[j], s, r1, s.attn_out, s.C, 0, defer ? &tail : nullptr);
             char nm[16]; snprintf(nm, sizeof nm, "up%d", j);

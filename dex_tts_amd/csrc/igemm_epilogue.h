@@ -40,6 +40,32 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmP& p, f32x16 (&acc)[MT
     float gs = 0.f, gss = 0.f;                   // GroupNorm partials of this lane's column
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
+        // Fast path: the 32 rows of this tile are 32 consecutive pixels of ONE output row, all in range (every layer of
+        // the network at widths that are multiples of 32, and every Linear).  One division per tile, one 64-bit base per
+        // tensor, 32-bit row offsets — the generic path below spends ~40 integer instructions per element.
+        const int mt0 = m0 + row0 + t * 32;
+        const int ho_t = mt0 / p.Wo, wo_t = mt0 - ho_t * p.Wo;
+        if (!unp && mt0 + 32 <= M && wo_t + 32 <= p.Wo) {
+            const int oh = ho_t * p.osh + oh0, ow0_ = (wo_t + 4 * hh) * p.osw + ow0;
+            const long pix0 = (long)oh * p.OWf + ow0_;
+            float* cp = Cb + pix0 * p.ldc + col_out;
+            const float* rp = Rb ? Rb + pix0 * p.ldres + ng : nullptr;
+            const float* mp = omask ? omask + (long)ow0_ * p.outmask_ws : nullptr;
+            const int cs = p.osw * p.ldc, rs = p.osw * p.ldres, ms = p.osw * p.outmask_ws;
+            float rv[16], mk[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = rp ? rp[((r & 3) + 8 * (r >> 2)) * rs] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mk[r] = mp ? mp[((r & 3) + 8 * (r >> 2)) * ms] : 1.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = acc[t][r] + bias;
+                gs += v; gss = fmaf(v, v, gss);
+                if (p.act == 1) v = gelu_erf(v);
+                cp[((r & 3) + 8 * (r >> 2)) * cs] = (v * gate + rv[r]) * mk[r];
+            }
+            continue;
+        }
         int opix[16], ow_[16];
         bool ok[16];
 #pragma unroll

@@ -50,11 +50,16 @@ struct Conv3P {
     const float* X; int ldx; int x_coff; int H, W, Cin, Cout;
     const void* Wbf; const float* bias; float* Y;            // bf16 [Cout][9*Cin]; Y is [B,H,W,Cout] contiguous
     const float* mask; int mask_ws; long mask_bstride;
-    const float* pro_stats; const float* pro_gamma; const float* pro_beta; const float* pro_tadd;
+    const float* pro_stats; const float* pro_gamma; const float* pro_beta; const float* pro_tadd;   // tadd may be null
+    // second prologue form (pro_res != null): the input is the preceding ResnetBlock's tail,
+    //   x = mask * Mish(GN(X)) + pro_res   (res_conv shortcut, diffusion.py:67-71), [H*W][Cin] like X;
+    // the kernel also writes x for its own output pixels to pro_xout ([H*W][Cin]) for the later consumers.
+    const float* pro_res; float* pro_xout;
     const int* step; float* gn_stats; int B;
     long long* dbg;                                          // optional phase timestamps (tools/kbench)
 };
 bool conv3x3_bf16_supported(int Cin, int Cout);
+bool conv3x3_bf16_tail_supported(int C);     // pro_res form (Cin == Cout == C)
 void launch_conv3x3_bf16(const Conv3P& p, hipStream_t st);
 
 // First ResnetBlock of the U-Net: 3x3 conv and 1x1 res_conv straight from the stacked input planes
