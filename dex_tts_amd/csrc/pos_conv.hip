@@ -34,8 +34,15 @@ __global__ __launch_bounds__(256) void pos_conv_direct_kernel(const PosConvP p) 
     u16* patch = reinterpret_cast<u16*>(smem_pc);          // [nrows][PW][LDP]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
-    const int w0 = blockIdx.x * CW, ho = blockIdx.y, b = blockIdx.z / p.G, g = blockIdx.z % p.G;
+    // XCD-aware decomposition: workgroup id % 8 selects the XCD (round-robin dispatch) and each XCD has a private L2, so
+    // the group index lives in the low bits — an XCD then only ever fetches ONE group's 512 KB of weights (with the
+    // group in grid.z every XCD pulled all 4 MB: PMC FETCH_SIZE showed 38 MB per launch at B=1).
     const int Hf = p.Hf, Wt = p.Wt;
+    const int nchunk = (Wt + CW - 1) / CW;
+    const int g = blockIdx.x % p.G;
+    int rest = blockIdx.x / p.G;
+    const int w0 = (rest % nchunk) * CW; rest /= nchunk;
+    const int ho = rest % Hf, b = rest / Hf;
     const int hi_lo = max(0, ho - PAD), hi_hi = min(Hf, ho + PAD);          // input rows [hi_lo, hi_hi)
     const int nrows = hi_hi - hi_lo;
     const int kh_lo = hi_lo - ho + PAD;                                     // kh of input row hi: hi - ho + PAD
@@ -151,7 +158,7 @@ static void launch_pc(const PosConvP& p, hipStream_t st) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&pos_conv_direct_kernel<CT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    dim3 grid((p.Wt + 32 * CT - 1) / (32 * CT), p.Hf, p.B * p.G);
+    dim3 grid((unsigned)(((p.Wt + 32 * CT - 1) / (32 * CT)) * p.Hf * p.B * p.G));
     hipLaunchKernelGGL(pos_conv_direct_kernel<CT>, grid, dim3(256), lds, st, p);
 }
 
