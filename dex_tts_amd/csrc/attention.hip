@@ -17,31 +17,47 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int HD = 128;
 constexpr int KT_LD = 33;                 // K^T tile [128 d][32 keys + 1]
 constexpr int O_LD = 132;                 // merged O tile [32 queries][128 d + 4]
-constexpr int WAVE_LDS = HD * KT_LD;      // 4224 floats == 32 * 132
+constexpr int V_LD = HD + 8;               // V tile [32 keys][128 d + 8]: rows 4 apart land 32 banks apart (the two half-waves of a
+                                          // PV step read keys 4 apart), 544-B rows keep ds_write_b128 aligned
+constexpr int WAVE_LDS = 32 * V_LD;       // 4352 floats >= HD * KT_LD (4224) >= 32 * O_LD: K^T, then V, then the merged O tile
 constexpr int Q_LD = HD + 1;              // shared Q tile row stride (odd: conflict-free column reads)
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void attn_f32_kernel(const AttnP p) {
+// QREG: the pre-scaled Q fragments live in 64 VGPRs instead of a shared LDS tile — the 4-wave variant then needs
+// 70 KB of LDS and 2 workgroups share a CU, so one workgroup's prologue / partial merge hides under the other's MFMAs.
+template <int NW, bool QREG>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QREG ? 2 : 1, 8))) void attn_f32_kernel(const AttnP p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
     const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
     float* kT = smem + wave * WAVE_LDS;
     float* stat = smem + NW * WAVE_LDS;                     // [NW][2][32]
-    float* qS = stat + NW * 64;                             // [32 queries][Q_LD]  pre-scaled Q tile, shared by all waves
+    float* qS = stat + NW * 64;                             // [32 queries][Q_LD]  pre-scaled Q tile, shared by all waves (!QREG)
     int Nk = p.Nk;
     if (p.kv_len) Nk = min(p.Nk, p.kv_len[b] + p.kv_len_add);
     const float* Qb = p.Q + (long)b * p.qb + h * HD;
     const float* Kb = p.K + (long)b * p.kb + h * HD;
     const float* Vb = p.V + (long)b * p.vb + h * HD;
 
-    // Q tile -> LDS (keeps 64 VGPRs free for the K prefetch; the B operand of S^T is one ds_read_b32 per MFMA)
-    for (int it = tid; it < 32 * (HD / 4); it += NW * 64) {
-        const int qi = it / (HD / 4), d4 = (it % (HD / 4)) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q0 + qi < p.Nq) v = *reinterpret_cast<const float4*>(Qb + (long)(q0 + qi) * p.ldq + d4);
-        float* d = qS + qi * Q_LD + d4;
-        d[0] = v.x * p.scale; d[1] = v.y * p.scale; d[2] = v.z * p.scale; d[3] = v.w * p.scale;
+    float qreg[QREG ? 64 : 1];
+    if constexpr (QREG) {
+        // B operand of S^T: lane (query i, half hh) holds Q[q0 + i][hh*64 + kk] * scale, kk = 0..63
+        const float sc = q0 + i < p.Nq ? p.scale : 0.f;
+        const float* qp = Qb + (long)min(q0 + i, p.Nq - 1) * p.ldq + hh * 64;
+#pragma unroll
+        for (int k4 = 0; k4 < 16; ++k4) {
+            const float4 v = *reinterpret_cast<const float4*>(qp + k4 * 4);
+            qreg[k4 * 4 + 0] = v.x * sc; qreg[k4 * 4 + 1] = v.y * sc; qreg[k4 * 4 + 2] = v.z * sc; qreg[k4 * 4 + 3] = v.w * sc;
+        }
+    } else {
+        // Q tile -> LDS (the B operand of S^T is one ds_read_b32 per MFMA)
+        for (int it = tid; it < 32 * (HD / 4); it += NW * 64) {
+            const int qi = it / (HD / 4), d4 = (it % (HD / 4)) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q0 + qi < p.Nq) v = *reinterpret_cast<const float4*>(Qb + (long)(q0 + qi) * p.ldq + d4);
+            float* d = qS + qi * Q_LD + d4;
+            d[0] = v.x * p.scale; d[1] = v.y * p.scale; d[2] = v.z * p.scale; d[3] = v.w * p.scale;
+        }
     }
     f32x16 o[4];
 #pragma unroll
@@ -53,20 +69,32 @@ __global__ __launch_bounds__(NW * 64) void attn_f32_kernel(const AttnP p) {
     const int ntiles = (Nk + 31) / 32;
     // K tile gather map: per instruction a 32-lane half covers 4 keys x 32 d (128-B coalesced rows); the LDS image
     // is K^T[d][key] with bank = (d + key) % 32 -> conflict-free writes and reads.
-    float4 kreg[16];
-    auto kload = [&](int kt) {
-        const int k0 = kt * 32;
+    // One 64-register staging buffer carries K, then V, then the next K: the V loads fly under the S^T MFMAs, the
+    // next K loads under the PV MFMAs.  Both tiles go through the wave-private LDS region (K transposed, V as is):
+    // reading V straight from global, one dword per lane per MFMA, made the PV phase 2.7x slower than S^T.
+    typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vectors: arrays of HIP's float4 struct can defeat SROA
+    f32x4 kreg[16];
+    // gather map of a 32x128 tile: per instruction a 32-lane half covers 4 rows x 32 d (128-B coalesced row segments)
+    {   // (unconditional: a wave without tiles loads a clamped tile it never uses — keeps the array in registers)
+        const int k0 = min(wave, max(ntiles - 1, 0)) * 32;
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int key = (it >> 2) * 8 + hh * 4 + (i >> 3);
             const int dd = (it & 3) * 32 + (i & 7) * 4;
-            kreg[it] = *reinterpret_cast<const float4*>(Kb + (long)min(k0 + key, Nk - 1) * p.ldk + dd);
+            kreg[it] = *reinterpret_cast<const f32x4*>(Kb + (long)min(k0 + key, Nk - 1) * p.ldk + dd);
         }
-    };
-    if (wave < ntiles) kload(wave);
+    }
     __syncthreads();                                        // Q tile visible
+#ifdef DEX_TIMING
+    long long tA = 0, tB = 0, tC = 0, tD = 0, t0_ = clock64(), w0_ = wall_clock64();
+#endif
     for (int kt = wave; kt < ntiles; kt += NW) {
         const int k0 = kt * 32;
+        const int kn = min(kt + NW, ntiles - 1) * 32;       // next tile of this wave (clamped re-read at the tail)
+#ifdef DEX_TIMING
+        long long c0 = clock64();
+#endif
+        // K -> K^T[d][key] (bank = (d + key) % 32: conflict-free writes and reads)
 #pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int key = (it >> 2) * 8 + hh * 4 + (i >> 3);
@@ -76,7 +104,17 @@ __global__ __launch_bounds__(NW * 64) void attn_f32_kernel(const AttnP p) {
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes landed (wave-private tile)
         __builtin_amdgcn_wave_barrier();
-        if (kt + NW < ntiles) kload(kt + NW);               // prefetch the next tile of this wave behind the MFMAs
+        // V tile of the same keys into the staging registers, behind the S^T MFMAs
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int key = (it >> 2) * 8 + hh * 4 + (i >> 3);
+            const int dd = (it & 3) * 32 + (i & 7) * 4;
+            kreg[it] = *reinterpret_cast<const f32x4*>(Vb + (long)min(k0 + key, Nk - 1) * p.ldv + dd);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef DEX_TIMING
+        long long c1 = clock64(); tA += c1 - c0;
+#endif
         // ---- S^T[key][query] = sum_d K[key][d] * Qs[query][d]
         f32x16 sT;
 #pragma unroll
@@ -85,7 +123,10 @@ __global__ __launch_bounds__(NW * 64) void attn_f32_kernel(const AttnP p) {
         const float* qa = qS + i * Q_LD + hh * 64;
 #pragma unroll
         for (int kk = 0; kk < 64; ++kk)
-            sT = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[kk * KT_LD], qa[kk], sT, 0, 0, 0);
+            sT = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[kk * KT_LD], QREG ? qreg[kk] : qa[kk], sT, 0, 0, 0);
+#ifdef DEX_TIMING
+        asm volatile("s_nop 0" :: "v"(sT[0]), "v"(sT[15])); long long c2 = clock64(); tB += c2 - c1;
+#endif
         // ---- online softmax over this lane's 16 keys (+ partner half via xor 32)
         float mx = -INFINITY;
 #pragma unroll
@@ -106,17 +147,42 @@ __global__ __launch_bounds__(NW * 64) void attn_f32_kernel(const AttnP p) {
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        // V -> LDS as V[key][d] over the K^T image (S^T is done with it), 16-byte stores
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int key = (it >> 2) * 8 + hh * 4 + (i >> 3);
+            const int dd = (it & 3) * 32 + (i & 7) * 4;
+            *reinterpret_cast<f32x4*>(kT + key * V_LD + dd) = kreg[it];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int key = (it >> 2) * 8 + hh * 4 + (i >> 3);
+            const int dd = (it & 3) * 32 + (i & 7) * 4;
+            kreg[it] = *reinterpret_cast<const f32x4*>(Kb + (long)min(kn + key, Nk - 1) * p.ldk + dd);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef DEX_TIMING
+        asm volatile("s_nop 0" :: "v"(o[0][0]), "v"(sT[15])); long long c3 = clock64(); tC += c3 - c2;
+#endif
         // ---- O^T[d][query] += sum_key V[key][d] * P[query][key];  step s uses key(s,hh) on both operands
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            const int key = min(k0 + (s & 3) + 8 * (s >> 2) + 4 * hh, Nk - 1);
-            const float* vp = Vb + (long)key * p.ldv + i;
+            const float* vp = kT + ((s & 3) + 8 * (s >> 2) + 4 * hh) * V_LD + i;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
                 o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[t * 32], sT[s], o[t], 0, 0, 0);
         }
         __builtin_amdgcn_wave_barrier();
+#ifdef DEX_TIMING
+        asm volatile("s_nop 0" :: "v"(o[0][0]), "v"(o[3][15])); tD += clock64() - c3;
+#endif
     }
+#ifdef DEX_TIMING
+    if (p.dbg && lane == 0 && wave == 0) { long long* d = p.dbg + ((long)blockIdx.x + gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z)) * 8; d[0] = tA; d[1] = tB; d[2] = tC; d[3] = tD; d[4] = clock64() - t0_; d[5] = wall_clock64() - w0_; }
+#endif
     // ---- merge the NW partials through LDS (reuse the K^T region as O[query][d])
     l_run += __shfl_xor(l_run, 32);
     __syncthreads();                                       // every wave is done with its K^T tile
@@ -155,32 +221,32 @@ __global__ __launch_bounds__(NW * 64) void attn_f32_kernel(const AttnP p) {
 
 void launch_attention_bf16(const AttnP& p, hipStream_t st);   // attention_bf16.hip
 
-template <int NW>
+template <int NW, bool QREG>
 static void launch_attn_nw(const AttnP& p, hipStream_t st) {
-    const size_t lds = (size_t)(NW * WAVE_LDS + NW * 64 + 32 * Q_LD) * sizeof(float);
+    const size_t lds = (size_t)(NW * WAVE_LDS + NW * 64 + (QREG ? 0 : 32 * Q_LD)) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_kernel<NW, QREG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     dim3 grid((p.Nq + 31) / 32, p.heads, p.B);
-    hipLaunchKernelGGL((attn_f32_kernel<NW>), grid, dim3(NW * 64), lds, st, p);
+    hipLaunchKernelGGL((attn_f32_kernel<NW, QREG>), grid, dim3(NW * 64), lds, st, p);
 }
 
 void launch_attention(const AttnP& p, int precision, hipStream_t st) {
     if (precision == 1) { launch_attention_bf16(p, st); return; }
     const long blocks = (long)((p.Nq + 31) / 32) * p.heads * p.B;
     const int ntiles = (p.Nk + 31) / 32;
-    // enough waves to cover ~1024 SIMDs, but never more waves than key tiles
-    // 8 waves per workgroup = 2 per SIMD: one wave's K staging / softmax hides behind the other's MFMA chain
-    // (measured at B=32 N=1300: 69 -> 78 TF/s vs 2 or 4 waves at one wave per SIMD)
+    // Many query tiles (batch): 4 key-splitting waves with Q in registers, two workgroups per CU (2 waves per SIMD as
+    // well, but one workgroup's prologue and partial merge overlap the other's MFMA loop).  Few query tiles: 8 waves
+    // per workgroup split the keys further; never more waves than key tiles.
+    if (blocks > 256 && ntiles >= 8) { launch_attn_nw<4, true>(p, st); return; }
     int nw = 8;
     if (ntiles < 8) nw = 4;
     if (ntiles < 4) nw = 2;
-    (void)blocks;
-    if (nw == 8) launch_attn_nw<8>(p, st);
-    else if (nw == 4) launch_attn_nw<4>(p, st);
-    else launch_attn_nw<2>(p, st);
+    if (nw == 8) launch_attn_nw<8, false>(p, st);
+    else if (nw == 4) launch_attn_nw<4, false>(p, st);
+    else launch_attn_nw<2, false>(p, st);
 }
 
 }  // namespace dex

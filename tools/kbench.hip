@@ -104,6 +104,16 @@ int main() {
         a.O = o; a.ldo = 256; a.ob = (long)N * 256; a.Nq = N; a.Nk = N; a.heads = 2; a.scale = 0.088f; a.B = Bb;
         char nm[64];
         snprintf(nm, 64, "attention fp32 B=%d N=%d", Bb, N); timeit(nm, 10, 4.0 * Bb * N * (double)N * 256, 16.0 * Bb * N * 256, [&] { launch_attention(a, 0, 0); });
+#ifdef DEX_TIMING
+        {
+            const int nb = ((N + 31) / 32) * 2 * Bb;
+            long long* dbg; hipMalloc(&dbg, nb * 64); hipMemset(dbg, 0, nb * 64);
+            a.dbg = dbg; launch_attention(a, 0, 0); hipDeviceSynchronize(); a.dbg = nullptr;
+            std::vector<long long> h(nb * 8); hipMemcpy(h.data(), dbg, nb * 64, hipMemcpyDeviceToHost);
+            for (int bl : {0, nb / 2, nb - 1}) { long long* d = &h[bl * 8];
+                printf("   wg %4d wave0: K stage=%lld S^T=%lld softmax=%lld PV=%lld loop total=%lld cycles, wall=%lld x10ns -> %.2f GHz\n", bl, d[0], d[1], d[2], d[3], d[4], d[5], d[4] / (d[5] * 10.0)); }
+        }
+#endif
         snprintf(nm, 64, "attention bf16 B=%d N=%d", Bb, N); timeit(nm, 10, 4.0 * Bb * N * (double)N * 256, 16.0 * Bb * N * 256, [&] { launch_attention(a, 1, 0); });
         hipFree(qkv); hipFree(o);
     }
