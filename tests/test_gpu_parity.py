@@ -175,6 +175,9 @@ def test_bf16_mfma_mode_tolerance(name, kw):
     ("gedex_lj", dict(B=1, T=512)),                                   # key-split attention partials (3 splits), 160-wg context pass
     ("gedex_lj", dict(B=26, T=512, lengths=[512 - 7 * i for i in range(26)])),   # batch regime: full-key attention kernel
     ("dex_vctk", dict(B=1, T=512, lengths=[500], Tr=348, Ts=348, sty_lengths=[301])),   # N=2580 tokens, 4 key splits
+    ("gedex_lj", dict(B=3, T=260, lengths=[260, 200, 96])),          # widths that are no multiple of 32 anywhere: every tail path
+    ("dex_vctk", dict(B=2, T=132, lengths=[132, 77], Tr=100, Ts=100, sty_lengths=[100, 64])),
+    ("gedex_vctk", dict(B=2, T=96, lengths=[96, 50])),               # speaker plane (3-plane first conv)
 ])
 def test_bf16_mode_full_size_shapes(name, kw):
     """The BASELINE.json-sized shapes pick kernel variants the small oracle cases never reach (key-split attention
