@@ -64,6 +64,8 @@ __global__ __launch_bounds__(256) void linattn_kvctx_kernel(const LinKvCtxP p) {
     // prefetched one iteration ahead.  PRO: the rows are the raw conv output + the residual, turned into x below.
     float4 xa[KS], xc[KS], ra[PRO ? KS : 1], rc[PRO ? KS : 1];
     float mkv = 1.f;
+    float ga_pre = 0.f, be_pre = 0.f;                       // GroupNorm affine of channel tid, requested with the first loads
+    if constexpr (PRO) { if (tid < C) { ga_pre = p.gamma[tid]; be_pre = p.beta[tid]; } }
     {
         const int pxr = min(px_base + i, p.npix - 1);
         const float* xr = X + (long)pxr * ldx + hh * 8;
@@ -105,9 +107,9 @@ __global__ __launch_bounds__(256) void linattn_kvctx_kernel(const LinKvCtxP p) {
     __syncthreads();
     if constexpr (PRO) {
         if (tid < C) {
-            const float ga = p.gamma[tid] * srstd[tid / (C / 8)];
+            const float ga = ga_pre * srstd[tid / (C / 8)];
             gsc_s[tid] = ga;
-            gsh_s[tid] = p.beta[tid] - smean[tid / (C / 8)] * ga;
+            gsh_s[tid] = be_pre - smean[tid / (C / 8)] * ga;
         }
         __syncthreads();
     }
