@@ -3,6 +3,7 @@
 // pointers + hipStream_t only.  Reference call chain replaced: GeDEX-TTS/model/diffusion.py:220-229 ->
 // model/edm.py:109-216 -> :88-98 -> diffusion.py:168-207 (+ model/dit.py:485-525, DEX ref_encoder.py).
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <cmath>
 #include <cstdarg>
@@ -522,7 +523,8 @@ struct Plan {
     float *up_out, *hF;
     int Hm, Wm, Hf, Wt, N;
     float *pe0, *emb, *pos_part, *tok, *xn, *qkv, *ao, *att_ml, *hmlp, *dbg_tok;
-    void *qh, *kh, *vt; int Npad; size_t vt_bytes;          // bf16 attention operands of the row-chain path
+    void *qh, *kh, *vt, *qh2, *kh2, *vt2; int Npad; size_t vt_bytes;   // bf16 attention operands of the row-chain path (two sets:
+                                                                        // a fused block reads one while its workgroups write the other)
     float *tv_keys, *tv_K, *tv_V, *tv_q, *tv_ao, *tv_out, *tiv_out, *tv_weff, *tv_beff; double *tv_stats, *tiv_stats;
     size_t bytes;
 };
@@ -597,6 +599,7 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
     P.xn = A.f(tok * hid); P.qkv = A.f(tok * 3 * hid); P.ao = A.f(tok * hid * ATT_KSPLIT_MAX); P.att_ml = A.f(tok * c.dit_heads * 2 * ATT_KSPLIT_MAX);
     P.Npad = (P.N + 31) / 32 * 32; P.vt_bytes = (size_t)B * hid * P.Npad * 2;
     P.qh = A.take(P.vt_bytes); P.kh = A.take(P.vt_bytes); P.vt = A.take(P.vt_bytes);    // all three padded to Npad rows
+    P.qh2 = A.take(P.vt_bytes); P.kh2 = A.take(P.vt_bytes); P.vt2 = A.take(P.vt_bytes);
     P.hmlp = A.f(tok * mlp_hidden(c));
     P.dbg_tok = A.f(tok * hid * (c.dit_depth + 1));
     P.tv_keys = P.tv_K = P.tv_V = P.tv_q = P.tv_ao = P.tv_out = P.tiv_out = P.tv_weff = P.tv_beff = nullptr;
@@ -833,14 +836,19 @@ struct Runner {
             DitChainP ch{};
             if (chain) {
                 ch.ksplit = 0; ch.heads = c.dit_heads; ch.rows_per_batch = N; ch.X = P.tok; ch.ada = ada; ch.step = sp; ch.M = B * N; ch.B = B;
-                ch.Qh = P.qh; ch.Kh = P.kh; ch.Vt = P.vt; ch.Npad = P.Npad;
+                // operand set k & 1 is read by block k (separate attention kernel or in-kernel attention), the other is written
+                ch.Qh = (k & 1) ? P.qh : P.qh2; ch.Kh = (k & 1) ? P.kh : P.kh2; ch.Vt = (k & 1) ? P.vt : P.vt2;
+                ch.Qin = (k & 1) ? P.qh2 : P.qh; ch.Kin = (k & 1) ? P.kh2 : P.kh; ch.Vin = (k & 1) ? P.vt2 : P.vt;
+                ch.Npad = P.Npad;
                 ch.qscale = scale * 1.4426950408889634f;      // log2(e) folded in: the attention kernels use exp2
             }
             if (chain && k == 0) {                                   // first block: LN + modulate + qkv only
                 ch.qkv_only = 1; ch.Wq = x->frag_of.at(w.wqkv); ch.bq = w.bqkv;
+                ch.Qh = P.qh; ch.Kh = P.kh; ch.Vt = P.vt;        // block 0 reads set 0
                 ch.next_shift = ada; ch.next_scale = ada + hid; ch.next_step_stride = 6L * hid;
                 run("dit_qkv", 2.0 * B * N * 3.0 * hid * hid, 4.0 * B * N * hid + 2.0 * B * N * 3 * hid, [&] { launch_dit_rowchain(ch, st); });
                 ch.qkv_only = 0; ch.Wq = nullptr; ch.bq = nullptr; ch.next_shift = ch.next_scale = nullptr;
+                ch.Qh = P.qh2; ch.Kh = P.kh2; ch.Vt = P.vt2;     // ... and writes set 1
             }
             if (!chain) {
                 IGemmP q = base_gemm(fuse_ln ? P.tok : P.xn, hid, 0, 1, N, hid, w.wqkv, 3 * hid, w.bqkv, P.qkv, 3 * hid, 0);
@@ -854,13 +862,21 @@ struct Runner {
             if (chain) {
                 // few workgroups (small batch): split the keys over up to 4 workgroups per query tile so a wave sees
                 // one or two key tiles (one global round trip); the row-chain kernel merges the partials on load
-                const long blocks = (long)((N + 31) / 32) * 2 * B;
-                const int ntiles = (N + 31) / 32;
-                const int ks = (int)std::max<long>(1, std::min<long>(std::min<long>(768 / blocks, (ntiles + 7) / 8), ATT_KSPLIT_MAX));
-                AttnDirectP ad{P.qh, P.kh, P.vt, N, P.Npad, B, P.ao, (long)B * N * hid, ks > 1 ? P.att_ml : nullptr, ks, nullptr};
-                run("dit_attention", 4.0 * B * (double)N * N * hid, 2.0 * 3 * B * N * hid + 4.0 * B * N * hid * ks, [&] { launch_attention_direct(ad, st); });
+                // The attention core runs inside the row-chain launch (dit_rowchain_kernel<true>): every workgroup computes
+                // the attention of its own 32 queries for both heads, so no attention launch and no partials in HBM.
+                // DEX_ATTN_SEPARATE=1 restores the separate kernels (attention_direct.hip) for A/B measurements.
+                static const bool separate = getenv("DEX_ATTN_SEPARATE") && atoi(getenv("DEX_ATTN_SEPARATE"));
+                int ks = 1;
+                if (separate) {
+                    const long blocks = (long)((N + 31) / 32) * 2 * B;
+                    const int ntiles = (N + 31) / 32;
+                    ks = (int)std::max<long>(1, std::min<long>(std::min<long>(768 / blocks, (ntiles + 7) / 8), ATT_KSPLIT_MAX));
+                    AttnDirectP ad{ch.Qin, ch.Kin, ch.Vin, N, P.Npad, B, P.ao, (long)B * N * hid, ks > 1 ? P.att_ml : nullptr, ks, nullptr};
+                    run("dit_attention", 4.0 * B * (double)N * N * hid, 2.0 * 3 * B * N * hid + 4.0 * B * N * hid * ks, [&] { launch_attention_direct(ad, st); });
+                }
+                ch.attn_inline = separate ? 0 : 1;
                 const bool last = k + 1 == c.dit_depth;
-                ch.O = P.ao; ch.ksplit = ks; ch.o_sstride = ad.o_sstride; ch.ml = P.att_ml;
+                ch.O = P.ao; ch.ksplit = ks; ch.o_sstride = (long)B * N * hid; ch.ml = P.att_ml;
                 ch.Wp = x->frag_of.at(w.wproj); ch.W1 = x->frag_of.at(w.wfc1); ch.W2 = x->frag_of.at(w.wfc2);
                 ch.bp = w.bproj; ch.b1 = w.bfc1; ch.b2 = w.bfc2;
                 if (!last) {
@@ -870,7 +886,8 @@ struct Runner {
                 }
                 const double M = (double)B * N;
                 const double wel = (double)hid * hid + 2.0 * hid * mh + (last ? 0.0 : 3.0 * hid * hid);
-                run("dit_rowchain", 2.0 * M * wel, 4.0 * M * hid * (last ? 3 : 6) + 2.0 * wel, [&] { launch_dit_rowchain(ch, st); });
+                run(separate ? "dit_rowchain" : "dit_block", 2.0 * M * wel + (separate ? 0.0 : 4.0 * B * (double)N * N * hid),
+                    4.0 * M * hid * (last ? 3 : 6) + 2.0 * wel, [&] { launch_dit_rowchain(ch, st); });
                 if (debug) {
                     float* dst = P.dbg_tok + (size_t)(k + 1) * B * N * hid;
                     hipMemcpyAsync(dst, P.tok, (size_t)B * N * hid * 4, hipMemcpyDeviceToDevice, st);
@@ -1050,6 +1067,7 @@ struct Runner {
             run("cond_mlp", 2.0 * rows * K * N, 4.0 * K * N, [&] { launch_small_linear(s, st); });
         };
         hipMemsetAsync(P.vt, 0, P.vt_bytes, st);      // key padding of the transposed V operand (attention_direct.hip)
+        hipMemsetAsync(P.vt2, 0, P.vt_bytes, st);
         CondPrepP cp{sigmas_dev, n, c.pe_scale, dim, P.scal, SCAL_STRIDE, P.t_unet, P.t_dit};
         run("cond_prep", 0, 0, [&] { launch_cond_prep(cp, st); });
         lin(P.t_unet, dim, n, dim, "mlp.0", true, 4 * dim, P.tmp_u, 0, 1);

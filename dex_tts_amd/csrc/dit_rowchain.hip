@@ -29,6 +29,8 @@ constexpr int RC_H = 256, RC_MLP = 512, RC_ROWS = 32, RC_NW = 8;
 constexpr int A_LD = RC_H + 8;       // bf16 elements; row stride 528 B: b128 reads of 16 rows hit 64 distinct banks
 constexpr int H_LD = RC_MLP + 8;
 constexpr int X_LD = RC_H + 4;       // floats
+constexpr int AT_LD = 132;           // attention partial O tile row stride (floats)
+constexpr size_t RC_LDS_ATTN = (size_t)(RC_NW * 32 * AT_LD + RC_NW * 64) * sizeof(float);
 constexpr size_t RC_LDS = (size_t)RC_ROWS * (A_LD + H_LD) * sizeof(u16) + (size_t)RC_ROWS * X_LD * sizeof(float) + 4 * RC_H * sizeof(float);
 
 // exact-erf GELU with erf from Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7, far below the bf16 rounding the value
@@ -165,6 +167,10 @@ __device__ __forceinline__ void store_qkv_tile(const DitChainP& p, const f32x16&
 
 }  // namespace
 
+// ATTN: the attention core of the block runs INSIDE this launch (no attention kernel, no partials in HBM): waves 0-3 take
+// head 0, waves 4-7 head 1, each group splits the key tiles four ways (attention_direct.hip's wave body), the partial
+// (m, l, O) are merged through LDS straight into the bf16 A tile of the projection.
+template <bool ATTN>
 __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChainP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_rc[];
     u16* As = reinterpret_cast<u16*>(smem_rc);                 // [32][A_LD]  bf16 A operand (O, then LN outputs)
@@ -185,12 +191,14 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
     long long tst[10] = {0,0,0,0,0,0,0,0,0,0};
     tst[0] = wall_clock64();
 #endif
-    {   // both LayerNorm parameter sets -> LDS now (a dependent L2 round trip inside each LN otherwise)
+    float2 lnv;
+    {   // both LayerNorm parameter sets -> LDS (a dependent L2 round trip inside each LN otherwise)
         const int which = tid >> 7, c2 = (tid & 127) * 2;       // 512 threads x 2 floats = 4 x 256
         const float* src = which == 0 ? ada + 3 * RC_H : which == 1 ? ada + 4 * RC_H
                          : which == 2 ? (has_q ? p.next_shift + (long)step * p.next_step_stride : ada)
                                       : (has_q ? p.next_scale + (long)step * p.next_step_stride : ada);
-        *reinterpret_cast<float2*>(LNp + which * RC_H + c2) = *reinterpret_cast<const float2*>(src + c2);
+        lnv = *reinterpret_cast<const float2*>(src + c2);
+        if (!ATTN || p.qkv_only) *reinterpret_cast<float2*>(LNp + which * RC_H + c2) = lnv;     // ATTN: the LDS is attention scratch first
     }
     uint4 wa[16], wb[16];
     const int col = wave * 32 + i;
@@ -205,6 +213,95 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
 #pragma unroll
         for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(X1 + row * X_LD + q * 64 + seg * 4) = *reinterpret_cast<const float4*>(src + q * 64);
     } else {
+    f32x16 ao[4];
+    float am = -INFINITY, al = 0.f;
+    if constexpr (ATTN) {
+        union DFr { uint4 u; bf16x8 v; };
+        const int head = wave >> 2, part = wave & 3;
+        const long hbq = ((long)b * 2 + head) * p.Npad * 16;
+        const uint4* Qg = reinterpret_cast<const uint4*>(p.Qin) + hbq + lane;
+        const uint4* Kg = reinterpret_cast<const uint4*>(p.Kin) + hbq + lane;
+        const uint4* Vg = reinterpret_cast<const uint4*>(p.Vin) + hbq + lane;
+        const int ntiles = (N + 31) / 32;
+        DFr qf[8], kf[8], vf[4][2];
+        int kt = part;
+        {
+            const uint4* qp = Qg + (long)(n0 >> 5) * 512;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) qf[ks].u = qp[ks * 64];
+            const uint4* kp = Kg + (long)min(kt, ntiles - 1) * 512;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) kf[ks].u = kp[ks * 64];
+            const uint4* vp = Vg + (long)min(kt, ntiles - 1) * 512;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) vf[t][k2].u = vp[(t * 2 + k2) * 64];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ao[t][r] = 0.f;
+        while (kt < ntiles) {
+            const int k0 = kt * 32, kn = kt + 4;
+            f32x16 sc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks].v, qf[ks].v, sc, 0, 0, 0);
+            if (kn < ntiles) {
+                const uint4* kp = Kg + (long)kn * 512;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) kf[ks].u = kp[ks * 64];
+            }
+            if (k0 + 32 > N) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) if (k0 + (r & 3) + 8 * (r >> 2) + 4 * hh >= N) sc[r] = -INFINITY;
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(am, mx);
+            const float alpha = exp2f(am - m_new);               // scores are in the log2 domain (q scale carries log2 e)
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sc[r] = __builtin_amdgcn_exp2f(sc[r] - m_new); psum += sc[r]; }
+            al = al * alpha + psum;
+            am = m_new;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ao[t][r] *= alpha;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                DFr pb;
+                pb.u.x = pack2_bf16(sc[8 * k2 + 0], sc[8 * k2 + 1]); pb.u.y = pack2_bf16(sc[8 * k2 + 2], sc[8 * k2 + 3]);
+                pb.u.z = pack2_bf16(sc[8 * k2 + 4], sc[8 * k2 + 5]); pb.u.w = pack2_bf16(sc[8 * k2 + 6], sc[8 * k2 + 7]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) ao[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[t][k2].v, pb.v, ao[t], 0, 0, 0);
+            }
+            if (kn < ntiles) {
+                const uint4* vp = Vg + (long)kn * 512;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) vf[t][k2].u = vp[(t * 2 + k2) * 64];
+            }
+            kt = kn;
+        }
+        al += __shfl_xor(al, 32);
+        // partial (m, l, O[query][d]) of this wave -> LDS scratch (the chain's buffers are not live yet)
+        float* scr = reinterpret_cast<float*>(smem_rc);
+        float* oS = scr + wave * (32 * AT_LD);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq)
+                *reinterpret_cast<float4*>(oS + i * AT_LD + t * 32 + 8 * rq + 4 * hh) =
+                    make_float4(ao[t][rq * 4 + 0], ao[t][rq * 4 + 1], ao[t][rq * 4 + 2], ao[t][rq * 4 + 3]);
+        if (hh == 0) { scr[RC_NW * 32 * AT_LD + (wave * 2 + 0) * 32 + i] = am; scr[RC_NW * 32 * AT_LD + (wave * 2 + 1) * 32 + i] = al; }
+    }
     wload(wa, p.Wp, 16, wave, 0, lane);
     // residual rows of this lane's output column + the attention output tile
     float xres[16];
@@ -218,7 +315,34 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
         const int n = min(n0 + row, N - 1);
         const float* src = p.O + (mb + n) * RC_H + seg * 4;
         float4 v[4];
-        if (p.ksplit <= 1) {
+        if constexpr (ATTN) {
+            lds_barrier();                                   // every wave's partial is in the scratch
+            const float* scr = reinterpret_cast<const float*>(smem_rc);
+            const float* stat = scr + RC_NW * 32 * AT_LD;
+#pragma unroll
+            for (int hd = 0; hd < 2; ++hd) {
+                float mw[4], M = -INFINITY;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { mw[w] = stat[((hd * 4 + w) * 2) * 32 + row]; M = fmaxf(M, mw[w]); }
+                float L = 0.f, f[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) { f[w] = (mw[w] == -INFINITY) ? 0.f : exp2f(mw[w] - M); L += f[w] * stat[((hd * 4 + w) * 2 + 1) * 32 + row]; }
+                const float inv = 1.f / L;
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const float4 t4 = *reinterpret_cast<const float4*>(scr + ((hd * 4 + w) * 32 + row) * AT_LD + qq * 64 + seg * 4);
+                        a.x = fmaf(f[w], t4.x, a.x); a.y = fmaf(f[w], t4.y, a.y); a.z = fmaf(f[w], t4.z, a.z); a.w = fmaf(f[w], t4.w, a.w);
+                    }
+                    v[hd * 2 + qq] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+                }
+            }
+            lds_barrier();                                   // scratch fully read: the chain's buffers may now be written
+            const int which = tid >> 7, c2 = (tid & 127) * 2;
+            *reinterpret_cast<float2*>(LNp + which * RC_H + c2) = lnv;
+        } else if (p.ksplit <= 1) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(src + q * 64);
         } else {
@@ -382,10 +506,16 @@ bool dit_rowchain_supported(int hidden, int mlp_hidden) { return hidden == RC_H 
 void launch_dit_rowchain(const DitChainP& p, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&dit_rowchain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC_LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&dit_rowchain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC_LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&dit_rowchain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(RC_LDS_ATTN > RC_LDS ? RC_LDS_ATTN : RC_LDS));
         attr = true;
     }
-    hipLaunchKernelGGL(dit_rowchain_kernel, dim3(p.B * ((p.rows_per_batch + RC_ROWS - 1) / RC_ROWS)), dim3(RC_NW * 64), RC_LDS, st, p);
+    dim3 grid(p.B * ((p.rows_per_batch + RC_ROWS - 1) / RC_ROWS));
+    if (p.attn_inline && !p.qkv_only)
+        hipLaunchKernelGGL(dit_rowchain_kernel<true>, grid, dim3(RC_NW * 64), RC_LDS_ATTN > RC_LDS ? RC_LDS_ATTN : RC_LDS, st, p);
+    else
+        hipLaunchKernelGGL(dit_rowchain_kernel<false>, grid, dim3(RC_NW * 64), RC_LDS, st, p);
 }
 
 // fp32 [K][N] -> bf16 in MFMA B-fragment order: dst[((nt * K/16 + ks) * 64 + lane) * 8 + j] =

@@ -161,8 +161,11 @@ struct DitChainP { const float* O; int ksplit; long o_sstride; const float* ml; 
                    float* X; const void *Wp, *W1, *W2, *Wq; const float *bp, *b1, *b2, *bq;
                    const float* ada;                       // this block's [n_steps][6*hidden] adaLN table
                    const float *next_shift, *next_scale; long next_step_stride;   // null: no qkv stage (last block)
-                   void *Qh, *Kh, *Vt; int Npad; float qscale;          // bf16 head-major q,k and transposed v (attention_direct.hip)
+                   void *Qh, *Kh, *Vt; int Npad; float qscale;          // bf16 q, k, v^T in fragment order (attention_direct.hip): written
+                   const void *Qin, *Kin, *Vin;                          // attn_inline: operands READ by the in-kernel attention — a different
+                                                                        // buffer set than the one written (workgroups of one launch overlap)
                    int qkv_only;                                        // 1: only LN+modulate+qkv of X (first block)
+                   int attn_inline;                                     // 1: the attention core runs inside this launch (O / ml unused)
                    const int* step; int M; int B; long long* dbg; };   // M = B * rows_per_batch
 bool dit_rowchain_supported(int hidden, int mlp_hidden);
 // Softmax attention on the row chain's bf16 operands (2 heads x 128): no staging, K / V^T / Q fragments are read
