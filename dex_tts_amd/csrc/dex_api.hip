@@ -865,7 +865,8 @@ struct Runner {
                 // The attention core runs inside the row-chain launch (dit_rowchain_kernel<true>): every workgroup computes
                 // the attention of its own 32 queries for both heads, so no attention launch and no partials in HBM.
                 // DEX_ATTN_SEPARATE=1 restores the separate kernels (attention_direct.hip) for A/B measurements.
-                static const bool separate = getenv("DEX_ATTN_SEPARATE") && atoi(getenv("DEX_ATTN_SEPARATE"));
+                const char* sep_env = getenv("DEX_ATTN_SEPARATE");     // read per call: bench.py flips it for one profiling pass
+                const bool separate = sep_env && atoi(sep_env);
                 int ks = 1;
                 if (separate) {
                     const long blocks = (long)((N + 31) / 32) * 2 * B;
