@@ -97,17 +97,20 @@ __global__ __launch_bounds__(NWD * 64) void attn_direct_kernel(const AttnDirectP
             mx = fmaxf(mx, s[r]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);            // scores are in the log2 domain (q scale carries log2 e)
+        if (__builtin_amdgcn_ballot_w64(mx > m_run + 8.f) != 0) {     // lazy rescale (see attn_direct_full_kernel)
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = exp2f(m_run - m_new);        // scores are in the log2 domain (q scale carries log2 e)
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        }
         float psum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_new); psum += s[r]; }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_run); psum += s[r]; }
+        l_run += psum;
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
             DFrag pb;
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(NWD * 64) void attn_direct_kernel(const AttnDirectP
 // before: 1220 cycles S^T + 870 softmax + 430 PV + 500 copy/barrier with three waves per SIMD taking turns); K
 // therefore runs one tile ahead of V in LDS.  S^T uses two accumulators (even / odd K-steps) to halve the dependent
 // MFMA chain.  Scores are in the log2 domain (log2 e is folded into the q scale by the producer): p = exp2(s - m).
-// The running-max rescale of O is skipped (wave-uniform test) whenever no lane's maximum moved.
+// The running-max rescale of O is lazy (see the loop).
 __device__ __forceinline__ f32x16 attn_qk(const uint4* kbuf, const DFrag (&qf)[8], int lane) {
     f32x16 s0, s1;
 #pragma unroll
@@ -252,7 +255,11 @@ __global__ __launch_bounds__(256) void attn_direct_full_kernel(const AttnDirectP
 #pragma unroll
         for (int r = 4; r < 16; r += 4) mx = fmaxf(mx, fmaxf(fmaxf(s[r], s[r + 1]), fmaxf(s[r + 2], s[r + 3])));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        if (__builtin_amdgcn_ballot_w64(mx > m_run) != 0) {           // some lane's running maximum moves: rescale
+        // Lazy rescale: the reference maximum only moves when some query's true maximum exceeds it by more than 2^8
+        // (scores are log2-domain), so P = 2^(s - m_ref) <= 256 stays exact in fp32 sums and well inside bf16 range,
+        // the result is mathematically unchanged (the final division uses the same reference), and the 64-register
+        // rescale of O — which with 32 queries per wave fired on nearly every tile — runs a handful of times.
+        if (__builtin_amdgcn_ballot_w64(mx > m_run + 8.f) != 0) {
             const float m_new = fmaxf(m_run, mx);
             const float alpha = exp2f(m_run - m_new);
             l_run *= alpha;

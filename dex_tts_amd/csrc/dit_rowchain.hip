@@ -262,17 +262,20 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(am, mx);
-            const float alpha = exp2f(am - m_new);               // scores are in the log2 domain (q scale carries log2 e)
+            if (__builtin_amdgcn_ballot_w64(mx > am + 8.f) != 0) {   // lazy rescale (attention_direct.hip): reference max moves rarely
+                const float m_new = fmaxf(am, mx);
+                const float alpha = exp2f(am - m_new);           // scores are in the log2 domain (q scale carries log2 e)
+                al *= alpha;
+                am = m_new;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ao[t][r] *= alpha;
+            }
             float psum = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { sc[r] = __builtin_amdgcn_exp2f(sc[r] - m_new); psum += sc[r]; }
-            al = al * alpha + psum;
-            am = m_new;
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ao[t][r] *= alpha;
+            for (int r = 0; r < 16; ++r) { sc[r] = __builtin_amdgcn_exp2f(sc[r] - am); psum += sc[r]; }
+            al += psum;
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
                 DFr pb;
