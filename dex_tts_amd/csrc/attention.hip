@@ -136,17 +136,22 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QREG ? 
             mx = fmaxf(mx, sT[r]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __expf(m_run - m_new);          // first tile: exp(-inf) = 0
+        // lazy rescale: the reference maximum moves only when some query exceeds it by more than 8 (P <= e^8 stays exact in
+        // fp32; the partial merge and the final division use the same reference, so the result is unchanged)
+        if (__builtin_amdgcn_ballot_w64(mx > m_run + 8.f) != 0) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __expf(m_run - m_new);      // first tile: exp(-inf) = 0
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        }
         float psum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sT[r] = __expf(sT[r] - m_new); psum += sT[r]; }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        for (int r = 0; r < 16; ++r) { sT[r] = __expf(sT[r] - m_run); psum += sT[r]; }
+        l_run += psum;
         // V -> LDS as V[key][d] over the K^T image (S^T is done with it), 16-byte stores
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
