@@ -37,6 +37,7 @@ WORKLOADS = {
     "dex_b1": ("dex_vctk", 1, 512, 50, 348),
     "dex_b32": ("dex_vctk", 32, 256, 50, 348),
     "gedex_long": ("gedex_lj", 1, 4000, 50, 0),
+    "dex_esd_b32_n100": ("dex_esd", 32, 256, 100, 348),     # per-GPU share of BASELINE.json configs[3] (256 utterances / 8 GPUs)
 }
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
@@ -193,7 +194,7 @@ def main():
         frames_s = valid_total * args.steps / dt
         audio_s = valid_total * 256 / 22050.0
         res = {
-            "metric": "mel-frames/s at n_timesteps=50, 80-ch mel (sampler only); RTF",
+            "metric": f"mel-frames/s at n_timesteps={n_steps}, 80-ch mel (sampler only); RTF",
             "value": round(frames_s, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic (portable random weights with zero-inits overridden; mel-like mu; mask from lengths)",
