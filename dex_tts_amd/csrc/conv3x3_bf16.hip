@@ -102,7 +102,7 @@ __device__ __forceinline__ void cv_epilogue(const Conv3P& p, f32x16 (&acc)[NT], 
 
 // CC channels per chunk, output-channel slice [slice*NSL, +NSL) of COUT, TH rows (waves: TH x (4/TH)).
 // grid.z = b * (COUT/NSL) + slice.
-template <int CC, int COUT, int NSL, int TH, bool PRO2 = false>
+template <int CC, int COUT, int NSL, int TH, bool PRO2 = false, bool RES = false>
 __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
     constexpr int PW = 34, PH = TH + 2;
     constexpr int LDP = CC + 8;
@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* patch = smem;                                // [PH*PW][LDP]
     u16* wbuf = smem + PH * PW * LDP;                 // [2][NSL][LDP]
+    u16* rbuf = wbuf + 2 * NSL * LDP;                 // [NSL][LDP]  1x1 shortcut weights of this chunk (RES)
     __shared__ float smean[8], srstd[8], gnred[16];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -139,6 +140,13 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
+    f32x16 accr[RES ? NT : 1];
+    if constexpr (RES) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accr[t][r] = 0.f;
+    }
     // weight item j of this thread: output channel wn[j], 8 input channels at wc8[j] (same for every tap)
     int wofs[WPT], wlds[WPT];
 #pragma unroll
@@ -154,7 +162,15 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
     for (int ch = 0; ch < nchunk; ++ch) {
         const int cbase = ch * CC;
         // ---- every global load of the chunk's first round goes out back to back: weights of taps 0..RING, the patch
-        u32x4 w0r[WPT], wr[RING][WPT];
+        u32x4 w0r[WPT], wr[RING][WPT], rwr[RES ? WPT : 1];
+        if constexpr (RES) {
+            const u16* Rg = reinterpret_cast<const u16*>(p.res_w) + (long)slice * NSL * p.Cin;      // [COUT][Cin]
+#pragma unroll
+            for (int j = 0; j < WPT; ++j) {
+                const int it = tid + 256 * j;
+                rwr[j] = *reinterpret_cast<const u32x4*>(Rg + (long)(it / (CC / 8)) * p.Cin + cbase + (it % (CC / 8)) * 8);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < WPT; ++j) w0r[j] = *reinterpret_cast<const u32x4*>(Wg + wofs[j] + cbase);
 #pragma unroll
@@ -204,6 +220,10 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
                 if (pro) { const int g = (cbase + pc8) / (p.Cin / 8); mean = smean[g]; rstd = srstd[g]; }
 #pragma unroll
                 for (int j = 0; j < WPT; ++j) *reinterpret_cast<u32x4*>(wbuf + wlds[j]) = w0r[j];
+                if constexpr (RES) {
+#pragma unroll
+                    for (int j = 0; j < WPT; ++j) *reinterpret_cast<u32x4*>(rbuf + wlds[j]) = rwr[j];
+                }
             }
 #pragma unroll
             for (int q = 0; q < NIP; ++q) {
@@ -260,26 +280,50 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
                     const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bp + t * 32 * LDP + ks * 16);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
                 }
+                if constexpr (RES) {
+                    if (tap == 4) {                   // centre tap: the same A fragment feeds the 1x1 shortcut
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) {
+                            const bf16x8 rf = *reinterpret_cast<const bf16x8*>(rbuf + (wcol * NT * 32 + t * 32 + i) * LDP + hh * 8 + ks * 16);
+                            accr[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, rf, accr[t], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if constexpr (RES) {
+        // shortcut output: + bias, no statistics, same tile addressing as the main output
+        const int ho = h0 + wrow, nb = slice * NSL + wcol * NT * 32;
+        float* yl = p.res_y + ((long)b * p.H * p.W + (long)ho * p.W + w0 + 4 * hh) * COUT + nb + i;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float bias = p.res_b[nb + t * 32 + i];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int wo = w0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (ho < p.H && wo < p.W) yl[((r & 3) + 8 * (r >> 2)) * COUT + t * 32] = accr[t][r] + bias;
             }
         }
     }
     cv_epilogue<NT, COUT>(p, acc, b, h0 + wrow, w0, slice * NSL + wcol * NT * 32, lane, tid, gnred);
 }
 
-template <int CC, int COUT, int NSL, int TH, bool PRO2 = false>
+template <int CC, int COUT, int NSL, int TH, bool PRO2 = false, bool RES = false>
 static void launch_c3(const Conv3P& p, hipStream_t st) {
     constexpr int LDP = CC + 8;
-    const size_t lds = ((size_t)(TH + 2) * 34 * LDP + 2 * NSL * LDP) * sizeof(u16);
+    const size_t lds = ((size_t)(TH + 2) * 34 * LDP + (2 + (RES ? 1 : 0)) * NSL * LDP) * sizeof(u16);
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<CC, COUT, NSL, TH, PRO2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<CC, COUT, NSL, TH, PRO2, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     dim3 grid((p.W + 31) / 32, (p.H + TH - 1) / TH, p.B * (COUT / NSL));
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<CC, COUT, NSL, TH, PRO2>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<CC, COUT, NSL, TH, PRO2, RES>), grid, dim3(256), lds, st, p);
 }
 
 bool conv3x3_bf16_tail_supported(int C) { return C == 64 || C == 128; }
+bool conv3x3_bf16_res_supported(int Cin, int Cout) { return (Cout == 128 && Cin == 64) || (Cout == 64 && (Cin == 128 || Cin == 256)); }
 bool conv3x3_bf16_supported(int Cin, int Cout) {
     return (Cin == 64 || Cin == 128 || Cin == 256) && (Cout == 64 || Cout == 128);
 }
@@ -293,6 +337,10 @@ void launch_conv3x3_bf16(const Conv3P& p, hipStream_t st) {
         if (p.Cin == 64 && p.Cout == 64) { small ? launch_c3<64, 64, 64, 2, true>(p, st) : launch_c3<64, 64, 64, 4, true>(p, st); }
         else { small ? launch_c3<128, 128, 64, 2, true>(p, st) : launch_c3<128, 128, 128, 4, true>(p, st); }
         return;
+    }
+    if (p.res_w) {        // fused 1x1 shortcut: the channel-changing first convs (64 -> 128 on the way down, 128/256 -> 64 on the way up)
+        if (p.Cout == 128 && p.Cin == 64) { small ? launch_c3<64, 128, 64, 2, false, true>(p, st) : launch_c3<64, 128, 128, 4, false, true>(p, st); return; }
+        if (p.Cout == 64 && p.Cin >= 128) { small ? launch_c3<128, 64, 64, 2, false, true>(p, st) : launch_c3<128, 64, 64, 4, false, true>(p, st); return; }
     }
     if (p.Cout == 64) {
         if (p.Cin == 64) { small ? launch_c3<64, 64, 64, 2>(p, st) : launch_c3<64, 64, 64, 4>(p, st); }

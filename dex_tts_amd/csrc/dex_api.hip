@@ -671,7 +671,7 @@ struct Runner {
     struct Pro { const float* stats; const float *gamma, *beta, *tadd; const float* res = nullptr; float* xout = nullptr; };
     bool fast_conv(int cin, int cout) const { return x->precision == DEX_PREC_BF16 && conv3x3_bf16_supported(cin, cout); }
     void conv3x3(const char* name, const TD& X, int H, int W, int mask_ws, bool inmask, const float* Wt, const float* bias, int Cout, float* out,
-                 float* gn = nullptr, const Pro* pro = nullptr) {
+                 float* gn = nullptr, const Pro* pro = nullptr, const ResW* shortcut = nullptr, float* shortcut_out = nullptr) {
         auto it = x->bf16_of.find(Wt);
         if (fast_conv(X.C, Cout) && it != x->bf16_of.end()) {
             Conv3P c{};
@@ -679,6 +679,9 @@ struct Runner {
             c.Wbf = it->second; c.bias = bias; c.Y = out; c.mask = mask; c.mask_ws = mask_ws; c.mask_bstride = P.d.T;
             if (pro) { c.pro_stats = pro->stats; c.pro_gamma = pro->gamma; c.pro_beta = pro->beta; c.pro_tadd = pro->tadd; c.pro_res = pro->res; c.pro_xout = pro->xout; }
             c.step = sp; c.gn_stats = gn; c.B = P.d.B;
+            if (shortcut) {       // the block's 1x1 res_conv rides on the centre tap of this conv
+                c.res_w = x->bf16_of.at(shortcut->wr); c.res_b = shortcut->br; c.res_y = shortcut_out;
+            }
             const double M = (double)H * W * P.d.B;
             run(name, 2.0 * M * Cout * 9 * X.C, 4.0 * M * (X.C + Cout) + 2.0 * 9 * X.C * Cout, [&] { launch_conv3x3_bf16(c, st); });
             return;
@@ -725,13 +728,17 @@ struct Runner {
             resptr = s.rbuf; ldres = w.cout; resb = npix * w.cout;
         } else {
             st1 = next_stats();
+            bool fused_res = false;
             if (head) {
                 TD H2{s.h2, X.C, 0, X.C};                  // previous block's raw conv2 output
                 conv3x3("conv3x3", H2, s.H, s.W, s.mask_ws, true, w.w1, w.b1, w.cout, s.h1, st1, head);
             } else {
-                conv3x3("conv3x3", X, s.H, s.W, s.mask_ws, true, w.w1, w.b1, w.cout, s.h1, st1);
+                fused_res = w.wr && fast_conv(X.C, w.cout) && conv3x3_bf16_res_supported(X.C, w.cout) && x->bf16_of.count(w.wr);
+                conv3x3("conv3x3", X, s.H, s.W, s.mask_ws, true, w.w1, w.b1, w.cout, s.h1, st1, nullptr, fused_res ? &w : nullptr, s.rbuf);
             }
-            if (w.wr) {
+            if (fused_res) {
+                resptr = s.rbuf; ldres = w.cout; resb = npix * w.cout;
+            } else if (w.wr) {
                 IGemmP g = base_gemm(X.p, X.ld, X.coff, s.H, s.W, X.C, w.wr, w.cout, w.br, s.rbuf, w.cout, 0);
                 g.inmask = mask; g.inmask_ws = s.mask_ws;
                 gemm("conv1x1_res", g);

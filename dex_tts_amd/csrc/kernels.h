@@ -55,11 +55,15 @@ struct Conv3P {
     //   x = mask * Mish(GN(X)) + pro_res   (res_conv shortcut, diffusion.py:67-71), [H*W][Cin] like X;
     // the kernel also writes x for its own output pixels to pro_xout ([H*W][Cin]) for the later consumers.
     const float* pro_res; float* pro_xout;
+    // fused 1x1 shortcut of the ResnetBlock (res_conv(x * mask), diffusion.py:70): a second output computed from the
+    // patch's centre tap; res_w = bf16 [Cout][Cin], res_y = [H*W][Cout] fp32
+    const void* res_w; const float* res_b; float* res_y;
     const int* step; float* gn_stats; int B;
     long long* dbg;                                          // optional phase timestamps (tools/kbench)
 };
 bool conv3x3_bf16_supported(int Cin, int Cout);
 bool conv3x3_bf16_tail_supported(int C);     // pro_res form (Cin == Cout == C)
+bool conv3x3_bf16_res_supported(int Cin, int Cout);   // res_w form (fused 1x1 shortcut)
 void launch_conv3x3_bf16(const Conv3P& p, hipStream_t st);
 
 // First ResnetBlock of the U-Net: 3x3 conv and 1x1 res_conv straight from the stacked input planes
