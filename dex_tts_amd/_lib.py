@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(HERE, "lib", "libdexamd.so")
 DEX_OK = 0
 VARIANT = {"gedex": 0, "dex": 1}
 PRECISION = {"fp32": 0, "bf16": 1}
+SOLVER = {"euler": 0, "heun": 1}
 
 
 class DexConfig(C.Structure):
@@ -29,7 +30,7 @@ class DexSampleArgs(C.Structure):
                 ("ref_skips_dev", C.POINTER(C.c_void_p)), ("n_ref", C.c_int32), ("Tr", C.c_int32),
                 ("sty_dev", C.c_void_p), ("sty_lengths_dev", C.c_void_p), ("Ts", C.c_int32),
                 ("out_dev", C.c_void_p), ("workspace_dev", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("use_graph", C.c_int32)]
+                ("use_graph", C.c_int32), ("solver", C.c_int32)]
 
 
 class DexDenoiseArgs(C.Structure):
@@ -42,6 +43,7 @@ SYMBOLS = [
     ("dex_ctx_destroy", None, [C.c_void_p]),
     ("dex_last_error", C.c_char_p, [C.c_void_p]),
     ("dex_version", C.c_char_p, []),
+    ("dex_num_evals", C.c_int, [C.c_int, C.c_int]),
     ("dex_ctx_num_weights", C.c_int, [C.c_void_p]),
     ("dex_ctx_weight_info", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     ("dex_ctx_load_weight", C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),

@@ -518,6 +518,7 @@ struct Plan {
     float *spk_tmp, *spk_plane;
     int* step; int* step_tab; float* stats; long stats_bytes; int n_gn;   // stats: two arenas (Euler-step parity)
     float* xbuf;
+    float *xprime, *dbuf, *hsig, *htab;      // Heun: x', slope d_cur, per-evaluation sigma / h tables
     std::vector<StageBuf> down, up;
     std::vector<float*> cat;
     float *up_out, *hF;
@@ -557,6 +558,8 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
     P.stats_bytes = (long)P.n_gn * B * 8 * GN_SLOTS * 2 * sizeof(float);
     P.stats = (float*)A.take(2 * P.stats_bytes);
     P.xbuf = A.f((size_t)B * 80 * d.T);
+    P.xprime = A.f((size_t)B * 80 * d.T); P.dbuf = A.f((size_t)B * 80 * d.T);
+    P.hsig = A.f((size_t)n + 2); P.htab = A.f((size_t)n + 2);
     P.cat.assign(c.n_stages - 1, nullptr);
     for (int j = 0; j < c.n_stages - 1; ++j) {
         const int i = c.n_stages - 1 - j;
@@ -624,6 +627,8 @@ struct Runner {
     const int* sp = nullptr;        // device pointer to the current Euler-step index
     float* stats_base = nullptr;    // statistics arena of this step
     float* stats_other = nullptr;   // arena to clear for the next step (eager mode), or null
+    int fin_mode = 0;               // FinalP::mode of this network evaluation (Heun predictor / corrector)
+    const float* fin_htab = nullptr;
 
     template <typename F> void run(const char* name, double flops, double bytes, F&& f) {
         if (x->prof_on) {
@@ -1062,6 +1067,7 @@ struct Runner {
         f.gamma = x->fin_g; f.beta = x->fin_be; f.mask = mask; f.mask_bstride = P.d.T; f.wfc = x->fconv_w; f.bfc = x->fconv_b;
         f.xcur = xcur; f.denoised = denoised; f.xnext = xnext; f.scal = P.scal; f.scal_stride = SCAL_STRIDE; f.step = sp; f.B = B;
         f.zero_ptr = stats_other; f.zero_n = P.stats_bytes / (long)sizeof(float);
+        f.mode = fin_mode; f.htab = fin_htab; f.dbuf = P.dbuf; f.xhat = P.xbuf;
         run("final_conv_euler", 14.0 * 80 * P.d.T * c.dim * B, 4.0 * 80 * P.d.T * (c.dim + 3) * B, [&] { launch_final(f, st); });
     }
 
@@ -1142,6 +1148,37 @@ int validate(DexCtx* x, const DexSampleArgs* a, bool need_z) {
 
 __global__ void set_sigma_pair(const float* src, float* dst) { dst[0] = src[0]; dst[1] = 0.f; }
 
+// ablation_sampler(solver='heun', alpha=1) — edm.py:199-214.  2n-1 network evaluations: evaluation 2i is step i's
+// predictor at t_i, evaluation 2i+1 its corrector at t' = t_i + h (none on the last step).  The conditioning tables are
+// built per EVALUATION; the last kernel of each evaluation does the predictor / corrector update.  Eager launches only.
+int sample_heun(DexCtx* x, const DexSampleArgs* a, hipStream_t st) {
+    const int n = a->n_steps, E = 2 * n - 1;
+    Plan P; Dims d{a->B, a->T, a->Tr, a->Ts, E};
+    make_plan(x, d, nullptr, P);
+    if (P.bytes > a->workspace_bytes) return x->fail(DEX_ERR_WORKSPACE, "workspace too small: need %zu bytes (Heun: dex_workspace_bytes with dex_num_evals(n_steps, solver)), got %zu", P.bytes, a->workspace_bytes);
+    make_plan(x, d, a->workspace_dev, P);
+    x->taps.clear();
+    if (x->prof_on) { for (auto& pr : x->prof) { hipEventDestroy(pr.a); hipEventDestroy(pr.b); } x->prof.clear(); x->prof_agg.clear(); }
+    Runner R{x, P, st, a->mask_dev, a->mu_dev, P.xbuf, a, false};
+    launch_iota(P.step_tab, E, st);
+    launch_heun_expand(a->sigmas_dev, n, P.hsig, P.htab, st);
+    R.prepare(P.hsig, E);
+    R.run("init_scale", 0, 8.0 * a->B * 80 * a->T, [&] { launch_scale_copy(a->z_dev, P.xbuf, (long)a->B * 80 * a->T, P.scal, st); });
+    float* arena[2] = {P.stats, P.stats + P.stats_bytes / (long)sizeof(float)};
+    hipMemsetAsync(P.stats, 0, 2 * P.stats_bytes, st);
+    R.fin_htab = P.htab;
+    for (int e = 0; e < E; ++e) {
+        const bool corrector = (e & 1) != 0, last = (e == E - 1);
+        R.sp = P.step_tab + e; R.stats_base = arena[e & 1]; R.stats_other = arena[(e + 1) & 1];
+        R.xcur = corrector ? P.xprime : P.xbuf;
+        R.fin_mode = corrector ? 2 : (last ? 0 : 1);
+        R.step(nullptr, (corrector || last) ? P.xbuf : P.xprime);
+    }
+    HIPCHK(x, hipMemcpyAsync(a->out_dev, P.xbuf, (size_t)a->B * 80 * a->T * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIPCHK(x, hipGetLastError());
+    return DEX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1152,6 +1189,8 @@ size_t dex_workspace_bytes(const DexCtx* x, int B, int T, int Tr, int Ts, int n_
     make_plan(x, d, nullptr, P);
     return P.bytes;
 }
+
+int dex_num_evals(int n_steps, int solver) { return solver == DEX_SOLVER_HEUN ? 2 * n_steps - 1 : n_steps; }
 
 int dex_edm_sigmas(int n, float* out) {
     if (n < 2 || !out) return DEX_ERR_ARG;
@@ -1190,6 +1229,8 @@ int dex_denoise_once(DexCtx* x, const DexDenoiseArgs* da, dex_stream_t stream) {
 int dex_sample(DexCtx* x, const DexSampleArgs* a, dex_stream_t stream) {
     int rc = validate(x, a, true);
     if (rc) return rc;
+    if (a->solver != DEX_SOLVER_EULER && a->solver != DEX_SOLVER_HEUN) return x->fail(DEX_ERR_ARG, "solver must be DEX_SOLVER_EULER or DEX_SOLVER_HEUN (edm.py:107)");
+    if (a->solver == DEX_SOLVER_HEUN) return sample_heun(x, a, (hipStream_t)stream);
     hipStream_t st = (hipStream_t)stream;
     Plan P; Dims d{a->B, a->T, a->Tr, a->Ts, a->n_steps};
     make_plan(x, d, nullptr, P);

@@ -106,8 +106,15 @@ struct FinalP {
     const float* scal; int scal_stride; const int* step;
     float* zero_ptr; long zero_n;                         // optional: clear the OTHER parity's GroupNorm statistics arena
     int B;
+    // Heun (edm.py:207-214).  mode 0: Euler update with h = sigma_next - sigma (or htab[step] when given);
+    // mode 1: predictor - also stores the slope d_cur in dbuf (xnext receives x' = x_hat + h d_cur);
+    // mode 2: corrector - xcur is x', xhat the state the step started from: xnext = xhat + h (0.5 d_cur + 0.5 d').
+    int mode; const float* htab; float* dbuf; const float* xhat;
 };
 void launch_final(const FinalP& p, hipStream_t st);
+// Heun evaluation tables from the schedule t_0..t_N: sig[2i] = t_i, sig[2i+1] = t_i + (t_{i+1} - t_i) (i < n-1),
+// sig[2n-1] = 0; h[2i] = h[2i+1] = t_{i+1} - t_i.
+void launch_heun_expand(const float* sigmas, int n, float* sig, float* h, hipStream_t st);
 
 // Linear attention (diffusion.py:82-92): qkv [B,n,3*heads*32]; softmax over positions on k.
 struct LinAttnCtxP { const float* qkv; int ld; long bstride; int n; int heads; int chunk; int nchunks;

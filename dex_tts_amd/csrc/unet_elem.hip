@@ -270,7 +270,13 @@ __global__ __launch_bounds__(256) void final_kernel(const FinalP p) {
             if (p.xnext) {
                 const float inv = 1.f / sigma;
                 const float d = inv * xc - inv * D;
-                p.xnext[o] = xc + (sigma_next - sigma) * d;
+                const float h = p.htab ? p.htab[step] : sigma_next - sigma;
+                if (p.mode == 2) {
+                    p.xnext[o] = p.xhat[o] + h * (0.5f * p.dbuf[o] + 0.5f * d);
+                } else {
+                    if (p.mode == 1) p.dbuf[o] = d;
+                    p.xnext[o] = xc + h * d;
+                }
             }
         }
     }
@@ -278,6 +284,17 @@ __global__ __launch_bounds__(256) void final_kernel(const FinalP p) {
         const long nthreads = (long)gridDim.x * gridDim.y * 256;
         for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < p.zero_n; i += nthreads) p.zero_ptr[i] = 0.f;
     }
+}
+__global__ void heun_expand_kernel(const float* sigmas, int n, float* sig, float* h) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float t = sigmas[i], hh = sigmas[i + 1] - t;
+    sig[2 * i] = t; h[2 * i] = hh;
+    if (i < n - 1) { sig[2 * i + 1] = t + hh; h[2 * i + 1] = hh; }
+    else sig[2 * i + 1] = 0.f;
+}
+void launch_heun_expand(const float* sigmas, int n, float* sig, float* h, hipStream_t st) {
+    hipLaunchKernelGGL(heun_expand_kernel, dim3((n + 63) / 64), dim3(64), 0, st, sigmas, n, sig, h);
 }
 void launch_final(const FinalP& p, hipStream_t st) {
     long blocks = (p.npix + 15) / 16;

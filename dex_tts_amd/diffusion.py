@@ -83,6 +83,7 @@ class Diffusion(nn.Module):
         self.loss_fn = None                      # EDMLoss is training-only (edm.py:22-68): out of scope
         self.precision = "fp32"
         self.use_graph = False
+        self.solver = "euler"                    # the reference wires 'euler' (diffusion.py:216); 'heun' = edm.py:207-214
         self.rng_parity = True                   # replay the reference's per-step randn_like draws (edm.py:196)
         self._engine = None
         self._engine_key = None
@@ -111,7 +112,7 @@ class Diffusion(nn.Module):
     def _sample(self, z, mask, mu, steps, spk=None, ref=None, sty=None, sty_lengths=None):
         eng = self.engine(z.device)
         return eng.sample(z, mask, mu, int(steps), spk=spk, ref=ref, sty=sty, sty_lengths=sty_lengths,
-                          use_graph=self.use_graph)
+                          use_graph=self.use_graph, solver=self.solver)
 
     def _advance_rng(self, like: torch.Tensor, n: int):
         """The reference draws ``randn_like(x_cur)`` once per Euler step and multiplies it by 0

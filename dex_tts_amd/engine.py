@@ -21,6 +21,19 @@ def edm_sigmas(n_steps: int) -> torch.Tensor:
     return torch.cat([s.to(torch.float32), torch.zeros(1)])
 
 
+def heun_eval_sigmas(n_steps: int) -> torch.Tensor:
+    """Sigma of each of the 2n-1 network evaluations of ablation_sampler(solver='heun', alpha=1), plus a trailing
+    0: t_i for step i's predictor and fl(t_i + fl(t_{i+1} - t_i)) for its corrector (edm.py:199-207).  The library
+    builds the same table on the device; this host copy exists for tests and tooling."""
+    ts = edm_sigmas(n_steps)
+    out = []
+    for i in range(n_steps):
+        out.append(ts[i])
+        if i < n_steps - 1:
+            out.append(ts[i] + (ts[i + 1] - ts[i]))
+    return torch.stack(out + [torch.zeros(())]).to(torch.float32)
+
+
 class ScoreNetEngine:
     def __init__(self, cfg: ScoreNetConfig, device: torch.device):
         if device.type != "cuda":
@@ -80,7 +93,10 @@ class ScoreNetEngine:
         return self._ws
 
     # ---------------------------------------------------------------------------------------
-    def _fill_args(self, a: _lib.DexSampleArgs, mu, mask, sigmas, out, n_steps, spk, ref, sty, sty_lengths, use_graph):
+    def _fill_args(self, a: _lib.DexSampleArgs, mu, mask, sigmas, out, n_steps, spk, ref, sty, sty_lengths, use_graph,
+                   solver="euler"):
+        if solver not in _lib.SOLVER:
+            raise ValueError(f"solver must be 'euler' or 'heun' (edm.py:107), got {solver!r}")
         B, F, T = mu.shape
         if F != 80:
             raise ValueError("mel dimension must be 80")
@@ -106,7 +122,8 @@ class ScoreNetEngine:
             keep += ref + [sty, sl, arr]
             a.ref_skips_dev, a.n_ref, a.Tr = C.cast(arr, C.POINTER(C.c_void_p)), len(ref), Tr
             a.sty_dev, a.sty_lengths_dev, a.Ts = sty.data_ptr(), sl.data_ptr(), Ts
-        ws = self.workspace(B, T, Tr, Ts, max(n_steps, 1))
+        a.solver = _lib.SOLVER[solver]
+        ws = self.workspace(B, T, Tr, Ts, max(int(self.lib.dex_num_evals(n_steps, a.solver)), 1))
         base = (ws.data_ptr() + 255) // 256 * 256
         a.workspace_dev, a.workspace_bytes = base, ws.numel() - (base - ws.data_ptr())
         a.use_graph = 1 if use_graph else 0
@@ -117,8 +134,11 @@ class ScoreNetEngine:
         m = mask.to(device=device, dtype=torch.float32).reshape(B, T).contiguous()
         return m
 
-    def sample(self, z, mask, mu, n_steps, spk=None, ref=None, sty=None, sty_lengths=None, use_graph=False):
-        """ablation_sampler(euler, edm, linear, none) for latent z — edm.py:109-216.  Asynchronous."""
+    def sample(self, z, mask, mu, n_steps, spk=None, ref=None, sty=None, sty_lengths=None, use_graph=False,
+               solver="euler"):
+        """ablation_sampler(solver, edm, linear, none) for latent z — edm.py:109-216.  ``solver`` is 'euler' (what
+        Diffusion wires, diffusion.py:216) or 'heun' (edm.py:207-214; 2n-1 network evaluations).  Asynchronous."""
+        use_graph = use_graph and solver == "euler"
         with torch.cuda.device(self.device):
             mu = mu.to(device=self.device, dtype=torch.float32).contiguous()
             z = z.to(device=self.device, dtype=torch.float32).contiguous()
@@ -127,7 +147,7 @@ class ScoreNetEngine:
             sig = edm_sigmas(n_steps).to(self.device)
             out = torch.empty_like(mu)
             a = _lib.DexSampleArgs()
-            keep = self._fill_args(a, mu, mask, sig, out, n_steps, spk, ref, sty, sty_lengths, use_graph)
+            keep = self._fill_args(a, mu, mask, sig, out, n_steps, spk, ref, sty, sty_lengths, use_graph, solver)
             a.z_dev = z.data_ptr()
             cur = torch.cuda.current_stream(self.device)
             if use_graph and cur.cuda_stream == 0:

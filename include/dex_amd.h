@@ -40,6 +40,8 @@ typedef enum {
 
 typedef enum { DEX_VARIANT_GEDEX = 0, DEX_VARIANT_DEX = 1 } DexVariant;
 typedef enum { DEX_PREC_FP32 = 0, DEX_PREC_BF16 = 1 } DexPrecision;
+/* ablation_sampler's solver argument (edm.py:107). */
+typedef enum { DEX_SOLVER_EULER = 0, DEX_SOLVER_HEUN = 1 } DexSolver;
 
 /* Mirrors Diffusion(**cfg.decoder, dit_cfg=cfg.dit): GeDEX diffusion.py:210, dit.py:339-356. */
 typedef struct {
@@ -74,7 +76,8 @@ typedef struct {
     float* out_dev;             /* [B,80,T] x_N (unmasked, like edm.py:216) */
     void*  workspace_dev;       /* >= dex_workspace_bytes(...) bytes, 256-B aligned */
     size_t workspace_bytes;
-    int32_t use_graph;          /* 1: replay a cached hipGraph of one Euler step */
+    int32_t use_graph;          /* 1: replay a cached hipGraph of one Euler step (ignored by the Heun solver) */
+    int32_t solver;             /* DexSolver; 0 = Euler, what Diffusion wires (diffusion.py:216) */
 } DexSampleArgs;
 
 /* One EDMPrecond.forward call (edm.py:88-98): out = c_skip*x + c_out*F(c_in*x, mask, mu, ln(sigma)/4). */
@@ -98,7 +101,10 @@ int  dex_ctx_load_weight(DexCtx* ctx, const char* key, const float* w_dev, const
 int  dex_ctx_finalize(DexCtx* ctx, dex_stream_t stream);
 int  dex_ctx_set_precision(DexCtx* ctx, int precision /* DexPrecision */);
 
-size_t dex_workspace_bytes(const DexCtx* ctx, int B, int T, int Tr, int Ts, int n_steps);
+/* n_evals = number of network evaluations of the run: dex_num_evals(n_steps, solver). */
+size_t dex_workspace_bytes(const DexCtx* ctx, int B, int T, int Tr, int Ts, int n_evals);
+/* Euler: n_steps.  Heun (edm.py:202-214): 2*n_steps - 1 (no corrector on the last step). */
+int  dex_num_evals(int n_steps, int solver /* DexSolver */);
 int  dex_sample(DexCtx* ctx, const DexSampleArgs* args, dex_stream_t stream);
 int  dex_denoise_once(DexCtx* ctx, const DexDenoiseArgs* args, dex_stream_t stream);
 

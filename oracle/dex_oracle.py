@@ -330,10 +330,40 @@ def edm_euler_sampler(W, cfg, z: Tensor, mask: Tensor, mu: Tensor, n_steps: int,
     return x
 
 
-def diffusion_infer(W, cfg, mask: Tensor, mu: Tensor, n_timesteps: int, z: Tensor, **kw) -> Tensor:
+def edm_heun_sampler(W, cfg, z: Tensor, mask: Tensor, mu: Tensor, n_steps: int, trace: Optional[list] = None,
+                     **kw) -> Tensor:
+    """ablation_sampler(solver='heun', alpha=1, discretization='edm', schedule='linear', scaling='none')
+    — edm.py:186-214.  Predictor as in Euler (edm.py:199-204); every step but the last then evaluates the
+    network a second time at (x', t') with t' = t + 1*h (fp32: not necessarily bit-equal to t_next) and
+    averages the two slopes (edm.py:207-214).  S_churn = 0, so x_hat = x_cur and t_hat = t_cur."""
+    ts = edm_sigmas(n_steps, z.dtype)
+    x = z * ts[0]
+    for i in range(n_steps):
+        t_cur, t_next = ts[i], ts[i + 1]
+        h = t_next - t_cur
+        den = edm_precond(W, cfg, x, t_cur, mask, mu, **kw)
+        d_cur = (1 / t_cur) * x - (1 / t_cur) * den
+        if i == n_steps - 1:
+            x = x + h * d_cur
+        else:
+            x_prime = x + h * d_cur
+            t_prime = t_cur + h
+            den = edm_precond(W, cfg, x_prime, t_prime, mask, mu, **kw)
+            d_prime = (1 / t_prime) * x_prime - (1 / t_prime) * den
+            x = x + h * (0.5 * d_cur + 0.5 * d_prime)
+        if trace is not None:
+            trace.append(x.clone())
+    return x
+
+
+def diffusion_infer(W, cfg, mask: Tensor, mu: Tensor, n_timesteps: int, z: Tensor, solver: str = "euler", **kw) -> Tensor:
     """Diffusion.forward(infer=True) with the latent z = randn/temperature + mu supplied explicitly
-    (GeDEX diffusion.py:225-229 / DEX :255-259)."""
-    return edm_euler_sampler(W, cfg, z, mask, mu, n_timesteps, **kw)
+    (GeDEX diffusion.py:225-229 / DEX :255-259).  The reference wires solver='euler' (diffusion.py:216);
+    'heun' is the other branch of the same ablation_sampler."""
+    if solver not in ("euler", "heun"):
+        raise ValueError(f"solver must be 'euler' or 'heun', got {solver!r}")
+    fn = edm_euler_sampler if solver == "euler" else edm_heun_sampler
+    return fn(W, cfg, z, mask, mu, n_timesteps, **kw)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -141,7 +141,61 @@ def golden_audio():
     print("audio:", sr, len(wav), melf.shape, out["sample1_1s_mel"].shape)
 
 
+@torch.no_grad()
+def golden_heun():
+    """Second-order branch of the reference's own ablation_sampler (edm.py:207-214) on the inputs of the
+    gedex_lj / dex_vctk fixtures (same seeds, so only the outputs are stored), plus the sigma sequence the
+    network is called with (pins t' = t + 1*h in fp32)."""
+    out = {}
+    for name, cfg, B, T, lengths, steps, dex_dims in (
+            ("gedex_lj", C.gedex_lj(), 2, 64, [64, 44], (4, 7), None),
+            ("dex_vctk", C.dex_vctk(), 1, 64, [57], (4,), (40, 40, [33]))):
+        m = manifest(name + "_heun", cfg)
+        edm = sys.modules[type(m.precond_model).__module__]
+        mu, mask, z, lengths = synth.make_inputs(B, T, lengths, seed=1234)
+        tmu, tmask, tz = map(torch.from_numpy, (mu, mask, z))
+        kw = {}
+        if cfg.variant == "dex":
+            Tr, Ts, sl = dex_dims
+            ref, ref_len, sty, sty_len = synth.make_dex_style(B, Tr, Ts, cfg.mid_dim, sty_lengths=sl)
+            kw = dict(ref=[torch.from_numpy(r) for r in ref], ref_lengths=torch.from_numpy(ref_len),
+                      sty=torch.from_numpy(sty), sty_lengths=torch.from_numpy(sty_len))
+        for n in steps:
+            y = edm.ablation_sampler(net=m.precond_model, latents=tz, mask=tmask, mu=tmu, spk=None, num_steps=n,
+                                     solver="heun", discretization="edm", schedule="linear", scaling="none", **kw)
+            out[f"{name}_n{n}"] = y.numpy()
+
+    ref_import.import_reference("GeDEX-TTS")
+    edm = sys.modules["model.edm"]
+
+    class Rec:
+        sigma_min, sigma_max = 0, float("inf")
+
+        def __init__(self):
+            self.s = []
+
+        def round_sigma(self, s):
+            return torch.as_tensor(s)
+
+        def __call__(self, x, sigma, mask, mu, spk=None):
+            self.s.append(float(sigma))
+            return x * 0.5
+
+    for n in (6, 50):
+        r = Rec()
+        edm.ablation_sampler(net=r, latents=torch.ones(1, 1, 1), num_steps=n, solver="heun",
+                             discretization="edm", schedule="linear", scaling="none")
+        out[f"sigmas_n{n}"] = np.asarray(r.s, dtype=np.float32)
+    np.savez_compressed(os.path.join(OUT, "heun.npz"), **out)
+    print("heun:", {k: (v.shape, float(np.abs(v).max())) for k, v in out.items()})
+
+
 def main():
+    if "--heun-only" in sys.argv:
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        golden_heun()
+        return
     torch.manual_seed(0)
     torch.set_num_threads(8)
     os.makedirs(OUT, exist_ok=True)
@@ -151,6 +205,7 @@ def main():
     golden_model("gedex_vctk", C.gedex_vctk(), B=2, T=32, lengths=[32, 21], sampler_steps=[4], spk=True)
     golden_model("dex_vctk", C.dex_vctk(), B=1, T=64, lengths=[57], sampler_steps=[4, 10], dex_dims=(40, 40, [33]))
     golden_audio()
+    golden_heun()
 
 
 if __name__ == "__main__":

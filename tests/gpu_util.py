@@ -92,10 +92,10 @@ def run_precond(name, case, sigma, dtype=torch.float32, with_taps=True):
     return got, ref, terr
 
 
-def run_sampler(name, case, n_steps, use_graph=False):
+def run_sampler(name, case, n_steps, use_graph=False, solver="euler"):
     cfg, eng, w = engine_for(name)
     W = O.as_torch(w, torch.float32)
     mu, mask, z = (torch.from_numpy(case[k]) for k in ("mu", "mask", "z"))
-    got = eng.sample(z, mask, mu, n_steps, use_graph=use_graph, **engine_kwargs(case)).cpu().numpy()
-    ref = O.diffusion_infer(W, cfg, mask, mu, n_steps, z, **oracle_kwargs(case)).numpy()
+    got = eng.sample(z, mask, mu, n_steps, use_graph=use_graph, solver=solver, **engine_kwargs(case)).cpu().numpy()
+    ref = O.diffusion_infer(W, cfg, mask, mu, n_steps, z, solver=solver, **oracle_kwargs(case)).numpy()
     return got, ref

@@ -72,6 +72,65 @@ def test_oracle_sampler(name, kw, n):
     assert err.max() <= 2e-3 and err.mean() <= 2e-4, (err.max(), err.mean())
 
 
+@pytest.mark.parametrize("key", ["gedex_lj_n4", "gedex_lj_n7", "dex_vctk_n4"])
+def test_heun_golden(key):
+    """solver='heun' (edm.py:207-214) against goldens from the reference's own ablation_sampler."""
+    name, n = key.rsplit("_n", 1)
+    g, h = gold(name), gold("heun")
+    cfg, eng, w = U.engine_for(name)
+    mu, mask, z = (torch.from_numpy(g[k]) for k in ("mu", "mask", "z"))
+    got = eng.sample(z, mask, mu, int(n), solver="heun", **U.engine_kwargs(g)).cpu().numpy()
+    err = np.abs(got - h[key])
+    assert err.max() <= 2e-3 and err.mean() <= 2e-4, (key, err.max(), err.mean())
+
+
+@pytest.mark.parametrize("name,kw,n", [
+    ("gedex_lj", dict(B=3, T=100, lengths=[100, 61, 7]), 5),
+    ("gedex_vctk", dict(B=2, T=36, lengths=[36, 20]), 3),
+    ("dex_vctk", dict(B=2, T=64, lengths=[64, 40], Tr=48, Ts=48, sty_lengths=[48, 20]), 4),
+])
+def test_heun_oracle(name, kw, n):
+    cfg, eng, w = U.engine_for(name)
+    case = U.make_case(cfg, **kw)
+    got, ref = U.run_sampler(name, case, n, solver="heun")
+    err = np.abs(got - ref)
+    assert err.max() <= 2e-3 and err.mean() <= 2e-4, (err.max(), err.mean())
+    # the same engine goes straight back to Euler (table sizes and modes are per call)
+    got, ref = U.run_sampler(name, case, n)
+    err = np.abs(got - ref)
+    assert err.max() <= 2e-3 and err.mean() <= 2e-4, (err.max(), err.mean())
+
+
+def test_heun_bf16_mode_and_module_switch():
+    """bf16 mode under Heun stays inside the documented bf16 tolerance; Diffusion.solver selects the branch."""
+    from dex_tts_amd import config as C, synth
+    from dex_tts_amd.diffusion import from_config
+    cfg, eng, w = U.engine_for("gedex_lj")
+    case = U.make_case(cfg, B=2, T=128, lengths=[128, 77])
+    _, ref = U.run_sampler("gedex_lj", case, 6, solver="heun")
+    eng.set_precision("bf16")
+    try:
+        got, _ = U.run_sampler("gedex_lj", case, 6, solver="heun")
+    finally:
+        eng.set_precision("fp32")
+    err = np.abs(got - ref)
+    assert err.max() <= 5e-2 and err.mean() <= 8e-3, (err.max(), err.mean())
+    m = from_config(cfg)
+    sd = {}
+    for k, v in w.items():
+        sd[f"denoise_fn.{k}"] = torch.from_numpy(v)
+        sd[f"precond_model.model.{k}"] = torch.from_numpy(v)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    mu, mask, z = (torch.from_numpy(case[k]).cuda() for k in ("mu", "mask", "z"))
+    m.solver = "heun"
+    y = m.sampler(z, mask, mu, None, 6).cpu().numpy()
+    err = np.abs(y - ref)
+    assert err.max() <= 2e-3 and err.mean() <= 2e-4
+    with pytest.raises(ValueError):
+        eng.sample(z, mask, mu, 4, solver="rk4")
+
+
 def test_graph_replay_matches_eager():
     cfg, eng, w = U.engine_for("gedex_lj")
     case = U.make_case(cfg, B=2, T=64, lengths=[64, 50])

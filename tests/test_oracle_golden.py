@@ -81,6 +81,43 @@ def test_sampler(golden_dir, name):
         assert err.max() <= 1e-3 and err.mean() <= 1e-4, (key, err.max(), err.mean())
 
 
+@pytest.mark.parametrize("key", ["gedex_lj_n4", "gedex_lj_n7", "dex_vctk_n4"])
+def test_sampler_heun(golden_dir, key):
+    """Second-order branch (edm.py:207-214): goldens from the reference's ablation_sampler(solver='heun') on the
+    gedex_lj / dex_vctk fixture inputs."""
+    h = load(golden_dir, "heun")
+    name, n = key.rsplit("_n", 1)
+    g = load(golden_dir, name)
+    cfg = CASES[name]()
+    W = O.as_torch(synth.make_weights(C.param_shapes(cfg)), torch.float32)
+    mu, mask, z = (torch.from_numpy(g[k]) for k in ("mu", "mask", "z"))
+    y = O.diffusion_infer(W, cfg, mask, mu, int(n), z, solver="heun", **oracle_kwargs(g, torch.float32)).numpy()
+    err = np.abs(y - h[key])
+    assert err.max() <= 1e-3 and err.mean() <= 1e-4, (key, err.max(), err.mean())
+    # and it is a different trajectory from Euler's on the same inputs (the test would otherwise pin nothing)
+    if f"sampler_n{n}" in g:
+        assert np.abs(h[key] - g[f"sampler_n{n}"]).max() > 1e-2
+
+
+def test_heun_sigma_sequence(golden_dir):
+    """The sigma each network evaluation sees: t_i for the predictor, fl(t_i + fl(t_{i+1} - t_i)) for the
+    corrector, no corrector on the last step -> 2n-1 evaluations."""
+    from dex_tts_amd.engine import heun_eval_sigmas
+    h = load(golden_dir, "heun")
+    for k in ("sigmas_n6", "sigmas_n50"):
+        n = int(k[len("sigmas_n"):])
+        want = h[k]
+        assert len(want) == 2 * n - 1
+        ts = O.edm_sigmas(n)
+        got = []
+        for i in range(n):
+            got.append(float(ts[i]))
+            if i < n - 1:
+                got.append(float(ts[i] + (ts[i + 1] - ts[i])))
+        np.testing.assert_array_equal(np.asarray(got, np.float32), want)
+        np.testing.assert_array_equal(heun_eval_sigmas(n).numpy()[:-1], want)
+
+
 def test_sigma_tables(golden_dir):
     g = dict(np.load(os.path.join(golden_dir, "sigma_tables.npz")))
     for k, v in g.items():
