@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libdexamd.so")
+# DEX_AMD_LIB: A/B tooling only (two builds of the same library side by side); still no fallback if it is absent
+LIB_PATH = os.environ.get("DEX_AMD_LIB") or os.path.join(HERE, "lib", "libdexamd.so")
 
 DEX_OK = 0
 VARIANT = {"gedex": 0, "dex": 1}

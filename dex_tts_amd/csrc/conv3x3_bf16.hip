@@ -27,7 +27,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: 
 __device__ __forceinline__ float cv_mish(float x) {           // branch-free: tanh(softplus(x)) == 1 to fp32 for x > 20
     const float e = __expf(fminf(x, 20.f));
     const float n = e * (e + 2.f);
-    return x * (n / (n + 2.f));
+    return x * (n * __builtin_amdgcn_rcpf(n + 2.f));
 }
 
 // mean / rstd of the producer's GroupNorm from the slot-spread fp32 partials (8 groups x GN_SLOTS == 256 threads)

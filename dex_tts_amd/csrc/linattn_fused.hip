@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void linattn_kvctx_kernel(const LinKvCtxP p) {
                     const float t = fmaf(v[j], gsc[j], gsh[j]);
                     const float e = __expf(fminf(t, 20.f));
                     const float n = e * (e + 2.f);
-                    const float y = t * (n / (n + 2.f));                 // Mish
+                    const float y = t * (n * __builtin_amdgcn_rcpf(n + 2.f));   // Mish (rcp: 1 ulp, bf16 consumers)
                     v[j] = under ? (y + r_[j]) * mkv : fmaf(y, mkv, r_[j]);
                 }
                 xa[ks] = make_float4(v[0], v[1], v[2], v[3]); xc[ks] = make_float4(v[4], v[5], v[6], v[7]);
