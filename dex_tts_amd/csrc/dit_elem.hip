@@ -4,7 +4,7 @@
 
 namespace dex {
 
-__device__ __forceinline__ float silu_d(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float silu_d(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 __device__ __forceinline__ float gelu_d(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // PatchEmbed2D.proj[0..1] (dit.py:57-58): depthwise k x k, stride s, pad k/2; the reference right-pads the

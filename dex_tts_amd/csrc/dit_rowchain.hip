@@ -37,7 +37,7 @@ constexpr size_t RC_LDS = (size_t)RC_ROWS * (A_LD + H_LD) * sizeof(u16) + (size_
 // gets next): ~15 VALU ops instead of the ~45 of libm erff, 32 of them per lane in the fc1 epilogue
 __device__ __forceinline__ float gelu_erf_rc(float x) {
     const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));   // v_rcp_f32 (1 ulp); __frcp_rn expands to the IEEE divide
     float pl = fmaf(1.061405429f, t, -1.453152027f);
     pl = fmaf(pl, t, 1.421413741f); pl = fmaf(pl, t, -0.284496736f); pl = fmaf(pl, t, 0.254829592f);
     const float er = 1.0f - pl * t * __expf(-z * z);           // erf(|x|/sqrt2)

@@ -11,9 +11,9 @@ __device__ __forceinline__ float mish_f(float x) {
     if (x > 20.f) return x;
     const float e = __expf(x);
     const float n = e * (e + 2.f);
-    return x * (n / (n + 2.f));
+    return x * (n * __builtin_amdgcn_rcpf(n + 2.f));        // v_rcp_f32: 1 ulp, an order below the parity tolerances
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
 
 // mean / rstd of each GroupNorm group from the slot-spread fp64 partials: thread (g = tid/16, slot = tid%16)
