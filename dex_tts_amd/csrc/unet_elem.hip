@@ -297,7 +297,11 @@ void launch_heun_expand(const float* sigmas, int n, float* sig, float* h, hipStr
     hipLaunchKernelGGL(heun_expand_kernel, dim3((n + 63) / 64), dim3(64), 0, st, sigmas, n, sig, h);
 }
 void launch_final(const FinalP& p, hipStream_t st) {
+    // every block pays the GroupNorm-coefficient prologue (fp64 divide + sqrt behind a barrier, ~2 us): at large batch
+    // keep the total near 16K blocks so each one streams several 16-pixel groups instead of one
     long blocks = (p.npix + 15) / 16;
+    const long cap = 16384 / p.B > 128 ? 16384 / p.B : 128;
+    if (blocks > cap) blocks = cap;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(final_kernel, dim3((unsigned)blocks, p.B), dim3(256), 0, st, p);
 }
