@@ -329,6 +329,7 @@ bool conv3x3_bf16_supported(int Cin, int Cout) {
 }
 
 void launch_conv3x3_bf16(const Conv3P& p, hipStream_t st) {
+    if (const int tpw = conv3x3_stream_tiles(p)) { launch_conv3x3_stream(p, tpw, st); return; }   // batched synthesis
     // few tiles (half resolution at small batch): 2-row tiles and 64-channel output slices put more, lighter
     // workgroups on the chip (per-tap weight traffic per workgroup halves, two workgroups fit per CU)
     const long tiles4 = (long)((p.W + 31) / 32) * ((p.H + 3) / 4) * p.B;

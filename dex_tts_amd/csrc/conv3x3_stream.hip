@@ -1,0 +1,315 @@
+// conv3x3_stream.hip — 3x3 convolution 64 -> 64 channels for LARGE grids (batched synthesis), bf16 MFMA, fp32 in/out.
+//
+// The tile kernel in conv3x3_bf16.hip is built for latency (batch 1): every workgroup loads its whole patch up front,
+// converts, runs nine taps with the weights streamed through LDS, stores.  With two workgroups per CU those phases
+// barely overlap, and at batch 32 the launch sits at ~2.6 TB/s with the matrix pipe 15 % busy.  This kernel is the
+// throughput form of the same arithmetic:
+//   * one workgroup of eight waves per CU walks DOWN a 32-pixel-wide strip of the image, eight rows per iteration
+//     (one wave per image row, 64 output channels each);
+//   * all nine taps of the weights (9 x 64 x 64 bf16 = 72 KB) are loaded into LDS ONCE per workgroup, so the
+//     iteration has no weight traffic, no per-tap barrier and no global load other than the next rows of the strip;
+//   * the rows of iteration t+1 are requested before the MFMAs of iteration t and converted after them (two
+//     8-row slots in LDS: the rows iteration t no longer needs are overwritten behind a barrier), so HBM latency is
+//     covered by a whole iteration of matrix work;
+//   * rows are read once per strip segment instead of once per 4-row tile (halo 1.05x instead of 1.5x), which also
+//     cuts the fused GroupNorm + Mish prologue by a third;
+//   * GroupNorm partial sums of the output stay in registers across the strip: one reduction per workgroup.
+// Prologue forms are the ones of conv3x3_bf16.hip: PRO (producer's GroupNorm + Mish + time bias, runtime flag) and
+// PRO2 (the previous ResnetBlock's tail: x = mask * Mish(GN(h2)) + res, also written out for later consumers).
+// Reference: Block / ResnetBlock, diffusion.py:42-71.
+#include "kernels.h"
+#include "bf16_util.h"
+#include <cstdlib>
+
+namespace dex {
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SC = 64;                 // channels in and out
+constexpr int SPW = 34;                // patch width: 32 pixels + halo
+constexpr int SLDP = SC + 8;           // LDS row stride (u16) of one pixel / one weight row
+constexpr int STR = 8;                 // image rows per iteration == waves per workgroup
+constexpr int SNT = 512;               // threads
+constexpr int SITEMS = STR * SPW * (SC / 8);          // 8-channel items of one 8-row chunk (2176)
+constexpr int SNI = (SITEMS + SNT - 1) / SNT;         // per thread (5; the last one only for tid < 128)
+constexpr size_t S_LDS = ((size_t)2 * STR * SPW * SLDP + (size_t)9 * SC * SLDP) * sizeof(u16);   // 161280 B
+
+__device__ __forceinline__ float st_mish(float x) {
+    const float e = __expf(fminf(x, 20.f));
+    const float n = e * (e + 2.f);
+    return x * (n * __builtin_amdgcn_rcpf(n + 2.f));
+}
+// x * a + b as an opaque instruction: the first operation on a prefetched value stays where it is written (below the
+// MFMAs of the current iteration) instead of being hoisted to the load together with its s_waitcnt
+__device__ __forceinline__ float fma_pinned(float x, float a, float b) {
+    float r;
+    asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(a), "v"(b));
+    return r;
+}
+
+struct ChunkRegs {
+    f32x4 a[SNI], c[SNI];       // 8 channels of one pixel
+    float mk[SNI];              // mask of the pixel, 0 outside the image
+};
+
+template <bool PRO2>
+__global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, const int tiles_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) u16 smem[];
+    u16* patch = smem;                                 // [2 slots][8 rows][34][SLDP]
+    u16* wts = smem + 2 * STR * SPW * SLDP;            // [9 taps][64 cout][SLDP]
+    __shared__ float smean[8], srstd[8], gnred[16];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int w0 = blockIdx.x * 32, b = blockIdx.z;
+    const int ntile_total = (p.H + STR - 1) / STR;
+    const int t0 = blockIdx.y * tiles_per_wg;
+    const int nt = min(tiles_per_wg, ntile_total - t0);
+    const int hs = t0 * STR;
+    const int step = p.step ? *p.step : 0;
+    const float* X = p.X + (long)b * p.H * p.W * p.ldx + p.x_coff;
+    const float* R = PRO2 ? p.pro_res + (long)b * p.H * p.W * SC : nullptr;
+    const float* mrow = p.mask + (long)b * p.mask_bstride;
+    const bool pro = p.pro_stats != nullptr;
+    const int c8 = (tid & 7) * 8;                      // this thread's channel group in every chunk item
+
+    // ---- weights: all nine taps, once
+    {
+        const u16* Wg = reinterpret_cast<const u16*>(p.Wbf);          // [64][9*64]
+        u32x4 wr[9];
+        const int n = tid >> 3;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) wr[q] = *reinterpret_cast<const u32x4*>(Wg + (long)n * (9 * SC) + q * SC + c8);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) *reinterpret_cast<u32x4*>(wts + (q * SC + n) * SLDP + c8) = wr[q];
+    }
+    // ---- prologue coefficients of this thread's 8 channels:  y = Mish(x * sc + sh) + ta
+    float sc[8], sh[8], ta[8];
+    if (pro) {
+        if (tid < 8 * GN_SLOTS) {
+            const int g = tid / GN_SLOTS;
+            const float* src = p.pro_stats + (((long)b * 8 + g) * GN_SLOTS + (tid % GN_SLOTS)) * 2;
+            double s1 = (double)src[0], s2 = (double)src[1];
+            for (int o = 1; o < GN_SLOTS; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+            if ((tid % GN_SLOTS) == 0) {
+                const double n = (double)p.H * p.W * (SC / 8);
+                const double mean = s1 / n;
+                double var = s2 / n - mean * mean;
+                var = var < 0.0 ? 0.0 : var;
+                smean[g] = (float)mean;
+                srstd[g] = (float)(1.0 / sqrt(var + 1e-5));
+            }
+        }
+        __syncthreads();
+        const float mean = smean[c8 / 8], rstd = srstd[c8 / 8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float ga = p.pro_gamma[c8 + k], be = p.pro_beta[c8 + k];
+            sc[k] = rstd * ga;
+            sh[k] = be - mean * rstd * ga;
+            ta[k] = p.pro_tadd ? p.pro_tadd[(long)step * SC + c8 + k] : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { sc[k] = 1.f; sh[k] = 0.f; ta[k] = 0.f; }
+    }
+
+    // chunk c = image rows hs - 1 + 8c .. + 7, LDS slot c & 1
+    auto load_chunk = [&](int c, ChunkRegs& x, ChunkRegs& r) {
+        // the mask values first: their select is an ordinary instruction the compiler places right behind its load, and
+        // loads retire in order - behind the big loads that wait would drain the whole prefetch before the MFMAs
+#pragma unroll
+        for (int q = 0; q < SNI; ++q) {
+            const int pxi = min((tid >> 3) + (SNT / 8) * q, STR * SPW - 1);
+            const int j = pxi / SPW, pw = pxi - j * SPW;
+            const int hi = hs - 1 + STR * c + j, wi = w0 + pw - 1;
+            const bool inb = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const float mk = mrow[(inb ? wi : 0) * p.mask_ws];
+            x.mk[q] = inb ? mk : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < SNI; ++q) {
+            const int pxi = min((tid >> 3) + (SNT / 8) * q, STR * SPW - 1);
+            const int j = pxi / SPW, pw = pxi - j * SPW;
+            const int hi = hs - 1 + STR * c + j, wi = w0 + pw - 1;
+            const bool inb = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const int hc = inb ? hi : 0, wc = inb ? wi : 0;
+            const float* src = X + ((long)hc * p.W + wc) * p.ldx + c8;
+            x.a[q] = *reinterpret_cast<const f32x4*>(src);
+            x.c[q] = *reinterpret_cast<const f32x4*>(src + 4);
+            if constexpr (PRO2) {
+                const float* rs = R + ((long)hc * p.W + wc) * SC + c8;
+                r.a[q] = *reinterpret_cast<const f32x4*>(rs);
+                r.c[q] = *reinterpret_cast<const f32x4*>(rs + 4);
+            }
+        }
+    };
+    auto store_chunk = [&](int c, const ChunkRegs& x, const ChunkRegs& r) {
+        u16* dst = patch + (c & 1) * STR * SPW * SLDP;
+        const int row_lo = hs, row_hi = min(hs + STR * nt, p.H);        // image rows this workgroup owns (PRO2 write-out)
+#pragma unroll
+        for (int q = 0; q < SNI; ++q) {
+            const int pxi = (tid >> 3) + (SNT / 8) * q;
+            const float mk = x.mk[q];
+            float v[8] = {x.a[q][0], x.a[q][1], x.a[q][2], x.a[q][3], x.c[q][0], x.c[q][1], x.c[q][2], x.c[q][3]};
+            uint4 o;
+            if (pro) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = st_mish(fma_pinned(v[k], sc[k], sh[k])) + ta[k];
+                if constexpr (PRO2) {
+                    const float rr[8] = {r.a[q][0], r.a[q][1], r.a[q][2], r.a[q][3], r.c[q][0], r.c[q][1], r.c[q][2], r.c[q][3]};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = fmaf(v[k], mk, rr[k]);
+                    const int j = pxi / SPW, pw = pxi - j * SPW;
+                    const int hi = hs - 1 + STR * c + j;
+                    if (pxi < STR * SPW && hi >= row_lo && hi < row_hi && pw >= 1 && pw <= 32 && w0 + pw - 1 < p.W) {
+                        float* xo = p.pro_xout + ((long)b * p.H * p.W + (long)hi * p.W + (w0 + pw - 1)) * SC + c8;
+                        *reinterpret_cast<float4*>(xo) = make_float4(v[0], v[1], v[2], v[3]);
+                        *reinterpret_cast<float4*>(xo + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    }
+                }
+                o.x = pack2_bf16(v[0] * mk, v[1] * mk); o.y = pack2_bf16(v[2] * mk, v[3] * mk);
+                o.z = pack2_bf16(v[4] * mk, v[5] * mk); o.w = pack2_bf16(v[6] * mk, v[7] * mk);
+            } else {
+                o.x = pack2_mul_bf16_pinned(v[0], v[1], mk); o.y = pack2_mul_bf16_pinned(v[2], v[3], mk);
+                o.z = pack2_mul_bf16_pinned(v[4], v[5], mk); o.w = pack2_mul_bf16_pinned(v[6], v[7], mk);
+            }
+            if (pxi < STR * SPW) *reinterpret_cast<uint4*>(dst + pxi * SLDP + c8) = o;
+        }
+    };
+
+    ChunkRegs cx, cr;
+    load_chunk(0, cx, cr);
+    store_chunk(0, cx, cr);
+    load_chunk(1, cx, cr);
+    store_chunk(1, cx, cr);
+    lds_barrier();
+
+    const float bias0 = p.bias[i], bias1 = p.bias[32 + i];
+    float gs[2] = {0.f, 0.f}, gss[2] = {0.f, 0.f};
+    float* Yb = p.Y + (long)b * p.H * p.W * SC;
+
+    for (int t = 0; t < nt; ++t) {
+        const bool more = t + 1 < nt;
+        if (more) load_chunk(t + 2, cx, cr);                  // rows of the NEXT iteration; in flight under the MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+        // 36 (tap, K-step) pairs, the fragments of pair s+1 are read from LDS before the MFMAs of pair s are issued
+        const u16* arow[3];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int r = wave + kh;                                          // row of the 10-row window
+            arow[kh] = patch + ((((t + (r >> 3)) & 1) * STR + (r & 7)) * SPW + i) * SLDP + hh * 8;
+        }
+        const u16* brow = wts + i * SLDP + hh * 8;
+        bf16x8 af[2], b0[2], b1[2];
+        af[0] = *reinterpret_cast<const bf16x8*>(arow[0]);
+        b0[0] = *reinterpret_cast<const bf16x8*>(brow);
+        b1[0] = *reinterpret_cast<const bf16x8*>(brow + 32 * SLDP);
+#pragma unroll
+        for (int s = 0; s < 36; ++s) {
+            if (s + 1 < 36) {
+                const int tap = (s + 1) >> 2, ks = (s + 1) & 3, kh = tap / 3, kw = tap - kh * 3;
+                af[(s + 1) & 1] = *reinterpret_cast<const bf16x8*>(arow[kh] + kw * SLDP + ks * 16);
+                b0[(s + 1) & 1] = *reinterpret_cast<const bf16x8*>(brow + tap * SC * SLDP + ks * 16);
+                b1[(s + 1) & 1] = *reinterpret_cast<const bf16x8*>(brow + (tap * SC + 32) * SLDP + ks * 16);
+            }
+            __builtin_amdgcn_sched_barrier(0);            // (the scheduler otherwise sinks each read to right above its MFMA)
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1], b0[s & 1], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1], b1[s & 1], acc[1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- epilogue of this wave's image row
+        {
+            const int ho = hs + STR * t + wave;
+            const bool full = ho < p.H && w0 + 32 <= p.W;
+            float* yl = Yb + ((long)ho * p.W + w0 + 4 * hh) * SC + i;
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2) {
+                const float bias = n2 ? bias1 : bias0;
+                if (full) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[n2][r] + bias;
+                        gs[n2] += v; gss[n2] = fmaf(v, v, gss[n2]);
+                        yl[((r & 3) + 8 * (r >> 2)) * SC + n2 * 32] = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int wo = w0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        const bool ok = ho < p.H && wo < p.W;
+                        const float v = acc[n2][r] + bias;
+                        const float vs = ok ? v : 0.f;
+                        gs[n2] += vs; gss[n2] = fmaf(vs, vs, gss[n2]);
+                        if (ok) yl[((r & 3) + 8 * (r >> 2)) * SC + n2 * 32] = v;
+                    }
+                }
+            }
+        }
+        if (more) {
+            lds_barrier();                                    // every wave is done with the slot of chunk t
+            store_chunk(t + 2, cx, cr);
+            lds_barrier();
+        }
+    }
+
+    if (p.gn_stats) {
+        if (tid < 16) gnred[tid] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) {
+            float a = gs[n2], q = gss[n2];
+            for (int o = 1; o < 8; o <<= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+            a += __shfl_xor(a, 32); q += __shfl_xor(q, 32);
+            if (hh == 0 && (i & 7) == 0) {
+                const int g = (n2 * 32 + i) / 8;
+                atomicAdd(&gnred[g * 2], a); atomicAdd(&gnred[g * 2 + 1], q);
+            }
+        }
+        __syncthreads();
+        if (tid < 16) {
+            const int slot = (blockIdx.x + blockIdx.y * gridDim.x) % GN_SLOTS;
+            atomicAdd(p.gn_stats + (((long)b * 8 + (tid >> 1)) * GN_SLOTS + slot) * 2 + (tid & 1), gnred[tid]);
+        }
+    }
+}
+
+}  // namespace
+
+// Largest strip segment (iterations per workgroup) that still fills the chip once; 0 = use the tile kernel.
+int conv3x3_stream_tiles(const Conv3P& p) {
+    if (p.Cin != SC || p.Cout != SC || p.res_w || p.ldx % 4 != 0 || p.x_coff % 4 != 0) return 0;
+    const char* e = getenv("DEX_CONV_STREAM");           // 0: never, 2: whenever the shape allows (tests), default: by grid size
+    const int mode = e ? atoi(e) : 1;
+    if (mode == 0) return 0;
+    const int tiles = (p.H + STR - 1) / STR;
+    const long strips = (long)((p.W + 31) / 32) * p.B;
+    for (int tpw = tiles < 5 ? tiles : 5; tpw >= 2; --tpw)
+        if (strips * ((tiles + tpw - 1) / tpw) >= 256) return tpw;
+    return mode == 2 ? (tiles < 5 ? tiles : 5) : 0;
+}
+
+void launch_conv3x3_stream(const Conv3P& p, int tiles_per_wg, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_stream64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_stream64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS);
+        attr = true;
+    }
+    const int tiles = (p.H + STR - 1) / STR;
+    dim3 grid((p.W + 31) / 32, (tiles + tiles_per_wg - 1) / tiles_per_wg, p.B);
+    if (p.pro_res) hipLaunchKernelGGL(conv3x3_stream64_kernel<true>, grid, dim3(SNT), S_LDS, st, p, tiles_per_wg);
+    else hipLaunchKernelGGL(conv3x3_stream64_kernel<false>, grid, dim3(SNT), S_LDS, st, p, tiles_per_wg);
+}
+
+}  // namespace dex

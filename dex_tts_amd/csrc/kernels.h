@@ -65,6 +65,9 @@ bool conv3x3_bf16_supported(int Cin, int Cout);
 bool conv3x3_bf16_tail_supported(int C);     // pro_res form (Cin == Cout == C)
 bool conv3x3_bf16_res_supported(int Cin, int Cout);   // res_w form (fused 1x1 shortcut)
 void launch_conv3x3_bf16(const Conv3P& p, hipStream_t st);
+// throughput form for large grids (conv3x3_stream.hip): iterations per workgroup, 0 = not applicable
+int conv3x3_stream_tiles(const Conv3P& p);
+void launch_conv3x3_stream(const Conv3P& p, int tiles_per_wg, hipStream_t st);
 
 // First ResnetBlock of the U-Net: 3x3 conv and 1x1 res_conv straight from the stacked input planes
 // (mu, c_in*x[, spk]) * mask  (diffusion.py:171-175,185; edm.py:96).

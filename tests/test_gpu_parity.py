@@ -259,6 +259,43 @@ def test_bf16_mode_full_size_shapes(name, kw):
         eng.set_precision("fp32")
 
 
+@pytest.mark.parametrize("name,kw", [
+    ("gedex_lj", dict(B=2, T=128, lengths=[128, 77])),               # 4 strips x 2 segments, full tiles
+    ("gedex_lj", dict(B=3, T=100, lengths=[100, 61, 7])),            # last strip 4 pixels wide
+    ("gedex_lj", dict(B=1, T=4)),                                     # one strip narrower than the halo logic assumes
+    ("gedex_vctk", dict(B=2, T=96, lengths=[96, 50])),
+    ("dex_vctk", dict(B=2, T=132, lengths=[132, 77], Tr=100, Ts=100, sty_lengths=[100, 64])),
+])
+def test_conv_stream_path(name, kw):
+    """The strip-streaming 64->64 convolution (conv3x3_stream.hip) is picked by grid size (batched synthesis); here it
+    is forced onto small shapes (DEX_CONV_STREAM=2) and checked against the fp32 mode and against the tile kernel
+    (DEX_CONV_STREAM=0): same bf16 operands, different summation order of the GroupNorm partials only."""
+    cfg, eng, w = U.engine_for(name)
+    case = U.make_case(cfg, **kw)
+    mu, mask, eps = (torch.from_numpy(case[k]) for k in ("mu", "mask", "eps"))
+    old = os.environ.get("DEX_CONV_STREAM")
+    try:
+        for sigma in (80.0, 0.5):
+            x = mu + float(sigma) * eps
+            eng.set_precision("fp32")
+            ref = eng.denoise_once(x, sigma, mask, mu, **U.engine_kwargs(case)).cpu().numpy()
+            eng.set_precision("bf16")
+            os.environ["DEX_CONV_STREAM"] = "0"
+            tile = eng.denoise_once(x, sigma, mask, mu, **U.engine_kwargs(case)).cpu().numpy()
+            os.environ["DEX_CONV_STREAM"] = "2"
+            got = eng.denoise_once(x, sigma, mask, mu, **U.engine_kwargs(case)).cpu().numpy()
+            e = np.abs(got - ref)
+            assert np.isfinite(got).all() and e.max() <= 5e-2 and e.mean() <= 8e-3, (sigma, e.max(), e.mean())
+            d = np.abs(got - tile)
+            assert d.max() <= 5e-2 and d.mean() <= 3e-3, (sigma, d.max(), d.mean())     # two bf16 runs of ONE kernel differ by up to 2e-2 / 1.5e-3 (atomic order)
+    finally:
+        eng.set_precision("fp32")
+        if old is None:
+            os.environ.pop("DEX_CONV_STREAM", None)
+        else:
+            os.environ["DEX_CONV_STREAM"] = old
+
+
 def test_repeatability_fp32_mode():
     """Two identical calls differ only by the summation order of the GroupNorm partial-sum atomics (fp32): <= 2e-5 on a
     single EDMPrecond call at sigma = 80 (measured 4e-6)."""
