@@ -39,6 +39,11 @@ __device__ __forceinline__ float mul_pinned(float x, float y) {
     return r;
 }
 
+// one dword of 2 x bf16 -> the two fp32 values (exact)
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ unsigned short bf16_bits(float x) { return (unsigned short)(pack2_bf16(x, 0.f) & 0xffffu); }
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a full workgroup-scope fence, which the
 // compiler implements as s_waitcnt vmcnt(0): every global load still in flight (a prefetched weight tile, the next
 // K tile of a register ring) is waited for at EVERY barrier, which serialises software pipelines.  Use this one

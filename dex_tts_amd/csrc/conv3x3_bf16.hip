@@ -52,13 +52,15 @@ template <int NT, int COUT>
 __device__ __forceinline__ void cv_epilogue(const Conv3P& p, f32x16 (&acc)[NT], int b, int ho, int w0, int nbase, int lane, int tid,
                                             float* gnred) {
     const int i = lane & 31, hh = lane >> 5;
-    float* Y = p.Y + (long)b * p.H * p.W * COUT;
     constexpr int cpg = COUT / 8;
     if (p.gn_stats) { if (tid < 16) gnred[tid] = 0.f; __syncthreads(); }
     // one 64-bit base per lane; the 16 rows of a tile are compile-time offsets from it (the first version rebuilt a
     // 64-bit address and a bounds predicate per element).  Full tiles (the common case: W % 32 == 0) store unpredicated.
     const bool full = ho < p.H && w0 + 32 <= p.W;
-    float* yl = Y + ((long)ho * p.W + w0 + 4 * hh) * COUT + nbase + i;
+    const long ybase = (long)b * p.H * p.W * COUT + ((long)ho * p.W + w0 + 4 * hh) * COUT + nbase + i;
+    float* yl = p.Y + ybase;
+    u16* yh = reinterpret_cast<u16*>(p.Y) + ybase;            // y_bf16: same element offsets, half the bytes
+    const bool yb = p.y_bf16 != 0;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int n = nbase + t * 32 + i;
@@ -69,7 +71,8 @@ __device__ __forceinline__ void cv_epilogue(const Conv3P& p, f32x16 (&acc)[NT], 
             for (int r = 0; r < 16; ++r) {
                 const float v = acc[t][r] + bias;
                 gs += v; gss = fmaf(v, v, gss);
-                yl[((r & 3) + 8 * (r >> 2)) * COUT + t * 32] = v;
+                if (yb) yh[((r & 3) + 8 * (r >> 2)) * COUT + t * 32] = bf16_bits(v);
+                else yl[((r & 3) + 8 * (r >> 2)) * COUT + t * 32] = v;
             }
         } else {
 #pragma unroll
@@ -79,7 +82,10 @@ __device__ __forceinline__ void cv_epilogue(const Conv3P& p, f32x16 (&acc)[NT], 
                 const float v = acc[t][r] + bias;
                 const float vs = ok ? v : 0.f;
                 gs += vs; gss = fmaf(vs, vs, gss);
-                if (ok) yl[((r & 3) + 8 * (r >> 2)) * COUT + t * 32] = v;
+                if (ok) {
+                    if (yb) yh[((r & 3) + 8 * (r >> 2)) * COUT + t * 32] = bf16_bits(v);
+                    else yl[((r & 3) + 8 * (r >> 2)) * COUT + t * 32] = v;
+                }
             }
         }
         if (p.gn_stats) {
@@ -102,7 +108,7 @@ __device__ __forceinline__ void cv_epilogue(const Conv3P& p, f32x16 (&acc)[NT], 
 
 // CC channels per chunk, output-channel slice [slice*NSL, +NSL) of COUT, TH rows (waves: TH x (4/TH)).
 // grid.z = b * (COUT/NSL) + slice.
-template <int CC, int COUT, int NSL, int TH, bool PRO2 = false, bool RES = false>
+template <int CC, int COUT, int NSL, int TH, bool PRO2 = false, bool RES = false, bool XB = false>
 __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
     constexpr int PW = 34, PH = TH + 2;
     constexpr int LDP = CC + 8;
@@ -129,6 +135,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
     const int b = blockIdx.z / NSLICE, slice = blockIdx.z % NSLICE;
     const int step = p.step ? *p.step : 0;
     const float* X = p.X + (long)b * p.H * p.W * p.ldx + p.x_coff;
+    const u16* Xh = reinterpret_cast<const u16*>(p.X) + (long)b * p.H * p.W * p.ldx + p.x_coff;   // XB: the input is bf16
     const float* mrow = p.mask + (long)b * p.mask_bstride;
     const int K = 9 * p.Cin;
     const u16* Wg = reinterpret_cast<const u16*>(p.Wbf) + (long)slice * NSL * K;     // [COUT][9*Cin], rows of this slice
@@ -190,7 +197,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
         }
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
-            float4 pf0[NIP], pf1[NIP], rf0[PRO2 ? NIP : 1], rf1[PRO2 ? NIP : 1];
+            float4 pf0[NIP], pf1[XB ? 1 : NIP], rf0[PRO2 ? NIP : 1], rf1[PRO2 ? NIP : 1];   // XB: pf0 holds the 8 raw bf16
             float pmk[NIP];
             bool pin[NIP];
 #pragma unroll
@@ -201,9 +208,13 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
                 const int hi = h0 + ph - 1, wi = w0 + pw - 1;
                 const bool inb = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
                 const int hc = inb ? hi : 0, wc = inb ? wi : 0;          // clamped: every load is unconditional
-                const float* src = X + ((long)hc * p.W + wc) * p.ldx + cbase + pc8;
-                pf0[q] = *reinterpret_cast<const float4*>(src);
-                pf1[q] = *reinterpret_cast<const float4*>(src + 4);
+                if constexpr (XB) {
+                    pf0[q] = *reinterpret_cast<const float4*>(Xh + ((long)hc * p.W + wc) * p.ldx + cbase + pc8);
+                } else {
+                    const float* src = X + ((long)hc * p.W + wc) * p.ldx + cbase + pc8;
+                    pf0[q] = *reinterpret_cast<const float4*>(src);
+                    pf1[q] = *reinterpret_cast<const float4*>(src + 4);
+                }
                 if constexpr (PRO2) {
                     const float* rs = p.pro_res + ((long)b * p.H * p.W + (long)hc * p.W + wc) * p.Cin + cbase + pc8;
                     rf0[q] = *reinterpret_cast<const float4*>(rs);
@@ -227,7 +238,13 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
             }
 #pragma unroll
             for (int q = 0; q < NIP; ++q) {
-                float4 f0 = pf0[q], f1 = pf1[q];
+                float4 f0, f1;
+                if constexpr (XB) {
+                    const float4 r = pf0[q];
+                    const unsigned u0 = __float_as_uint(r.x), u1 = __float_as_uint(r.y), u2 = __float_as_uint(r.z), u3 = __float_as_uint(r.w);
+                    f0 = make_float4(bf16_lo(u0), bf16_hi(u0), bf16_lo(u1), bf16_hi(u1));
+                    f1 = make_float4(bf16_lo(u2), bf16_hi(u2), bf16_lo(u3), bf16_hi(u3));
+                } else { f0 = pf0[q]; f1 = pf1[q]; }
                 if (pro) {
                     f0.x = cv_mish((f0.x - mean) * rstd * ga0.x + be0.x) + t0.x; f0.y = cv_mish((f0.y - mean) * rstd * ga0.y + be0.y) + t0.y;
                     f0.z = cv_mish((f0.z - mean) * rstd * ga0.z + be0.z) + t0.z; f0.w = cv_mish((f0.w - mean) * rstd * ga0.w + be0.w) + t0.w;
@@ -309,20 +326,21 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
     cv_epilogue<NT, COUT>(p, acc, b, h0 + wrow, w0, slice * NSL + wcol * NT * 32, lane, tid, gnred);
 }
 
-template <int CC, int COUT, int NSL, int TH, bool PRO2 = false, bool RES = false>
+template <int CC, int COUT, int NSL, int TH, bool PRO2 = false, bool RES = false, bool XB = false>
 static void launch_c3(const Conv3P& p, hipStream_t st) {
     constexpr int LDP = CC + 8;
     const size_t lds = ((size_t)(TH + 2) * 34 * LDP + (2 + (RES ? 1 : 0)) * NSL * LDP) * sizeof(u16);
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<CC, COUT, NSL, TH, PRO2, RES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<CC, COUT, NSL, TH, PRO2, RES, XB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     dim3 grid((p.W + 31) / 32, (p.H + TH - 1) / TH, p.B * (COUT / NSL));
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<CC, COUT, NSL, TH, PRO2, RES>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<CC, COUT, NSL, TH, PRO2, RES, XB>), grid, dim3(256), lds, st, p);
 }
 
 bool conv3x3_bf16_tail_supported(int C) { return C == 64 || C == 128; }
+bool conv3x3_bf16_xb_supported(int Cin, int Cout) { return Cin == Cout && (Cin == 64 || Cin == 128); }   // bf16 INPUT (needs pro_stats)
 bool conv3x3_bf16_res_supported(int Cin, int Cout) { return (Cout == 128 && Cin == 64) || (Cout == 64 && (Cin == 128 || Cin == 256)); }
 bool conv3x3_bf16_supported(int Cin, int Cout) {
     return (Cin == 64 || Cin == 128 || Cin == 256) && (Cout == 64 || Cout == 128);
@@ -334,6 +352,16 @@ void launch_conv3x3_bf16(const Conv3P& p, hipStream_t st) {
     // workgroups on the chip (per-tap weight traffic per workgroup halves, two workgroups fit per CU)
     const long tiles4 = (long)((p.W + 31) / 32) * ((p.H + 3) / 4) * p.B;
     const bool small = tiles4 < 256;       // (at B=32 the 4-row tiles win despite one workgroup per CU: 189 vs 218 us)
+    if (p.x_bf16) {       // raw conv output stored as bf16: the GroupNorm-prologue forms with Cin == Cout (conv3x3_bf16_xb_supported)
+        if (p.pro_res) {
+            if (p.Cin == 64) { small ? launch_c3<64, 64, 64, 2, true, false, true>(p, st) : launch_c3<64, 64, 64, 4, true, false, true>(p, st); }
+            else { small ? launch_c3<128, 128, 64, 2, true, false, true>(p, st) : launch_c3<128, 128, 128, 4, true, false, true>(p, st); }
+        } else {
+            if (p.Cin == 64) { small ? launch_c3<64, 64, 64, 2, false, false, true>(p, st) : launch_c3<64, 64, 64, 4, false, false, true>(p, st); }
+            else { small ? launch_c3<128, 128, 64, 2, false, false, true>(p, st) : launch_c3<128, 128, 128, 4, false, false, true>(p, st); }
+        }
+        return;
+    }
     if (p.pro_res) {      // fused ResnetBlock tail in front: only the Cin == Cout shapes of the second block's first conv
         if (p.Cin == 64 && p.Cout == 64) { small ? launch_c3<64, 64, 64, 2, true>(p, st) : launch_c3<64, 64, 64, 4, true>(p, st); }
         else { small ? launch_c3<128, 128, 64, 2, true>(p, st) : launch_c3<128, 128, 128, 4, true>(p, st); }

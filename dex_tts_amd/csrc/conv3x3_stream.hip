@@ -54,11 +54,11 @@ __device__ __forceinline__ float fma_pinned(float x, float a, float b) {
 }
 
 struct ChunkRegs {
-    f32x4 a[SNI], c[SNI];       // 8 channels of one pixel
+    f32x4 a[SNI], c[SNI];       // 8 channels of one pixel (bf16 input: a holds the 8 raw values, c is unused)
     float mk[SNI];              // mask of the pixel, 0 outside the image
 };
 
-template <bool PRO2>
+template <bool PRO2, bool XB>
 __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, const int tiles_per_wg) {
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* patch = smem;                                 // [2 slots][8 rows][34][SLDP]
@@ -74,6 +74,7 @@ __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, c
     const int hs = t0 * STR;
     const int step = p.step ? *p.step : 0;
     const float* X = p.X + (long)b * p.H * p.W * p.ldx + p.x_coff;
+    const u16* Xh = reinterpret_cast<const u16*>(p.X) + (long)b * p.H * p.W * p.ldx + p.x_coff;      // XB: bf16 input
     const float* R = PRO2 ? p.pro_res + (long)b * p.H * p.W * SC : nullptr;
     const float* mrow = p.mask + (long)b * p.mask_bstride;
     const bool pro = p.pro_stats != nullptr;
@@ -140,9 +141,13 @@ __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, c
             const int hi = hs - 1 + STR * c + j, wi = w0 + pw - 1;
             const bool inb = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
             const int hc = inb ? hi : 0, wc = inb ? wi : 0;
-            const float* src = X + ((long)hc * p.W + wc) * p.ldx + c8;
-            x.a[q] = *reinterpret_cast<const f32x4*>(src);
-            x.c[q] = *reinterpret_cast<const f32x4*>(src + 4);
+            if constexpr (XB) {
+                x.a[q] = *reinterpret_cast<const f32x4*>(Xh + ((long)hc * p.W + wc) * p.ldx + c8);     // 8 raw bf16
+            } else {
+                const float* src = X + ((long)hc * p.W + wc) * p.ldx + c8;
+                x.a[q] = *reinterpret_cast<const f32x4*>(src);
+                x.c[q] = *reinterpret_cast<const f32x4*>(src + 4);
+            }
             if constexpr (PRO2) {
                 const float* rs = R + ((long)hc * p.W + wc) * SC + c8;
                 r.a[q] = *reinterpret_cast<const f32x4*>(rs);
@@ -157,7 +162,17 @@ __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, c
         for (int q = 0; q < SNI; ++q) {
             const int pxi = (tid >> 3) + (SNT / 8) * q;
             const float mk = x.mk[q];
-            float v[8] = {x.a[q][0], x.a[q][1], x.a[q][2], x.a[q][3], x.c[q][0], x.c[q][1], x.c[q][2], x.c[q][3]};
+            float v[8];
+            if constexpr (XB) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const unsigned u = __float_as_uint(x.a[q][k]);
+                    v[2 * k] = bf16_lo(u); v[2 * k + 1] = bf16_hi(u);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) { v[k] = x.a[q][k]; v[4 + k] = x.c[q][k]; }
+            }
             uint4 o;
             if (pro) {
 #pragma unroll
@@ -232,7 +247,10 @@ __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, c
         {
             const int ho = hs + STR * t + wave;
             const bool full = ho < p.H && w0 + 32 <= p.W;
-            float* yl = Yb + ((long)ho * p.W + w0 + 4 * hh) * SC + i;
+            const long yoff = ((long)ho * p.W + w0 + 4 * hh) * SC + i;
+            float* yl = Yb + yoff;
+            u16* yh = reinterpret_cast<u16*>(p.Y) + (long)b * p.H * p.W * SC + yoff;
+            const bool yb = p.y_bf16 != 0;
 #pragma unroll
             for (int n2 = 0; n2 < 2; ++n2) {
                 const float bias = n2 ? bias1 : bias0;
@@ -241,7 +259,8 @@ __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, c
                     for (int r = 0; r < 16; ++r) {
                         const float v = acc[n2][r] + bias;
                         gs[n2] += v; gss[n2] = fmaf(v, v, gss[n2]);
-                        yl[((r & 3) + 8 * (r >> 2)) * SC + n2 * 32] = v;
+                        if (yb) yh[((r & 3) + 8 * (r >> 2)) * SC + n2 * 32] = bf16_bits(v);
+                        else yl[((r & 3) + 8 * (r >> 2)) * SC + n2 * 32] = v;
                     }
                 } else {
 #pragma unroll
@@ -251,7 +270,10 @@ __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, c
                         const float v = acc[n2][r] + bias;
                         const float vs = ok ? v : 0.f;
                         gs[n2] += vs; gss[n2] = fmaf(vs, vs, gss[n2]);
-                        if (ok) yl[((r & 3) + 8 * (r >> 2)) * SC + n2 * 32] = v;
+                        if (ok) {
+                            if (yb) yh[((r & 3) + 8 * (r >> 2)) * SC + n2 * 32] = bf16_bits(v);
+                            else yl[((r & 3) + 8 * (r >> 2)) * SC + n2 * 32] = v;
+                        }
                     }
                 }
             }
@@ -288,28 +310,36 @@ __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, c
 
 // Largest strip segment (iterations per workgroup) that still fills the chip once; 0 = use the tile kernel.
 int conv3x3_stream_tiles(const Conv3P& p) {
-    if (p.Cin != SC || p.Cout != SC || p.res_w || p.ldx % 4 != 0 || p.x_coff % 4 != 0) return 0;
+    if (p.Cin != SC || p.Cout != SC || p.res_w || p.ldx % 8 != 0 || p.x_coff % 8 != 0) return 0;
     const char* e = getenv("DEX_CONV_STREAM");           // 0: never, 2: whenever the shape allows (tests), default: by grid size
     const int mode = e ? atoi(e) : 1;
     if (mode == 0) return 0;
     const int tiles = (p.H + STR - 1) / STR;
     const long strips = (long)((p.W + 31) / 32) * p.B;
-    for (int tpw = tiles < 5 ? tiles : 5; tpw >= 2; --tpw)
+    if (mode != 3) for (int tpw = tiles < 5 ? tiles : 5; tpw >= 2; --tpw)
         if (strips * ((tiles + tpw - 1) / tpw) >= 256) return tpw;
+    if (mode == 3) return strips * tiles >= 128 ? 1 : 0;      // experiment: one 8-row tile per workgroup at batch 1
     return mode == 2 ? (tiles < 5 ? tiles : 5) : 0;
 }
 
 void launch_conv3x3_stream(const Conv3P& p, int tiles_per_wg, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_stream64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_stream64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_stream64_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_stream64_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_stream64_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_stream64_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS);
         attr = true;
     }
     const int tiles = (p.H + STR - 1) / STR;
     dim3 grid((p.W + 31) / 32, (tiles + tiles_per_wg - 1) / tiles_per_wg, p.B);
-    if (p.pro_res) hipLaunchKernelGGL(conv3x3_stream64_kernel<true>, grid, dim3(SNT), S_LDS, st, p, tiles_per_wg);
-    else hipLaunchKernelGGL(conv3x3_stream64_kernel<false>, grid, dim3(SNT), S_LDS, st, p, tiles_per_wg);
+    if (p.x_bf16) {
+        if (p.pro_res) hipLaunchKernelGGL((conv3x3_stream64_kernel<true, true>), grid, dim3(SNT), S_LDS, st, p, tiles_per_wg);
+        else hipLaunchKernelGGL((conv3x3_stream64_kernel<false, true>), grid, dim3(SNT), S_LDS, st, p, tiles_per_wg);
+    } else {
+        if (p.pro_res) hipLaunchKernelGGL((conv3x3_stream64_kernel<true, false>), grid, dim3(SNT), S_LDS, st, p, tiles_per_wg);
+        else hipLaunchKernelGGL((conv3x3_stream64_kernel<false, false>), grid, dim3(SNT), S_LDS, st, p, tiles_per_wg);
+    }
 }
 
 }  // namespace dex

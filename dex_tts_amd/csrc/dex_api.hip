@@ -673,13 +673,18 @@ struct Runner {
     }
     // Block conv (diffusion.py:44).  pro != null fuses the producer's GN-apply + Mish + time bias into the load
     // (bf16 patch kernel only).
-    struct Pro { const float* stats; const float *gamma, *beta, *tadd; const float* res = nullptr; float* xout = nullptr; };
+    struct Pro { const float* stats; const float *gamma, *beta, *tadd; const float* res = nullptr; float* xout = nullptr; bool x_bf16 = false; };
+    // raw conv outputs read only by a fused GroupNorm prologue (h1, h2 of a ResnetBlock, the final block's conv) are kept
+    // in HBM as bf16 in bf16 mode: half the bytes of the largest tensors of the step.  DEX_H_BF16=0 keeps them fp32.
+    bool h_bf16() const { const char* e = getenv("DEX_H_BF16"); return x->precision == DEX_PREC_BF16 && !(e && e[0] == '0'); }
     bool fast_conv(int cin, int cout) const { return x->precision == DEX_PREC_BF16 && conv3x3_bf16_supported(cin, cout); }
     void conv3x3(const char* name, const TD& X, int H, int W, int mask_ws, bool inmask, const float* Wt, const float* bias, int Cout, float* out,
-                 float* gn = nullptr, const Pro* pro = nullptr, const ResW* shortcut = nullptr, float* shortcut_out = nullptr) {
+                 float* gn = nullptr, const Pro* pro = nullptr, const ResW* shortcut = nullptr, float* shortcut_out = nullptr,
+                 bool xb = false, bool yb = false) {
         auto it = x->bf16_of.find(Wt);
         if (fast_conv(X.C, Cout) && it != x->bf16_of.end()) {
             Conv3P c{};
+            c.x_bf16 = xb ? 1 : 0; c.y_bf16 = yb ? 1 : 0;
             c.X = X.p; c.ldx = X.ld; c.x_coff = X.coff; c.H = H; c.W = W; c.Cin = X.C; c.Cout = Cout;
             c.Wbf = it->second; c.bias = bias; c.Y = out; c.mask = mask; c.mask_ws = mask_ws; c.mask_bstride = P.d.T;
             if (pro) { c.pro_stats = pro->stats; c.pro_gamma = pro->gamma; c.pro_beta = pro->beta; c.pro_tadd = pro->tadd; c.pro_res = pro->res; c.pro_xout = pro->xout; }
@@ -723,8 +728,15 @@ struct Runner {
         const long npix = s.npix;
         const float* resptr; int ldres; long resb; bool under = false;
         float* st1 = nullptr;
+        // h1 / h2 of this block as bf16: conv2 must be the GroupNorm-prologue conv that can read bf16, conv1 a kernel that can
+        // write it; h2 additionally needs a fused consumer (the next block's first conv or the attention's context pass)
+        const bool conv2_fast = fast_conv(w.cout, w.cout) && conv3x3_bf16_xb_supported(w.cout, w.cout) && x->bf16_of.count(w.w2);
+        const bool conv1_fast = first_layer || (head ? true : (fast_conv(X.C, w.cout) && x->bf16_of.count(w.w1)));
+        const bool h1b = h_bf16() && conv2_fast && conv1_fast;
+        const bool h2b = h_bf16() && conv2_fast && (ctail || tail);
         if (first_layer) {
             FirstConvP f{};
+            f.h1_bf16 = h1b ? 1 : 0;
             f.mu = mu; f.x = xcur; f.spk = P.spk_plane; f.mask = mask; f.B = P.d.B; f.H = s.H; f.T = s.W; f.planes = w.cin; f.C = w.cout;
             f.W3 = w.w1; f.b3 = w.b1; f.W1 = w.wr; f.b1 = w.br; f.scal = P.scal; f.scal_stride = SCAL_STRIDE; f.step = sp;
             f.h1 = s.h1; f.res = s.rbuf;
@@ -736,10 +748,10 @@ struct Runner {
             bool fused_res = false;
             if (head) {
                 TD H2{s.h2, X.C, 0, X.C};                  // previous block's raw conv2 output
-                conv3x3("conv3x3", H2, s.H, s.W, s.mask_ws, true, w.w1, w.b1, w.cout, s.h1, st1, head);
+                conv3x3("conv3x3", H2, s.H, s.W, s.mask_ws, true, w.w1, w.b1, w.cout, s.h1, st1, head, nullptr, nullptr, head->x_bf16, h1b);
             } else {
                 fused_res = w.wr && fast_conv(X.C, w.cout) && conv3x3_bf16_res_supported(X.C, w.cout) && x->bf16_of.count(w.wr);
-                conv3x3("conv3x3", X, s.H, s.W, s.mask_ws, true, w.w1, w.b1, w.cout, s.h1, st1, nullptr, fused_res ? &w : nullptr, s.rbuf);
+                conv3x3("conv3x3", X, s.H, s.W, s.mask_ws, true, w.w1, w.b1, w.cout, s.h1, st1, nullptr, fused_res ? &w : nullptr, s.rbuf, false, h1b);
             }
             if (fused_res) {
                 resptr = s.rbuf; ldres = w.cout; resb = npix * w.cout;
@@ -758,7 +770,7 @@ struct Runner {
             // block1's GN-apply + Mish + time bias + mask is applied while block2's conv stages its input patch
             Pro pro{st1, w.g1, w.be1, tadd};
             TD H1{s.h1, w.cout, 0, w.cout};
-            conv3x3("conv3x3", H1, s.H, s.W, s.mask_ws, true, w.w2, w.b2, w.cout, s.h2, st2, &pro);
+            conv3x3("conv3x3", H1, s.H, s.W, s.mask_ws, true, w.w2, w.b2, w.cout, s.h2, st2, &pro, nullptr, nullptr, h1b, h2b);
         } else {
             gn_apply(s.h1, w.cout, npix, s.W, s.mask_ws, st1, w.g1, w.be1, tadd, nullptr, 0, 0, false, s.a1);
             TD A1{s.a1, w.cout, 0, w.cout};
@@ -766,12 +778,14 @@ struct Runner {
         }
         if (ctail) {       // res_conv shortcut only (resptr is a dense [npix][cout] buffer, added outside the mask)
             ctail->stats = st2; ctail->gamma = w.g2; ctail->beta = w.be2; ctail->tadd = nullptr; ctail->res = resptr; ctail->xout = out;
+            ctail->x_bf16 = h2b;
             return;
         }
         if (tail) {
             tail->H2 = s.h2; tail->gn_stats = st2; tail->gamma = w.g2; tail->beta = w.be2;
             tail->res = resptr; tail->ldres = ldres; tail->resb = resb; tail->res_under_mask = under ? 1 : 0;
             tail->mask = mask; tail->mask_ws = s.mask_ws; tail->mask_bstride = P.d.T; tail->W = s.W; tail->Xout = out;
+            tail->h2_bf16 = h2b ? 1 : 0;
             return;
         }
         gn_apply(s.h2, w.cout, npix, s.W, s.mask_ws, st2, w.g2, w.be2, nullptr, resptr, ldres, resb, under, out);
@@ -1061,8 +1075,10 @@ struct Runner {
         tap("up_out", P.up_out, (long)B * 80 * P.d.T, c.dim, c.dim);
         TD U{P.up_out, c.dim, 0, c.dim};
         float* stf = next_stats();
-        conv3x3("conv3x3", U, 80, P.d.T, 1, true, x->fin_w, x->fin_b, c.dim, P.hF, stf);
+        const bool hfb = h_bf16() && fast_conv(c.dim, c.dim) && x->bf16_of.count(x->fin_w);
+        conv3x3("conv3x3", U, 80, P.d.T, 1, true, x->fin_w, x->fin_b, c.dim, P.hF, stf, nullptr, nullptr, nullptr, false, hfb);
         FinalP f{};
+        f.x_bf16 = hfb ? 1 : 0;
         f.X = P.hF; f.xb = 80L * P.d.T * c.dim; f.npix = 80 * P.d.T; f.W = P.d.T; f.C = c.dim; f.groups = 8; f.stats = stf;
         f.gamma = x->fin_g; f.beta = x->fin_be; f.mask = mask; f.mask_bstride = P.d.T; f.wfc = x->fconv_w; f.bfc = x->fconv_b;
         f.xcur = xcur; f.denoised = denoised; f.xnext = xnext; f.scal = P.scal; f.scal_stride = SCAL_STRIDE; f.step = sp; f.B = B;

@@ -60,10 +60,14 @@ struct Conv3P {
     const void* res_w; const float* res_b; float* res_y;
     const int* step; float* gn_stats; int B;
     long long* dbg;                                          // optional phase timestamps (tools/kbench)
+    // raw conv outputs that only a GroupNorm prologue reads next (h1, h2 of a ResnetBlock) may live in HBM as bf16:
+    // x_bf16: X is bf16 [.. ldx] (PRO / PRO2 forms only); y_bf16: Y is written as bf16.  Statistics stay fp32.
+    int x_bf16, y_bf16;
 };
 bool conv3x3_bf16_supported(int Cin, int Cout);
 bool conv3x3_bf16_tail_supported(int C);     // pro_res form (Cin == Cout == C)
 bool conv3x3_bf16_res_supported(int Cin, int Cout);   // res_w form (fused 1x1 shortcut)
+bool conv3x3_bf16_xb_supported(int Cin, int Cout);    // x_bf16 form (bf16 input under a GroupNorm prologue)
 void launch_conv3x3_bf16(const Conv3P& p, hipStream_t st);
 // throughput form for large grids (conv3x3_stream.hip): iterations per workgroup, 0 = not applicable
 int conv3x3_stream_tiles(const Conv3P& p);
@@ -78,6 +82,7 @@ struct FirstConvP {
     const float* W1; const float* b1;                     // [planes][C], [C]
     const float* scal; int scal_stride; const int* step;  // per-step scalars; scal[step*stride + 2] = c_in
     float* h1; float* res;                                // [B,H,T,C] each
+    int h1_bf16;                                          // h1 stored as bf16 (its only reader is the next conv's GN prologue)
     float* gn_stats;                                      // fused GroupNorm partials of h1 (8 groups, slot-spread) or null
 };
 void launch_first_conv(const FirstConvP& p, hipStream_t st);
@@ -113,6 +118,7 @@ struct FinalP {
     // mode 1: predictor - also stores the slope d_cur in dbuf (xnext receives x' = x_hat + h d_cur);
     // mode 2: corrector - xcur is x', xhat the state the step started from: xnext = xhat + h (0.5 d_cur + 0.5 d').
     int mode; const float* htab; float* dbuf; const float* xhat;
+    int x_bf16;                                           // X (the final conv's raw output) is bf16
 };
 void launch_final(const FinalP& p, hipStream_t st);
 // Heun evaluation tables from the schedule t_0..t_N: sig[2i] = t_i, sig[2i+1] = t_i + (t_{i+1} - t_i) (i < n-1),
@@ -138,7 +144,8 @@ struct LinKvCtxP { const float* X; int ldx; int x_coff; long xb; int npix; int C
                    // not read (diffusion.py:49,67-71).  gn_stats: slot-spread partials of H2; W/mask_ws: mask column map.
                    const float* H2; const float* gn_stats; const float* gamma; const float* beta;
                    const float* res; int ldres; long resb; int res_under_mask;
-                   const float* mask; int mask_ws; long mask_bstride; int W; float* Xout; };
+                   const float* mask; int mask_ws; long mask_bstride; int W; float* Xout;
+                   int h2_bf16; };                          // H2 is bf16 [npix][C]
 void launch_linattn_kvctx(const LinKvCtxP& p, hipStream_t st);
 struct LinMergeP { const float* part_m; const float* part_s; const float* part_c; int nblk;
                    const float* Wout; const float* g; int C; void* W2; int B; };       // Wout fp32 [C][128]

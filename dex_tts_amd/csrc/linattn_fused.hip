@@ -66,13 +66,20 @@ __global__ __launch_bounds__(256) void linattn_kvctx_kernel(const LinKvCtxP p) {
     float mkv = 1.f;
     float ga_pre = 0.f, be_pre = 0.f;                       // GroupNorm affine of channel tid, requested with the first loads
     if constexpr (PRO) { if (tid < C) { ga_pre = p.gamma[tid]; be_pre = p.beta[tid]; } }
+    const bool hb = PRO && p.h2_bf16 != 0;                 // H2 stored as bf16: xa holds the 8 raw values until they are used
+    const unsigned short* Xh = PRO ? reinterpret_cast<const unsigned short*>(p.H2) + (long)b * p.npix * C : nullptr;
     {
         const int pxr = min(px_base + i, p.npix - 1);
         const float* xr = X + (long)pxr * ldx + hh * 8;
+        if (hb) {
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            xa[ks] = *reinterpret_cast<const float4*>(xr + ks * 16);
-            xc[ks] = *reinterpret_cast<const float4*>(xr + ks * 16 + 4);
+            for (int ks = 0; ks < KS; ++ks) { xa[ks] = *reinterpret_cast<const float4*>(Xh + (long)pxr * C + hh * 8 + ks * 16); xc[ks] = xa[ks]; }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                xa[ks] = *reinterpret_cast<const float4*>(xr + ks * 16);
+                xc[ks] = *reinterpret_cast<const float4*>(xr + ks * 16 + 4);
+            }
         }
         if constexpr (PRO) {
             if (R) {
@@ -124,6 +131,11 @@ __global__ __launch_bounds__(256) void linattn_kvctx_kernel(const LinKvCtxP p) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 float v[8] = {xa[ks].x, xa[ks].y, xa[ks].z, xa[ks].w, xc[ks].x, xc[ks].y, xc[ks].z, xc[ks].w};
+                if (hb) {
+                    const unsigned u0 = __float_as_uint(xa[ks].x), u1 = __float_as_uint(xa[ks].y), u2 = __float_as_uint(xa[ks].z), u3 = __float_as_uint(xa[ks].w);
+                    v[0] = bf16_lo(u0); v[1] = bf16_hi(u0); v[2] = bf16_lo(u1); v[3] = bf16_hi(u1);
+                    v[4] = bf16_lo(u2); v[5] = bf16_hi(u2); v[6] = bf16_lo(u3); v[7] = bf16_hi(u3);
+                }
                 float r_[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 const float4 sc0 = *reinterpret_cast<const float4*>(gsc_s + ks * 16 + hh * 8), sc1 = *reinterpret_cast<const float4*>(gsc_s + ks * 16 + hh * 8 + 4);
                 const float4 sh0 = *reinterpret_cast<const float4*>(gsh_s + ks * 16 + hh * 8), sh1 = *reinterpret_cast<const float4*>(gsh_s + ks * 16 + hh * 8 + 4);
@@ -155,10 +167,15 @@ __global__ __launch_bounds__(256) void linattn_kvctx_kernel(const LinKvCtxP p) {
         if (sub + 1 < p.nsub) {
             const int pxr = min(px0 + 32 + i, p.npix - 1);
             const float* xr = X + (long)pxr * ldx + hh * 8;
+            if (hb) {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                xa[ks] = *reinterpret_cast<const float4*>(xr + ks * 16);
-                xc[ks] = *reinterpret_cast<const float4*>(xr + ks * 16 + 4);
+                for (int ks = 0; ks < KS; ++ks) { xa[ks] = *reinterpret_cast<const float4*>(Xh + (long)pxr * C + hh * 8 + ks * 16); xc[ks] = xa[ks]; }
+            } else {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    xa[ks] = *reinterpret_cast<const float4*>(xr + ks * 16);
+                    xc[ks] = *reinterpret_cast<const float4*>(xr + ks * 16 + 4);
+                }
             }
             if constexpr (PRO) {
                 if (R) {

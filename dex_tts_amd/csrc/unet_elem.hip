@@ -2,6 +2,7 @@
 // first-layer direct convolution, GroupNorm statistics, GN-apply+Mish+mask(+time bias)(+residual),
 // the fused final_block tail + final_conv + EDM combine + Euler update, conditioning tables.
 #include "kernels.h"
+#include "bf16_util.h"
 
 namespace dex {
 
@@ -106,9 +107,17 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const FirstConvP p) {
         }
     }
     if (live) {
+        if (p.h1_bf16) {
+            uint4 lo, hi;
+            lo.x = pack2_bf16(a3[0].x, a3[0].y); lo.y = pack2_bf16(a3[0].z, a3[0].w); lo.z = pack2_bf16(a3[1].x, a3[1].y); lo.w = pack2_bf16(a3[1].z, a3[1].w);
+            hi.x = pack2_bf16(a3[2].x, a3[2].y); hi.y = pack2_bf16(a3[2].z, a3[2].w); hi.z = pack2_bf16(a3[3].x, a3[3].y); hi.w = pack2_bf16(a3[3].z, a3[3].w);
+            unsigned short* h = reinterpret_cast<unsigned short*>(p.h1) + pix * C + cq * 16;
+            *reinterpret_cast<uint4*>(h) = lo;
+            *reinterpret_cast<uint4*>(h + 8) = hi;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            *reinterpret_cast<float4*>(p.h1 + pix * C + cq * 16 + j * 4) = a3[j];
+            if (!p.h1_bf16) *reinterpret_cast<float4*>(p.h1 + pix * C + cq * 16 + j * 4) = a3[j];
             *reinterpret_cast<float4*>(p.res + pix * C + cq * 16 + j * 4) = a1[j];
         }
     }
@@ -251,7 +260,11 @@ __global__ __launch_bounds__(256) void final_kernel(const FinalP p) {
         for (int c = sub * 4; c < p.C; c += 64) {
             const int g = c / cpg;
             const float mean = smean[g], rstd = srstd[g];
-            const float4 x = *reinterpret_cast<const float4*>(X + px * p.C + c);
+            float4 x;
+            if (p.x_bf16) {
+                const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.X) + (long)b * p.xb + px * p.C + c);
+                x = make_float4(bf16_lo(r.x), bf16_hi(r.x), bf16_lo(r.y), bf16_hi(r.y));
+            } else x = *reinterpret_cast<const float4*>(X + px * p.C + c);
             const float4 ga = *reinterpret_cast<const float4*>(p.gamma + c);
             const float4 be = *reinterpret_cast<const float4*>(p.beta + c);
             const float4 wv = *reinterpret_cast<const float4*>(p.wfc + c);
