@@ -58,12 +58,13 @@ struct ChunkRegs {
     float mk[SNI];              // mask of the pixel, 0 outside the image
 };
 
-template <bool PRO2, bool XB>
+template <bool PRO, bool PRO2, bool XB>
 __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, const int tiles_per_wg) {
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* patch = smem;                                 // [2 slots][8 rows][34][SLDP]
     u16* wts = smem + 2 * STR * SPW * SLDP;            // [9 taps][64 cout][SLDP]
     __shared__ float smean[8], srstd[8], gnred[16];
+    __shared__ __attribute__((aligned(16))) float coef[3][SC];        // GroupNorm prologue per channel: scale, shift, time bias
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
@@ -77,52 +78,36 @@ __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, c
     const u16* Xh = reinterpret_cast<const u16*>(p.X) + (long)b * p.H * p.W * p.ldx + p.x_coff;      // XB: bf16 input
     const float* R = PRO2 ? p.pro_res + (long)b * p.H * p.W * SC : nullptr;
     const float* mrow = p.mask + (long)b * p.mask_bstride;
-    const bool pro = p.pro_stats != nullptr;
+    constexpr bool pro = PRO;
     const int c8 = (tid & 7) * 8;                      // this thread's channel group in every chunk item
+#ifdef DEX_TIMING
+    long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long tk0 = __builtin_readcyclecounter();
+#define STAMP(k) do { const long long now_ = __builtin_readcyclecounter(); tk[k] += now_ - tlast; tlast = now_; } while (0)
+    long long tlast = tk0;
+#else
+#define STAMP(k) do {} while (0)
+#endif
 
-    // ---- weights: all nine taps, once
+    // ---- set-up loads go out together: GroupNorm partials first (oldest in the queue: their wait leaves the rest in
+    // flight), all nine taps of the weights, then (below) the first two row chunks
+    float gn_s1 = 0.f, gn_s2 = 0.f, gn_ga = 0.f, gn_be = 0.f, gn_ta = 0.f;
+    if constexpr (PRO) {
+        if (tid < 8 * GN_SLOTS) {
+            const float* src = p.pro_stats + (((long)b * 8 + tid / GN_SLOTS) * GN_SLOTS + (tid % GN_SLOTS)) * 2;
+            gn_s1 = src[0]; gn_s2 = src[1];
+        }
+        if (tid < SC) { gn_ga = p.pro_gamma[tid]; gn_be = p.pro_beta[tid]; gn_ta = p.pro_tadd ? p.pro_tadd[(long)step * SC + tid] : 0.f; }
+    }
+    u32x4 wr[9];
     {
         const u16* Wg = reinterpret_cast<const u16*>(p.Wbf);          // [64][9*64]
-        u32x4 wr[9];
-        const int n = tid >> 3;
 #pragma unroll
-        for (int q = 0; q < 9; ++q) wr[q] = *reinterpret_cast<const u32x4*>(Wg + (long)n * (9 * SC) + q * SC + c8);
-#pragma unroll
-        for (int q = 0; q < 9; ++q) *reinterpret_cast<u32x4*>(wts + (q * SC + n) * SLDP + c8) = wr[q];
-    }
-    // ---- prologue coefficients of this thread's 8 channels:  y = Mish(x * sc + sh) + ta
-    float sc[8], sh[8], ta[8];
-    if (pro) {
-        if (tid < 8 * GN_SLOTS) {
-            const int g = tid / GN_SLOTS;
-            const float* src = p.pro_stats + (((long)b * 8 + g) * GN_SLOTS + (tid % GN_SLOTS)) * 2;
-            double s1 = (double)src[0], s2 = (double)src[1];
-            for (int o = 1; o < GN_SLOTS; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-            if ((tid % GN_SLOTS) == 0) {
-                const double n = (double)p.H * p.W * (SC / 8);
-                const double mean = s1 / n;
-                double var = s2 / n - mean * mean;
-                var = var < 0.0 ? 0.0 : var;
-                smean[g] = (float)mean;
-                srstd[g] = (float)(1.0 / sqrt(var + 1e-5));
-            }
-        }
-        __syncthreads();
-        const float mean = smean[c8 / 8], rstd = srstd[c8 / 8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const float ga = p.pro_gamma[c8 + k], be = p.pro_beta[c8 + k];
-            sc[k] = rstd * ga;
-            sh[k] = be - mean * rstd * ga;
-            ta[k] = p.pro_tadd ? p.pro_tadd[(long)step * SC + c8 + k] : 0.f;
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { sc[k] = 1.f; sh[k] = 0.f; ta[k] = 0.f; }
+        for (int q = 0; q < 9; ++q) wr[q] = *reinterpret_cast<const u32x4*>(Wg + (long)(tid >> 3) * (9 * SC) + q * SC + c8);
     }
 
     // chunk c = image rows hs - 1 + 8c .. + 7, LDS slot c & 1
-    auto load_chunk = [&](int c, ChunkRegs& x, ChunkRegs& r) {
+    auto load_chunk = [&](int c, ChunkRegs& x, ChunkRegs& r) __attribute__((always_inline)) {
         // the mask values first: their select is an ordinary instruction the compiler places right behind its load, and
         // loads retire in order - behind the big loads that wait would drain the whole prefetch before the MFMAs
 #pragma unroll
@@ -155,7 +140,7 @@ __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, c
             }
         }
     };
-    auto store_chunk = [&](int c, const ChunkRegs& x, const ChunkRegs& r) {
+    auto store_chunk = [&](int c, const ChunkRegs& x, const ChunkRegs& r) __attribute__((always_inline)) {
         u16* dst = patch + (c & 1) * STR * SPW * SLDP;
         const int row_lo = hs, row_hi = min(hs + STR * nt, p.H);        // image rows this workgroup owns (PRO2 write-out)
 #pragma unroll
@@ -174,7 +159,11 @@ __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, c
                 for (int k = 0; k < 4; ++k) { v[k] = x.a[q][k]; v[4 + k] = x.c[q][k]; }
             }
             uint4 o;
-            if (pro) {
+            if constexpr (PRO) {
+                float sc[8], sh[8], ta[8];
+                *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(&coef[0][c8]); *reinterpret_cast<float4*>(sc + 4) = *reinterpret_cast<const float4*>(&coef[0][c8 + 4]);
+                *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(&coef[1][c8]); *reinterpret_cast<float4*>(sh + 4) = *reinterpret_cast<const float4*>(&coef[1][c8 + 4]);
+                *reinterpret_cast<float4*>(ta) = *reinterpret_cast<const float4*>(&coef[2][c8]); *reinterpret_cast<float4*>(ta + 4) = *reinterpret_cast<const float4*>(&coef[2][c8 + 4]);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) v[k] = st_mish(fma_pinned(v[k], sc[k], sh[k])) + ta[k];
                 if constexpr (PRO2) {
@@ -199,24 +188,79 @@ __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, c
         }
     };
 
-    ChunkRegs cx, cr;
+    ChunkRegs cx, cr, cx1;
     load_chunk(0, cx, cr);
+    if constexpr (!PRO2) load_chunk(1, cx1, cr);              // (PRO2 carries the residual rows too: one chunk at a time)
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PRO) {        // prologue coefficients per channel:  y = Mish(x * coef0 + coef1) + coef2
+        if (tid < 8 * GN_SLOTS) {
+            double s1 = (double)gn_s1, s2 = (double)gn_s2;
+            for (int o = 1; o < GN_SLOTS; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+            if ((tid % GN_SLOTS) == 0) {
+                const double n = (double)p.H * p.W * (SC / 8);
+                const double mean = s1 / n;
+                double var = s2 / n - mean * mean;
+                var = var < 0.0 ? 0.0 : var;
+                smean[tid / GN_SLOTS] = (float)mean;
+                srstd[tid / GN_SLOTS] = (float)(1.0 / sqrt(var + 1e-5));
+            }
+        }
+        lds_barrier();
+        if (tid < SC) {
+            const float mean = smean[tid / 8], rstd = srstd[tid / 8];
+            coef[0][tid] = rstd * gn_ga;
+            coef[1][tid] = gn_be - mean * rstd * gn_ga;
+            coef[2][tid] = gn_ta;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q) *reinterpret_cast<u32x4*>(wts + (q * SC + (tid >> 3)) * SLDP + c8) = wr[q];
+    lds_barrier();                                            // coefficients visible before the first conversion
     store_chunk(0, cx, cr);
-    load_chunk(1, cx, cr);
-    store_chunk(1, cx, cr);
+    if constexpr (PRO2) { load_chunk(1, cx, cr); store_chunk(1, cx, cr); }
+    else store_chunk(1, cx1, cr);
     lds_barrier();
 
+    STAMP(0);
     const float bias0 = p.bias[i], bias1 = p.bias[32 + i];
     float gs[2] = {0.f, 0.f}, gss[2] = {0.f, 0.f};
-    float* Yb = p.Y + (long)b * p.H * p.W * SC;
+    const bool yb = p.y_bf16 != 0;
 
-    for (int t = 0; t < nt; ++t) {
+    // Epilogue of one wave's image row (32 pixels x 64 channels): + bias, GroupNorm partials, 32 stores from one 64-bit base
+    // per lane (a lane owns ONE channel of 16 pixel rows; each store covers two full 128-byte lines).  Two alternatives
+    // were measured at B=32 and lost: (a) the tile through a wave-private LDS scratch so that it leaves as 16-byte chunks,
+    // 8 stores of 1 KB instead of 32 (164 vs 156 us: one more barrier, same time inside the stores); (b) the previous tile's
+    // stores trickled into the next MFMA loop, one per K-step, with a second accumulator set (175 us: each store still
+    // stalls its wave ~150 cycles, now inside the MFMA loop).  The epilogue waits for the CU's memory pipeline either way.
+    auto emit_tile = [&](const f32x16 (&acc)[2], int t) __attribute__((always_inline)) {
+        const int ho = hs + STR * t + wave;
+        const long off = (long)b * p.H * p.W * SC + ((long)ho * p.W + w0 + 4 * hh) * SC + i;
+        float* yf = p.Y + off; u16* yh = reinterpret_cast<u16*>(p.Y) + off;
+        const bool full = ho < p.H && w0 + 32 <= p.W;
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) {
+            const float bias = n2 ? bias1 : bias0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const bool ok = full || (ho < p.H && w0 + (r & 3) + 8 * (r >> 2) + 4 * hh < p.W);
+                const float v = acc[n2][r] + bias;
+                const float vs = ok ? v : 0.f;
+                gs[n2] += vs; gss[n2] = fmaf(vs, vs, gss[n2]);
+                if (ok) {
+                    if (yb) yh[((r & 3) + 8 * (r >> 2)) * SC + n2 * 32] = bf16_bits(v);
+                    else yf[((r & 3) + 8 * (r >> 2)) * SC + n2 * 32] = v;
+                }
+            }
+        }
+    };
+    // iteration t: request the rows of iteration t+1, then the 72 MFMAs of this wave's image row
+    auto iteration = [&](int t, f32x16 (&cur)[2]) __attribute__((always_inline)) {
         const bool more = t + 1 < nt;
         if (more) load_chunk(t + 2, cx, cr);                  // rows of the NEXT iteration; in flight under the MFMAs
         __builtin_amdgcn_sched_barrier(0);
-        f32x16 acc[2];
+        STAMP(1);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { cur[0][r] = 0.f; cur[1][r] = 0.f; }
         // 36 (tap, K-step) pairs, the fragments of pair s+1 are read from LDS before the MFMAs of pair s are issued
         const u16* arow[3];
 #pragma unroll
@@ -238,53 +282,34 @@ __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, c
                 b1[(s + 1) & 1] = *reinterpret_cast<const bf16x8*>(brow + (tap * SC + 32) * SLDP + ks * 16);
             }
             __builtin_amdgcn_sched_barrier(0);            // (the scheduler otherwise sinks each read to right above its MFMA)
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1], b0[s & 1], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1], b1[s & 1], acc[1], 0, 0, 0);
+            cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1], b0[s & 1], cur[0], 0, 0, 0);
+            cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1], b1[s & 1], cur[1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- epilogue of this wave's image row
-        {
-            const int ho = hs + STR * t + wave;
-            const bool full = ho < p.H && w0 + 32 <= p.W;
-            const long yoff = ((long)ho * p.W + w0 + 4 * hh) * SC + i;
-            float* yl = Yb + yoff;
-            u16* yh = reinterpret_cast<u16*>(p.Y) + (long)b * p.H * p.W * SC + yoff;
-            const bool yb = p.y_bf16 != 0;
-#pragma unroll
-            for (int n2 = 0; n2 < 2; ++n2) {
-                const float bias = n2 ? bias1 : bias0;
-                if (full) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = acc[n2][r] + bias;
-                        gs[n2] += v; gss[n2] = fmaf(v, v, gss[n2]);
-                        if (yb) yh[((r & 3) + 8 * (r >> 2)) * SC + n2 * 32] = bf16_bits(v);
-                        else yl[((r & 3) + 8 * (r >> 2)) * SC + n2 * 32] = v;
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int wo = w0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                        const bool ok = ho < p.H && wo < p.W;
-                        const float v = acc[n2][r] + bias;
-                        const float vs = ok ? v : 0.f;
-                        gs[n2] += vs; gss[n2] = fmaf(vs, vs, gss[n2]);
-                        if (ok) {
-                            if (yb) yh[((r & 3) + 8 * (r >> 2)) * SC + n2 * 32] = bf16_bits(v);
-                            else yl[((r & 3) + 8 * (r >> 2)) * SC + n2 * 32] = v;
-                        }
-                    }
-                }
-            }
-        }
-        if (more) {
-            lds_barrier();                                    // every wave is done with the slot of chunk t
+    };
+    f32x16 acc[2];
+    for (int t = 0; t < nt; ++t) {
+        iteration(t, acc);
+        STAMP(2);
+        emit_tile(acc, t);
+        STAMP(3);
+        if (t + 1 < nt) {
+            lds_barrier();                                    // every wave is done reading the slot of chunk t
+            STAMP(4);
             store_chunk(t + 2, cx, cr);
+            STAMP(5);
             lds_barrier();
+            STAMP(6);
         }
     }
 
+#ifdef DEX_TIMING
+    if (p.dbg && tid == 0) {
+        long long* d = p.dbg + ((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
+        for (int k = 0; k < 7; ++k) d[k] = tk[k];
+        d[7] = __builtin_readcyclecounter() - tk0;
+    }
+#endif
     if (p.gn_stats) {
         if (tid < 16) gnred[tid] = 0.f;
         __syncthreads();
@@ -308,9 +333,19 @@ __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, c
 
 }  // namespace
 
+template <bool PRO, bool PRO2, bool XB>
+static void stream_go(const Conv3P& p, int tiles_per_wg, dim3 grid, hipStream_t st) {
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_stream64_kernel<PRO, PRO2, XB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS);
+        attr = true;
+    }
+    hipLaunchKernelGGL((conv3x3_stream64_kernel<PRO, PRO2, XB>), grid, dim3(SNT), S_LDS, st, p, tiles_per_wg);
+}
+
 // Largest strip segment (iterations per workgroup) that still fills the chip once; 0 = use the tile kernel.
 int conv3x3_stream_tiles(const Conv3P& p) {
-    if (p.Cin != SC || p.Cout != SC || p.res_w || p.ldx % 8 != 0 || p.x_coff % 8 != 0) return 0;
+    if (p.Cin != SC || p.Cout != SC || p.res_w || p.ldx % 8 != 0 || p.x_coff % 8 != 0 || (p.x_bf16 && !p.pro_stats)) return 0;
     const char* e = getenv("DEX_CONV_STREAM");           // 0: never, 2: whenever the shape allows (tests), default: by grid size
     const int mode = e ? atoi(e) : 1;
     if (mode == 0) return 0;
@@ -323,23 +358,12 @@ int conv3x3_stream_tiles(const Conv3P& p) {
 }
 
 void launch_conv3x3_stream(const Conv3P& p, int tiles_per_wg, hipStream_t st) {
-    static bool attr = false;
-    if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_stream64_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_stream64_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_stream64_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_stream64_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)S_LDS);
-        attr = true;
-    }
     const int tiles = (p.H + STR - 1) / STR;
     dim3 grid((p.W + 31) / 32, (tiles + tiles_per_wg - 1) / tiles_per_wg, p.B);
-    if (p.x_bf16) {
-        if (p.pro_res) hipLaunchKernelGGL((conv3x3_stream64_kernel<true, true>), grid, dim3(SNT), S_LDS, st, p, tiles_per_wg);
-        else hipLaunchKernelGGL((conv3x3_stream64_kernel<false, true>), grid, dim3(SNT), S_LDS, st, p, tiles_per_wg);
-    } else {
-        if (p.pro_res) hipLaunchKernelGGL((conv3x3_stream64_kernel<true, false>), grid, dim3(SNT), S_LDS, st, p, tiles_per_wg);
-        else hipLaunchKernelGGL((conv3x3_stream64_kernel<false, false>), grid, dim3(SNT), S_LDS, st, p, tiles_per_wg);
-    }
+    const bool pro = p.pro_stats != nullptr;
+    if (p.pro_res) { p.x_bf16 ? stream_go<true, true, true>(p, tiles_per_wg, grid, st) : stream_go<true, true, false>(p, tiles_per_wg, grid, st); }
+    else if (pro) { p.x_bf16 ? stream_go<true, false, true>(p, tiles_per_wg, grid, st) : stream_go<true, false, false>(p, tiles_per_wg, grid, st); }
+    else stream_go<false, false, false>(p, tiles_per_wg, grid, st);
 }
 
 }  // namespace dex
