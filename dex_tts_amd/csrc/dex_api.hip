@@ -693,7 +693,11 @@ struct Runner {
                 c.res_w = x->bf16_of.at(shortcut->wr); c.res_b = shortcut->br; c.res_y = shortcut_out;
             }
             const double M = (double)H * W * P.d.B;
-            run(name, 2.0 * M * Cout * 9 * X.C, 4.0 * M * (X.C + Cout) + 2.0 * 9 * X.C * Cout, [&] { launch_conv3x3_bf16(c, st); });
+            // algorithmic bytes: input + output at their stored width, + the residual read and the x write-out of the PRO2 form,
+            // + the shortcut output of the RES form, + the weights once
+            const double bytes = M * ((xb ? 2.0 : 4.0) * X.C + (yb ? 2.0 : 4.0) * Cout + (pro && pro->res ? 8.0 * X.C : 0.0) + (shortcut ? 4.0 * Cout : 0.0))
+                                 + 2.0 * 9 * X.C * Cout;
+            run(name, 2.0 * M * Cout * (9 * X.C + (shortcut ? X.C : 0)), bytes, [&] { launch_conv3x3_bf16(c, st); });
             return;
         }
         IGemmP g = base_gemm(X.p, X.ld, X.coff, H, W, X.C, Wt, Cout, bias, out, Cout, 0);
@@ -741,7 +745,7 @@ struct Runner {
             f.W3 = w.w1; f.b3 = w.b1; f.W1 = w.wr; f.b1 = w.br; f.scal = P.scal; f.scal_stride = SCAL_STRIDE; f.step = sp;
             f.h1 = s.h1; f.res = s.rbuf;
             st1 = next_stats(); f.gn_stats = st1;
-            run("first_conv", 2.0 * npix * P.d.B * w.cout * (w.cin * 10), 4.0 * npix * P.d.B * (2 * w.cout + w.cin), [&] { launch_first_conv(f, st); });
+            run("first_conv", 2.0 * npix * P.d.B * w.cout * (w.cin * 10), npix * P.d.B * ((h1b ? 6.0 : 8.0) * w.cout + 4.0 * w.cin), [&] { launch_first_conv(f, st); });
             resptr = s.rbuf; ldres = w.cout; resb = npix * w.cout;
         } else {
             st1 = next_stats();
@@ -805,7 +809,7 @@ struct Runner {
             if (tail) k = *tail;
             k.X = X.p; k.ldx = X.ld; k.x_coff = X.coff; k.xb = npix * X.ld; k.npix = (int)npix; k.C = X.C; k.Wkv = w.wkv_bf16;
             k.nsub = nsub; k.nblk = nblk; k.part_m = s.pm; k.part_s = s.ps; k.part_c = s.pc; k.B = B;
-            run("linattn_kvctx", 2.0 * npix * B * (256.0 * X.C + 128 * 32), (tail ? 12.0 : 4.0) * npix * X.C * B, [&] { launch_linattn_kvctx(k, st); });
+            run("linattn_kvctx", 2.0 * npix * B * (256.0 * X.C + 128 * 32), (tail ? (tail->h2_bf16 ? 10.0 : 12.0) : 4.0) * npix * X.C * B, [&] { launch_linattn_kvctx(k, st); });
             LinMergeP mg{s.pm, s.ps, s.pc, nblk, w.wout_raw, w.g, X.C, s.mbf, B};
             run("linattn_merge", 2.0 * 128 * 32 * X.C * B, 4.0 * nblk * 4 * 1088 * B, [&] { launch_linattn_merge(mg, st); });
             LinOut2P o{X.p, X.ld, X.coff, npix * X.ld, (int)npix, X.C, w.wq_bf16, s.mbf, w.bias_eff, out, ldo, ocoff, npix * ldo, B};
@@ -1084,7 +1088,7 @@ struct Runner {
         f.xcur = xcur; f.denoised = denoised; f.xnext = xnext; f.scal = P.scal; f.scal_stride = SCAL_STRIDE; f.step = sp; f.B = B;
         f.zero_ptr = stats_other; f.zero_n = P.stats_bytes / (long)sizeof(float);
         f.mode = fin_mode; f.htab = fin_htab; f.dbuf = P.dbuf; f.xhat = P.xbuf;
-        run("final_conv_euler", 14.0 * 80 * P.d.T * c.dim * B, 4.0 * 80 * P.d.T * (c.dim + 3) * B, [&] { launch_final(f, st); });
+        run("final_conv_euler", 14.0 * 80 * P.d.T * c.dim * B, 80.0 * P.d.T * ((hfb ? 2.0 : 4.0) * c.dim + 12.0) * B, [&] { launch_final(f, st); });
     }
 
     // conditioning tables for every Euler step (depend only on sigma_i)

@@ -1,6 +1,6 @@
 set -x
 cd /tmp && export TMPDIR=/tmp
-R=/root/repo; O=$R/gpurun_out/r1f; mkdir -p $O
+R=/root/repo; O=$R/gpurun_out/r1g; mkdir -p $O
 python $R/bench.py > $O/bench_default.json 2>$O/bench_default.err
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -o b1 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile > $O/bench_under_rocprof.json 2>/dev/null
 cp /tmp/p1/b1_kernel_stats.csv $O/b1_kernel_stats.csv
