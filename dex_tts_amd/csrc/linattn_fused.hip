@@ -294,6 +294,31 @@ void launch_linattn_kvctx(const LinKvCtxP& p, hipStream_t st) {
 // W2 = g * Wout * blockdiag(ctx^T) per workgroup).  W2 is written as bf16 in the A-fragment order the tail kernel
 // consumes: he index permuted to the accumulator row order of the q^T tiles (see linattn_out2_kernel).
 // thread = (column e = tid%32, partial lane pl = tid/32): 8 lanes stride the partial list with independent loads.
+template <int MC>
+__device__ __forceinline__ void merge_fold(const LinMergeP& p, long pbase, int d, int e, int pl, float& m, float& acc, float& s) {
+    for (int c0 = 0; c0 < p.nblk; c0 += 8 * MC) {
+        float pm[MC], ps[MC], pc[MC];
+#pragma unroll
+        for (int k = 0; k < MC; ++k) {
+            const int c = min(c0 + pl + 8 * k, p.nblk - 1);           // clamped: loads are unconditional
+            pm[k] = p.part_m[(pbase + c) * 32 + d];
+            ps[k] = p.part_s[(pbase + c) * 32 + d];
+            pc[k] = p.part_c[(pbase + c) * 1024 + d * 32 + e];
+        }
+#pragma unroll
+        for (int k = 0; k < MC; ++k) {
+            if (c0 + pl + 8 * k < p.nblk) {
+                const float mn = fmaxf(m, pm[k]);
+                const float a = (m == -INFINITY) ? 0.f : __expf(m - mn);
+                const float w = (pm[k] == -INFINITY) ? 0.f : __expf(pm[k] - mn);
+                acc = fmaf(acc, a, w * pc[k]);
+                s = fmaf(s, a, w * ps[k]);
+                m = mn;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void linattn_merge_kernel(const LinMergeP p) {
     __shared__ float redm[8], reda[8][32], reds[8], cvec[32];
     const int tid = threadIdx.x, h = blockIdx.x, b = blockIdx.y, d = blockIdx.z;
@@ -307,28 +332,27 @@ __global__ __launch_bounds__(256) void linattn_merge_kernel(const LinMergeP p) {
     const float g = p.g[0];
     const long pbase = ((long)b * 4 + h) * p.nblk;
     const int e = tid & 31, pl = tid >> 5;
-    float m = -INFINITY;
-#pragma unroll 8
-    for (int c = pl; c < p.nblk; c += 8) m = fmaxf(m, p.part_m[(pbase + c) * 32 + d]);
-    if (e == 0) redm[pl] = m;
-    __syncthreads();
-    m = redm[0];
-#pragma unroll
-    for (int k = 1; k < 8; ++k) m = fmaxf(m, redm[k]);
-    float acc = 0.f, s = 0.f;
-#pragma unroll 8
-    for (int c = pl; c < p.nblk; c += 8) {
-        const float w = __expf(p.part_m[(pbase + c) * 32 + d] - m);
-        acc = fmaf(w, p.part_c[(pbase + c) * 1024 + d * 32 + e], acc);
-        s = fmaf(w, p.part_s[(pbase + c) * 32 + d], s);
-    }
+    // ONE pass: every lane first requests its whole share of the partial list (up to MC entries per round, all loads
+    // in flight together), then folds them with a running maximum (flash-style).  The two-pass form (maximum, then
+    // weighted sum) walked the list twice in rounds of 8 dependent-latency loads: 9.3 us at 160 partials, B=1.
+    float m = -INFINITY, acc = 0.f, s = 0.f;
+    const int per_lane = (p.nblk + 7) / 8;
+    if (per_lane <= 8) merge_fold<8>(p, pbase, d, e, pl, m, acc, s);
+    else if (per_lane <= 16) merge_fold<16>(p, pbase, d, e, pl, m, acc, s);
+    else merge_fold<24>(p, pbase, d, e, pl, m, acc, s);
+    if (e == 0) { redm[pl] = m; reds[pl] = s; }
     reda[pl][e] = acc;
-    if (e == 0) reds[pl] = s;
     __syncthreads();
     if (pl == 0) {
+        float M = redm[0];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) M = fmaxf(M, redm[k]);
         float a = 0.f, ss = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { a += reda[k][e]; ss += reds[k]; }
+        for (int k = 0; k < 8; ++k) {
+            const float w = (redm[k] == -INFINITY) ? 0.f : __expf(redm[k] - M);
+            a = fmaf(w, reda[k][e], a); ss = fmaf(w, reds[k], ss);
+        }
         cvec[e] = a / ss;
     }
     __syncthreads();
