@@ -526,7 +526,7 @@ struct Plan {
     float *pe0, *emb, *pos_part, *tok, *xn, *qkv, *ao, *att_ml, *hmlp, *dbg_tok;
     void *qh, *kh, *vt, *qh2, *kh2, *vt2; int Npad; size_t vt_bytes;   // bf16 attention operands of the row-chain path (two sets:
                                                                         // a fused block reads one while its workgroups write the other)
-    float *tv_keys, *tv_K, *tv_V, *tv_q, *tv_ao, *tv_out, *tiv_out, *tv_weff, *tv_beff; double *tv_stats, *tiv_stats;
+    float *tv_keys, *tv_K, *tv_V, *tv_q, *tv_ao, *tv_out, *tiv_out, *tv_weff, *tv_beff, *tv_stats, *tiv_stats;
     size_t bytes;
 };
 
@@ -612,8 +612,8 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
         P.tv_keys = A.f((size_t)B * d.Ts * mid); P.tv_K = A.f((size_t)B * (d.Ts + 1) * mid); P.tv_V = A.f((size_t)B * (d.Ts + 1) * mid);
         P.tv_q = A.f(pm * mid); P.tv_ao = A.f(pm * mid); P.tv_out = A.f(pm * mid); P.tiv_out = A.f(pm * mid);
         P.tv_weff = A.f((size_t)B * mid * mid); P.tv_beff = A.f((size_t)B * mid);
-        P.tv_stats = (double*)A.take((size_t)B * mid * 2 * sizeof(double) * 2);
-        P.tiv_stats = A.dry ? nullptr : P.tv_stats + (size_t)B * mid * 2;
+        P.tv_stats = A.f((size_t)B * mid * IN_SLOTS * 2 * 2);       // IN2d partial sums of the TV input and the TIV input
+        P.tiv_stats = A.dry ? nullptr : P.tv_stats + (size_t)B * mid * IN_SLOTS * 2;
     }
     P.bytes = (A.off + 255) & ~size_t(255);
 }
@@ -975,7 +975,8 @@ struct Runner {
         const DexConfig& c = x->cfg;
         const int B = P.d.B, mid = mid_dim(c);
         const long npix = (long)P.Hm * P.Wm;
-        hipMemsetAsync(P.tv_stats, 0, (size_t)B * mid * 2 * sizeof(double) * 2, st);
+        // (both statistics arrays are zero here: cleared once in prepare(), then by this step's / the previous step's
+        // time-token kernel, which runs after their last reader)
         InStatsP is{X.p + X.coff, X.ld, npix * X.ld, (int)npix, mid, P.tv_stats, B, mask, mask_ws, (long)P.d.T, P.Wm};
         run("in2d_stats", 3.0 * npix * mid * B, 4.0 * npix * mid * B, [&] { launch_in_stats(is, st); });
         InFoldP fo{P.tv_stats, (int)npix, 1e-5f, x->tv_wq_raw, mid, P.tv_weff, P.tv_beff, B};
@@ -983,7 +984,7 @@ struct Runner {
         IGemmP q = base_gemm(X.p, X.ld, X.coff, P.Hm, P.Wm, mid, P.tv_weff, mid, P.tv_beff, P.tv_q, mid, 0);
         q.w_bstride = (long)mid * mid; q.bias_bstride = mid; q.inmask = mask; q.inmask_ws = mask_ws;
         gemm("tv_q", q);
-        TvRow0P r0{P.tv_k0, P.tv_v0, sp, P.tv_K, P.tv_V, (long)(P.d.Ts + 1) * mid, mid, B};
+        TvRow0P r0{P.tv_k0, P.tv_v0, sp, P.tv_K, P.tv_V, (long)(P.d.Ts + 1) * mid, mid, B, P.tv_stats, (long)B * mid * IN_SLOTS * 2 * 2};
         run("tv_time_token", 0, 8.0 * mid * B, [&] { launch_tv_row0(r0, st); });
         AttnP a{};
         a.Q = P.tv_q; a.ldq = mid; a.qb = npix * mid; a.K = P.tv_K; a.ldk = mid; a.kb = (long)(P.d.Ts + 1) * mid;
@@ -1100,6 +1101,7 @@ struct Runner {
             SmallLinP s{X, ldx, rows, K, R(w + ".weight"), bias ? R(w + ".bias") : nullptr, N, Y, N, ai, ao};
             run("cond_mlp", 2.0 * rows * K * N, 4.0 * K * N, [&] { launch_small_linear(s, st); });
         };
+        if (P.tv_stats) hipMemsetAsync(P.tv_stats, 0, (size_t)B * mid_dim(c) * IN_SLOTS * 2 * 2 * sizeof(float), st);
         hipMemsetAsync(P.vt, 0, P.vt_bytes, st);      // key padding of the transposed V operand (attention_direct.hip)
         hipMemsetAsync(P.vt2, 0, P.vt_bytes, st);
         CondPrepP cp{sigmas_dev, n, c.pe_scale, dim, P.scal, SCAL_STRIDE, P.t_unet, P.t_dit};

@@ -31,13 +31,13 @@ void launch_row_stats(const float* X, int B, int C, int len, float eps, float* m
     hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, X, B, C, len, eps, mean, sd, out_bstride);
 }
 
-// per-(b,c) sum / sumsq over all pixels (incl. padding), fp64.  grid (chunks, B); C <= 256.
+// per-(b,c) sum / sumsq over all pixels (incl. padding).  grid (chunks, B); C <= 256.
 constexpr int IN_PIX = 256;
 __global__ __launch_bounds__(256) void in_stats_kernel(const InStatsP p) {
-    __shared__ double red[256][2];
+    __shared__ float red[256][2];
     const int tid = threadIdx.x, b = blockIdx.y;
     const int C4 = p.C >> 2;
-    red[tid][0] = 0.0; red[tid][1] = 0.0;
+    red[tid][0] = 0.f; red[tid][1] = 0.f;
     __syncthreads();
     const int cq = tid % C4, prow = tid / C4, rpp = 256 / C4;
     const int pbeg = blockIdx.x * IN_PIX, pend = min(p.npix, pbeg + IN_PIX);
@@ -53,24 +53,28 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const InStatsP p) {
         q.x = fmaf(v.x, v.x, q.x); q.y = fmaf(v.y, v.y, q.y); q.z = fmaf(v.z, v.z, q.z); q.w = fmaf(v.w, v.w, q.w);
     }
     const int c = cq * 4;
-    atomicAdd(&red[c + 0][0], (double)s.x); atomicAdd(&red[c + 0][1], (double)q.x);
-    atomicAdd(&red[c + 1][0], (double)s.y); atomicAdd(&red[c + 1][1], (double)q.y);
-    atomicAdd(&red[c + 2][0], (double)s.z); atomicAdd(&red[c + 2][1], (double)q.z);
-    atomicAdd(&red[c + 3][0], (double)s.w); atomicAdd(&red[c + 3][1], (double)q.w);
+    atomicAdd(&red[c + 0][0], s.x); atomicAdd(&red[c + 0][1], q.x);
+    atomicAdd(&red[c + 1][0], s.y); atomicAdd(&red[c + 1][1], q.y);
+    atomicAdd(&red[c + 2][0], s.z); atomicAdd(&red[c + 2][1], q.z);
+    atomicAdd(&red[c + 3][0], s.w); atomicAdd(&red[c + 3][1], q.w);
     __syncthreads();
     if (tid < p.C) {
-        atomicAdd(p.stats + ((long)b * p.C + tid) * 2 + 0, red[tid][0]);
-        atomicAdd(p.stats + ((long)b * p.C + tid) * 2 + 1, red[tid][1]);
+        float* dst = p.stats + (((long)b * p.C + tid) * IN_SLOTS + (blockIdx.x % IN_SLOTS)) * 2;
+        atomicAdd(dst, red[tid][0]);
+        atomicAdd(dst + 1, red[tid][1]);
     }
 }
 void launch_in_stats(const InStatsP& p, hipStream_t st) {
     hipLaunchKernelGGL(in_stats_kernel, dim3((p.npix + IN_PIX - 1) / IN_PIX, p.B), dim3(256), 0, st, p);
 }
 
-__device__ __forceinline__ void in_mean_rstd(const double* stats, long idx, int npix, float eps, float& mean, float& rstd) {
+__device__ __forceinline__ void in_mean_rstd(const float* stats, long idx, int npix, float eps, float& mean, float& rstd) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < IN_SLOTS; ++k) { s1 += (double)stats[(idx * IN_SLOTS + k) * 2]; s2 += (double)stats[(idx * IN_SLOTS + k) * 2 + 1]; }
     const double n = (double)npix;
-    const double mu = stats[idx * 2] / n;
-    double var = (stats[idx * 2 + 1] - n * mu * mu) / (n - 1.0);    // unbiased (torch.var default, base.py:99)
+    const double mu = s1 / n;
+    double var = (s2 - n * mu * mu) / (n - 1.0);    // unbiased (torch.var default, base.py:99)
     var = var < 0.0 ? 0.0 : var;
     mean = (float)mu;
     rstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -112,24 +116,47 @@ void launch_sap(const SapP& p, hipStream_t st) {
 
 // TVAdaptor: q = w_q(IN2d(x)) folded into a per-batch weight/bias (ref_encoder.py:166):
 //   Weff[b][k][n] = rstd[b,k] * Wq[n][k];   beff[b][n] = -sum_k mean[b,k] * rstd[b,k] * Wq[n][k]
+// grid (C/16 + 1, B): workgroup j < C/16 writes rows k = 16j .. 16j+15 of Weff (Wq read through an LDS tile so that both
+// sides are coalesced), the last one the bias.  (One workgroup per batch element took 16 us at B=1.)
 __global__ __launch_bounds__(256) void in_fold_kernel(const InFoldP p) {
     __shared__ float smean[256], srstd[256];
-    const int tid = threadIdx.x, b = blockIdx.x;
-    if (tid < p.C) in_mean_rstd(p.stats, (long)b * p.C + tid, p.npix, p.eps, smean[tid], srstd[tid]);
-    __syncthreads();
-    float* We = p.Weff + (long)b * p.C * p.C;
-    for (int idx = tid; idx < p.C * p.C; idx += 256) {
-        const int k = idx / p.C, n = idx - k * p.C;
-        We[idx] = srstd[k] * p.Wq[(long)n * p.C + k];
-    }
-    if (tid < p.C) {
-        float a = 0.f;
-        for (int k = 0; k < p.C; ++k) a = fmaf(smean[k] * srstd[k], p.Wq[(long)tid * p.C + k], a);
-        p.beff[(long)b * p.C + tid] = -a;
+    __shared__ float tile[16][257];
+    const int tid = threadIdx.x, b = blockIdx.y, C = p.C;
+    const int nslice = C / 16;
+    if (blockIdx.x < nslice) {
+        const int k0 = blockIdx.x * 16;
+        if (tid < 16) { float m; in_mean_rstd(p.stats, (long)b * C + k0 + tid, p.npix, p.eps, m, srstd[tid]); }
+        // tile[kk][n] = Wq[n][k0 + kk]: thread reads 16 consecutive k of row n (64 B)
+        for (int n = tid; n < C; n += 256) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const float4 w = *reinterpret_cast<const float4*>(p.Wq + (long)n * C + k0 + q4 * 4);
+                tile[q4 * 4 + 0][n] = w.x; tile[q4 * 4 + 1][n] = w.y; tile[q4 * 4 + 2][n] = w.z; tile[q4 * 4 + 3][n] = w.w;
+            }
+        }
+        __syncthreads();
+        float* We = p.Weff + (long)b * C * C + (long)k0 * C;
+        for (int idx = tid; idx < 16 * C; idx += 256) {
+            const int kk = idx / C, n = idx - kk * C;
+            We[idx] = srstd[kk] * tile[kk][n];
+        }
+    } else {
+        if (tid < C) in_mean_rstd(p.stats, (long)b * C + tid, p.npix, p.eps, smean[tid], srstd[tid]);
+        __syncthreads();
+        if (tid < C) {
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            const float* wr = p.Wq + (long)tid * C;
+            for (int k = 0; k < C; k += 4) {
+                const float4 w = *reinterpret_cast<const float4*>(wr + k);
+                a0 = fmaf(smean[k] * srstd[k], w.x, a0); a1 = fmaf(smean[k + 1] * srstd[k + 1], w.y, a1);
+                a2 = fmaf(smean[k + 2] * srstd[k + 2], w.z, a2); a3 = fmaf(smean[k + 3] * srstd[k + 3], w.w, a3);
+            }
+            p.beff[(long)b * C + tid] = -((a0 + a1) + (a2 + a3));
+        }
     }
 }
 void launch_in_fold(const InFoldP& p, hipStream_t st) {
-    hipLaunchKernelGGL(in_fold_kernel, dim3(p.B), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(in_fold_kernel, dim3(p.C / 16 + 1, p.B), dim3(256), 0, st, p);
 }
 
 // TIVAdaptor: y = IN2d(x) * s + m, output NOT masked (ref_encoder.py:271)
@@ -169,6 +196,7 @@ void launch_tiv_apply(const TivApplyP& p, hipStream_t st) {
 __global__ void tv_row0_kernel(const TvRow0P p) {
     const int b = blockIdx.x, c = threadIdx.x;
     const int step = p.step ? *p.step : 0;
+    if (p.zero_ptr) for (long i = (long)b * blockDim.x + c; i < p.zero_n; i += (long)gridDim.x * blockDim.x) p.zero_ptr[i] = 0.f;
     if (c < p.C) {
         p.K[(long)b * p.kvb + c] = p.k0[(long)step * p.C + c];
         p.V[(long)b * p.kvb + c] = p.v0[(long)step * p.C + c];

@@ -230,7 +230,10 @@ void launch_spk_plane(const float* spk_out, float* plane, int B, int F, hipStrea
 // per-row mean / sqrt(unbiased var + eps) over the last dim (InstanceNorm1D.cal_stats, base.py:72-78)
 void launch_row_stats(const float* X, int B, int C, int len, float eps, float* mean, float* std, long out_bstride, hipStream_t st);
 // per-(b,c) sum / sumsq over pixels (InstanceNorm2D statistics, base.py:95-103), fp64 atomics
-struct InStatsP { const float* X; int ld; long bstride; int npix; int C; double* stats; int B;
+// statistics: [B][C][IN_SLOTS][2] fp32 partial (sum, sumsq), native L2 atomics spread over the slots; consumers add the
+// slots in fp64 (the first version used fp64 LDS + global atomics: 170 ns each on one address, 14 us per call at B=1)
+constexpr int IN_SLOTS = 8;
+struct InStatsP { const float* X; int ld; long bstride; int npix; int C; float* stats; int B;
                   const float* mask; int mask_ws; long mask_bstride; int W; };   // optional x*mask on load
 void launch_in_stats(const InStatsP& p, hipStream_t st);
 // SelfAttentionPooling for all steps (ref_encoder.py:246-253): out[step][b][C]
@@ -238,14 +241,15 @@ struct SapP { const float* t_tok; int t_ld; int t_coff; int nsteps; const float*
               const float* w; const float* bias; float* out; int B; };
 void launch_sap(const SapP& p, hipStream_t st);
 // TV: fold InstanceNorm2D into w_q:  Weff[b][k][n] = rstd[b,k]*Wq[n,k];  beff[b][n] = -sum_k mean*rstd*Wq[n,k]
-struct InFoldP { const double* stats; int npix; float eps; const float* Wq; int C; float* Weff; float* beff; int B; };
+struct InFoldP { const float* stats; int npix; float eps; const float* Wq; int C; float* Weff; float* beff; int B; };
 void launch_in_fold(const InFoldP& p, hipStream_t st);
 // TIV: y = IN2d(x)*s + m  (ref_encoder.py:271); s,m indexed [step][b][C]
-struct TivApplyP { const float* X; int ld; long xb; float* Y; int ldy; long yb; int npix; int C; const double* stats;
+struct TivApplyP { const float* X; int ld; long xb; float* Y; int ldy; long yb; int npix; int C; const float* stats;
                    float eps; const float* s_tab; const float* m_tab; const int* step; int B; };
 void launch_tiv_apply(const TivApplyP& p, hipStream_t st);
 // write per-step time-token rows into K/V row 0 (ref_encoder.py:157)
-struct TvRow0P { const float* k0; const float* v0; const int* step; float* K; float* V; long kvb; int C; int B; };
+struct TvRow0P { const float* k0; const float* v0; const int* step; float* K; float* V; long kvb; int C; int B;
+                 float* zero_ptr; long zero_n; };          // optional: clear the IN2d statistics for their next use
 void launch_tv_row0(const TvRow0P& p, hipStream_t st);
 // transpose [B,C,L] -> [B, L(+row_off), C]
 void launch_transpose_cl(const float* src, float* dst, int B, int C, int L, int row_off, long dst_bstride, hipStream_t st);
