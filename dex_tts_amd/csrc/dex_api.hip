@@ -995,10 +995,10 @@ struct Runner {
         IGemmP o = base_gemm(P.tv_ao, mid, 0, P.Hm, P.Wm, mid, x->tv_wl, mid, nullptr, P.tv_out, mid, 0);
         o.res = X.p; o.ldres = X.ld; o.res_coff = X.coff; o.res_bstride = npix * X.ld;
         o.outmask = mask; o.outmask_ws = mask_ws;
+        // the TIV adaptor's InstanceNorm statistics of this output ride in the epilogue (per-channel = groups of one)
+        o.gn_stats = P.tiv_stats; o.gn_groups = mid; o.gn_cpg = 1; o.stats_final = 1;
         gemm("tv_out", o);
         tap("tv", P.tv_out, B * npix, mid, mid);
-        InStatsP is2{P.tv_out, mid, npix * mid, (int)npix, mid, P.tiv_stats, B, nullptr, 1, 0, P.Wm};
-        run("in2d_stats", 3.0 * npix * mid * B, 4.0 * npix * mid * B, [&] { launch_in_stats(is2, st); });
         TivApplyP ta{P.tv_out, mid, npix * mid, P.tiv_out, mid, npix * mid, (int)npix, mid, P.tiv_stats, 1e-5f, P.sap_s, P.sap_m, sp, B};
         run("tiv_adain", 2.0 * npix * mid * B, 8.0 * npix * mid * B, [&] { launch_tiv_apply(ta, st); });
         tap("tiv", P.tiv_out, B * npix, mid, mid);

@@ -32,7 +32,7 @@ void launch_row_stats(const float* X, int B, int C, int len, float eps, float* m
 }
 
 // per-(b,c) sum / sumsq over all pixels (incl. padding).  grid (chunks, B); C <= 256.
-constexpr int IN_PIX = 256;
+constexpr int IN_PIX = 256;     // few workgroups (few atomics: 40k global atomics cost ~5 us), 16 loads in flight per thread
 __global__ __launch_bounds__(256) void in_stats_kernel(const InStatsP p) {
     __shared__ float red[256][2];
     const int tid = threadIdx.x, b = blockIdx.y;
@@ -43,14 +43,23 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const InStatsP p) {
     const int pbeg = blockIdx.x * IN_PIX, pend = min(p.npix, pbeg + IN_PIX);
     const float* X = p.X + (long)b * p.bstride;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int px = pbeg + prow; px < pend; px += rpp) {
-        float4 v = *reinterpret_cast<const float4*>(X + (long)px * p.ld + cq * 4);
-        if (p.mask) {
-            const float mk = p.mask[(long)b * p.mask_bstride + (px % p.W) * p.mask_ws];
-            v.x *= mk; v.y *= mk; v.z *= mk; v.w *= mk;
+    // rounds of 16 unconditional (clamped) loads in flight together (a plain loop serialised 32 round trips: 14-17 us)
+    constexpr int RN = 16;
+    for (int px0 = pbeg + prow; px0 < pend; px0 += RN * rpp) {
+        float4 v[RN]; float mk[RN];
+#pragma unroll
+        for (int k = 0; k < RN; ++k) {
+            const int px = min(px0 + k * rpp, pend - 1);
+            v[k] = *reinterpret_cast<const float4*>(X + (long)px * p.ld + cq * 4);
+            mk[k] = p.mask ? p.mask[(long)b * p.mask_bstride + (px % p.W) * p.mask_ws] : 1.f;
         }
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        q.x = fmaf(v.x, v.x, q.x); q.y = fmaf(v.y, v.y, q.y); q.z = fmaf(v.z, v.z, q.z); q.w = fmaf(v.w, v.w, q.w);
+#pragma unroll
+        for (int k = 0; k < RN; ++k) {
+            const float m = (px0 + k * rpp < pend) ? mk[k] : 0.f;
+            const float4 t = make_float4(v[k].x * m, v[k].y * m, v[k].z * m, v[k].w * m);
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+            q.x = fmaf(t.x, t.x, q.x); q.y = fmaf(t.y, t.y, q.y); q.z = fmaf(t.z, t.z, q.z); q.w = fmaf(t.w, t.w, q.w);
+        }
     }
     const int c = cq * 4;
     atomicAdd(&red[c + 0][0], s.x); atomicAdd(&red[c + 0][1], q.x);

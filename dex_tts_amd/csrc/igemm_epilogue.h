@@ -60,9 +60,11 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmP& p, f32x16 (&acc)[MT
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = acc[t][r] + bias;
-                gs += v; gss = fmaf(v, v, gss);
+                if (!p.stats_final) { gs += v; gss = fmaf(v, v, gss); }
                 if (p.act == 1) v = gelu_erf(v);
-                cp[((r & 3) + 8 * (r >> 2)) * cs] = (v * gate + rv[r]) * mk[r];
+                v = (v * gate + rv[r]) * mk[r];
+                if (p.stats_final) { gs += v; gss = fmaf(v, v, gss); }
+                cp[((r & 3) + 8 * (r >> 2)) * cs] = v;
             }
             continue;
         }
@@ -101,9 +103,10 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmP& p, f32x16 (&acc)[MT
         for (int r = 0; r < 16; ++r) {
             float v = acc[t][r] + bias;
             const float vs = ok[r] ? v : 0.f;
-            gs += vs; gss = fmaf(vs, vs, gss);
+            if (!p.stats_final) { gs += vs; gss = fmaf(vs, vs, gss); }
             if (p.act == 1) v = gelu_erf(v);
             v = (v * gate + rv[r]) * mk[r];
+            if (p.stats_final && ok[r]) { gs += v; gss = fmaf(v, v, gss); }
             if (ok[r]) Cb[(long)opix[r] * p.ldc + col_out] = v;
         }
     }

@@ -38,6 +38,8 @@ struct IGemmP {
     int parity;                                        // 1: blockIdx.z = b*4 + (ph*2+pw): ConvTranspose2d(4,2,1) as four 2x2-tap
                                                        // sub-convolutions in ONE launch (off/oh0/ow0 = parity, weights += par*K*N)
     float* gn_stats; int gn_groups, gn_cpg;            // fused GroupNorm partial statistics of (acc + bias), or null
+    int stats_final;                                   // 1: the statistics are of the STORED value (after activation, gate,
+                                                       // residual, mask) - InstanceNorm of the next adaptor (cpg = 1)
     const float* ln_shift; const float* ln_scale; long ln_step_stride;   // fused LayerNorm(eps 1e-6)+modulate on the A rows
                                                        // (single-shot bf16 kernel only; needs K == Cin == row length)
     int B;
@@ -232,7 +234,7 @@ void launch_row_stats(const float* X, int B, int C, int len, float eps, float* m
 // per-(b,c) sum / sumsq over pixels (InstanceNorm2D statistics, base.py:95-103), fp64 atomics
 // statistics: [B][C][IN_SLOTS][2] fp32 partial (sum, sumsq), native L2 atomics spread over the slots; consumers add the
 // slots in fp64 (the first version used fp64 LDS + global atomics: 170 ns each on one address, 14 us per call at B=1)
-constexpr int IN_SLOTS = 8;
+constexpr int IN_SLOTS = GN_SLOTS;     // same layout as the GroupNorm partials: a GEMM epilogue can produce them (cpg = 1)
 struct InStatsP { const float* X; int ld; long bstride; int npix; int C; float* stats; int B;
                   const float* mask; int mask_ws; long mask_bstride; int W; };   // optional x*mask on load
 void launch_in_stats(const InStatsP& p, hipStream_t st);
