@@ -526,7 +526,7 @@ struct Plan {
     float *pe0, *emb, *pos_part, *tok, *xn, *qkv, *ao, *att_ml, *hmlp, *dbg_tok;
     void *qh, *kh, *vt, *qh2, *kh2, *vt2; int Npad; size_t vt_bytes;   // bf16 attention operands of the row-chain path (two sets:
                                                                         // a fused block reads one while its workgroups write the other)
-    float *tv_keys, *tv_K, *tv_V, *tv_q, *tv_ao, *tv_out, *tiv_out, *tv_weff, *tv_beff, *tv_stats, *tiv_stats;
+    float *tv_keys, *tv_K, *tv_V, *tv_q, *tv_ao, *tv_out, *tiv_out, *tv_weff, *tv_beff, *tv_stats, *tiv_stats; void* tv_wbf;
     size_t bytes;
 };
 
@@ -605,13 +605,14 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
     P.qh2 = A.take(P.vt_bytes); P.kh2 = A.take(P.vt_bytes); P.vt2 = A.take(P.vt_bytes);
     P.hmlp = A.f(tok * mlp_hidden(c));
     P.dbg_tok = A.f(tok * hid * (c.dit_depth + 1));
-    P.tv_keys = P.tv_K = P.tv_V = P.tv_q = P.tv_ao = P.tv_out = P.tiv_out = P.tv_weff = P.tv_beff = nullptr;
+    P.tv_keys = P.tv_K = P.tv_V = P.tv_q = P.tv_ao = P.tv_out = P.tiv_out = P.tv_weff = P.tv_beff = nullptr; P.tv_wbf = nullptr;
     P.tv_stats = P.tiv_stats = nullptr;
     if (c.variant == DEX_VARIANT_DEX) {
         const size_t pm = (size_t)B * P.Hm * P.Wm;
         P.tv_keys = A.f((size_t)B * d.Ts * mid); P.tv_K = A.f((size_t)B * (d.Ts + 1) * mid); P.tv_V = A.f((size_t)B * (d.Ts + 1) * mid);
         P.tv_q = A.f(pm * mid); P.tv_ao = A.f(pm * mid); P.tv_out = A.f(pm * mid); P.tiv_out = A.f(pm * mid);
         P.tv_weff = A.f((size_t)B * mid * mid); P.tv_beff = A.f((size_t)B * mid);
+        P.tv_wbf = A.take((size_t)B * mid * mid * 2);
         P.tv_stats = A.f((size_t)B * mid * IN_SLOTS * 2 * 2);       // IN2d partial sums of the TV input and the TIV input
         P.tiv_stats = A.dry ? nullptr : P.tv_stats + (size_t)B * mid * IN_SLOTS * 2;
     }
@@ -979,10 +980,12 @@ struct Runner {
         // time-token kernel, which runs after their last reader)
         InStatsP is{X.p + X.coff, X.ld, npix * X.ld, (int)npix, mid, P.tv_stats, B, mask, mask_ws, (long)P.d.T, P.Wm};
         run("in2d_stats", 3.0 * npix * mid * B, 4.0 * npix * mid * B, [&] { launch_in_stats(is, st); });
-        InFoldP fo{P.tv_stats, (int)npix, 1e-5f, x->tv_wq_raw, mid, P.tv_weff, P.tv_beff, B};
+        const bool qbf = x->precision == DEX_PREC_BF16;     // bf16 mode: the folded per-utterance weight is written as the bf16 GEMM operand
+        InFoldP fo{P.tv_stats, (int)npix, 1e-5f, x->tv_wq_raw, mid, P.tv_weff, P.tv_beff, B, qbf ? P.tv_wbf : nullptr};
         run("tv_fold_in2d", 2.0 * mid * mid * B, 8.0 * mid * mid * B, [&] { launch_in_fold(fo, st); });
         IGemmP q = base_gemm(X.p, X.ld, X.coff, P.Hm, P.Wm, mid, P.tv_weff, mid, P.tv_beff, P.tv_q, mid, 0);
         q.w_bstride = (long)mid * mid; q.bias_bstride = mid; q.inmask = mask; q.inmask_ws = mask_ws;
+        if (qbf) q.Wbf = P.tv_wbf;
         gemm("tv_q", q);
         TvRow0P r0{P.tv_k0, P.tv_v0, sp, P.tv_K, P.tv_V, (long)(P.d.Ts + 1) * mid, mid, B, P.tv_stats, (long)B * mid * IN_SLOTS * 2 * 2};
         run("tv_time_token", 0, 8.0 * mid * B, [&] { launch_tv_row0(r0, st); });

@@ -2,6 +2,7 @@
 // around the shared attention / GEMM kernels: instance-norm statistics, SAP pooling tables, IN2d folded
 // into w_q, AdaIN apply, time-token rows, layout transposes.
 #include "kernels.h"
+#include "bf16_util.h"
 
 namespace dex {
 
@@ -135,6 +136,23 @@ __global__ __launch_bounds__(256) void in_fold_kernel(const InFoldP p) {
     if (blockIdx.x < nslice) {
         const int k0 = blockIdx.x * 16;
         if (tid < 16) { float m; in_mean_rstd(p.stats, (long)b * C + k0 + tid, p.npix, p.eps, m, srstd[tid]); }
+        if (p.Wbf) {            // [n][k] bf16: no transpose - 64 B in, 32 B out per thread
+            __syncthreads();
+            unsigned short* Wo = reinterpret_cast<unsigned short*>(p.Wbf) + (long)b * C * C;
+            for (int n = tid; n < C; n += 256) {
+                uint4 o[2];
+                unsigned* ow = reinterpret_cast<unsigned*>(o);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const float4 w = *reinterpret_cast<const float4*>(p.Wq + (long)n * C + k0 + q4 * 4);
+                    ow[q4 * 2] = pack2_bf16(w.x * srstd[q4 * 4], w.y * srstd[q4 * 4 + 1]);
+                    ow[q4 * 2 + 1] = pack2_bf16(w.z * srstd[q4 * 4 + 2], w.w * srstd[q4 * 4 + 3]);
+                }
+                *reinterpret_cast<uint4*>(Wo + (long)n * C + k0) = o[0];
+                *reinterpret_cast<uint4*>(Wo + (long)n * C + k0 + 8) = o[1];
+            }
+            return;
+        }
         // tile[kk][n] = Wq[n][k0 + kk]: thread reads 16 consecutive k of row n (64 B)
         for (int n = tid; n < C; n += 256) {
 #pragma unroll

@@ -243,7 +243,8 @@ struct SapP { const float* t_tok; int t_ld; int t_coff; int nsteps; const float*
               const float* w; const float* bias; float* out; int B; };
 void launch_sap(const SapP& p, hipStream_t st);
 // TV: fold InstanceNorm2D into w_q:  Weff[b][k][n] = rstd[b,k]*Wq[n,k];  beff[b][n] = -sum_k mean*rstd*Wq[n,k]
-struct InFoldP { const float* stats; int npix; float eps; const float* Wq; int C; float* Weff; float* beff; int B; };
+struct InFoldP { const float* stats; int npix; float eps; const float* Wq; int C; float* Weff; float* beff; int B;
+                 void* Wbf; };         // bf16 mode: write rstd[k] * Wq[n][k] as bf16 [B][n][k] (the bf16 GEMM's weight layout) instead of Weff
 void launch_in_fold(const InFoldP& p, hipStream_t st);
 // TIV: y = IN2d(x)*s + m  (ref_encoder.py:271); s,m indexed [step][b][C]
 struct TivApplyP { const float* X; int ld; long xb; float* Y; int ldy; long yb; int npix; int C; const float* stats;
