@@ -351,9 +351,9 @@ int conv3x3_stream_tiles(const Conv3P& p) {
     if (mode == 0) return 0;
     const int tiles = (p.H + STR - 1) / STR;
     const long strips = (long)((p.W + 31) / 32) * p.B;
-    if (mode != 3) for (int tpw = tiles < 5 ? tiles : 5; tpw >= 2; --tpw)
+    for (int tpw = tiles < 5 ? tiles : 5; tpw >= 2; --tpw)
         if (strips * ((tiles + tpw - 1) / tpw) >= 256) return tpw;
-    if (mode == 3) return strips * tiles >= 128 ? 1 : 0;      // experiment: one 8-row tile per workgroup at batch 1
+    // (one 8-row tile per workgroup at batch 1 was measured too: 16.5 us, the same as the tile kernel - not kept)
     return mode == 2 ? (tiles < 5 ? tiles : 5) : 0;
 }
 
