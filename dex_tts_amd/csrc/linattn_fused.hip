@@ -25,7 +25,7 @@ union LFrag { uint4 u; bf16x8 v; };
 // grid (nblk, B); 256 threads; each wave owns `nsub` consecutive 32-pixel sub-tiles.
 // part_m/part_s: [B][4][nblk][32], part_c: [B][4][nblk][32 d][32 e]   (same layout linattn_combine reads)
 template <int C, bool PRO>
-__global__ __launch_bounds__(256) void linattn_kvctx_kernel(const LinKvCtxP p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 ? 2 : 1, C == 64 ? 2 : 8))) void linattn_kvctx_kernel(const LinKvCtxP p) {
     constexpr int LDW = C + 8, KS = C / 16;
     extern __shared__ __attribute__((aligned(16))) u16 smem_la[];
     u16* Ws = smem_la;                                       // [256][LDW]  rows: k(4x32) then v(4x32)
@@ -189,27 +189,28 @@ __global__ __launch_bounds__(256) void linattn_kvctx_kernel(const LinKvCtxP p) {
                 mkv = mrow[(pxr % p.W) * p.mask_ws];
             }
         }
-        f32x16 kv[8];
-#pragma unroll
-        for (int nt = 0; nt < 8; ++nt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) kv[nt][r] = 0.f;
-            const u16* bp = Ws + (nt * 32 + i) * LDW + hh * 8;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                LFrag bf; bf.u = *reinterpret_cast<const uint4*>(bp + ks * 16);
-                kv[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks].v, bf.v, kv[nt], 0, 0, 0);
-            }
-        }
+        // head by head: k_h and v_h tiles (2 x 16 accumulator registers live instead of the 128 of all eight tiles at once -
+        // the kernel sat at one wave per SIMD), softmax statistics, then ctx_h += v_h^T p_h from those registers
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
+            f32x16 kh, vh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { kh[r] = 0.f; vh[r] = 0.f; }
+            const u16* bk = Ws + (h * 32 + i) * LDW + hh * 8;
+            const u16* bv = Ws + ((4 + h) * 32 + i) * LDW + hh * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                LFrag fk, fv; fk.u = *reinterpret_cast<const uint4*>(bk + ks * 16); fv.u = *reinterpret_cast<const uint4*>(bv + ks * 16);
+                kh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks].v, fk.v, kh, 0, 0, 0);
+                vh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks].v, fv.v, vh, 0, 0, 0);
+            }
             // column (channel d = lane&31) max over the 32 pixels of the sub-tile
             float mx = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int px = px0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (px >= p.npix) kv[h][r] = -INFINITY;
-                mx = fmaxf(mx, kv[h][r]);
+                if (px >= p.npix) kh[r] = -INFINITY;
+                mx = fmaxf(mx, kh[r]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float mn = fmaxf(m_run[h], mx);
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256) void linattn_kvctx_kernel(const LinKvCtxP p) {
             m_run[h] = mn;
             float ps = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { kv[h][r] = __expf(kv[h][r] - mn); ps += kv[h][r]; }
+            for (int r = 0; r < 16; ++r) { kh[r] = __expf(kh[r] - mn); ps += kh[r]; }
             s_run[h] = s_run[h] * alpha + ps;
 #pragma unroll
             for (int r = 0; r < 16; ++r) ctxT[h][r] *= alpha;
@@ -225,12 +226,13 @@ __global__ __launch_bounds__(256) void linattn_kvctx_kernel(const LinKvCtxP p) {
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
                 LFrag va, pb;
-                va.u.x = pack2_bf16(kv[4 + h][8 * k2 + 0], kv[4 + h][8 * k2 + 1]); va.u.y = pack2_bf16(kv[4 + h][8 * k2 + 2], kv[4 + h][8 * k2 + 3]);
-                va.u.z = pack2_bf16(kv[4 + h][8 * k2 + 4], kv[4 + h][8 * k2 + 5]); va.u.w = pack2_bf16(kv[4 + h][8 * k2 + 6], kv[4 + h][8 * k2 + 7]);
-                pb.u.x = pack2_bf16(kv[h][8 * k2 + 0], kv[h][8 * k2 + 1]); pb.u.y = pack2_bf16(kv[h][8 * k2 + 2], kv[h][8 * k2 + 3]);
-                pb.u.z = pack2_bf16(kv[h][8 * k2 + 4], kv[h][8 * k2 + 5]); pb.u.w = pack2_bf16(kv[h][8 * k2 + 6], kv[h][8 * k2 + 7]);
+                va.u.x = pack2_bf16(vh[8 * k2 + 0], vh[8 * k2 + 1]); va.u.y = pack2_bf16(vh[8 * k2 + 2], vh[8 * k2 + 3]);
+                va.u.z = pack2_bf16(vh[8 * k2 + 4], vh[8 * k2 + 5]); va.u.w = pack2_bf16(vh[8 * k2 + 6], vh[8 * k2 + 7]);
+                pb.u.x = pack2_bf16(kh[8 * k2 + 0], kh[8 * k2 + 1]); pb.u.y = pack2_bf16(kh[8 * k2 + 2], kh[8 * k2 + 3]);
+                pb.u.z = pack2_bf16(kh[8 * k2 + 4], kh[8 * k2 + 5]); pb.u.w = pack2_bf16(kh[8 * k2 + 6], kh[8 * k2 + 7]);
                 ctxT[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va.v, pb.v, ctxT[h], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);            // keep the heads sequential: interleaving them brings all tiles back to life
         }
     }
     // ---- merge the 4 waves of the workgroup through LDS, write one partial per head
