@@ -15,6 +15,7 @@
 // Epilogue: +bias, GroupNorm partial statistics (workgroup-combined, one fp32 atomic pair per group into a
 // slot-spread buffer), fp32 channels-last store (128-B rows).
 #include "kernels.h"
+#include <cstdlib>
 #include "bf16_util.h"
 
 namespace dex {
@@ -32,6 +33,7 @@ __device__ __forceinline__ float cv_mish(float x) {           // branch-free: ta
 
 // mean / rstd of the producer's GroupNorm from the slot-spread fp32 partials (8 groups x GN_SLOTS == 256 threads)
 __device__ __forceinline__ void cv_gn_coeffs(const Conv3P& p, int b, int tid, float* smean, float* srstd) {
+    if (tid >= 8 * GN_SLOTS) return;                  // 512-thread workgroups: whole waves 4..7 sit this out
     const int g = tid / GN_SLOTS;
     const float* src = p.pro_stats + (((long)b * 8 + g) * GN_SLOTS + (tid % GN_SLOTS)) * 2;
     double s1 = (double)src[0], s2 = (double)src[1];
@@ -108,16 +110,17 @@ __device__ __forceinline__ void cv_epilogue(const Conv3P& p, f32x16 (&acc)[NT], 
 
 // CC channels per chunk, output-channel slice [slice*NSL, +NSL) of COUT, TH rows (waves: TH x (4/TH)).
 // grid.z = b * (COUT/NSL) + slice.
-template <int CC, int COUT, int NSL, int TH, bool PRO2 = false, bool RES = false, bool XB = false>
-__global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
+template <int CC, int COUT, int NSL, int TH, bool PRO2 = false, bool RES = false, bool XB = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void conv3x3_bf16_kernel(const Conv3P p) {
     constexpr int PW = 34, PH = TH + 2;
     constexpr int LDP = CC + 8;
-    constexpr int WN = 4 / TH;
+    constexpr int WN = NW / TH;                          // NW = 8: two waves per SIMD in ONE workgroup (the 128-channel layers fill the LDS with one)
+    constexpr int NTHR = 64 * NW;
     constexpr int NT = NSL / 32 / WN;
     constexpr int NSLICE = COUT / NSL;
     constexpr int ITEMS = PH * PW * (CC / 8);            // 8-channel patch items
-    constexpr int NI = (ITEMS + 255) / 256;              // per thread
-    constexpr int WPT = NSL * CC / 8 / 256;              // weight items (16 B) per thread per tap
+    constexpr int NI = (ITEMS + NTHR - 1) / NTHR;        // per thread
+    constexpr int WPT = NSL * CC / 8 / NTHR;             // weight items (16 B) per thread per tap
     constexpr int RING = CC == 128 ? (PRO2 ? 1 : 2) : 3;  // taps of weights in flight ahead of the MFMAs
     constexpr int NPASS = CC == 128 ? (PRO2 ? 5 : 2) : (PRO2 ? 3 : 1);   // patch staging passes: 128-channel chunks (or two source tensors) would need >256 registers in one
     constexpr int NIP = (NI + NPASS - 1) / NPASS;        // (1 workgroup per CU instead of 2: measured 16 -> 22 us at 40x256)
@@ -158,7 +161,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
     int wofs[WPT], wlds[WPT];
 #pragma unroll
     for (int j = 0; j < WPT; ++j) {
-        const int it = tid + 256 * j;
+        const int it = tid + NTHR * j;
         const int n = it / (CC / 8), c8 = (it % (CC / 8)) * 8;
         wofs[j] = n * K + c8;
         wlds[j] = n * LDP + c8;
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
             const u16* Rg = reinterpret_cast<const u16*>(p.res_w) + (long)slice * NSL * p.Cin;      // [COUT][Cin]
 #pragma unroll
             for (int j = 0; j < WPT; ++j) {
-                const int it = tid + 256 * j;
+                const int it = tid + NTHR * j;
                 rwr[j] = *reinterpret_cast<const u32x4*>(Rg + (long)(it / (CC / 8)) * p.Cin + cbase + (it % (CC / 8)) * 8);
             }
         }
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
             bool pin[NIP];
 #pragma unroll
             for (int q = 0; q < NIP; ++q) {
-                const int it = min(tid + 256 * (ps * NIP + q), ITEMS - 1);
+                const int it = min(tid + NTHR * (ps * NIP + q), ITEMS - 1);
                 const int px = it / (CC / 8);
                 const int pw = px % PW, ph = px / PW;
                 const int hi = h0 + ph - 1, wi = w0 + pw - 1;
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
                     f1.z = cv_mish((f1.z - mean) * rstd * ga1.z + be1.z) + t1.z; f1.w = cv_mish((f1.w - mean) * rstd * ga1.w + be1.w) + t1.w;
                 }
                 const float mk = pmk[q];
-                const int it = tid + 256 * (ps * NIP + q);
+                const int it = tid + NTHR * (ps * NIP + q);
                 if constexpr (PRO2) {
                     // x = mask * Mish(GN(h2)) + res: the value the un-fused gn_apply kernel wrote; the conv then sees x * mask
                     f0.x = fmaf(f0.x, mk, rf0[q].x); f0.y = fmaf(f0.y, mk, rf0[q].y); f0.z = fmaf(f0.z, mk, rf0[q].z); f0.w = fmaf(f0.w, mk, rf0[q].w);
@@ -326,17 +329,17 @@ __global__ __launch_bounds__(256) void conv3x3_bf16_kernel(const Conv3P p) {
     cv_epilogue<NT, COUT>(p, acc, b, h0 + wrow, w0, slice * NSL + wcol * NT * 32, lane, tid, gnred);
 }
 
-template <int CC, int COUT, int NSL, int TH, bool PRO2 = false, bool RES = false, bool XB = false>
+template <int CC, int COUT, int NSL, int TH, bool PRO2 = false, bool RES = false, bool XB = false, int NW = 4>
 static void launch_c3(const Conv3P& p, hipStream_t st) {
     constexpr int LDP = CC + 8;
     const size_t lds = ((size_t)(TH + 2) * 34 * LDP + (2 + (RES ? 1 : 0)) * NSL * LDP) * sizeof(u16);
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<CC, COUT, NSL, TH, PRO2, RES, XB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<CC, COUT, NSL, TH, PRO2, RES, XB, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     dim3 grid((p.W + 31) / 32, (p.H + TH - 1) / TH, p.B * (COUT / NSL));
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<CC, COUT, NSL, TH, PRO2, RES, XB>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<CC, COUT, NSL, TH, PRO2, RES, XB, NW>), grid, dim3(64 * NW), lds, st, p);
 }
 
 bool conv3x3_bf16_tail_supported(int C) { return C == 64 || C == 128; }
@@ -352,6 +355,17 @@ void launch_conv3x3_bf16(const Conv3P& p, hipStream_t st) {
     // workgroups on the chip (per-tap weight traffic per workgroup halves, two workgroups fit per CU)
     const long tiles4 = (long)((p.W + 31) / 32) * ((p.H + 3) / 4) * p.B;
     const bool small = tiles4 < 256;       // (at B=32 the 4-row tiles win despite one workgroup per CU: 189 vs 218 us)
+    // the 128-channel-wide forms at 4-row tiles fill the LDS with ONE workgroup per CU; as eight waves (4 rows x 2 halves
+    // of the output channels) that workgroup keeps two waves per SIMD busy instead of one: +8.6 % end to end at B=32
+    // (DEX_CONV_W8=0 restores the four-wave form)
+    static const int w8 = getenv("DEX_CONV_W8") ? atoi(getenv("DEX_CONV_W8")) : 1;
+    if (w8 && !small && p.Cin == 128 && p.Cout == 128 && !p.res_w) {
+        if (p.x_bf16) { p.pro_res ? launch_c3<128, 128, 128, 4, true, false, true, 8>(p, st) : launch_c3<128, 128, 128, 4, false, false, true, 8>(p, st); }
+        else { p.pro_res ? launch_c3<128, 128, 128, 4, true, false, false, 8>(p, st) : launch_c3<128, 128, 128, 4, false, false, false, 8>(p, st); }
+        return;
+    }
+    if (w8 && !small && p.res_w && p.Cout == 128 && p.Cin == 64) { launch_c3<64, 128, 128, 4, false, true, false, 8>(p, st); return; }
+    if (w8 && !small && p.res_w && p.Cout == 64 && p.Cin >= 128) { launch_c3<128, 64, 64, 4, false, true, false, 8>(p, st); return; }
     if (p.x_bf16) {       // raw conv output stored as bf16: the GroupNorm-prologue forms with Cin == Cout (conv3x3_bf16_xb_supported)
         if (p.pro_res) {
             if (p.Cin == 64) { small ? launch_c3<64, 64, 64, 2, true, false, true>(p, st) : launch_c3<64, 64, 64, 4, true, false, true>(p, st); }
