@@ -31,20 +31,42 @@ __device__ __forceinline__ float cv_mish(float x) {           // branch-free: ta
     return x * (n * __builtin_amdgcn_rcpf(n + 2.f));
 }
 
-// mean / rstd of the producer's GroupNorm from the slot-spread fp32 partials (8 groups x GN_SLOTS == 256 threads)
-__device__ __forceinline__ void cv_gn_coeffs(const Conv3P& p, int b, int tid, float* smean, float* srstd) {
+// Prologue coefficients of the producer's GroupNorm, per input channel:  y = Mish(x * coef0 + coef1) + coef2.
+// Thread (group g = tid/32, k = tid%32) of the first 256: one slot of group g's fp32 partials; after the xor-reduction every
+// lane of the group holds the sums, so lane k < Cin/8 finishes channel g*Cin/8 + k itself.  The loads (statistics, gamma,
+// beta, time bias: ONE value per thread) are issued before the weight/patch loads so they return first; the table lives in
+// LDS.  (The first version had every thread fetch gamma/beta/time bias of its 8 channels: 24 KB of redundant L1 traffic per
+// workgroup in the phase where the TA is the bottleneck - the load-issue phase measured 4.4k cycles per workgroup at B=1.)
+struct CvGnLoads { float s1, s2, ga, be, ta; };
+__device__ __forceinline__ CvGnLoads cv_gn_issue(const Conv3P& p, int b, int tid, int step) {
+    CvGnLoads l{0.f, 0.f, 0.f, 0.f, 0.f};
+    if (tid < 8 * GN_SLOTS) {
+        const int g = tid / GN_SLOTS, k = tid % GN_SLOTS, cpg = p.Cin / 8;
+        const float* src = p.pro_stats + (((long)b * 8 + g) * GN_SLOTS + k) * 2;
+        l.s1 = src[0]; l.s2 = src[1];
+        if (k < cpg) {
+            const int c = g * cpg + k;
+            l.ga = p.pro_gamma[c]; l.be = p.pro_beta[c];
+            l.ta = p.pro_tadd ? p.pro_tadd[(long)step * p.Cin + c] : 0.f;
+        }
+    }
+    return l;
+}
+__device__ __forceinline__ void cv_gn_finish(const Conv3P& p, const CvGnLoads& l, int tid, float (*coef)[256]) {
     if (tid >= 8 * GN_SLOTS) return;                  // 512-thread workgroups: whole waves 4..7 sit this out
-    const int g = tid / GN_SLOTS;
-    const float* src = p.pro_stats + (((long)b * 8 + g) * GN_SLOTS + (tid % GN_SLOTS)) * 2;
-    double s1 = (double)src[0], s2 = (double)src[1];
+    const int g = tid / GN_SLOTS, k = tid % GN_SLOTS, cpg = p.Cin / 8;
+    double s1 = (double)l.s1, s2 = (double)l.s2;
     for (int o = 1; o < GN_SLOTS; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-    if ((tid % GN_SLOTS) == 0) {
-        const double n = (double)p.H * p.W * (p.Cin / 8);
-        const double mean = s1 / n;
-        double var = s2 / n - mean * mean;
-        var = var < 0.0 ? 0.0 : var;
-        smean[g] = (float)mean;
-        srstd[g] = (float)(1.0 / sqrt(var + 1e-5));
+    const double n = (double)p.H * p.W * cpg;
+    const double mean = s1 / n;
+    double var = s2 / n - mean * mean;
+    var = var < 0.0 ? 0.0 : var;
+    const float rstd = (float)(1.0 / sqrt(var + 1e-5)), mu = (float)mean;
+    if (k < cpg) {
+        const int c = g * cpg + k;
+        coef[0][c] = rstd * l.ga;
+        coef[1][c] = l.be - mu * rstd * l.ga;
+        coef[2][c] = l.ta;
     }
 }
 
@@ -129,11 +151,20 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_bf16_kernel(const Conv3P p) {
     u16* patch = smem;                                // [PH*PW][LDP]
     u16* wbuf = smem + PH * PW * LDP;                 // [2][NSL][LDP]
     u16* rbuf = wbuf + 2 * NSL * LDP;                 // [NSL][LDP]  1x1 shortcut weights of this chunk (RES)
-    __shared__ float smean[8], srstd[8], gnred[16];
+    __shared__ float gnred[16];
+    __shared__ __attribute__((aligned(16))) float coef[3][256];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
     const int wrow = wave % TH, wcol = wave / TH;
+#ifdef DEX_TIMING
+    long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long tk0 = __builtin_readcyclecounter();
+    long long tlast = tk0;
+#define CSTAMP(k) do { const long long now_ = __builtin_readcyclecounter(); tk[k] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define CSTAMP(k) do {} while (0)
+#endif
     const int w0 = blockIdx.x * 32, h0 = blockIdx.y * TH;
     const int b = blockIdx.z / NSLICE, slice = blockIdx.z % NSLICE;
     const int step = p.step ? *p.step : 0;
@@ -168,6 +199,8 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_bf16_kernel(const Conv3P p) {
     }
     const int pc8 = (tid % (CC / 8)) * 8;             // 256 % (CC/8) == 0: a thread's patch items share one channel chunk
 
+    CvGnLoads gnl{};
+    if (pro) gnl = cv_gn_issue(p, b, tid, step);
     const int nchunk = p.Cin / CC;
     for (int ch = 0; ch < nchunk; ++ch) {
         const int cbase = ch * CC;
@@ -187,17 +220,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_bf16_kernel(const Conv3P p) {
         for (int s = 0; s < RING; ++s)
 #pragma unroll
             for (int j = 0; j < WPT; ++j) wr[s][j] = *reinterpret_cast<const u32x4*>(Wg + wofs[j] + (long)(s + 1) * p.Cin + cbase);
-        float4 ga0, ga1, be0, be1, t0, t1;
-        float mean = 0.f, rstd = 1.f;
-        if (pro) {
-            const int c = cbase + pc8;
-            ga0 = *reinterpret_cast<const float4*>(p.pro_gamma + c); ga1 = *reinterpret_cast<const float4*>(p.pro_gamma + c + 4);
-            be0 = *reinterpret_cast<const float4*>(p.pro_beta + c); be1 = *reinterpret_cast<const float4*>(p.pro_beta + c + 4);
-            if (p.pro_tadd) {
-                const float* ta = p.pro_tadd + (long)step * p.Cin + c;
-                t0 = *reinterpret_cast<const float4*>(ta); t1 = *reinterpret_cast<const float4*>(ta + 4);
-            } else { t0 = make_float4(0.f, 0.f, 0.f, 0.f); t1 = t0; }
-        }
+        float4 sc0, sc1, sh0, sh1, t0, t1;                // this thread's 8 channels of the coefficient table (read after the barrier)
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
             float4 pf0[NIP], pf1[XB ? 1 : NIP], rf0[PRO2 ? NIP : 1], rf1[PRO2 ? NIP : 1];   // XB: pf0 holds the 8 raw bf16
@@ -228,10 +251,17 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_bf16_kernel(const Conv3P p) {
                 pin[q] = inb;
             }
             if (ps == 0) {
-                if (pro && ch == 0) cv_gn_coeffs(p, b, tid, smean, srstd);
+                CSTAMP(0);
+                if (pro && ch == 0) cv_gn_finish(p, gnl, tid, coef);
                 __builtin_amdgcn_sched_barrier(0);
                 lds_barrier();                            // GN coefficients visible; previous chunk's MFMAs done with patch/wbuf
-                if (pro) { const int g = (cbase + pc8) / (p.Cin / 8); mean = smean[g]; rstd = srstd[g]; }
+                CSTAMP(1);
+                if (pro) {
+                    const int c = cbase + pc8;
+                    sc0 = *reinterpret_cast<const float4*>(&coef[0][c]); sc1 = *reinterpret_cast<const float4*>(&coef[0][c + 4]);
+                    sh0 = *reinterpret_cast<const float4*>(&coef[1][c]); sh1 = *reinterpret_cast<const float4*>(&coef[1][c + 4]);
+                    t0 = *reinterpret_cast<const float4*>(&coef[2][c]); t1 = *reinterpret_cast<const float4*>(&coef[2][c + 4]);
+                }
 #pragma unroll
                 for (int j = 0; j < WPT; ++j) *reinterpret_cast<u32x4*>(wbuf + wlds[j]) = w0r[j];
                 if constexpr (RES) {
@@ -249,10 +279,10 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_bf16_kernel(const Conv3P p) {
                     f1 = make_float4(bf16_lo(u2), bf16_hi(u2), bf16_lo(u3), bf16_hi(u3));
                 } else { f0 = pf0[q]; f1 = pf1[q]; }
                 if (pro) {
-                    f0.x = cv_mish((f0.x - mean) * rstd * ga0.x + be0.x) + t0.x; f0.y = cv_mish((f0.y - mean) * rstd * ga0.y + be0.y) + t0.y;
-                    f0.z = cv_mish((f0.z - mean) * rstd * ga0.z + be0.z) + t0.z; f0.w = cv_mish((f0.w - mean) * rstd * ga0.w + be0.w) + t0.w;
-                    f1.x = cv_mish((f1.x - mean) * rstd * ga1.x + be1.x) + t1.x; f1.y = cv_mish((f1.y - mean) * rstd * ga1.y + be1.y) + t1.y;
-                    f1.z = cv_mish((f1.z - mean) * rstd * ga1.z + be1.z) + t1.z; f1.w = cv_mish((f1.w - mean) * rstd * ga1.w + be1.w) + t1.w;
+                    f0.x = cv_mish(fmaf(f0.x, sc0.x, sh0.x)) + t0.x; f0.y = cv_mish(fmaf(f0.y, sc0.y, sh0.y)) + t0.y;
+                    f0.z = cv_mish(fmaf(f0.z, sc0.z, sh0.z)) + t0.z; f0.w = cv_mish(fmaf(f0.w, sc0.w, sh0.w)) + t0.w;
+                    f1.x = cv_mish(fmaf(f1.x, sc1.x, sh1.x)) + t1.x; f1.y = cv_mish(fmaf(f1.y, sc1.y, sh1.y)) + t1.y;
+                    f1.z = cv_mish(fmaf(f1.z, sc1.z, sh1.z)) + t1.z; f1.w = cv_mish(fmaf(f1.w, sc1.w, sh1.w)) + t1.w;
                 }
                 const float mk = pmk[q];
                 const int it = tid + NTHR * (ps * NIP + q);
@@ -273,6 +303,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_bf16_kernel(const Conv3P p) {
                 if (it < ITEMS) *reinterpret_cast<uint4*>(patch + (it / (CC / 8)) * LDP + pc8) = v;
             }
         }
+        CSTAMP(2);
         // ---- nine taps; tap t's weights sit in wbuf[t & 1], taps t+1 .. t+RING are in registers / in flight
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -326,7 +357,16 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_bf16_kernel(const Conv3P p) {
             }
         }
     }
+    CSTAMP(3);
     cv_epilogue<NT, COUT>(p, acc, b, h0 + wrow, w0, slice * NSL + wcol * NT * 32, lane, tid, gnred);
+#ifdef DEX_TIMING
+    CSTAMP(4);
+    if (p.dbg && tid == 0) {
+        long long* d = p.dbg + ((long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8;
+        for (int k = 0; k < 5; ++k) d[k] = tk[k];
+        d[7] = __builtin_readcyclecounter() - tk0;
+    }
+#endif
 }
 
 template <int CC, int COUT, int NSL, int TH, bool PRO2 = false, bool RES = false, bool XB = false, int NW = 4>

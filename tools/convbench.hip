@@ -34,7 +34,16 @@ int main(int argc, char** argv) {
             printf("%-18s %s: %8.2f us\n", nm, mode ? "stream" : "tile  ", ms * 1000 / 20);
         }
 #ifdef DEX_TIMING
-        {
+        if (!conv3x3_stream_tiles(p)) {                    // small grid: the tile kernel's phase counters
+            const int nb = (W / 32) * (H / 4) * B;
+            long long* dbg; hipMalloc(&dbg, (size_t)nb * 64); hipMemset(dbg, 0, (size_t)nb * 64);
+            p.dbg = dbg; launch_conv3x3_bf16(p, 0); hipDeviceSynchronize(); p.dbg = nullptr;
+            std::vector<long long> h((size_t)nb * 8); hipMemcpy(h.data(), dbg, (size_t)nb * 64, hipMemcpyDeviceToHost);
+            double a[8] = {0}; for (int bl = 0; bl < nb; ++bl) for (int k = 0; k < 8; ++k) a[k] += h[(size_t)bl * 8 + k];
+            printf("   tile kernel, avg cycles/wg (%d wgs): issue loads %.0f | GN coeffs + barrier %.0f | convert + LDS %.0f | nine taps %.0f | epilogue %.0f | total %.0f\n",
+                   nb, a[0] / nb, a[1] / nb, a[2] / nb, a[3] / nb, a[4] / nb, a[7] / nb);
+            hipFree(dbg);
+        } else {
             const int tpw = conv3x3_stream_tiles(p);
             const int nb = (W / 32) * ((H / 8 + tpw - 1) / tpw) * B;
             long long* dbg; hipMalloc(&dbg, (size_t)nb * 64); hipMemset(dbg, 0, (size_t)nb * 64);
