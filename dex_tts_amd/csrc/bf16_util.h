@@ -44,6 +44,11 @@ __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u 
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 __device__ __forceinline__ unsigned short bf16_bits(float x) { return (unsigned short)(pack2_bf16(x, 0.f) & 0xffffu); }
 
+// value of the neighbouring lane (lane ^ 1) through DPP quad_perm [1,0,3,2]: one VALU move, no LDS crossbar
+__device__ __forceinline__ float lane_xor1(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a full workgroup-scope fence, which the
 // compiler implements as s_waitcnt vmcnt(0): every global load still in flight (a prefetched weight tile, the next
 // K tile of a register ring) is waited for at EVERY barrier, which serialises software pipelines.  Use this one

@@ -90,13 +90,28 @@ __device__ __forceinline__ void cv_epilogue(const Conv3P& p, f32x16 (&acc)[NT], 
         const int n = nbase + t * 32 + i;
         const float bias = p.bias[n];
         float gs = 0.f, gss = 0.f;
-        if (full) {
+        if (full && yb) {
+            // bf16 output: a lane owns ONE channel of 16 pixel rows, i.e. 2-byte stores.  Neighbouring lanes swap half of
+            // their rows (DPP), so each lane stores channel PAIRS of 8 rows: 8 dword stores instead of 16 short stores
+            // (the epilogue is store-issue bound: 64 addresses per instruction whatever their width).
+            const bool odd = (lane & 1) != 0;
+            u16* yp = yh + (odd ? 16 * COUT - 1 : 0) + t * 32;        // odd lanes: rows 16..27 of the tile, pair starts one channel left
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float v = acc[t][r] + bias; gs += v; gss = fmaf(v, v, gss); }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float lo_r = acc[t][j] + bias, hi_r = acc[t][8 + j] + bias;       // rows j and 8+j of this lane's channel
+                const float recv = lane_xor1(odd ? lo_r : hi_r);                          // the partner's value for MY row set
+                const float mine = odd ? hi_r : lo_r;
+                const unsigned pk = odd ? pack2_bf16(recv, mine) : pack2_bf16(mine, recv);
+                *reinterpret_cast<unsigned*>(yp + ((j & 3) + 8 * (j >> 2)) * COUT) = pk;
+            }
+        } else if (full) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float v = acc[t][r] + bias;
                 gs += v; gss = fmaf(v, v, gss);
-                if (yb) yh[((r & 3) + 8 * (r >> 2)) * COUT + t * 32] = bf16_bits(v);
-                else yl[((r & 3) + 8 * (r >> 2)) * COUT + t * 32] = v;
+                yl[((r & 3) + 8 * (r >> 2)) * COUT + t * 32] = v;
             }
         } else {
 #pragma unroll
