@@ -237,6 +237,25 @@ __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, c
         const long off = (long)b * p.H * p.W * SC + ((long)ho * p.W + w0 + 4 * hh) * SC + i;
         float* yf = p.Y + off; u16* yh = reinterpret_cast<u16*>(p.Y) + off;
         const bool full = ho < p.H && w0 + 32 <= p.W;
+        if (full && yb) {          // channel pairs of 8 rows per lane after a DPP swap with the neighbouring lane (see cv_epilogue)
+            const bool odd = (lane & 1) != 0;
+            u16* yp = yh + (odd ? 16 * SC - 1 : 0);
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2) {
+                const float bias = n2 ? bias1 : bias0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float v = acc[n2][r] + bias; gs[n2] += v; gss[n2] = fmaf(v, v, gss[n2]); }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float lo_r = acc[n2][j] + bias, hi_r = acc[n2][8 + j] + bias;
+                    const float recv = lane_xor1(odd ? lo_r : hi_r);
+                    const float mine = odd ? hi_r : lo_r;
+                    const unsigned pk = odd ? pack2_bf16(recv, mine) : pack2_bf16(mine, recv);
+                    *reinterpret_cast<unsigned*>(yp + ((j & 3) + 8 * (j >> 2)) * SC + n2 * 32) = pk;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int n2 = 0; n2 < 2; ++n2) {
             const float bias = n2 ? bias1 : bias0;
