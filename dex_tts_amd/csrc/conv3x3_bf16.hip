@@ -106,12 +106,17 @@ __device__ __forceinline__ void cv_epilogue(const Conv3P& p, f32x16 (&acc)[NT], 
                 const unsigned pk = odd ? pack2_bf16(recv, mine) : pack2_bf16(mine, recv);
                 *reinterpret_cast<unsigned*>(yp + ((j & 3) + 8 * (j >> 2)) * COUT) = pk;
             }
-        } else if (full) {
+        } else if (full) {          // fp32 output: the same swap, 8-byte stores
+            const bool odd = (lane & 1) != 0;
+            float* yp = yl + (odd ? 16 * COUT - 1 : 0) + t * 32;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = acc[t][r] + bias;
-                gs += v; gss = fmaf(v, v, gss);
-                yl[((r & 3) + 8 * (r >> 2)) * COUT + t * 32] = v;
+            for (int r = 0; r < 16; ++r) { const float v = acc[t][r] + bias; gs += v; gss = fmaf(v, v, gss); }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float lo_r = acc[t][j] + bias, hi_r = acc[t][8 + j] + bias;
+                const float recv = lane_xor1(odd ? lo_r : hi_r);
+                const float mine = odd ? hi_r : lo_r;
+                *reinterpret_cast<float2*>(yp + ((j & 3) + 8 * (j >> 2)) * COUT) = odd ? make_float2(recv, mine) : make_float2(mine, recv);
             }
         } else {
 #pragma unroll
@@ -362,13 +367,26 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_bf16_kernel(const Conv3P p) {
         // shortcut output: + bias, no statistics, same tile addressing as the main output
         const int ho = h0 + wrow, nb = slice * NSL + wcol * NT * 32;
         float* yl = p.res_y + ((long)b * p.H * p.W + (long)ho * p.W + w0 + 4 * hh) * COUT + nb + i;
+        const bool rfull = ho < p.H && w0 + 32 <= p.W;
+        const bool odd = (lane & 1) != 0;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const float bias = p.res_b[nb + t * 32 + i];
+            if (rfull) {           // channel pairs of 8 rows per lane (DPP swap with the neighbouring lane): 8-byte stores
+                float* yp = yl + (odd ? 16 * COUT - 1 : 0) + t * 32;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int wo = w0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (ho < p.H && wo < p.W) yl[((r & 3) + 8 * (r >> 2)) * COUT + t * 32] = accr[t][r] + bias;
+                for (int j = 0; j < 8; ++j) {
+                    const float lo_r = accr[t][j] + bias, hi_r = accr[t][8 + j] + bias;
+                    const float recv = lane_xor1(odd ? lo_r : hi_r);
+                    const float mine = odd ? hi_r : lo_r;
+                    *reinterpret_cast<float2*>(yp + ((j & 3) + 8 * (j >> 2)) * COUT) = odd ? make_float2(recv, mine) : make_float2(mine, recv);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int wo = w0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (ho < p.H && wo < p.W) yl[((r & 3) + 8 * (r >> 2)) * COUT + t * 32] = accr[t][r] + bias;
+                }
             }
         }
     }
