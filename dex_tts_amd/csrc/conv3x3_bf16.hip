@@ -55,7 +55,10 @@ __device__ __forceinline__ CvGnLoads cv_gn_issue(const Conv3P& p, int b, int tid
 __device__ __forceinline__ void cv_gn_finish(const Conv3P& p, const CvGnLoads& l, int tid, float (*coef)[256]) {
     if (tid >= 8 * GN_SLOTS) return;                  // 512-thread workgroups: whole waves 4..7 sit this out
     const int g = tid / GN_SLOTS, k = tid % GN_SLOTS, cpg = p.Cin / 8;
-    double s1 = (double)l.s1, s2 = (double)l.s2;
+    // first touch of the loaded partials through a pinned instruction: as a plain conversion it is hoisted to right behind
+    // the load, and the s_waitcnt vmcnt(0) that comes with it stalls the workgroup a full round trip BEFORE the weight
+    // and patch loads are even issued (seen in the ISA of the first version of this function)
+    double s1 = (double)mul_pinned(l.s1, 1.f), s2 = (double)mul_pinned(l.s2, 1.f);
     for (int o = 1; o < GN_SLOTS; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
     const double n = (double)p.H * p.W * cpg;
     const double mean = s1 / n;
