@@ -227,22 +227,9 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_bf16_kernel(const Conv3P p) {
     const int nchunk = p.Cin / CC;
     for (int ch = 0; ch < nchunk; ++ch) {
         const int cbase = ch * CC;
-        // ---- every global load of the chunk's first round goes out back to back: weights of taps 0..RING, the patch
+        // ---- every global load of the chunk's first round goes out back to back: the patch FIRST (loads return in order and
+        // the conversion, the long phase, needs only the patch), then the weights of taps 0..RING, which land under it
         u32x4 w0r[WPT], wr[RING][WPT], rwr[RES ? WPT : 1];
-        if constexpr (RES) {
-            const u16* Rg = reinterpret_cast<const u16*>(p.res_w) + (long)slice * NSL * p.Cin;      // [COUT][Cin]
-#pragma unroll
-            for (int j = 0; j < WPT; ++j) {
-                const int it = tid + NTHR * j;
-                rwr[j] = *reinterpret_cast<const u32x4*>(Rg + (long)(it / (CC / 8)) * p.Cin + cbase + (it % (CC / 8)) * 8);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < WPT; ++j) w0r[j] = *reinterpret_cast<const u32x4*>(Wg + wofs[j] + cbase);
-#pragma unroll
-        for (int s = 0; s < RING; ++s)
-#pragma unroll
-            for (int j = 0; j < WPT; ++j) wr[s][j] = *reinterpret_cast<const u32x4*>(Wg + wofs[j] + (long)(s + 1) * p.Cin + cbase);
         float4 sc0, sc1, sh0, sh1, t0, t1;                // this thread's 8 channels of the coefficient table (read after the barrier)
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
@@ -274,6 +261,20 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_bf16_kernel(const Conv3P p) {
                 pin[q] = inb;
             }
             if (ps == 0) {
+                if constexpr (RES) {
+                    const u16* Rg = reinterpret_cast<const u16*>(p.res_w) + (long)slice * NSL * p.Cin;      // [COUT][Cin]
+#pragma unroll
+                    for (int j = 0; j < WPT; ++j) {
+                        const int it = tid + NTHR * j;
+                        rwr[j] = *reinterpret_cast<const u32x4*>(Rg + (long)(it / (CC / 8)) * p.Cin + cbase + (it % (CC / 8)) * 8);
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < WPT; ++j) w0r[j] = *reinterpret_cast<const u32x4*>(Wg + wofs[j] + cbase);
+#pragma unroll
+                for (int s = 0; s < RING; ++s)
+#pragma unroll
+                    for (int j = 0; j < WPT; ++j) wr[s][j] = *reinterpret_cast<const u32x4*>(Wg + wofs[j] + (long)(s + 1) * p.Cin + cbase);
                 CSTAMP(0);
                 if (pro && ch == 0) cv_gn_finish(p, gnl, tid, coef);
                 __builtin_amdgcn_sched_barrier(0);
@@ -284,12 +285,6 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_bf16_kernel(const Conv3P p) {
                     sc0 = *reinterpret_cast<const float4*>(&coef[0][c]); sc1 = *reinterpret_cast<const float4*>(&coef[0][c + 4]);
                     sh0 = *reinterpret_cast<const float4*>(&coef[1][c]); sh1 = *reinterpret_cast<const float4*>(&coef[1][c + 4]);
                     t0 = *reinterpret_cast<const float4*>(&coef[2][c]); t1 = *reinterpret_cast<const float4*>(&coef[2][c + 4]);
-                }
-#pragma unroll
-                for (int j = 0; j < WPT; ++j) *reinterpret_cast<u32x4*>(wbuf + wlds[j]) = w0r[j];
-                if constexpr (RES) {
-#pragma unroll
-                    for (int j = 0; j < WPT; ++j) *reinterpret_cast<u32x4*>(rbuf + wlds[j]) = rwr[j];
                 }
             }
 #pragma unroll
@@ -325,6 +320,12 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_bf16_kernel(const Conv3P p) {
                 v.z = pack2_bf16(f1.x * mk, f1.y * mk); v.w = pack2_bf16(f1.z * mk, f1.w * mk);
                 if (it < ITEMS) *reinterpret_cast<uint4*>(patch + (it / (CC / 8)) * LDP + pc8) = v;
             }
+        }
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) *reinterpret_cast<u32x4*>(wbuf + wlds[j]) = w0r[j];
+        if constexpr (RES) {
+#pragma unroll
+            for (int j = 0; j < WPT; ++j) *reinterpret_cast<u32x4*>(rbuf + wlds[j]) = rwr[j];
         }
         CSTAMP(2);
         // ---- nine taps; tap t's weights sit in wbuf[t & 1], taps t+1 .. t+RING are in registers / in flight
