@@ -26,7 +26,7 @@ struct TD { float* p; int ld; int coff; int C; };          // channels-last acti
 
 struct ResW { const float *w1, *b1, *g1, *be1, *w2, *b2, *g2, *be2, *wr, *br, *mlp_w, *mlp_b; int cin, cout; };
 constexpr int ATT_KSPLIT_MAX = 4;     // key-split attention partials kept per token (dit_rowchain.hip merges them)
-struct LinW { const float *wqkv, *wqkv_raw, *wout_raw, *bias_eff, *g; const void *wq_bf16, *wkv_bf16; int C; };
+struct LinW { const float *wqkv, *wqkv_raw, *wout_raw, *bias_eff, *g; const void *wq_bf16, *wkv_bf16, *wq_frag; int C; };
 struct DitBlockW { const float *wqkv, *bqkv, *wproj, *bproj, *wfc1, *bfc1, *wfc2, *bfc2, *ada_w, *ada_b; };
 
 struct Prof { std::string name; hipEvent_t a, b; double flops, bytes; };
@@ -363,6 +363,10 @@ struct Packer {
             unsigned short* qb = (unsigned short*)alloc((384L * c + 1) / 2);
             if (qb) launch_f32_to_bf16(l.wqkv_raw, qb, 384L * c, st);
             l.wq_bf16 = qb; l.wkv_bf16 = qb ? qb + 128L * c : nullptr;
+            // the q rows again in MFMA fragment order (A operand of the tail's first GEMM: 1 KB contiguous per wave load)
+            void* qf = alloc((128L * c + 1) / 2);
+            if (qf) launch_pack_bf16_frag_nk(l.wqkv_raw, qf, c, 128, st);
+            l.wq_frag = qf;
         }
         l.g = raw(p + ".fn.g");
         float* be = alloc(c);
@@ -813,7 +817,7 @@ struct Runner {
             run("linattn_kvctx", 2.0 * npix * B * (256.0 * X.C + 128 * 32), (tail ? (tail->h2_bf16 ? 10.0 : 12.0) : 4.0) * npix * X.C * B, [&] { launch_linattn_kvctx(k, st); });
             LinMergeP mg{s.pm, s.ps, s.pc, nblk, w.wout_raw, w.g, X.C, s.mbf, B};
             run("linattn_merge", 2.0 * 128 * 32 * X.C * B, 4.0 * nblk * 4 * 1088 * B, [&] { launch_linattn_merge(mg, st); });
-            LinOut2P o{X.p, X.ld, X.coff, npix * X.ld, (int)npix, X.C, w.wq_bf16, s.mbf, w.bias_eff, out, ldo, ocoff, npix * ldo, B};
+            LinOut2P o{X.p, X.ld, X.coff, npix * X.ld, (int)npix, X.C, w.wq_frag, s.mbf, w.bias_eff, out, ldo, ocoff, npix * ldo, B};
             run("linattn_out", 4.0 * npix * B * 128.0 * X.C, 8.0 * npix * X.C * B, [&] { launch_linattn_out2(o, st); });
             return;
         }

@@ -533,6 +533,20 @@ __global__ void pack_bf16_frag_kernel(const float* __restrict__ src, u16* __rest
         dst[o] = (u16)(pack2_bf16(src[(long)k * N + n], 0.f) & 0xffffu);
     }
 }
+// same fragment order from a row-major [N][K] source (nn.Linear / 1x1-conv weight layout)
+__global__ void pack_bf16_frag_nk_kernel(const float* __restrict__ src, u16* __restrict__ dst, int K, int N) {
+    const long total = (long)K * N;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(o & 7), lane = (int)((o >> 3) & 63);
+        const long t = o >> 9;
+        const int ks = (int)(t % (K / 16)), nt = (int)(t / (K / 16));
+        const int k = ks * 16 + (lane >> 5) * 8 + j, n = nt * 32 + (lane & 31);
+        dst[o] = (u16)(pack2_bf16(src[(long)n * K + k], 0.f) & 0xffffu);
+    }
+}
+void launch_pack_bf16_frag_nk(const float* src, void* dst, int K, int N, hipStream_t st) {
+    hipLaunchKernelGGL(pack_bf16_frag_nk_kernel, dim3(256), dim3(256), 0, st, src, reinterpret_cast<u16*>(dst), K, N);
+}
 void launch_pack_bf16_frag(const float* src, void* dst, int K, int N, hipStream_t st) {
     hipLaunchKernelGGL(pack_bf16_frag_kernel, dim3(256), dim3(256), 0, st, src, reinterpret_cast<u16*>(dst), K, N);
 }

@@ -153,7 +153,7 @@ struct LinMergeP { const float* part_m; const float* part_s; const float* part_c
                    const float* Wout; const float* g; int C; void* W2; int B; };       // Wout fp32 [C][128]
 void launch_linattn_merge(const LinMergeP& p, hipStream_t st);
 struct LinOut2P { const float* X; int ldx; int x_coff; long xb; int npix; int C; const void* Wq; const void* W2;
-                  const float* bias; float* Y; int ldy; int y_coff; long yb; int B; }; // Wq bf16 [128][C]
+                  const float* bias; float* Y; int ldy; int y_coff; long yb; int B; }; // Wq bf16 in MFMA fragment order (launch_pack_bf16_frag_nk)
 void launch_linattn_out2(const LinOut2P& p, hipStream_t st);
 
 // Depthwise patch-embed conv + SiLU (dit.py:57-58), channels-last, zero padding incl. right pad to patch multiple.
@@ -197,6 +197,7 @@ struct AttnDirectP { const void *Qh, *Kh, *Vt; int N, Npad, B; float* O; long o_
 void launch_attention_direct(const AttnDirectP& p, hipStream_t st);
 void launch_dit_rowchain(const DitChainP& p, hipStream_t st);
 void launch_pack_bf16_frag(const float* src, void* dst, int K, int N, hipStream_t st);
+void launch_pack_bf16_frag_nk(const float* src, void* dst, int K, int N, hipStream_t st);   // source [N][K]
 
 // Softmax attention, head_dim 128, no key mask except kv_len (timm Attention core / TVAdaptor core).
 struct AttnP { const float* Q; int ldq; long qb; const float* K; int ldk; long kb; const float* V; int ldv; long vb;

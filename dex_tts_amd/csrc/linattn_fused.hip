@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void linattn_out2_kernel(const LinOut2P p) {
         xf[ks].u.z = pack2_bf16(xc[ks].x, xc[ks].y); xf[ks].u.w = pack2_bf16(xc[ks].z, xc[ks].w);
     }
     // ---- GEMM1: q^T, four 32-row he tiles; converted to bf16 B fragments tile by tile
-    const u16* wq = reinterpret_cast<const u16*>(p.Wq) + (long)i * C + hh * 8;      // bf16 [128][C]
+    const uint4* wq = reinterpret_cast<const uint4*>(p.Wq) + lane;                  // bf16, fragment order [he tile][K-step][lane][8]
     LFrag qf[8];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void linattn_out2_kernel(const LinOut2P p) {
         for (int r = 0; r < 16; ++r) q[r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) {
-            LFrag af; af.u = *reinterpret_cast<const uint4*>(wq + (long)t * 32 * C + ks * 16);
+            LFrag af; af.u = wq[(t * KS1 + ks) * 64];
             q = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.v, xf[ks].v, q, 0, 0, 0);
         }
 #pragma unroll
