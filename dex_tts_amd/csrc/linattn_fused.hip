@@ -376,14 +376,15 @@ void launch_linattn_merge(const LinMergeP& p, hipStream_t st) {
     hipLaunchKernelGGL(linattn_merge_kernel, dim3(4, p.B, 32), dim3(256), 0, st, p);
 }
 
-// Tail: y = x + W2 (Wq x) + g*b per pixel, as two chained MFMA GEMMs computed TRANSPOSED so that no operand ever
+// Tail, latency form (small grids): y = x + W2 (Wq x) + g*b per pixel, as two chained MFMA GEMMs computed TRANSPOSED so that no operand ever
 // needs a layout change:  q^T[he][px] = Wq[he][:] . x[px][:]  (A = Wq rows, B = x rows),  then
 // y^T[co][px] = sum_he W2[co][he] q^T[he][px]  (A = W2, B = the q^T accumulators re-used in place: a lane already
 // holds, for its pixel column, 8 he values per K-step — in accumulator row order, which is why W2 is stored with
-// that permutation).  Each wave owns 32 pixels end to end: no LDS, no barrier, every global load issued up front.
+// that permutation).  Each wave owns 32 pixels end to end: no LDS, no barrier, every global load issued up front
+// (at B=1 the LDS-staged form below costs 1.5 % end to end: one more dependent round trip in a latency-bound chain).
 // grid (ceil(npix/128), B), 256 threads.
 template <int C>
-__global__ __launch_bounds__(256) void linattn_out2_kernel(const LinOut2P p) {
+__global__ __launch_bounds__(256) void linattn_out2_direct_kernel(const LinOut2P p) {
     constexpr int KS1 = C / 16, CT = C / 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
@@ -464,10 +465,126 @@ __global__ __launch_bounds__(256) void linattn_out2_kernel(const LinOut2P p) {
         }
     }
 }
+// Tail, throughput form (large grids: +1.2 % end to end at B=32): y = x + W2 (Wq x) + g*b per pixel, two chained MFMA GEMMs computed TRANSPOSED so that no operand ever
+// needs a layout change:  q^T[he][px] = Wq[he][:] . x[px][:]  (A = Wq rows, B = x rows),  then
+// y^T[co][px] = sum_he W2[co][he] q^T[he][px]  (A = W2, B = the q^T accumulators re-used in place: a lane already
+// holds, for its pixel column, 8 he values per K-step — in accumulator row order, which is why W2 is stored with
+// that permutation).  Each wave owns 32 pixels end to end, no workgroup barrier.
+// The x tile goes through a WAVE-PRIVATE LDS image: the MFMA layouts have a lane own 8 (operand) or 4 (result) channels
+// of ONE pixel, so direct loads/stores touch 32 cache lines per instruction and use 16-32 bytes of each (x: 8 loads,
+// residual re-read: 4*CT, y: 4*CT stores — ~770 line touches per tile for 128 lines of data, and this kernel is bound by
+// the CU's address/line rate).  Through LDS every global instruction moves 1 KB of contiguous pixels (8 lines), the
+// residual comes from the image, and y is staged in place over it.
+// grid (ceil(npix/128), B), 256 threads, dynamic LDS 4 * 32 * (C + 4) floats.
+template <int C>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, C == 64 ? 4 : 2))) void linattn_out2_kernel(const LinOut2P p) {
+    constexpr int KS1 = C / 16, CT = C / 32;
+    constexpr int LDX = C + 4;                          // floats: row stride 4 mod 64 dwords -> conflict-free b128 rows
+    constexpr int NCH = 32 * C / 4 / 64;                // 16-byte chunks of the tile per lane (8 for C = 64)
+    extern __shared__ __attribute__((aligned(16))) float smem_o2[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.y;
+    const int px0 = (blockIdx.x * 4 + wave) * 32;
+    if (px0 >= p.npix) return;
+    float* xs = smem_o2 + wave * 32 * LDX;
+    const float* X = p.X + (long)b * p.xb + p.x_coff;
+    // coalesced tile load: chunk c = lane + 64k covers pixel c / (C/4), channels (c % (C/4)) * 4 .. +4
+    float4 xin[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c = lane + 64 * k, px = c / (C / 4), ch = (c % (C / 4)) * 4;
+        xin[k] = *reinterpret_cast<const float4*>(X + (long)min(px0 + px, p.npix - 1) * p.ldx + ch);
+    }
+    // A fragments of GEMM2 (all of W2 for this utterance: CT x 8 K-steps)
+    const uint4* w2 = reinterpret_cast<const uint4*>(p.W2) + (long)b * CT * 8 * 64 + lane;
+    uint4 w2f[CT][8];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) w2f[ct][ks] = w2[(ct * 8 + ks) * 64];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c = lane + 64 * k, px = c / (C / 4), ch = (c % (C / 4)) * 4;
+        *reinterpret_cast<float4*>(xs + px * LDX + ch) = xin[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // B fragments of GEMM1: lane (pixel column i, half hh) holds x[px][ks*16 + hh*8 .. +8]
+    LFrag xf[KS1];
+#pragma unroll
+    for (int ks = 0; ks < KS1; ++ks) {
+        const float4 xa = *reinterpret_cast<const float4*>(xs + i * LDX + ks * 16 + hh * 8);
+        const float4 xc = *reinterpret_cast<const float4*>(xs + i * LDX + ks * 16 + hh * 8 + 4);
+        xf[ks].u.x = pack2_bf16(xa.x, xa.y); xf[ks].u.y = pack2_bf16(xa.z, xa.w);
+        xf[ks].u.z = pack2_bf16(xc.x, xc.y); xf[ks].u.w = pack2_bf16(xc.z, xc.w);
+    }
+    // ---- GEMM1: q^T, four 32-row he tiles; converted to bf16 B fragments tile by tile
+    const uint4* wq = reinterpret_cast<const uint4*>(p.Wq) + lane;                  // bf16, fragment order [he tile][K-step][lane][8]
+    LFrag qf[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        f32x16 q;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) q[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) {
+            LFrag af; af.u = wq[(t * KS1 + ks) * 64];
+            q = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.v, xf[ks].v, q, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            qf[t * 2 + k2].u.x = pack2_bf16(q[8 * k2 + 0], q[8 * k2 + 1]); qf[t * 2 + k2].u.y = pack2_bf16(q[8 * k2 + 2], q[8 * k2 + 3]);
+            qf[t * 2 + k2].u.z = pack2_bf16(q[8 * k2 + 4], q[8 * k2 + 5]); qf[t * 2 + k2].u.w = pack2_bf16(q[8 * k2 + 6], q[8 * k2 + 7]);
+        }
+    }
+    // ---- GEMM2 + epilogue: rows co = ct*32 + (r&3) + 8*(r>>2) + 4*hh  ->  4 consecutive channels per register quad;
+    // y = result + x (from the image) + bias replaces x in the image, location by location
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        f32x16 y;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) y[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            LFrag af; af.u = w2f[ct][ks];
+            y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.v, qf[ks].v, y, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int co = ct * 32 + 8 * g4 + 4 * hh;
+            float* slot = xs + i * LDX + co;
+            const float4 res = *reinterpret_cast<const float4*>(slot);
+            const float4 bia = *reinterpret_cast<const float4*>(p.bias + co);
+            float4 o;
+            o.x = y[g4 * 4 + 0] + res.x + bia.x; o.y = y[g4 * 4 + 1] + res.y + bia.y;
+            o.z = y[g4 * 4 + 2] + res.z + bia.z; o.w = y[g4 * 4 + 3] + res.w + bia.w;
+            *reinterpret_cast<float4*>(slot) = o;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    float* Y = p.Y + (long)b * p.yb + p.y_coff;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c = lane + 64 * k, px = c / (C / 4), ch = (c % (C / 4)) * 4;
+        const float4 o = *reinterpret_cast<const float4*>(xs + px * LDX + ch);
+        if (px0 + px < p.npix) *reinterpret_cast<float4*>(Y + (long)(px0 + px) * p.ldy + ch) = o;
+    }
+}
 void launch_linattn_out2(const LinOut2P& p, hipStream_t st) {
     dim3 grid((p.npix + 127) / 128, p.B);
-    if (p.C == 64) hipLaunchKernelGGL(linattn_out2_kernel<64>, grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(linattn_out2_kernel<128>, grid, dim3(256), 0, st, p);
+    const size_t lds = (size_t)4 * 32 * (p.C + 4) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_out2_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)4 * 32 * 132 * sizeof(float)));
+        attr = true;
+    }
+    if ((long)grid.x * p.B < 2048) {        // latency regime: the direct form
+        if (p.C == 64) hipLaunchKernelGGL(linattn_out2_direct_kernel<64>, grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(linattn_out2_direct_kernel<128>, grid, dim3(256), 0, st, p);
+        return;
+    }
+    if (p.C == 64) hipLaunchKernelGGL(linattn_out2_kernel<64>, grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL(linattn_out2_kernel<128>, grid, dim3(256), lds, st, p);
 }
 
 }  // namespace dex
