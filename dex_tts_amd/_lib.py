@@ -48,6 +48,7 @@ SYMBOLS = [
     ("dex_ctx_num_weights", C.c_int, [C.c_void_p]),
     ("dex_ctx_weight_info", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     ("dex_ctx_load_weight", C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    ("dex_ctx_load_weight_async", C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
     ("dex_ctx_finalize", C.c_int, [C.c_void_p, C.c_void_p]),
     ("dex_ctx_set_precision", C.c_int, [C.c_void_p, C.c_int]),
     ("dex_workspace_bytes", C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),

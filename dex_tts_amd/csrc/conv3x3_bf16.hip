@@ -37,13 +37,13 @@ __device__ __forceinline__ float cv_mish(float x) {           // branch-free: ta
 // beta, time bias: ONE value per thread) are issued before the weight/patch loads so they return first; the table lives in
 // LDS.  (The first version had every thread fetch gamma/beta/time bias of its 8 channels: 24 KB of redundant L1 traffic per
 // workgroup in the phase where the TA is the bottleneck - the load-issue phase measured 4.4k cycles per workgroup at B=1.)
-struct CvGnLoads { float s1, s2, ga, be, ta; };
+struct CvGnLoads { unsigned s1l, s1h, s2l, s2h; float ga, be, ta; };
 __device__ __forceinline__ CvGnLoads cv_gn_issue(const Conv3P& p, int b, int tid, int step) {
-    CvGnLoads l{0.f, 0.f, 0.f, 0.f, 0.f};
+    CvGnLoads l{0u, 0u, 0u, 0u, 0.f, 0.f, 0.f};
     if (tid < 8 * GN_SLOTS) {
         const int g = tid / GN_SLOTS, k = tid % GN_SLOTS, cpg = p.Cin / 8;
-        const float* src = p.pro_stats + (((long)b * 8 + g) * GN_SLOTS + k) * 2;
-        l.s1 = src[0]; l.s2 = src[1];
+        const uint4 v = *reinterpret_cast<const uint4*>(p.pro_stats + (((long)b * 8 + g) * GN_SLOTS + k) * 2);   // one 16-byte load
+        l.s1l = v.x; l.s1h = v.y; l.s2l = v.z; l.s2h = v.w;
         if (k < cpg) {
             const int c = g * cpg + k;
             l.ga = p.pro_gamma[c]; l.be = p.pro_beta[c];
@@ -58,13 +58,11 @@ __device__ __forceinline__ void cv_gn_finish(const Conv3P& p, const CvGnLoads& l
     // first touch of the loaded partials through a pinned instruction: as a plain conversion it is hoisted to right behind
     // the load, and the s_waitcnt vmcnt(0) that comes with it stalls the workgroup a full round trip BEFORE the weight
     // and patch loads are even issued (seen in the ISA of the first version of this function)
-    double s1 = (double)mul_pinned(l.s1, 1.f), s2 = (double)mul_pinned(l.s2, 1.f);
-    for (int o = 1; o < GN_SLOTS; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-    const double n = (double)p.H * p.W * cpg;
-    const double mean = s1 / n;
-    double var = s2 / n - mean * mean;
-    var = var < 0.0 ? 0.0 : var;
-    const float rstd = (float)(1.0 / sqrt(var + 1e-5)), mu = (float)mean;
+    long long s1 = (long long)(((unsigned long long)mov_pinned(l.s1h) << 32) | mov_pinned(l.s1l));
+    long long s2 = (long long)(((unsigned long long)mov_pinned(l.s2h) << 32) | mov_pinned(l.s2l));
+    gn_slots_reduce<GN_SLOTS>(s1, s2);
+    float rstd, mu;
+    gn_moments(s1, s2, 1e-5, mu, rstd);
     if (k < cpg) {
         const int c = g * cpg + k;
         coef[0][c] = rstd * l.ga;
@@ -77,10 +75,10 @@ __device__ __forceinline__ void cv_gn_finish(const Conv3P& p, const CvGnLoads& l
 // GroupNorm partials are combined across the workgroup's waves in LDS (gnred[8][2]) before the atomics.
 template <int NT, int COUT>
 __device__ __forceinline__ void cv_epilogue(const Conv3P& p, f32x16 (&acc)[NT], int b, int ho, int w0, int nbase, int lane, int tid,
-                                            float* gnred) {
+                                            long long* gnred) {
     const int i = lane & 31, hh = lane >> 5;
     constexpr int cpg = COUT / 8;
-    if (p.gn_stats) { if (tid < 16) gnred[tid] = 0.f; __syncthreads(); }
+    if (p.gn_stats) { if (tid < 16) gnred[tid] = 0; __syncthreads(); }
     // one 64-bit base per lane; the 16 rows of a tile are compile-time offsets from it (the first version rebuilt a
     // 64-bit address and a bounds predicate per element).  Full tiles (the common case: W % 32 == 0) store unpredicated.
     const bool full = ho < p.H && w0 + 32 <= p.W;
@@ -138,16 +136,19 @@ __device__ __forceinline__ void cv_epilogue(const Conv3P& p, f32x16 (&acc)[NT], 
         if (p.gn_stats) {
             for (int o = 1; o < cpg; o <<= 1) { gs += __shfl_xor(gs, o); gss += __shfl_xor(gss, o); }
             gs += __shfl_xor(gs, 32); gss += __shfl_xor(gss, 32);
-            if (hh == 0 && (i & (cpg - 1)) == 0) { atomicAdd(&gnred[(n / cpg) * 2], gs); atomicAdd(&gnred[(n / cpg) * 2 + 1], gss); }
+            if (hh == 0 && (i & (cpg - 1)) == 0) {      // a wave's sums come out of a fixed shuffle order; the integer adds commute
+                const double inv_n = 1.0 / ((double)p.H * p.W * cpg);
+                gn_add(&gnred[(n / cpg) * 2], gn_fix(gs, inv_n)); gn_add(&gnred[(n / cpg) * 2 + 1], gn_fix(gss, inv_n));
+            }
         }
     }
     if (p.gn_stats) {
         __syncthreads();
         if (tid < 16) {
-            const float v = gnred[tid];
-            if (v != 0.f) {
+            const long long v = gnred[tid];
+            if (v != 0) {
                 const int slot = (blockIdx.x + blockIdx.y * gridDim.x) % GN_SLOTS;
-                atomicAdd(p.gn_stats + (((long)b * 8 + (tid >> 1)) * GN_SLOTS + slot) * 2 + (tid & 1), v);
+                gn_add(p.gn_stats + (((long)b * 8 + (tid >> 1)) * GN_SLOTS + slot) * 2 + (tid & 1), v);
             }
         }
     }
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_bf16_kernel(const Conv3P p) {
     u16* patch = smem;                                // [PH*PW][LDP]
     u16* wbuf = smem + PH * PW * LDP;                 // [2][NSL][LDP]
     u16* rbuf = wbuf + 2 * NSL * LDP;                 // [NSL][LDP]  1x1 shortcut weights of this chunk (RES)
-    __shared__ float gnred[16];
+    __shared__ long long gnred[16];
     __shared__ __attribute__((aligned(16))) float coef[3][256];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

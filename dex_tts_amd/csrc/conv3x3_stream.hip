@@ -63,7 +63,8 @@ __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, c
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* patch = smem;                                 // [2 slots][8 rows][34][SLDP]
     u16* wts = smem + 2 * STR * SPW * SLDP;            // [9 taps][64 cout][SLDP]
-    __shared__ float smean[8], srstd[8], gnred[16];
+    __shared__ float smean[8], srstd[8];
+    __shared__ long long gnred[16];
     __shared__ __attribute__((aligned(16))) float coef[3][SC];        // GroupNorm prologue per channel: scale, shift, time bias
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -91,12 +92,11 @@ __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, c
 
     // ---- set-up loads go out together: GroupNorm partials first (oldest in the queue: their wait leaves the rest in
     // flight), all nine taps of the weights, then (below) the first two row chunks
-    float gn_s1 = 0.f, gn_s2 = 0.f, gn_ga = 0.f, gn_be = 0.f, gn_ta = 0.f;
+    float gn_ga = 0.f, gn_be = 0.f, gn_ta = 0.f;
+    uint4 gn_raw = make_uint4(0u, 0u, 0u, 0u);                  // one slot's fixed-point (mean, mean-of-squares) pair
     if constexpr (PRO) {
-        if (tid < 8 * GN_SLOTS) {
-            const float* src = p.pro_stats + (((long)b * 8 + tid / GN_SLOTS) * GN_SLOTS + (tid % GN_SLOTS)) * 2;
-            gn_s1 = src[0]; gn_s2 = src[1];
-        }
+        if (tid < 8 * GN_SLOTS)
+            gn_raw = *reinterpret_cast<const uint4*>(p.pro_stats + (((long)b * 8 + tid / GN_SLOTS) * GN_SLOTS + (tid % GN_SLOTS)) * 2);
         if (tid < SC) { gn_ga = p.pro_gamma[tid]; gn_be = p.pro_beta[tid]; gn_ta = p.pro_tadd ? p.pro_tadd[(long)step * SC + tid] : 0.f; }
     }
     u32x4 wr[9];
@@ -194,16 +194,10 @@ __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, c
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (PRO) {        // prologue coefficients per channel:  y = Mish(x * coef0 + coef1) + coef2
         if (tid < 8 * GN_SLOTS) {
-            double s1 = (double)gn_s1, s2 = (double)gn_s2;
-            for (int o = 1; o < GN_SLOTS; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-            if ((tid % GN_SLOTS) == 0) {
-                const double n = (double)p.H * p.W * (SC / 8);
-                const double mean = s1 / n;
-                double var = s2 / n - mean * mean;
-                var = var < 0.0 ? 0.0 : var;
-                smean[tid / GN_SLOTS] = (float)mean;
-                srstd[tid / GN_SLOTS] = (float)(1.0 / sqrt(var + 1e-5));
-            }
+            long long s1 = (long long)(((unsigned long long)gn_raw.y << 32) | gn_raw.x);
+            long long s2 = (long long)(((unsigned long long)gn_raw.w << 32) | gn_raw.z);
+            gn_slots_reduce<GN_SLOTS>(s1, s2);
+            if ((tid % GN_SLOTS) == 0) gn_moments(s1, s2, 1e-5, smean[tid / GN_SLOTS], srstd[tid / GN_SLOTS]);
         }
         lds_barrier();
         if (tid < SC) {
@@ -330,22 +324,23 @@ __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, c
     }
 #endif
     if (p.gn_stats) {
-        if (tid < 16) gnred[tid] = 0.f;
+        if (tid < 16) gnred[tid] = 0;
         __syncthreads();
 #pragma unroll
         for (int n2 = 0; n2 < 2; ++n2) {
             float a = gs[n2], q = gss[n2];
             for (int o = 1; o < 8; o <<= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
             a += __shfl_xor(a, 32); q += __shfl_xor(q, 32);
-            if (hh == 0 && (i & 7) == 0) {
+            if (hh == 0 && (i & 7) == 0) {         // a wave's sums come out of a fixed order; the integer adds commute
                 const int g = (n2 * 32 + i) / 8;
-                atomicAdd(&gnred[g * 2], a); atomicAdd(&gnred[g * 2 + 1], q);
+                const double inv_n = 1.0 / ((double)p.H * p.W * (SC / 8));
+                gn_add(&gnred[g * 2], gn_fix(a, inv_n)); gn_add(&gnred[g * 2 + 1], gn_fix(q, inv_n));
             }
         }
         __syncthreads();
         if (tid < 16) {
             const int slot = (blockIdx.x + blockIdx.y * gridDim.x) % GN_SLOTS;
-            atomicAdd(p.gn_stats + (((long)b * 8 + (tid >> 1)) * GN_SLOTS + slot) * 2 + (tid & 1), gnred[tid]);
+            gn_add(p.gn_stats + (((long)b * 8 + (tid >> 1)) * GN_SLOTS + slot) * 2 + (tid & 1), gnred[tid]);
         }
     }
 }

@@ -76,9 +76,12 @@ struct DexCtx {
     bool prof_on = false;
     std::vector<Prof> prof;
     std::vector<ProfAgg> prof_agg;
-    // hipGraph cache of one Euler step
-    hipGraphExec_t graph_exec = nullptr;
-    std::vector<uint64_t> graph_key;
+    // hipGraph cache: one captured graph per (shape, pointer set) holds a WHOLE sampler call (conditioning tables, every
+    // network evaluation, the final copy) and is replayed with one hipGraphLaunch
+    struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec; uint64_t stamp; };
+    std::vector<GraphEntry> graphs;
+    uint64_t graph_clock = 0;
+    void drop_graphs() { for (auto& g : graphs) hipGraphExecDestroy(g.exec); graphs.clear(); }
 
     int fail(int code, const char* fmt, ...) {
         char buf[512];
@@ -250,7 +253,7 @@ void dex_ctx_destroy(DexCtx* x) {
     if (x->mel_basis) hipFree(x->mel_basis);
     if (x->mel_filt) hipFree(x->mel_filt);
     if (x->mel_ws) hipFree(x->mel_ws);
-    if (x->graph_exec) hipGraphExecDestroy(x->graph_exec);
+    x->drop_graphs();
     for (auto& pr : x->prof) { hipEventDestroy(pr.a); hipEventDestroy(pr.b); }
     delete x;
 }
@@ -267,7 +270,7 @@ int dex_ctx_weight_info(const DexCtx* x, int i, const char** key, int64_t shape[
     return DEX_OK;
 }
 
-int dex_ctx_load_weight(DexCtx* x, const char* key, const float* w_dev, const int64_t* shape, int ndim) {
+static int load_weight_impl(DexCtx* x, const char* key, const float* w_dev, const int64_t* shape, int ndim, bool async, hipStream_t st) {
     if (!x || !key || !w_dev) return DEX_ERR_ARG;
     auto it = x->raw.find(key);
     if (it == x->raw.end()) return x->fail(DEX_ERR_ARG, "unknown weight key '%s'", key);
@@ -276,10 +279,21 @@ int dex_ctx_load_weight(DexCtx* x, const char* key, const float* w_dev, const in
     for (int k = 0; k < ndim; ++k)
         if (r.shape[k] != shape[k]) return x->fail(DEX_ERR_ARG, "weight '%s': dim %d is %lld, expected %lld", key, k, (long long)shape[k], (long long)r.shape[k]);
     if (!r.p) HIPCHK(x, hipMalloc((void**)&r.p, r.numel * sizeof(float)));
-    HIPCHK(x, hipMemcpy(r.p, w_dev, r.numel * sizeof(float), hipMemcpyDeviceToDevice));
+    if (async) {
+        HIPCHK(x, hipMemcpyAsync(r.p, w_dev, r.numel * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else {
+        HIPCHK(x, hipMemcpy(r.p, w_dev, r.numel * sizeof(float), hipMemcpyDeviceToDevice));
+        HIPCHK(x, hipStreamSynchronize(nullptr));       // a device-to-device hipMemcpy may return before it has run
+    }
     r.loaded = true;
     x->finalized = false;
     return DEX_OK;
+}
+int dex_ctx_load_weight(DexCtx* x, const char* key, const float* w_dev, const int64_t* shape, int ndim) {
+    return load_weight_impl(x, key, w_dev, shape, ndim, false, nullptr);
+}
+int dex_ctx_load_weight_async(DexCtx* x, const char* key, const float* w_dev, const int64_t* shape, int ndim, dex_stream_t stream) {
+    return load_weight_impl(x, key, w_dev, shape, ndim, true, (hipStream_t)stream);
 }
 
 int dex_ctx_set_precision(DexCtx* x, int precision) {
@@ -416,7 +430,7 @@ extern "C" int dex_ctx_finalize(DexCtx* x, dex_stream_t stream) {
     for (void* p : x->owned) hipFree(p);
     x->owned.clear();
     x->bf16_of.clear(); x->frag_of.clear();
-    if (x->graph_exec) { hipGraphExecDestroy(x->graph_exec); x->graph_exec = nullptr; x->graph_key.clear(); }
+    x->drop_graphs();
     const DexConfig& c = x->cfg;
     hipStream_t st = (hipStream_t)stream;
     Packer P{x, st};
@@ -520,7 +534,7 @@ struct Plan {
     std::vector<float*> tadd_down, tadd_up, ada;
     float *adap_tmp, *t_adap, *t_sty, *tv_k0, *tv_v0, *sap_m, *sap_s, *ref_mean, *ref_std;
     float *spk_tmp, *spk_plane;
-    int* step; int* step_tab; float* stats; long stats_bytes; int n_gn;   // stats: two arenas (Euler-step parity)
+    int* step; int* step_tab; gnfix_t* stats; long stats_bytes; int n_gn;   // stats: two arenas (Euler-step parity)
     float* xbuf;
     float *xprime, *dbuf, *hsig, *htab;      // Heun: x', slope d_cur, per-evaluation sigma / h tables
     std::vector<StageBuf> down, up;
@@ -530,7 +544,7 @@ struct Plan {
     float *pe0, *emb, *pos_part, *tok, *xn, *qkv, *ao, *att_ml, *hmlp, *dbg_tok;
     void *qh, *kh, *vt, *qh2, *kh2, *vt2; int Npad; size_t vt_bytes;   // bf16 attention operands of the row-chain path (two sets:
                                                                         // a fused block reads one while its workgroups write the other)
-    float *tv_keys, *tv_K, *tv_V, *tv_q, *tv_ao, *tv_out, *tiv_out, *tv_weff, *tv_beff, *tv_stats, *tiv_stats; void* tv_wbf;
+    float *tv_keys, *tv_K, *tv_V, *tv_q, *tv_ao, *tv_out, *tiv_out, *tv_weff, *tv_beff; gnfix_t *tv_stats, *tiv_stats; void* tv_wbf;
     size_t bytes;
 };
 
@@ -559,8 +573,8 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
     P.step = (int*)A.take(256);
     P.step_tab = (int*)A.take((size_t)(n + 1) * sizeof(int));
     P.n_gn = 4 * c.n_stages + 4 * (c.n_stages - 1) + 1;
-    P.stats_bytes = (long)P.n_gn * B * 8 * GN_SLOTS * 2 * sizeof(float);
-    P.stats = (float*)A.take(2 * P.stats_bytes);
+    P.stats_bytes = (long)P.n_gn * B * 8 * GN_SLOTS * 2 * sizeof(gnfix_t);
+    P.stats = (gnfix_t*)A.take(2 * P.stats_bytes);
     P.xbuf = A.f((size_t)B * 80 * d.T);
     P.xprime = A.f((size_t)B * 80 * d.T); P.dbuf = A.f((size_t)B * 80 * d.T);
     P.hsig = A.f((size_t)n + 2); P.htab = A.f((size_t)n + 2);
@@ -617,7 +631,7 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
         P.tv_q = A.f(pm * mid); P.tv_ao = A.f(pm * mid); P.tv_out = A.f(pm * mid); P.tiv_out = A.f(pm * mid);
         P.tv_weff = A.f((size_t)B * mid * mid); P.tv_beff = A.f((size_t)B * mid);
         P.tv_wbf = A.take((size_t)B * mid * mid * 2);
-        P.tv_stats = A.f((size_t)B * mid * IN_SLOTS * 2 * 2);       // IN2d partial sums of the TV input and the TIV input
+        P.tv_stats = (gnfix_t*)A.take((size_t)B * mid * IN_SLOTS * 2 * 2 * sizeof(gnfix_t));   // IN2d partials of the TV input and the TIV input
         P.tiv_stats = A.dry ? nullptr : P.tv_stats + (size_t)B * mid * IN_SLOTS * 2;
     }
     P.bytes = (A.off + 255) & ~size_t(255);
@@ -630,8 +644,8 @@ struct Runner {
     bool debug;
     int gn_idx = 0;
     const int* sp = nullptr;        // device pointer to the current Euler-step index
-    float* stats_base = nullptr;    // statistics arena of this step
-    float* stats_other = nullptr;   // arena to clear for the next step (eager mode), or null
+    gnfix_t* stats_base = nullptr;  // statistics arena of this step
+    gnfix_t* stats_other = nullptr;   // arena to clear for the next step (eager mode), or null
     int fin_mode = 0;               // FinalP::mode of this network evaluation (Heun predictor / corrector)
     const float* fin_htab = nullptr;
 
@@ -643,7 +657,7 @@ struct Runner {
             x->prof.push_back(pr);
         } else f();
     }
-    float* next_stats() { return stats_base + (size_t)(gn_idx++) * P.d.B * 8 * GN_SLOTS * 2; }
+    gnfix_t* next_stats() { return stats_base + (size_t)(gn_idx++) * P.d.B * 8 * GN_SLOTS * 2; }
     void tap(const char* name, const float* p, long rows, int C, int ld) {
         if (!debug) return;
         DexCtx::Tap t; t.name = name; t.p = p; t.shape = {rows, C, ld};
@@ -678,13 +692,13 @@ struct Runner {
     }
     // Block conv (diffusion.py:44).  pro != null fuses the producer's GN-apply + Mish + time bias into the load
     // (bf16 patch kernel only).
-    struct Pro { const float* stats; const float *gamma, *beta, *tadd; const float* res = nullptr; float* xout = nullptr; bool x_bf16 = false; };
+    struct Pro { const gnfix_t* stats; const float *gamma, *beta, *tadd; const float* res = nullptr; float* xout = nullptr; bool x_bf16 = false; };
     // raw conv outputs read only by a fused GroupNorm prologue (h1, h2 of a ResnetBlock, the final block's conv) are kept
     // in HBM as bf16 in bf16 mode: half the bytes of the largest tensors of the step.  DEX_H_BF16=0 keeps them fp32.
     bool h_bf16() const { const char* e = getenv("DEX_H_BF16"); return x->precision == DEX_PREC_BF16 && !(e && e[0] == '0'); }
     bool fast_conv(int cin, int cout) const { return x->precision == DEX_PREC_BF16 && conv3x3_bf16_supported(cin, cout); }
     void conv3x3(const char* name, const TD& X, int H, int W, int mask_ws, bool inmask, const float* Wt, const float* bias, int Cout, float* out,
-                 float* gn = nullptr, const Pro* pro = nullptr, const ResW* shortcut = nullptr, float* shortcut_out = nullptr,
+                 gnfix_t* gn = nullptr, const Pro* pro = nullptr, const ResW* shortcut = nullptr, float* shortcut_out = nullptr,
                  bool xb = false, bool yb = false) {
         auto it = x->bf16_of.find(Wt);
         if (fast_conv(X.C, Cout) && it != x->bf16_of.end()) {
@@ -711,11 +725,11 @@ struct Runner {
         g.gn_stats = gn; g.gn_groups = 8; g.gn_cpg = Cout / 8;
         gemm(name, g);
     }
-    void gn_stats(const float* h, int C, long npix, float* stats) {
+    void gn_stats(const float* h, int C, long npix, gnfix_t* stats) {
         GnStatsP s{h, C, npix * C, (int)npix, C, 8, stats, P.d.B};
         run("gn_stats", 3.0 * npix * C * P.d.B, 4.0 * npix * C * P.d.B, [&] { launch_gn_stats(s, st); });
     }
-    void gn_apply(const float* h, int C, long npix, int W, int mask_ws, const float* stats, const float* gamma, const float* beta,
+    void gn_apply(const float* h, int C, long npix, int W, int mask_ws, const gnfix_t* stats, const float* gamma, const float* beta,
                   const float* tadd, const float* res, int ldres, long resb, bool res_under_mask, float* out) {
         GnApplyP a{};
         a.X = h; a.ldx = C; a.xb = npix * C; a.Y = out; a.ldy = C; a.yb = npix * C; a.y_coff = 0;
@@ -736,7 +750,7 @@ struct Runner {
                   const Pro* head = nullptr, Pro* ctail = nullptr) {
         const long npix = s.npix;
         const float* resptr; int ldres; long resb; bool under = false;
-        float* st1 = nullptr;
+        gnfix_t* st1 = nullptr;
         // h1 / h2 of this block as bf16: conv2 must be the GroupNorm-prologue conv that can read bf16, conv1 a kernel that can
         // write it; h2 additionally needs a fused consumer (the next block's first conv or the attention's context pass)
         const bool conv2_fast = fast_conv(w.cout, w.cout) && conv3x3_bf16_xb_supported(w.cout, w.cout) && x->bf16_of.count(w.w2);
@@ -774,7 +788,7 @@ struct Runner {
             }
         }
         if (!st1) { st1 = next_stats(); gn_stats(s.h1, w.cout, npix, st1); }
-        float* st2 = next_stats();
+        gnfix_t* st2 = next_stats();
         if (fast_conv(w.cout, w.cout)) {
             // block1's GN-apply + Mish + time bias + mask is applied while block2's conv stages its input patch
             Pro pro{st1, w.g1, w.be1, tadd};
@@ -991,7 +1005,8 @@ struct Runner {
         q.w_bstride = (long)mid * mid; q.bias_bstride = mid; q.inmask = mask; q.inmask_ws = mask_ws;
         if (qbf) q.Wbf = P.tv_wbf;
         gemm("tv_q", q);
-        TvRow0P r0{P.tv_k0, P.tv_v0, sp, P.tv_K, P.tv_V, (long)(P.d.Ts + 1) * mid, mid, B, P.tv_stats, (long)B * mid * IN_SLOTS * 2 * 2};
+        TvRow0P r0{P.tv_k0, P.tv_v0, sp, P.tv_K, P.tv_V, (long)(P.d.Ts + 1) * mid, mid, B, reinterpret_cast<float*>(P.tv_stats),
+                   (long)B * mid * IN_SLOTS * 2 * 2 * (long)(sizeof(gnfix_t) / sizeof(float))};
         run("tv_time_token", 0, 8.0 * mid * B, [&] { launch_tv_row0(r0, st); });
         AttnP a{};
         a.Q = P.tv_q; a.ldq = mid; a.qb = npix * mid; a.K = P.tv_K; a.ldk = mid; a.kb = (long)(P.d.Ts + 1) * mid;
@@ -1016,7 +1031,7 @@ struct Runner {
         const DexConfig& c = x->cfg;
         const int B = P.d.B, ns = c.n_stages;
         gn_idx = 0;
-        if (!stats_other) hipMemsetAsync(stats_base, 0, P.stats_bytes, st);   // graph mode / single call: clear in place
+        if (!stats_other) hipMemsetAsync(stats_base, 0, P.stats_bytes, st);   // single call (dex_denoise_once): clear in place
         TD cur{nullptr, 0, 0, 0};
         for (int i = 0; i < ns; ++i) {
             const StageBuf& s = P.down[i];
@@ -1086,7 +1101,7 @@ struct Runner {
         }
         tap("up_out", P.up_out, (long)B * 80 * P.d.T, c.dim, c.dim);
         TD U{P.up_out, c.dim, 0, c.dim};
-        float* stf = next_stats();
+        gnfix_t* stf = next_stats();
         const bool hfb = h_bf16() && fast_conv(c.dim, c.dim) && x->bf16_of.count(x->fin_w);
         conv3x3("conv3x3", U, 80, P.d.T, 1, true, x->fin_w, x->fin_b, c.dim, P.hF, stf, nullptr, nullptr, nullptr, false, hfb);
         FinalP f{};
@@ -1094,7 +1109,7 @@ struct Runner {
         f.X = P.hF; f.xb = 80L * P.d.T * c.dim; f.npix = 80 * P.d.T; f.W = P.d.T; f.C = c.dim; f.groups = 8; f.stats = stf;
         f.gamma = x->fin_g; f.beta = x->fin_be; f.mask = mask; f.mask_bstride = P.d.T; f.wfc = x->fconv_w; f.bfc = x->fconv_b;
         f.xcur = xcur; f.denoised = denoised; f.xnext = xnext; f.scal = P.scal; f.scal_stride = SCAL_STRIDE; f.step = sp; f.B = B;
-        f.zero_ptr = stats_other; f.zero_n = P.stats_bytes / (long)sizeof(float);
+        f.zero_ptr = reinterpret_cast<float*>(stats_other); f.zero_n = P.stats_bytes / (long)sizeof(float);
         f.mode = fin_mode; f.htab = fin_htab; f.dbuf = P.dbuf; f.xhat = P.xbuf;
         run("final_conv_euler", 14.0 * 80 * P.d.T * c.dim * B, 80.0 * P.d.T * ((hfb ? 2.0 : 4.0) * c.dim + 12.0) * B, [&] { launch_final(f, st); });
     }
@@ -1108,7 +1123,7 @@ struct Runner {
             SmallLinP s{X, ldx, rows, K, R(w + ".weight"), bias ? R(w + ".bias") : nullptr, N, Y, N, ai, ao};
             run("cond_mlp", 2.0 * rows * K * N, 4.0 * K * N, [&] { launch_small_linear(s, st); });
         };
-        if (P.tv_stats) hipMemsetAsync(P.tv_stats, 0, (size_t)B * mid_dim(c) * IN_SLOTS * 2 * 2 * sizeof(float), st);
+        if (P.tv_stats) hipMemsetAsync(P.tv_stats, 0, (size_t)B * mid_dim(c) * IN_SLOTS * 2 * 2 * sizeof(gnfix_t), st);
         hipMemsetAsync(P.vt, 0, P.vt_bytes, st);      // key padding of the transposed V operand (attention_direct.hip)
         hipMemsetAsync(P.vt2, 0, P.vt_bytes, st);
         CondPrepP cp{sigmas_dev, n, c.pe_scale, dim, P.scal, SCAL_STRIDE, P.t_unet, P.t_dit};
@@ -1180,20 +1195,16 @@ __global__ void set_sigma_pair(const float* src, float* dst) { dst[0] = src[0]; 
 // ablation_sampler(solver='heun', alpha=1) — edm.py:199-214.  2n-1 network evaluations: evaluation 2i is step i's
 // predictor at t_i, evaluation 2i+1 its corrector at t' = t_i + h (none on the last step).  The conditioning tables are
 // built per EVALUATION; the last kernel of each evaluation does the predictor / corrector update.  Eager launches only.
-int sample_heun(DexCtx* x, const DexSampleArgs* a, hipStream_t st) {
+int enqueue_heun(DexCtx* x, const DexSampleArgs* a, hipStream_t st) {
     const int n = a->n_steps, E = 2 * n - 1;
     Plan P; Dims d{a->B, a->T, a->Tr, a->Ts, E};
-    make_plan(x, d, nullptr, P);
-    if (P.bytes > a->workspace_bytes) return x->fail(DEX_ERR_WORKSPACE, "workspace too small: need %zu bytes (Heun: dex_workspace_bytes with dex_num_evals(n_steps, solver)), got %zu", P.bytes, a->workspace_bytes);
     make_plan(x, d, a->workspace_dev, P);
-    x->taps.clear();
-    if (x->prof_on) { for (auto& pr : x->prof) { hipEventDestroy(pr.a); hipEventDestroy(pr.b); } x->prof.clear(); x->prof_agg.clear(); }
     Runner R{x, P, st, a->mask_dev, a->mu_dev, P.xbuf, a, false};
     launch_iota(P.step_tab, E, st);
     launch_heun_expand(a->sigmas_dev, n, P.hsig, P.htab, st);
     R.prepare(P.hsig, E);
     R.run("init_scale", 0, 8.0 * a->B * 80 * a->T, [&] { launch_scale_copy(a->z_dev, P.xbuf, (long)a->B * 80 * a->T, P.scal, st); });
-    float* arena[2] = {P.stats, P.stats + P.stats_bytes / (long)sizeof(float)};
+    gnfix_t* arena[2] = {P.stats, P.stats + P.stats_bytes / (long)sizeof(gnfix_t)};
     hipMemsetAsync(P.stats, 0, 2 * P.stats_bytes, st);
     R.fin_htab = P.htab;
     for (int e = 0; e < E; ++e) {
@@ -1204,7 +1215,27 @@ int sample_heun(DexCtx* x, const DexSampleArgs* a, hipStream_t st) {
         R.step(nullptr, (corrector || last) ? P.xbuf : P.xprime);
     }
     HIPCHK(x, hipMemcpyAsync(a->out_dev, P.xbuf, (size_t)a->B * 80 * a->T * sizeof(float), hipMemcpyDeviceToDevice, st));
-    HIPCHK(x, hipGetLastError());
+    return DEX_OK;
+}
+
+// ablation_sampler(solver='euler') — edm.py:186-208.  The step index comes from a device table and the GroupNorm statistics
+// alternate between two arenas; each step's last kernel clears the arena of the next step.
+int enqueue_euler(DexCtx* x, const DexSampleArgs* a, hipStream_t st) {
+    Plan P; Dims d{a->B, a->T, a->Tr, a->Ts, a->n_steps};
+    make_plan(x, d, a->workspace_dev, P);
+    Runner R{x, P, st, a->mask_dev, a->mu_dev, P.xbuf, a, false};
+    launch_iota(P.step_tab, a->n_steps, st);
+    R.sp = P.step_tab;
+    R.prepare(a->sigmas_dev, a->n_steps);
+    // x_0 = z * sigma_0 (edm.py:188-189)
+    R.run("init_scale", 0, 8.0 * a->B * 80 * a->T, [&] { launch_scale_copy(a->z_dev, P.xbuf, (long)a->B * 80 * a->T, P.scal, st); });
+    gnfix_t* arena[2] = {P.stats, P.stats + P.stats_bytes / (long)sizeof(gnfix_t)};
+    hipMemsetAsync(P.stats, 0, 2 * P.stats_bytes, st);
+    for (int i = 0; i < a->n_steps; ++i) {
+        R.sp = P.step_tab + i; R.stats_base = arena[i & 1]; R.stats_other = arena[(i + 1) & 1];
+        R.step(nullptr, P.xbuf);
+    }
+    HIPCHK(x, hipMemcpyAsync(a->out_dev, P.xbuf, (size_t)a->B * 80 * a->T * sizeof(float), hipMemcpyDeviceToDevice, st));
     return DEX_OK;
 }
 
@@ -1259,52 +1290,63 @@ int dex_sample(DexCtx* x, const DexSampleArgs* a, dex_stream_t stream) {
     int rc = validate(x, a, true);
     if (rc) return rc;
     if (a->solver != DEX_SOLVER_EULER && a->solver != DEX_SOLVER_HEUN) return x->fail(DEX_ERR_ARG, "solver must be DEX_SOLVER_EULER or DEX_SOLVER_HEUN (edm.py:107)");
-    if (a->solver == DEX_SOLVER_HEUN) return sample_heun(x, a, (hipStream_t)stream);
     hipStream_t st = (hipStream_t)stream;
-    Plan P; Dims d{a->B, a->T, a->Tr, a->Ts, a->n_steps};
-    make_plan(x, d, nullptr, P);
-    if (P.bytes > a->workspace_bytes) return x->fail(DEX_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", P.bytes, a->workspace_bytes);
-    make_plan(x, d, a->workspace_dev, P);
+    const bool heun = a->solver == DEX_SOLVER_HEUN;
+    {
+        Plan P; Dims d{a->B, a->T, a->Tr, a->Ts, dex_num_evals(a->n_steps, a->solver)};
+        make_plan(x, d, nullptr, P);
+        if (P.bytes > a->workspace_bytes)
+            return x->fail(DEX_ERR_WORKSPACE, "workspace too small: need %zu bytes (dex_workspace_bytes with dex_num_evals(n_steps, solver)), got %zu", P.bytes, a->workspace_bytes);
+    }
     x->taps.clear();
     if (x->prof_on) { for (auto& pr : x->prof) { hipEventDestroy(pr.a); hipEventDestroy(pr.b); } x->prof.clear(); x->prof_agg.clear(); }
-    Runner R{x, P, st, a->mask_dev, a->mu_dev, P.xbuf, a, false};
-    R.sp = P.step; R.stats_base = P.stats; R.stats_other = nullptr;
-    launch_step_reset(P.step, st);
-    launch_iota(P.step_tab, a->n_steps, st);
-    R.prepare(a->sigmas_dev, a->n_steps);
-    // x_0 = z * sigma_0 (edm.py:188-189)
-    R.run("init_scale", 0, 8.0 * a->B * 80 * a->T, [&] { launch_scale_copy(a->z_dev, P.xbuf, (long)a->B * 80 * a->T, P.scal, st); });
+    auto enqueue = [&]() { return heun ? enqueue_heun(x, a, st) : enqueue_euler(x, a, st); };
     const bool use_graph = a->use_graph && !x->prof_on;
-    if (use_graph) {
-        std::vector<uint64_t> key = {(uint64_t)a->B, (uint64_t)a->T, (uint64_t)a->Tr, (uint64_t)a->Ts, (uint64_t)a->n_steps, (uint64_t)x->precision,
-                                     (uint64_t)(uintptr_t)a->mu_dev, (uint64_t)(uintptr_t)a->mask_dev, (uint64_t)(uintptr_t)a->workspace_dev,
-                                     (uint64_t)(uintptr_t)a->sty_lengths_dev, (uint64_t)(uintptr_t)st};
-        if (!x->graph_exec || key != x->graph_key) {
-            if (x->graph_exec) { hipGraphExecDestroy(x->graph_exec); x->graph_exec = nullptr; }
-            hipGraph_t graph = nullptr;
-            if (st == nullptr) return x->fail(DEX_ERR_ARG, "use_graph needs a non-default stream (the legacy null stream cannot be captured)");
-            HIPCHK(x, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            R.step(nullptr, P.xbuf);
-            launch_step_inc(P.step, st);
-            hipError_t ec = hipStreamEndCapture(st, &graph);          // always leave capture mode
-            if (ec != hipSuccess || !graph) return x->fail(DEX_ERR_HIP, "stream capture failed: %s", hipGetErrorString(ec));
-            ec = hipGraphInstantiate(&x->graph_exec, graph, nullptr, nullptr, 0);
-            hipGraphDestroy(graph);
-            if (ec != hipSuccess) { x->graph_exec = nullptr; return x->fail(DEX_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ec)); }
-            x->graph_key = key;
-        }
-        for (int i = 0; i < a->n_steps; ++i) HIPCHK(x, hipGraphLaunch(x->graph_exec, st));
-    } else {
-        // eager: the step index comes from a device table (no increment kernel) and the GroupNorm statistics
-        // alternate between two arenas; each step's last kernel clears the arena of the next step
-        float* arena[2] = {P.stats, P.stats + P.stats_bytes / (long)sizeof(float)};
-        hipMemsetAsync(P.stats, 0, 2 * P.stats_bytes, st);
-        for (int i = 0; i < a->n_steps; ++i) {
-            R.sp = P.step_tab + i; R.stats_base = arena[i & 1]; R.stats_other = arena[(i + 1) & 1];
-            R.step(nullptr, P.xbuf);
-        }
+    if (!use_graph) {
+        rc = enqueue();
+        if (rc) return rc;
+        HIPCHK(x, hipGetLastError());
+        return DEX_OK;
     }
-    HIPCHK(x, hipMemcpyAsync(a->out_dev, P.xbuf, (size_t)a->B * 80 * a->T * sizeof(float), hipMemcpyDeviceToDevice, st));
+    // One graph = the whole call.  Every device pointer the captured kernels dereference is part of the key, so a replay
+    // is only ever issued against the buffers it was captured with (the host mirror keeps persistent staging buffers, which
+    // makes every call of one shape a cache hit).
+    if (st == nullptr) return x->fail(DEX_ERR_ARG, "use_graph needs a non-default stream (the legacy null stream cannot be captured)");
+    std::vector<uint64_t> key = {(uint64_t)a->B, (uint64_t)a->T, (uint64_t)a->Tr, (uint64_t)a->Ts, (uint64_t)a->n_steps, (uint64_t)a->solver,
+                                 (uint64_t)x->precision, (uint64_t)a->n_ref, (uint64_t)(uintptr_t)st,
+                                 (uint64_t)(uintptr_t)a->z_dev, (uint64_t)(uintptr_t)a->mu_dev, (uint64_t)(uintptr_t)a->mask_dev,
+                                 (uint64_t)(uintptr_t)a->sigmas_dev, (uint64_t)(uintptr_t)a->spk_dev, (uint64_t)(uintptr_t)a->sty_dev,
+                                 (uint64_t)(uintptr_t)a->sty_lengths_dev, (uint64_t)(uintptr_t)a->out_dev, (uint64_t)(uintptr_t)a->workspace_dev};
+    for (int j = 0; j < a->n_ref; ++j) key.push_back((uint64_t)(uintptr_t)a->ref_skips_dev[j]);
+    for (const char* e : {"DEX_CONV_STREAM", "DEX_H_BF16", "DEX_ATTN_SEPARATE"}) {     // knobs read at enqueue time
+        const char* v = getenv(e);
+        key.push_back(v ? (uint64_t)atoi(v) + 1 : 0);
+    }
+    DexCtx::GraphEntry* hit = nullptr;
+    for (auto& g : x->graphs) if (g.key == key) { hit = &g; break; }
+    if (!hit) {
+        constexpr size_t MAX_GRAPHS = 8;
+        if (x->graphs.size() >= MAX_GRAPHS) {                 // evict the least recently used graph
+            size_t lru = 0;
+            for (size_t i = 1; i < x->graphs.size(); ++i) if (x->graphs[i].stamp < x->graphs[lru].stamp) lru = i;
+            hipGraphExecDestroy(x->graphs[lru].exec);
+            x->graphs.erase(x->graphs.begin() + lru);
+        }
+        hipGraph_t graph = nullptr;
+        HIPCHK(x, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        rc = enqueue();
+        hipError_t ec = hipStreamEndCapture(st, &graph);          // always leave capture mode
+        if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+        if (ec != hipSuccess || !graph) return x->fail(DEX_ERR_HIP, "stream capture failed: %s", hipGetErrorString(ec));
+        hipGraphExec_t exec = nullptr;
+        ec = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        if (ec != hipSuccess) return x->fail(DEX_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ec));
+        x->graphs.push_back({key, exec, 0});
+        hit = &x->graphs.back();
+    }
+    hit->stamp = ++x->graph_clock;
+    HIPCHK(x, hipGraphLaunch(hit->exec, st));
     HIPCHK(x, hipGetLastError());
     return DEX_OK;
 }
@@ -1374,8 +1416,9 @@ int dex_mel_from_wav(DexCtx* x, const float* wav_dev, int n, float* mel_dev, flo
     const int frames = dex_mel_frames(n), NP = 1152;
     const size_t pad_len = (size_t)(frames - 1) * 256 + 1024 + 256;
     const size_t need = (pad_len + (size_t)frames * NP) * sizeof(float) + 512;
-    if (need > x->mel_ws_bytes) {
-        if (x->mel_ws) hipFree(x->mel_ws);
+    if (need > x->mel_ws_bytes) {       // grow-only scratch, single-stream use (documented in include/dex_amd.h)
+        if (x->mel_ws) { HIPCHK(x, hipStreamSynchronize(st)); hipFree(x->mel_ws); }
+        x->mel_ws = nullptr; x->mel_ws_bytes = 0;
         HIPCHK(x, hipMalloc(&x->mel_ws, need));
         x->mel_ws_bytes = need;
     }

@@ -35,10 +35,10 @@ void launch_row_stats(const float* X, int B, int C, int len, float eps, float* m
 // per-(b,c) sum / sumsq over all pixels (incl. padding).  grid (chunks, B); C <= 256.
 constexpr int IN_PIX = 256;     // few workgroups (few atomics: 40k global atomics cost ~5 us), 16 loads in flight per thread
 __global__ __launch_bounds__(256) void in_stats_kernel(const InStatsP p) {
-    __shared__ float red[256][2];
+    __shared__ long long red[256][2];
     const int tid = threadIdx.x, b = blockIdx.y;
     const int C4 = p.C >> 2;
-    red[tid][0] = 0.f; red[tid][1] = 0.f;
+    red[tid][0] = 0; red[tid][1] = 0;
     __syncthreads();
     const int cq = tid % C4, prow = tid / C4, rpp = 256 / C4;
     const int pbeg = blockIdx.x * IN_PIX, pend = min(p.npix, pbeg + IN_PIX);
@@ -63,28 +63,29 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const InStatsP p) {
         }
     }
     const int c = cq * 4;
-    atomicAdd(&red[c + 0][0], s.x); atomicAdd(&red[c + 0][1], q.x);
-    atomicAdd(&red[c + 1][0], s.y); atomicAdd(&red[c + 1][1], q.y);
-    atomicAdd(&red[c + 2][0], s.z); atomicAdd(&red[c + 2][1], q.z);
-    atomicAdd(&red[c + 3][0], s.w); atomicAdd(&red[c + 3][1], q.w);
+    const double inv_n = 1.0 / (double)p.npix;          // per-thread sums run in a fixed order; the integer adds commute
+    gn_add(&red[c + 0][0], gn_fix(s.x, inv_n)); gn_add(&red[c + 0][1], gn_fix(q.x, inv_n));
+    gn_add(&red[c + 1][0], gn_fix(s.y, inv_n)); gn_add(&red[c + 1][1], gn_fix(q.y, inv_n));
+    gn_add(&red[c + 2][0], gn_fix(s.z, inv_n)); gn_add(&red[c + 2][1], gn_fix(q.z, inv_n));
+    gn_add(&red[c + 3][0], gn_fix(s.w, inv_n)); gn_add(&red[c + 3][1], gn_fix(q.w, inv_n));
     __syncthreads();
     if (tid < p.C) {
-        float* dst = p.stats + (((long)b * p.C + tid) * IN_SLOTS + (blockIdx.x % IN_SLOTS)) * 2;
-        atomicAdd(dst, red[tid][0]);
-        atomicAdd(dst + 1, red[tid][1]);
+        gnfix_t* dst = p.stats + (((long)b * p.C + tid) * IN_SLOTS + (blockIdx.x % IN_SLOTS)) * 2;
+        gn_add(dst, red[tid][0]);
+        gn_add(dst + 1, red[tid][1]);
     }
 }
 void launch_in_stats(const InStatsP& p, hipStream_t st) {
     hipLaunchKernelGGL(in_stats_kernel, dim3((p.npix + IN_PIX - 1) / IN_PIX, p.B), dim3(256), 0, st, p);
 }
 
-__device__ __forceinline__ void in_mean_rstd(const float* stats, long idx, int npix, float eps, float& mean, float& rstd) {
-    double s1 = 0.0, s2 = 0.0;
+__device__ __forceinline__ void in_mean_rstd(const gnfix_t* stats, long idx, int npix, float eps, float& mean, float& rstd) {
+    long long t1 = 0, t2 = 0;
 #pragma unroll
-    for (int k = 0; k < IN_SLOTS; ++k) { s1 += (double)stats[(idx * IN_SLOTS + k) * 2]; s2 += (double)stats[(idx * IN_SLOTS + k) * 2 + 1]; }
+    for (int k = 0; k < IN_SLOTS; ++k) { t1 += stats[(idx * IN_SLOTS + k) * 2]; t2 += stats[(idx * IN_SLOTS + k) * 2 + 1]; }
     const double n = (double)npix;
-    const double mu = s1 / n;
-    double var = (s2 - n * mu * mu) / (n - 1.0);    // unbiased (torch.var default, base.py:99)
+    const double mu = (double)t1 * (1.0 / GN_FIX_ONE);
+    double var = ((double)t2 * (1.0 / GN_FIX_ONE) - mu * mu) * (n / (n - 1.0));    // unbiased (torch.var default, base.py:99)
     var = var < 0.0 ? 0.0 : var;
     mean = (float)mu;
     rstd = (float)(1.0 / sqrt(var + (double)eps));

@@ -8,6 +8,7 @@
 // serialising behind per-element branches.
 #pragma once
 #include "kernels.h"
+#include "bf16_util.h"
 
 namespace dex {
 
@@ -112,16 +113,17 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmP& p, f32x16 (&acc)[MT
     }
     if (p.gn_stats) {
         // channels-per-group cpg in {8,16,32}: reduce over the cpg lanes of a group and over both half-waves,
-        // then ONE fp32 atomic pair per group per wave into slot (blockIdx.x % GN_SLOTS) — slots spread the
-        // same-address atomic traffic; the consumer sums the slots in fp64.
+        // then ONE fixed-point atomic pair per group per wave into slot (blockIdx.x % GN_SLOTS) — slots spread the
+        // same-address atomic traffic; integer adds commute, so the totals do not depend on the arrival order.
         const int cpg = p.gn_cpg;
         for (int o = 1; o < cpg; o <<= 1) { gs += __shfl_xor(gs, o); gss += __shfl_xor(gss, o); }
         gs += __shfl_xor(gs, 32); gss += __shfl_xor(gss, 32);
         if (hh == 0 && (i & (cpg - 1)) == 0) {
             const int grp = ng / cpg;
-            float* dst = p.gn_stats + (((long)b * p.gn_groups + grp) * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * 2;
-            atomicAdd(dst, gs);
-            atomicAdd(dst + 1, gss);
+            gnfix_t* dst = p.gn_stats + (((long)b * p.gn_groups + grp) * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * 2;
+            const double inv_n = 1.0 / ((double)p.Ho * p.Wo * cpg);
+            gn_add(dst, gn_fix(gs, inv_n));
+            gn_add(dst + 1, gn_fix(gss, inv_n));
         }
     }
 }

@@ -8,8 +8,13 @@
 
 namespace dex {
 
-constexpr int GN_SLOTS = 32;   // GroupNorm statistics: [B][groups][GN_SLOTS][2] fp32 partial sums (native L2 atomics,
-                                // spread over slots; fp64 atomics measured ~170 ns each on one address); consumers sum the slots in fp64
+// GroupNorm / InstanceNorm statistics: [B][groups][GN_SLOTS][2] partial (mean, mean-of-squares) contributions as 64-bit
+// FIXED-POINT integers (2^-36 resolution, see bf16_util.h gn_fix): integer addition is associative, so the native L2
+// atomics that accumulate them give the same bits whatever order the workgroups arrive in — every sampler call is bitwise
+// reproducible (the first version accumulated fp32 partial sums and differed run to run in the last bits, which bf16
+// rounding then amplified to 7e-3).  Slots spread the same-address atomic traffic (~170 ns each on one address).
+constexpr int GN_SLOTS = 32;
+typedef long long gnfix_t;
 
 // ------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution / linear:  C[m, n] = epi( sum_k gather(A)[m,k] * W[k,n] )
@@ -37,7 +42,7 @@ struct IGemmP {
     int unpatch_s, unpatch_C;                          // >0: scatter rows (f,w) x cols (p1,p2,c) -> NHWC image
     int parity;                                        // 1: blockIdx.z = b*4 + (ph*2+pw): ConvTranspose2d(4,2,1) as four 2x2-tap
                                                        // sub-convolutions in ONE launch (off/oh0/ow0 = parity, weights += par*K*N)
-    float* gn_stats; int gn_groups, gn_cpg;            // fused GroupNorm partial statistics of (acc + bias), or null
+    gnfix_t* gn_stats; int gn_groups, gn_cpg;          // fused GroupNorm partial statistics of (acc + bias), or null
     int stats_final;                                   // 1: the statistics are of the STORED value (after activation, gate,
                                                        // residual, mask) - InstanceNorm of the next adaptor (cpg = 1)
     const float* ln_shift; const float* ln_scale; long ln_step_stride;   // fused LayerNorm(eps 1e-6)+modulate on the A rows
@@ -52,7 +57,7 @@ struct Conv3P {
     const float* X; int ldx; int x_coff; int H, W, Cin, Cout;
     const void* Wbf; const float* bias; float* Y;            // bf16 [Cout][9*Cin]; Y is [B,H,W,Cout] contiguous
     const float* mask; int mask_ws; long mask_bstride;
-    const float* pro_stats; const float* pro_gamma; const float* pro_beta; const float* pro_tadd;   // tadd may be null
+    const gnfix_t* pro_stats; const float* pro_gamma; const float* pro_beta; const float* pro_tadd;   // tadd may be null
     // second prologue form (pro_res != null): the input is the preceding ResnetBlock's tail,
     //   x = mask * Mish(GN(X)) + pro_res   (res_conv shortcut, diffusion.py:67-71), [H*W][Cin] like X;
     // the kernel also writes x for its own output pixels to pro_xout ([H*W][Cin]) for the later consumers.
@@ -60,7 +65,7 @@ struct Conv3P {
     // fused 1x1 shortcut of the ResnetBlock (res_conv(x * mask), diffusion.py:70): a second output computed from the
     // patch's centre tap; res_w = bf16 [Cout][Cin], res_y = [H*W][Cout] fp32
     const void* res_w; const float* res_b; float* res_y;
-    const int* step; float* gn_stats; int B;
+    const int* step; gnfix_t* gn_stats; int B;
     long long* dbg;                                          // optional phase timestamps (tools/kbench)
     // raw conv outputs that only a GroupNorm prologue reads next (h1, h2 of a ResnetBlock) may live in HBM as bf16:
     // x_bf16: X is bf16 [.. ldx] (PRO / PRO2 forms only); y_bf16: Y is written as bf16.  Statistics stay fp32.
@@ -85,19 +90,19 @@ struct FirstConvP {
     const float* scal; int scal_stride; const int* step;  // per-step scalars; scal[step*stride + 2] = c_in
     float* h1; float* res;                                // [B,H,T,C] each
     int h1_bf16;                                          // h1 stored as bf16 (its only reader is the next conv's GN prologue)
-    float* gn_stats;                                      // fused GroupNorm partials of h1 (8 groups, slot-spread) or null
+    gnfix_t* gn_stats;                                    // fused GroupNorm partials of h1 (8 groups, slot-spread) or null
 };
 void launch_first_conv(const FirstConvP& p, hipStream_t st);
 
 // GroupNorm statistics: per (b, group) sum / sum-of-squares in fp64 (biased variance later).
-struct GnStatsP { const float* X; int ld; long bstride; int npix; int C; int groups; float* stats; int B; };
+struct GnStatsP { const float* X; int ld; long bstride; int npix; int C; int groups; gnfix_t* stats; int B; };
 void launch_gn_stats(const GnStatsP& p, hipStream_t st);
 
 // y = mask*(Mish(GN(x)) + tadd[c]) + res   (Block / ResnetBlock tails, diffusion.py:41-50,66-71)
 struct GnApplyP {
     const float* X; int ldx; long xb;
     float* Y; int ldy; long yb; int y_coff;
-    int npix, W, C, groups; const float* stats; const float* gamma; const float* beta;
+    int npix, W, C, groups; const gnfix_t* stats; const float* gamma; const float* beta;
     const float* mask; int mask_ws; long mask_bstride;
     const float* tadd; long tadd_step_stride; const int* step;
     const float* res; int ldres; long resb; int res_under_mask;   // 1: y = mask*(mish + tadd + res)
@@ -107,7 +112,7 @@ void launch_gn_apply(const GnApplyP& p, hipStream_t st);
 
 // final_block tail + final_conv + EDM combine + Euler update (diffusion.py:204-207, edm.py:97,202-208)
 struct FinalP {
-    const float* X; long xb; int npix, W, C, groups; const float* stats; const float* gamma; const float* beta;
+    const float* X; long xb; int npix, W, C, groups; const gnfix_t* stats; const float* gamma; const float* beta;
     const float* mask; long mask_bstride;
     const float* wfc; const float* bfc;                   // final_conv weight [C], bias [1]
     const float* xcur;                                    // [B,80,T] current sampler state (x_hat)
@@ -144,7 +149,7 @@ struct LinKvCtxP { const float* X; int ldx; int x_coff; long xb; int npix; int C
                    // optional fused tail of the preceding ResnetBlock (H2 != null): x = mask*(Mish(GN(H2)) [+ res]) [+ res]
                    // is computed while the tile is loaded, written to Xout ([npix][C]) for the later consumers, and X is
                    // not read (diffusion.py:49,67-71).  gn_stats: slot-spread partials of H2; W/mask_ws: mask column map.
-                   const float* H2; const float* gn_stats; const float* gamma; const float* beta;
+                   const float* H2; const gnfix_t* gn_stats; const float* gamma; const float* beta;
                    const float* res; int ldres; long resb; int res_under_mask;
                    const float* mask; int mask_ws; long mask_bstride; int W; float* Xout;
                    int h2_bf16; };                          // H2 is bf16 [npix][C]
@@ -233,10 +238,10 @@ void launch_spk_plane(const float* spk_out, float* plane, int B, int F, hipStrea
 // per-row mean / sqrt(unbiased var + eps) over the last dim (InstanceNorm1D.cal_stats, base.py:72-78)
 void launch_row_stats(const float* X, int B, int C, int len, float eps, float* mean, float* std, long out_bstride, hipStream_t st);
 // per-(b,c) sum / sumsq over pixels (InstanceNorm2D statistics, base.py:95-103), fp64 atomics
-// statistics: [B][C][IN_SLOTS][2] fp32 partial (sum, sumsq), native L2 atomics spread over the slots; consumers add the
-// slots in fp64 (the first version used fp64 LDS + global atomics: 170 ns each on one address, 14 us per call at B=1)
+// statistics: [B][C][IN_SLOTS][2] fixed-point (mean, mean-of-squares) contributions, native L2 integer atomics spread over
+// the slots (the first version used fp64 LDS + global atomics: 170 ns each on one address, 14 us per call at B=1)
 constexpr int IN_SLOTS = GN_SLOTS;     // same layout as the GroupNorm partials: a GEMM epilogue can produce them (cpg = 1)
-struct InStatsP { const float* X; int ld; long bstride; int npix; int C; float* stats; int B;
+struct InStatsP { const float* X; int ld; long bstride; int npix; int C; gnfix_t* stats; int B;
                   const float* mask; int mask_ws; long mask_bstride; int W; };   // optional x*mask on load
 void launch_in_stats(const InStatsP& p, hipStream_t st);
 // SelfAttentionPooling for all steps (ref_encoder.py:246-253): out[step][b][C]
@@ -244,11 +249,11 @@ struct SapP { const float* t_tok; int t_ld; int t_coff; int nsteps; const float*
               const float* w; const float* bias; float* out; int B; };
 void launch_sap(const SapP& p, hipStream_t st);
 // TV: fold InstanceNorm2D into w_q:  Weff[b][k][n] = rstd[b,k]*Wq[n,k];  beff[b][n] = -sum_k mean*rstd*Wq[n,k]
-struct InFoldP { const float* stats; int npix; float eps; const float* Wq; int C; float* Weff; float* beff; int B;
+struct InFoldP { const gnfix_t* stats; int npix; float eps; const float* Wq; int C; float* Weff; float* beff; int B;
                  void* Wbf; };         // bf16 mode: write rstd[k] * Wq[n][k] as bf16 [B][n][k] (the bf16 GEMM's weight layout) instead of Weff
 void launch_in_fold(const InFoldP& p, hipStream_t st);
 // TIV: y = IN2d(x)*s + m  (ref_encoder.py:271); s,m indexed [step][b][C]
-struct TivApplyP { const float* X; int ld; long xb; float* Y; int ldy; long yb; int npix; int C; const float* stats;
+struct TivApplyP { const float* X; int ld; long xb; float* Y; int ldy; long yb; int npix; int C; const gnfix_t* stats;
                    float eps; const float* s_tab; const float* m_tab; const int* step; int B; };
 void launch_tiv_apply(const TivApplyP& p, hipStream_t st);
 // write per-step time-token rows into K/V row 0 (ref_encoder.py:157)

@@ -98,17 +98,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 ? 2
     if constexpr (PRO) {
         {   // 8 groups x GN_SLOTS partials == 256 threads
             const int g = tid / GN_SLOTS;
-            const float* src = p.gn_stats + (((long)b * 8 + g) * GN_SLOTS + (tid % GN_SLOTS)) * 2;
-            double s1 = (double)src[0], s2 = (double)src[1];
-            for (int o = 1; o < GN_SLOTS; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-            if ((tid % GN_SLOTS) == 0) {
-                const double n = (double)p.npix * (C / 8);
-                const double mean = s1 / n;
-                double var = s2 / n - mean * mean;
-                var = var < 0.0 ? 0.0 : var;
-                smean[g] = (float)mean;
-                srstd[g] = (float)(1.0 / sqrt(var + 1e-5));
-            }
+            const longlong2 sv = *reinterpret_cast<const longlong2*>(p.gn_stats + (((long)b * 8 + g) * GN_SLOTS + (tid % GN_SLOTS)) * 2);
+            long long s1 = sv.x, s2 = sv.y;
+            gn_slots_reduce<GN_SLOTS>(s1, s2);
+            if ((tid % GN_SLOTS) == 0) gn_moments(s1, s2, 1e-5, smean[g], srstd[g]);
         }
     }
     __syncthreads();

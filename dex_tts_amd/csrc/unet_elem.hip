@@ -17,21 +17,15 @@ __device__ __forceinline__ float mish_f(float x) {
 __device__ __forceinline__ float silu_f(float x) { return x * __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
 
 
-// mean / rstd of each GroupNorm group from the slot-spread fp64 partials: thread (g = tid/16, slot = tid%16)
-// loads one (sum, sumsq) pair, GN_SLOTS-lane shuffle reduce — one global round trip instead of 16 serial ones.
-__device__ __forceinline__ void gn_mean_rstd(const float* stats, int b, int groups, double n, float* smean, float* srstd, int tid) {
+// mean / rstd of each GroupNorm group from the slot-spread fixed-point partials: thread (g = tid/GN_SLOTS, slot = tid%GN_SLOTS)
+// loads one (mean, mean-of-squares) pair, GN_SLOTS-lane shuffle reduce — one global round trip instead of 32 serial ones.
+__device__ __forceinline__ void gn_mean_rstd(const gnfix_t* stats, int b, int groups, float* smean, float* srstd, int tid) {
     if (tid < groups * GN_SLOTS) {
         const int g = tid / GN_SLOTS;
-        const float* src = stats + (((long)b * groups + g) * GN_SLOTS + (tid % GN_SLOTS)) * 2;
-        double s1 = (double)src[0], s2 = (double)src[1];
-        for (int o = 1; o < GN_SLOTS; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-        if ((tid % GN_SLOTS) == 0) {
-            const double mean = s1 / n;
-            double var = s2 / n - mean * mean;
-            var = var < 0.0 ? 0.0 : var;
-            smean[g] = (float)mean;
-            srstd[g] = (float)(1.0 / sqrt(var + 1e-5));
-        }
+        const longlong2 v = *reinterpret_cast<const longlong2*>(stats + (((long)b * groups + g) * GN_SLOTS + (tid % GN_SLOTS)) * 2);
+        long long s1 = v.x, s2 = v.y;
+        gn_slots_reduce<GN_SLOTS>(s1, s2);
+        if ((tid % GN_SLOTS) == 0) gn_moments(s1, s2, 1e-5, smean[g], srstd[g]);
     }
 }
 
@@ -45,11 +39,11 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const FirstConvP p) {
     constexpr int C = 64;
     __shared__ __attribute__((aligned(16))) float w3s[PLANES * 9 * C];
     __shared__ __attribute__((aligned(16))) float w1s[PLANES * C];
-    __shared__ float red[16];
+    __shared__ long long red[16];
     const int tid = threadIdx.x;
     for (int k = tid; k < PLANES * 9 * C; k += 256) w3s[k] = p.W3[k];
     for (int k = tid; k < PLANES * C; k += 256) w1s[k] = p.W1[k];
-    if (tid < 16) red[tid] = 0.f;
+    if (tid < 16) red[tid] = 0;
     const long npix = (long)p.B * p.H * p.T;
     const long pix_raw = (long)blockIdx.x * 64 + (tid >> 2);
     const bool live = pix_raw < npix;
@@ -134,14 +128,15 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const FirstConvP p) {
 #pragma unroll
             for (int g = 0; g < 2; ++g) { gs[g] += __shfl_xor(gs[g], o); gq[g] += __shfl_xor(gq[g], o); }
         }
-        if ((tid & 63) < 4) {
+        if ((tid & 63) < 4) {          // one wave's sums (fixed shuffle order) -> fixed point; integer adds commute
+            const double inv_n = 1.0 / ((double)p.H * p.T * 8);
 #pragma unroll
-            for (int g = 0; g < 2; ++g) { atomicAdd(&red[(2 * cq + g) * 2], gs[g]); atomicAdd(&red[(2 * cq + g) * 2 + 1], gq[g]); }
+            for (int g = 0; g < 2; ++g) { gn_add(&red[(2 * cq + g) * 2], gn_fix(gs[g], inv_n)); gn_add(&red[(2 * cq + g) * 2 + 1], gn_fix(gq[g], inv_n)); }
         }
         __syncthreads();
         // a 64-pixel block never straddles two utterances when H*T is a multiple of 64 (T is)
         if (tid < 16)
-            atomicAdd(p.gn_stats + (((long)b * 8 + (tid >> 1)) * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * 2 + (tid & 1), red[tid]);
+            gn_add(p.gn_stats + (((long)b * 8 + (tid >> 1)) * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * 2 + (tid & 1), red[tid]);
     }
 }
 void launch_first_conv(const FirstConvP& p, hipStream_t st) {
@@ -153,13 +148,13 @@ void launch_first_conv(const FirstConvP& p, hipStream_t st) {
 
 // ------------------------------------------------------------------------------------------------
 // GroupNorm statistics: grid (chunks, B); each block reduces GN_PIX pixels x C channels into
-// per-group (sum, sumsq), block-combined in LDS (fp64), then one fp64 atomic pair per group.
+// per-group fixed-point (mean, mean-of-squares) contributions, block-combined in LDS, then one atomic pair per group.
 constexpr int GN_PIX = 256;
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GnStatsP p) {
-    __shared__ double red[32][2];
+    __shared__ long long red[32][2];
     const int tid = threadIdx.x, b = blockIdx.y;
     const int C4 = p.C >> 2, cpg = p.C / p.groups;
-    if (tid < 32) { red[tid][0] = 0.0; red[tid][1] = 0.0; }
+    if (tid < 32) { red[tid][0] = 0; red[tid][1] = 0; }
     __syncthreads();
     const int cq = tid % C4, prow = tid / C4, rpp = 256 / C4;
     const int pbeg = blockIdx.x * GN_PIX;
@@ -172,12 +167,13 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnStatsP p) {
         ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
     }
     const int g = (cq * 4) / cpg;
-    atomicAdd(&red[g][0], (double)s);
-    atomicAdd(&red[g][1], (double)ss);
+    const double inv_n = 1.0 / ((double)p.npix * cpg);
+    gn_add(&red[g][0], gn_fix(s, inv_n));          // per-thread sums in a fixed order; the integer adds commute
+    gn_add(&red[g][1], gn_fix(ss, inv_n));
     __syncthreads();
     if (tid < p.groups * 2) {
         const int gg = tid >> 1, k = tid & 1;
-        atomicAdd(p.stats + (((long)b * p.groups + gg) * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * 2 + k, (float)red[gg][k]);
+        gn_add(p.stats + (((long)b * p.groups + gg) * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * 2 + k, red[gg][k]);
     }
 }
 void launch_gn_stats(const GnStatsP& p, hipStream_t st) {
@@ -190,7 +186,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnApplyP p) {
     __shared__ float smean[32], srstd[32];
     const int tid = threadIdx.x, b = blockIdx.y;
     const int C4 = p.C >> 2, cpg = p.C / p.groups;
-    gn_mean_rstd(p.stats, b, p.groups, (double)p.npix * cpg, smean, srstd, tid);
+    gn_mean_rstd(p.stats, b, p.groups, smean, srstd, tid);
     __syncthreads();
     const int step = p.step ? *p.step : 0;
     const long total = (long)p.npix * C4;
@@ -245,7 +241,7 @@ __global__ __launch_bounds__(256) void final_kernel(const FinalP p) {
     __shared__ float smean[32], srstd[32];
     const int tid = threadIdx.x, b = blockIdx.y;
     const int cpg = p.C / p.groups;
-    gn_mean_rstd(p.stats, b, p.groups, (double)p.npix * cpg, smean, srstd, tid);
+    gn_mean_rstd(p.stats, b, p.groups, smean, srstd, tid);
     __syncthreads();
     const int step = p.step ? *p.step : 0;
     const float* sc = p.scal + (long)step * p.scal_stride;

@@ -120,14 +120,12 @@ class Diffusion(nn.Module):
         if not self.rng_parity or n <= 0:
             return
         gen = torch.cuda.default_generators[like.device.index if like.device.index is not None else torch.cuda.current_device()]
-        try:
+        if n > 1 and hasattr(gen, "get_offset") and hasattr(gen, "set_offset"):
             o0 = gen.get_offset()
-            torch.randn_like(like)
-            step = gen.get_offset() - o0
-            if n > 1:
-                gen.set_offset(o0 + n * step)
-        except Exception:
-            for _ in range(n - 1):
+            torch.randn_like(like)                       # one real draw measures the per-draw offset increment
+            gen.set_offset(o0 + n * (gen.get_offset() - o0))
+        else:                                            # no offset API: draw exactly n times like the reference
+            for _ in range(n):
                 torch.randn_like(like)
 
     # ---- reference call surface ----------------------------------------------------------------

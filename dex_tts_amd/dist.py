@@ -7,10 +7,13 @@ unnatural, so anything finer than utterance granularity is "replicas only".
 Padding is not neutral in the reference (norm/softmax statistics include padded columns), so the padded
 length of every utterance is fixed BEFORE sharding: all ranks pad to the global batch maximum, which is
 exactly what a single-GPU batched run would do.
+
+A rank needs only ITS utterances plus the lengths of all of them (``take_shard`` / ``local=True``): the
+partition is a pure function of the lengths, so every rank derives the same deal without communication.
 """
 from __future__ import annotations
 
-from typing import Callable, List, Sequence, Tuple
+from typing import Callable, List, Sequence
 
 import torch
 import torch.distributed as dist
@@ -31,29 +34,71 @@ def padded_length(lengths: Sequence[int], n_stages: int = 2) -> int:
     return fix_len_compatibility(max(int(l) for l in lengths), n_stages)
 
 
+def _world_rank(group):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group), dist.get_rank(group)
+    return 1, 0
+
+
+def take_shard(t: torch.Tensor, lengths: Sequence[int], group=None) -> torch.Tensor:
+    """Rows of a full-batch tensor that belong to this rank, in shard order (what ``local=True`` expects)."""
+    world, rank = _world_rank(group)
+    idx = torch.as_tensor(partition(lengths, world)[rank], dtype=torch.long, device=t.device)
+    return t.index_select(0, idx)
+
+
+def _all_gather(out_local: torch.Tensor, world: int, group) -> torch.Tensor:
+    """[per, ...] on every rank -> [world * per, ...].  RCCL gathers device tensors directly; the gloo backend
+    (CPU tests, single-GPU smoke runs) is staged through host memory."""
+    if world == 1:
+        return out_local
+    backend = dist.get_backend(group)
+    if backend == "gloo" and out_local.is_cuda:
+        host = out_local.cpu()
+        g = torch.empty(world * host.shape[0], *host.shape[1:], dtype=host.dtype)
+        dist.all_gather_into_tensor(g, host, group=group)
+        return g.to(out_local.device)
+    g = torch.empty(world * out_local.shape[0], *out_local.shape[1:], dtype=out_local.dtype, device=out_local.device)
+    dist.all_gather_into_tensor(g, out_local.contiguous(), group=group)
+    return g
+
+
 def sample_sharded(sample_fn: Callable[[torch.Tensor, torch.Tensor, torch.Tensor], torch.Tensor],
                    mu: torch.Tensor, mask: torch.Tensor, z: torch.Tensor, lengths: Sequence[int],
-                   group=None) -> torch.Tensor:
-    """Every rank calls this with the SAME full batch (mu, mask, z: [B,80,T] / [B,1,T], T already the
-    global padded length).  Each rank samples only its shard via ``sample_fn(z, mask, mu) -> [b,80,T]``
-    and the results are all-gathered; returns the full [B,80,T] on every rank, in input order."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    rank = dist.get_rank(group) if dist.is_initialized() else 0
-    B = mu.shape[0]
+                   group=None, local: bool = False) -> torch.Tensor:
+    """Sample a batch of ``len(lengths)`` utterances over the ranks of ``group``.
+
+    ``lengths`` lists ALL utterances (identical on every rank); T of the tensors is already the global padded
+    length.  With ``local=False`` every rank passes the full batch (mu, z: [B,80,T], mask: [B,1,T]) and its rows are
+    selected here; with ``local=True`` a rank passes only its own utterances in shard order (``take_shard``).
+    Each rank runs ``sample_fn(z, mask, mu) -> [b,80,T]`` on its shard; ONE all-gather exchanges the finished mels
+    and one ``index_copy_`` puts them back in input order.  Returns the full [B,80,T] on every rank."""
+    world, rank = _world_rank(group)
+    B = len(lengths)
     shards = partition(lengths, world)
     per = max(len(s) for s in shards)
     mine = shards[rank]
-    out_local = torch.zeros(per, mu.shape[1], mu.shape[2], dtype=torch.float32, device=mu.device)
-    if mine:
-        idx = torch.as_tensor(mine, device=mu.device)
-        out_local[: len(mine)] = sample_fn(z.index_select(0, idx), mask.index_select(0, idx), mu.index_select(0, idx))
+    if not local and world > 1:
+        idx = torch.as_tensor(mine, dtype=torch.long, device=mu.device)
+        mu, mask, z = mu.index_select(0, idx), mask.index_select(0, idx), z.index_select(0, idx)
+    if mu.shape[0] != len(mine):
+        raise ValueError(f"rank {rank} holds {mu.shape[0]} utterances, its shard has {len(mine)}")
+    F, T = mu.shape[1], mu.shape[2]
+    if len(mine) == per:
+        out_local = sample_fn(z, mask, mu)
+    else:                                   # uneven deal: pad the gather slot, not the sampler batch
+        out_local = torch.zeros(per, F, T, dtype=torch.float32, device=mu.device)
+        if mine:
+            out_local[: len(mine)] = sample_fn(z, mask, mu)
     if world == 1:
-        gathered = out_local[None]
+        return out_local
+    gathered = _all_gather(out_local, world, group)                     # [world * per, F, T], slot r*per + s
+    src = [r * per + s for r, sh in enumerate(shards) for s in range(len(sh))]
+    dst = [i for sh in shards for i in sh]
+    full = torch.empty(B, F, T, dtype=torch.float32, device=mu.device)
+    dst_t = torch.as_tensor(dst, dtype=torch.long, device=mu.device)
+    if len(src) == world * per:
+        full.index_copy_(0, dst_t, gathered)
     else:
-        gathered = torch.empty(world, *out_local.shape, dtype=out_local.dtype, device=out_local.device)
-        dist.all_gather_into_tensor(gathered.view(-1, *out_local.shape[1:]), out_local, group=group)
-    full = torch.empty(B, mu.shape[1], mu.shape[2], dtype=torch.float32, device=mu.device)
-    for r, s in enumerate(shards):
-        for slot, i in enumerate(s):
-            full[i] = gathered[r, slot]
+        full.index_copy_(0, dst_t, gathered.index_select(0, torch.as_tensor(src, dtype=torch.long, device=mu.device)))
     return full

@@ -49,6 +49,8 @@ class ScoreNetEngine:
         self._ws: Optional[torch.Tensor] = None
         self._keep: list = []
         self._side = None
+        self._stage: dict = {}
+        self._stage_out: dict = {}
         self.loaded_version = None
 
     # ---------------------------------------------------------------------------------------
@@ -74,6 +76,11 @@ class ScoreNetEngine:
     def load_weights(self, weights: Dict[str, torch.Tensor]):
         """weights: state-dict entries relative to ``denoise_fn.`` in the reference layout."""
         with torch.cuda.device(self.device):
+            # every copy is enqueued on torch's CURRENT stream, i.e. behind the .to()/.contiguous() kernels that may have
+            # produced the staging tensor on it; dex_ctx_finalize packs on the same stream and waits for it on the host,
+            # so the packed weights are complete for sampler calls on any stream afterwards
+            st = self._stream()
+            staged = []
             for key, shape in self.shapes.items():
                 if key not in weights:
                     raise KeyError(f"missing weight {key}")
@@ -81,9 +88,10 @@ class ScoreNetEngine:
                 if tuple(w.shape) != tuple(shape):
                     raise ValueError(f"{key}: shape {tuple(w.shape)} != {tuple(shape)}")
                 shp = (C.c_int64 * 4)(*([int(s) for s in shape] + [0] * (4 - len(shape))))
-                self._check(self.lib.dex_ctx_load_weight(self.h, key.encode(), C.c_void_p(w.data_ptr()), shp, len(shape)))
-            torch.cuda.synchronize(self.device)
-            self._check(self.lib.dex_ctx_finalize(self.h, self._stream()))
+                self._check(self.lib.dex_ctx_load_weight_async(self.h, key.encode(), C.c_void_p(w.data_ptr()), shp, len(shape), st))
+                staged.append(w)                  # alive until the stream has consumed them
+            self._check(self.lib.dex_ctx_finalize(self.h, st))
+            del staged
 
     def workspace(self, B, T, Tr, Ts, n_steps) -> torch.Tensor:
         need = int(self.lib.dex_workspace_bytes(self.h, B, T, Tr, Ts, n_steps))
@@ -115,9 +123,19 @@ class ScoreNetEngine:
             ref = [r.to(device=self.device, dtype=torch.float32).contiguous() for r in ref]
             sty = sty.to(device=self.device, dtype=torch.float32).contiguous()
             sl = sty_lengths.to(device=self.device, dtype=torch.int32).contiguous()
-            if any(r.shape[0] != B for r in ref) or sty.shape[0] != B or sl.shape[0] != B:
-                raise ValueError("DEX style tensors must have the batch size of mu")
+            if not 1 <= len(ref) <= 7:
+                raise ValueError(f"DEX needs 1..7 reference skips, got {len(ref)}")
+            mid = self.cfg.mid_dim
             Tr, Ts = ref[0].shape[-1], sty.shape[-1]
+            for j, r in enumerate(ref):           # the library reads B*mid*Tr floats per skip: shapes are checked here
+                if tuple(r.shape) != (B, mid, Tr):
+                    raise ValueError(f"ref[{j}] has shape {tuple(r.shape)}, expected {(B, mid, Tr)}")
+            if sty.dim() != 3 or sty.shape[0] != B or sty.shape[1] != mid:
+                raise ValueError(f"sty has shape {tuple(sty.shape)}, expected ({B}, {mid}, Ts)")
+            if tuple(sl.shape) != (B,):
+                raise ValueError(f"sty_lengths has shape {tuple(sl.shape)}, expected ({B},)")
+            if Tr < 2 or Ts < 1:
+                raise ValueError("DEX needs Tr >= 2 reference frames and Ts >= 1 style tokens")
             arr = (C.c_void_p * len(ref))(*[r.data_ptr() for r in ref])
             keep += ref + [sty, sl, arr]
             a.ref_skips_dev, a.n_ref, a.Tr = C.cast(arr, C.POINTER(C.c_void_p)), len(ref), Tr
@@ -134,34 +152,72 @@ class ScoreNetEngine:
         m = mask.to(device=device, dtype=torch.float32).reshape(B, T).contiguous()
         return m
 
+    def _staged(self, key, tensors):
+        """Persistent device buffers for graph replays: a captured graph dereferences fixed addresses, so the inputs of a
+        call are copied into buffers that live as long as the engine (one set per shape), which makes every call of a
+        shape a hit in the library's graph cache."""
+        bufs = self._stage.get(key)
+        if bufs is None:
+            if len(self._stage) >= 8:
+                self._stage.pop(next(iter(self._stage)))
+            bufs = [torch.empty_like(t) for t in tensors]
+            self._stage[key] = bufs
+        for b, t in zip(bufs, tensors):
+            b.copy_(t, non_blocking=True)
+        return bufs
+
     def sample(self, z, mask, mu, n_steps, spk=None, ref=None, sty=None, sty_lengths=None, use_graph=False,
                solver="euler"):
         """ablation_sampler(solver, edm, linear, none) for latent z — edm.py:109-216.  ``solver`` is 'euler' (what
-        Diffusion wires, diffusion.py:216) or 'heun' (edm.py:207-214; 2n-1 network evaluations).  Asynchronous."""
-        use_graph = use_graph and solver == "euler"
+        Diffusion wires, diffusion.py:216) or 'heun' (edm.py:207-214; 2n-1 network evaluations).  Asynchronous.
+        ``use_graph``: the whole call (conditioning tables + every network evaluation) is one cached hipGraph."""
         with torch.cuda.device(self.device):
-            mu = mu.to(device=self.device, dtype=torch.float32).contiguous()
-            z = z.to(device=self.device, dtype=torch.float32).contiguous()
-            B, _, T = mu.shape
-            mask = self._prep_mask(mask, B, T, self.device)
-            sig = edm_sigmas(n_steps).to(self.device)
-            out = torch.empty_like(mu)
-            a = _lib.DexSampleArgs()
-            keep = self._fill_args(a, mu, mask, sig, out, n_steps, spk, ref, sty, sty_lengths, use_graph, solver)
-            a.z_dev = z.data_ptr()
             cur = torch.cuda.current_stream(self.device)
+            run_on = cur
             if use_graph and cur.cuda_stream == 0:
                 # the legacy default stream cannot be captured: replay on a private stream, ordered
                 # after / before the caller's stream
                 if self._side is None:
                     self._side = torch.cuda.Stream(self.device)
                 self._side.wait_stream(cur)
-                with torch.cuda.stream(self._side):
-                    self._check(self.lib.dex_sample(self.h, C.byref(a), self._stream()))
-                cur.wait_stream(self._side)
-            else:
+                run_on = self._side
+            with torch.cuda.stream(run_on):
+                mu = mu.to(device=self.device, dtype=torch.float32).contiguous()
+                z = z.to(device=self.device, dtype=torch.float32).contiguous()
+                B, _, T = mu.shape
+                mask = self._prep_mask(mask, B, T, self.device)
+                sig = edm_sigmas(n_steps).to(self.device)
+                if self.cfg.variant == "dex" and ref is not None and sty is not None and sty_lengths is not None:
+                    ref = [r.to(device=self.device, dtype=torch.float32).contiguous() for r in ref]
+                    sty = sty.to(device=self.device, dtype=torch.float32).contiguous()
+                    sty_lengths = sty_lengths.to(device=self.device, dtype=torch.int32).contiguous()
+                if spk is not None and self.cfg.n_spks > 1:
+                    spk = spk.to(device=self.device, dtype=torch.float32).contiguous()
+                else:
+                    spk = None
+                if use_graph:
+                    dexin = ([sty, sty_lengths] + list(ref)) if (self.cfg.variant == "dex" and ref is not None) else []
+                    flat = [z, mu, mask, sig] + ([spk] if spk is not None else []) + dexin
+                    key = (n_steps, solver, spk is not None) + tuple((tuple(t.shape), t.dtype) for t in flat)
+                    st = self._staged(key, flat)
+                    z, mu, mask, sig = st[:4]
+                    k = 4
+                    if spk is not None:
+                        spk = st[k]; k += 1
+                    if dexin:
+                        sty, sty_lengths, ref = st[k], st[k + 1], st[k + 2:]
+                    out = self._stage_out.setdefault(key, torch.empty_like(mu))
+                else:
+                    out = torch.empty_like(mu)
+                a = _lib.DexSampleArgs()
+                keep = self._fill_args(a, mu, mask, sig, out, n_steps, spk, ref, sty, sty_lengths, use_graph, solver)
+                a.z_dev = z.data_ptr()
                 self._check(self.lib.dex_sample(self.h, C.byref(a), self._stream()))
-            self._keep = keep + [z]           # keep inputs alive until the stream work is enqueued & consumed
+                self._keep = keep + [z]           # keep inputs alive until the stream work is enqueued & consumed
+                if use_graph:
+                    out = out.clone()             # the staging output is overwritten by the next replay
+            if run_on is not cur:
+                cur.wait_stream(run_on)
             return out
 
     def denoise_once(self, x, sigma: float, mask, mu, spk=None, ref=None, sty=None, sty_lengths=None):

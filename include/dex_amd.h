@@ -76,7 +76,9 @@ typedef struct {
     float* out_dev;             /* [B,80,T] x_N (unmasked, like edm.py:216) */
     void*  workspace_dev;       /* >= dex_workspace_bytes(...) bytes, 256-B aligned */
     size_t workspace_bytes;
-    int32_t use_graph;          /* 1: replay a cached hipGraph of one Euler step (ignored by the Heun solver) */
+    int32_t use_graph;          /* 1: the whole call (conditioning tables + every network evaluation + the final copy) is captured
+                                 * once into a hipGraph, cached under (shapes, solver, precision, stream, every device pointer
+                                 * above) and replayed with ONE hipGraphLaunch; needs a non-default stream */
     int32_t solver;             /* DexSolver; 0 = Euler, what Diffusion wires (diffusion.py:216) */
 } DexSampleArgs;
 
@@ -94,10 +96,19 @@ const char* dex_version(void);
 /* Number of state-dict tensors the context expects, and the i-th key (relative to "denoise_fn.") + shape. */
 int  dex_ctx_num_weights(const DexCtx* ctx);
 int  dex_ctx_weight_info(const DexCtx* ctx, int i, const char** key, int64_t shape[4], int* ndim);
-/* Hand over one tensor in the REFERENCE layout (fp32, contiguous, device memory). The pointer must stay
- * valid until dex_ctx_finalize returns. */
+/* Hand over one tensor in the REFERENCE layout (fp32, contiguous, device memory).  The library copies it into its own
+ * HBM before returning control of the pointer:
+ *   dex_ctx_load_weight        synchronous — the copy runs on the legacy null stream and has completed on return; the
+ *                              caller must have completed whatever produced w_dev (it is NOT ordered against
+ *                              non-blocking streams);
+ *   dex_ctx_load_weight_async  the copy is enqueued on `stream`, i.e. ordered after the kernels that produced w_dev on
+ *                              that stream; w_dev must stay valid until the stream reaches the copy (dex_ctx_finalize on
+ *                              the same stream synchronises it). */
 int  dex_ctx_load_weight(DexCtx* ctx, const char* key, const float* w_dev, const int64_t* shape, int ndim);
-/* Pack all weights into kernel layouts (library-owned HBM); synchronises the stream once. */
+int  dex_ctx_load_weight_async(DexCtx* ctx, const char* key, const float* w_dev, const int64_t* shape, int ndim,
+                               dex_stream_t stream);
+/* Pack all weights into kernel layouts (library-owned HBM) on `stream` and wait for it on the host before returning:
+ * after dex_ctx_finalize the packed weights are complete for work on ANY stream. */
 int  dex_ctx_finalize(DexCtx* ctx, dex_stream_t stream);
 int  dex_ctx_set_precision(DexCtx* ctx, int precision /* DexPrecision */);
 
