@@ -7,14 +7,20 @@ sampler) on MI355X.
         bench.py --gpus N --steps K --warmup W
 
 A "step" is ONE full sampler call (n_timesteps Euler steps) over one batch of synthetic utterances.
-Default workload = BASELINE.json configs[1]: GeDEX-LJ, B=1, T=512 mel frames, n_timesteps=50.
-For N>1 every rank samples its own shard of independent utterances (weak scaling, no data-path collective)
-and the finished mels are all-gathered over RCCL inside the timed region (the path's one exchange step).
-Prints ONE JSON line on rank 0.
+Default workload = BASELINE.json configs[1]: GeDEX-LJ, B=1, T=512 mel frames, n_timesteps=50, bf16.
+For N>1 the batch is B utterances PER GPU (weak scaling): every rank holds only its shard, samples it with the product
+sharder (dex_tts_amd.dist.sample_sharded) and the finished mels are all-gathered over RCCL inside the timed region
+(the path's one exchange step).  Prints ONE JSON line on rank 0.
+
+The default N=1 run also carries, in the same line: `roofline` for the dominant kernel SYMBOL of the workload (HIP
+events on the launch stream; HBM traffic from the committed PMC summary), `roofline_attention` (the DiT attention
+kernel on its own), `fp32_mode`, `roofline_batch32`, driver-timed blocks for BASELINE.json configs[2], [3] (per-GPU
+share) and [4] under `configs`, and `cpu_baseline` (the CPU oracle on the host cores, bounded sample).
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -30,30 +36,43 @@ sys.path.insert(0, ROOT)
 from dex_tts_amd import config as C, synth  # noqa: E402
 
 WORKLOADS = {
-    # name: (preset, B, T, n_timesteps, Tr/Ts)
-    "gedex_b1": ("gedex_lj", 1, 512, 50, 0),
-    "gedex_b1_t800": ("gedex_lj", 1, 800, 50, 0),
-    "gedex_b32": ("gedex_lj", 32, 512, 50, 0),
-    "dex_b1": ("dex_vctk", 1, 512, 50, 348),
-    "dex_b32": ("dex_vctk", 32, 256, 50, 348),
-    "gedex_long": ("gedex_lj", 1, 4000, 50, 0),
-    "dex_esd_b32_n100": ("dex_esd", 32, 256, 100, 348),     # per-GPU share of BASELINE.json configs[3] (256 utterances / 8 GPUs)
+    # name: (preset, B per GPU, T, n_timesteps, Tr/Ts, precision or None = --precision)
+    "gedex_b1": ("gedex_lj", 1, 512, 50, 0, None),               # BASELINE.json configs[1]
+    "gedex_b1_t800": ("gedex_lj", 1, 800, 50, 0, None),
+    "gedex_b32": ("gedex_lj", 32, 512, 50, 0, None),
+    "dex_b1": ("dex_vctk", 1, 512, 50, 348, None),
+    "dex_b32": ("dex_vctk", 32, 256, 50, 348, None),             # configs[2]
+    "dex_esd_b32_n100": ("dex_esd", 32, 256, 100, 348, None),    # per-GPU share of configs[3] (256 utterances / 8 GPUs)
+    "gedex_long": ("gedex_lj", 1, 4000, 50, 0, None),            # configs[4] shape
 }
-PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+CONFIG_TAG = {"gedex_b1": "BASELINE.json configs[1]", "dex_b32": "BASELINE.json configs[2]",
+              "dex_esd_b32_n100": "BASELINE.json configs[3], per-GPU share (256 utterances / 8 GPUs)",
+              "gedex_long": "BASELINE.json configs[4] shape"}
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+DTYPE_KEY = {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}
+# library profile row -> rocprofv3 kernel symbol (rows of the conv kernels already carry their symbol)
+SYMBOL_OF = {"dit_block": "dit_rowchain_kernel<true>", "dit_qkv": "dit_rowchain_kernel<false>", "dit_rowchain": "dit_rowchain_kernel<false>",
+             "dit_attention": "attn_direct", "linattn_kvctx": "linattn_kvctx_kernel", "linattn_out": "linattn_out2",
+             "linattn_merge": "linattn_merge_kernel", "first_conv": "first_conv_kernel", "final_conv_euler": "final_kernel",
+             "pos_conv": "pos_conv_direct_kernel", "upsample_convT": "igemm_bf16_ss_kernel", "downsample": "igemm_bf16_kernel",
+             "dit_final_unpatchify": "igemm_bf16_ss_kernel", "tv_attention": "attn_bf16", "patch_dwconv_silu": "dwconv_silu_kernel"}
 
 
-def make_inputs(cfg, B, T, TrTs, device, rank):
-    lengths = None if B == 1 else [int(T * (0.6 + 0.4 * ((7 * i + 3 * rank) % 11) / 10.0)) for i in range(B)]
-    mu, mask, z, _ = synth.make_inputs(B, T, lengths, seed=1234 + rank)
+def lengths_for(B, T, salt=0):
+    return [T] * B if B == 1 else [int(T * (0.6 + 0.4 * ((7 * i + 3 * salt) % 11) / 10.0)) for i in range(B)]
+
+
+def make_inputs(cfg, lengths, T, TrTs, device, seed):
+    B = len(lengths)
+    mu, mask, z, _ = synth.make_inputs(B, T, list(lengths), seed=seed)
     kw = {}
     if cfg.variant == "dex":
         ref, rl, sty, sl = synth.make_dex_style(B, TrTs, TrTs, cfg.mid_dim)
         kw = dict(ref=[torch.from_numpy(r).to(device) for r in ref], sty=torch.from_numpy(sty).to(device),
                   sty_lengths=torch.from_numpy(sl).to(device))
     t = lambda a: torch.from_numpy(a).to(device)
-    valid = int(mask.sum())
-    return t(mu), t(mask), t(z), kw, valid
+    return t(mu), t(mask), t(z), kw
 
 
 def cpu_baseline(cfg, weights, B, T, n_timesteps, TrTs):
@@ -89,15 +108,36 @@ def cpu_baseline(cfg, weights, B, T, n_timesteps, TrTs):
                       f"{per_step * 1e3:.1f} ms/Euler-step on {torch.get_num_threads()} threads"}
 
 
-def roof(r, dtype_key):
-    """Roofline entry of one kernel class from its event-timed profile row.  The binding roof is the one that takes
+_PMC = None
+
+
+def pmc_traffic(workload, row_name):
+    """HBM bytes per launch of one kernel symbol from the committed PMC summary (profiles/pmc_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, FETCH doubled as MI355X_MICROARCH.md §HBM says)."""
+    global _PMC
+    if _PMC is None:
+        path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        _PMC = json.load(open(path)) if os.path.exists(path) else {}
+    table = _PMC.get(workload, {})
+    sym = SYMBOL_OF.get(row_name, row_name)
+    for k, v in table.items():
+        if sym in k:
+            return v
+    return None
+
+
+def roof(r, dtype_key, workload=None, force_mfma=False):
+    """Roofline entry of one kernel symbol from its event-timed profile row.  The binding roof is the one that takes
     longer for the kernel's ALGORITHMIC work: flops / MFMA peak  vs  bytes / HBM peak."""
     sec = r["ms"] * 1e-3
     t_mfma = r["flops"] / (PEAK_TFLOPS[dtype_key] * 1e12)
     t_hbm = r["bytes"] / (PEAK_HBM_GBS * 1e9)
-    ent = {"kernel": r["name"], "avg_launch_us": round(r["ms"] / r["calls"] * 1e3, 2),
+    ent = {"kernel": SYMBOL_OF.get(r["name"], r["name"]), "profile_row": r["name"], "launches": r["calls"],
+           "avg_launch_us": round(r["ms"] / r["calls"] * 1e3, 2),
+           "algorithmic_GFLOP_per_launch": round(r["flops"] / r["calls"] / 1e9, 4),
+           "algorithmic_MB_per_launch": round(r["bytes"] / r["calls"] / 1e6, 4),
            "mfma_TFLOP/s": round(r["flops"] / sec / 1e12, 2), "hbm_GB/s": round(r["bytes"] / sec / 1e9, 1), "traffic": None}
-    if t_mfma >= t_hbm or r["name"] == "dit_attention":       # SURVEY 8(d)(i): the DiT attention is judged against the MFMA peak
+    if t_mfma >= t_hbm or force_mfma:
         ach = r["flops"] / sec / 1e12
         ent.update({"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dtype_key], "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_TFLOPS[dtype_key], 4)})
@@ -105,6 +145,109 @@ def roof(r, dtype_key):
         ach = r["bytes"] / sec / 1e9
         ent.update({"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(ach / PEAK_HBM_GBS, 4)})
+    if workload:
+        t = pmc_traffic(workload, r["name"])
+        if t:
+            ent["traffic"] = t.get("hbm_bytes_per_launch")
+            ent["traffic_source"] = t.get("source")
+    return ent
+
+
+def timed_calls(call, steps, warmup, device, dist=None):
+    """W untimed calls, then EXACTLY K calls between barrier + synchronize on both sides.  Returns (wall seconds,
+    per-call HIP-event milliseconds measured on the launch stream)."""
+    for _ in range(warmup):
+        call()
+    torch.cuda.synchronize(device)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    out = None
+    for a, b in evs:
+        a.record()
+        out = call()
+        b.record()
+    torch.cuda.synchronize(device)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    return dt, [a.elapsed_time(b) for a, b in evs], out
+
+
+def profile_rows(eng, call, device):
+    eng.profile(True)
+    call()
+    torch.cuda.synchronize(device)
+    rows = sorted(eng.profile_rows(), key=lambda r: -r["ms"])
+    eng.profile(False)
+    return rows
+
+
+def attention_row(eng, call, device, rows):
+    att = [r for r in rows if r["name"] == "dit_attention"]
+    if att:
+        return att[0]
+    # reduced-precision modes run the attention core inside the fused DiT-block launch; one extra profiling pass with
+    # the separate attention kernel (same wave body, attention_direct.hip) times it on its own
+    os.environ["DEX_ATTN_SEPARATE"] = "1"
+    try:
+        att = [r for r in profile_rows(eng, call, device) if r["name"] == "dit_attention"]
+    finally:
+        del os.environ["DEX_ATTN_SEPARATE"]
+    return att[0] if att else None
+
+
+def pick_graph(eng_call, device, mode):
+    """--graph auto: two calls each way, keep the faster (reported in config.hipgraph)."""
+    if mode != "auto":
+        return mode == "on"
+    best = {}
+    for g in (False, True):
+        eng_call(g); eng_call(g)
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            eng_call(g)
+        torch.cuda.synchronize(device)
+        best[g] = time.perf_counter() - t0
+    return best[True] < best[False]
+
+
+def side_workload(name, precision, device, stream, graph_mode, steps=3, warmup=1):
+    """Driver-timed block for another BASELINE.json config on this GPU (same timing discipline, fewer calls)."""
+    from dex_tts_amd.engine import ScoreNetEngine
+    preset, B, T, n_steps, TrTs, prec_o = WORKLOADS[name]
+    prec = prec_o or precision
+    cfg = C.PRESETS[preset]()
+    eng = ScoreNetEngine(cfg, device)
+    eng.load_weights({k: torch.from_numpy(v) for k, v in synth.make_weights(C.param_shapes(cfg)).items()})
+    eng.set_precision(prec)
+    lengths = lengths_for(B, T)
+    mu, mask, z, kw = make_inputs(cfg, lengths, T, TrTs, device, 1234)
+    with torch.cuda.stream(stream):
+        g = pick_graph(lambda gg: eng.sample(z, mask, mu, n_steps, use_graph=gg, **kw), device, graph_mode)
+        call = lambda: eng.sample(z, mask, mu, n_steps, use_graph=g, **kw)
+        dt, ev, out = timed_calls(call, steps, warmup, device)
+        assert torch.isfinite(out).all()
+        rows = profile_rows(eng, lambda: eng.sample(z, mask, mu, n_steps, use_graph=False, **kw), device)
+        att = attention_row(eng, lambda: eng.sample(z, mask, mu, n_steps, use_graph=False, **kw), device, rows)
+    valid = sum(lengths)
+    key = DTYPE_KEY[prec]
+    ent = {"workload": f"{name}: {preset} B={B} T={T} n_timesteps={n_steps}" + (f" Tr=Ts={TrTs}" if TrTs else "") + f" ({CONFIG_TAG.get(name, '')})",
+           "value": round(valid * steps / dt, 1), "unit": "mel-frames/s", "dtype": key, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(dt / steps * 1e3, 3), "hip_event_median_ms": round(statistics.median(ev), 3),
+           "ms_per_euler_step": round(dt / steps * 1e3 / n_steps, 4), "hipgraph": g,
+           "rtf": round((dt / steps) / (valid * 256 / 22050.0), 6),
+           "roofline": roof(rows[0], key, name)}
+    if att:
+        ent["roofline_attention"] = roof(att, key, name, force_mfma=True)
+    ent["kernels"] = [{"kernel": r["name"], "calls": r["calls"], "avg_us": round(r["ms"] / r["calls"] * 1e3, 2),
+                       "share": round(r["ms"] / sum(q["ms"] for q in rows), 3)} for r in rows[:6]]
+    del eng
+    torch.cuda.empty_cache()
     return ent
 
 
@@ -114,10 +257,12 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="gedex_b1", choices=sorted(WORKLOADS))
-    ap.add_argument("--precision", default="bf16", choices=["fp32", "bf16"])
-    ap.add_argument("--graph", action="store_true", help="replay one captured hipGraph per Euler step")
+    ap.add_argument("--precision", default="bf16", choices=sorted(__import__("dex_tts_amd._lib", fromlist=["x"]).PRECISION))
+    ap.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                    help="whole-sampler hipGraph replay: auto = measure both at start-up and keep the faster")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the configs[2]/[3]/[4] blocks of the default run")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N>1 (nccl == RCCL over xGMI; gloo only for single-GPU smoke tests)")
     ap.add_argument("--all-on-device0", action="store_true",
@@ -127,9 +272,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback in the product path)"
     if args.all_on_device0:
         local_rank = 0
@@ -142,54 +286,39 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group("gloo")
-
-    preset, B, T, n_steps, TrTs = WORKLOADS[args.workload]
-    cfg = C.PRESETS[preset]()
+    from dex_tts_amd import dist as D
     from dex_tts_amd.engine import ScoreNetEngine
+
+    preset, B, T, n_steps, TrTs, prec_o = WORKLOADS[args.workload]
+    precision = prec_o or args.precision
+    cfg = C.PRESETS[preset]()
     weights = synth.make_weights(C.param_shapes(cfg))
     eng = ScoreNetEngine(cfg, device)
     eng.load_weights({k: torch.from_numpy(v) for k, v in weights.items()})
-    eng.set_precision(args.precision)
-    mu, mask, z, kw, valid = make_inputs(cfg, B, T, TrTs, device, rank)
-    use_graph = args.graph
+    eng.set_precision(precision)
+    # the job: B utterances per GPU.  Every rank derives the same global length list and deal; it materialises ONLY the
+    # utterances of its own shard (dist.partition is a pure function of the lengths)
+    lengths = [l for r in range(world) for l in lengths_for(B, T, r)] if world > 1 else lengths_for(B, T)
+    mine = D.partition(lengths, world)[rank]
+    mu, mask, z, kw = make_inputs(cfg, [lengths[i] for i in mine], T, TrTs, device, 1234 + rank)
     stream = torch.cuda.Stream(device)
-    gdev = device if args.backend == "nccl" else torch.device("cpu")
-    gathered = torch.empty(world * B, 80, T, device=gdev) if world > 1 else None
-
-    def one_call():
-        out = eng.sample(z, mask, mu, n_steps, use_graph=use_graph, **kw)
-        if world > 1:       # the path's one exchange step: finished mels of every shard
-            dist.all_gather_into_tensor(gathered, out if args.backend == "nccl" else out.cpu())
-        return out
-
     with torch.cuda.stream(stream):
-        for _ in range(args.warmup):
-            one_call()
-        torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = one_call()
-        torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(device)
-        dt = time.perf_counter() - t0
+        use_graph = pick_graph(lambda g: eng.sample(z, mask, mu, n_steps, use_graph=g, **kw), device, args.graph)
+        sample_fn = lambda zz, mm, uu: eng.sample(zz, mm, uu, n_steps, use_graph=use_graph, **kw)
+        # N == 1: sample_sharded degenerates to one sampler call; N > 1: shard sampler + the ONE all-gather + index_copy_
+        one_call = lambda: D.sample_sharded(sample_fn, mu, mask, z, lengths, local=True)
+        dt, ev_ms, out = timed_calls(one_call, args.steps, args.warmup, device, dist)
+    gdev = device if (world == 1 or args.backend == "nccl") else torch.device("cpu")
     if world > 1:
         t = torch.tensor([dt], device=gdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        v = torch.tensor([float(valid)], device=gdev, dtype=torch.float64)
-        dist.all_reduce(v)
-        valid_total = int(v.item())
-    else:
-        valid_total = valid
+        assert out.shape[0] == len(lengths)
+    valid_total = sum(lengths)
     assert torch.isfinite(out).all()
 
     if rank == 0:
-        dtype = "f32" if args.precision == "fp32" else "bf16"
+        dtype = DTYPE_KEY[precision]
         ms_per_step = dt / args.steps * 1e3
         frames_s = valid_total * args.steps / dt
         audio_s = valid_total * 256 / 22050.0
@@ -199,108 +328,84 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic (portable random weights with zero-inits overridden; mel-like mu; mask from lengths)",
             "config": {"workload": f"{args.workload}: {preset} B={B}/GPU T={T} n_timesteps={n_steps}"
-                                   + (f" Tr=Ts={TrTs}" if TrTs else "") + " (BASELINE.json configs[1])" * (args.workload == "gedex_b1"),
+                                   + (f" Tr=Ts={TrTs}" if TrTs else "") + (f" ({CONFIG_TAG[args.workload]})" if args.workload in CONFIG_TAG else ""),
                        "global_batch": B * world, "frames": T, "n_timesteps": n_steps, "hipgraph": use_graph,
-                       "parallelism": f"{world} independent replicas, utterance-sharded; RCCL all-gather of finished mels"},
+                       "parallelism": f"{world} replica(s), utterances dealt by dex_tts_amd.dist.partition, each rank holds its shard only; "
+                                      "one RCCL all-gather of the finished mels per call" if world > 1 else "1 GPU"},
             "rtf": round((dt / args.steps) / audio_s, 6),
             "ms_per_euler_step": round(ms_per_step / n_steps, 4),
+            "hip_event_median_ms": round(statistics.median(ev_ms), 3),
+            "hip_event_min_ms": round(min(ev_ms), 3),
         }
-        if world == 1 and not args.no_profile:
-            # per-kernel HIP-event timing on the launch stream (eager launches, same work)
-            eng.profile(True)
+        prof = world == 1 and not args.no_profile
+        call_eager = lambda: eng.sample(z, mask, mu, n_steps, use_graph=False, **kw)
+        if prof:
             with torch.cuda.stream(stream):
-                eng.sample(z, mask, mu, n_steps, use_graph=False, **kw)
-                torch.cuda.synchronize(device)
-            rows = sorted(eng.profile_rows(), key=lambda r: -r["ms"])
-            eng.profile(False)
-            tot = sum(r["ms"] for r in rows)
-            kern = []
-            for r in rows[:int(os.environ.get("DEX_BENCH_TOPK", "8"))]:
-                tf = r["flops"] / (r["ms"] * 1e-3) / 1e12
-                gb = r["bytes"] / (r["ms"] * 1e-3) / 1e9
-                kern.append({"kernel": r["name"], "calls": r["calls"], "avg_us": round(r["ms"] / r["calls"] * 1e3, 2),
-                             "share": round(r["ms"] / tot, 3), "TFLOP/s": round(tf, 2), "GB/s": round(gb, 1)})
-            res["roofline"] = roof(rows[0], dtype)
-            res["roofline"]["launches"] = rows[0]["calls"]
-            att = [r for r in rows if r["name"] == "dit_attention"]
-            if not att and args.precision == "bf16":
-                # bf16 mode runs the attention core inside the fused DiT-block launch ("dit_block"); one extra profiling
-                # pass with the separate attention kernel (same wave body, attention_direct.hip) times it on its own
-                os.environ["DEX_ATTN_SEPARATE"] = "1"
-                eng.profile(True)
-                with torch.cuda.stream(stream):
-                    eng.sample(z, mask, mu, n_steps, use_graph=False, **kw)
-                    torch.cuda.synchronize(device)
-                att = [r for r in eng.profile_rows() if r["name"] == "dit_attention"]
-                eng.profile(False)
-                del os.environ["DEX_ATTN_SEPARATE"]
+                # per-kernel HIP-event timing on the launch stream (eager launches, same work)
+                rows = profile_rows(eng, call_eager, device)
+                tot = sum(r["ms"] for r in rows)
+                res["roofline"] = roof(rows[0], dtype, args.workload)          # dominant SYMBOL by time
+                att = attention_row(eng, call_eager, device, rows)
             if att:
-                res["roofline_attention"] = roof(att[0], dtype)
+                res["roofline_attention"] = roof(att, dtype, args.workload, force_mfma=True)   # judged against the MFMA peak
                 res["roofline_attention"]["note"] = "timed as a separate launch; the default path fuses it into dit_block"
-            res["kernels"] = kern
+            res["kernels"] = [{"kernel": r["name"], "calls": r["calls"], "avg_us": round(r["ms"] / r["calls"] * 1e3, 2),
+                               "share": round(r["ms"] / tot, 3), "TFLOP/s": round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2),
+                               "GB/s": round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)} for r in rows[:int(os.environ.get("DEX_BENCH_TOPK", "8"))]]
             res["eager_event_total_ms"] = round(tot, 2)
-        if world == 1 and not args.no_profile and args.precision == "bf16":
+        if prof and precision != "fp32":
             # companion number in the exact-fp32 MFMA mode (parity mode of the tests)
             eng.set_precision("fp32")
             with torch.cuda.stream(stream):
-                eng.sample(z, mask, mu, n_steps, **kw)
-                torch.cuda.synchronize(device)
-                t0 = time.perf_counter()
-                for _ in range(2):
-                    eng.sample(z, mask, mu, n_steps, **kw)
-                torch.cuda.synchronize(device)
-                dt32 = (time.perf_counter() - t0) / 2
-            eng.profile(True)
-            with torch.cuda.stream(stream):
-                eng.sample(z, mask, mu, n_steps, **kw)
-                torch.cuda.synchronize(device)
-            r32 = sorted(eng.profile_rows(), key=lambda r: -r["ms"])
-            eng.profile(False)
-            eng.set_precision("bf16")
-            res["fp32_mode"] = {"value": round(valid * 1.0 / dt32, 1), "unit": "mel-frames/s", "ms_per_step": round(dt32 * 1e3, 3),
+                dt32, ev32, _ = timed_calls(call_eager, 2, 1, device)
+                r32 = profile_rows(eng, call_eager, device)
+            eng.set_precision(precision)
+            res["fp32_mode"] = {"value": round(valid_total * 2 / dt32, 1), "unit": "mel-frames/s", "ms_per_step": round(dt32 / 2 * 1e3, 3),
                                 "roofline": roof(r32[0], "f32")}
-        if world == 1 and not args.no_profile and args.workload == "gedex_b1":
-            # The B=1 headline workload is launch/latency-bound (~47 dependent launches of a few us per Euler step), so
-            # its roofline fractions say little about the kernels.  Same kernels in the bandwidth/MFMA regime:
-            # one B=32 sampler call per precision, event-timed per kernel class.
-            p32, B32, T32, n32, _ = WORKLOADS["gedex_b32"]
-            mu2, mask2, z2, kw2, valid2 = make_inputs(cfg, B32, T32, 0, device, 0)
+        if prof and args.workload == "gedex_b1":
+            # The B=1 headline workload is latency-bound (35 dependent launches of ~12 us per Euler step), so its roofline
+            # fractions say little about the kernels.  Same kernels in the bandwidth/MFMA regime: one B=32 sampler call per
+            # precision, event-timed per kernel symbol.
+            p32, B32, T32, n32, _, _ = WORKLOADS["gedex_b32"]
+            l32 = lengths_for(B32, T32)
+            mu2, mask2, z2, kw2 = make_inputs(cfg, l32, T32, 0, device, 1234)
             scale = {}
-            for prec, key in (("bf16", "bf16"), ("fp32", "f32")):
+            for prec in ([precision, "fp32"] if precision != "fp32" else ["fp32"]):
+                key = DTYPE_KEY[prec]
                 eng.set_precision(prec)
                 with torch.cuda.stream(stream):
-                    eng.sample(z2, mask2, mu2, n32, **kw2)      # full warm-up call (plan, conditioning tables, clocks)
-                    torch.cuda.synchronize(device)
-                    t0 = time.perf_counter()
-                    eng.sample(z2, mask2, mu2, n32, **kw2)
-                    torch.cuda.synchronize(device)
-                    dtb = time.perf_counter() - t0
-                    eng.profile(True)
-                    eng.sample(z2, mask2, mu2, 4, **kw2)
-                    torch.cuda.synchronize(device)
-                rb = {r["name"]: r for r in eng.profile_rows()}
-                eng.profile(False)
-                if "dit_attention" not in rb:
-                    os.environ["DEX_ATTN_SEPARATE"] = "1"
-                    eng.profile(True)
-                    with torch.cuda.stream(stream):
-                        eng.sample(z2, mask2, mu2, 4, **kw2)
-                        torch.cuda.synchronize(device)
-                    rb.update({r["name"]: r for r in eng.profile_rows() if r["name"] == "dit_attention"})
-                    eng.profile(False)
-                    del os.environ["DEX_ATTN_SEPARATE"]
-                ent = {"value": round(valid2 / dtb, 1), "unit": "mel-frames/s", "workload": f"gedex_lj B={B32} T={T32} n_timesteps={n32}"}
-                for kname in ("conv3x3", "dit_attention", "dit_block", "pos_conv"):
-                    if kname in rb:
-                        ent[kname] = roof(rb[kname], key)
+                    c2 = lambda: eng.sample(z2, mask2, mu2, n32, **kw2)
+                    dtb, evb, _ = timed_calls(c2, 1, 1, device)
+                    c4 = lambda: eng.sample(z2, mask2, mu2, 4, **kw2)
+                    rb = profile_rows(eng, c4, device)
+                    attb = attention_row(eng, c4, device, rb)
+                ent = {"value": round(sum(l32) / dtb, 1), "unit": "mel-frames/s", "workload": f"gedex_lj B={B32} T={T32} n_timesteps={n32}",
+                       "dominant": roof(rb[0], key, "gedex_b32")}
+                if attb:
+                    ent["dit_attention"] = roof(attb, key, "gedex_b32", force_mfma=True)
+                for r in rb:
+                    if r["name"] in ("dit_block", "pos_conv"):
+                        ent[r["name"]] = roof(r, key, "gedex_b32")
+                ent["convs"] = [roof(r, key, "gedex_b32") for r in rb if r["name"].startswith("conv3x3")][:4]
                 scale[prec] = ent
-            eng.set_precision(args.precision)
+            eng.set_precision(precision)
             res["roofline_batch32"] = scale
+            del mu2, mask2, z2
+        if prof and args.workload == "gedex_b1" and not args.no_configs:
+            del eng
+            torch.cuda.empty_cache()
+            from dex_tts_amd import _lib
+            res["configs"] = {
+                "configs[2]": side_workload("dex_b32", precision, device, stream, args.graph),
+                "configs[3]": side_workload("dex_esd_b32_n100", precision, device, stream, args.graph, steps=2),
+                "configs[4]": side_workload("gedex_long", "fp16" if "fp16" in _lib.PRECISION else precision, device, stream, "on"),
+            }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, weights, B, T, n_steps, TrTs)
             res["gpu_over_cpu"] = round(frames_s / res["cpu_baseline"]["value"], 1)
         print(json.dumps(res), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -22,8 +22,21 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
          "-Wno-unused-result", "-Wno-unused-variable", "-Wno-unused-value"]
 
 
+# the MFMA-heavy kernel files of the reduced-precision modes are compiled twice: operands bf16 (namespace dex::bf16) and,
+# with -DDEX_LP_F16, fp16 (namespace dex::f16) — csrc/lp_config.h
+LP_SOURCES = ("conv3x3_bf16.hip", "conv3x3_stream.hip", "igemm_bf16.hip", "attention_bf16.hip", "attention_direct.hip",
+              "dit_rowchain.hip", "linattn_fused.hip", "pos_conv.hip")
+
+
 def sources():
-    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    """(source file, extra flags, object suffix) per compilation."""
+    out = []
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith(".hip"):
+            out.append((f, [], ""))
+            if f in LP_SOURCES:
+                out.append((f, ["-DDEX_LP_F16"], ".f16"))
+    return out
 
 
 def _stale(target, deps):
@@ -33,15 +46,16 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def _compile(src, force):
-    obj = os.path.join(OBJ, src[:-4] + ".o")
+def _compile(job, force):
+    src, extra, suffix = job
+    obj = os.path.join(OBJ, src[:-4] + suffix + ".o")
     deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     deps.append(os.path.join(HERE, "..", "include", "dex_amd.h"))
     if force or _stale(obj, deps):
-        cmd = [HIPCC, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [HIPCC, *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
-            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+            raise RuntimeError(f"hipcc failed for {src} {extra}:\n{r.stdout}\n{r.stderr}")
         if r.stderr.strip():
             sys.stderr.write(r.stderr)
     return obj
@@ -51,7 +65,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     srcs = sources()
-    with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+    with cf.ThreadPoolExecutor(max_workers=min(12, len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(s, force), srcs))
     if force or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]

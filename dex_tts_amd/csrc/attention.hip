@@ -224,7 +224,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QREG ? 
     }
 }
 
-void launch_attention_bf16(const AttnP& p, hipStream_t st);   // attention_bf16.hip
+void launch_attention_lp(const AttnP& p, int precision, hipStream_t st);   // lp_dispatch.hip -> attention_bf16.hip (bf16 / fp16 build)
 
 template <int NW, bool QREG>
 static void launch_attn_nw(const AttnP& p, hipStream_t st) {
@@ -239,7 +239,7 @@ static void launch_attn_nw(const AttnP& p, hipStream_t st) {
 }
 
 void launch_attention(const AttnP& p, int precision, hipStream_t st) {
-    if (precision == 1) { launch_attention_bf16(p, st); return; }
+    if (prec_is_lp(precision)) { launch_attention_lp(p, precision, st); return; }
     const long blocks = (long)((p.Nq + 31) / 32) * p.heads * p.B;
     const int ntiles = (p.Nk + 31) / 32;
     // Many query tiles (batch): 4 key-splitting waves with Q in registers, two workgroups per CU (2 waves per SIMD as

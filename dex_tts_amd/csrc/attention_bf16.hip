@@ -14,11 +14,12 @@
 //   SPLIT=true : NW waves share ONE 32-query tile and split the keys (wave-private 32-key tiles, partial
 //                (m, l, O) merged through LDS) — keeps small token counts (N=650 at B=1) spread over the chip.
 #include "kernels.h"
-#include "bf16_util.h"
+#include "lp_util.h"
+#include "kernels_lp.h"
 
 namespace dex {
+namespace DEX_LP_NS {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned short u16;
 constexpr int AHD = 128;
@@ -26,7 +27,7 @@ constexpr int K_LD = AHD + 8;             // bf16 elements per K row in LDS (272
 
 __device__ __forceinline__ int key_pos(int k) { return (k & ~12) | ((k & 4) << 1) | ((k & 8) >> 1); }
 
-union Frag { uint4 u; bf16x8 v; };
+union Frag { uint4 u; lp8 v; };
 
 // Stage KT keys starting at k0 (rows clamped to Nk-1; masked later through the scores) with GS cooperating
 // threads (index t): K -> kS[key][K_LD], V -> vT[d][KT+8] (transposed, key positions permuted).
@@ -64,18 +65,18 @@ struct Stager {
             const int it = t + GS * j;
             const int key = it / (AHD / 8), d8 = (it % (AHD / 8)) * 8;
             uint4 u;
-            u.x = pack2_bf16_asm(kr[j][0].x, kr[j][0].y); u.y = pack2_bf16_asm(kr[j][0].z, kr[j][0].w);
-            u.z = pack2_bf16_asm(kr[j][1].x, kr[j][1].y); u.w = pack2_bf16_asm(kr[j][1].z, kr[j][1].w);
+            u.x = pack2_lp_asm(kr[j][0].x, kr[j][0].y); u.y = pack2_lp_asm(kr[j][0].z, kr[j][0].w);
+            u.z = pack2_lp_asm(kr[j][1].x, kr[j][1].y); u.w = pack2_lp_asm(kr[j][1].z, kr[j][1].w);
             *reinterpret_cast<uint4*>(kS + key * K_LD + d8) = u;
         }
 #pragma unroll
         for (int j = 0; j < VI; ++j) {
             const int kp = v_kp(t + GS * j), d4 = v_d4(t + GS * j);
             unsigned* dst = reinterpret_cast<unsigned*>(vT + key_pos(2 * kp));      // even position: dword aligned
-            dst[((d4 + 0) * V_LD) >> 1] = pack2_bf16_asm(vr[j][0].x, vr[j][1].x);
-            dst[((d4 + 1) * V_LD) >> 1] = pack2_bf16_asm(vr[j][0].y, vr[j][1].y);
-            dst[((d4 + 2) * V_LD) >> 1] = pack2_bf16_asm(vr[j][0].z, vr[j][1].z);
-            dst[((d4 + 3) * V_LD) >> 1] = pack2_bf16_asm(vr[j][0].w, vr[j][1].w);
+            dst[((d4 + 0) * V_LD) >> 1] = pack2_lp_asm(vr[j][0].x, vr[j][1].x);
+            dst[((d4 + 1) * V_LD) >> 1] = pack2_lp_asm(vr[j][0].y, vr[j][1].y);
+            dst[((d4 + 2) * V_LD) >> 1] = pack2_lp_asm(vr[j][0].z, vr[j][1].z);
+            dst[((d4 + 3) * V_LD) >> 1] = pack2_lp_asm(vr[j][0].w, vr[j][1].w);
         }
     }
 };
@@ -95,7 +96,7 @@ __device__ __forceinline__ void attn_tile(const u16* kS, const u16* vT, const Fr
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             Frag a; a.u = *reinterpret_cast<const uint4*>(ka + ks * 16);
-            s[st] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, qf[ks].v, s[st], 0, 0, 0);
+            s[st] = DEX_MFMA_LP(a.v, qf[ks].v, s[st], 0, 0, 0);
         }
     }
     float mx = -INFINITY;
@@ -126,13 +127,13 @@ __device__ __forceinline__ void attn_tile(const u16* kS, const u16* vT, const Fr
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
             Frag pb;
-            pb.u.x = pack2_bf16_asm(s[st][8 * k2 + 0], s[st][8 * k2 + 1]); pb.u.y = pack2_bf16_asm(s[st][8 * k2 + 2], s[st][8 * k2 + 3]);
-            pb.u.z = pack2_bf16_asm(s[st][8 * k2 + 4], s[st][8 * k2 + 5]); pb.u.w = pack2_bf16_asm(s[st][8 * k2 + 6], s[st][8 * k2 + 7]);
+            pb.u.x = pack2_lp_asm(s[st][8 * k2 + 0], s[st][8 * k2 + 1]); pb.u.y = pack2_lp_asm(s[st][8 * k2 + 2], s[st][8 * k2 + 3]);
+            pb.u.z = pack2_lp_asm(s[st][8 * k2 + 4], s[st][8 * k2 + 5]); pb.u.w = pack2_lp_asm(s[st][8 * k2 + 6], s[st][8 * k2 + 7]);
             const u16* va = vT + i * V_LD + (st * 2 + k2) * 16 + hh * 8;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 Frag a; a.u = *reinterpret_cast<const uint4*>(va + t * 32 * V_LD);
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, pb.v, o[t], 0, 0, 0);
+                o[t] = DEX_MFMA_LP(a.v, pb.v, o[t], 0, 0, 0);
             }
         }
 }
@@ -151,14 +152,14 @@ __device__ __forceinline__ void load_q(Frag (&qf)[8], const float* Qb, int ldq, 
         }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            qf[k0 + ks].u.x = pack2_bf16_asm(a[ks].x * sc, a[ks].y * sc); qf[k0 + ks].u.y = pack2_bf16_asm(a[ks].z * sc, a[ks].w * sc);
-            qf[k0 + ks].u.z = pack2_bf16_asm(c[ks].x * sc, c[ks].y * sc); qf[k0 + ks].u.w = pack2_bf16_asm(c[ks].z * sc, c[ks].w * sc);
+            qf[k0 + ks].u.x = pack2_lp_asm(a[ks].x * sc, a[ks].y * sc); qf[k0 + ks].u.y = pack2_lp_asm(a[ks].z * sc, a[ks].w * sc);
+            qf[k0 + ks].u.z = pack2_lp_asm(c[ks].x * sc, c[ks].y * sc); qf[k0 + ks].u.w = pack2_lp_asm(c[ks].z * sc, c[ks].w * sc);
         }
     }
 }
 
 // ---- SPLIT=false: 4 waves, 4 query tiles, shared K/V tiles of 64 keys ---------------------------------
-__global__ __launch_bounds__(256) void attn_bf16_shared_kernel(const AttnP p) {
+__global__ __launch_bounds__(256) void attn_lp_shared_kernel(const AttnP p) {
     constexpr int KT = 64, V_LD = KT + 8;
     constexpr int KBUF = KT * K_LD, VBUF = AHD * V_LD;
     extern __shared__ __attribute__((aligned(16))) u16 smem_b[];
@@ -209,7 +210,7 @@ constexpr int SP_WAVE_U16 = SP_KT * K_LD + AHD * (SP_KT + 8);   // 4352 + 5120 =
 constexpr int SP_O_LD = 132;
 
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void attn_bf16_split_kernel(const AttnP p) {
+__global__ __launch_bounds__(NW * 64) void attn_lp_split_kernel(const AttnP p) {
     extern __shared__ __attribute__((aligned(16))) u16 smem_b[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
@@ -318,25 +319,25 @@ static void launch_split(const AttnP& p, hipStream_t st) {
     const size_t lds = (size_t)NW * SP_WAVE_U16 * sizeof(u16) + NW * 64 * sizeof(float);
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf16_split_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_lp_split_kernel<NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     dim3 grid((p.Nq + 31) / 32, p.heads, p.B * (p.ksplit > 1 ? p.ksplit : 1));
-    hipLaunchKernelGGL((attn_bf16_split_kernel<NW>), grid, dim3(NW * 64), lds, st, p);
+    hipLaunchKernelGGL((attn_lp_split_kernel<NW>), grid, dim3(NW * 64), lds, st, p);
 }
 
-void launch_attention_bf16(const AttnP& p, hipStream_t st) {
+void launch_attention_lp(const AttnP& p, hipStream_t st) {
     const long blocks128 = (long)((p.Nq + 127) / 128) * p.heads * p.B;
     if (blocks128 >= 256 && p.ksplit <= 1) {
         constexpr int KT = 64;
         const size_t lds = (size_t)(2 * KT * K_LD + 2 * AHD * (KT + 8)) * sizeof(u16);
         static bool attr = false;
         if (!attr) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bf16_shared_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_lp_shared_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr = true;
         }
         dim3 grid((p.Nq + 127) / 128, p.heads, p.B);
-        hipLaunchKernelGGL(attn_bf16_shared_kernel, grid, dim3(256), lds, st, p);
+        hipLaunchKernelGGL(attn_lp_shared_kernel, grid, dim3(256), lds, st, p);
         return;
     }
     const long blocks32 = (long)((p.Nq + 31) / 32) * p.heads * p.B;
@@ -349,4 +350,5 @@ void launch_attention_bf16(const AttnP& p, hipStream_t st) {
     else launch_split<2>(p, st);
 }
 
+}  // namespace DEX_LP_NS
 }  // namespace dex

@@ -19,17 +19,18 @@
 // each split writes normalised O plus (max, sum) for the consumer to merge.
 #include <hip/hip_runtime.h>
 #include "kernels.h"
-#include "bf16_util.h"
+#include "lp_util.h"
+#include "kernels_lp.h"
 
 namespace dex {
+namespace DEX_LP_NS {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned short u16;
 
 namespace {
 constexpr int HD = 128, O_LD = 132, NWD = 8;
-union DFrag { uint4 u; bf16x8 v; };
+union DFrag { uint4 u; lp8 v; };
 }  // namespace
 
 __global__ __launch_bounds__(NWD * 64) void attn_direct_kernel(const AttnDirectP p) {
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(NWD * 64) void attn_direct_kernel(const AttnDirectP
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks].v, qf[ks].v, s, 0, 0, 0);
+        for (int ks = 0; ks < 8; ++ks) s = DEX_MFMA_LP(kf[ks].v, qf[ks].v, s, 0, 0, 0);
         if (kn < t_hi) {                                   // next K tile into the registers just consumed
             const uint4* kp = Kg + (long)kn * 8 * 64;
 #pragma unroll
@@ -114,10 +115,10 @@ __global__ __launch_bounds__(NWD * 64) void attn_direct_kernel(const AttnDirectP
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
             DFrag pb;
-            pb.u.x = pack2_bf16(s[8 * k2 + 0], s[8 * k2 + 1]); pb.u.y = pack2_bf16(s[8 * k2 + 2], s[8 * k2 + 3]);
-            pb.u.z = pack2_bf16(s[8 * k2 + 4], s[8 * k2 + 5]); pb.u.w = pack2_bf16(s[8 * k2 + 6], s[8 * k2 + 7]);
+            pb.u.x = pack2_lp(s[8 * k2 + 0], s[8 * k2 + 1]); pb.u.y = pack2_lp(s[8 * k2 + 2], s[8 * k2 + 3]);
+            pb.u.z = pack2_lp(s[8 * k2 + 4], s[8 * k2 + 5]); pb.u.w = pack2_lp(s[8 * k2 + 6], s[8 * k2 + 7]);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[t][k2].v, pb.v, o[t], 0, 0, 0);
+            for (int t = 0; t < 4; ++t) o[t] = DEX_MFMA_LP(vf[t][k2].v, pb.v, o[t], 0, 0, 0);
         }
         if (kn < t_hi) {                                   // next V^T tile
             const uint4* vp = Vg + (long)kn * 8 * 64;
@@ -197,8 +198,8 @@ __device__ __forceinline__ f32x16 attn_qk(const uint4* kbuf, const DFrag (&qf)[8
     for (int ks = 0; ks < 8; ks += 2) {
         DFrag k0; k0.u = kbuf[ks * 64 + lane];
         DFrag k1; k1.u = kbuf[(ks + 1) * 64 + lane];
-        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0.v, qf[ks].v, s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1.v, qf[ks + 1].v, s1, 0, 0, 0);
+        s0 = DEX_MFMA_LP(k0.v, qf[ks].v, s0, 0, 0, 0);
+        s1 = DEX_MFMA_LP(k1.v, qf[ks + 1].v, s1, 0, 0, 0);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) s0[r] += s1[r];
@@ -277,12 +278,12 @@ __global__ __launch_bounds__(256) void attn_direct_full_kernel(const AttnDirectP
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
             DFrag pb;
-            pb.u.x = pack2_bf16(s[8 * k2 + 0], s[8 * k2 + 1]); pb.u.y = pack2_bf16(s[8 * k2 + 2], s[8 * k2 + 3]);
-            pb.u.z = pack2_bf16(s[8 * k2 + 4], s[8 * k2 + 5]); pb.u.w = pack2_bf16(s[8 * k2 + 6], s[8 * k2 + 7]);
+            pb.u.x = pack2_lp(s[8 * k2 + 0], s[8 * k2 + 1]); pb.u.y = pack2_lp(s[8 * k2 + 2], s[8 * k2 + 3]);
+            pb.u.z = pack2_lp(s[8 * k2 + 4], s[8 * k2 + 5]); pb.u.w = pack2_lp(s[8 * k2 + 6], s[8 * k2 + 7]);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 DFrag vf; vf.u = vcur[(t * 2 + k2) * 64 + lane];
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pb.v, o[t], 0, 0, 0);
+                o[t] = DEX_MFMA_LP(vf.v, pb.v, o[t], 0, 0, 0);
             }
         }
         // K(kt+2) replaces K(kt) (read one iteration ago), V(kt+1) replaces V(kt-1)
@@ -319,4 +320,5 @@ void launch_attention_direct(const AttnDirectP& p, hipStream_t st) {
     hipLaunchKernelGGL(attn_direct_kernel, grid, dim3(NWD * 64), lds, st, p);
 }
 
+}  // namespace DEX_LP_NS
 }  // namespace dex

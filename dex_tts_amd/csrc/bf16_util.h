@@ -50,6 +50,19 @@ __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u 
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 __device__ __forceinline__ unsigned short bf16_bits(float x) { return (unsigned short)(pack2_bf16(x, 0.f) & 0xffffu); }
 
+// fp16 twins (the fp16 mode's stores / loads in the element-wise kernels that are compiled once and take the mode as a
+// runtime field: 1 = bf16, 2 = fp16)
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2_f16(float lo, float hi) {
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));      // v_cvt_pk_f16_f32, round to nearest even
+}
+__device__ __forceinline__ float f16_lo(unsigned u) { return (float)__builtin_bit_cast(f16x2_t, u)[0]; }
+__device__ __forceinline__ float f16_hi(unsigned u) { return (float)__builtin_bit_cast(f16x2_t, u)[1]; }
+__device__ __forceinline__ unsigned pack2_kind(float lo, float hi, int kind) { return kind == 2 ? pack2_f16(lo, hi) : pack2_bf16(lo, hi); }
+__device__ __forceinline__ float lo_kind(unsigned u, int kind) { return kind == 2 ? f16_lo(u) : bf16_lo(u); }
+__device__ __forceinline__ float hi_kind(unsigned u, int kind) { return kind == 2 ? f16_hi(u) : bf16_hi(u); }
+
 // value of the neighbouring lane (lane ^ 1) through DPP quad_perm [1,0,3,2]: one VALU move, no LDS crossbar
 __device__ __forceinline__ float lane_xor1(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, true));

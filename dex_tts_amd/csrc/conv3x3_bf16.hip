@@ -16,11 +16,13 @@
 // slot-spread buffer), fp32 channels-last store (128-B rows).
 #include "kernels.h"
 #include <cstdlib>
-#include "bf16_util.h"
+#include <cstdio>
+#include "lp_util.h"
+#include "kernels_lp.h"
 
 namespace dex {
+namespace DEX_LP_NS {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned short u16;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vector: register rings of HIP's uint4 struct defeat SROA
@@ -104,7 +106,7 @@ __device__ __forceinline__ void cv_epilogue(const Conv3P& p, f32x16 (&acc)[NT], 
                 const float lo_r = acc[t][j] + bias, hi_r = acc[t][8 + j] + bias;       // rows j and 8+j of this lane's channel
                 const float recv = lane_xor1(odd ? lo_r : hi_r);                          // the partner's value for MY row set
                 const float mine = odd ? hi_r : lo_r;
-                const unsigned pk = odd ? pack2_bf16(recv, mine) : pack2_bf16(mine, recv);
+                const unsigned pk = odd ? pack2_lp(recv, mine) : pack2_lp(mine, recv);
                 *reinterpret_cast<unsigned*>(yp + ((j & 3) + 8 * (j >> 2)) * COUT) = pk;
             }
         } else if (full) {          // fp32 output: the same swap, 8-byte stores
@@ -128,7 +130,7 @@ __device__ __forceinline__ void cv_epilogue(const Conv3P& p, f32x16 (&acc)[NT], 
                 const float vs = ok ? v : 0.f;
                 gs += vs; gss = fmaf(vs, vs, gss);
                 if (ok) {
-                    if (yb) yh[((r & 3) + 8 * (r >> 2)) * COUT + t * 32] = bf16_bits(v);
+                    if (yb) yh[((r & 3) + 8 * (r >> 2)) * COUT + t * 32] = lp_bits(v);
                     else yl[((r & 3) + 8 * (r >> 2)) * COUT + t * 32] = v;
                 }
             }
@@ -157,7 +159,7 @@ __device__ __forceinline__ void cv_epilogue(const Conv3P& p, f32x16 (&acc)[NT], 
 // CC channels per chunk, output-channel slice [slice*NSL, +NSL) of COUT, TH rows (waves: TH x (4/TH)).
 // grid.z = b * (COUT/NSL) + slice.
 template <int CC, int COUT, int NSL, int TH, bool PRO2 = false, bool RES = false, bool XB = false, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void conv3x3_bf16_kernel(const Conv3P p) {
+__global__ __launch_bounds__(64 * NW) void conv3x3_lp_kernel(const Conv3P p) {
     constexpr int PW = 34, PH = TH + 2;
     constexpr int LDP = CC + 8;
     constexpr int WN = NW / TH;                          // NW = 8: two waves per SIMD in ONE workgroup (the 128-channel layers fill the LDS with one)
@@ -294,8 +296,8 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_bf16_kernel(const Conv3P p) {
                 if constexpr (XB) {
                     const float4 r = pf0[q];
                     const unsigned u0 = __float_as_uint(r.x), u1 = __float_as_uint(r.y), u2 = __float_as_uint(r.z), u3 = __float_as_uint(r.w);
-                    f0 = make_float4(bf16_lo(u0), bf16_hi(u0), bf16_lo(u1), bf16_hi(u1));
-                    f1 = make_float4(bf16_lo(u2), bf16_hi(u2), bf16_lo(u3), bf16_hi(u3));
+                    f0 = make_float4(lp_lo(u0), lp_hi(u0), lp_lo(u1), lp_hi(u1));
+                    f1 = make_float4(lp_lo(u2), lp_hi(u2), lp_lo(u3), lp_hi(u3));
                 } else { f0 = pf0[q]; f1 = pf1[q]; }
                 if (pro) {
                     f0.x = cv_mish(fmaf(f0.x, sc0.x, sh0.x)) + t0.x; f0.y = cv_mish(fmaf(f0.y, sc0.y, sh0.y)) + t0.y;
@@ -317,8 +319,8 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_bf16_kernel(const Conv3P p) {
                     }
                 }
                 uint4 v;
-                v.x = pack2_bf16(f0.x * mk, f0.y * mk); v.y = pack2_bf16(f0.z * mk, f0.w * mk);
-                v.z = pack2_bf16(f1.x * mk, f1.y * mk); v.w = pack2_bf16(f1.z * mk, f1.w * mk);
+                v.x = pack2_lp(f0.x * mk, f0.y * mk); v.y = pack2_lp(f0.z * mk, f0.w * mk);
+                v.z = pack2_lp(f1.x * mk, f1.y * mk); v.w = pack2_lp(f1.z * mk, f1.w * mk);
                 if (it < ITEMS) *reinterpret_cast<uint4*>(patch + (it / (CC / 8)) * LDP + pc8) = v;
             }
         }
@@ -350,18 +352,18 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_bf16_kernel(const Conv3P p) {
             const u16* bp = wb + (wcol * NT * 32 + i) * LDP + hh * 8;
 #pragma unroll
             for (int ks = 0; ks < CC / 16; ++ks) {
-                const bf16x8 af = *reinterpret_cast<const bf16x8*>(ap + ks * 16);
+                const lp8 af = *reinterpret_cast<const lp8*>(ap + ks * 16);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bp + t * 32 * LDP + ks * 16);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
+                    const lp8 bf = *reinterpret_cast<const lp8*>(bp + t * 32 * LDP + ks * 16);
+                    acc[t] = DEX_MFMA_LP(af, bf, acc[t], 0, 0, 0);
                 }
                 if constexpr (RES) {
                     if (tap == 4) {                   // centre tap: the same A fragment feeds the 1x1 shortcut
 #pragma unroll
                         for (int t = 0; t < NT; ++t) {
-                            const bf16x8 rf = *reinterpret_cast<const bf16x8*>(rbuf + (wcol * NT * 32 + t * 32 + i) * LDP + hh * 8 + ks * 16);
-                            accr[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, rf, accr[t], 0, 0, 0);
+                            const lp8 rf = *reinterpret_cast<const lp8*>(rbuf + (wcol * NT * 32 + t * 32 + i) * LDP + hh * 8 + ks * 16);
+                            accr[t] = DEX_MFMA_LP(af, rf, accr[t], 0, 0, 0);
                         }
                     }
                 }
@@ -413,11 +415,14 @@ static void launch_c3(const Conv3P& p, hipStream_t st) {
     const size_t lds = ((size_t)(TH + 2) * 34 * LDP + (2 + (RES ? 1 : 0)) * NSL * LDP) * sizeof(u16);
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_bf16_kernel<CC, COUT, NSL, TH, PRO2, RES, XB, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_lp_kernel<CC, COUT, NSL, TH, PRO2, RES, XB, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     dim3 grid((p.W + 31) / 32, (p.H + TH - 1) / TH, p.B * (COUT / NSL));
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<CC, COUT, NSL, TH, PRO2, RES, XB, NW>), grid, dim3(64 * NW), lds, st, p);
+    static char sym[96];
+    if (!sym[0]) snprintf(sym, sizeof sym, "conv3x3_lp_kernel<%d,%d,%d,%d,%d,%d,%d,%d>", CC, COUT, NSL, TH, (int)PRO2, (int)RES, (int)XB, NW);
+    g_last_symbol = sym;
+    hipLaunchKernelGGL((conv3x3_lp_kernel<CC, COUT, NSL, TH, PRO2, RES, XB, NW>), grid, dim3(64 * NW), lds, st, p);
 }
 
 bool conv3x3_bf16_tail_supported(int C) { return C == 64 || C == 128; }
@@ -427,7 +432,7 @@ bool conv3x3_bf16_supported(int Cin, int Cout) {
     return (Cin == 64 || Cin == 128 || Cin == 256) && (Cout == 64 || Cout == 128);
 }
 
-void launch_conv3x3_bf16(const Conv3P& p, hipStream_t st) {
+void launch_conv3x3_lp(const Conv3P& p, hipStream_t st) {
     if (const int tpw = conv3x3_stream_tiles(p)) { launch_conv3x3_stream(p, tpw, st); return; }   // batched synthesis
     // few tiles (half resolution at small batch): 2-row tiles and 64-channel output slices put more, lighter
     // workgroups on the chip (per-tap weight traffic per workgroup halves, two workgroups fit per CU)
@@ -472,4 +477,5 @@ void launch_conv3x3_bf16(const Conv3P& p, hipStream_t st) {
     }
 }
 
+}  // namespace DEX_LP_NS
 }  // namespace dex

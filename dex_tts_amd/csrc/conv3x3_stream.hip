@@ -18,14 +18,15 @@
 // PRO2 (the previous ResnetBlock's tail: x = mask * Mish(GN(h2)) + res, also written out for later consumers).
 // Reference: Block / ResnetBlock, diffusion.py:42-71.
 #include "kernels.h"
-#include "bf16_util.h"
+#include "lp_util.h"
+#include "kernels_lp.h"
 #include <cstdlib>
 
 namespace dex {
+namespace DEX_LP_NS {
 
 namespace {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, c
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const unsigned u = __float_as_uint(x.a[q][k]);
-                    v[2 * k] = bf16_lo(u); v[2 * k + 1] = bf16_hi(u);
+                    v[2 * k] = lp_lo(u); v[2 * k + 1] = lp_hi(u);
                 }
             } else {
 #pragma unroll
@@ -178,11 +179,11 @@ __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, c
                         *reinterpret_cast<float4*>(xo + 4) = make_float4(v[4], v[5], v[6], v[7]);
                     }
                 }
-                o.x = pack2_bf16(v[0] * mk, v[1] * mk); o.y = pack2_bf16(v[2] * mk, v[3] * mk);
-                o.z = pack2_bf16(v[4] * mk, v[5] * mk); o.w = pack2_bf16(v[6] * mk, v[7] * mk);
+                o.x = pack2_lp(v[0] * mk, v[1] * mk); o.y = pack2_lp(v[2] * mk, v[3] * mk);
+                o.z = pack2_lp(v[4] * mk, v[5] * mk); o.w = pack2_lp(v[6] * mk, v[7] * mk);
             } else {
-                o.x = pack2_mul_bf16_pinned(v[0], v[1], mk); o.y = pack2_mul_bf16_pinned(v[2], v[3], mk);
-                o.z = pack2_mul_bf16_pinned(v[4], v[5], mk); o.w = pack2_mul_bf16_pinned(v[6], v[7], mk);
+                o.x = pack2_mul_lp_pinned(v[0], v[1], mk); o.y = pack2_mul_lp_pinned(v[2], v[3], mk);
+                o.z = pack2_mul_lp_pinned(v[4], v[5], mk); o.w = pack2_mul_lp_pinned(v[6], v[7], mk);
             }
             if (pxi < STR * SPW) *reinterpret_cast<uint4*>(dst + pxi * SLDP + c8) = o;
         }
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, c
                     const float lo_r = acc[n2][j] + bias, hi_r = acc[n2][8 + j] + bias;
                     const float recv = lane_xor1(odd ? lo_r : hi_r);
                     const float mine = odd ? hi_r : lo_r;
-                    const unsigned pk = odd ? pack2_bf16(recv, mine) : pack2_bf16(mine, recv);
+                    const unsigned pk = odd ? pack2_lp(recv, mine) : pack2_lp(mine, recv);
                     *reinterpret_cast<unsigned*>(yp + ((j & 3) + 8 * (j >> 2)) * SC + n2 * 32) = pk;
                 }
             }
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, c
                 const float vs = ok ? v : 0.f;
                 gs[n2] += vs; gss[n2] = fmaf(vs, vs, gss[n2]);
                 if (ok) {
-                    if (yb) yh[((r & 3) + 8 * (r >> 2)) * SC + n2 * 32] = bf16_bits(v);
+                    if (yb) yh[((r & 3) + 8 * (r >> 2)) * SC + n2 * 32] = lp_bits(v);
                     else yf[((r & 3) + 8 * (r >> 2)) * SC + n2 * 32] = v;
                 }
             }
@@ -282,21 +283,21 @@ __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, c
             arow[kh] = patch + ((((t + (r >> 3)) & 1) * STR + (r & 7)) * SPW + i) * SLDP + hh * 8;
         }
         const u16* brow = wts + i * SLDP + hh * 8;
-        bf16x8 af[2], b0[2], b1[2];
-        af[0] = *reinterpret_cast<const bf16x8*>(arow[0]);
-        b0[0] = *reinterpret_cast<const bf16x8*>(brow);
-        b1[0] = *reinterpret_cast<const bf16x8*>(brow + 32 * SLDP);
+        lp8 af[2], b0[2], b1[2];
+        af[0] = *reinterpret_cast<const lp8*>(arow[0]);
+        b0[0] = *reinterpret_cast<const lp8*>(brow);
+        b1[0] = *reinterpret_cast<const lp8*>(brow + 32 * SLDP);
 #pragma unroll
         for (int s = 0; s < 36; ++s) {
             if (s + 1 < 36) {
                 const int tap = (s + 1) >> 2, ks = (s + 1) & 3, kh = tap / 3, kw = tap - kh * 3;
-                af[(s + 1) & 1] = *reinterpret_cast<const bf16x8*>(arow[kh] + kw * SLDP + ks * 16);
-                b0[(s + 1) & 1] = *reinterpret_cast<const bf16x8*>(brow + tap * SC * SLDP + ks * 16);
-                b1[(s + 1) & 1] = *reinterpret_cast<const bf16x8*>(brow + (tap * SC + 32) * SLDP + ks * 16);
+                af[(s + 1) & 1] = *reinterpret_cast<const lp8*>(arow[kh] + kw * SLDP + ks * 16);
+                b0[(s + 1) & 1] = *reinterpret_cast<const lp8*>(brow + tap * SC * SLDP + ks * 16);
+                b1[(s + 1) & 1] = *reinterpret_cast<const lp8*>(brow + (tap * SC + 32) * SLDP + ks * 16);
             }
             __builtin_amdgcn_sched_barrier(0);            // (the scheduler otherwise sinks each read to right above its MFMA)
-            cur[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1], b0[s & 1], cur[0], 0, 0, 0);
-            cur[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s & 1], b1[s & 1], cur[1], 0, 0, 0);
+            cur[0] = DEX_MFMA_LP(af[s & 1], b0[s & 1], cur[0], 0, 0, 0);
+            cur[1] = DEX_MFMA_LP(af[s & 1], b1[s & 1], cur[1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -375,9 +376,12 @@ void launch_conv3x3_stream(const Conv3P& p, int tiles_per_wg, hipStream_t st) {
     const int tiles = (p.H + STR - 1) / STR;
     dim3 grid((p.W + 31) / 32, (tiles + tiles_per_wg - 1) / tiles_per_wg, p.B);
     const bool pro = p.pro_stats != nullptr;
+    g_last_symbol = p.pro_res ? (p.x_bf16 ? "conv3x3_stream64_kernel<1,1,1>" : "conv3x3_stream64_kernel<1,1,0>")
+                  : pro ? (p.x_bf16 ? "conv3x3_stream64_kernel<1,0,1>" : "conv3x3_stream64_kernel<1,0,0>") : "conv3x3_stream64_kernel<0,0,0>";
     if (p.pro_res) { p.x_bf16 ? stream_go<true, true, true>(p, tiles_per_wg, grid, st) : stream_go<true, true, false>(p, tiles_per_wg, grid, st); }
     else if (pro) { p.x_bf16 ? stream_go<true, false, true>(p, tiles_per_wg, grid, st) : stream_go<true, false, false>(p, tiles_per_wg, grid, st); }
     else stream_go<false, false, false>(p, tiles_per_wg, grid, st);
 }
 
+}  // namespace DEX_LP_NS
 }  // namespace dex

@@ -18,6 +18,7 @@
 #include "kernels.h"
 
 using namespace dex;
+static_assert(PREC_FP32 == DEX_PREC_FP32 && PREC_BF16 == DEX_PREC_BF16 && PREC_FP16 == DEX_PREC_FP16, "kernels.h mirrors DexPrecision");
 
 namespace {
 
@@ -26,7 +27,7 @@ struct TD { float* p; int ld; int coff; int C; };          // channels-last acti
 
 struct ResW { const float *w1, *b1, *g1, *be1, *w2, *b2, *g2, *be2, *wr, *br, *mlp_w, *mlp_b; int cin, cout; };
 constexpr int ATT_KSPLIT_MAX = 4;     // key-split attention partials kept per token (dit_rowchain.hip merges them)
-struct LinW { const float *wqkv, *wqkv_raw, *wout_raw, *bias_eff, *g; const void *wq_bf16, *wkv_bf16, *wq_frag; int C; };
+struct LinW { const float *wqkv, *wqkv_raw, *wout_raw, *bias_eff, *g; const void *wq_lp[2], *wkv_lp[2], *wq_frag[2]; int C; };   // [0] bf16, [1] fp16
 struct DitBlockW { const float *wqkv, *bqkv, *wproj, *bproj, *wfc1, *bfc1, *wfc2, *bfc2, *ada_w, *ada_b; };
 
 struct Prof { std::string name; hipEvent_t a, b; double flops, bytes; };
@@ -51,8 +52,15 @@ struct DexCtx {
     std::vector<std::string> keys;
     std::map<std::string, RawW> raw;
     std::vector<void*> owned;                              // hipMalloc'ed packed weights
-    std::map<const float*, const void*> bf16_of;           // fp32 [K][N] pack -> bf16 [N][K] twin
-    std::map<const float*, const void*> frag_of;           // fp32 [K][N] pack -> bf16 MFMA-fragment-order twin (DiT row chain)
+    // low-precision twins of the fp32 [K][N] packs, one set per operand type: [0] bf16, [1] fp16 (both are packed at
+    // finalize: the precision mode may change afterwards)
+    std::map<const float*, const void*> lp_of_[2];         // -> [N][K] twin
+    std::map<const float*, const void*> frag_of_[2];       // -> MFMA-fragment-order twin (DiT row chain)
+    int lpi() const { return precision == DEX_PREC_FP16 ? 1 : 0; }
+    int lp_kind() const { return precision == DEX_PREC_FP16 ? 2 : 1; }      // the element-wise kernels' runtime code
+    bool lp() const { return precision != DEX_PREC_FP32; }
+    const std::map<const float*, const void*>& lp_of() const { return lp_of_[lpi()]; }
+    const std::map<const float*, const void*>& frag_of() const { return frag_of_[lpi()]; }
     bool finalized = false;
     int precision = DEX_PREC_FP32;
     // packed weights
@@ -63,7 +71,7 @@ struct DexCtx {
     const float *fc_w3 = nullptr, *fc_w1 = nullptr;        // first conv packs
     const float *fin_w = nullptr, *fin_b = nullptr, *fin_g = nullptr, *fin_be = nullptr, *fconv_w = nullptr, *fconv_b = nullptr;
     const float *pe_dw = nullptr, *pe_db = nullptr, *pe_pw = nullptr, *pe_pb = nullptr, *pos_w = nullptr, *pos_b = nullptr, *freq_pos = nullptr;
-    const void* pos_wfrag = nullptr;                        // pos-conv weights in MFMA fragment order (pos_conv.hip)
+    const void* pos_wfrag[2] = {nullptr, nullptr};          // pos-conv weights in MFMA fragment order (pos_conv.hip), bf16 / fp16
     std::vector<DitBlockW> blocks;
     const float *fl_w = nullptr, *fl_b = nullptr, *fl_ada_w = nullptr, *fl_ada_b = nullptr;
     const float *tv_wq_raw = nullptr, *tv_wk = nullptr, *tv_wv = nullptr, *tv_wl = nullptr;
@@ -194,17 +202,6 @@ void build_inventory(DexCtx* x) {
     add_key(x, "final_conv.weight", {1, d, 1, 1}); add_key(x, "final_conv.bias", {1});
 }
 
-// fp32 [K][N] -> bf16 [N][K] (round-to-nearest-even)
-__global__ void pack_bf16_nk_kernel(const float* src, unsigned short* dst, int K, int N) {
-    const long total = (long)K * N;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int k = (int)(i % K), n = (int)(i / K);
-        unsigned u = __float_as_uint(src[(long)k * N + n]);
-        u += 0x7FFFu + ((u >> 16) & 1u);
-        dst[i] = (unsigned short)(u >> 16);
-    }
-}
-
 // ConvTranspose2d(4,2,1) -> four 2x2-tap parity sub-convolutions.
 // dst[par = ph*2+pw][(th*2+tw)*Cin + ci][co] = src[ci][co][kh][kw],  kh = (ph ? 0 : 1) + 2*th, kw likewise.
 __global__ void pack_convt_kernel(const float* src, float* dst, int Cin, int Cout) {
@@ -297,7 +294,7 @@ int dex_ctx_load_weight_async(DexCtx* x, const char* key, const float* w_dev, co
 }
 
 int dex_ctx_set_precision(DexCtx* x, int precision) {
-    if (!x || (precision != DEX_PREC_FP32 && precision != DEX_PREC_BF16)) return DEX_ERR_ARG;
+    if (!x || (precision != DEX_PREC_FP32 && precision != DEX_PREC_BF16 && precision != DEX_PREC_FP16)) return DEX_ERR_ARG;
     x->precision = precision;
     return DEX_OK;
 }
@@ -319,19 +316,23 @@ struct Packer {
     // bf16 [N][K] twins of `count` consecutive fp32 [K][N] matrices starting at p
     void twin(const float* p, int count, int K, int N) {
         if (!p) return;
-        unsigned short* d = (unsigned short*)alloc(((long)count * K * N + 1) / 2);
-        if (!d) return;
-        for (int c = 0; c < count; ++c) {
-            hipLaunchKernelGGL(pack_bf16_nk_kernel, dim3(256), dim3(256), 0, st, p + (long)c * K * N, d + (long)c * K * N, K, N);
-            x->bf16_of[p + (long)c * K * N] = d + (long)c * K * N;
+        for (int t = 0; t < 2; ++t) {
+            unsigned short* d = (unsigned short*)alloc(((long)count * K * N + 1) / 2);
+            if (!d) return;
+            for (int c = 0; c < count; ++c) {
+                launch_pack_lp_nk(p + (long)c * K * N, d + (long)c * K * N, K, N, t ? PREC_FP16 : PREC_BF16, st);
+                x->lp_of_[t][p + (long)c * K * N] = d + (long)c * K * N;
+            }
         }
     }
     void frag(const float* p, int K, int N) {
         if (!p) return;
-        void* d = alloc(((long)K * N + 1) / 2);
-        if (!d) return;
-        launch_pack_bf16_frag(p, d, K, N, st);
-        x->frag_of[p] = d;
+        for (int t = 0; t < 2; ++t) {
+            void* d = alloc(((long)K * N + 1) / 2);
+            if (!d) return;
+            launch_pack_lp_frag(p, d, K, N, t ? PREC_FP16 : PREC_BF16, st);
+            x->frag_of_[t][p] = d;
+        }
     }
     const RawW& R(const std::string& k) { return x->raw.at(k); }
     const float* raw(const std::string& k) { return R(k).p; }
@@ -374,13 +375,16 @@ struct Packer {
         l.wqkv_raw = raw(p + ".fn.fn.to_qkv.weight");                 // [384][C]: rows q | k | v
         l.wout_raw = raw(p + ".fn.fn.to_out.weight");
         {   // bf16 copy of the q | k | v rows in their native [N][K] layout (MFMA operands of the fused kernels)
-            unsigned short* qb = (unsigned short*)alloc((384L * c + 1) / 2);
-            if (qb) launch_f32_to_bf16(l.wqkv_raw, qb, 384L * c, st);
-            l.wq_bf16 = qb; l.wkv_bf16 = qb ? qb + 128L * c : nullptr;
-            // the q rows again in MFMA fragment order (A operand of the tail's first GEMM: 1 KB contiguous per wave load)
-            void* qf = alloc((128L * c + 1) / 2);
-            if (qf) launch_pack_bf16_frag_nk(l.wqkv_raw, qf, c, 128, st);
-            l.wq_frag = qf;
+            for (int t = 0; t < 2; ++t) {
+                const int prec = t ? PREC_FP16 : PREC_BF16;
+                unsigned short* qb = (unsigned short*)alloc((384L * c + 1) / 2);
+                if (qb) launch_f32_to_lp(l.wqkv_raw, qb, 384L * c, prec, st);
+                l.wq_lp[t] = qb; l.wkv_lp[t] = qb ? qb + 128L * c : nullptr;
+                // the q rows again in MFMA fragment order (A operand of the tail's first GEMM: 1 KB contiguous per wave load)
+                void* qf = alloc((128L * c + 1) / 2);
+                if (qf) launch_pack_lp_frag_nk(l.wqkv_raw, qf, c, 128, prec, st);
+                l.wq_frag[t] = qf;
+            }
         }
         l.g = raw(p + ".fn.g");
         float* be = alloc(c);
@@ -429,7 +433,7 @@ extern "C" int dex_ctx_finalize(DexCtx* x, dex_stream_t stream) {
         if (!x->raw.at(k).loaded) return x->fail(DEX_ERR_STATE, "weight '%s' was never loaded", k.c_str());
     for (void* p : x->owned) hipFree(p);
     x->owned.clear();
-    x->bf16_of.clear(); x->frag_of.clear();
+    for (int t = 0; t < 2; ++t) { x->lp_of_[t].clear(); x->frag_of_[t].clear(); }
     x->drop_graphs();
     const DexConfig& c = x->cfg;
     hipStream_t st = (hipStream_t)stream;
@@ -466,12 +470,14 @@ extern "C" int dex_ctx_finalize(DexCtx* x, dex_stream_t stream) {
     x->pe_pw = P.kn("vit.x_embedder.proj.2.weight"); x->pe_pb = P.raw("vit.x_embedder.proj.2.bias");
     x->pos_w = P.perm("vit.pos_conv.0.weight", G, hid / G, hid / G, kp * kp, 0, 3, 2, 1);   // [G][tap][ci][n]
     P.twin(x->pos_w, G, kp * kp * (hid / G), hid / G);
-    x->pos_wfrag = nullptr;
+    x->pos_wfrag[0] = x->pos_wfrag[1] = nullptr;
     if (pos_conv_direct_supported(hid, G, kp, token_rows(c))) {
         const long kn_ = (long)kp * kp * (hid / G) * (hid / G);
-        unsigned short* wf = (unsigned short*)P.alloc((G * kn_ + 1) / 2);
-        if (wf) for (int g = 0; g < G; ++g) launch_pack_bf16_frag(x->pos_w + g * kn_, wf + g * kn_, kp * kp * (hid / G), hid / G, st);
-        x->pos_wfrag = wf;
+        for (int t = 0; t < 2; ++t) {
+            unsigned short* wf = (unsigned short*)P.alloc((G * kn_ + 1) / 2);
+            if (wf) for (int g = 0; g < G; ++g) launch_pack_lp_frag(x->pos_w + g * kn_, wf + g * kn_, kp * kp * (hid / G), hid / G, t ? PREC_FP16 : PREC_BF16, st);
+            x->pos_wfrag[t] = wf;
+        }
     }
     x->pos_b = P.raw("vit.pos_conv.0.bias");
     x->freq_pos = P.perm("vit.freq_new_pos_embed", 1, hid, grid_h(c), 1, 0, 2, 3, 1);       // [Hf][hid]
@@ -653,7 +659,9 @@ struct Runner {
         if (x->prof_on) {
             Prof pr; pr.name = name; pr.flops = flops; pr.bytes = bytes;
             hipEventCreate(&pr.a); hipEventCreate(&pr.b);
+            g_last_symbol = nullptr;
             hipEventRecord(pr.a, st); f(); hipEventRecord(pr.b, st);
+            if (g_last_symbol) pr.name = g_last_symbol;        // the instantiation the launcher picked (rocprofv3's name for it)
             x->prof.push_back(pr);
         } else f();
     }
@@ -673,7 +681,7 @@ struct Runner {
         g.KH = 1; g.KW = 1; g.sh = 1; g.sw = 1; g.off_h = 0; g.off_w = 0; g.step_h = 1; g.step_w = 1;
         g.Ho = H; g.Wo = W;
         g.W = Wt; g.w_bstride = 0; g.w_gstride = 0;
-        { auto it = x->bf16_of.find(Wt); g.Wbf = (it != x->bf16_of.end()) ? it->second : nullptr; }
+        { auto it = x->lp_of().find(Wt); g.Wbf = (it != x->lp_of().end()) ? it->second : nullptr; }
         g.N = N; g.K = Cin; g.ksplit = 1; g.groups = 1;
         g.bias = bias; g.bias_bstride = 0;
         g.C = C; g.ldc = ldc; g.c_bstride = (long)H * W * ldc; g.c_sstride = 0; g.c_coff = ccoff;
@@ -695,13 +703,13 @@ struct Runner {
     struct Pro { const gnfix_t* stats; const float *gamma, *beta, *tadd; const float* res = nullptr; float* xout = nullptr; bool x_bf16 = false; };
     // raw conv outputs read only by a fused GroupNorm prologue (h1, h2 of a ResnetBlock, the final block's conv) are kept
     // in HBM as bf16 in bf16 mode: half the bytes of the largest tensors of the step.  DEX_H_BF16=0 keeps them fp32.
-    bool h_bf16() const { const char* e = getenv("DEX_H_BF16"); return x->precision == DEX_PREC_BF16 && !(e && e[0] == '0'); }
-    bool fast_conv(int cin, int cout) const { return x->precision == DEX_PREC_BF16 && conv3x3_bf16_supported(cin, cout); }
+    bool h_bf16() const { const char* e = getenv("DEX_H_BF16"); return x->lp() && !(e && e[0] == '0'); }
+    bool fast_conv(int cin, int cout) const { return x->lp() && conv3x3_bf16_supported(cin, cout); }
     void conv3x3(const char* name, const TD& X, int H, int W, int mask_ws, bool inmask, const float* Wt, const float* bias, int Cout, float* out,
                  gnfix_t* gn = nullptr, const Pro* pro = nullptr, const ResW* shortcut = nullptr, float* shortcut_out = nullptr,
                  bool xb = false, bool yb = false) {
-        auto it = x->bf16_of.find(Wt);
-        if (fast_conv(X.C, Cout) && it != x->bf16_of.end()) {
+        auto it = x->lp_of().find(Wt);
+        if (fast_conv(X.C, Cout) && it != x->lp_of().end()) {
             Conv3P c{};
             c.x_bf16 = xb ? 1 : 0; c.y_bf16 = yb ? 1 : 0;
             c.X = X.p; c.ldx = X.ld; c.x_coff = X.coff; c.H = H; c.W = W; c.Cin = X.C; c.Cout = Cout;
@@ -709,14 +717,14 @@ struct Runner {
             if (pro) { c.pro_stats = pro->stats; c.pro_gamma = pro->gamma; c.pro_beta = pro->beta; c.pro_tadd = pro->tadd; c.pro_res = pro->res; c.pro_xout = pro->xout; }
             c.step = sp; c.gn_stats = gn; c.B = P.d.B;
             if (shortcut) {       // the block's 1x1 res_conv rides on the centre tap of this conv
-                c.res_w = x->bf16_of.at(shortcut->wr); c.res_b = shortcut->br; c.res_y = shortcut_out;
+                c.res_w = x->lp_of().at(shortcut->wr); c.res_b = shortcut->br; c.res_y = shortcut_out;
             }
             const double M = (double)H * W * P.d.B;
             // algorithmic bytes: input + output at their stored width, + the residual read and the x write-out of the PRO2 form,
             // + the shortcut output of the RES form, + the weights once
             const double bytes = M * ((xb ? 2.0 : 4.0) * X.C + (yb ? 2.0 : 4.0) * Cout + (pro && pro->res ? 8.0 * X.C : 0.0) + (shortcut ? 4.0 * Cout : 0.0))
                                  + 2.0 * 9 * X.C * Cout;
-            run(name, 2.0 * M * Cout * (9 * X.C + (shortcut ? X.C : 0)), bytes, [&] { launch_conv3x3_bf16(c, st); });
+            run(name, 2.0 * M * Cout * (9 * X.C + (shortcut ? X.C : 0)), bytes, [&] { launch_conv3x3_lp(c, x->precision, st); });
             return;
         }
         IGemmP g = base_gemm(X.p, X.ld, X.coff, H, W, X.C, Wt, Cout, bias, out, Cout, 0);
@@ -753,13 +761,13 @@ struct Runner {
         gnfix_t* st1 = nullptr;
         // h1 / h2 of this block as bf16: conv2 must be the GroupNorm-prologue conv that can read bf16, conv1 a kernel that can
         // write it; h2 additionally needs a fused consumer (the next block's first conv or the attention's context pass)
-        const bool conv2_fast = fast_conv(w.cout, w.cout) && conv3x3_bf16_xb_supported(w.cout, w.cout) && x->bf16_of.count(w.w2);
-        const bool conv1_fast = first_layer || (head ? true : (fast_conv(X.C, w.cout) && x->bf16_of.count(w.w1)));
+        const bool conv2_fast = fast_conv(w.cout, w.cout) && conv3x3_bf16_xb_supported(w.cout, w.cout) && x->lp_of().count(w.w2);
+        const bool conv1_fast = first_layer || (head ? true : (fast_conv(X.C, w.cout) && x->lp_of().count(w.w1)));
         const bool h1b = h_bf16() && conv2_fast && conv1_fast;
         const bool h2b = h_bf16() && conv2_fast && (ctail || tail);
         if (first_layer) {
             FirstConvP f{};
-            f.h1_bf16 = h1b ? 1 : 0;
+            f.h1_bf16 = h1b ? x->lp_kind() : 0;
             f.mu = mu; f.x = xcur; f.spk = P.spk_plane; f.mask = mask; f.B = P.d.B; f.H = s.H; f.T = s.W; f.planes = w.cin; f.C = w.cout;
             f.W3 = w.w1; f.b3 = w.b1; f.W1 = w.wr; f.b1 = w.br; f.scal = P.scal; f.scal_stride = SCAL_STRIDE; f.step = sp;
             f.h1 = s.h1; f.res = s.rbuf;
@@ -773,7 +781,7 @@ struct Runner {
                 TD H2{s.h2, X.C, 0, X.C};                  // previous block's raw conv2 output
                 conv3x3("conv3x3", H2, s.H, s.W, s.mask_ws, true, w.w1, w.b1, w.cout, s.h1, st1, head, nullptr, nullptr, head->x_bf16, h1b);
             } else {
-                fused_res = w.wr && fast_conv(X.C, w.cout) && conv3x3_bf16_res_supported(X.C, w.cout) && x->bf16_of.count(w.wr);
+                fused_res = w.wr && fast_conv(X.C, w.cout) && conv3x3_bf16_res_supported(X.C, w.cout) && x->lp_of().count(w.wr);
                 conv3x3("conv3x3", X, s.H, s.W, s.mask_ws, true, w.w1, w.b1, w.cout, s.h1, st1, nullptr, fused_res ? &w : nullptr, s.rbuf, false, h1b);
             }
             if (fused_res) {
@@ -815,10 +823,10 @@ struct Runner {
     }
 
     // Residual(Rezero(LinearAttention)) (diffusion.py:74-102)
-    bool linattn_fused(int C) const { return x->precision == DEX_PREC_BF16 && (C == 64 || C == 128); }
+    bool linattn_fused(int C) const { return x->lp() && (C == 64 || C == 128); }
     void linattn(const LinW& w, const StageBuf& s, const TD& X, float* out, int ldo, int ocoff, const LinKvCtxP* tail = nullptr) {
         const long npix = s.npix; const int B = P.d.B;
-        if (x->precision == DEX_PREC_BF16 && (X.C == 64 || X.C == 128)) {
+        if (x->lp() && (X.C == 64 || X.C == 128)) {
             // fused: y = x + W2 (Wq x) + g*b  with  W2 = g Wout blockdiag(ctx^T)   (linattn_fused.hip)
             int nsub = 1;
             // measured at 80x512, B=1: 320 / 160 / 80 workgroups -> context 19.9 / 13.7 / 19.4 us, merge 8.7 / 6.1 / 4.7 us
@@ -826,13 +834,13 @@ struct Runner {
             const int nblk = (int)((npix + 128L * nsub - 1) / (128L * nsub));
             LinKvCtxP k{};
             if (tail) k = *tail;
-            k.X = X.p; k.ldx = X.ld; k.x_coff = X.coff; k.xb = npix * X.ld; k.npix = (int)npix; k.C = X.C; k.Wkv = w.wkv_bf16;
+            k.X = X.p; k.ldx = X.ld; k.x_coff = X.coff; k.xb = npix * X.ld; k.npix = (int)npix; k.C = X.C; k.Wkv = w.wkv_lp[x->lpi()];
             k.nsub = nsub; k.nblk = nblk; k.part_m = s.pm; k.part_s = s.ps; k.part_c = s.pc; k.B = B;
-            run("linattn_kvctx", 2.0 * npix * B * (256.0 * X.C + 128 * 32), (tail ? (tail->h2_bf16 ? 10.0 : 12.0) : 4.0) * npix * X.C * B, [&] { launch_linattn_kvctx(k, st); });
+            run("linattn_kvctx", 2.0 * npix * B * (256.0 * X.C + 128 * 32), (tail ? (tail->h2_bf16 ? 10.0 : 12.0) : 4.0) * npix * X.C * B, [&] { launch_linattn_kvctx(k, x->precision, st); });
             LinMergeP mg{s.pm, s.ps, s.pc, nblk, w.wout_raw, w.g, X.C, s.mbf, B};
-            run("linattn_merge", 2.0 * 128 * 32 * X.C * B, 4.0 * nblk * 4 * 1088 * B, [&] { launch_linattn_merge(mg, st); });
-            LinOut2P o{X.p, X.ld, X.coff, npix * X.ld, (int)npix, X.C, w.wq_frag, s.mbf, w.bias_eff, out, ldo, ocoff, npix * ldo, B};
-            run("linattn_out", 4.0 * npix * B * 128.0 * X.C, 8.0 * npix * X.C * B, [&] { launch_linattn_out2(o, st); });
+            run("linattn_merge", 2.0 * 128 * 32 * X.C * B, 4.0 * nblk * 4 * 1088 * B, [&] { launch_linattn_merge(mg, x->precision, st); });
+            LinOut2P o{X.p, X.ld, X.coff, npix * X.ld, (int)npix, X.C, w.wq_frag[x->lpi()], s.mbf, w.bias_eff, out, ldo, ocoff, npix * ldo, B};
+            run("linattn_out", 4.0 * npix * B * 128.0 * X.C, 8.0 * npix * X.C * B, [&] { launch_linattn_out2(o, x->precision, st); });
             return;
         }
         IGemmP g = base_gemm(X.p, X.ld, X.coff, s.H, s.W, X.C, w.wqkv, 384, nullptr, s.qkv, 384, 0);
@@ -862,9 +870,9 @@ struct Runner {
         // grouped 16x16 pos-conv, split-K partials (bias added in the tail)
         const int G = c.dit_conv_pos_groups, kp = c.dit_conv_pos, cg = hid / G;
         int nsplit = POS_SPLIT;
-        if (x->precision == DEX_PREC_BF16 && x->pos_wfrag) {
-            PosConvP pcd{P.emb, x->pos_wfrag, P.pos_part, P.Hf, P.Wt, hid, G, B};
-            run("pos_conv", 2.0 * B * N * (double)kp * kp * cg * hid, 8.0 * B * N * hid + 2.0 * kp * kp * cg * hid, [&] { launch_pos_conv_direct(pcd, st); });
+        if (x->lp() && x->pos_wfrag[x->lpi()]) {
+            PosConvP pcd{P.emb, x->pos_wfrag[x->lpi()], P.pos_part, P.Hf, P.Wt, hid, G, B};
+            run("pos_conv", 2.0 * B * N * (double)kp * kp * cg * hid, 8.0 * B * N * hid + 2.0 * kp * kp * cg * hid, [&] { launch_pos_conv_direct(pcd, x->precision, st); });
             nsplit = 1;
         } else {
             IGemmP pc = base_gemm(P.emb, hid, 0, P.Hf, P.Wt, cg, x->pos_w, cg, nullptr, P.pos_part, hid, 0);
@@ -877,11 +885,11 @@ struct Runner {
         if (debug) hipMemcpyAsync(P.dbg_tok, P.tok, (size_t)B * N * hid * 4, hipMemcpyDeviceToDevice, st);
         tap("tok_in", P.dbg_tok, (long)B * N, hid, hid);
         const float scale = 1.0f / sqrtf((float)(hid / c.dit_heads));
-        const bool chain = x->precision == DEX_PREC_BF16 && dit_rowchain_supported(hid, mh) && c.dit_heads == 2 && x->frag_of.count(x->blocks[0].wproj);
+        const bool chain = x->lp() && dit_rowchain_supported(hid, mh) && c.dit_heads == 2 && x->frag_of().count(x->blocks[0].wproj);
         for (int k = 0; k < c.dit_depth; ++k) {
             const DitBlockW& w = x->blocks[k];
             const float* ada = P.ada[k];
-            const bool fuse_ln = x->precision == DEX_PREC_BF16;      // LayerNorm+modulate inside the GEMM's A staging
+            const bool fuse_ln = x->lp();      // LayerNorm+modulate inside the GEMM's A staging
             DitChainP ch{};
             if (chain) {
                 ch.ksplit = 0; ch.heads = c.dit_heads; ch.rows_per_batch = N; ch.X = P.tok; ch.ada = ada; ch.step = sp; ch.M = B * N; ch.B = B;
@@ -892,10 +900,10 @@ struct Runner {
                 ch.qscale = scale * 1.4426950408889634f;      // log2(e) folded in: the attention kernels use exp2
             }
             if (chain && k == 0) {                                   // first block: LN + modulate + qkv only
-                ch.qkv_only = 1; ch.Wq = x->frag_of.at(w.wqkv); ch.bq = w.bqkv;
+                ch.qkv_only = 1; ch.Wq = x->frag_of().at(w.wqkv); ch.bq = w.bqkv;
                 ch.Qh = P.qh; ch.Kh = P.kh; ch.Vt = P.vt;        // block 0 reads set 0
                 ch.next_shift = ada; ch.next_scale = ada + hid; ch.next_step_stride = 6L * hid;
-                run("dit_qkv", 2.0 * B * N * 3.0 * hid * hid, 4.0 * B * N * hid + 2.0 * B * N * 3 * hid, [&] { launch_dit_rowchain(ch, st); });
+                run("dit_qkv", 2.0 * B * N * 3.0 * hid * hid, 4.0 * B * N * hid + 2.0 * B * N * 3 * hid, [&] { launch_dit_rowchain(ch, x->precision, st); });
                 ch.qkv_only = 0; ch.Wq = nullptr; ch.bq = nullptr; ch.next_shift = ch.next_scale = nullptr;
                 ch.Qh = P.qh2; ch.Kh = P.kh2; ch.Vt = P.vt2;     // ... and writes set 1
             }
@@ -922,22 +930,22 @@ struct Runner {
                     const int ntiles = (N + 31) / 32;
                     ks = (int)std::max<long>(1, std::min<long>(std::min<long>(768 / blocks, (ntiles + 7) / 8), ATT_KSPLIT_MAX));
                     AttnDirectP ad{ch.Qin, ch.Kin, ch.Vin, N, P.Npad, B, P.ao, (long)B * N * hid, ks > 1 ? P.att_ml : nullptr, ks, nullptr};
-                    run("dit_attention", 4.0 * B * (double)N * N * hid, 2.0 * 3 * B * N * hid + 4.0 * B * N * hid * ks, [&] { launch_attention_direct(ad, st); });
+                    run("dit_attention", 4.0 * B * (double)N * N * hid, 2.0 * 3 * B * N * hid + 4.0 * B * N * hid * ks, [&] { launch_attention_direct(ad, x->precision, st); });
                 }
                 ch.attn_inline = separate ? 0 : 1;
                 const bool last = k + 1 == c.dit_depth;
                 ch.O = P.ao; ch.ksplit = ks; ch.o_sstride = (long)B * N * hid; ch.ml = P.att_ml;
-                ch.Wp = x->frag_of.at(w.wproj); ch.W1 = x->frag_of.at(w.wfc1); ch.W2 = x->frag_of.at(w.wfc2);
+                ch.Wp = x->frag_of().at(w.wproj); ch.W1 = x->frag_of().at(w.wfc1); ch.W2 = x->frag_of().at(w.wfc2);
                 ch.bp = w.bproj; ch.b1 = w.bfc1; ch.b2 = w.bfc2;
                 if (!last) {
                     const DitBlockW& wn = x->blocks[k + 1];
-                    ch.Wq = x->frag_of.at(wn.wqkv); ch.bq = wn.bqkv;
+                    ch.Wq = x->frag_of().at(wn.wqkv); ch.bq = wn.bqkv;
                     ch.next_shift = P.ada[k + 1]; ch.next_scale = P.ada[k + 1] + hid; ch.next_step_stride = 6L * hid;
                 }
                 const double M = (double)B * N;
                 const double wel = (double)hid * hid + 2.0 * hid * mh + (last ? 0.0 : 3.0 * hid * hid);
                 run(separate ? "dit_rowchain" : "dit_block", 2.0 * M * wel + (separate ? 0.0 : 4.0 * B * (double)N * N * hid),
-                    4.0 * M * hid * (last ? 3 : 6) + 2.0 * wel, [&] { launch_dit_rowchain(ch, st); });
+                    4.0 * M * hid * (last ? 3 : 6) + 2.0 * wel, [&] { launch_dit_rowchain(ch, x->precision, st); });
                 if (debug) {
                     float* dst = P.dbg_tok + (size_t)(k + 1) * B * N * hid;
                     hipMemcpyAsync(dst, P.tok, (size_t)B * N * hid * 4, hipMemcpyDeviceToDevice, st);
@@ -975,7 +983,7 @@ struct Runner {
                 tap(nm, dst, (long)B * N, hid, hid);
             }
         }
-        const bool fuse_lnf = x->precision == DEX_PREC_BF16;
+        const bool fuse_lnf = x->lp();
         const int s2c = c.dit_stride * c.dit_stride * mid;
         IGemmP fl = base_gemm(fuse_lnf ? P.tok : P.xn, hid, 0, P.Hf, P.Wt, hid, x->fl_w, s2c, x->fl_b, out, ldo, ocoff);
         if (fuse_lnf) { fl.ln_shift = P.fin_mod; fl.ln_scale = P.fin_mod + hid; fl.ln_step_stride = 2L * hid; }
@@ -998,8 +1006,8 @@ struct Runner {
         // time-token kernel, which runs after their last reader)
         InStatsP is{X.p + X.coff, X.ld, npix * X.ld, (int)npix, mid, P.tv_stats, B, mask, mask_ws, (long)P.d.T, P.Wm};
         run("in2d_stats", 3.0 * npix * mid * B, 4.0 * npix * mid * B, [&] { launch_in_stats(is, st); });
-        const bool qbf = x->precision == DEX_PREC_BF16;     // bf16 mode: the folded per-utterance weight is written as the bf16 GEMM operand
-        InFoldP fo{P.tv_stats, (int)npix, 1e-5f, x->tv_wq_raw, mid, P.tv_weff, P.tv_beff, B, qbf ? P.tv_wbf : nullptr};
+        const bool qbf = x->lp();      // reduced-precision modes: the folded per-utterance weight is written as the MFMA GEMM operand
+        InFoldP fo{P.tv_stats, (int)npix, 1e-5f, x->tv_wq_raw, mid, P.tv_weff, P.tv_beff, B, qbf ? P.tv_wbf : nullptr, x->lp_kind()};
         run("tv_fold_in2d", 2.0 * mid * mid * B, 8.0 * mid * mid * B, [&] { launch_in_fold(fo, st); });
         IGemmP q = base_gemm(X.p, X.ld, X.coff, P.Hm, P.Wm, mid, P.tv_weff, mid, P.tv_beff, P.tv_q, mid, 0);
         q.w_bstride = (long)mid * mid; q.bias_bstride = mid; q.inmask = mask; q.inmask_ws = mask_ws;
@@ -1038,7 +1046,7 @@ struct Runner {
             // block 0's tail (GN-apply + Mish + res_conv shortcut) rides in block 1's first conv when that conv has the
             // fused form (bf16 mode, 64/128 channels, block 0 has a res_conv)
             Pro t0{};
-            const bool defer0 = x->precision == DEX_PREC_BF16 && conv3x3_bf16_tail_supported(s.C) && fast_conv(s.C, s.C) &&
+            const bool defer0 = x->lp() && conv3x3_bf16_tail_supported(s.C) && fast_conv(s.C, s.C) &&
                                 (i == 0 || x->down_res[i][0].wr != nullptr);
             resblock(x->down_res[i][0], s, cur, P.tadd_down[2 * i], s.r0out, i == 0, nullptr, nullptr, defer0 ? &t0 : nullptr);
             TD r0{s.r0out, s.C, 0, s.C};
@@ -1076,7 +1084,7 @@ struct Runner {
             const int i = ns - 1 - j;
             TD X{P.cat[j], 2 * stage_dim(c, i), 0, 2 * stage_dim(c, i)};
             Pro t0{};
-            const bool defer0 = x->precision == DEX_PREC_BF16 && conv3x3_bf16_tail_supported(s.C) && fast_conv(s.C, s.C) &&
+            const bool defer0 = x->lp() && conv3x3_bf16_tail_supported(s.C) && fast_conv(s.C, s.C) &&
                                 x->up_res[j][0].wr != nullptr;
             resblock(x->up_res[j][0], s, X, P.tadd_up[2 * j], s.r0out, false, nullptr, nullptr, defer0 ? &t0 : nullptr);
             TD r0{s.r0out, s.C, 0, s.C};
@@ -1102,10 +1110,10 @@ struct Runner {
         tap("up_out", P.up_out, (long)B * 80 * P.d.T, c.dim, c.dim);
         TD U{P.up_out, c.dim, 0, c.dim};
         gnfix_t* stf = next_stats();
-        const bool hfb = h_bf16() && fast_conv(c.dim, c.dim) && x->bf16_of.count(x->fin_w);
+        const bool hfb = h_bf16() && fast_conv(c.dim, c.dim) && x->lp_of().count(x->fin_w);
         conv3x3("conv3x3", U, 80, P.d.T, 1, true, x->fin_w, x->fin_b, c.dim, P.hF, stf, nullptr, nullptr, nullptr, false, hfb);
         FinalP f{};
-        f.x_bf16 = hfb ? 1 : 0;
+        f.x_bf16 = hfb ? x->lp_kind() : 0;
         f.X = P.hF; f.xb = 80L * P.d.T * c.dim; f.npix = 80 * P.d.T; f.W = P.d.T; f.C = c.dim; f.groups = 8; f.stats = stf;
         f.gamma = x->fin_g; f.beta = x->fin_be; f.mask = mask; f.mask_bstride = P.d.T; f.wfc = x->fconv_w; f.bfc = x->fconv_b;
         f.xcur = xcur; f.denoised = denoised; f.xnext = xnext; f.scal = P.scal; f.scal_stride = SCAL_STRIDE; f.step = sp; f.B = B;

@@ -146,8 +146,8 @@ __global__ __launch_bounds__(256) void in_fold_kernel(const InFoldP p) {
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
                     const float4 w = *reinterpret_cast<const float4*>(p.Wq + (long)n * C + k0 + q4 * 4);
-                    ow[q4 * 2] = pack2_bf16(w.x * srstd[q4 * 4], w.y * srstd[q4 * 4 + 1]);
-                    ow[q4 * 2 + 1] = pack2_bf16(w.z * srstd[q4 * 4 + 2], w.w * srstd[q4 * 4 + 3]);
+                    ow[q4 * 2] = pack2_kind(w.x * srstd[q4 * 4], w.y * srstd[q4 * 4 + 1], p.lp);
+                    ow[q4 * 2 + 1] = pack2_kind(w.z * srstd[q4 * 4 + 2], w.w * srstd[q4 * 4 + 3], p.lp);
                 }
                 *reinterpret_cast<uint4*>(Wo + (long)n * C + k0) = o[0];
                 *reinterpret_cast<uint4*>(Wo + (long)n * C + k0 + 8) = o[1];

@@ -9,18 +9,19 @@
 // ~0.3 GFLOP.  Here a workgroup of 8 waves owns a 32-row tile and walks the whole chain with the activations in
 // LDS (bf16 MFMA A operands, fp32 residual stream); each wave owns 32-column slices of every weight matrix and
 // streams them from L2 straight into MFMA B-operand registers.  Weights are host-packed in fragment order
-// (`pack_bf16_frag_kernel`: one 1-KB contiguous read per wave per K-step of 16) and double-buffered one 16-KB
+// (`pack_lp_frag_kernel`: one 1-KB contiguous read per wave per K-step of 16) and double-buffered one 16-KB
 // tile ahead, across stage boundaries — weights never depend on the data.
 //
 // Accumulator layout (32x32x16 bf16): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
 #include <hip/hip_runtime.h>
 #include "kernels.h"
-#include "bf16_util.h"
+#include "lp_util.h"
+#include "kernels_lp.h"
 
 namespace dex {
+namespace DEX_LP_NS {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
 namespace {
@@ -71,7 +72,7 @@ __device__ __forceinline__ void mma16(f32x16& acc, const uint4 (&w)[16], const u
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[j]), __builtin_bit_cast(bf16x8, w[h * 8 + j]), acc, 0, 0, 0);
+            acc = DEX_MFMA_LP(__builtin_bit_cast(lp8, a[j]), __builtin_bit_cast(lp8, w[h * 8 + j]), acc, 0, 0, 0);
     }
 }
 
@@ -107,8 +108,8 @@ __device__ __forceinline__ void ln_to_A(const float* X1, u16* As, const float* s
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         uint2 o;
-        o.x = pack2_bf16(v[q].x * rstd * (1.f + sc[q].x) + sh[q].x, v[q].y * rstd * (1.f + sc[q].y) + sh[q].y);
-        o.y = pack2_bf16(v[q].z * rstd * (1.f + sc[q].z) + sh[q].z, v[q].w * rstd * (1.f + sc[q].w) + sh[q].w);
+        o.x = pack2_lp(v[q].x * rstd * (1.f + sc[q].x) + sh[q].x, v[q].y * rstd * (1.f + sc[q].y) + sh[q].y);
+        o.y = pack2_lp(v[q].z * rstd * (1.f + sc[q].z) + sh[q].z, v[q].w * rstd * (1.f + sc[q].w) + sh[q].w);
         *reinterpret_cast<uint2*>(As + row * A_LD + q * 64 + seg * 4) = o;
     }
 }
@@ -130,7 +131,7 @@ __device__ __forceinline__ void store_qkv_tile(const DitChainP& p, const f32x16&
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-        scr[row * QK_LD + i] = (u16)(pack2_bf16((acc[r] + bias) * sc, 0.f) & 0xffffu);
+        scr[row * QK_LD + i] = (u16)(pack2_lp((acc[r] + bias) * sc, 0.f) & 0xffffu);
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);                  // lgkmcnt(0): this wave's scratch writes landed
     __builtin_amdgcn_wave_barrier();
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
     f32x16 ao[4];
     float am = -INFINITY, al = 0.f;
     if constexpr (ATTN) {
-        union DFr { uint4 u; bf16x8 v; };
+        union DFr { uint4 u; lp8 v; };
         const int head = wave >> 2, part = wave & 3;
         const long hbq = ((long)b * 2 + head) * p.Npad * 16;
         const uint4* Qg = reinterpret_cast<const uint4*>(p.Qin) + hbq + lane;
@@ -248,7 +249,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
 #pragma unroll
             for (int r = 0; r < 16; ++r) sc[r] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 8; ++ks) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks].v, qf[ks].v, sc, 0, 0, 0);
+            for (int ks = 0; ks < 8; ++ks) sc = DEX_MFMA_LP(kf[ks].v, qf[ks].v, sc, 0, 0, 0);
             if (kn < ntiles) {
                 const uint4* kp = Kg + (long)kn * 512;
 #pragma unroll
@@ -279,10 +280,10 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
                 DFr pb;
-                pb.u.x = pack2_bf16(sc[8 * k2 + 0], sc[8 * k2 + 1]); pb.u.y = pack2_bf16(sc[8 * k2 + 2], sc[8 * k2 + 3]);
-                pb.u.z = pack2_bf16(sc[8 * k2 + 4], sc[8 * k2 + 5]); pb.u.w = pack2_bf16(sc[8 * k2 + 6], sc[8 * k2 + 7]);
+                pb.u.x = pack2_lp(sc[8 * k2 + 0], sc[8 * k2 + 1]); pb.u.y = pack2_lp(sc[8 * k2 + 2], sc[8 * k2 + 3]);
+                pb.u.z = pack2_lp(sc[8 * k2 + 4], sc[8 * k2 + 5]); pb.u.w = pack2_lp(sc[8 * k2 + 6], sc[8 * k2 + 7]);
 #pragma unroll
-                for (int t = 0; t < 4; ++t) ao[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[t][k2].v, pb.v, ao[t], 0, 0, 0);
+                for (int t = 0; t < 4; ++t) ao[t] = DEX_MFMA_LP(vf[t][k2].v, pb.v, ao[t], 0, 0, 0);
             }
             if (kn < ntiles) {
                 const uint4* vp = Vg + (long)kn * 512;
@@ -392,7 +393,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             uint2 o;
-            o.x = pack2_bf16(v[q].x, v[q].y); o.y = pack2_bf16(v[q].z, v[q].w);
+            o.x = pack2_lp(v[q].x, v[q].y); o.y = pack2_lp(v[q].z, v[q].w);
             *reinterpret_cast<uint2*>(As + row * A_LD + q * 64 + seg * 4) = o;
         }
     }
@@ -431,7 +432,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-        Hs[row * H_LD + col] = (u16)(pack2_bf16(gelu_erf_rc(acc[r] + b_1a), 0.f) & 0xffffu);
+        Hs[row * H_LD + col] = (u16)(pack2_lp(gelu_erf_rc(acc[r] + b_1a), 0.f) & 0xffffu);
     }
     wload(wb, p.W2, 32, wave, 0, lane);
     acc = zero16();
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
-        Hs[row * H_LD + col + 256] = (u16)(pack2_bf16(gelu_erf_rc(acc[r] + b_1b), 0.f) & 0xffffu);
+        Hs[row * H_LD + col + 256] = (u16)(pack2_lp(gelu_erf_rc(acc[r] + b_1b), 0.f) & 0xffffu);
     }
     lds_barrier();
 #ifdef DEX_TIMING
@@ -523,32 +524,33 @@ void launch_dit_rowchain(const DitChainP& p, hipStream_t st) {
 
 // fp32 [K][N] -> bf16 in MFMA B-fragment order: dst[((nt * K/16 + ks) * 64 + lane) * 8 + j] =
 // W[k = ks*16 + (lane >> 5)*8 + j][n = nt*32 + (lane & 31)]
-__global__ void pack_bf16_frag_kernel(const float* __restrict__ src, u16* __restrict__ dst, int K, int N) {
+__global__ void pack_lp_frag_kernel(const float* __restrict__ src, u16* __restrict__ dst, int K, int N) {
     const long total = (long)K * N;
     for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
         const int j = (int)(o & 7), lane = (int)((o >> 3) & 63);
         const long t = o >> 9;
         const int ks = (int)(t % (K / 16)), nt = (int)(t / (K / 16));
         const int k = ks * 16 + (lane >> 5) * 8 + j, n = nt * 32 + (lane & 31);
-        dst[o] = (u16)(pack2_bf16(src[(long)k * N + n], 0.f) & 0xffffu);
+        dst[o] = (u16)(pack2_lp(src[(long)k * N + n], 0.f) & 0xffffu);
     }
 }
 // same fragment order from a row-major [N][K] source (nn.Linear / 1x1-conv weight layout)
-__global__ void pack_bf16_frag_nk_kernel(const float* __restrict__ src, u16* __restrict__ dst, int K, int N) {
+__global__ void pack_lp_frag_nk_kernel(const float* __restrict__ src, u16* __restrict__ dst, int K, int N) {
     const long total = (long)K * N;
     for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
         const int j = (int)(o & 7), lane = (int)((o >> 3) & 63);
         const long t = o >> 9;
         const int ks = (int)(t % (K / 16)), nt = (int)(t / (K / 16));
         const int k = ks * 16 + (lane >> 5) * 8 + j, n = nt * 32 + (lane & 31);
-        dst[o] = (u16)(pack2_bf16(src[(long)n * K + k], 0.f) & 0xffffu);
+        dst[o] = (u16)(pack2_lp(src[(long)n * K + k], 0.f) & 0xffffu);
     }
 }
-void launch_pack_bf16_frag_nk(const float* src, void* dst, int K, int N, hipStream_t st) {
-    hipLaunchKernelGGL(pack_bf16_frag_nk_kernel, dim3(256), dim3(256), 0, st, src, reinterpret_cast<u16*>(dst), K, N);
+void launch_pack_lp_frag_nk(const float* src, void* dst, int K, int N, hipStream_t st) {
+    hipLaunchKernelGGL(pack_lp_frag_nk_kernel, dim3(256), dim3(256), 0, st, src, reinterpret_cast<u16*>(dst), K, N);
 }
-void launch_pack_bf16_frag(const float* src, void* dst, int K, int N, hipStream_t st) {
-    hipLaunchKernelGGL(pack_bf16_frag_kernel, dim3(256), dim3(256), 0, st, src, reinterpret_cast<u16*>(dst), K, N);
+void launch_pack_lp_frag(const float* src, void* dst, int K, int N, hipStream_t st) {
+    hipLaunchKernelGGL(pack_lp_frag_kernel, dim3(256), dim3(256), 0, st, src, reinterpret_cast<u16*>(dst), K, N);
 }
 
+}  // namespace DEX_LP_NS
 }  // namespace dex

@@ -123,10 +123,10 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
     igemm_epilogue<MT>(p, acc, m0, n0, wm * (MT * 32), wn * 32, lane, b, g, s, M, oh0, ow0);
 }
 
-void launch_igemm_bf16(const IGemmP& p, hipStream_t st);   // igemm_bf16.hip
+void launch_igemm_lp(const IGemmP& p, int precision, hipStream_t st);   // lp_dispatch.hip -> igemm_bf16.hip (bf16 / fp16 build)
 
 void launch_igemm(const IGemmP& p, int precision, hipStream_t st) {
-    if (precision == 1 && p.Wbf != nullptr) { launch_igemm_bf16(p, st); return; }
+    if (prec_is_lp(precision) && p.Wbf != nullptr) { launch_igemm_lp(p, precision, st); return; }
     const int M = p.Ho * p.Wo;
     const int zdim = p.B * p.groups * p.ksplit * (p.parity ? 4 : 1);
     if (p.N % 64 == 0) {

@@ -3,12 +3,13 @@
 // Same gather semantics and the same epilogue as igemm.hip.  LDS tiles are row-major [rows][BK+8] bf16:
 // the 16-byte pad makes every ds_read_b128 / ds_write_b128 lane group hit 64 distinct banks.
 #include "kernels.h"
-#include "bf16_util.h"
+#include "lp_util.h"
+#include "kernels_lp.h"
 #include "igemm_epilogue.h"
 
 namespace dex {
+namespace DEX_LP_NS {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
 
@@ -44,7 +45,7 @@ __device__ __forceinline__ void igemm_load_tile(const IGemmP& p, float4 (&fa)[AP
 // code does the compiler keep exact vmcnt(N) waits (inside a loop it falls back to vmcnt(0) at every LDS store,
 // which serialises the ring: measured 19 -> 24.5 us on the stride-2 downsample conv before unrolling).
 template <int BM, int BN, int BK, bool PT = false, int D = 1, int NKT = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void igemm_bf16_kernel(const IGemmP p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void igemm_lp_kernel(const IGemmP p) {
     constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (WM * 32);
     constexpr int TPR = BK / 8;                 // threads per tile row (8 elements each)
     constexpr int RPP = 256 / TPR;              // rows per pass
@@ -125,8 +126,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                 const float mk = has_mask ? mul_pinned(fm[d][j], fo[d][j]) : fo[d][j];
                 const float4 f0 = fa[d][j][0], f1 = fa[d][j][1];
                 uint4 v;
-                v.x = pack2_mul_bf16_pinned(f0.x, f0.y, mk); v.y = pack2_mul_bf16_pinned(f0.z, f0.w, mk);
-                v.z = pack2_mul_bf16_pinned(f1.x, f1.y, mk); v.w = pack2_mul_bf16_pinned(f1.z, f1.w, mk);
+                v.x = pack2_mul_lp_pinned(f0.x, f0.y, mk); v.y = pack2_mul_lp_pinned(f0.z, f0.w, mk);
+                v.z = pack2_mul_lp_pinned(f1.x, f1.y, mk); v.w = pack2_mul_lp_pinned(f1.z, f1.w, mk);
                 *reinterpret_cast<uint4*>(As + (trow + RPP * j) * LDS_LD + tk8) = v;
             }
             if (BN >= RPP || trow < BN) *reinterpret_cast<uint4*>(Bs + trow * LDS_LD + tk8) = rb0[d];
@@ -138,11 +139,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             const u16* bp = Bs + (wn * 32 + i) * LDS_LD + hh * 8;
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
-                const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bp + ks * 16);
+                const lp8 bf = *reinterpret_cast<const lp8*>(bp + ks * 16);
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
-                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(ap + t * 32 * LDS_LD + ks * 16);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
+                    const lp8 af = *reinterpret_cast<const lp8*>(ap + t * 32 * LDS_LD + ks * 16);
+                    acc[t] = DEX_MFMA_LP(af, bf, acc[t], 0, 0, 0);
                 }
             }
         }
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // are pure latency: 4-8 exposed round trips at ~1.2 us each).  Optional fused prologue on the A rows:
 // LayerNorm(eps 1e-6, no affine) + adaLN modulate (dit.py:78-79,288-289) when the row IS the K extent.
 template <int BM, int BN, int K>
-__global__ __launch_bounds__(256) void igemm_bf16_ss_kernel(const IGemmP p) {
+__global__ __launch_bounds__(256) void igemm_lp_ss_kernel(const IGemmP p) {
     constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (WM * 32);
     constexpr int LDS_LD = K + 8, KC = K / 8;               // KC: 8-element chunks per row (power of two <= 64)
     constexpr int AIT = BM * KC / 256, BIT = BN * KC / 256; // items per thread
@@ -243,8 +244,8 @@ __global__ __launch_bounds__(256) void igemm_bf16_ss_kernel(const IGemmP p) {
             }
             const float m_ = mk[j];
             uint4 v;
-            v.x = pack2_bf16(a.x * m_, a.y * m_); v.y = pack2_bf16(a.z * m_, a.w * m_);
-            v.z = pack2_bf16(c.x * m_, c.y * m_); v.w = pack2_bf16(c.z * m_, c.w * m_);
+            v.x = pack2_lp(a.x * m_, a.y * m_); v.y = pack2_lp(a.z * m_, a.w * m_);
+            v.z = pack2_lp(c.x * m_, c.y * m_); v.w = pack2_lp(c.z * m_, c.w * m_);
             *reinterpret_cast<uint4*>(As + row * LDS_LD + k8) = v;
         }
     }
@@ -258,11 +259,11 @@ __global__ __launch_bounds__(256) void igemm_bf16_ss_kernel(const IGemmP p) {
     const u16* bp = Bs + (wn * 32 + i) * LDS_LD + hh * 8;
 #pragma unroll
     for (int ks = 0; ks < K / 16; ++ks) {
-        const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bp + ks * 16);
+        const lp8 bf = *reinterpret_cast<const lp8*>(bp + ks * 16);
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
-            const bf16x8 af = *reinterpret_cast<const bf16x8*>(ap + t * 32 * LDS_LD + ks * 16);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
+            const lp8 af = *reinterpret_cast<const lp8*>(ap + t * 32 * LDS_LD + ks * 16);
+            acc[t] = DEX_MFMA_LP(af, bf, acc[t], 0, 0, 0);
         }
     }
     igemm_epilogue<MT>(p, acc, m0, n0, wm * (MT * 32), wn * 32, lane, b, 0, 0, M, oh0, ow0);
@@ -273,11 +274,11 @@ static void launch_ss(const IGemmP& p, hipStream_t st) {
     const size_t lds = (size_t)(64 + 64) * (K + 8) * sizeof(u16);
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_bf16_ss_kernel<64, 64, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_lp_ss_kernel<64, 64, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     dim3 grid((p.Ho * p.Wo + 63) / 64, p.N / 64, p.B * (p.parity ? 4 : 1));
-    hipLaunchKernelGGL((igemm_bf16_ss_kernel<64, 64, K>), grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((igemm_lp_ss_kernel<64, 64, K>), grid, dim3(256), lds, st, p);
 }
 
 static bool ss_eligible(const IGemmP& p) {
@@ -287,7 +288,7 @@ static bool ss_eligible(const IGemmP& p) {
     return blocks <= 4096 || p.ln_shift != nullptr;
 }
 
-void launch_igemm_bf16(const IGemmP& p, hipStream_t st) {
+void launch_igemm_lp(const IGemmP& p, hipStream_t st) {
     const int M = p.Ho * p.Wo;
     if (ss_eligible(p)) {
         if (p.K == 64) launch_ss<64>(p, st);
@@ -302,20 +303,21 @@ void launch_igemm_bf16(const IGemmP& p, hipStream_t st) {
         const long blocks128 = (long)((M + 127) / 128) * (p.N / 64) * zdim;
         if (blocks128 < 1024) {
             dim3 grid((M + 63) / 64, p.N / 64, zdim);
-            if (k64 && p.K / p.ksplit == 576) hipLaunchKernelGGL((igemm_bf16_kernel<64, 64, 64, false, 3, 9>), grid, dim3(256), 0, st, p);   // 3x3 x 64ch
-            else if (k64) hipLaunchKernelGGL((igemm_bf16_kernel<64, 64, 64>), grid, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((igemm_bf16_kernel<64, 64, 32>), grid, dim3(256), 0, st, p);
+            if (k64 && p.K / p.ksplit == 576) hipLaunchKernelGGL((igemm_lp_kernel<64, 64, 64, false, 3, 9>), grid, dim3(256), 0, st, p);   // 3x3 x 64ch
+            else if (k64) hipLaunchKernelGGL((igemm_lp_kernel<64, 64, 64>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((igemm_lp_kernel<64, 64, 32>), grid, dim3(256), 0, st, p);
         } else {
             dim3 grid((M + 127) / 128, p.N / 64, zdim);
-            if (k64) hipLaunchKernelGGL((igemm_bf16_kernel<128, 64, 64>), grid, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((igemm_bf16_kernel<128, 64, 32>), grid, dim3(256), 0, st, p);
+            if (k64) hipLaunchKernelGGL((igemm_lp_kernel<128, 64, 64>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((igemm_lp_kernel<128, 64, 32>), grid, dim3(256), 0, st, p);
         }
     } else {
         dim3 grid((M + 127) / 128, p.N / 32, zdim);
-        if (p.K / p.ksplit == 1024 && p.Cin % 8 == 0) hipLaunchKernelGGL((igemm_bf16_kernel<128, 32, 128, true, 2, 8>), grid, dim3(256), 0, st, p);   // pos-conv split
-        else if ((p.K / p.ksplit) % 128 == 0 && p.Cin % 8 == 0) hipLaunchKernelGGL((igemm_bf16_kernel<128, 32, 128, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((igemm_bf16_kernel<128, 32, 32>), grid, dim3(256), 0, st, p);
+        if (p.K / p.ksplit == 1024 && p.Cin % 8 == 0) hipLaunchKernelGGL((igemm_lp_kernel<128, 32, 128, true, 2, 8>), grid, dim3(256), 0, st, p);   // pos-conv split
+        else if ((p.K / p.ksplit) % 128 == 0 && p.Cin % 8 == 0) hipLaunchKernelGGL((igemm_lp_kernel<128, 32, 128, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((igemm_lp_kernel<128, 32, 32>), grid, dim3(256), 0, st, p);
     }
 }
 
+}  // namespace DEX_LP_NS
 }  // namespace dex

@@ -16,6 +16,16 @@ namespace dex {
 constexpr int GN_SLOTS = 32;
 typedef long long gnfix_t;
 
+// Profiling aid: launch functions that pick one of several template instantiations leave the chosen SYMBOL here, so the
+// library's event profile (dex_profile_get) names rows like rocprofv3's kernel trace does instead of by kernel class.
+extern thread_local const char* g_last_symbol;
+
+// Precision modes (== DexPrecision of include/dex_amd.h).  The reduced-precision kernels exist twice — namespace dex::bf16
+// and dex::f16, the same sources compiled for either operand type (lp_config.h) — and the launch functions below that
+// take a `precision` pick the namespace (lp_dispatch.hip).
+constexpr int PREC_FP32 = 0, PREC_BF16 = 1, PREC_FP16 = 2;
+inline bool prec_is_lp(int precision) { return precision != PREC_FP32; }
+
 // ------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution / linear:  C[m, n] = epi( sum_k gather(A)[m,k] * W[k,n] )
 //   m = (ho, wo) in an Ho x Wo grid per batch; k = tap*Cin + c; tap=(kh,kw);
@@ -75,10 +85,7 @@ bool conv3x3_bf16_supported(int Cin, int Cout);
 bool conv3x3_bf16_tail_supported(int C);     // pro_res form (Cin == Cout == C)
 bool conv3x3_bf16_res_supported(int Cin, int Cout);   // res_w form (fused 1x1 shortcut)
 bool conv3x3_bf16_xb_supported(int Cin, int Cout);    // x_bf16 form (bf16 input under a GroupNorm prologue)
-void launch_conv3x3_bf16(const Conv3P& p, hipStream_t st);
-// throughput form for large grids (conv3x3_stream.hip): iterations per workgroup, 0 = not applicable
-int conv3x3_stream_tiles(const Conv3P& p);
-void launch_conv3x3_stream(const Conv3P& p, int tiles_per_wg, hipStream_t st);
+void launch_conv3x3_lp(const Conv3P& p, int precision, hipStream_t st);   // picks the strip-streaming form (conv3x3_stream.hip) for large grids
 
 // First ResnetBlock of the U-Net: 3x3 conv and 1x1 res_conv straight from the stacked input planes
 // (mu, c_in*x[, spk]) * mask  (diffusion.py:171-175,185; edm.py:96).
@@ -89,7 +96,7 @@ struct FirstConvP {
     const float* W1; const float* b1;                     // [planes][C], [C]
     const float* scal; int scal_stride; const int* step;  // per-step scalars; scal[step*stride + 2] = c_in
     float* h1; float* res;                                // [B,H,T,C] each
-    int h1_bf16;                                          // h1 stored as bf16 (its only reader is the next conv's GN prologue)
+    int h1_bf16;                                          // h1 stored as bf16 (1) / fp16 (2): its only reader is the next conv's GN prologue
     gnfix_t* gn_stats;                                    // fused GroupNorm partials of h1 (8 groups, slot-spread) or null
 };
 void launch_first_conv(const FirstConvP& p, hipStream_t st);
@@ -125,7 +132,7 @@ struct FinalP {
     // mode 1: predictor - also stores the slope d_cur in dbuf (xnext receives x' = x_hat + h d_cur);
     // mode 2: corrector - xcur is x', xhat the state the step started from: xnext = xhat + h (0.5 d_cur + 0.5 d').
     int mode; const float* htab; float* dbuf; const float* xhat;
-    int x_bf16;                                           // X (the final conv's raw output) is bf16
+    int x_bf16;                                           // X (the final conv's raw output) is bf16 (1) / fp16 (2)
 };
 void launch_final(const FinalP& p, hipStream_t st);
 // Heun evaluation tables from the schedule t_0..t_N: sig[2i] = t_i, sig[2i+1] = t_i + (t_{i+1} - t_i) (i < n-1),
@@ -153,13 +160,13 @@ struct LinKvCtxP { const float* X; int ldx; int x_coff; long xb; int npix; int C
                    const float* res; int ldres; long resb; int res_under_mask;
                    const float* mask; int mask_ws; long mask_bstride; int W; float* Xout;
                    int h2_bf16; };                          // H2 is bf16 [npix][C]
-void launch_linattn_kvctx(const LinKvCtxP& p, hipStream_t st);
+void launch_linattn_kvctx(const LinKvCtxP& p, int precision, hipStream_t st);
 struct LinMergeP { const float* part_m; const float* part_s; const float* part_c; int nblk;
                    const float* Wout; const float* g; int C; void* W2; int B; };       // Wout fp32 [C][128]
-void launch_linattn_merge(const LinMergeP& p, hipStream_t st);
+void launch_linattn_merge(const LinMergeP& p, int precision, hipStream_t st);
 struct LinOut2P { const float* X; int ldx; int x_coff; long xb; int npix; int C; const void* Wq; const void* W2;
-                  const float* bias; float* Y; int ldy; int y_coff; long yb; int B; }; // Wq bf16 in MFMA fragment order (launch_pack_bf16_frag_nk)
-void launch_linattn_out2(const LinOut2P& p, hipStream_t st);
+                  const float* bias; float* Y; int ldy; int y_coff; long yb; int B; }; // Wq bf16 in MFMA fragment order (launch_pack_lp_frag_nk)
+void launch_linattn_out2(const LinOut2P& p, int precision, hipStream_t st);
 
 // Depthwise patch-embed conv + SiLU (dit.py:57-58), channels-last, zero padding incl. right pad to patch multiple.
 struct DwConvP { const float* X; int ldx; long xb; int Hi, Wi, C; int k, s, pad; const float* Wd; const float* bd;
@@ -169,11 +176,11 @@ void launch_dwconv_silu(const DwConvP& p, hipStream_t st);
 
 // pos-conv tail: sum split-K partials + bias -> GELU -> mean over freq -> tokens = emb + pos + freq_pos (dit.py:450-454)
 // Direct grouped 16x16 positional convolution (pos_conv.hip): X = patch embedding [B][Hf][Wt][hid] fp32, Wf = bf16
-// weights in MFMA fragment order per group ([g][tap][ks][lane][8], launch_pack_bf16_frag of each group's [K][32]
+// weights in MFMA fragment order per group ([g][tap][ks][lane][8], launch_pack_lp_frag of each group's [K][32]
 // matrix), Y = raw convolution sums [B][Hf*Wt][hid].
 struct PosConvP { const float* X; const void* Wf; float* Y; int Hf, Wt, hid, G, B; };
 bool pos_conv_direct_supported(int hid, int groups, int kernel, int Hf);
-void launch_pos_conv_direct(const PosConvP& p, hipStream_t st);
+void launch_pos_conv_direct(const PosConvP& p, int precision, hipStream_t st);
 struct PosFinishP { const float* part; int nsplit; long split_stride; const float* bias; const float* emb;
                     const float* freq_pos; float* tok; int Hf, Wt, D; int B; };
 void launch_pos_finish(const PosFinishP& p, hipStream_t st);
@@ -184,7 +191,7 @@ struct LnModP { const float* X; float* Y; int rows_per_batch; int D; const float
 void launch_ln_mod(const LnModP& p, hipStream_t st);
 
 // Row-local remainder of a DiT block + the next block's qkv projection in one launch (dit_rowchain.hip; bf16 mode,
-// hidden 256 / mlp 512).  Weights are bf16 in MFMA fragment order (launch_pack_bf16_frag).
+// hidden 256 / mlp 512).  Weights are bf16 in MFMA fragment order (launch_pack_lp_frag).
 struct DitChainP { const float* O; int ksplit; long o_sstride; const float* ml; int heads; int rows_per_batch;   // attention partials
                    float* X; const void *Wp, *W1, *W2, *Wq; const float *bp, *b1, *b2, *bq;
                    const float* ada;                       // this block's [n_steps][6*hidden] adaLN table
@@ -199,10 +206,10 @@ bool dit_rowchain_supported(int hidden, int mlp_hidden);
 // Softmax attention on the row chain's bf16 operands (2 heads x 128): no staging, K / V^T / Q fragments are read
 // straight from global memory.  O: fp32 [ksplit][B][N][256] partials + ml (merged by the next row chain launch).
 struct AttnDirectP { const void *Qh, *Kh, *Vt; int N, Npad, B; float* O; long o_sstride; float* ml; int ksplit; long long* dbg; };
-void launch_attention_direct(const AttnDirectP& p, hipStream_t st);
-void launch_dit_rowchain(const DitChainP& p, hipStream_t st);
-void launch_pack_bf16_frag(const float* src, void* dst, int K, int N, hipStream_t st);
-void launch_pack_bf16_frag_nk(const float* src, void* dst, int K, int N, hipStream_t st);   // source [N][K]
+void launch_attention_direct(const AttnDirectP& p, int precision, hipStream_t st);
+void launch_dit_rowchain(const DitChainP& p, int precision, hipStream_t st);
+void launch_pack_lp_frag(const float* src, void* dst, int K, int N, int precision, hipStream_t st);
+void launch_pack_lp_frag_nk(const float* src, void* dst, int K, int N, int precision, hipStream_t st);   // source [N][K]
 
 // Softmax attention, head_dim 128, no key mask except kv_len (timm Attention core / TVAdaptor core).
 struct AttnP { const float* Q; int ldq; long qb; const float* K; int ldk; long kb; const float* V; int ldv; long vb;
@@ -231,7 +238,8 @@ void launch_step_inc(int* step, hipStream_t st);
 void launch_iota(int* dst, int n, hipStream_t st);
 void launch_permute4(const float* src, float* dst, int d0, int d1, int d2, int d3, int p0, int p1, int p2, int p3,
                      hipStream_t st);   // dst = src.permute(p0..p3).contiguous()
-void launch_f32_to_bf16(const float* src, void* dst, long n, hipStream_t st);
+void launch_f32_to_lp(const float* src, void* dst, long n, int precision, hipStream_t st);        // fp32 -> bf16 / fp16, round to nearest even
+void launch_pack_lp_nk(const float* src, void* dst, int K, int N, int precision, hipStream_t st);  // fp32 [K][N] -> low precision [N][K]
 void launch_spk_plane(const float* spk_out, float* plane, int B, int F, hipStream_t st);
 
 // DEX style adaptors -------------------------------------------------------------------------
@@ -250,7 +258,8 @@ struct SapP { const float* t_tok; int t_ld; int t_coff; int nsteps; const float*
 void launch_sap(const SapP& p, hipStream_t st);
 // TV: fold InstanceNorm2D into w_q:  Weff[b][k][n] = rstd[b,k]*Wq[n,k];  beff[b][n] = -sum_k mean*rstd*Wq[n,k]
 struct InFoldP { const gnfix_t* stats; int npix; float eps; const float* Wq; int C; float* Weff; float* beff; int B;
-                 void* Wbf; };         // bf16 mode: write rstd[k] * Wq[n][k] as bf16 [B][n][k] (the bf16 GEMM's weight layout) instead of Weff
+                 void* Wbf; int lp; }; // reduced-precision modes: write rstd[k] * Wq[n][k] as bf16 (lp = 1) / fp16 (lp = 2) [B][n][k]
+                                       // (the MFMA GEMM's weight layout) instead of Weff
 void launch_in_fold(const InFoldP& p, hipStream_t st);
 // TIV: y = IN2d(x)*s + m  (ref_encoder.py:271); s,m indexed [step][b][C]
 struct TivApplyP { const float* X; int ld; long xb; float* Y; int ldy; long yb; int npix; int C; const gnfix_t* stats;

@@ -1,0 +1,37 @@
+// kernels_lp.h — launch interfaces of the low-precision (bf16 / fp16 operand) kernel files, declared inside
+// namespace dex::DEX_LP_NS.  No include guard on purpose: lp_dispatch.hip includes it once per namespace.
+// The parameter structs are the shared ones of kernels.h.
+#include "kernels.h"
+#include "lp_config.h"
+
+namespace dex {
+namespace DEX_LP_NS {
+
+// Patch-staged 3x3/s1/p1 Block convolution (conv3x3_bf16.hip) and its strip-streaming form (conv3x3_stream.hip)
+bool conv3x3_bf16_supported(int Cin, int Cout);
+bool conv3x3_bf16_tail_supported(int C);              // pro_res form (Cin == Cout == C)
+bool conv3x3_bf16_res_supported(int Cin, int Cout);   // res_w form (fused 1x1 shortcut)
+bool conv3x3_bf16_xb_supported(int Cin, int Cout);    // x_bf16 form (low-precision input under a GroupNorm prologue)
+void launch_conv3x3_lp(const Conv3P& p, hipStream_t st);
+int conv3x3_stream_tiles(const Conv3P& p);            // iterations per workgroup of the throughput form, 0 = not applicable
+void launch_conv3x3_stream(const Conv3P& p, int tiles_per_wg, hipStream_t st);
+// implicit GEMM on the low-precision MFMA (igemm_bf16.hip)
+void launch_igemm_lp(const IGemmP& p, hipStream_t st);
+// softmax attention (attention_bf16.hip: fp32 q/k/v in HBM; attention_direct.hip: fragment-ordered operands)
+void launch_attention_lp(const AttnP& p, hipStream_t st);
+void launch_attention_direct(const AttnDirectP& p, hipStream_t st);
+// DiT row chain (dit_rowchain.hip) and its weight packing
+bool dit_rowchain_supported(int hidden, int mlp_hidden);
+void launch_dit_rowchain(const DitChainP& p, hipStream_t st);
+void launch_pack_lp_frag(const float* src, void* dst, int K, int N, hipStream_t st);
+void launch_pack_lp_frag_nk(const float* src, void* dst, int K, int N, hipStream_t st);   // source [N][K]
+// fused linear attention (linattn_fused.hip)
+void launch_linattn_kvctx(const LinKvCtxP& p, hipStream_t st);
+void launch_linattn_merge(const LinMergeP& p, hipStream_t st);
+void launch_linattn_out2(const LinOut2P& p, hipStream_t st);
+// direct grouped positional convolution (pos_conv.hip)
+bool pos_conv_direct_supported(int hid, int groups, int kernel, int Hf);
+void launch_pos_conv_direct(const PosConvP& p, hipStream_t st);
+
+}  // namespace DEX_LP_NS
+}  // namespace dex

@@ -12,14 +12,15 @@
 // GEMMs per 32-pixel wave tile, M_b itself is never formed).
 // HBM traffic per call: x read twice + y written, instead of writing q,k,v (6x the size of x) and re-reading them.
 #include "kernels.h"
-#include "bf16_util.h"
+#include "lp_util.h"
+#include "kernels_lp.h"
 
 namespace dex {
+namespace DEX_LP_NS {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned short u16;
-union LFrag { uint4 u; bf16x8 v; };
+union LFrag { uint4 u; lp8 v; };
 
 
 // grid (nblk, B); 256 threads; each wave owns `nsub` consecutive 32-pixel sub-tiles.
@@ -126,8 +127,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 ? 2
                 float v[8] = {xa[ks].x, xa[ks].y, xa[ks].z, xa[ks].w, xc[ks].x, xc[ks].y, xc[ks].z, xc[ks].w};
                 if (hb) {
                     const unsigned u0 = __float_as_uint(xa[ks].x), u1 = __float_as_uint(xa[ks].y), u2 = __float_as_uint(xa[ks].z), u3 = __float_as_uint(xa[ks].w);
-                    v[0] = bf16_lo(u0); v[1] = bf16_hi(u0); v[2] = bf16_lo(u1); v[3] = bf16_hi(u1);
-                    v[4] = bf16_lo(u2); v[5] = bf16_hi(u2); v[6] = bf16_lo(u3); v[7] = bf16_hi(u3);
+                    v[0] = lp_lo(u0); v[1] = lp_hi(u0); v[2] = lp_lo(u1); v[3] = lp_hi(u1);
+                    v[4] = lp_lo(u2); v[5] = lp_hi(u2); v[6] = lp_lo(u3); v[7] = lp_hi(u3);
                 }
                 float r_[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
                 const float4 sc0 = *reinterpret_cast<const float4*>(gsc_s + ks * 16 + hh * 8), sc1 = *reinterpret_cast<const float4*>(gsc_s + ks * 16 + hh * 8 + 4);
@@ -154,8 +155,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 ? 2
         LFrag af[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            af[ks].u.x = pack2_bf16(xa[ks].x, xa[ks].y); af[ks].u.y = pack2_bf16(xa[ks].z, xa[ks].w);
-            af[ks].u.z = pack2_bf16(xc[ks].x, xc[ks].y); af[ks].u.w = pack2_bf16(xc[ks].z, xc[ks].w);
+            af[ks].u.x = pack2_lp(xa[ks].x, xa[ks].y); af[ks].u.y = pack2_lp(xa[ks].z, xa[ks].w);
+            af[ks].u.z = pack2_lp(xc[ks].x, xc[ks].y); af[ks].u.w = pack2_lp(xc[ks].z, xc[ks].w);
         }
         if (sub + 1 < p.nsub) {
             const int pxr = min(px0 + 32 + i, p.npix - 1);
@@ -194,8 +195,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 ? 2
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 LFrag fk, fv; fk.u = *reinterpret_cast<const uint4*>(bk + ks * 16); fv.u = *reinterpret_cast<const uint4*>(bv + ks * 16);
-                kh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks].v, fk.v, kh, 0, 0, 0);
-                vh = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks].v, fv.v, vh, 0, 0, 0);
+                kh = DEX_MFMA_LP(af[ks].v, fk.v, kh, 0, 0, 0);
+                vh = DEX_MFMA_LP(af[ks].v, fv.v, vh, 0, 0, 0);
             }
             // column (channel d = lane&31) max over the 32 pixels of the sub-tile
             float mx = -INFINITY;
@@ -206,7 +207,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 ? 2
                 mx = fmaxf(mx, kh[r]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float mn = fmaxf(m_run[h], mx);
+            // fp16 operands: the softmax reference sits 14 octaves BELOW the running maximum, so p = exp(k - ref) spans
+            // [.., 2^14] and a position 2^-38 below the maximum still survives the fp16 rounding of the MFMA operand (over
+            // n = 80*T positions nearly all of them sit far below the maximum); the partial's (m, s, ctx) are consistent
+            // with that reference, so nothing downstream changes.  bf16 has fp32's exponent range: no shift.
+            constexpr float KSHIFT = LP_IS_F16 ? 14.f * 0.69314718056f : 0.f;
+            const float mn = fmaxf(m_run[h], mx - KSHIFT);
             const float alpha = __expf(m_run[h] - mn);
             m_run[h] = mn;
             float ps = 0.f;
@@ -219,11 +225,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 ? 2
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
                 LFrag va, pb;
-                va.u.x = pack2_bf16(vh[8 * k2 + 0], vh[8 * k2 + 1]); va.u.y = pack2_bf16(vh[8 * k2 + 2], vh[8 * k2 + 3]);
-                va.u.z = pack2_bf16(vh[8 * k2 + 4], vh[8 * k2 + 5]); va.u.w = pack2_bf16(vh[8 * k2 + 6], vh[8 * k2 + 7]);
-                pb.u.x = pack2_bf16(kh[8 * k2 + 0], kh[8 * k2 + 1]); pb.u.y = pack2_bf16(kh[8 * k2 + 2], kh[8 * k2 + 3]);
-                pb.u.z = pack2_bf16(kh[8 * k2 + 4], kh[8 * k2 + 5]); pb.u.w = pack2_bf16(kh[8 * k2 + 6], kh[8 * k2 + 7]);
-                ctxT[h] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va.v, pb.v, ctxT[h], 0, 0, 0);
+                va.u.x = pack2_lp(vh[8 * k2 + 0], vh[8 * k2 + 1]); va.u.y = pack2_lp(vh[8 * k2 + 2], vh[8 * k2 + 3]);
+                va.u.z = pack2_lp(vh[8 * k2 + 4], vh[8 * k2 + 5]); va.u.w = pack2_lp(vh[8 * k2 + 6], vh[8 * k2 + 7]);
+                pb.u.x = pack2_lp(kh[8 * k2 + 0], kh[8 * k2 + 1]); pb.u.y = pack2_lp(kh[8 * k2 + 2], kh[8 * k2 + 3]);
+                pb.u.z = pack2_lp(kh[8 * k2 + 4], kh[8 * k2 + 5]); pb.u.w = pack2_lp(kh[8 * k2 + 6], kh[8 * k2 + 7]);
+                ctxT[h] = DEX_MFMA_LP(va.v, pb.v, ctxT[h], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);            // keep the heads sequential: interleaving them brings all tiles back to life
         }
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(256) void linattn_merge_kernel(const LinMergeP p) {
         // fragment slot of (co = tid, he = h*32 + d):  d = (j&3) + 8*(2*ksl + (j>>2)) + 4*hh
         const int co = tid, hh = (d >> 2) & 1, j = (d & 3) + 4 * ((d >> 3) & 1), ks = 2 * h + (d >> 4);
         const long dst = ((((long)b * (C / 32) + (co >> 5)) * 8 + ks) * 64 + hh * 32 + (co & 31)) * 8 + j;
-        reinterpret_cast<u16*>(p.W2)[dst] = (u16)(pack2_bf16(a, 0.f) & 0xffffu);
+        reinterpret_cast<u16*>(p.W2)[dst] = (u16)(pack2_lp(a, 0.f) & 0xffffu);
     }
 }
 void launch_linattn_merge(const LinMergeP& p, hipStream_t st) {
@@ -404,8 +410,8 @@ __global__ __launch_bounds__(256) void linattn_out2_direct_kernel(const LinOut2P
     LFrag xf[KS1];
 #pragma unroll
     for (int ks = 0; ks < KS1; ++ks) {
-        xf[ks].u.x = pack2_bf16(xa[ks].x, xa[ks].y); xf[ks].u.y = pack2_bf16(xa[ks].z, xa[ks].w);
-        xf[ks].u.z = pack2_bf16(xc[ks].x, xc[ks].y); xf[ks].u.w = pack2_bf16(xc[ks].z, xc[ks].w);
+        xf[ks].u.x = pack2_lp(xa[ks].x, xa[ks].y); xf[ks].u.y = pack2_lp(xa[ks].z, xa[ks].w);
+        xf[ks].u.z = pack2_lp(xc[ks].x, xc[ks].y); xf[ks].u.w = pack2_lp(xc[ks].z, xc[ks].w);
     }
     // ---- GEMM1: q^T, four 32-row he tiles; converted to bf16 B fragments tile by tile
     const uint4* wq = reinterpret_cast<const uint4*>(p.Wq) + lane;                  // bf16, fragment order [he tile][K-step][lane][8]
@@ -418,12 +424,12 @@ __global__ __launch_bounds__(256) void linattn_out2_direct_kernel(const LinOut2P
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) {
             LFrag af; af.u = wq[(t * KS1 + ks) * 64];
-            q = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.v, xf[ks].v, q, 0, 0, 0);
+            q = DEX_MFMA_LP(af.v, xf[ks].v, q, 0, 0, 0);
         }
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
-            qf[t * 2 + k2].u.x = pack2_bf16(q[8 * k2 + 0], q[8 * k2 + 1]); qf[t * 2 + k2].u.y = pack2_bf16(q[8 * k2 + 2], q[8 * k2 + 3]);
-            qf[t * 2 + k2].u.z = pack2_bf16(q[8 * k2 + 4], q[8 * k2 + 5]); qf[t * 2 + k2].u.w = pack2_bf16(q[8 * k2 + 6], q[8 * k2 + 7]);
+            qf[t * 2 + k2].u.x = pack2_lp(q[8 * k2 + 0], q[8 * k2 + 1]); qf[t * 2 + k2].u.y = pack2_lp(q[8 * k2 + 2], q[8 * k2 + 3]);
+            qf[t * 2 + k2].u.z = pack2_lp(q[8 * k2 + 4], q[8 * k2 + 5]); qf[t * 2 + k2].u.w = pack2_lp(q[8 * k2 + 6], q[8 * k2 + 7]);
         }
     }
     // ---- GEMM2 + epilogue: rows co = ct*32 + (r&3) + 8*(r>>2) + 4*hh  ->  4 consecutive channels per register quad
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(256) void linattn_out2_direct_kernel(const LinOut2P
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             LFrag af; af.u = w2f[ct][ks];
-            y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.v, qf[ks].v, y, 0, 0, 0);
+            y = DEX_MFMA_LP(af.v, qf[ks].v, y, 0, 0, 0);
         }
         if (ok) {
 #pragma unroll
@@ -508,8 +514,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, C == 64 
     for (int ks = 0; ks < KS1; ++ks) {
         const float4 xa = *reinterpret_cast<const float4*>(xs + i * LDX + ks * 16 + hh * 8);
         const float4 xc = *reinterpret_cast<const float4*>(xs + i * LDX + ks * 16 + hh * 8 + 4);
-        xf[ks].u.x = pack2_bf16(xa.x, xa.y); xf[ks].u.y = pack2_bf16(xa.z, xa.w);
-        xf[ks].u.z = pack2_bf16(xc.x, xc.y); xf[ks].u.w = pack2_bf16(xc.z, xc.w);
+        xf[ks].u.x = pack2_lp(xa.x, xa.y); xf[ks].u.y = pack2_lp(xa.z, xa.w);
+        xf[ks].u.z = pack2_lp(xc.x, xc.y); xf[ks].u.w = pack2_lp(xc.z, xc.w);
     }
     // ---- GEMM1: q^T, four 32-row he tiles; converted to bf16 B fragments tile by tile
     const uint4* wq = reinterpret_cast<const uint4*>(p.Wq) + lane;                  // bf16, fragment order [he tile][K-step][lane][8]
@@ -522,12 +528,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, C == 64 
 #pragma unroll
         for (int ks = 0; ks < KS1; ++ks) {
             LFrag af; af.u = wq[(t * KS1 + ks) * 64];
-            q = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.v, xf[ks].v, q, 0, 0, 0);
+            q = DEX_MFMA_LP(af.v, xf[ks].v, q, 0, 0, 0);
         }
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
-            qf[t * 2 + k2].u.x = pack2_bf16(q[8 * k2 + 0], q[8 * k2 + 1]); qf[t * 2 + k2].u.y = pack2_bf16(q[8 * k2 + 2], q[8 * k2 + 3]);
-            qf[t * 2 + k2].u.z = pack2_bf16(q[8 * k2 + 4], q[8 * k2 + 5]); qf[t * 2 + k2].u.w = pack2_bf16(q[8 * k2 + 6], q[8 * k2 + 7]);
+            qf[t * 2 + k2].u.x = pack2_lp(q[8 * k2 + 0], q[8 * k2 + 1]); qf[t * 2 + k2].u.y = pack2_lp(q[8 * k2 + 2], q[8 * k2 + 3]);
+            qf[t * 2 + k2].u.z = pack2_lp(q[8 * k2 + 4], q[8 * k2 + 5]); qf[t * 2 + k2].u.w = pack2_lp(q[8 * k2 + 6], q[8 * k2 + 7]);
         }
     }
     // ---- GEMM2 + epilogue: rows co = ct*32 + (r&3) + 8*(r>>2) + 4*hh  ->  4 consecutive channels per register quad;
@@ -540,7 +546,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, C == 64 
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             LFrag af; af.u = w2f[ct][ks];
-            y = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af.v, qf[ks].v, y, 0, 0, 0);
+            y = DEX_MFMA_LP(af.v, qf[ks].v, y, 0, 0, 0);
         }
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -580,4 +586,5 @@ void launch_linattn_out2(const LinOut2P& p, hipStream_t st) {
     else hipLaunchKernelGGL(linattn_out2_kernel<128>, grid, dim3(256), lds, st, p);
 }
 
+}  // namespace DEX_LP_NS
 }  // namespace dex

@@ -1,0 +1,37 @@
+// lp_dispatch.hip — the reduced-precision kernels exist once per operand type (namespace dex::bf16 and dex::f16: the same
+// sources compiled twice, lp_config.h); these are the precision-taking launch functions of kernels.h that pick one.
+#include "kernels.h"
+
+#include "kernels_lp.h"          // namespace dex::bf16
+#undef DEX_LP_NS
+#define DEX_LP_NS f16
+#include "kernels_lp.h"          // namespace dex::f16
+#undef DEX_LP_NS
+
+namespace dex {
+
+thread_local const char* g_last_symbol = nullptr;
+
+// shape predicates do not depend on the operand type
+bool conv3x3_bf16_supported(int Cin, int Cout) { return bf16::conv3x3_bf16_supported(Cin, Cout); }
+bool conv3x3_bf16_tail_supported(int C) { return bf16::conv3x3_bf16_tail_supported(C); }
+bool conv3x3_bf16_res_supported(int Cin, int Cout) { return bf16::conv3x3_bf16_res_supported(Cin, Cout); }
+bool conv3x3_bf16_xb_supported(int Cin, int Cout) { return bf16::conv3x3_bf16_xb_supported(Cin, Cout); }
+bool pos_conv_direct_supported(int hid, int groups, int kernel, int Hf) { return bf16::pos_conv_direct_supported(hid, groups, kernel, Hf); }
+bool dit_rowchain_supported(int hidden, int mlp_hidden) { return bf16::dit_rowchain_supported(hidden, mlp_hidden); }
+
+#define DEX_LP_CALL(fn, ...) do { if (precision == PREC_FP16) f16::fn(__VA_ARGS__); else bf16::fn(__VA_ARGS__); } while (0)
+
+void launch_conv3x3_lp(const Conv3P& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_conv3x3_lp, p, st); }
+void launch_igemm_lp(const IGemmP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_igemm_lp, p, st); }
+void launch_attention_lp(const AttnP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_attention_lp, p, st); }
+void launch_attention_direct(const AttnDirectP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_attention_direct, p, st); }
+void launch_dit_rowchain(const DitChainP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_dit_rowchain, p, st); }
+void launch_pack_lp_frag(const float* src, void* dst, int K, int N, int precision, hipStream_t st) { DEX_LP_CALL(launch_pack_lp_frag, src, dst, K, N, st); }
+void launch_pack_lp_frag_nk(const float* src, void* dst, int K, int N, int precision, hipStream_t st) { DEX_LP_CALL(launch_pack_lp_frag_nk, src, dst, K, N, st); }
+void launch_linattn_kvctx(const LinKvCtxP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_linattn_kvctx, p, st); }
+void launch_linattn_merge(const LinMergeP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_linattn_merge, p, st); }
+void launch_linattn_out2(const LinOut2P& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_linattn_out2, p, st); }
+void launch_pos_conv_direct(const PosConvP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_pos_conv_direct, p, st); }
+
+}  // namespace dex

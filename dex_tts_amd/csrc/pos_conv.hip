@@ -12,11 +12,12 @@
 // Output: raw convolution sums [B][N][hid]; bias + GELU + the mean over frequency stay in pos_finish (dit_elem.hip).
 #include <hip/hip_runtime.h>
 #include "kernels.h"
-#include "bf16_util.h"
+#include "lp_util.h"
+#include "kernels_lp.h"
 
 namespace dex {
+namespace DEX_LP_NS {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
@@ -82,8 +83,8 @@ __global__ __launch_bounds__(256) void pos_conv_direct_kernel(const PosConvP p) 
                 if (it < items) {
                     const float m = ok[q] ? 1.f : 0.f;
                     uint4 v;
-                    v.x = pack2_bf16(f0[q].x * m, f0[q].y * m); v.y = pack2_bf16(f0[q].z * m, f0[q].w * m);
-                    v.z = pack2_bf16(f1[q].x * m, f1[q].y * m); v.w = pack2_bf16(f1[q].z * m, f1[q].w * m);
+                    v.x = pack2_lp(f0[q].x * m, f0[q].y * m); v.y = pack2_lp(f0[q].z * m, f0[q].w * m);
+                    v.z = pack2_lp(f1[q].x * m, f1[q].y * m); v.w = pack2_lp(f1[q].z * m, f1[q].w * m);
                     const int px = it >> 2;
                     *reinterpret_cast<uint4*>(patch + px * LDP + (((it & 3) ^ ((px >> 2) & 3)) * 8)) = v;
                 }
@@ -105,16 +106,16 @@ __global__ __launch_bounds__(256) void pos_conv_direct_kernel(const PosConvP p) 
             const int t = wave + 4 * (n0 + d);
             const int pr = t / KP, kw = t % KP;
             const int px = pr * PW + i + kw;                // patch pixel of column tile 0 (tile ct: + 32*ct, same swizzle phase)
-            const bf16x8 b0 = __builtin_bit_cast(bf16x8, wr[d][0]);
-            const bf16x8 b1 = __builtin_bit_cast(bf16x8, wr[d][1]);
+            const lp8 b0 = __builtin_bit_cast(lp8, wr[d][0]);
+            const lp8 b1 = __builtin_bit_cast(lp8, wr[d][1]);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 const int sw = (px >> 2) & 3;                 // (px + 32*ct) >> 2 has the same low two bits
                 const u16* ap = patch + (long)(px + 32 * ct) * LDP;
-                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(ap + ((hh ^ sw) * 8));
-                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(ap + (((2 + hh) ^ sw) * 8));
-                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[ct], 0, 0, 0);
-                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[ct], 0, 0, 0);
+                const lp8 a0 = *reinterpret_cast<const lp8*>(ap + ((hh ^ sw) * 8));
+                const lp8 a1 = *reinterpret_cast<const lp8*>(ap + (((2 + hh) ^ sw) * 8));
+                acc[ct] = DEX_MFMA_LP(a0, b0, acc[ct], 0, 0, 0);
+                acc[ct] = DEX_MFMA_LP(a1, b1, acc[ct], 0, 0, 0);
             }
             const int tn = min(t + 16, ntaps - 4 + wave);   // refill (clamped re-read at the tail, never consumed)
             const int tap = (kh_lo + tn / KP) * KP + (tn % KP);
@@ -180,4 +181,5 @@ void launch_pos_conv_direct(const PosConvP& p, hipStream_t st) {
     else launch_pc<1>(p, st);
 }
 
+}  // namespace DEX_LP_NS
 }  // namespace dex

@@ -103,8 +103,9 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const FirstConvP p) {
     if (live) {
         if (p.h1_bf16) {
             uint4 lo, hi;
-            lo.x = pack2_bf16(a3[0].x, a3[0].y); lo.y = pack2_bf16(a3[0].z, a3[0].w); lo.z = pack2_bf16(a3[1].x, a3[1].y); lo.w = pack2_bf16(a3[1].z, a3[1].w);
-            hi.x = pack2_bf16(a3[2].x, a3[2].y); hi.y = pack2_bf16(a3[2].z, a3[2].w); hi.z = pack2_bf16(a3[3].x, a3[3].y); hi.w = pack2_bf16(a3[3].z, a3[3].w);
+            const int kd = p.h1_bf16;               // 1 = bf16, 2 = fp16
+            lo.x = pack2_kind(a3[0].x, a3[0].y, kd); lo.y = pack2_kind(a3[0].z, a3[0].w, kd); lo.z = pack2_kind(a3[1].x, a3[1].y, kd); lo.w = pack2_kind(a3[1].z, a3[1].w, kd);
+            hi.x = pack2_kind(a3[2].x, a3[2].y, kd); hi.y = pack2_kind(a3[2].z, a3[2].w, kd); hi.z = pack2_kind(a3[3].x, a3[3].y, kd); hi.w = pack2_kind(a3[3].z, a3[3].w, kd);
             unsigned short* h = reinterpret_cast<unsigned short*>(p.h1) + pix * C + cq * 16;
             *reinterpret_cast<uint4*>(h) = lo;
             *reinterpret_cast<uint4*>(h + 8) = hi;
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(256) void final_kernel(const FinalP p) {
             float4 x;
             if (p.x_bf16) {
                 const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.X) + (long)b * p.xb + px * p.C + c);
-                x = make_float4(bf16_lo(r.x), bf16_hi(r.x), bf16_lo(r.y), bf16_hi(r.y));
+                x = make_float4(lo_kind(r.x, p.x_bf16), hi_kind(r.x, p.x_bf16), lo_kind(r.y, p.x_bf16), hi_kind(r.y, p.x_bf16));
             } else x = *reinterpret_cast<const float4*>(X + px * p.C + c);
             const float4 ga = *reinterpret_cast<const float4*>(p.gamma + c);
             const float4 be = *reinterpret_cast<const float4*>(p.beta + c);
@@ -425,16 +426,24 @@ void launch_permute4(const float* src, float* dst, int d0, int d1, int d2, int d
     hipLaunchKernelGGL(permute4_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, d0, d1, d2, d3, p0, p1, p2, p3);
 }
 
-__global__ void f32_to_bf16_kernel(const float* src, unsigned short* dst, long n) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        unsigned u = __float_as_uint(src[i]);
-        u += 0x7FFFu + ((u >> 16) & 1u);          // round to nearest even
-        dst[i] = (unsigned short)(u >> 16);
+__global__ void f32_to_lp_kernel(const float* src, unsigned short* dst, long n, int kind) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dst[i] = (unsigned short)(pack2_kind(src[i], 0.f, kind) & 0xffffu);            // round to nearest even
+}
+void launch_f32_to_lp(const float* src, void* dst, long n, int precision, hipStream_t st) {
+    long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(f32_to_lp_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, (unsigned short*)dst, n, precision);
+}
+// fp32 [K][N] -> low precision [N][K] (the MFMA GEMMs' weight operand: K contiguous)
+__global__ void pack_lp_nk_kernel(const float* src, unsigned short* dst, int K, int N, int kind) {
+    const long total = (long)K * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K), n = (int)(i / K);
+        dst[i] = (unsigned short)(pack2_kind(src[(long)k * N + n], 0.f, kind) & 0xffffu);
     }
 }
-void launch_f32_to_bf16(const float* src, void* dst, long n, hipStream_t st) {
-    long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, (unsigned short*)dst, n);
+void launch_pack_lp_nk(const float* src, void* dst, int K, int N, int precision, hipStream_t st) {
+    hipLaunchKernelGGL(pack_lp_nk_kernel, dim3(256), dim3(256), 0, st, src, (unsigned short*)dst, K, N, precision);
 }
 
 // speaker plane: the reference repeats spk_mlp(spk) [B,80] along time (diffusion.py:173-175); we keep [B,80].

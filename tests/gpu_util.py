@@ -14,6 +14,18 @@ from dex_tts_amd import config as C, synth  # noqa: E402
 from oracle import dex_oracle as O  # noqa: E402
 
 _ENG = {}
+_LOG = os.path.join(ROOT, "gpurun_out")
+
+
+def record(tag, **vals):
+    """Measured errors go to gpurun_out/parity_measured.jsonl (scratch) so tolerances can be set from data."""
+    import json
+    try:
+        os.makedirs(_LOG, exist_ok=True)
+        with open(os.path.join(_LOG, "parity_measured.jsonl"), "a") as f:
+            f.write(json.dumps({"tag": tag, **{k: float(v) for k, v in vals.items()}}) + "\n")
+    except OSError:
+        pass
 _ORACLE = {}          # oracle outputs are mode-independent: computed once per (case, sigma / n) and reused across precisions
 
 

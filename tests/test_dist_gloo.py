@@ -22,12 +22,15 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, lengths, T, q):
+def _worker(rank, world, port, lengths, T, q, local=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     mu, mask, z, _ = synth.make_inputs(len(lengths), T, lengths)
     mu, mask, z = map(torch.from_numpy, (mu, mask, z))
-    full = D.sample_sharded(fake_sampler, mu, mask, z, lengths)
+    if local:       # a rank holds only its own utterances (in shard order) plus the lengths of all of them
+        mu, mask, z = (D.take_shard(t, lengths) for t in (mu, mask, z))
+        assert mu.shape[0] == len(D.partition(lengths, world)[rank])
+    full = D.sample_sharded(fake_sampler, mu, mask, z, lengths, local=local)
     q.put((rank, full.numpy()))
     dist.barrier()
     dist.destroy_process_group()
@@ -42,14 +45,15 @@ def test_partition_balanced():
     assert D.padded_length(lengths) == 300 and D.padded_length([301]) == 304
 
 
-@pytest.mark.parametrize("lengths", [[64, 40, 52, 30, 64], [16]])
-def test_sharded_equals_unsharded(lengths):
+@pytest.mark.parametrize("lengths,local", [([64, 40, 52, 30, 64], False), ([16], False), ([64, 40, 52, 30, 64], True),
+                                           ([48, 48, 20, 36], True)])
+def test_sharded_equals_unsharded(lengths, local):
     T = D.padded_length(lengths)
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, lengths, T, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, lengths, T, q, local)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=120) for _ in range(world))

@@ -9,7 +9,6 @@ plus the batch-regime fp32 kernels (B=8, T=512), which only large grids select.
 Tolerances.  fp32 mode: as tests/test_gpu_parity.py (single call max|d| <= 1e-3*max(1,|y|max); sampler max 2e-3 /
 mean 2e-4).  bf16 / fp16 modes have no reference counterpart (the reference cannot run in reduced precision, SURVEY
 2.1); they are held to <= 2x what was measured on MI355X against the fp32 oracle (tests/tolerances.py)."""
-import json
 import os
 
 import numpy as np
@@ -20,7 +19,6 @@ from tests import gpu_util as U
 from tests.tolerances import LOWP, FP32_CALL_REL, FP32_SAMPLER_MAX, FP32_SAMPLER_MEAN
 
 pytestmark = pytest.mark.gpu
-_LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
 
 
 def set_prec(eng, prec):
@@ -30,14 +28,7 @@ def set_prec(eng, prec):
     eng.set_precision(prec)
 
 
-def record(tag, **vals):
-    """Measured errors go to gpurun_out/parity_measured.jsonl (scratch) so tolerances can be set from data."""
-    try:
-        os.makedirs(_LOG, exist_ok=True)
-        with open(os.path.join(_LOG, "parity_measured.jsonl"), "a") as f:
-            f.write(json.dumps({"tag": tag, **{k: float(v) for k, v in vals.items()}}) + "\n")
-    except OSError:
-        pass
+record = U.record
 
 
 def check_lowp(tag, prec, kind, got, ref):

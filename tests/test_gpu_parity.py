@@ -12,8 +12,18 @@ import pytest
 import torch
 
 from tests import gpu_util as U
+from tests.tolerances import LOWP
 
 pytestmark = pytest.mark.gpu
+
+
+def lowp_ok(tag, prec, kind, got, ref):
+    e = np.abs(got - ref)
+    U.record(f"{tag}:{prec}:{kind}", max=e.max(), mean=e.mean())
+    mx, mn = LOWP[prec][kind]
+    assert np.isfinite(got).all() and e.max() <= mx and e.mean() <= mn, (tag, prec, kind, float(e.max()), float(e.mean()))
+
+
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -113,8 +123,7 @@ def test_heun_bf16_mode_and_module_switch():
         got, _ = U.run_sampler("gedex_lj", case, 6, solver="heun")
     finally:
         eng.set_precision("fp32")
-    err = np.abs(got - ref)
-    assert err.max() <= 5e-2 and err.mean() <= 8e-3, (err.max(), err.mean())
+    lowp_ok("heun_bf16", "bf16", "sampler", got, ref)
     m = from_config(cfg)
     sd = {}
     for k, v in w.items():
@@ -138,8 +147,17 @@ def test_graph_replay_matches_eager():
     a = eng.sample(z, mask, mu, 8, use_graph=False).cpu().numpy()
     b = eng.sample(z, mask, mu, 8, use_graph=True).cpu().numpy()
     c = eng.sample(z, mask, mu, 8, use_graph=True).cpu().numpy()     # second replay of the cached graph
-    # fp64 atomics in the norm statistics make runs agree to round-off, not bitwise
-    assert np.abs(a - b).max() <= 1e-4 and np.abs(b - c).max() <= 1e-4
+    # the norm statistics accumulate as integers: graph replay, eager launches and repeated calls agree BITWISE
+    assert np.array_equal(a, b) and np.array_equal(b, c)
+    # a different input through the same cached graph (persistent staging buffers) is a different result, not a stale one
+    z2 = z + 0.25
+    d = eng.sample(z2, mask, mu, 8, use_graph=True).cpu().numpy()
+    e = eng.sample(z2, mask, mu, 8, use_graph=False).cpu().numpy()
+    assert np.array_equal(d, e) and not np.array_equal(d, a)
+    # Heun under graph replay (2n-1 evaluations in one graph)
+    h0 = eng.sample(z, mask, mu, 4, solver="heun").cpu().numpy()
+    h1 = eng.sample(z, mask, mu, 4, solver="heun", use_graph=True).cpu().numpy()
+    assert np.array_equal(h0, h1)
 
 
 def test_batch_independence_at_equal_padding():
@@ -150,7 +168,7 @@ def test_batch_independence_at_equal_padding():
     both = eng.sample(z, mask, mu, 5).cpu().numpy()
     for b in range(2):
         one = eng.sample(z[b:b + 1], mask[b:b + 1], mu[b:b + 1], 5).cpu().numpy()
-        assert np.abs(one[0] - both[b]).max() <= 1e-4
+        assert np.array_equal(one[0], both[b])          # same kernel variants at these sizes: bitwise
 
 
 def test_diffusion_module_forward_seeded():
@@ -212,20 +230,17 @@ def test_mel_frontend_golden():
 ])
 def test_bf16_mfma_mode_tolerance(name, kw):
     """bf16-MFMA mode (bf16 operands, fp32 accumulate/norms/softmax) has no reference counterpart — the
-    reference cannot run in bf16 — so it is held to a stated tolerance against the fp32 oracle:
-    single EDMPrecond call max|d| <= 5e-2, mean|d| <= 8e-3; 10-step sampler max|d| <= 5e-2, mean|d| <= 8e-3
-    (measured on MI355X: ~1.4e-2 / 2e-3 and ~1e-2 / 1.6e-3)."""
+    reference cannot run in bf16 — so it is held to the stated tolerance of tests/tolerances.py against the
+    fp32 oracle (<= 2x the worst measured case)."""
     cfg, eng, w = U.engine_for(name)
     eng.set_precision("bf16")
     try:
         case = U.make_case(cfg, **kw)
         for sigma in (80.0, 1.0, 0.002):
             got, ref, _ = U.run_precond(name, case, sigma, with_taps=False)
-            e = np.abs(got - ref)
-            assert np.isfinite(got).all() and e.max() <= 5e-2 and e.mean() <= 8e-3, (sigma, e.max(), e.mean())
+            lowp_ok(f"small_{name}_{sigma}", "bf16", "call", got, ref)
         got, ref = U.run_sampler(name, case, 10)
-        e = np.abs(got - ref)
-        assert e.max() <= 5e-2 and e.mean() <= 8e-3, (e.max(), e.mean())
+        lowp_ok(f"small_{name}_n10", "bf16", "sampler", got, ref)
     finally:
         eng.set_precision("fp32")
 
@@ -240,21 +255,19 @@ def test_bf16_mfma_mode_tolerance(name, kw):
 ])
 def test_bf16_mode_full_size_shapes(name, kw):
     """The BASELINE.json-sized shapes pick kernel variants the small oracle cases never reach (key-split attention
-    partials merged by the row chain, the batch-regime attention kernel, multi-sub-tile context passes).  The fp32
-    mode of the library is pinned to the oracle by the tests above, so it serves as the reference here:
-    single EDMPrecond call, bf16 mode vs fp32 mode, max|d| <= 5e-2 and mean|d| <= 8e-3 (same bound as the oracle test)."""
+    partials merged by the row chain, the batch-regime attention kernel, multi-sub-tile context passes): single
+    EDMPrecond call in bf16 mode AND in fp32 mode, both against the CPU oracle."""
     cfg, eng, w = U.engine_for(name)
     case = U.make_case(cfg, **kw)
-    mu, mask, eps = (torch.from_numpy(case[k]) for k in ("mu", "mask", "eps"))
     try:
         for sigma in (80.0, 0.5):
-            x = mu + float(sigma) * eps
             eng.set_precision("fp32")
-            ref = eng.denoise_once(x, sigma, mask, mu, **U.engine_kwargs(case)).cpu().numpy()
-            eng.set_precision("bf16")
-            got = eng.denoise_once(x, sigma, mask, mu, **U.engine_kwargs(case)).cpu().numpy()
+            got, ref, _ = U.run_precond(name, case, sigma, with_taps=False)
             e = np.abs(got - ref)
-            assert np.isfinite(got).all() and e.max() <= 5e-2 and e.mean() <= 8e-3, (sigma, e.max(), e.mean())
+            assert np.isfinite(got).all() and e.max() <= 1e-3 * max(1.0, np.abs(ref).max()), (sigma, float(e.max()))
+            eng.set_precision("bf16")
+            got, ref, _ = U.run_precond(name, case, sigma, with_taps=False)
+            lowp_ok(f"full_{name}_B{kw['B']}_T{kw['T']}_{sigma}", "bf16", "call", got, ref)
     finally:
         eng.set_precision("fp32")
 
@@ -268,26 +281,23 @@ def test_bf16_mode_full_size_shapes(name, kw):
 ])
 def test_conv_stream_path(name, kw):
     """The strip-streaming 64->64 convolution (conv3x3_stream.hip) is picked by grid size (batched synthesis); here it
-    is forced onto small shapes (DEX_CONV_STREAM=2) and checked against the fp32 mode and against the tile kernel
-    (DEX_CONV_STREAM=0): same bf16 operands, different summation order of the GroupNorm partials only."""
+    is forced onto small shapes (DEX_CONV_STREAM=2) and checked against the CPU oracle and against the tile kernel
+    (DEX_CONV_STREAM=0): same bf16 operands, different accumulation order inside the MFMA chains."""
     cfg, eng, w = U.engine_for(name)
     case = U.make_case(cfg, **kw)
-    mu, mask, eps = (torch.from_numpy(case[k]) for k in ("mu", "mask", "eps"))
     old = os.environ.get("DEX_CONV_STREAM")
     try:
+        eng.set_precision("bf16")
         for sigma in (80.0, 0.5):
-            x = mu + float(sigma) * eps
-            eng.set_precision("fp32")
-            ref = eng.denoise_once(x, sigma, mask, mu, **U.engine_kwargs(case)).cpu().numpy()
-            eng.set_precision("bf16")
             os.environ["DEX_CONV_STREAM"] = "0"
-            tile = eng.denoise_once(x, sigma, mask, mu, **U.engine_kwargs(case)).cpu().numpy()
+            tile, ref, _ = U.run_precond(name, case, sigma, with_taps=False)
             os.environ["DEX_CONV_STREAM"] = "2"
-            got = eng.denoise_once(x, sigma, mask, mu, **U.engine_kwargs(case)).cpu().numpy()
-            e = np.abs(got - ref)
-            assert np.isfinite(got).all() and e.max() <= 5e-2 and e.mean() <= 8e-3, (sigma, e.max(), e.mean())
+            got, ref, _ = U.run_precond(name, case, sigma, with_taps=False)
+            lowp_ok(f"stream_{name}_{sigma}", "bf16", "call", got, ref)
             d = np.abs(got - tile)
-            assert d.max() <= 5e-2 and d.mean() <= 3e-3, (sigma, d.max(), d.mean())     # two bf16 runs of ONE kernel differ by up to 2e-2 / 1.5e-3 (atomic order)
+            U.record(f"stream_vs_tile_{name}_{sigma}", max=d.max(), mean=d.mean())
+            mx, mn = LOWP["bf16"]["call"]
+            assert d.max() <= mx and d.mean() <= mn, (sigma, d.max(), d.mean())     # same bf16 operands, another summation order
     finally:
         eng.set_precision("fp32")
         if old is None:
@@ -297,8 +307,7 @@ def test_conv_stream_path(name, kw):
 
 
 def test_repeatability_fp32_mode():
-    """Two identical calls differ only by the summation order of the GroupNorm partial-sum atomics (fp32): <= 2e-5 on a
-    single EDMPrecond call at sigma = 80 (measured 4e-6)."""
+    """Identical calls give identical bits (integer-accumulated norm statistics)."""
     cfg, eng, w = U.engine_for("gedex_lj")
     case = U.make_case(cfg, B=2, T=260, lengths=[260, 130])
     mu, mask, eps = (torch.from_numpy(case[k]) for k in ("mu", "mask", "eps"))
@@ -306,4 +315,4 @@ def test_repeatability_fp32_mode():
     a = eng.denoise_once(x, 80.0, mask, mu, **U.engine_kwargs(case)).cpu().numpy()
     for _ in range(3):
         b = eng.denoise_once(x, 80.0, mask, mu, **U.engine_kwargs(case)).cpu().numpy()
-        assert np.abs(a - b).max() <= 2e-5
+        assert np.array_equal(a, b)
