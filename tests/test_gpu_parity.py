@@ -228,19 +228,20 @@ def test_mel_frontend_golden():
     ("gedex_lj", dict(B=1, T=100)),
     ("dex_vctk", dict(B=1, T=64, lengths=[57], Tr=40, Ts=40, sty_lengths=[33])),
 ])
-def test_bf16_mfma_mode_tolerance(name, kw):
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_bf16_mfma_mode_tolerance(name, kw, prec):
     """bf16-MFMA mode (bf16 operands, fp32 accumulate/norms/softmax) has no reference counterpart — the
     reference cannot run in bf16 — so it is held to the stated tolerance of tests/tolerances.py against the
     fp32 oracle (<= 2x the worst measured case)."""
     cfg, eng, w = U.engine_for(name)
-    eng.set_precision("bf16")
+    eng.set_precision(prec)
     try:
         case = U.make_case(cfg, **kw)
         for sigma in (80.0, 1.0, 0.002):
             got, ref, _ = U.run_precond(name, case, sigma, with_taps=False)
-            lowp_ok(f"small_{name}_{sigma}", "bf16", "call", got, ref)
+            lowp_ok(f"small_{name}_{sigma}", prec, "call", got, ref)
         got, ref = U.run_sampler(name, case, 10)
-        lowp_ok(f"small_{name}_n10", "bf16", "sampler", got, ref)
+        lowp_ok(f"small_{name}_n10", prec, "sampler", got, ref)
     finally:
         eng.set_precision("fp32")
 
@@ -265,9 +266,10 @@ def test_bf16_mode_full_size_shapes(name, kw):
             got, ref, _ = U.run_precond(name, case, sigma, with_taps=False)
             e = np.abs(got - ref)
             assert np.isfinite(got).all() and e.max() <= 1e-3 * max(1.0, np.abs(ref).max()), (sigma, float(e.max()))
-            eng.set_precision("bf16")
-            got, ref, _ = U.run_precond(name, case, sigma, with_taps=False)
-            lowp_ok(f"full_{name}_B{kw['B']}_T{kw['T']}_{sigma}", "bf16", "call", got, ref)
+            for prec in ("bf16", "fp16"):
+                eng.set_precision(prec)
+                got, ref, _ = U.run_precond(name, case, sigma, with_taps=False)
+                lowp_ok(f"full_{name}_B{kw['B']}_T{kw['T']}_{sigma}", prec, "call", got, ref)
     finally:
         eng.set_precision("fp32")
 
@@ -287,17 +289,18 @@ def test_conv_stream_path(name, kw):
     case = U.make_case(cfg, **kw)
     old = os.environ.get("DEX_CONV_STREAM")
     try:
-        eng.set_precision("bf16")
-        for sigma in (80.0, 0.5):
-            os.environ["DEX_CONV_STREAM"] = "0"
-            tile, ref, _ = U.run_precond(name, case, sigma, with_taps=False)
-            os.environ["DEX_CONV_STREAM"] = "2"
-            got, ref, _ = U.run_precond(name, case, sigma, with_taps=False)
-            lowp_ok(f"stream_{name}_{sigma}", "bf16", "call", got, ref)
-            d = np.abs(got - tile)
-            U.record(f"stream_vs_tile_{name}_{sigma}", max=d.max(), mean=d.mean())
-            mx, mn = LOWP["bf16"]["call"]
-            assert d.max() <= mx and d.mean() <= mn, (sigma, d.max(), d.mean())     # same bf16 operands, another summation order
+        for prec in ("bf16", "fp16"):
+            eng.set_precision(prec)
+            for sigma in (80.0, 0.5):
+                os.environ["DEX_CONV_STREAM"] = "0"
+                tile, ref, _ = U.run_precond(name, case, sigma, with_taps=False)
+                os.environ["DEX_CONV_STREAM"] = "2"
+                got, ref, _ = U.run_precond(name, case, sigma, with_taps=False)
+                lowp_ok(f"stream_{name}_{sigma}", prec, "call", got, ref)
+                d = np.abs(got - tile)
+                U.record(f"stream_vs_tile_{name}_{sigma}:{prec}", max=d.max(), mean=d.mean())
+                mx, mn = LOWP[prec]["call"]
+                assert d.max() <= mx and d.mean() <= mn, (sigma, d.max(), d.mean())     # same operands, another summation order
     finally:
         eng.set_precision("fp32")
         if old is None:
