@@ -98,7 +98,7 @@ __global__ __launch_bounds__(NWD * 64) void attn_direct_kernel(const AttnDirectP
             mx = fmaxf(mx, s[r]);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        if (__builtin_amdgcn_ballot_w64(mx > m_run + 8.f) != 0) {     // lazy rescale (see attn_direct_full_kernel)
+        if (__builtin_amdgcn_ballot_w64(mx > m_run + 8.f) != 0) {     // lazy rescale (see attn_direct_ring_kernel)
             const float m_new = fmaxf(m_run, mx);
             const float alpha = exp2f(m_run - m_new);        // scores are in the log2 domain (q scale carries log2 e)
             l_run *= alpha;
@@ -181,56 +181,58 @@ __global__ __launch_bounds__(NWD * 64) void attn_direct_kernel(const AttnDirectP
 #endif
 }
 
-// ---- batch regime: 4 waves = 4 consecutive 32-query tiles of one (batch, head), each walking ALL key tiles (no key
-// split, no partial merge).  K and V^T tiles are shared through double-buffered LDS images that keep the fragment
-// order of the global layout (1 KB-contiguous copies, conflict-free ds_read_b128).
-// Software pipeline inside a wave: the S^T MFMAs of tile kt+1 are issued BEFORE the softmax VALU work of tile kt, so
-// the matrix pipe runs under the exp/max/sum instructions instead of waiting for them (measured per tile and wave
-// before: 1220 cycles S^T + 870 softmax + 430 PV + 500 copy/barrier with three waves per SIMD taking turns); K
-// therefore runs one tile ahead of V in LDS.  S^T uses two accumulators (even / odd K-steps) to halve the dependent
-// MFMA chain.  Scores are in the log2 domain (log2 e is folded into the q scale by the producer): p = exp2(s - m).
-// The running-max rescale of O is lazy (see the loop).
-__device__ __forceinline__ f32x16 attn_qk(const uint4* kbuf, const DFrag (&qf)[8], int lane) {
-    f32x16 s0, s1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-#pragma unroll
-    for (int ks = 0; ks < 8; ks += 2) {
-        DFrag k0; k0.u = kbuf[ks * 64 + lane];
-        DFrag k1; k1.u = kbuf[(ks + 1) * 64 + lane];
-        s0 = DEX_MFMA_LP(k0.v, qf[ks].v, s0, 0, 0, 0);
-        s1 = DEX_MFMA_LP(k1.v, qf[ks + 1].v, s1, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s0[r] += s1[r];
-    return s0;
-}
-
-__global__ __launch_bounds__(256) void attn_direct_full_kernel(const AttnDirectP p) {
-    __shared__ __attribute__((aligned(16))) uint4 kS[2][512];          // [buf][ks*64 + lane]
-    __shared__ __attribute__((aligned(16))) uint4 vS[2][512];          // [buf][(t*2+k2)*64 + lane]
+// ---- batch regime: 4 waves = 4 consecutive 32-query tiles of one (batch, head) walk the key tiles together; K and V^T
+// tiles are shared through 3-slot LDS rings that keep the fragment order of the global layout and are filled by LDS-DMA
+// (global_load_lds_dwordx4: a fragment-ordered tile is 8 contiguous 1-KB pieces, two per wave) TWO tiles ahead: K(kt+3)
+// goes into the slot K(kt) left after iteration kt-1, V(kt+2) into V(kt-1)'s, so a DMA group has two iterations to land
+// and the loop waits with vmcnt(4) for the previous group only.  ONE barrier per key tile.  161 VGPRs, no AGPR traffic:
+// three waves per SIMD (the first version staged through registers, used 256 VGPRs + accvgpr moves and ran two).
+// Inside a wave the S^T MFMAs of tile kt+1 are issued before the softmax VALU work of tile kt; the S^T chain is ONE
+// accumulator (a dependent 32x32x16 chain issues back to back; the two-accumulator form cost 16 adds and 16 registers).
+// Scores are in the log2 domain (log2 e is folded into the q scale by the producer): p = exp2(s - m); the running-max
+// rescale of O is lazy (see the loop).  Optional key split (blockIdx.z = b * ksplit + sp) for grids that would leave CUs
+// idle or unevenly loaded: split sp walks key tiles [t_lo, t_hi) and writes its normalised O and (m, l); the row chain
+// merges the partials.
+// Measured on MI355X (tools/attnbench.hip, B=32 N=1300): 0.255 of the nominal 2.5 PF vs 0.20 before.  The same loop with
+// the MFMAs alone (no LDS reads, no softmax, no refill) reaches 0.42: with random operands the chip clocks down to
+// ~1.5 GHz under dense bf16 MFMA load (clock64 / wall_clock64 inside the kernel), and 704 workgroups on 256 CUs lose 8 %.
+__global__ __launch_bounds__(256, 3) void attn_direct_ring_kernel(const AttnDirectP p) {
+    __shared__ __attribute__((aligned(16))) uint4 kS[3][512];
+    __shared__ __attribute__((aligned(16))) uint4 vS[3][512];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
-    const int h = blockIdx.y, b = blockIdx.z;
+    const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
+    const int h = blockIdx.y, b = blockIdx.z / ksplit, sp = blockIdx.z % ksplit;
     const int N = p.N;
     const int ntiles = (N + 31) / 32;
-    const int qt = min(blockIdx.x * 4 + wave, ntiles - 1);            // surplus waves shadow the last tile (no store)
-    const bool live_wave = blockIdx.x * 4 + wave < ntiles;
+    const int t_lo = (int)((long)ntiles * sp / ksplit), t_hi = (int)((long)ntiles * (sp + 1) / ksplit);
+    const int qt = min((int)blockIdx.x * 4 + wave, ntiles - 1);
+    const bool live_wave = (int)blockIdx.x * 4 + wave < ntiles;
     const int q0 = qt * 32;
     const long hb = (long)b * 2 + h;
     const uint4* Qg = reinterpret_cast<const uint4*>(p.Qh) + hb * p.Npad * (HD / 8) + lane;
-    const uint4* Kt = reinterpret_cast<const uint4*>(p.Kh) + hb * p.Npad * (HD / 8) + tid;   // cooperative copy: thread-linear
-    const uint4* Vt = reinterpret_cast<const uint4*>(p.Vt) + hb * p.Npad * (HD / 8) + tid;
+    const uint4* Kg = reinterpret_cast<const uint4*>(p.Kh) + hb * p.Npad * (HD / 8) + lane;
+    const uint4* Vg = reinterpret_cast<const uint4*>(p.Vt) + hb * p.Npad * (HD / 8) + lane;
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto dma_k = [&](int tile, int slot) __attribute__((always_inline)) {
+        const long t = min(tile, t_hi - 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds(Kg + t * 512 + (2 * wave + j) * 64, (lds_ptr)&kS[slot][(2 * wave + j) * 64], 16, 0, 0);
+    };
+    auto dma_v = [&](int tile, int slot) __attribute__((always_inline)) {
+        const long t = min(tile, t_hi - 1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_global_load_lds(Vg + t * 512 + (2 * wave + j) * 64, (lds_ptr)&vS[slot][(2 * wave + j) * 64], 16, 0, 0);
+    };
+    // ring slot of tile t = (t - t_lo) % 3
+    dma_k(t_lo, 0); dma_v(t_lo, 0); dma_k(t_lo + 1, 1); dma_v(t_lo + 1, 1); dma_k(t_lo + 2, 2);
     DFrag qf[8];
     {
-        const uint4* qp = Qg + (long)qt * 8 * 64;
+        const uint4* qp = Qg + (long)qt * 512;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) qf[ks].u = qp[ks * 64];
-    }
-    {
-        const long t1 = min(1, ntiles - 1);
-        const uint4 a0 = Kt[0], a1 = Kt[256], a2 = Kt[t1 * 512], a3 = Kt[t1 * 512 + 256], a4 = Vt[0], a5 = Vt[256];
-        kS[0][tid] = a0; kS[0][tid + 256] = a1; kS[1][tid] = a2; kS[1][tid + 256] = a3; vS[0][tid] = a4; vS[0][tid + 256] = a5;
     }
     f32x16 o[4];
 #pragma unroll
@@ -238,17 +240,24 @@ __global__ __launch_bounds__(256) void attn_direct_full_kernel(const AttnDirectP
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
-    lds_barrier();
-    f32x16 s = attn_qk(kS[0], qf, lane);
-    for (int kt = 0; kt < ntiles; ++kt) {
+    auto qk = [&](const uint4* kbuf) __attribute__((always_inline)) -> f32x16 {
+        f32x16 s0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s0[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) { DFrag k0; k0.u = kbuf[ks * 64 + lane]; s0 = DEX_MFMA_LP(k0.v, qf[ks].v, s0, 0, 0, 0); }
+        return s0;
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    f32x16 s = qk(kS[0]);
+    lds_barrier();                      // K(t_lo) has been read by everyone: its slot may take K(t_lo + 3)
+    int s0 = 0, s1 = 1, s2 = 2;         // slots of tiles kt, kt+1, kt+2 (relative): K(kt+1) in s1, V(kt) in s0
+    for (int kt = t_lo; kt < t_hi; ++kt) {
         const int k0 = kt * 32;
-        // global prefetch: K(kt+2) and V(kt+1) (clamped re-reads past the end; never consumed)
-        const long tk = min(kt + 2, ntiles - 1), tv = min(kt + 1, ntiles - 1);
-        const uint4 g0 = Kt[tk * 512], g1 = Kt[tk * 512 + 256], g2 = Vt[tv * 512], g3 = Vt[tv * 512 + 256];
-        // S^T of the NEXT tile goes to the matrix pipe first ...
-        const f32x16 sn = attn_qk(kS[(kt + 1) & 1], qf, lane);
-        // ... and the softmax of THIS tile runs on the VALU meanwhile
-        if (k0 + 32 > N) {                                 // only the last tile has keys to mask
+        dma_k(kt + 3, s0); dma_v(kt + 2, s2);          // K(kt) was read last iteration, V(kt-1) too (slot s2 == slot of tile kt-1)
+        const f32x16 sn = qk(kS[s1]);
+        if (k0 + 32 > N) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) if (k0 + (r & 3) + 8 * (r >> 2) + 4 * hh >= N) s[r] = -INFINITY;
         }
@@ -257,7 +266,7 @@ __global__ __launch_bounds__(256) void attn_direct_full_kernel(const AttnDirectP
         for (int r = 4; r < 16; r += 4) mx = fmaxf(mx, fmaxf(fmaxf(s[r], s[r + 1]), fmaxf(s[r + 2], s[r + 3])));
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         // Lazy rescale: the reference maximum only moves when some query's true maximum exceeds it by more than 2^8
-        // (scores are log2-domain), so P = 2^(s - m_ref) <= 256 stays exact in fp32 sums and well inside bf16 range,
+        // (scores are log2-domain), so P = 2^(s - m_ref) <= 256 stays exact in fp32 sums and well inside bf16 / fp16 range,
         // the result is mathematically unchanged (the final division uses the same reference), and the 64-register
         // rescale of O — which with 32 queries per wave fired on nearly every tile — runs a handful of times.
         if (__builtin_amdgcn_ballot_w64(mx > m_run + 8.f) != 0) {
@@ -274,7 +283,7 @@ __global__ __launch_bounds__(256) void attn_direct_full_kernel(const AttnDirectP
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(s[r] - m_run); psum += s[r]; }
         l_run += psum;
-        const uint4* vcur = vS[kt & 1];
+        const uint4* vcur = vS[s0];
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
             DFrag pb;
@@ -286,22 +295,37 @@ __global__ __launch_bounds__(256) void attn_direct_full_kernel(const AttnDirectP
                 o[t] = DEX_MFMA_LP(vf.v, pb.v, o[t], 0, 0, 0);
             }
         }
-        // K(kt+2) replaces K(kt) (read one iteration ago), V(kt+1) replaces V(kt-1)
-        kS[kt & 1][tid] = g0; kS[kt & 1][tid + 256] = g1; vS[(kt + 1) & 1][tid] = g2; vS[(kt + 1) & 1][tid + 256] = g3;
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // the group issued LAST iteration (K(kt+2), V(kt+1)) landed; this one's flies on
         lds_barrier();
         s = sn;
+        const int tmp = s0; s0 = s1; s1 = s2; s2 = tmp;
     }
     l_run += __shfl_xor(l_run, 32);
     if (live_wave && q0 + i < N) {
-        const float inv = 1.f / l_run;
-        float* op = p.O + ((long)b * N + q0 + i) * (2 * HD) + h * HD + 4 * hh;
+        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+        float* op = p.O + (long)sp * p.o_sstride + ((long)b * N + q0 + i) * (2 * HD) + h * HD + 4 * hh;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq)
                 *reinterpret_cast<float4*>(op + t * 32 + 8 * rq) =
                     make_float4(o[t][rq * 4 + 0] * inv, o[t][rq * 4 + 1] * inv, o[t][rq * 4 + 2] * inv, o[t][rq * 4 + 3] * inv);
+        if (p.ml && hh == 0) {
+            float* ml = p.ml + ((((long)sp * p.B + b) * 2 + h) * N + q0 + i) * 2;
+            ml[0] = m_run; ml[1] = l_run;
+        }
     }
+}
+
+// Many (query tile, head, batch) items: the shared-ring kernel; few: 8 key-splitting waves per 32-query tile.
+bool attention_direct_batch_regime(int N, int B) { return (long)((N + 31) / 32) * 2 * B >= 1024; }
+// Key split of the batch regime: enough workgroups to load 256 CUs evenly (>= 2 per CU), never below 8 key tiles per split.
+int attention_direct_ksplit(int N, int B) {
+    const int ntiles = (N + 31) / 32;
+    const long wgs = (long)((ntiles + 3) / 4) * 2 * B;
+    int ks = 1;
+    while (ks < 4 && wgs * ks < 384 && ntiles / (ks * 2) >= 8) ks *= 2;       // (the consumer pays for every extra partial it merges)
+    return ks;
 }
 
 void launch_attention_direct(const AttnDirectP& p, hipStream_t st) {
@@ -311,9 +335,9 @@ void launch_attention_direct(const AttnDirectP& p, hipStream_t st) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_direct_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
-    if (p.ksplit <= 1 && (long)((p.N + 31) / 32) * 2 * p.B >= 1024) {
-        dim3 grid(((p.N + 31) / 32 + 3) / 4, 2, p.B);
-        hipLaunchKernelGGL(attn_direct_full_kernel, grid, dim3(256), 0, st, p);
+    if (attention_direct_batch_regime(p.N, p.B)) {          // batch regime (the caller sized ksplit with attention_direct_ksplit)
+        dim3 grid(((p.N + 31) / 32 + 3) / 4, 2, p.B * (p.ksplit > 1 ? p.ksplit : 1));
+        hipLaunchKernelGGL(attn_direct_ring_kernel, grid, dim3(256), 0, st, p);
         return;
     }
     dim3 grid((p.N + 31) / 32, 2, p.B * (p.ksplit > 1 ? p.ksplit : 1));

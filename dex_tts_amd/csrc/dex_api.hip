@@ -922,13 +922,20 @@ struct Runner {
                 // The attention core runs inside the row-chain launch (dit_rowchain_kernel<true>): every workgroup computes
                 // the attention of its own 32 queries for both heads, so no attention launch and no partials in HBM.
                 // DEX_ATTN_SEPARATE=1 restores the separate kernels (attention_direct.hip) for A/B measurements.
+                // Large grids (batched synthesis: >= 1024 (query tile, head) items) run the attention as its OWN launch on the
+                // shared-ring kernel (attention_direct.hip): K / V^T tiles are read from L2 once per 128 queries instead of
+                // once per 32, 0.25 vs 0.20 of the MFMA peak.  DEX_ATTN_SEPARATE=0 / 1 forces either form (A/B, profiling).
                 const char* sep_env = getenv("DEX_ATTN_SEPARATE");     // read per call: bench.py flips it for one profiling pass
-                const bool separate = sep_env && atoi(sep_env);
+                const bool batch_regime = attention_direct_batch_regime(N, B);
+                // (measured end to end: DEX B=32 N=1300 +0.6 %, GeDEX B=32 N=650 -0.9 % — short key loops gain nothing from the
+                // rings and pay for the extra launch and the fp32 O round trip, so the automatic switch wants N >= 1024 too)
+                const bool separate = sep_env ? atoi(sep_env) != 0 : (batch_regime && N >= 1024);
                 int ks = 1;
                 if (separate) {
                     const long blocks = (long)((N + 31) / 32) * 2 * B;
                     const int ntiles = (N + 31) / 32;
-                    ks = (int)std::max<long>(1, std::min<long>(std::min<long>(768 / blocks, (ntiles + 7) / 8), ATT_KSPLIT_MAX));
+                    ks = batch_regime ? attention_direct_ksplit(N, B)
+                                      : (int)std::max<long>(1, std::min<long>(std::min<long>(768 / blocks, (ntiles + 7) / 8), ATT_KSPLIT_MAX));
                     AttnDirectP ad{ch.Qin, ch.Kin, ch.Vin, N, P.Npad, B, P.ao, (long)B * N * hid, ks > 1 ? P.att_ml : nullptr, ks, nullptr};
                     run("dit_attention", 4.0 * B * (double)N * N * hid, 2.0 * 3 * B * N * hid + 4.0 * B * N * hid * ks, [&] { launch_attention_direct(ad, x->precision, st); });
                 }

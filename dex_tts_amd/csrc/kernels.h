@@ -207,6 +207,8 @@ bool dit_rowchain_supported(int hidden, int mlp_hidden);
 // straight from global memory.  O: fp32 [ksplit][B][N][256] partials + ml (merged by the next row chain launch).
 struct AttnDirectP { const void *Qh, *Kh, *Vt; int N, Npad, B; float* O; long o_sstride; float* ml; int ksplit; long long* dbg; };
 void launch_attention_direct(const AttnDirectP& p, int precision, hipStream_t st);
+bool attention_direct_batch_regime(int N, int B);     // shared-ring kernel (many query tiles) vs key-splitting waves (few)
+int attention_direct_ksplit(int N, int B);             // key split the batch regime wants for an even load
 void launch_dit_rowchain(const DitChainP& p, int precision, hipStream_t st);
 void launch_pack_lp_frag(const float* src, void* dst, int K, int N, int precision, hipStream_t st);
 void launch_pack_lp_frag_nk(const float* src, void* dst, int K, int N, int precision, hipStream_t st);   // source [N][K]

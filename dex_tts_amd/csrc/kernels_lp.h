@@ -20,6 +20,8 @@ void launch_igemm_lp(const IGemmP& p, hipStream_t st);
 // softmax attention (attention_bf16.hip: fp32 q/k/v in HBM; attention_direct.hip: fragment-ordered operands)
 void launch_attention_lp(const AttnP& p, hipStream_t st);
 void launch_attention_direct(const AttnDirectP& p, hipStream_t st);
+bool attention_direct_batch_regime(int N, int B);
+int attention_direct_ksplit(int N, int B);
 // DiT row chain (dit_rowchain.hip) and its weight packing
 bool dit_rowchain_supported(int hidden, int mlp_hidden);
 void launch_dit_rowchain(const DitChainP& p, hipStream_t st);

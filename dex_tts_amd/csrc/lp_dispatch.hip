@@ -18,6 +18,8 @@ bool conv3x3_bf16_tail_supported(int C) { return bf16::conv3x3_bf16_tail_support
 bool conv3x3_bf16_res_supported(int Cin, int Cout) { return bf16::conv3x3_bf16_res_supported(Cin, Cout); }
 bool conv3x3_bf16_xb_supported(int Cin, int Cout) { return bf16::conv3x3_bf16_xb_supported(Cin, Cout); }
 bool pos_conv_direct_supported(int hid, int groups, int kernel, int Hf) { return bf16::pos_conv_direct_supported(hid, groups, kernel, Hf); }
+bool attention_direct_batch_regime(int N, int B) { return bf16::attention_direct_batch_regime(N, B); }
+int attention_direct_ksplit(int N, int B) { return bf16::attention_direct_ksplit(N, B); }
 bool dit_rowchain_supported(int hidden, int mlp_hidden) { return bf16::dit_rowchain_supported(hidden, mlp_hidden); }
 
 #define DEX_LP_CALL(fn, ...) do { if (precision == PREC_FP16) f16::fn(__VA_ARGS__); else bf16::fn(__VA_ARGS__); } while (0)
