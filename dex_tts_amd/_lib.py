@@ -31,7 +31,8 @@ class DexSampleArgs(C.Structure):
                 ("ref_skips_dev", C.POINTER(C.c_void_p)), ("n_ref", C.c_int32), ("Tr", C.c_int32),
                 ("sty_dev", C.c_void_p), ("sty_lengths_dev", C.c_void_p), ("Ts", C.c_int32),
                 ("out_dev", C.c_void_p), ("workspace_dev", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("use_graph", C.c_int32), ("solver", C.c_int32)]
+                ("use_graph", C.c_int32), ("solver", C.c_int32),
+                ("noise_dev", C.c_void_p), ("S_churn", C.c_float), ("S_min", C.c_float), ("S_max", C.c_float), ("S_noise", C.c_float)]
 
 
 class DexDenoiseArgs(C.Structure):

@@ -543,6 +543,7 @@ struct Plan {
     int* step; int* step_tab; gnfix_t* stats; long stats_bytes; int n_gn;   // stats: two arenas (Euler-step parity)
     float* xbuf;
     float *xprime, *dbuf, *hsig, *htab;      // Heun: x', slope d_cur, per-evaluation sigma / h tables
+    float *that, *hstep, *ncoef;             // churn tables per STEP: t_hat, h = t_next - t_hat, noise coefficient (edm.py:194-196)
     std::vector<StageBuf> down, up;
     std::vector<float*> cat;
     float *up_out, *hF;
@@ -584,6 +585,7 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
     P.xbuf = A.f((size_t)B * 80 * d.T);
     P.xprime = A.f((size_t)B * 80 * d.T); P.dbuf = A.f((size_t)B * 80 * d.T);
     P.hsig = A.f((size_t)n + 2); P.htab = A.f((size_t)n + 2);
+    P.that = A.f((size_t)n + 2); P.hstep = A.f((size_t)n + 2); P.ncoef = A.f((size_t)n + 2);
     P.cat.assign(c.n_stages - 1, nullptr);
     for (int j = 0; j < c.n_stages - 1; ++j) {
         const int i = c.n_stages - 1 - j;
@@ -1195,6 +1197,8 @@ int validate(DexCtx* x, const DexSampleArgs* a, bool need_z) {
     if (need_z && a->n_steps < 2) return x->fail(DEX_ERR_ARG, "n_steps must be >= 2 (edm.py:157 divides by num_steps - 1)");
     if (!a->mu_dev || !a->mask_dev || !a->sigmas_dev || !a->out_dev || !a->workspace_dev) return x->fail(DEX_ERR_ARG, "null device pointer");
     if (need_z && !a->z_dev) return x->fail(DEX_ERR_ARG, "z_dev is null");
+    if (need_z && a->S_churn < 0.f) return x->fail(DEX_ERR_ARG, "S_churn must be >= 0");
+    if (need_z && a->S_churn > 0.f && !a->noise_dev) return x->fail(DEX_ERR_ARG, "S_churn > 0 needs noise_dev ([n_steps][B,80,T] draws of randn_like, edm.py:196)");
     if (x->cfg.n_spks > 1 && !a->spk_dev) return x->fail(DEX_ERR_ARG, "spk_dev required when n_spks > 1");
     if (x->cfg.variant == DEX_VARIANT_DEX) {
         if (!a->ref_skips_dev || !a->sty_dev || !a->sty_lengths_dev || a->Tr < 2 || a->Ts < 1 || a->n_ref < 1 || a->n_ref > 7)
@@ -1216,15 +1220,21 @@ int enqueue_heun(DexCtx* x, const DexSampleArgs* a, hipStream_t st) {
     make_plan(x, d, a->workspace_dev, P);
     Runner R{x, P, st, a->mask_dev, a->mu_dev, P.xbuf, a, false};
     launch_iota(P.step_tab, E, st);
-    launch_heun_expand(a->sigmas_dev, n, P.hsig, P.htab, st);
+    launch_churn_tables(a->sigmas_dev, n, a->S_churn, a->S_min, a->S_max, a->S_noise, P.that, P.hstep, P.ncoef, st);
+    launch_heun_expand(P.that, P.hstep, n, P.hsig, P.htab, st);
     R.prepare(P.hsig, E);
-    R.run("init_scale", 0, 8.0 * a->B * 80 * a->T, [&] { launch_scale_copy(a->z_dev, P.xbuf, (long)a->B * 80 * a->T, P.scal, st); });
+    const bool churn = a->S_churn > 0.f;
+    const long nx = (long)a->B * 80 * a->T;
+    // x_0 = z * t_0 (edm.py:188-189; t_0, not t_hat_0)
+    R.run("init_scale", 0, 8.0 * nx, [&] { launch_scale_copy(a->z_dev, P.xbuf, nx, a->sigmas_dev, st); });
     gnfix_t* arena[2] = {P.stats, P.stats + P.stats_bytes / (long)sizeof(gnfix_t)};
     hipMemsetAsync(P.stats, 0, 2 * P.stats_bytes, st);
     R.fin_htab = P.htab;
     for (int e = 0; e < E; ++e) {
         const bool corrector = (e & 1) != 0, last = (e == E - 1);
         R.sp = P.step_tab + e; R.stats_base = arena[e & 1]; R.stats_other = arena[(e + 1) & 1];
+        if (churn && !corrector)        // x_hat = x_cur + sqrt(t_hat^2 - t_cur^2) S_noise randn_like(x_cur), in place (edm.py:196)
+            R.run("churn_noise", 2.0 * nx, 12.0 * nx, [&] { launch_add_noise(P.xbuf, a->noise_dev + (long)(e / 2) * nx, P.ncoef + e / 2, nx, st); });
         R.xcur = corrector ? P.xprime : P.xbuf;
         R.fin_mode = corrector ? 2 : (last ? 0 : 1);
         R.step(nullptr, (corrector || last) ? P.xbuf : P.xprime);
@@ -1241,13 +1251,23 @@ int enqueue_euler(DexCtx* x, const DexSampleArgs* a, hipStream_t st) {
     Runner R{x, P, st, a->mask_dev, a->mu_dev, P.xbuf, a, false};
     launch_iota(P.step_tab, a->n_steps, st);
     R.sp = P.step_tab;
-    R.prepare(a->sigmas_dev, a->n_steps);
-    // x_0 = z * sigma_0 (edm.py:188-189)
-    R.run("init_scale", 0, 8.0 * a->B * 80 * a->T, [&] { launch_scale_copy(a->z_dev, P.xbuf, (long)a->B * 80 * a->T, P.scal, st); });
+    const bool churn = a->S_churn > 0.f;
+    const long nx = (long)a->B * 80 * a->T;
+    if (churn) {        // the network sees t_hat_i, the update uses h_i = t_{i+1} - t_hat_i (edm.py:194-199)
+        launch_churn_tables(a->sigmas_dev, a->n_steps, a->S_churn, a->S_min, a->S_max, a->S_noise, P.that, P.hstep, P.ncoef, st);
+        R.prepare(P.that, a->n_steps);
+        R.fin_htab = P.hstep;
+    } else {
+        R.prepare(a->sigmas_dev, a->n_steps);
+    }
+    // x_0 = z * t_0 (edm.py:188-189)
+    R.run("init_scale", 0, 8.0 * nx, [&] { launch_scale_copy(a->z_dev, P.xbuf, nx, a->sigmas_dev, st); });
     gnfix_t* arena[2] = {P.stats, P.stats + P.stats_bytes / (long)sizeof(gnfix_t)};
     hipMemsetAsync(P.stats, 0, 2 * P.stats_bytes, st);
     for (int i = 0; i < a->n_steps; ++i) {
         R.sp = P.step_tab + i; R.stats_base = arena[i & 1]; R.stats_other = arena[(i + 1) & 1];
+        if (churn)          // x_hat = x_cur + sqrt(t_hat^2 - t_cur^2) S_noise randn_like(x_cur), in place (edm.py:196)
+            R.run("churn_noise", 2.0 * nx, 12.0 * nx, [&] { launch_add_noise(P.xbuf, a->noise_dev + (long)i * nx, P.ncoef + i, nx, st); });
         R.step(nullptr, P.xbuf);
     }
     HIPCHK(x, hipMemcpyAsync(a->out_dev, P.xbuf, (size_t)a->B * 80 * a->T * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -1331,7 +1351,9 @@ int dex_sample(DexCtx* x, const DexSampleArgs* a, dex_stream_t stream) {
                                  (uint64_t)x->precision, (uint64_t)a->n_ref, (uint64_t)(uintptr_t)st,
                                  (uint64_t)(uintptr_t)a->z_dev, (uint64_t)(uintptr_t)a->mu_dev, (uint64_t)(uintptr_t)a->mask_dev,
                                  (uint64_t)(uintptr_t)a->sigmas_dev, (uint64_t)(uintptr_t)a->spk_dev, (uint64_t)(uintptr_t)a->sty_dev,
-                                 (uint64_t)(uintptr_t)a->sty_lengths_dev, (uint64_t)(uintptr_t)a->out_dev, (uint64_t)(uintptr_t)a->workspace_dev};
+                                 (uint64_t)(uintptr_t)a->sty_lengths_dev, (uint64_t)(uintptr_t)a->out_dev, (uint64_t)(uintptr_t)a->workspace_dev,
+                                 (uint64_t)(uintptr_t)(a->S_churn > 0.f ? a->noise_dev : nullptr)};
+    for (float v : {a->S_churn, a->S_min, a->S_max, a->S_noise}) { uint32_t u; memcpy(&u, &v, 4); key.push_back(u); }
     for (int j = 0; j < a->n_ref; ++j) key.push_back((uint64_t)(uintptr_t)a->ref_skips_dev[j]);
     for (const char* e : {"DEX_CONV_STREAM", "DEX_H_BF16", "DEX_ATTN_SEPARATE"}) {     // knobs read at enqueue time
         const char* v = getenv(e);

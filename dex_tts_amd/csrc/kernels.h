@@ -135,9 +135,16 @@ struct FinalP {
     int x_bf16;                                           // X (the final conv's raw output) is bf16 (1) / fp16 (2)
 };
 void launch_final(const FinalP& p, hipStream_t st);
-// Heun evaluation tables from the schedule t_0..t_N: sig[2i] = t_i, sig[2i+1] = t_i + (t_{i+1} - t_i) (i < n-1),
-// sig[2n-1] = 0; h[2i] = h[2i+1] = t_{i+1} - t_i.
-void launch_heun_expand(const float* sigmas, int n, float* sig, float* h, hipStream_t st);
+// "Increase noise temporarily" tables (edm.py:194-196, schedule 'linear', scaling 'none'): for the schedule t_0..t_N
+//   t_hat[i] = t_i + gamma_i t_i,  gamma_i = min(S_churn / n, sqrt(2) - 1) if S_min <= t_i <= S_max else 0  (t_hat[n] = 0),
+//   h[i] = t_{i+1} - t_hat[i],  ncoef[i] = sqrt(max(t_hat^2 - t_i^2, 0)) * S_noise      — fp32, in the reference's op order.
+void launch_churn_tables(const float* sigmas, int n, float S_churn, float S_min, float S_max, float S_noise,
+                         float* t_hat, float* h, float* ncoef, hipStream_t st);
+// x_hat = x + ncoef[i] * noise (two rounded fp32 ops like the reference's mul then add)
+void launch_add_noise(float* x, const float* noise, const float* ncoef_i, long n, hipStream_t st);
+// Heun evaluation tables from t_hat_0..t_hat_{n-1} and the step sizes h_i = t_{i+1} - t_hat_i:
+// sig[2i] = t_hat_i, sig[2i+1] = t_hat_i + h_i (i < n-1), sig[2n-1] = 0; hout[2i] = hout[2i+1] = h_i.
+void launch_heun_expand(const float* t_hat, const float* h, int n, float* sig, float* hout, hipStream_t st);
 
 // Linear attention (diffusion.py:82-92): qkv [B,n,3*heads*32]; softmax over positions on k.
 struct LinAttnCtxP { const float* qkv; int ld; long bstride; int n; int heads; int chunk; int nchunks;

@@ -295,16 +295,45 @@ __global__ __launch_bounds__(256) void final_kernel(const FinalP p) {
         for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < p.zero_n; i += nthreads) p.zero_ptr[i] = 0.f;
     }
 }
-__global__ void heun_expand_kernel(const float* sigmas, int n, float* sig, float* h) {
+__global__ void churn_tables_kernel(const float* sigmas, int n, float S_churn, float S_min, float S_max, float S_noise,
+                                    float* t_hat, float* h, float* ncoef) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { t_hat[n] = 0.f; return; }
+    const float t = sigmas[i];
+    // gamma is a python float in the reference (edm.py:194); multiplying the fp32 0-dim tensor t_cur by it happens in fp32
+    const double gd = fmin((double)S_churn / (double)n, sqrt(2.0) - 1.0);
+    const bool on = S_churn > 0.f && (double)S_min <= (double)t && (S_max <= 0.f || (double)t <= (double)S_max);
+    const float g = on ? (float)gd : 0.f;
+    const float th = __fadd_rn(t, __fmul_rn(g, t));                  // t_cur + gamma * t_cur, no contraction
+    t_hat[i] = th;
+    h[i] = __fsub_rn(sigmas[i + 1], th);
+    const float d2 = __fsub_rn(__fmul_rn(th, th), __fmul_rn(t, t));
+    ncoef[i] = __fmul_rn(sqrtf(fmaxf(d2, 0.f)), S_noise);
+}
+void launch_churn_tables(const float* sigmas, int n, float S_churn, float S_min, float S_max, float S_noise,
+                         float* t_hat, float* h, float* ncoef, hipStream_t st) {
+    hipLaunchKernelGGL(churn_tables_kernel, dim3((n + 64) / 64), dim3(64), 0, st, sigmas, n, S_churn, S_min, S_max, S_noise, t_hat, h, ncoef);
+}
+__global__ void add_noise_kernel(float* x, const float* noise, const float* ncoef, long n) {
+    const float c = *ncoef;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        x[i] = __fadd_rn(x[i], __fmul_rn(c, noise[i]));
+}
+void launch_add_noise(float* x, const float* noise, const float* ncoef_i, long n, hipStream_t st) {
+    long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(add_noise_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, noise, ncoef_i, n);
+}
+__global__ void heun_expand_kernel(const float* t_hat, const float* hin, int n, float* sig, float* h) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float t = sigmas[i], hh = sigmas[i + 1] - t;
+    const float t = t_hat[i], hh = hin[i];
     sig[2 * i] = t; h[2 * i] = hh;
     if (i < n - 1) { sig[2 * i + 1] = t + hh; h[2 * i + 1] = hh; }
     else sig[2 * i + 1] = 0.f;
 }
-void launch_heun_expand(const float* sigmas, int n, float* sig, float* h, hipStream_t st) {
-    hipLaunchKernelGGL(heun_expand_kernel, dim3((n + 63) / 64), dim3(64), 0, st, sigmas, n, sig, h);
+void launch_heun_expand(const float* t_hat, const float* hin, int n, float* sig, float* h, hipStream_t st) {
+    hipLaunchKernelGGL(heun_expand_kernel, dim3((n + 63) / 64), dim3(64), 0, st, t_hat, hin, n, sig, h);
 }
 void launch_final(const FinalP& p, hipStream_t st) {
     // every block pays the GroupNorm-coefficient prologue (fp64 divide + sqrt behind a barrier, ~2 us): at large batch

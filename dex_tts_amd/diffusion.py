@@ -85,6 +85,8 @@ class Diffusion(nn.Module):
         self.use_graph = False
         self.solver = "euler"                    # the reference wires 'euler' (diffusion.py:216); 'heun' = edm.py:207-214
         self.rng_parity = True                   # replay the reference's per-step randn_like draws (edm.py:196)
+        # ablation_sampler's stochastic settings (edm.py:109,194-196); the reference wires the defaults (S_churn = 0)
+        self.S_churn, self.S_min, self.S_max, self.S_noise = 0.0, 0.0, float("inf"), 1.0
         self._engine = None
         self._engine_key = None
         if variant == "dex":
@@ -111,13 +113,18 @@ class Diffusion(nn.Module):
 
     def _sample(self, z, mask, mu, steps, spk=None, ref=None, sty=None, sty_lengths=None):
         eng = self.engine(z.device)
+        noise = None
+        if self.S_churn > 0:
+            # the draws the reference makes inside its loop, one randn_like(x_cur) per step (edm.py:196), in that order
+            noise = torch.stack([torch.randn_like(z) for _ in range(int(steps))])
         return eng.sample(z, mask, mu, int(steps), spk=spk, ref=ref, sty=sty, sty_lengths=sty_lengths,
-                          use_graph=self.use_graph, solver=self.solver)
+                          use_graph=self.use_graph, solver=self.solver, noise=noise, S_churn=self.S_churn, S_min=self.S_min,
+                          S_max=self.S_max, S_noise=self.S_noise)
 
     def _advance_rng(self, like: torch.Tensor, n: int):
         """The reference draws ``randn_like(x_cur)`` once per Euler step and multiplies it by 0
         (edm.py:196); only the generator state matters.  Advance the Philox offset by the same amount."""
-        if not self.rng_parity or n <= 0:
+        if not self.rng_parity or n <= 0 or self.S_churn > 0:      # (with S_churn > 0 the draws were really made, in _sample)
             return
         gen = torch.cuda.default_generators[like.device.index if like.device.index is not None else torch.cuda.current_device()]
         if n > 1 and hasattr(gen, "get_offset") and hasattr(gen, "set_offset"):

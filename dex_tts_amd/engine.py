@@ -102,7 +102,7 @@ class ScoreNetEngine:
 
     # ---------------------------------------------------------------------------------------
     def _fill_args(self, a: _lib.DexSampleArgs, mu, mask, sigmas, out, n_steps, spk, ref, sty, sty_lengths, use_graph,
-                   solver="euler"):
+                   solver="euler", noise=None, churn=None):
         if solver not in _lib.SOLVER:
             raise ValueError(f"solver must be 'euler' or 'heun' (edm.py:107), got {solver!r}")
         B, F, T = mu.shape
@@ -145,6 +145,15 @@ class ScoreNetEngine:
         base = (ws.data_ptr() + 255) // 256 * 256
         a.workspace_dev, a.workspace_bytes = base, ws.numel() - (base - ws.data_ptr())
         a.use_graph = 1 if use_graph else 0
+        a.noise_dev, a.S_churn, a.S_min, a.S_max, a.S_noise = None, 0.0, 0.0, 0.0, 1.0
+        if churn is not None and churn[0] > 0:
+            S_churn, S_min, S_max, S_noise = churn
+            if noise is None or tuple(noise.shape) != (n_steps, B, F, T):
+                raise ValueError(f"S_churn > 0 needs noise of shape {(n_steps, B, F, T)} (one randn_like draw per step, edm.py:196)")
+            keep.append(noise)
+            a.noise_dev = noise.data_ptr()
+            a.S_churn, a.S_min, a.S_noise = float(S_churn), float(S_min), float(S_noise)
+            a.S_max = 0.0 if S_max == float("inf") else float(S_max)          # <= 0 is the library's +inf
         return keep
 
     @staticmethod
@@ -167,10 +176,12 @@ class ScoreNetEngine:
         return bufs
 
     def sample(self, z, mask, mu, n_steps, spk=None, ref=None, sty=None, sty_lengths=None, use_graph=False,
-               solver="euler"):
+               solver="euler", noise=None, S_churn=0.0, S_min=0.0, S_max=float("inf"), S_noise=1.0):
         """ablation_sampler(solver, edm, linear, none) for latent z — edm.py:109-216.  ``solver`` is 'euler' (what
         Diffusion wires, diffusion.py:216) or 'heun' (edm.py:207-214; 2n-1 network evaluations).  Asynchronous.
-        ``use_graph``: the whole call (conditioning tables + every network evaluation) is one cached hipGraph."""
+        ``use_graph``: the whole call (conditioning tables + every network evaluation) is one cached hipGraph.
+        ``S_churn > 0`` turns on the stochastic sampler (edm.py:194-196); ``noise`` [n_steps,B,80,T] then holds step i's
+        ``randn_like(x_cur)`` draw (the caller owns the RNG, as with ablation_sampler's ``randn_like`` argument)."""
         with torch.cuda.device(self.device):
             cur = torch.cuda.current_stream(self.device)
             run_on = cur
@@ -195,22 +206,31 @@ class ScoreNetEngine:
                     spk = spk.to(device=self.device, dtype=torch.float32).contiguous()
                 else:
                     spk = None
+                churn = (S_churn, S_min, S_max, S_noise) if S_churn and S_churn > 0 else None
+                if churn is not None:
+                    if noise is None:
+                        raise ValueError("S_churn > 0 needs the per-step noise draws (noise=[n_steps,B,80,T])")
+                    noise = noise.to(device=self.device, dtype=torch.float32).contiguous()
+                else:
+                    noise = None
                 if use_graph:
                     dexin = ([sty, sty_lengths] + list(ref)) if (self.cfg.variant == "dex" and ref is not None) else []
-                    flat = [z, mu, mask, sig] + ([spk] if spk is not None else []) + dexin
-                    key = (n_steps, solver, spk is not None) + tuple((tuple(t.shape), t.dtype) for t in flat)
+                    flat = [z, mu, mask, sig] + ([spk] if spk is not None else []) + ([noise] if noise is not None else []) + dexin
+                    key = (n_steps, solver, spk is not None, noise is not None) + tuple((tuple(t.shape), t.dtype) for t in flat)
                     st = self._staged(key, flat)
                     z, mu, mask, sig = st[:4]
                     k = 4
                     if spk is not None:
                         spk = st[k]; k += 1
+                    if noise is not None:
+                        noise = st[k]; k += 1
                     if dexin:
                         sty, sty_lengths, ref = st[k], st[k + 1], st[k + 2:]
                     out = self._stage_out.setdefault(key, torch.empty_like(mu))
                 else:
                     out = torch.empty_like(mu)
                 a = _lib.DexSampleArgs()
-                keep = self._fill_args(a, mu, mask, sig, out, n_steps, spk, ref, sty, sty_lengths, use_graph, solver)
+                keep = self._fill_args(a, mu, mask, sig, out, n_steps, spk, ref, sty, sty_lengths, use_graph, solver, noise, churn)
                 a.z_dev = z.data_ptr()
                 self._check(self.lib.dex_sample(self.h, C.byref(a), self._stream()))
                 self._keep = keep + [z]           # keep inputs alive until the stream work is enqueued & consumed

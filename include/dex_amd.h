@@ -82,6 +82,11 @@ typedef struct {
                                  * once into a hipGraph, cached under (shapes, solver, precision, stream, every device pointer
                                  * above) and replayed with ONE hipGraphLaunch; needs a non-default stream */
     int32_t solver;             /* DexSolver; 0 = Euler, what Diffusion wires (diffusion.py:216) */
+    /* Stochastic sampler, ablation_sampler's S_churn / S_min / S_max / S_noise (edm.py:109,194-196).  Zero-initialised
+     * fields = the deterministic sampler the reference wires (S_churn = 0: its per-step randn_like is multiplied by 0). */
+    const float* noise_dev;     /* [n_steps][B,80,T]: step i's randn_like(x_cur) draw (the caller owns the RNG); required
+                                 * when S_churn > 0, ignored otherwise */
+    float S_churn, S_min, S_max, S_noise;   /* S_max <= 0 means +inf; S_noise is used as given when S_churn > 0 */
 } DexSampleArgs;
 
 /* One EDMPrecond.forward call (edm.py:88-98): out = c_skip*x + c_out*F(c_in*x, mask, mu, ln(sigma)/4). */

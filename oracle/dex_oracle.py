@@ -313,41 +313,60 @@ def edm_precond(W, cfg, x: Tensor, sigma: Tensor, mask: Tensor, mu: Tensor, **kw
     return c_skip * x + c_out * f
 
 
+def churn_step(x: Tensor, t_cur: Tensor, n_steps: int, noise_i: Optional[Tensor], S_churn: float, S_min: float, S_max: float,
+               S_noise: float):
+    """"Increase noise temporarily" — edm.py:194-196 with schedule='linear', scaling='none' (sigma(t) = t, s(t) = 1):
+    gamma = min(S_churn/num_steps, sqrt(2)-1) if S_min <= t_cur <= S_max else 0;  t_hat = t_cur + gamma t_cur;
+    x_hat = x_cur + sqrt(clip(t_hat^2 - t_cur^2, 0)) * S_noise * randn_like(x_cur).  The noise draw is an input here
+    (ablation_sampler's ``randn_like`` argument).  Returns (x_hat, t_hat)."""
+    gamma = min(S_churn / n_steps, np.sqrt(2) - 1) if S_min <= float(t_cur) <= S_max else 0
+    t_hat = torch.as_tensor(t_cur + gamma * t_cur)
+    if noise_i is None:
+        return x, t_hat
+    x_hat = x + (t_hat ** 2 - t_cur ** 2).clip(min=0).sqrt() * S_noise * noise_i
+    return x_hat, t_hat
+
+
 def edm_euler_sampler(W, cfg, z: Tensor, mask: Tensor, mu: Tensor, n_steps: int, trace: Optional[list] = None,
-                      **kw) -> Tensor:
+                      noise: Optional[Tensor] = None, S_churn: float = 0, S_min: float = 0, S_max: float = float("inf"),
+                      S_noise: float = 1, **kw) -> Tensor:
     """ablation_sampler(solver='euler', discretization='edm', schedule='linear', scaling='none')
-    — edm.py:109-216: x0 = z*sigma_0; per step d = (x - D(x, sigma))/sigma; x += (sigma_next - sigma) d.
-    The per-step ``0 * randn_like`` (edm.py:196) contributes exactly zero and is omitted here."""
+    — edm.py:109-216: x0 = z*sigma_0; per step (x_hat, t_hat) = churn(x, t) (edm.py:194-196), d = (x_hat - D(x_hat, t_hat))/t_hat,
+    x = x_hat + (t_next - t_hat) d.  With S_churn = 0 (what Diffusion wires) the per-step ``0 * randn_like`` contributes
+    exactly zero and ``noise`` may be None; otherwise noise[i] is the draw of step i."""
     ts = edm_sigmas(n_steps, z.dtype)
     x = z * ts[0]
     for i in range(n_steps):
         t_cur, t_next = ts[i], ts[i + 1]
-        den = edm_precond(W, cfg, x, t_cur, mask, mu, **kw)
-        d = (1 / t_cur) * x - (1 / t_cur) * den
-        x = x + (t_next - t_cur) * d
+        x, t_hat = churn_step(x, t_cur, n_steps, None if noise is None else noise[i], S_churn, S_min, S_max, S_noise)
+        den = edm_precond(W, cfg, x, t_hat, mask, mu, **kw)
+        d = (1 / t_hat) * x - (1 / t_hat) * den
+        x = x + (t_next - t_hat) * d
         if trace is not None:
             trace.append(x.clone())
     return x
 
 
 def edm_heun_sampler(W, cfg, z: Tensor, mask: Tensor, mu: Tensor, n_steps: int, trace: Optional[list] = None,
-                     **kw) -> Tensor:
+                     noise: Optional[Tensor] = None, S_churn: float = 0, S_min: float = 0, S_max: float = float("inf"),
+                     S_noise: float = 1, **kw) -> Tensor:
     """ablation_sampler(solver='heun', alpha=1, discretization='edm', schedule='linear', scaling='none')
     — edm.py:186-214.  Predictor as in Euler (edm.py:199-204); every step but the last then evaluates the
-    network a second time at (x', t') with t' = t + 1*h (fp32: not necessarily bit-equal to t_next) and
-    averages the two slopes (edm.py:207-214).  S_churn = 0, so x_hat = x_cur and t_hat = t_cur."""
+    network a second time at (x', t') with t' = t_hat + 1*h (fp32: not necessarily bit-equal to t_next) and
+    averages the two slopes (edm.py:207-214)."""
     ts = edm_sigmas(n_steps, z.dtype)
     x = z * ts[0]
     for i in range(n_steps):
         t_cur, t_next = ts[i], ts[i + 1]
-        h = t_next - t_cur
-        den = edm_precond(W, cfg, x, t_cur, mask, mu, **kw)
-        d_cur = (1 / t_cur) * x - (1 / t_cur) * den
+        x, t_hat = churn_step(x, t_cur, n_steps, None if noise is None else noise[i], S_churn, S_min, S_max, S_noise)
+        h = t_next - t_hat
+        den = edm_precond(W, cfg, x, t_hat, mask, mu, **kw)
+        d_cur = (1 / t_hat) * x - (1 / t_hat) * den
         if i == n_steps - 1:
             x = x + h * d_cur
         else:
             x_prime = x + h * d_cur
-            t_prime = t_cur + h
+            t_prime = t_hat + h
             den = edm_precond(W, cfg, x_prime, t_prime, mask, mu, **kw)
             d_prime = (1 / t_prime) * x_prime - (1 / t_prime) * den
             x = x + h * (0.5 * d_cur + 0.5 * d_prime)

@@ -190,7 +190,38 @@ def golden_heun():
     print("heun:", {k: (v.shape, float(np.abs(v).max())) for k, v in out.items()})
 
 
+@torch.no_grad()
+def golden_churn():
+    """Stochastic branch of the reference's own ablation_sampler (edm.py:194-196, S_churn > 0) on the gedex_lj fixture
+    inputs, with the per-step noise injected through the sampler's ``randn_like`` argument (stored: it is the draw the
+    library has to be fed), Euler and Heun, plus the t_hat sequence the network sees."""
+    out = {}
+    cfg = C.gedex_lj()
+    m = manifest("gedex_lj_churn", cfg)
+    edm = sys.modules[type(m.precond_model).__module__]
+    B, T, lengths = 2, 64, [64, 44]
+    mu, mask, z, lengths = synth.make_inputs(B, T, lengths, seed=1234)
+    tmu, tmask, tz = map(torch.from_numpy, (mu, mask, z))
+    for solver, n, S_churn, S_min, S_max, S_noise in (("euler", 6, 30.0, 0.05, 50.0, 1.003), ("heun", 4, 10.0, 0.0, float("inf"), 1.0)):
+        noise = synth.normalish(f"churn_{solver}", (n, B, 80, T), 4321)
+        it = iter(torch.from_numpy(noise))
+        y = edm.ablation_sampler(net=m.precond_model, latents=tz, mask=tmask, mu=tmu, spk=None, num_steps=n, solver=solver,
+                                 discretization="edm", schedule="linear", scaling="none", randn_like=lambda x: next(it),
+                                 S_churn=S_churn, S_min=S_min, S_max=S_max, S_noise=S_noise)
+        tag = f"{solver}_n{n}"
+        out[tag] = y.numpy()
+        # (the noise itself is regenerated by the tests from the same portable generator: synth.normalish(f"churn_{solver}", ...))
+        out[tag + "_params"] = np.asarray([S_churn, S_min, min(S_max, 3.0e38), S_noise], dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, "churn.npz"), **out)
+    print("churn:", {k: v.shape for k, v in out.items()})
+
+
 def main():
+    if "--churn-only" in sys.argv:
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        golden_churn()
+        return
     if "--heun-only" in sys.argv:
         torch.manual_seed(0)
         torch.set_num_threads(8)
@@ -206,6 +237,7 @@ def main():
     golden_model("dex_vctk", C.dex_vctk(), B=1, T=64, lengths=[57], sampler_steps=[4, 10], dex_dims=(40, 40, [33]))
     golden_audio()
     golden_heun()
+    golden_churn()
 
 
 if __name__ == "__main__":

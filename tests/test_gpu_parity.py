@@ -111,6 +111,53 @@ def test_heun_oracle(name, kw, n):
     assert err.max() <= 2e-3 and err.mean() <= 2e-4, (err.max(), err.mean())
 
 
+@pytest.mark.parametrize("tag", ["euler_n6", "heun_n4"])
+def test_churn_golden(tag):
+    """Stochastic sampler (edm.py:194-196, S_churn > 0) against goldens from the reference's own ablation_sampler fed the
+    same per-step noise; eager and graph replay."""
+    from tests.test_oracle_golden import churn_case
+    g, want, solver, n, noise, sp = churn_case(GOLD, tag)
+    cfg, eng, w = U.engine_for("gedex_lj")
+    mu, mask, z = (torch.from_numpy(g[k]) for k in ("mu", "mask", "z"))
+    got = eng.sample(z, mask, mu, n, solver=solver, noise=torch.from_numpy(noise), **sp).cpu().numpy()
+    err = np.abs(got - want)
+    assert err.max() <= 2e-3 and err.mean() <= 2e-4, (tag, err.max(), err.mean())
+    rep = eng.sample(z, mask, mu, n, solver=solver, noise=torch.from_numpy(noise), use_graph=True, **sp).cpu().numpy()
+    assert np.array_equal(got, rep)
+    with pytest.raises(ValueError):
+        eng.sample(z, mask, mu, n, solver=solver, S_churn=5.0)          # no noise handed over
+
+
+def test_churn_module_rng_stream():
+    """Diffusion.S_churn > 0: the module draws z and then one randn_like per step from the device generator, exactly the
+    reference's order; the result equals the oracle fed those draws."""
+    from dex_tts_amd import config as C, synth
+    from dex_tts_amd.diffusion import from_config
+    from oracle import dex_oracle as O
+    cfg, eng, w = U.engine_for("gedex_lj")
+    m = from_config(cfg)
+    sd = {}
+    for k, v in w.items():
+        sd[f"denoise_fn.{k}"] = torch.from_numpy(v)
+        sd[f"precond_model.model.{k}"] = torch.from_numpy(v)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    m.S_churn, m.S_min, m.S_max, m.S_noise = 20.0, 0.01, 60.0, 1.0
+    mu, mask, _, _ = synth.make_inputs(2, 64, [64, 48])
+    mu_t, mask_t = torch.from_numpy(mu).cuda(), torch.from_numpy(mask).cuda()
+    torch.manual_seed(7)
+    out = m(mu_t, mask_t, mu_t, n_timesteps=5, infer=True, temperature=1.5).cpu().numpy()
+    off = torch.cuda.default_generators[0].get_offset()
+    torch.manual_seed(7)
+    z = torch.randn((2, 80, 64), device="cuda") / 1.5 + mu_t
+    noise = torch.stack([torch.randn_like(z) for _ in range(5)])
+    assert torch.cuda.default_generators[0].get_offset() == off
+    ref = O.diffusion_infer(O.as_torch(w), cfg, torch.from_numpy(mask), torch.from_numpy(mu), 5, z.cpu(), noise=noise.cpu(),
+                            S_churn=20.0, S_min=0.01, S_max=60.0, S_noise=1.0).numpy()
+    err = np.abs(out - ref)
+    assert err.max() <= 2e-3 and err.mean() <= 2e-4, (err.max(), err.mean())
+
+
 def test_heun_bf16_mode_and_module_switch():
     """bf16 mode under Heun stays inside the documented bf16 tolerance; Diffusion.solver selects the branch."""
     from dex_tts_amd import config as C, synth

@@ -99,6 +99,32 @@ def test_sampler_heun(golden_dir, key):
         assert np.abs(h[key] - g[f"sampler_n{n}"]).max() > 1e-2
 
 
+def churn_case(golden_dir, tag):
+    """Inputs of the stochastic-sampler goldens (tests/golden/churn.npz, oracle/make_golden.py::golden_churn): the gedex_lj
+    fixture inputs, the per-step noise regenerated from the portable generator, the S_* parameters."""
+    c = load(golden_dir, "churn")
+    solver, n = tag.split("_n")
+    g = load(golden_dir, "gedex_lj")
+    S_churn, S_min, S_max, S_noise = (float(v) for v in c[tag + "_params"])
+    noise = synth.normalish(f"churn_{solver}", (int(n),) + g["z"].shape, 4321)
+    return g, c[tag], solver, int(n), noise, dict(S_churn=S_churn, S_min=S_min, S_max=S_max, S_noise=S_noise)
+
+
+@pytest.mark.parametrize("tag", ["euler_n6", "heun_n4"])
+def test_sampler_churn(golden_dir, tag):
+    """Stochastic branch (edm.py:194-196, S_churn > 0): goldens from the reference's own ablation_sampler fed the noise
+    through its ``randn_like`` argument."""
+    g, want, solver, n, noise, sp = churn_case(golden_dir, tag)
+    cfg = C.gedex_lj()
+    W = O.as_torch(synth.make_weights(C.param_shapes(cfg)), torch.float32)
+    mu, mask, z = (torch.from_numpy(g[k]) for k in ("mu", "mask", "z"))
+    y = O.diffusion_infer(W, cfg, mask, mu, n, z, solver=solver, noise=torch.from_numpy(noise), **sp).numpy()
+    err = np.abs(y - want)
+    assert err.max() <= 1e-3 and err.mean() <= 1e-4, (tag, err.max(), err.mean())
+    y0 = O.diffusion_infer(W, cfg, mask, mu, n, z, solver=solver).numpy()          # the deterministic trajectory differs
+    assert np.abs(y0 - want).max() > 1e-2
+
+
 def test_heun_sigma_sequence(golden_dir):
     """The sigma each network evaluation sees: t_i for the predictor, fl(t_i + fl(t_{i+1} - t_i)) for the
     corrector, no corrector on the last step -> 2n-1 evaluations."""
