@@ -5,14 +5,17 @@
 #include <cstdlib>
 #include <vector>
 #include "../dex_tts_amd/csrc/kernels.h"
+#include "../dex_tts_amd/csrc/kernels_lp.h"      // reduced-precision launchers, bf16 build (namespace dex::bf16)
 using namespace dex;
+using namespace dex::bf16;
+namespace dex { thread_local const char* g_last_symbol = nullptr; }   // defined in lp_dispatch.hip in the library build
 static float* dalloc(size_t n, int fill = 0) { float* p; hipMalloc(&p, n * 4); hipMemset(p, fill, n * 4); return p; }
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 32, H = 80, W = 512, C = 64;
     const long npix = (long)H * W;
     float* x = dalloc(B * npix * C); float* y = dalloc(B * npix * C); float* res = dalloc(B * npix * C); float* xout = dalloc(B * npix * C);
     unsigned short* wb; hipMalloc(&wb, 9L * C * C * 2); hipMemset(wb, 0, 9L * C * C * 2);
-    float* bias = dalloc(C); float* mask = dalloc((size_t)B * W, 0x3f); float* st = dalloc(8 * 64 * 2 * B); float* st2 = dalloc(8 * 64 * 2 * B);
+    float* bias = dalloc(C); float* mask = dalloc((size_t)B * W, 0x3f); gnfix_t* st = (gnfix_t*)dalloc(8 * 64 * 2 * 2 * B); gnfix_t* st2 = (gnfix_t*)dalloc(8 * 64 * 2 * 2 * B);
     float* gam = dalloc(C); float* bet = dalloc(C);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int variant = 0; variant < 6; ++variant) {
@@ -26,9 +29,9 @@ int main(int argc, char** argv) {
         if (variant == 5) { p.y_bf16 = 1; nm = "plain fp32->bf16"; }
         for (int mode = 0; mode < 2; ++mode) {
             setenv("DEX_CONV_STREAM", mode ? "1" : "0", 1);
-            for (int it = 0; it < 3; ++it) launch_conv3x3_bf16(p, 0);
+            for (int it = 0; it < 3; ++it) launch_conv3x3_lp(p, 0);
             hipEventRecord(e0, 0);
-            for (int it = 0; it < 20; ++it) launch_conv3x3_bf16(p, 0);
+            for (int it = 0; it < 20; ++it) launch_conv3x3_lp(p, 0);
             hipEventRecord(e1, 0); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             printf("%-18s %s: %8.2f us\n", nm, mode ? "stream" : "tile  ", ms * 1000 / 20);
@@ -37,7 +40,7 @@ int main(int argc, char** argv) {
         if (!conv3x3_stream_tiles(p)) {                    // small grid: the tile kernel's phase counters
             const int nb = (W / 32) * (H / 4) * B;
             long long* dbg; hipMalloc(&dbg, (size_t)nb * 64); hipMemset(dbg, 0, (size_t)nb * 64);
-            p.dbg = dbg; launch_conv3x3_bf16(p, 0); hipDeviceSynchronize(); p.dbg = nullptr;
+            p.dbg = dbg; launch_conv3x3_lp(p, 0); hipDeviceSynchronize(); p.dbg = nullptr;
             std::vector<long long> h((size_t)nb * 8); hipMemcpy(h.data(), dbg, (size_t)nb * 64, hipMemcpyDeviceToHost);
             double a[8] = {0}; for (int bl = 0; bl < nb; ++bl) for (int k = 0; k < 8; ++k) a[k] += h[(size_t)bl * 8 + k];
             printf("   tile kernel, avg cycles/wg (%d wgs): issue loads %.0f | GN coeffs + barrier %.0f | convert + LDS %.0f | nine taps %.0f | epilogue %.0f | total %.0f\n",
@@ -47,7 +50,7 @@ int main(int argc, char** argv) {
             const int tpw = conv3x3_stream_tiles(p);
             const int nb = (W / 32) * ((H / 8 + tpw - 1) / tpw) * B;
             long long* dbg; hipMalloc(&dbg, (size_t)nb * 64); hipMemset(dbg, 0, (size_t)nb * 64);
-            p.dbg = dbg; launch_conv3x3_bf16(p, 0); hipDeviceSynchronize(); p.dbg = nullptr;
+            p.dbg = dbg; launch_conv3x3_lp(p, 0); hipDeviceSynchronize(); p.dbg = nullptr;
             std::vector<long long> h((size_t)nb * 8); hipMemcpy(h.data(), dbg, (size_t)nb * 64, hipMemcpyDeviceToHost);
             double a[8] = {0}; for (int bl = 0; bl < nb; ++bl) for (int k = 0; k < 8; ++k) a[k] += h[(size_t)bl * 8 + k];
             printf("   avg cycles/wg (tpw=%d, %d wgs): setup %.0f | per wg total: load-issue %.0f mfma %.0f epilogue %.0f barrier1 %.0f convert+lds %.0f barrier2 %.0f | total %.0f\n",

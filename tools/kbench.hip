@@ -7,7 +7,9 @@
 #include <functional>
 #include <algorithm>
 #include "kernels.h"
+#include "kernels_lp.h"          // the reduced-precision launchers, bf16 build (namespace dex::bf16)
 using namespace dex;
+using namespace dex::bf16;
 
 static float* dalloc(size_t n, float val = 0.01f) {
     float* p; hipMalloc(&p, n * 4);
@@ -153,14 +155,14 @@ int main() {
         float* w = dalloc(9L * c.Cin * c.Cout, 0.1f); float* bias = dalloc(c.Cout);
         unsigned short* wb; hipMalloc(&wb, 9L * c.Cin * c.Cout * 2); hipMemset(wb, 0, 9L * c.Cin * c.Cout * 2);
         float* mask = dalloc(B * T, 0.f); hipMemset(mask, 0, 4); // values irrelevant
-        float* st; hipMalloc(&st, 8 * 64 * 2 * 8 * B); hipMemset(st, 0, 8 * 64 * 2 * 8 * B);
+        gnfix_t* st; hipMalloc(&st, 8 * 64 * 2 * 8 * B); hipMemset(st, 0, 8 * 64 * 2 * 8 * B);
         Conv3P p{}; p.X = x; p.ldx = c.Cin; p.H = c.H; p.W = c.W; p.Cin = c.Cin; p.Cout = c.Cout; p.Wbf = wb; p.bias = bias; p.Y = y;
         p.mask = mask; p.mask_ws = 512 / c.W; p.mask_bstride = T; p.gn_stats = st; p.B = B;
         char nm[80];
         const double fl = 2.0 * npix * c.Cout * 9 * c.Cin, by = 4.0 * npix * (c.Cin + c.Cout);
-        snprintf(nm, 80, "conv3x3 bf16 patch %d->%d @%dx%d", c.Cin, c.Cout, c.H, c.W); timeit(nm, 50, fl, by, [&] { launch_conv3x3_bf16(p, 0); });
+        snprintf(nm, 80, "conv3x3 bf16 patch %d->%d @%dx%d", c.Cin, c.Cout, c.H, c.W); timeit(nm, 50, fl, by, [&] { launch_conv3x3_lp(p, 0); });
         p.gn_stats = nullptr;
-        snprintf(nm, 80, "  .. same, no GN atomics"); timeit(nm, 50, fl, by, [&] { launch_conv3x3_bf16(p, 0); });
+        snprintf(nm, 80, "  .. same, no GN atomics"); timeit(nm, 50, fl, by, [&] { launch_conv3x3_lp(p, 0); });
         p.gn_stats = st;
         IGemmP g{}; g.A = x; g.lda = c.Cin; g.a_bstride = npix * c.Cin; g.Hi = c.H; g.Wi = c.W; g.Cin = c.Cin; g.KH = 3; g.KW = 3; g.sh = g.sw = 1; g.off_h = g.off_w = -1;
         g.step_h = g.step_w = 1; g.Ho = c.H; g.Wo = c.W; g.W = w; g.Wbf = wb; g.N = c.Cout; g.K = 9 * c.Cin; g.ksplit = 1; g.groups = 1; g.bias = bias;
