@@ -253,6 +253,31 @@ def side_workload(name, precision, device, stream, graph_mode, steps=3, warmup=1
     return ent
 
 
+def vocoder_block(device, stream, B=1, T=512, steps=10, warmup=3):
+    """HiFi-GAN V1 generator (the step right after the sampler) on the mel of the headline workload."""
+    from dex_tts_amd import vocoder as V
+    h = V.HIFIGAN_V1
+    gen = V.Generator()
+    gen.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_vocoder_weights(V.param_shapes(h)).items()})
+    gen = gen.to(device).eval()
+    mel = torch.from_numpy(synth.make_inputs(B, T, None, seed=1234)[0]).to(device)
+    # algorithmic work: every Conv1d / ConvTranspose1d as 2 * L_out * Cin * Cout * taps-per-output
+    fl, L, c = 2.0 * T * 80 * h["upsample_initial_channel"] * 7, T, h["upsample_initial_channel"]
+    for u, k in zip(h["upsample_rates"], h["upsample_kernel_sizes"]):
+        fl += 2.0 * L * c * (c // 2) * k
+        L, c = L * u, c // 2
+        fl += sum(2.0 * L * c * c * kk * 6 for kk in h["resblock_kernel_sizes"])
+    fl += 2.0 * L * c * 7
+    with torch.cuda.stream(stream):
+        dt, ev, wav = timed_calls(lambda: gen(mel), steps, warmup, device)
+    assert torch.isfinite(wav).all()
+    sec = dt / steps
+    return {"workload": f"HiFi-GAN V1 generator (hifigan/config.json), B={B}, T={T} mel frames -> {wav.shape[-1]} samples, exact-fp32 MFMA",
+            "value": round(B * T / sec, 1), "unit": "mel-frames/s", "ms_per_call": round(sec * 1e3, 3), "hip_event_median_ms": round(statistics.median(ev), 3),
+            "rtf": round(sec / (B * T * 256 / 22050.0), 6), "algorithmic_GFLOP": round(B * fl / 1e9, 1),
+            "mfma_TFLOP/s": round(B * fl / sec / 1e12, 1), "frac_of_fp32_mfma_peak": round(B * fl / sec / 1e12 / PEAK_TFLOPS["f32"], 3)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -402,6 +427,8 @@ def main():
                 "configs[3]": side_workload("dex_esd_b32_n100", precision, device, stream, args.graph, steps=2),
                 "configs[4]": side_workload("gedex_long", "fp16" if "fp16" in _lib.PRECISION else precision, device, stream, "on"),
             }
+        if prof and args.workload == "gedex_b1" and not args.no_configs:
+            res["vocoder"] = vocoder_block(device, stream)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, weights, B, T, n_steps, TrTs)
             res["gpu_over_cpu"] = round(frames_s / res["cpu_baseline"]["value"], 1)

@@ -35,6 +35,12 @@ class DexSampleArgs(C.Structure):
                 ("noise_dev", C.c_void_p), ("S_churn", C.c_float), ("S_min", C.c_float), ("S_max", C.c_float), ("S_noise", C.c_float)]
 
 
+class DexVocoderConfig(C.Structure):
+    _fields_ = [("num_mels", C.c_int32), ("upsample_initial_channel", C.c_int32), ("n_upsamples", C.c_int32),
+                ("upsample_rates", C.c_int32 * 6), ("upsample_kernel_sizes", C.c_int32 * 6), ("n_resblock_kernels", C.c_int32),
+                ("resblock_kernel_sizes", C.c_int32 * 3), ("resblock_dilation_sizes", (C.c_int32 * 3) * 3)]
+
+
 class DexDenoiseArgs(C.Structure):
     _fields_ = [("s", DexSampleArgs), ("x_dev", C.c_void_p)]
 
@@ -64,6 +70,16 @@ SYMBOLS = [
     ("dex_profile_num", C.c_int, [C.c_void_p]),
     ("dex_profile_get", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("dex_voc_create", C.c_int, [C.POINTER(DexVocoderConfig), C.POINTER(C.c_void_p)]),
+    ("dex_voc_destroy", None, [C.c_void_p]),
+    ("dex_voc_last_error", C.c_char_p, [C.c_void_p]),
+    ("dex_voc_num_weights", C.c_int, [C.c_void_p]),
+    ("dex_voc_weight_info", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    ("dex_voc_load_weight_async", C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
+    ("dex_voc_finalize", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("dex_voc_workspace_bytes", C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    ("dex_voc_samples", C.c_int, [C.c_void_p, C.c_int]),
+    ("dex_vocode", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("dex_mel_frames", C.c_int, [C.c_int]),
     ("dex_mel_from_wav", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
 ]

@@ -99,6 +99,11 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IGemmP p) {
                         const float mk = mrow[wi * p.inmask_ws];
                         v.x *= mk; v.y *= mk; v.z *= mk; v.w *= mk;
                     }
+                    if (p.act_in_slope != 0.f) {              // leaky_relu on load (vocoder)
+                        const float sl = p.act_in_slope;
+                        v.x = v.x > 0.f ? v.x : v.x * sl; v.y = v.y > 0.f ? v.y : v.y * sl;
+                        v.z = v.z > 0.f ? v.z : v.z * sl; v.w = v.w > 0.f ? v.w : v.w * sl;
+                    }
                 }
                 ra[j] = v;
             }

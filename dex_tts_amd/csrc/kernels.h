@@ -46,6 +46,8 @@ struct IGemmP {
     const float* outmask; int outmask_ws;
     long mask_bstride;
     int act;                                           // 0 none, 1 GELU(erf)
+    float act_in_slope;                                // != 0: leaky_relu(x, slope) on the gathered A elements (fp32 kernel only:
+                                                       // the vocoder's "x = leaky_relu(x); x = conv(x)", hifigan/models.py:98-103)
     const float* gate; int gate_nstride; long gate_step_stride;
     const float* res; int ldres; long res_bstride; int res_coff;
     const int* step;
@@ -280,6 +282,19 @@ struct TvRow0P { const float* k0; const float* v0; const int* step; float* K; fl
 void launch_tv_row0(const TvRow0P& p, hipStream_t st);
 // transpose [B,C,L] -> [B, L(+row_off), C]
 void launch_transpose_cl(const float* src, float* dst, int B, int C, int L, int row_off, long dst_bstride, hipStream_t st);
+
+// HiFi-GAN generator pieces (dex_vocoder.hip; reference hifigan/models.py:112-173) --------------------
+// mel [B,80,T] -> channels-last [B,T,ldc] with the channels past 80 zeroed (the implicit GEMM wants Cin % 32 == 0)
+void launch_mel_to_cl(const float* mel, float* out, int B, int C, int T, int ldc, hipStream_t st);
+// ConvTranspose1d(k, stride u, padding (k-u)/2) after its GEMM Y[l][j*Cout + co] = sum_ci x[l][ci] w[ci][co][j]:
+// out[t][co] = bias[co] + sum_{j = (t+pad) mod u, +u, .. < k} Y[(t+pad-j)/u][j][co]   (0 <= (t+pad-j)/u < L)
+struct ConvTFoldP { const float* Y; const float* bias; float* out; int L, Cout, k, u, pad, B; };
+void launch_convt_fold(const ConvTFoldP& p, hipStream_t st);
+// x = (a + b + c) * (1/3)  (the three ResBlocks of a stage, models.py:158-164); n floats
+void launch_avg3(const float* a, const float* b, const float* c, float* out, long n, hipStream_t st);
+// wav[t] = tanh(bias + sum_{tap<7} sum_{c<C} w[tap][c] * leaky_relu(x[t+tap-3][c], 0.01))   (models.py:165-167)
+struct ConvPostP { const float* X; const float* W; const float* bias; float* wav; int L, C, B; };
+void launch_conv_post_tanh(const ConvPostP& p, hipStream_t st);
 
 // STFT / mel -------------------------------------------------------------------------------------
 // clip to [-1,1] + reflect-pad n_fft/2 on both sides (stft.py:60-66, tools.py:9)

@@ -98,3 +98,23 @@ def make_dex_style(B: int, Tr: int, Ts: int, mid: int = 128, n_skips: int = 6, s
     ref_lengths = np.asarray(ref_lengths if ref_lengths is not None else [Tr] * B, dtype=np.int64)
     sty_lengths = np.asarray(sty_lengths if sty_lengths is not None else [Ts] * B, dtype=np.int64)
     return ref, ref_lengths, sty.astype(np.float32), sty_lengths
+
+
+def make_vocoder_weights(shapes: dict, seed: int = 0) -> dict:
+    """Portable non-degenerate HiFi-GAN generator weights (keys of ``vocoder.param_shapes``): Conv1d U(-a, a) with
+    a = gain*sqrt(3/(cin*k)) (gain 0.5 on the residual branches, 0.06 on conv_post so tanh stays out of saturation),
+    ConvTranspose1d a = sqrt(3/cin) (two taps reach an output sample), biases 0.05 u."""
+    out = {}
+    for name, shape in shapes.items():
+        shape = tuple(shape)
+        if name.endswith(".bias"):
+            w = symmetric("voc." + name, shape, 0.05, seed)
+        elif name.startswith("ups."):
+            cin, cout, k = shape
+            w = symmetric("voc." + name, shape, float(np.sqrt(3.0 * 2.0 / (cin * 2))), seed)
+        else:
+            cout, cin, k = shape
+            gain = 0.5 if name.startswith("resblocks.") else (0.06 if name.startswith("conv_post") else 1.0)
+            w = symmetric("voc." + name, shape, gain * float(np.sqrt(3.0 / (cin * k))), seed)
+        out[name] = np.ascontiguousarray(w, dtype=np.float32)
+    return out

@@ -148,6 +148,37 @@ int  dex_mel_frames(int n_samples);
 int  dex_mel_from_wav(DexCtx* ctx, const float* wav_dev, int n_samples, float* mel_dev, float* energy_dev,
                       dex_stream_t stream);
 
+/* ---- Vocoder: HiFi-GAN generator (GeDEX-TTS/hifigan/models.py:112-173, built by src/utils.py:251-281 from
+ * hifigan/config.json) — the step right after the sampler: mel [B,80,T] -> waveform [B, T * prod(upsample_rates)].
+ * A separate context: it shares nothing with the score network. */
+typedef struct DexVoc DexVoc;
+typedef struct {
+    int32_t num_mels;                   /* 80 */
+    int32_t upsample_initial_channel;   /* 512 (V1) */
+    int32_t n_upsamples;                /* len(upsample_rates), <= 6 */
+    int32_t upsample_rates[6];          /* [8,8,2,2] */
+    int32_t upsample_kernel_sizes[6];   /* [16,16,4,4] */
+    int32_t n_resblock_kernels;         /* len(resblock_kernel_sizes), must be 3 (the stage average is xs / 3) */
+    int32_t resblock_kernel_sizes[3];   /* [3,7,11] */
+    int32_t resblock_dilation_sizes[3][3]; /* [[1,3,5]]*3 (ResBlock "1": three dilated + three plain convs each) */
+} DexVocoderConfig;
+
+int  dex_voc_create(const DexVocoderConfig* cfg, DexVoc** out);
+void dex_voc_destroy(DexVoc* voc);
+const char* dex_voc_last_error(const DexVoc* voc);
+/* Generator.state_dict() keys AFTER remove_weight_norm() (models.py:169-173: "conv_pre.weight", "ups.0.bias",
+ * "resblocks.4.convs1.2.weight", "conv_post.weight", ...), reference shapes; the host folds weight_g / weight_v pairs. */
+int  dex_voc_num_weights(const DexVoc* voc);
+int  dex_voc_weight_info(const DexVoc* voc, int i, const char** key, int64_t shape[4], int* ndim);
+int  dex_voc_load_weight_async(DexVoc* voc, const char* key, const float* w_dev, const int64_t* shape, int ndim, dex_stream_t stream);
+int  dex_voc_finalize(DexVoc* voc, dex_stream_t stream);
+size_t dex_voc_workspace_bytes(const DexVoc* voc, int B, int T);
+int  dex_voc_samples(const DexVoc* voc, int T);          /* T * prod(upsample_rates) */
+/* Generator.forward (models.py:150-167): mel_dev [B,num_mels,T] fp32 -> wav_dev [B, dex_voc_samples(T)] fp32 in [-1,1].
+ * Exact-fp32 MFMA contractions (the reference's arithmetic).  Asynchronous on `stream`. */
+int  dex_vocode(DexVoc* voc, const float* mel_dev, int B, int T, float* wav_dev, void* workspace_dev, size_t workspace_bytes,
+                dex_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
