@@ -97,7 +97,12 @@ def dex_vctk() -> ScoreNetConfig:
     return ScoreNetConfig(variant="dex", dit=DiTConfig(patch_size=3, stride_size=2))
 
 
-PRESETS = {"gedex_lj": gedex_lj, "gedex_vctk": gedex_vctk, "dex_vctk": dex_vctk, "dex_esd": dex_vctk}
+def dex_libritts() -> ScoreNetConfig:
+    """DEX-TTS/config/LibriTTS/base.yaml:63-85: dim 128 (stages 128 / 256), DiT hidden 384 = 2 x 192."""
+    return ScoreNetConfig(variant="dex", dim=128, dit=DiTConfig(patch_size=3, stride_size=2, hidden_size=384))
+
+
+PRESETS = {"gedex_lj": gedex_lj, "gedex_vctk": gedex_vctk, "dex_vctk": dex_vctk, "dex_esd": dex_vctk, "dex_libritts": dex_libritts}
 
 
 def from_reference_yaml(decoder: dict, dit: dict, variant: str, n_spks: int = 1,

@@ -224,7 +224,158 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(QREG ? 
     }
 }
 
-void launch_attention_lp(const AttnP& p, int precision, hipStream_t st);   // lp_dispatch.hip -> attention_bf16.hip (bf16 / fp16 build)
+void launch_attention_lp(const AttnP& p, int precision, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------------------------------
+// Generic head_dim (a multiple of 64, <= 256): DEX-TTS/config/LibriTTS/base.yaml has hidden 384 = 2 x 192 in the DiT and a
+// 256-channel TVAdaptor.  Same transposed formulation, walked in 64-wide slices of the head dimension so the wave-private
+// LDS tile stays 9 KB whatever the head_dim: S^T accumulates over the slices of K, O^T keeps HD/32 accumulator tiles, the
+// NW partials are merged slice by slice.  No software pipelining — this shape is a correctness path, not a tuned one.
+constexpr int GC = 64;                      // head-dim slice
+constexpr int GKT_LD = 33;                  // K^T slice [64 d][32 keys + 1]
+constexpr int GV_LD = GC + 8;               // V slice [32 keys][64 d + 8];  also the merged O slice [32 queries][64 d + 8]
+constexpr int GWAVE_LDS = 32 * GV_LD;       // 2304 floats >= 64 * 33
+template <int HDG, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_f32_generic_kernel(const AttnP p) {
+    constexpr int NCH = HDG / GC, QLD = HDG + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int q0 = blockIdx.x * 32, h = blockIdx.y, b = blockIdx.z;
+    float* wt = smem + wave * GWAVE_LDS;                    // wave-private tile
+    float* stat = smem + NW * GWAVE_LDS;                    // [NW][2][32]
+    float* qS = stat + NW * 64;                             // [32 queries][QLD] pre-scaled Q
+    int Nk = p.Nk;
+    if (p.kv_len) Nk = min(p.Nk, p.kv_len[b] + p.kv_len_add);
+    const float* Qb = p.Q + (long)b * p.qb + h * HDG;
+    const float* Kb = p.K + (long)b * p.kb + h * HDG;
+    const float* Vb = p.V + (long)b * p.vb + h * HDG;
+    for (int it = tid; it < 32 * (HDG / 4); it += NW * 64) {
+        const int qi = it / (HDG / 4), d4 = (it % (HDG / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q0 + qi < p.Nq) v = *reinterpret_cast<const float4*>(Qb + (long)(q0 + qi) * p.ldq + d4);
+        float* d = qS + qi * QLD + d4;
+        d[0] = v.x * p.scale; d[1] = v.y * p.scale; d[2] = v.z * p.scale; d[3] = v.w * p.scale;
+    }
+    f32x16 o[HDG / 32];
+#pragma unroll
+    for (int t = 0; t < HDG / 32; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int ntiles = (Nk + 31) / 32;
+    __syncthreads();
+    for (int kt = wave; kt < ntiles; kt += NW) {
+        const int k0 = kt * 32;
+        f32x16 sT;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sT[r] = 0.f;
+        for (int c = 0; c < NCH; ++c) {
+            // K slice [32 keys][64 d] -> K^T[d][key]: 8 float4 per lane, a 32-lane half covers 2 keys x 64 d... (16 lanes per key row)
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int key = it * 4 + (lane >> 4), dd = (lane & 15) * 4;
+                const float4 v = *reinterpret_cast<const float4*>(Kb + (long)min(k0 + key, Nk - 1) * p.ldk + c * GC + dd);
+                float* d = wt + dd * GKT_LD + key;
+                d[0] = v.x; d[GKT_LD] = v.y; d[2 * GKT_LD] = v.z; d[3 * GKT_LD] = v.w;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            const float* ka = wt + (hh * 32) * GKT_LD + i;
+            const float* qa = qS + i * QLD + c * GC + hh * 32;
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) sT = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[kk * GKT_LD], qa[kk], sT, 0, 0, 0);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (key >= Nk) sT[r] = -INFINITY;
+            mx = fmaxf(mx, sT[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        if (__builtin_amdgcn_ballot_w64(mx > m_run + 8.f) != 0) {         // lazy rescale, as in the tuned kernel
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __expf(m_run - m_new);
+            l_run *= alpha;
+            m_run = m_new;
+#pragma unroll
+            for (int t = 0; t < HDG / 32; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        }
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sT[r] = __expf(sT[r] - m_run); psum += sT[r]; }
+        l_run += psum;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int key = it * 4 + (lane >> 4), dd = (lane & 15) * 4;
+                *reinterpret_cast<float4*>(wt + key * GV_LD + dd) = *reinterpret_cast<const float4*>(Vb + (long)min(k0 + key, Nk - 1) * p.ldv + c * GC + dd);
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float* vp = wt + ((s & 3) + 8 * (s >> 2) + 4 * hh) * GV_LD + i;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) o[c * 2 + t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[t * 32], sT[s], o[c * 2 + t], 0, 0, 0);
+            }
+        }
+    }
+    l_run += __shfl_xor(l_run, 32);
+    if (hh == 0) { stat[(wave * 2 + 0) * 32 + i] = m_run; stat[(wave * 2 + 1) * 32 + i] = l_run; }
+    // merge the NW partials, one 64-wide slice of the head dimension at a time
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        __syncthreads();                                    // previous slice consumed / every wave done with its tile
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq)
+                *reinterpret_cast<float4*>(wt + i * GV_LD + t * 32 + 8 * rq + 4 * hh) =
+                    make_float4(o[c * 2 + t][rq * 4 + 0], o[c * 2 + t][rq * 4 + 1], o[c * 2 + t][rq * 4 + 2], o[c * 2 + t][rq * 4 + 3]);
+        __syncthreads();
+        const int d4 = (tid & 15) * 4;
+        for (int q = tid >> 4; q < 32; q += NW * 4) {
+            if (q0 + q >= p.Nq) continue;
+            float M = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) M = fmaxf(M, stat[(w * 2) * 32 + q]);
+            float L = 0.f;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int w = 0; w < NW; ++w) {
+                const float mw = stat[(w * 2) * 32 + q];
+                const float f = (mw == -INFINITY) ? 0.f : __expf(mw - M);
+                L += f * stat[(w * 2 + 1) * 32 + q];
+                const float4 v = *reinterpret_cast<const float4*>(smem + w * GWAVE_LDS + q * GV_LD + d4);
+                acc.x = fmaf(f, v.x, acc.x); acc.y = fmaf(f, v.y, acc.y); acc.z = fmaf(f, v.z, acc.z); acc.w = fmaf(f, v.w, acc.w);
+            }
+            const float inv = 1.f / L;
+            float* op = p.O + (long)b * p.ob + (long)(q0 + q) * p.ldo + h * HDG + c * GC + d4;
+            *reinterpret_cast<float4*>(op) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+        }
+    }
+}
+template <int HDG>
+static void launch_attn_generic(const AttnP& p, hipStream_t st) {
+    constexpr int NW = 4;
+    const size_t lds = (size_t)(NW * GWAVE_LDS + NW * 64 + 32 * (HDG + 1)) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_generic_kernel<HDG, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    dim3 grid((p.Nq + 31) / 32, p.heads, p.B);
+    hipLaunchKernelGGL((attn_f32_generic_kernel<HDG, NW>), grid, dim3(NW * 64), lds, st, p);
+}
+bool attention_head_dim_supported(int hd) { return hd == 64 || hd == 128 || hd == 192 || hd == 256; }
+   // lp_dispatch.hip -> attention_bf16.hip (bf16 / fp16 build)
 
 template <int NW, bool QREG>
 static void launch_attn_nw(const AttnP& p, hipStream_t st) {
@@ -239,6 +390,14 @@ static void launch_attn_nw(const AttnP& p, hipStream_t st) {
 }
 
 void launch_attention(const AttnP& p, int precision, hipStream_t st) {
+    const int hd = p.head_dim ? p.head_dim : HD;
+    if (hd != HD || p.force_generic) {          // other head dims (DEX-LibriTTS: 192 / 256): the generic fp32 kernel in every mode
+        if (hd == 64) launch_attn_generic<64>(p, st);
+        else if (hd == 128) launch_attn_generic<128>(p, st);
+        else if (hd == 192) launch_attn_generic<192>(p, st);
+        else launch_attn_generic<256>(p, st);
+        return;
+    }
     if (prec_is_lp(precision)) { launch_attention_lp(p, precision, st); return; }
     const long blocks = (long)((p.Nq + 31) / 32) * p.heads * p.B;
     const int ntiles = (p.Nk + 31) / 32;

@@ -62,6 +62,7 @@ struct DexCtx {
     const std::map<const float*, const void*>& lp_of() const { return lp_of_[lpi()]; }
     const std::map<const float*, const void*>& frag_of() const { return frag_of_[lpi()]; }
     bool finalized = false;
+    bool tuned = true;                                     // geometry the reduced-precision kernels are built for (dex_ctx_create)
     int precision = DEX_PREC_FP32;
     // packed weights
     std::vector<std::vector<ResW>> down_res, up_res;       // [stage][2]
@@ -232,13 +233,21 @@ int dex_ctx_create(const DexConfig* cfg, DexCtx** out) {
     *out = x;
     if (c.n_feats != 80) return x->fail(DEX_ERR_ARG, "n_feats must be 80 (diffusion.py:226 hard-codes it)");
     if (c.n_stages < 2 || c.n_stages > 4) return x->fail(DEX_ERR_ARG, "n_stages must be in [2,4]");
-    if (c.dim != 64) return x->fail(DEX_ERR_ARG, "dim must be 64 (every released DEX-TTS config; the first-layer kernel is specialised for it)");
-    if (c.dit_hidden / c.dit_heads != 128) return x->fail(DEX_ERR_ARG, "DiT head_dim must be 128 (hidden %d heads %d)", c.dit_hidden, c.dit_heads);
+    if (c.dim != 64 && c.dim != 128) return x->fail(DEX_ERR_ARG, "dim must be 64 (GeDEX, DEX-VCTK/ESD) or 128 (DEX-LibriTTS)");
+    if (c.dit_heads < 1 || c.dit_hidden % c.dit_heads || !attention_head_dim_supported(c.dit_hidden / c.dit_heads))
+        return x->fail(DEX_ERR_ARG, "DiT head_dim must be 64, 128, 192 or 256 (hidden %d heads %d)", c.dit_hidden, c.dit_heads);
     if (c.dit_hidden % 64 || c.dit_hidden > 512) return x->fail(DEX_ERR_ARG, "dit_hidden must be a multiple of 64, <= 512");
     if (mlp_hidden(c) % 64) return x->fail(DEX_ERR_ARG, "mlp hidden must be a multiple of 64");
-    if ((c.dit_hidden / c.dit_conv_pos_groups) != 32) return x->fail(DEX_ERR_ARG, "pos-conv must have 32 channels per group");
+    if (c.dit_conv_pos_groups < 1 || c.dit_hidden % c.dit_conv_pos_groups || (c.dit_hidden / c.dit_conv_pos_groups) % 16 ||
+        c.dit_hidden / c.dit_conv_pos_groups > 64)
+        return x->fail(DEX_ERR_ARG, "pos-conv groups must be 16, 32, 48 or 64 channels wide");
     if (c.dit_conv_pos % 2) return x->fail(DEX_ERR_ARG, "conv_pos must be even");
-    if (c.variant == DEX_VARIANT_DEX && mid_dim(c) != 128) return x->fail(DEX_ERR_ARG, "DEX adaptors need mid_dim 128 (attention head_dim)");
+    if (c.variant == DEX_VARIANT_DEX && !attention_head_dim_supported(mid_dim(c)))
+        return x->fail(DEX_ERR_ARG, "DEX adaptors need mid_dim 64, 128, 192 or 256 (the cross-attention's head_dim)");
+    // The reduced-precision (bf16 / fp16) kernels are specialised for the geometry of every shipped config but DEX-LibriTTS
+    // (dim 64, DiT hidden 256 = 2 x 128, 32-channel pos-conv groups); other geometries run the exact-fp32 path only.
+    x->tuned = c.dim == 64 && c.dit_hidden == 256 && c.dit_heads == 2 && c.dit_hidden / c.dit_conv_pos_groups == 32 &&
+               (c.variant != DEX_VARIANT_DEX || mid_dim(c) == 128);
     build_inventory(x);
     return DEX_OK;
 }
@@ -295,6 +304,9 @@ int dex_ctx_load_weight_async(DexCtx* x, const char* key, const float* w_dev, co
 
 int dex_ctx_set_precision(DexCtx* x, int precision) {
     if (!x || (precision != DEX_PREC_FP32 && precision != DEX_PREC_BF16 && precision != DEX_PREC_FP16)) return DEX_ERR_ARG;
+    if (precision != DEX_PREC_FP32 && !x->tuned)
+        return x->fail(DEX_ERR_ARG, "the bf16 / fp16 kernels are specialised for dim 64, DiT hidden 256 (2 x 128), 32-channel pos-conv groups; "
+                                    "this geometry (dim %d, hidden %d, %d heads) runs DEX_PREC_FP32 only", x->cfg.dim, x->cfg.dit_hidden, x->cfg.dit_heads);
     x->precision = precision;
     return DEX_OK;
 }
@@ -469,6 +481,16 @@ extern "C" int dex_ctx_finalize(DexCtx* x, dex_stream_t stream) {
     x->pe_db = P.raw("vit.x_embedder.proj.0.bias");
     x->pe_pw = P.kn("vit.x_embedder.proj.2.weight"); x->pe_pb = P.raw("vit.x_embedder.proj.2.bias");
     x->pos_w = P.perm("vit.pos_conv.0.weight", G, hid / G, hid / G, kp * kp, 0, 3, 2, 1);   // [G][tap][ci][n]
+    if ((hid / G) % 32) {       // e.g. 48-channel groups (hidden 384): [G][tap][ci][n] -> zero-padded [G][tap][cgp][cgp], cgp = 64
+        const int cg = hid / G, cgp = 64;
+        float* wp = P.alloc((long)G * kp * kp * cgp * cgp);
+        if (wp) {
+            hipMemsetAsync(wp, 0, (size_t)G * kp * kp * cgp * cgp * sizeof(float), st);
+            for (long gt = 0; gt < (long)G * kp * kp; ++gt)     // one 2-D copy per (group, tap): cg rows of cg floats into a cgp x cgp tile
+                hipMemcpy2DAsync(wp + gt * cgp * cgp, (size_t)cgp * 4, x->pos_w + gt * cg * cg, (size_t)cg * 4, (size_t)cg * 4, cg, hipMemcpyDeviceToDevice, st);
+        }
+        x->pos_w = wp;
+    } else
     P.twin(x->pos_w, G, kp * kp * (hid / G), hid / G);
     x->pos_wfrag[0] = x->pos_wfrag[1] = nullptr;
     if (pos_conv_direct_supported(hid, G, kp, token_rows(c))) {
@@ -548,7 +570,7 @@ struct Plan {
     std::vector<float*> cat;
     float *up_out, *hF;
     int Hm, Wm, Hf, Wt, N;
-    float *pe0, *emb, *pos_part, *tok, *xn, *qkv, *ao, *att_ml, *hmlp, *dbg_tok;
+    float *pe0, *emb, *emb_pad, *pos_part, *tok, *xn, *qkv, *ao, *att_ml, *hmlp, *dbg_tok;
     void *qh, *kh, *vt, *qh2, *kh2, *vt2; int Npad; size_t vt_bytes;   // bf16 attention operands of the row-chain path (two sets:
                                                                         // a fused block reads one while its workgroups write the other)
     float *tv_keys, *tv_K, *tv_V, *tv_q, *tv_ao, *tv_out, *tiv_out, *tv_weff, *tv_beff; gnfix_t *tv_stats, *tiv_stats; void* tv_wbf;
@@ -624,7 +646,9 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
     P.Hm = mid_h(c); P.Wm = d.T >> (c.n_stages - 1);
     P.Hf = token_rows(c); P.Wt = token_cols(c, P.Wm); P.N = P.Hf * P.Wt;
     const size_t tok = (size_t)B * P.N;
-    P.pe0 = A.f(tok * mid); P.emb = A.f(tok * hid); P.pos_part = A.f(tok * hid * POS_SPLIT); P.tok = A.f(tok * hid);
+    const int cg_ = hid / c.dit_conv_pos_groups, cgp_ = (cg_ % 32) ? 64 : cg_;      // pos-conv group width, padded to the GEMM's granule
+    P.pe0 = A.f(tok * mid); P.emb = A.f(tok * hid); P.pos_part = A.f(tok * (size_t)c.dit_conv_pos_groups * cgp_ * POS_SPLIT); P.tok = A.f(tok * hid);
+    P.emb_pad = cgp_ != cg_ ? A.f(tok * (size_t)c.dit_conv_pos_groups * cgp_) : nullptr;
     P.xn = A.f(tok * hid); P.qkv = A.f(tok * 3 * hid); P.ao = A.f(tok * hid * ATT_KSPLIT_MAX); P.att_ml = A.f(tok * c.dit_heads * 2 * ATT_KSPLIT_MAX);
     P.Npad = (P.N + 31) / 32 * 32; P.vt_bytes = (size_t)B * hid * P.Npad * 2;
     P.qh = A.take(P.vt_bytes); P.kh = A.take(P.vt_bytes); P.vt = A.take(P.vt_bytes);    // all three padded to Npad rows
@@ -871,18 +895,26 @@ struct Runner {
         gemm("patch_pointwise", pe);
         // grouped 16x16 pos-conv, split-K partials (bias added in the tail)
         const int G = c.dit_conv_pos_groups, kp = c.dit_conv_pos, cg = hid / G;
-        int nsplit = POS_SPLIT;
+        int nsplit = POS_SPLIT, pcg = 0, pcgp = 0;
         if (x->lp() && x->pos_wfrag[x->lpi()]) {
             PosConvP pcd{P.emb, x->pos_wfrag[x->lpi()], P.pos_part, P.Hf, P.Wt, hid, G, B};
             run("pos_conv", 2.0 * B * N * (double)kp * kp * cg * hid, 8.0 * B * N * hid + 2.0 * kp * kp * cg * hid, [&] { launch_pos_conv_direct(pcd, x->precision, st); });
             nsplit = 1;
         } else {
-            IGemmP pc = base_gemm(P.emb, hid, 0, P.Hf, P.Wt, cg, x->pos_w, cg, nullptr, P.pos_part, hid, 0);
-            pc.KH = kp; pc.KW = kp; pc.off_h = -(kp / 2); pc.off_w = -(kp / 2); pc.K = kp * kp * cg;
-            pc.groups = G; pc.w_gstride = (long)kp * kp * cg * cg; pc.ksplit = POS_SPLIT; pc.c_sstride = (long)B * N * hid;
+            const int cgp = (cg % 32) ? 64 : cg;           // groups padded to the implicit GEMM's 32-channel granule (zero weights / inputs)
+            const float* src = P.emb;
+            if (cgp != cg) {
+                run("pos_group_pad", 0, 8.0 * B * N * hid, [&] { launch_group_pad(P.emb, P.emb_pad, (long)B * N, G, cg, cgp, st); });
+                src = P.emb_pad;
+            }
+            IGemmP pc = base_gemm(src, G * cgp, 0, P.Hf, P.Wt, cgp, x->pos_w, cgp, nullptr, P.pos_part, G * cgp, 0);
+            pc.KH = kp; pc.KW = kp; pc.off_h = -(kp / 2); pc.off_w = -(kp / 2); pc.K = kp * kp * cgp;
+            pc.groups = G; pc.w_gstride = (long)kp * kp * cgp * cgp; pc.ksplit = POS_SPLIT; pc.c_sstride = (long)B * N * G * cgp;
+            if (cgp != cg) pc.Wbf = nullptr;
             gemm("pos_conv", pc);
+            pcg = cgp != cg ? cg : 0; pcgp = cgp;
         }
-        PosFinishP pf{P.pos_part, nsplit, (long)B * N * hid, x->pos_b, P.emb, x->freq_pos, P.tok, P.Hf, P.Wt, hid, B};
+        PosFinishP pf{P.pos_part, nsplit, (long)B * N * (pcg ? G * pcgp : hid), x->pos_b, P.emb, x->freq_pos, P.tok, P.Hf, P.Wt, hid, B, pcg, pcgp};
         run("pos_finish", 20.0 * B * N * hid, 4.0 * B * N * hid * (nsplit + 2), [&] { launch_pos_finish(pf, st); });
         if (debug) hipMemcpyAsync(P.dbg_tok, P.tok, (size_t)B * N * hid * 4, hipMemcpyDeviceToDevice, st);
         tap("tok_in", P.dbg_tok, (long)B * N, hid, hid);
@@ -967,7 +999,8 @@ struct Runner {
             a.Q = P.qkv; a.ldq = 3 * hid; a.qb = (long)N * 3 * hid;
             a.K = P.qkv + hid; a.ldk = 3 * hid; a.kb = a.qb; a.V = P.qkv + 2 * hid; a.ldv = 3 * hid; a.vb = a.qb;
             a.O = P.ao; a.ldo = hid; a.ob = (long)N * hid; a.Nq = N; a.Nk = N; a.kv_len = nullptr; a.kv_len_add = 0;
-            a.heads = c.dit_heads; a.scale = scale; a.B = B;
+            a.heads = c.dit_heads; a.scale = scale; a.B = B; a.head_dim = hid / c.dit_heads;
+            { const char* ge = getenv("DEX_ATTN_GENERIC"); a.force_generic = (ge && atoi(ge) && x->precision == DEX_PREC_FP32) ? 1 : 0; }   // tests
             run("dit_attention", 4.0 * B * (double)N * N * hid, 4.0 * 4 * B * N * hid, [&] { launch_attention(a, x->precision, st); });
             IGemmP pr = base_gemm(P.ao, hid, 0, 1, N, hid, w.wproj, hid, w.bproj, P.tok, hid, 0);
             pr.gate = ada + 2 * hid; pr.gate_nstride = 1; pr.gate_step_stride = 6L * hid;
@@ -1029,7 +1062,7 @@ struct Runner {
         a.Q = P.tv_q; a.ldq = mid; a.qb = npix * mid; a.K = P.tv_K; a.ldk = mid; a.kb = (long)(P.d.Ts + 1) * mid;
         a.V = P.tv_V; a.ldv = mid; a.vb = a.kb; a.O = P.tv_ao; a.ldo = mid; a.ob = npix * mid;
         a.Nq = (int)npix; a.Nk = P.d.Ts + 1; a.kv_len = args->sty_lengths_dev; a.kv_len_add = 1; a.heads = 1;
-        a.scale = 1.0f / sqrtf((float)mid); a.B = B;
+        a.scale = 1.0f / sqrtf((float)mid); a.B = B; a.head_dim = mid;
         run("tv_attention", 4.0 * B * (double)npix * (P.d.Ts + 1) * mid, 4.0 * B * (2 * npix + 2 * (P.d.Ts + 1)) * mid, [&] { launch_attention(a, x->precision, st); });
         IGemmP o = base_gemm(P.tv_ao, mid, 0, P.Hm, P.Wm, mid, x->tv_wl, mid, nullptr, P.tv_out, mid, 0);
         o.res = X.p; o.ldres = X.ld; o.res_coff = X.coff; o.res_bstride = npix * X.ld;

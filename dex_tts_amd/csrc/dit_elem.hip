@@ -65,12 +65,16 @@ __global__ __launch_bounds__(256) void pos_finish_kernel(const PosFinishP p) {
         float4 part = make_float4(0.f, 0.f, 0.f, 0.f);
         if (act) {
             const float4 bias = *reinterpret_cast<const float4*>(p.bias + cq * 4);
+            // channel c = cq*4 of the partials: dense [row][D], or padded groups [row][G][cg_pad]
+            const int c = cq * 4;
+            const int pcol = p.cg ? (c / p.cg) * p.cg_pad + c % p.cg : c;
+            const long pld = p.cg ? (long)(p.D / p.cg) * p.cg_pad : p.D;
             for (int f = fl; f < p.Hf; f += 4) {
                 const long row = ((long)b * p.Hf + f) * p.Wt + wt;
                 float4 a = bias;
 #pragma unroll 8
                 for (int s = 0; s < p.nsplit; ++s) {
-                    const float4 v = *reinterpret_cast<const float4*>(p.part + (long)s * p.split_stride + row * p.D + cq * 4);
+                    const float4 v = *reinterpret_cast<const float4*>(p.part + (long)s * p.split_stride + row * pld + pcol);
                     a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
                 }
                 part.x += gelu_d(a.x); part.y += gelu_d(a.y); part.z += gelu_d(a.z); part.w += gelu_d(a.w);
@@ -99,6 +103,19 @@ __global__ __launch_bounds__(256) void pos_finish_kernel(const PosFinishP p) {
 }
 void launch_pos_finish(const PosFinishP& p, hipStream_t st) {
     hipLaunchKernelGGL(pos_finish_kernel, dim3(p.Wt, p.B), dim3(256), 0, st, p);
+}
+
+__global__ __launch_bounds__(256) void group_pad_kernel(const float* src, float* dst, long rows, int G, int cg, int cg_pad) {
+    const long total = rows * G * cg_pad;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int j = (int)(i % cg_pad);
+        const long rg = i / cg_pad;
+        dst[i] = j < cg ? src[rg * cg + j] : 0.f;
+    }
+}
+void launch_group_pad(const float* src, float* dst, long rows, int G, int cg, int cg_pad, hipStream_t st) {
+    long blocks = (rows * G * cg_pad + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(group_pad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, rows, G, cg, cg_pad);
 }
 
 // LayerNorm (eps 1e-6, biased var, no affine) then x*(1+scale)+shift.  One wave per token, D <= 512, D % 64 == 0.

@@ -191,8 +191,11 @@ struct PosConvP { const float* X; const void* Wf; float* Y; int Hf, Wt, hid, G, 
 bool pos_conv_direct_supported(int hid, int groups, int kernel, int Hf);
 void launch_pos_conv_direct(const PosConvP& p, int precision, hipStream_t st);
 struct PosFinishP { const float* part; int nsplit; long split_stride; const float* bias; const float* emb;
-                    const float* freq_pos; float* tok; int Hf, Wt, D; int B; };
+                    const float* freq_pos; float* tok; int Hf, Wt, D; int B;
+                    int cg, cg_pad; };      // > 0: the partials are [rows][G][cg_pad] with cg live channels per group (padded groups)
 void launch_pos_finish(const PosFinishP& p, hipStream_t st);
+// [rows][G][cg] -> [rows][G][cg_pad], zero-filled tail (grouped pos-conv whose groups are no multiple of 32 channels wide)
+void launch_group_pad(const float* src, float* dst, long rows, int G, int cg, int cg_pad, hipStream_t st);
 
 // LayerNorm(eps 1e-6, no affine) + modulate (dit.py:78-79,288-289,330)
 struct LnModP { const float* X; float* Y; int rows_per_batch; int D; const float* shift; const float* scale;
@@ -229,7 +232,10 @@ struct AttnP { const float* Q; int ldq; long qb; const float* K; int ldk; long k
                // tiles, writes its normalised O to O + s*o_sstride and (running max, row sum) to
                // ml[((s*B + b)*heads + h)*Nq + q][2]; the consumer merges (dit_rowchain.hip)
                int ksplit; long o_sstride; float* ml;
-               long long* dbg; };                            // DEX_TIMING builds only
+               long long* dbg;                               // DEX_TIMING builds only
+               int head_dim;                                 // 0 = 128 (the tuned kernels); 64 / 192 / 256 run the generic fp32 kernel
+               int force_generic; };                         // tests: the generic kernel at head_dim 128 too
+bool attention_head_dim_supported(int hd);
 void launch_attention(const AttnP& p, int precision, hipStream_t st);
 
 // y[r, n] = act_out( bias[n] + sum_k act_in(x[r,k]) * W[n,k] )   (tiny conditioning MLPs; W in reference layout)

@@ -30,13 +30,15 @@ __device__ __forceinline__ void gn_mean_rstd(const gnfix_t* stats, int b, int gr
 }
 
 // ------------------------------------------------------------------------------------------------
-// first conv (C == 64): one thread = one pixel x 16 output channels; the 3x3 and 1x1 weights sit in LDS (5-8 KB,
-// broadcast reads), so the 18-27 input taps of a pixel are loaded by 4 threads instead of 16 and the GroupNorm
-// partials are reduced by shuffles before they touch LDS (the per-thread LDS atomics of the first version were a
+// first conv (C = 64, or 128 for DEX-LibriTTS): one thread = one pixel x 16 output channels; the 3x3 and 1x1 weights sit
+// in LDS (5-16 KB, broadcast reads), so the 18-27 input taps of a pixel are loaded by C/16 threads instead of C/4 and the
+// GroupNorm partials are reduced by shuffles before they touch LDS (the per-thread LDS atomics of the first version were a
 // 32-way serialisation).  planes <= 3.
-template <int PLANES>
+template <int PLANES, int C>
 __global__ __launch_bounds__(256) void first_conv_kernel(const FirstConvP p) {
-    constexpr int C = 64;
+    constexpr int TPP = C / 16;                 // threads per pixel
+    constexpr int PPB = 256 / TPP;              // pixels per block
+    constexpr int CPG = C / 8;                  // channels per GroupNorm group (8 or 16)
     __shared__ __attribute__((aligned(16))) float w3s[PLANES * 9 * C];
     __shared__ __attribute__((aligned(16))) float w1s[PLANES * C];
     __shared__ long long red[16];
@@ -45,10 +47,10 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const FirstConvP p) {
     for (int k = tid; k < PLANES * C; k += 256) w1s[k] = p.W1[k];
     if (tid < 16) red[tid] = 0;
     const long npix = (long)p.B * p.H * p.T;
-    const long pix_raw = (long)blockIdx.x * 64 + (tid >> 2);
+    const long pix_raw = (long)blockIdx.x * PPB + tid / TPP;
     const bool live = pix_raw < npix;
     const long pix = live ? pix_raw : npix - 1;
-    const int cq = tid & 3;                                   // channels [cq*16, cq*16+16)
+    const int cq = tid % TPP;                                 // channels [cq*16, cq*16+16)
     const int w = (int)(pix % p.T);
     const int h = (int)((pix / p.T) % p.H);
     const int b = (int)(pix / ((long)p.T * p.H));
@@ -116,35 +118,48 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const FirstConvP p) {
             *reinterpret_cast<float4*>(p.res + pix * C + cq * 16 + j * 4) = a1[j];
         }
     }
-    if (p.gn_stats) {          // GroupNorm partials of h1: 8 channels per group -> this thread feeds groups 2cq, 2cq+1
-        float gs[2], gq[2];
+    if (p.gn_stats) {          // GroupNorm partials of h1: CPG channels per group -> this thread feeds 16 / CPG groups
+        constexpr int GPT = 16 / CPG;             // groups per thread: 2 (C = 64) or 1 (C = 128)
+        float gs[GPT], gq[GPT];
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const float4 u = a3[2 * g], t = a3[2 * g + 1];
-            gs[g] = live ? ((u.x + u.y) + (u.z + u.w)) + ((t.x + t.y) + (t.z + t.w)) : 0.f;
-            gq[g] = live ? ((u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w)) + ((t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w)) : 0.f;
+        for (int g = 0; g < GPT; ++g) { gs[g] = 0.f; gq[g] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int g = (j * 4) / CPG;
+            const float4 u = a3[j];
+            if (live) {
+                gs[g] += (u.x + u.y) + (u.z + u.w);
+                gq[g] += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w);
+            }
         }
+        // lanes of a wave with the same cq (stride TPP) hold the same groups: xor-reduce over the pixel index bits
 #pragma unroll
-        for (int o = 4; o < 64; o <<= 1) {
+        for (int o = TPP; o < 64; o <<= 1) {
 #pragma unroll
-            for (int g = 0; g < 2; ++g) { gs[g] += __shfl_xor(gs[g], o); gq[g] += __shfl_xor(gq[g], o); }
+            for (int g = 0; g < GPT; ++g) { gs[g] += __shfl_xor(gs[g], o); gq[g] += __shfl_xor(gq[g], o); }
         }
-        if ((tid & 63) < 4) {          // one wave's sums (fixed shuffle order) -> fixed point; integer adds commute
-            const double inv_n = 1.0 / ((double)p.H * p.T * 8);
+        if ((tid & 63) < TPP) {          // one wave's sums (fixed shuffle order) -> fixed point; integer adds commute
+            const double inv_n = 1.0 / ((double)p.H * p.T * CPG);
 #pragma unroll
-            for (int g = 0; g < 2; ++g) { gn_add(&red[(2 * cq + g) * 2], gn_fix(gs[g], inv_n)); gn_add(&red[(2 * cq + g) * 2 + 1], gn_fix(gq[g], inv_n)); }
+            for (int g = 0; g < GPT; ++g) { gn_add(&red[(GPT * cq + g) * 2], gn_fix(gs[g], inv_n)); gn_add(&red[(GPT * cq + g) * 2 + 1], gn_fix(gq[g], inv_n)); }
         }
         __syncthreads();
-        // a 64-pixel block never straddles two utterances when H*T is a multiple of 64 (T is)
+        // a PPB-pixel block never straddles two utterances when H*T is a multiple of PPB (T % 4 == 0, H = 80)
         if (tid < 16)
             gn_add(p.gn_stats + (((long)b * 8 + (tid >> 1)) * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * 2 + (tid & 1), red[tid]);
     }
 }
 void launch_first_conv(const FirstConvP& p, hipStream_t st) {
     const long npix = (long)p.B * p.H * p.T;
+    if (p.C == 128) {
+        const unsigned blocks = (unsigned)((npix + 31) / 32);
+        if (p.planes == 3) hipLaunchKernelGGL((first_conv_kernel<3, 128>), dim3(blocks), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((first_conv_kernel<2, 128>), dim3(blocks), dim3(256), 0, st, p);
+        return;
+    }
     const unsigned blocks = (unsigned)((npix + 63) / 64);
-    if (p.planes == 3) hipLaunchKernelGGL(first_conv_kernel<3>, dim3(blocks), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL(first_conv_kernel<2>, dim3(blocks), dim3(256), 0, st, p);
+    if (p.planes == 3) hipLaunchKernelGGL((first_conv_kernel<3, 64>), dim3(blocks), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((first_conv_kernel<2, 64>), dim3(blocks), dim3(256), 0, st, p);
 }
 
 // ------------------------------------------------------------------------------------------------

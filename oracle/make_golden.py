@@ -217,6 +217,11 @@ def golden_churn():
 
 
 def main():
+    if "--libritts-only" in sys.argv:
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        golden_model("dex_libritts", C.dex_libritts(), B=1, T=32, lengths=[29], sampler_steps=[4], dex_dims=(24, 24, [19]))
+        return
     if "--churn-only" in sys.argv:
         torch.manual_seed(0)
         torch.set_num_threads(8)
@@ -235,6 +240,7 @@ def main():
     golden_model("gedex_lj_n50", C.gedex_lj(), B=1, T=48, lengths=[48], sampler_steps=[50])
     golden_model("gedex_vctk", C.gedex_vctk(), B=2, T=32, lengths=[32, 21], sampler_steps=[4], spk=True)
     golden_model("dex_vctk", C.dex_vctk(), B=1, T=64, lengths=[57], sampler_steps=[4, 10], dex_dims=(40, 40, [33]))
+    golden_model("dex_libritts", C.dex_libritts(), B=1, T=32, lengths=[29], sampler_steps=[4], dex_dims=(24, 24, [19]))
     golden_audio()
     golden_heun()
     golden_churn()

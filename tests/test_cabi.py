@@ -32,7 +32,7 @@ def test_header_symbols_exported(lib):
     assert b"gfx950" in lib.dex_version()
 
 
-@pytest.mark.parametrize("preset", ["gedex_lj", "gedex_vctk", "dex_vctk"])
+@pytest.mark.parametrize("preset", ["gedex_lj", "gedex_vctk", "dex_vctk", "dex_libritts"])
 def test_inventory_matches_reference_state_dict(lib, preset):
     cfg = Cfg.PRESETS[preset]()
     cc = _lib.make_config(cfg)
@@ -53,11 +53,22 @@ def test_inventory_matches_reference_state_dict(lib, preset):
 
 def test_bad_config_rejected(lib):
     cfg = Cfg.gedex_lj()
-    cfg.dit.num_heads = 4                  # head_dim 64: unsupported by the attention kernel
+    cfg.dit.num_heads = 8                  # head_dim 32: no attention kernel for it
     cc = _lib.make_config(cfg)
     h = C.c_void_p()
     assert lib.dex_ctx_create(C.byref(cc), C.byref(h)) == -1
     assert b"head_dim" in lib.dex_last_error(h)
+    lib.dex_ctx_destroy(h)
+
+
+def test_untuned_geometry_is_fp32_only(lib):
+    """DEX-LibriTTS (dim 128, hidden 384 = 2 x 192) builds, but only the exact-fp32 path: asking for bf16 / fp16 is an error."""
+    cc = _lib.make_config(Cfg.dex_libritts())
+    h = C.c_void_p()
+    assert lib.dex_ctx_create(C.byref(cc), C.byref(h)) == 0, lib.dex_last_error(h)
+    assert lib.dex_ctx_set_precision(h, _lib.PRECISION["fp32"]) == 0
+    assert lib.dex_ctx_set_precision(h, _lib.PRECISION["bf16"]) == -1
+    assert b"DEX_PREC_FP32 only" in lib.dex_last_error(h)
     lib.dex_ctx_destroy(h)
 
 

@@ -32,7 +32,8 @@ def gold(name):
 
 
 @pytest.mark.parametrize("name,preset", [("gedex_lj", "gedex_lj"), ("gedex_lj_n50", "gedex_lj"),
-                                         ("gedex_vctk", "gedex_vctk"), ("dex_vctk", "dex_vctk")])
+                                         ("gedex_vctk", "gedex_vctk"), ("dex_vctk", "dex_vctk"),
+                                         ("dex_libritts", "dex_libritts")])      # dim 128, hidden 384 = 2 x 192: the generic fp32 path
 def test_golden_precond_and_sampler(name, preset):
     g = gold(name)
     cfg, eng, w = U.engine_for(preset)
@@ -57,6 +58,7 @@ def test_golden_precond_and_sampler(name, preset):
     ("gedex_vctk", dict(B=2, T=36, lengths=[36, 20])),
     ("dex_vctk", dict(B=1, T=64, lengths=[57], Tr=40, Ts=40, sty_lengths=[33])),
     ("dex_vctk", dict(B=2, T=52, lengths=[52, 31], Tr=37, Ts=65, sty_lengths=[65, 9])),   # batched DEX (build-defined)
+    ("dex_libritts", dict(B=2, T=68, lengths=[68, 41], Tr=37, Ts=50, sty_lengths=[50, 13])),   # 48-channel pos-conv groups, head_dim 192 / 256
 ])
 def test_oracle_precond_taps(name, kw):
     cfg, eng, w = U.engine_for(name)
@@ -73,6 +75,7 @@ def test_oracle_precond_taps(name, kw):
     ("gedex_lj", dict(B=2, T=128, lengths=[128, 90]), 6),
     ("gedex_lj", dict(B=1, T=512), 4),                               # bench shape, short schedule
     ("dex_vctk", dict(B=2, T=64, lengths=[64, 40], Tr=48, Ts=48, sty_lengths=[48, 20]), 6),
+    ("dex_libritts", dict(B=2, T=64, lengths=[64, 40], Tr=48, Ts=48, sty_lengths=[48, 20]), 4),
 ])
 def test_oracle_sampler(name, kw, n):
     cfg, eng, w = U.engine_for(name)
@@ -247,6 +250,21 @@ def test_diffusion_module_forward_seeded():
     for _ in range(4):
         torch.randn_like(z)
     assert torch.cuda.default_generators[0].get_offset() == off_after
+
+
+def test_generic_head_dim_attention_kernel_at_128():
+    """The generic fp32 attention kernel (head_dim 64..256 in 64-wide slices) forced onto the shipped head_dim 128: the same
+    results as the tuned kernel to fp32 round-off, which cross-checks it independently of the LibriTTS model path."""
+    cfg, eng, w = U.engine_for("gedex_lj")
+    case = U.make_case(cfg, B=2, T=100, lengths=[100, 61])
+    got, ref, _ = U.run_precond("gedex_lj", case, 0.7, with_taps=False)
+    os.environ["DEX_ATTN_GENERIC"] = "1"
+    try:
+        gen, _, _ = U.run_precond("gedex_lj", case, 0.7, with_taps=False)
+    finally:
+        del os.environ["DEX_ATTN_GENERIC"]
+    assert np.abs(gen - ref).max() <= 1e-3 * max(1.0, np.abs(ref).max())
+    assert np.abs(gen - got).max() <= 1e-4 and not np.array_equal(gen, got)       # another kernel really ran
 
 
 def test_error_behaviour():

@@ -10,7 +10,8 @@ import torch
 from dex_tts_amd import config as C, synth
 from oracle import dex_oracle as O
 
-CASES = {"gedex_lj": C.gedex_lj, "gedex_lj_n50": C.gedex_lj, "gedex_vctk": C.gedex_vctk, "dex_vctk": C.dex_vctk}
+CASES = {"gedex_lj": C.gedex_lj, "gedex_lj_n50": C.gedex_lj, "gedex_vctk": C.gedex_vctk, "dex_vctk": C.dex_vctk,
+         "dex_libritts": C.dex_libritts}
 
 
 def load(golden_dir, name):

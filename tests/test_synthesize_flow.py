@@ -18,6 +18,7 @@ SECTIONS = json.load(open(os.path.join(GOLD, "ref_model_sections.json")))
     ("GeDEX-TTS/config/VCTK/base.yaml", "manifest_gedex_vctk.json"),
     ("DEX-TTS/config/VCTK/base.yaml", "manifest_dex_vctk.json"),
     ("DEX-TTS/config/ESD/base.yaml", "manifest_dex_vctk.json"),          # same model section as VCTK
+    ("DEX-TTS/config/LibriTTS/base.yaml", "manifest_dex_libritts.json"),
 ])
 def test_from_reference_yaml_matches_reference_state_dict(rel, manifest):
     sec = SECTIONS[rel]
