@@ -41,6 +41,20 @@ class DexVocoderConfig(C.Structure):
                 ("resblock_kernel_sizes", C.c_int32 * 3), ("resblock_dilation_sizes", (C.c_int32 * 3) * 3)]
 
 
+class DexStyleConfig(C.Structure):
+    _fields_ = [("n_mels", C.c_int32), ("tiv_layers", C.c_int32), ("tiv_ch", C.c_int32),
+                ("tv_layers", C.c_int32), ("tv_ch", C.c_int32), ("tv_cout", C.c_int32), ("tv_cout_g", C.c_int32), ("tv_n_emb", C.c_int32),
+                ("lf0_ch", C.c_int32), ("lf0_cout", C.c_int32), ("lf0_cout_g", C.c_int32), ("lf0_layers", C.c_int32), ("sty_out", C.c_int32)]
+
+
+class DexStyleArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("Tr", C.c_int32), ("Ts", C.c_int32), ("Tl", C.c_int32),
+                ("ref_mel_dev", C.c_void_p), ("ref_lengths_dev", C.c_void_p), ("sty_mel_dev", C.c_void_p), ("sty_lengths_dev", C.c_void_p),
+                ("lf0_dev", C.c_void_p), ("lf0_lengths_dev", C.c_void_p), ("ref_skips_out_dev", C.POINTER(C.c_void_p)),
+                ("sty_dec_out_dev", C.c_void_p), ("sty_enc_out_dev", C.c_void_p), ("vq_idx_out_dev", C.c_void_p),
+                ("workspace_dev", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
 class DexDenoiseArgs(C.Structure):
     _fields_ = [("s", DexSampleArgs), ("x_dev", C.c_void_p)]
 
@@ -80,6 +94,15 @@ SYMBOLS = [
     ("dex_voc_workspace_bytes", C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     ("dex_voc_samples", C.c_int, [C.c_void_p, C.c_int]),
     ("dex_vocode", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("dex_style_create", C.c_int, [C.POINTER(DexStyleConfig), C.POINTER(C.c_void_p)]),
+    ("dex_style_destroy", None, [C.c_void_p]),
+    ("dex_style_last_error", C.c_char_p, [C.c_void_p]),
+    ("dex_style_num_weights", C.c_int, [C.c_void_p]),
+    ("dex_style_weight_info", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    ("dex_style_load_weight_async", C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
+    ("dex_style_finalize", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("dex_style_workspace_bytes", C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    ("dex_style_encode", C.c_int, [C.c_void_p, C.POINTER(DexStyleArgs), C.c_void_p]),
     ("dex_mel_frames", C.c_int, [C.c_int]),
     ("dex_mel_from_wav", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
 ]

@@ -62,7 +62,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmP& p, f32x16 (&acc)[MT
             for (int r = 0; r < 16; ++r) {
                 float v = acc[t][r] + bias;
                 if (!p.stats_final) { gs += v; gss = fmaf(v, v, gss); }
-                if (p.act == 1) v = gelu_erf(v);
+                if (p.act == 1) v = gelu_erf(v); else if (p.act == 2) v = fmaxf(v, 0.f);
                 v = (v * gate + rv[r]) * mk[r];
                 if (p.stats_final) { gs += v; gss = fmaf(v, v, gss); }
                 cp[((r & 3) + 8 * (r >> 2)) * cs] = v;
@@ -105,7 +105,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmP& p, f32x16 (&acc)[MT
             float v = acc[t][r] + bias;
             const float vs = ok[r] ? v : 0.f;
             if (!p.stats_final) { gs += vs; gss = fmaf(vs, vs, gss); }
-            if (p.act == 1) v = gelu_erf(v);
+            if (p.act == 1) v = gelu_erf(v); else if (p.act == 2) v = fmaxf(v, 0.f);
             v = (v * gate + rv[r]) * mk[r];
             if (p.stats_final && ok[r]) { gs += v; gss = fmaf(v, v, gss); }
             if (ok[r]) Cb[(long)opix[r] * p.ldc + col_out] = v;

@@ -45,7 +45,7 @@ struct IGemmP {
     const float* inmask; int inmask_ws;
     const float* outmask; int outmask_ws;
     long mask_bstride;
-    int act;                                           // 0 none, 1 GELU(erf)
+    int act;                                           // 0 none, 1 GELU(erf), 2 ReLU
     float act_in_slope;                                // != 0: leaky_relu(x, slope) on the gathered A elements (fp32 kernel only:
                                                        // the vocoder's "x = leaky_relu(x); x = conv(x)", hifigan/models.py:98-103)
     const float* gate; int gate_nstride; long gate_step_stride;
@@ -301,6 +301,34 @@ void launch_avg3(const float* a, const float* b, const float* c, float* out, lon
 // wav[t] = tanh(bias + sum_{tap<7} sum_{c<C} w[tap][c] * leaky_relu(x[t+tap-3][c], 0.01))   (models.py:165-167)
 struct ConvPostP { const float* X; const float* W; const float* bias; float* wav; int L, C, B; };
 void launch_conv_post_tanh(const ConvPostP& p, hipStream_t st);
+
+// DEX style encoders (dex_style.hip; reference DEX-TTS/model/ref_encoder.py:8-140,199-237) ------------
+// LayerNorm over the channels of channels-last rows (nn.LayerNorm / base.LayerNorm: biased variance), affine, then * mask[b][t]
+struct LnClP { const float* X; float* Y; long rows; int C; const float* gamma; const float* beta; float eps;
+               const float* mask; int T; };      // mask [B][T] (row = b*T + t) or null
+void launch_ln_cl(const LnClP& p, hipStream_t st);
+// InstanceNorm1D over the full padded length (unbiased variance, base.py:72-88), output * mask: X, Y [B][T][C]
+void launch_inorm_cl(const float* X, float* Y, const float* mask, int B, int T, int C, float eps, hipStream_t st);
+// out[b][c] = sum_t X[b][t][c] / sum_t mask[b][t]   (tts.py:62)
+void launch_masked_mean_cl(const float* X, const float* mask, float* out, int B, int T, int C, hipStream_t st);
+// X[b][t][c] += v[b][c]
+void launch_add_bcast_cl(float* X, const float* v, int B, int T, int C, hipStream_t st);
+// lf0 [B][T] * mask -> channels-last [B][T][ldc], channel 0 = value, the rest 0
+void launch_lf0_to_cl(const float* lf0, const float* mask, float* out, int B, int T, int ldc, hipStream_t st);
+// channels-last [B][T][C] -> channel-first [B][C][T]
+void launch_cl_to_cf(const float* X, float* out, int B, int T, int C, hipStream_t st);
+// sequence mask [B][T] (float 0/1) from int32 lengths
+void launch_len_mask(const int* lengths, float* mask, int B, int T, hipStream_t st);
+// VQEmbeddingEMA eval lookup (ref_encoder.py:205-216): dots [R][M] = x . e^T;  idx = argmin_m (|e_m|^2 + |x|^2) - 2 dots;
+// out[r][:] = e[idx] * mask[r]
+struct VqP { const float* X; const float* dots; const float* emb; const float* e2; const float* mask; float* out; int* idx;
+             long rows; int M, D; };
+void launch_vq_lookup(const VqP& p, hipStream_t st);
+void launch_row_sumsq(const float* X, float* out, long rows, int D, hipStream_t st);
+// one direction of one bidirectional GRU layer per (direction, batch element) workgroup (nn.GRU, hidden H = 96):
+// gi [B][T][2][3H] = W_ih x + b_ih (precomputed), Whh [2][3H][H], bhh [2][3H]; out [B][T][2H] (forward | reverse)
+struct GruP { const float* gi; const float* Whh; const float* bhh; float* out; int B, T, H; };
+void launch_gru_layer(const GruP& p, hipStream_t st);
 
 // STFT / mel -------------------------------------------------------------------------------------
 // clip to [-1,1] + reflect-pad n_fft/2 on both sides (stft.py:60-66, tools.py:9)

@@ -118,3 +118,42 @@ def make_vocoder_weights(shapes: dict, seed: int = 0) -> dict:
             w = symmetric("voc." + name, shape, gain * float(np.sqrt(3.0 / (cin * k))), seed)
         out[name] = np.ascontiguousarray(w, dtype=np.float32)
     return out
+
+
+def make_style_weights(shapes: dict, seed: int = 0) -> dict:
+    """Portable non-degenerate weights for the DEX style encoders (keys of ``style.param_shapes``: the reference's
+    ``tv_encoder.* / lf0_encoder.* / tiv_encoder.* / conv_sty.*`` state-dict entries): conv / GRU / linear weights
+    U(-a, a) with a = sqrt(3 / fan_in); norm scales 1 + 0.1 u; BatchNorm running_mean 0.1 u, running_var 1 + 0.3 u;
+    the VQ codebook 0.5 u; every other 1-D tensor 0.1 u."""
+    out = {}
+    for name, shape in shapes.items():
+        shape = tuple(shape)
+        key = "sty." + name
+        if name.endswith("num_batches_tracked"):
+            w = np.zeros(shape, dtype=np.int64)
+        elif name.endswith("running_var"):
+            w = 1.0 + symmetric(key, shape, 0.3, seed)
+        elif name.endswith("running_mean"):
+            w = symmetric(key, shape, 0.1, seed)
+        elif name.endswith(("ln.weight", "bn.weight", ".gamma")):
+            w = 1.0 + symmetric(key, shape, 0.1, seed)
+        elif name.endswith("vq.embedding"):
+            w = symmetric(key, shape, 0.5, seed)
+        elif name.endswith(("vq.ema_count", "vq.ema_weight")):
+            w = np.zeros(shape, dtype=np.float32)
+        elif len(shape) >= 2:
+            fan_in = int(np.prod(shape[1:]))
+            w = symmetric(key, shape, float(np.sqrt(3.0 / fan_in)), seed)
+        else:
+            w = symmetric(key, shape, 0.1, seed)
+        out[name] = np.ascontiguousarray(w, dtype=np.int64 if name.endswith("num_batches_tracked") else np.float32).reshape(shape)
+    return out
+
+
+def make_style_inputs(B: int, T: int, lengths=None, seed: int = 99):
+    """Synthetic reference-utterance features: mel [B,80,T] (mel-like), normalised log-f0 [B,T] with unvoiced zeros, lengths."""
+    mel = np.clip(normalish("sty_mel", (B, 80, T), seed) * 1.5 - 5.0, -11.5, 2.5).astype(np.float32)
+    lf0 = normalish("sty_lf0", (B, T), seed + 1).astype(np.float32)
+    lf0[uniform01("sty_uv", B * T, seed).reshape(B, T) < 0.3] = 0.0
+    lengths = np.asarray(lengths if lengths is not None else [T] * B, dtype=np.int64)
+    return mel, lf0, lengths

@@ -179,6 +179,42 @@ int  dex_voc_samples(const DexVoc* voc, int T);          /* T * prod(upsample_ra
 int  dex_vocode(DexVoc* voc, const float* mel_dev, int B, int T, float* wav_dev, void* workspace_dev, size_t workspace_bytes,
                 dex_stream_t stream);
 
+/* ---- DEX style encoders (DEX-TTS/model/ref_encoder.py TVEncoder :110-140 + VQEmbeddingEMA :199-237, LF0Encoder
+ * :36-55, TIVEncoder :83-108, DeXTTS.conv_sty tts.py:31) and the part of DeXTTS.forward that feeds the decoder (tts.py:55-66):
+ * the step right before the sampler for the DEX configs, once per reference utterance.  Eval mode (dropout off, BatchNorm on
+ * running statistics — folded into the convolutions by the caller —, frozen codebook).  A separate context. */
+typedef struct DexStyle DexStyle;
+typedef struct {
+    int32_t n_mels;                                             /* 80 */
+    int32_t tiv_layers, tiv_ch;                                 /* tiv_encoder: num_layer 6, c_h 128 (skips [B,c_h,Tr]) */
+    int32_t tv_layers, tv_ch, tv_cout, tv_cout_g, tv_n_emb;     /* tv_encoder: 6, 128, 192, 192, 512 */
+    int32_t lf0_ch, lf0_cout, lf0_cout_g, lf0_layers;           /* lf0_encoder: 192, 192, 192, 2 (GRU hidden = lf0_ch / 2 = 96) */
+    int32_t sty_out;                                            /* conv_sty output channels = 2 * decoder.dim (128) */
+} DexStyleConfig;
+typedef struct {
+    int32_t B, Tr, Ts, Tl;
+    const float* ref_mel_dev;  const int32_t* ref_lengths_dev;  /* [B,n_mels,Tr], [B]  -> TIVEncoder */
+    const float* sty_mel_dev;  const int32_t* sty_lengths_dev;  /* [B,n_mels,Ts], [B]  -> TVEncoder  */
+    const float* lf0_dev;      const int32_t* lf0_lengths_dev;  /* [B,Tl], [B]         -> LF0Encoder (normalised log-f0, 0 = unvoiced) */
+    float* const* ref_skips_out_dev;   /* HOST array of tiv_layers device pointers, each [B,tiv_ch,Tr]: Diffusion.forward's `ref` */
+    float* sty_dec_out_dev;            /* [B,sty_out,Ts]: Diffusion.forward's `sty` (conv_sty(z_dec + mean lf0_dec)) */
+    float* sty_enc_out_dev;            /* [B,tv_cout]: pooled style vector for the text encoder (tts.py:62-63) */
+    int32_t* vq_idx_out_dev;           /* optional [B,Ts]: the chosen codebook rows */
+    void* workspace_dev; size_t workspace_bytes;
+} DexStyleArgs;
+
+int  dex_style_create(const DexStyleConfig* cfg, DexStyle** out);
+void dex_style_destroy(DexStyle* sty);
+const char* dex_style_last_error(const DexStyle* sty);
+/* Keys = the reference state-dict names under tv_encoder.* / lf0_encoder.* / tiv_encoder.* / conv_sty.*; a conv followed by
+ * BatchNorm is handed over FOLDED as "<p>.conv.weight" + "<p>.conv.bias" (dex_tts_amd/style.py does it). */
+int  dex_style_num_weights(const DexStyle* sty);
+int  dex_style_weight_info(const DexStyle* sty, int i, const char** key, int64_t shape[4], int* ndim);
+int  dex_style_load_weight_async(DexStyle* sty, const char* key, const float* w_dev, const int64_t* shape, int ndim, dex_stream_t stream);
+int  dex_style_finalize(DexStyle* sty, dex_stream_t stream);
+size_t dex_style_workspace_bytes(const DexStyle* sty, int B, int Tr, int Ts, int Tl);
+int  dex_style_encode(DexStyle* sty, const DexStyleArgs* args, dex_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
