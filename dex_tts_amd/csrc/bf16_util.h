@@ -39,6 +39,26 @@ __device__ __forceinline__ float mul_pinned(float x, float y) {
     return r;
 }
 
+// Packed fp32 pairs (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of fp32 per VALU issue).  The GroupNorm +
+// Mish prologues of the convolutions are VALU-bound at batch size (phase counters: the conversion of a row chunk costs
+// more cycles than its 72 MFMAs), so they run on pairs; only v_exp_f32 / v_rcp_f32 / the clamp stay per value.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma_pinned(f32x2 x, f32x2 a, f32x2 b) {     // opaque: stays where it is written (see fma_pinned)
+    f32x2 r;
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(a), "v"(b));
+    return r;
+}
+// Mish(t) + add = t * n / (n + 2) + add with n = e (e + 2), e = exp(min(t, 20))  (tanh(softplus(t)) == 1 to fp32 beyond 20)
+__device__ __forceinline__ f32x2 mish2_add(f32x2 t, f32x2 add) {
+    f32x2 l = t * 1.44269504088896f;
+    l.x = fminf(l.x, 28.8539008f); l.y = fminf(l.y, 28.8539008f);
+    f32x2 e; e.x = __builtin_amdgcn_exp2f(l.x); e.y = __builtin_amdgcn_exp2f(l.y);
+    const f32x2 n = e * (e + 2.f);
+    const f32x2 d = n + 2.f;
+    f32x2 r; r.x = __builtin_amdgcn_rcpf(d.x); r.y = __builtin_amdgcn_rcpf(d.y);
+    return t * (n * r) + add;
+}
+
 __device__ __forceinline__ unsigned mov_pinned(unsigned x) {
     unsigned r;
     asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"(x));

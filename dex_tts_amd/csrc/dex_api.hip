@@ -726,7 +726,8 @@ struct Runner {
     }
     // Block conv (diffusion.py:44).  pro != null fuses the producer's GN-apply + Mish + time bias into the load
     // (bf16 patch kernel only).
-    struct Pro { const gnfix_t* stats; const float *gamma, *beta, *tadd; const float* res = nullptr; float* xout = nullptr; bool x_bf16 = false; };
+    struct Pro { const gnfix_t* stats; const float *gamma, *beta, *tadd; const float* res = nullptr; float* xout = nullptr; bool x_bf16 = false;
+                 bool res2 = false; FirstConvP res2f{}; };     // res2: `res` is not stored - recomputed from the first conv's inputs (res2f)
     // raw conv outputs read only by a fused GroupNorm prologue (h1, h2 of a ResnetBlock, the final block's conv) are kept
     // in HBM as bf16 in bf16 mode: half the bytes of the largest tensors of the step.  DEX_H_BF16=0 keeps them fp32.
     bool h_bf16() const { const char* e = getenv("DEX_H_BF16"); return x->lp() && !(e && e[0] == '0'); }
@@ -740,7 +741,12 @@ struct Runner {
             c.x_bf16 = xb ? 1 : 0; c.y_bf16 = yb ? 1 : 0;
             c.X = X.p; c.ldx = X.ld; c.x_coff = X.coff; c.H = H; c.W = W; c.Cin = X.C; c.Cout = Cout;
             c.Wbf = it->second; c.bias = bias; c.Y = out; c.mask = mask; c.mask_ws = mask_ws; c.mask_bstride = P.d.T;
-            if (pro) { c.pro_stats = pro->stats; c.pro_gamma = pro->gamma; c.pro_beta = pro->beta; c.pro_tadd = pro->tadd; c.pro_res = pro->res; c.pro_xout = pro->xout; }
+            if (pro) { c.pro_stats = pro->stats; c.pro_gamma = pro->gamma; c.pro_beta = pro->beta; c.pro_tadd = pro->tadd; c.pro_res = pro->res; c.pro_xout = pro->xout;
+                if (pro->res2) {
+                    const FirstConvP& f = pro->res2f;
+                    c.pro_res = nullptr; c.res2_w = f.W1; c.res2_b = f.b1; c.res2_mu = f.mu; c.res2_x = f.x; c.res2_spk = f.spk;
+                    c.res2_scal = f.scal; c.res2_scal_stride = f.scal_stride; c.res2_planes = f.planes;
+                } }
             c.step = sp; c.gn_stats = gn; c.B = P.d.B;
             if (shortcut) {       // the block's 1x1 res_conv rides on the centre tap of this conv
                 c.res_w = x->lp_of().at(shortcut->wr); c.res_b = shortcut->br; c.res_y = shortcut_out;
@@ -748,7 +754,7 @@ struct Runner {
             const double M = (double)H * W * P.d.B;
             // algorithmic bytes: input + output at their stored width, + the residual read and the x write-out of the PRO2 form,
             // + the shortcut output of the RES form, + the weights once
-            const double bytes = M * ((xb ? 2.0 : 4.0) * X.C + (yb ? 2.0 : 4.0) * Cout + (pro && pro->res ? 8.0 * X.C : 0.0) + (shortcut ? 4.0 * Cout : 0.0))
+            const double bytes = M * ((xb ? 2.0 : 4.0) * X.C + (yb ? 2.0 : 4.0) * Cout + (pro && (pro->res || pro->res2) ? (pro->res2 ? 4.0 * X.C : 8.0 * X.C) : 0.0) + (shortcut ? 4.0 * Cout : 0.0))
                                  + 2.0 * 9 * X.C * Cout;
             run(name, 2.0 * M * Cout * (9 * X.C + (shortcut ? X.C : 0)), bytes, [&] { launch_conv3x3_lp(c, x->precision, st); });
             return;
@@ -797,8 +803,13 @@ struct Runner {
             f.mu = mu; f.x = xcur; f.spk = P.spk_plane; f.mask = mask; f.B = P.d.B; f.H = s.H; f.T = s.W; f.planes = w.cin; f.C = w.cout;
             f.W3 = w.w1; f.b3 = w.b1; f.W1 = w.wr; f.b1 = w.br; f.scal = P.scal; f.scal_stride = SCAL_STRIDE; f.step = sp;
             f.h1 = s.h1; f.res = s.rbuf;
+            // the 1x1 shortcut of this block is two or three FMAs per value from the input planes: when the consumer is the next
+            // block's fused-tail convolution it recomputes it, and the fp32 [B,H,T,64] tensor is neither written nor read
+            // (DEX_RES2=0 stores it as before)
+            { const char* e = getenv("DEX_RES2");
+              if (ctail && h2b && w.cout == 64 && conv3x3_res2_form(s.H, s.W, P.d.B) && !(e && e[0] == '0')) { f.res = nullptr; ctail->res2 = true; ctail->res2f = f; } }
             st1 = next_stats(); f.gn_stats = st1;
-            run("first_conv", 2.0 * npix * P.d.B * w.cout * (w.cin * 10), npix * P.d.B * ((h1b ? 6.0 : 8.0) * w.cout + 4.0 * w.cin), [&] { launch_first_conv(f, st); });
+            run("first_conv", 2.0 * npix * P.d.B * w.cout * (w.cin * 10), npix * P.d.B * ((h1b ? 2.0 : 4.0) * w.cout + (f.res ? 4.0 * w.cout : 0.0) + 4.0 * w.cin), [&] { launch_first_conv(f, st); });
             resptr = s.rbuf; ldres = w.cout; resb = npix * w.cout;
         } else {
             st1 = next_stats();

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
     const bool has_q = p.next_shift != nullptr;
 
 #ifdef DEX_TIMING
-    long long tst[10] = {0,0,0,0,0,0,0,0,0,0};
+    long long tst[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
     tst[0] = wall_clock64();
 #endif
     float2 lnv;
@@ -294,6 +294,9 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
             }
             kt = kn;
         }
+#ifdef DEX_TIMING
+        tst[8] = wall_clock64();
+#endif
         al += __shfl_xor(al, 32);
         // partial (m, l, O[query][d]) of this wave -> LDS scratch (the chain's buffers are not live yet)
         float* scr = reinterpret_cast<float*>(smem_rc);
@@ -320,7 +323,13 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
         const float* src = p.O + (mb + n) * RC_H + seg * 4;
         float4 v[4];
         if constexpr (ATTN) {
+#ifdef DEX_TIMING
+            tst[9] = wall_clock64();
+#endif
             lds_barrier();                                   // every wave's partial is in the scratch
+#ifdef DEX_TIMING
+            tst[10] = wall_clock64();
+#endif
             const float* scr = reinterpret_cast<const float*>(smem_rc);
             const float* stat = scr + RC_NW * 32 * AT_LD;
 #pragma unroll
@@ -344,6 +353,9 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
                 }
             }
             lds_barrier();                                   // scratch fully read: the chain's buffers may now be written
+#ifdef DEX_TIMING
+            tst[11] = wall_clock64();
+#endif
             const int which = tid >> 7, c2 = (tid & 127) * 2;
             *reinterpret_cast<float2*>(LNp + which * RC_H + c2) = lnv;
         } else if (p.ksplit <= 1) {
@@ -501,7 +513,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
     mma16(acc, wb, a_lane);
     store_qkv_tile(p, acc, wave + 16, bq2, b, n0, lane, scr);
 #ifdef DEX_TIMING
-    if (p.dbg && tid == 0) { tst[7] = wall_clock64(); for (int k = 0; k < 8; ++k) p.dbg[blockIdx.x * 8 + k] = tst[k]; }
+    if (p.dbg && tid == 0) { tst[7] = wall_clock64(); for (int k = 0; k < 8; ++k) p.dbg[blockIdx.x * 8 + k] = tst[k]; for (int k = 8; k < 12; ++k) p.dbg[1024 + blockIdx.x * 4 + k - 8] = tst[k]; }
 #endif
 }
 

@@ -74,6 +74,11 @@ struct Conv3P {
     //   x = mask * Mish(GN(X)) + pro_res   (res_conv shortcut, diffusion.py:67-71), [H*W][Cin] like X;
     // the kernel also writes x for its own output pixels to pro_xout ([H*W][Cin]) for the later consumers.
     const float* pro_res; float* pro_xout;
+    // pro_res recomputed instead of read (res2_w != null, pro_res == null; Cin == 64): the shortcut of the U-Net's FIRST
+    // ResnetBlock is res_conv((mu, c_in*x[, spk]) * mask), a 1x1 conv of 2-3 input planes (diffusion.py:70,171-175) - two or
+    // three FMAs per value from planes that stay in cache, against 4 B written by the first conv and read back here.
+    // res2_w = fp32 [planes][64] (FirstConvP::W1), res2_b [64]; planes [B][H][W] (spk: [B][H]); c_in = res2_scal[step*stride+2].
+    const float *res2_w, *res2_b, *res2_mu, *res2_x, *res2_spk, *res2_scal; int res2_scal_stride, res2_planes;
     // fused 1x1 shortcut of the ResnetBlock (res_conv(x * mask), diffusion.py:70): a second output computed from the
     // patch's centre tap; res_w = bf16 [Cout][Cin], res_y = [H*W][Cout] fp32
     const void* res_w; const float* res_b; float* res_y;
@@ -87,6 +92,7 @@ bool conv3x3_bf16_supported(int Cin, int Cout);
 bool conv3x3_bf16_tail_supported(int C);     // pro_res form (Cin == Cout == C)
 bool conv3x3_bf16_res_supported(int Cin, int Cout);   // res_w form (fused 1x1 shortcut)
 bool conv3x3_bf16_xb_supported(int Cin, int Cout);    // x_bf16 form (bf16 input under a GroupNorm prologue)
+bool conv3x3_res2_form(int H, int W, int B);           // a 64 -> 64 fused-tail conv of this grid runs on the form that implements res2_*
 void launch_conv3x3_lp(const Conv3P& p, int precision, hipStream_t st);   // picks the strip-streaming form (conv3x3_stream.hip) for large grids
 
 // First ResnetBlock of the U-Net: 3x3 conv and 1x1 res_conv straight from the stacked input planes

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const FirstConvP p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (!p.h1_bf16) *reinterpret_cast<float4*>(p.h1 + pix * C + cq * 16 + j * 4) = a3[j];
-            *reinterpret_cast<float4*>(p.res + pix * C + cq * 16 + j * 4) = a1[j];
+            if (p.res) *reinterpret_cast<float4*>(p.res + pix * C + cq * 16 + j * 4) = a1[j];     // null: the consumer recomputes it (Conv3P::res2_*)
         }
     }
     if (p.gn_stats) {          // GroupNorm partials of h1: CPG channels per group -> this thread feeds 16 / CPG groups
@@ -252,7 +252,11 @@ void launch_gn_apply(const GnApplyP& p, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // final: per pixel  f = mask * (b + sum_c w[c] * mask * Mish(GN(x)[c]));  D = c_skip*x + c_out*f;
 //        x_next = x + (t_next - t)/t * (x - D).          scal row: [sigma, sigma_next, c_in, c_skip, c_out, c_noise]
-// 16 lanes cooperate on one pixel (C = 64 -> one float4 each; C = 128 -> two).
+// 8 lanes cooperate on one pixel (8 channels per lane and 64-channel block: one 16-byte load of bf16 / fp16, two of fp32).
+// A block owns FIN_U groups of 32 pixels per pass and issues every load of the pass - activations, mask, sampler state -
+// before the first use (the first version walked its pixels one dependent load at a time: 125 us for 168 MB at B=32);
+// the per-channel GroupNorm coefficient and final_conv weight live in registers for the block's life; Mish on packed pairs.
+constexpr int FIN_U = 4;
 __global__ __launch_bounds__(256) void final_kernel(const FinalP p) {
     __shared__ float smean[32], srstd[32];
     const int tid = threadIdx.x, b = blockIdx.y;
@@ -263,44 +267,88 @@ __global__ __launch_bounds__(256) void final_kernel(const FinalP p) {
     const float* sc = p.scal + (long)step * p.scal_stride;
     const float sigma = sc[0], sigma_next = sc[1], c_skip = sc[3], c_out = sc[4];
     const float* X = p.X + (long)b * p.xb;
+    const unsigned short* Xh = reinterpret_cast<const unsigned short*>(p.X) + (long)b * p.xb;
     const float* mrow = p.mask + (long)b * p.mask_bstride;
-    const int sub = tid & 15;
-    for (long px = (long)blockIdx.x * 16 + (tid >> 4); px < p.npix; px += (long)gridDim.x * 16) {
-        const int w = (int)(px % p.W);
-        const float mk = mrow[w];
-        float acc = 0.f;
-        for (int c = sub * 4; c < p.C; c += 64) {
-            const int g = c / cpg;
-            const float mean = smean[g], rstd = srstd[g];
-            float4 x;
-            if (p.x_bf16) {
-                const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.X) + (long)b * p.xb + px * p.C + c);
-                x = make_float4(lo_kind(r.x, p.x_bf16), hi_kind(r.x, p.x_bf16), lo_kind(r.y, p.x_bf16), hi_kind(r.y, p.x_bf16));
-            } else x = *reinterpret_cast<const float4*>(X + px * p.C + c);
-            const float4 ga = *reinterpret_cast<const float4*>(p.gamma + c);
-            const float4 be = *reinterpret_cast<const float4*>(p.beta + c);
-            const float4 wv = *reinterpret_cast<const float4*>(p.wfc + c);
-            acc = fmaf(mish_f((x.x - mean) * rstd * ga.x + be.x), wv.x, acc);
-            acc = fmaf(mish_f((x.y - mean) * rstd * ga.y + be.y), wv.y, acc);
-            acc = fmaf(mish_f((x.z - mean) * rstd * ga.z + be.z), wv.z, acc);
-            acc = fmaf(mish_f((x.w - mean) * rstd * ga.w + be.w), wv.w, acc);
+    const int sub = tid & 7;
+    const int nblk = p.C / 64;                       // 1, or 2 for the 128-channel geometry
+    f32x2 ca[2][4], cb[2][4], cw[2][4];              // t = x * ca + cb;  out += Mish(t) * cw
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (k < nblk) {
+            const int c = k * 64 + sub * 8;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c0 = c + 2 * j, c1 = c0 + 1;
+                const float a0 = srstd[c0 / cpg] * p.gamma[c0], a1 = srstd[c1 / cpg] * p.gamma[c1];
+                ca[k][j] = f32x2{a0, a1};
+                cb[k][j] = f32x2{p.beta[c0] - smean[c0 / cpg] * a0, p.beta[c1] - smean[c1 / cpg] * a1};
+                cw[k][j] = f32x2{p.wfc[c0], p.wfc[c1]};
+            }
         }
-        acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4); acc += __shfl_xor(acc, 8);
-        if (sub == 0) {
-            const float f = (acc * mk + p.bfc[0]) * mk;
-            const long o = (long)b * p.npix + px;            // [B,80,T] has the same (h*T + w) linear order
-            const float xc = p.xcur[o];
-            const float D = c_skip * xc + c_out * f;
-            if (p.denoised) p.denoised[o] = D;
-            if (p.xnext) {
-                const float inv = 1.f / sigma;
-                const float d = inv * xc - inv * D;
-                const float h = p.htab ? p.htab[step] : sigma_next - sigma;
-                if (p.mode == 2) {
-                    p.xnext[o] = p.xhat[o] + h * (0.5f * p.dbuf[o] + 0.5f * d);
-                } else {
-                    if (p.mode == 1) p.dbuf[o] = d;
-                    p.xnext[o] = xc + h * d;
+    }
+    const float bfc = p.bfc[0];
+    const float inv = 1.f / sigma;
+    const float h = p.htab ? p.htab[step] : sigma_next - sigma;
+    const long stride = (long)gridDim.x * 32 * FIN_U;
+    for (long base = (long)blockIdx.x * 32 * FIN_U; base < p.npix; base += stride) {
+        uint4 raw[FIN_U][2][2];                      // [pass][64-channel block][fp32: two halves; bf16: [0] only]
+        float mk[FIN_U], xc[FIN_U], xa[FIN_U], xd[FIN_U];
+#pragma unroll
+        for (int u = 0; u < FIN_U; ++u) {
+            const long pr = base + u * 32 + (tid >> 3);
+            const long px = pr < p.npix ? pr : p.npix - 1;
+            const long o = (long)b * p.npix + px;
+            mk[u] = mrow[(int)(px % p.W)];
+            xc[u] = p.xcur[o];
+            xa[u] = p.mode == 2 ? p.xhat[o] : 0.f;
+            xd[u] = p.mode == 2 ? p.dbuf[o] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (k < nblk) {
+                    if (p.x_bf16) raw[u][k][0] = *reinterpret_cast<const uint4*>(Xh + px * p.C + k * 64 + sub * 8);
+                    else {
+                        raw[u][k][0] = *reinterpret_cast<const uint4*>(X + px * p.C + k * 64 + sub * 8);
+                        raw[u][k][1] = *reinterpret_cast<const uint4*>(X + px * p.C + k * 64 + sub * 8 + 4);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < FIN_U; ++u) {
+            f32x2 acc2 = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (k < nblk) {
+                    f32x2 x[4];
+                    if (p.x_bf16) {
+                        const uint4 r = raw[u][k][0];
+                        x[0] = f32x2{lo_kind(r.x, p.x_bf16), hi_kind(r.x, p.x_bf16)}; x[1] = f32x2{lo_kind(r.y, p.x_bf16), hi_kind(r.y, p.x_bf16)};
+                        x[2] = f32x2{lo_kind(r.z, p.x_bf16), hi_kind(r.z, p.x_bf16)}; x[3] = f32x2{lo_kind(r.w, p.x_bf16), hi_kind(r.w, p.x_bf16)};
+                    } else {
+                        const uint4 r0 = raw[u][k][0], r1 = raw[u][k][1];
+                        x[0] = f32x2{__uint_as_float(r0.x), __uint_as_float(r0.y)}; x[1] = f32x2{__uint_as_float(r0.z), __uint_as_float(r0.w)};
+                        x[2] = f32x2{__uint_as_float(r1.x), __uint_as_float(r1.y)}; x[3] = f32x2{__uint_as_float(r1.z), __uint_as_float(r1.w)};
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc2 = mish2_add(x[j] * ca[k][j] + cb[k][j], f32x2{0.f, 0.f}) * cw[k][j] + acc2;
+                }
+            }
+            float acc = acc2.x + acc2.y;
+            acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+            const long pr = base + u * 32 + (tid >> 3);
+            if (sub == 0 && pr < p.npix) {
+                const float f = (acc * mk[u] + bfc) * mk[u];
+                const long o = (long)b * p.npix + pr;            // [B,80,T] has the same (h*T + w) linear order
+                const float D = c_skip * xc[u] + c_out * f;
+                if (p.denoised) p.denoised[o] = D;
+                if (p.xnext) {
+                    const float d = inv * xc[u] - inv * D;
+                    if (p.mode == 2) {
+                        p.xnext[o] = xa[u] + h * (0.5f * xd[u] + 0.5f * d);
+                    } else {
+                        if (p.mode == 1) p.dbuf[o] = d;
+                        p.xnext[o] = xc[u] + h * d;
+                    }
                 }
             }
         }
@@ -353,10 +401,9 @@ void launch_heun_expand(const float* t_hat, const float* hin, int n, float* sig,
 void launch_final(const FinalP& p, hipStream_t st) {
     // every block pays the GroupNorm-coefficient prologue (fp64 divide + sqrt behind a barrier, ~2 us): at large batch
     // keep the total near 16K blocks so each one streams several 16-pixel groups instead of one
-    long blocks = (p.npix + 15) / 16;
-    const long cap = 16384 / p.B > 128 ? 16384 / p.B : 128;
+    long blocks = (p.npix + 32 * FIN_U - 1) / (32 * FIN_U);      // one pass of FIN_U 32-pixel groups per block ...
+    const long cap = 8192 / p.B > 64 ? 8192 / p.B : 64;            // ... a few passes at large batch
     if (blocks > cap) blocks = cap;
-    if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(final_kernel, dim3((unsigned)blocks, p.B), dim3(256), 0, st, p);
 }
 

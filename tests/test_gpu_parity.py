@@ -352,7 +352,7 @@ def test_conv_stream_path(name, kw):
     (DEX_CONV_STREAM=0): same bf16 operands, different accumulation order inside the MFMA chains."""
     cfg, eng, w = U.engine_for(name)
     case = U.make_case(cfg, **kw)
-    old = os.environ.get("DEX_CONV_STREAM")
+    old = os.environ.get("DEX_CONV_STREAM"), os.environ.get("DEX_CONV_PP")
     try:
         for prec in ("bf16", "fp16"):
             eng.set_precision(prec)
@@ -360,18 +360,27 @@ def test_conv_stream_path(name, kw):
                 os.environ["DEX_CONV_STREAM"] = "0"
                 tile, ref, _ = U.run_precond(name, case, sigma, with_taps=False)
                 os.environ["DEX_CONV_STREAM"] = "2"
-                got, ref, _ = U.run_precond(name, case, sigma, with_taps=False)
-                lowp_ok(f"stream_{name}_{sigma}", prec, "call", got, ref)
-                d = np.abs(got - tile)
-                U.record(f"stream_vs_tile_{name}_{sigma}:{prec}", max=d.max(), mean=d.mean())
-                mx, mn = LOWP[prec]["call"]
-                assert d.max() <= mx and d.mean() <= mn, (sigma, d.max(), d.mean())     # same operands, another summation order
+                outs = {}
+                for pp in ("0", "2"):                     # the strip walker, and its two-group ping-pong form
+                    os.environ["DEX_CONV_PP"] = pp
+                    got, ref, _ = U.run_precond(name, case, sigma, with_taps=False)
+                    outs[pp] = got
+                    lowp_ok(f"stream{pp}_{name}_{sigma}", prec, "call", got, ref)
+                    d = np.abs(got - tile)
+                    U.record(f"stream{pp}_vs_tile_{name}_{sigma}:{prec}", max=d.max(), mean=d.mean())
+                    mx, mn = LOWP[prec]["call"]
+                    assert d.max() <= mx and d.mean() <= mn, (sigma, d.max(), d.mean())     # same operands, another summation order
+                # both forms run the same MFMA chain per output row; only the GroupNorm partial sums group differently
+                dd = np.abs(outs["0"] - outs["2"])
+                U.record(f"stream_pp_vs_walker_{name}_{sigma}:{prec}", max=dd.max(), mean=dd.mean())
+                assert dd.max() <= mx and dd.mean() <= mn
     finally:
         eng.set_precision("fp32")
-        if old is None:
-            os.environ.pop("DEX_CONV_STREAM", None)
-        else:
-            os.environ["DEX_CONV_STREAM"] = old
+        for k, v in zip(("DEX_CONV_STREAM", "DEX_CONV_PP"), old):
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def test_repeatability_fp32_mode():

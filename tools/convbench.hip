@@ -27,15 +27,30 @@ int main(int argc, char** argv) {
         if (variant == 3) { p.pro_res = res; p.pro_xout = xout; nm = "PRO2 fp32->fp32"; }
         if (variant == 4) { p.pro_res = res; p.pro_xout = xout; p.x_bf16 = 1; p.y_bf16 = 1; nm = "PRO2 bf16->bf16"; }
         if (variant == 5) { p.y_bf16 = 1; nm = "plain fp32->bf16"; }
-        for (int mode = 0; mode < 2; ++mode) {
+        for (int mode = 0; mode < 3; ++mode) {
             setenv("DEX_CONV_STREAM", mode ? "1" : "0", 1);
+            setenv("DEX_CONV_PP", mode == 2 ? "1" : "0", 1);
             for (int it = 0; it < 3; ++it) launch_conv3x3_lp(p, 0);
             hipEventRecord(e0, 0);
             for (int it = 0; it < 20; ++it) launch_conv3x3_lp(p, 0);
             hipEventRecord(e1, 0); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
-            printf("%-18s %s: %8.2f us\n", nm, mode ? "stream" : "tile  ", ms * 1000 / 20);
+            printf("%-18s %s: %8.2f us\n", nm, mode == 2 ? "pingpong" : mode ? "stream  " : "tile    ", ms * 1000 / 20);
         }
+#ifdef DEX_TIMING
+        {   // ping-pong form: per group (two per workgroup) cycles by role
+            setenv("DEX_CONV_PP", "1", 1); setenv("DEX_CONV_STREAM", "1", 1);
+            const int nb = 2 * 1024;
+            long long* dbg; hipMalloc(&dbg, (size_t)nb * 64); hipMemset(dbg, 0, (size_t)nb * 64);
+            p.dbg = dbg; launch_conv3x3_lp(p, 0); hipDeviceSynchronize(); p.dbg = nullptr;
+            std::vector<long long> h((size_t)nb * 8); hipMemcpy(h.data(), dbg, (size_t)nb * 64, hipMemcpyDeviceToHost);
+            double a[8] = {0}; int n = 0; for (int bl = 0; bl < nb; ++bl) if (h[(size_t)bl * 8 + 7]) { ++n; for (int k = 0; k < 8; ++k) a[k] += h[(size_t)bl * 8 + k]; }
+            if (n) printf("   ping-pong, avg cycles per group (%d groups): mfma role %.0f | emit %.0f | convert %.0f | barrier wait %.0f | loop total %.0f\n",
+                   n, a[1] / n, a[2] / n, a[3] / n, a[4] / n, a[7] / n);
+            hipFree(dbg);
+        }
+#endif
+        setenv("DEX_CONV_PP", "0", 1);
 #ifdef DEX_TIMING
         if (!conv3x3_stream_tiles(p)) {                    // small grid: the tile kernel's phase counters
             const int nb = (W / 32) * (H / 4) * B;

@@ -13,7 +13,7 @@ for r in rows[a:b]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     gap = s - prev_end
     prev_end = e
-    nm = r["Kernel_Name"].replace("dex::", "").split("(")[0][:44]
+    nm = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("dex::", "").split("(")[0][:44]
     grid = f'{r.get("Grid_Size_X","?")}x{r.get("Grid_Size_Y","?")}x{r.get("Grid_Size_Z","?")}'
     print(f"{nm:46s} grid={grid:16s} dur={(e-s)/1e3:8.2f}us gap={gap/1e3:7.2f}us")
     tot_k += e - s; tot_gap += gap
