@@ -55,6 +55,24 @@ class DexStyleArgs(C.Structure):
                 ("workspace_dev", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
+class DexTextConfig(C.Structure):
+    _fields_ = [("variant", C.c_int32), ("n_vocab", C.c_int32), ("n_feats", C.c_int32), ("n_channels", C.c_int32),
+                ("filter_channels", C.c_int32), ("filter_channels_dp", C.c_int32), ("n_heads", C.c_int32), ("n_layers", C.c_int32),
+                ("kernel_size", C.c_int32), ("n_spks", C.c_int32), ("spk_emb_dim", C.c_int32), ("use_softmax", C.c_int32), ("use_decay", C.c_int32)]
+
+
+class DexTextArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("tokens_dev", C.c_void_p), ("lengths_dev", C.c_void_p), ("spk_dev", C.c_void_p),
+                ("sty_dev", C.c_void_p), ("length_scale", C.c_float), ("mu_out_dev", C.c_void_p), ("logw_out_dev", C.c_void_p),
+                ("w_ceil_out_dev", C.c_void_p), ("y_lengths_out_dev", C.c_void_p), ("workspace_dev", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class DexAlignArgs(C.Structure):
+    _fields_ = [("B", C.c_int32), ("T", C.c_int32), ("Ty", C.c_int32), ("mu_x_dev", C.c_void_p), ("w_ceil_dev", C.c_void_p),
+                ("x_lengths_dev", C.c_void_p), ("y_lengths_dev", C.c_void_p), ("mu_y_out_dev", C.c_void_p), ("y_mask_out_dev", C.c_void_p),
+                ("attn_out_dev", C.c_void_p), ("workspace_dev", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
 class DexDenoiseArgs(C.Structure):
     _fields_ = [("s", DexSampleArgs), ("x_dev", C.c_void_p)]
 
@@ -103,6 +121,16 @@ SYMBOLS = [
     ("dex_style_finalize", C.c_int, [C.c_void_p, C.c_void_p]),
     ("dex_style_workspace_bytes", C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     ("dex_style_encode", C.c_int, [C.c_void_p, C.POINTER(DexStyleArgs), C.c_void_p]),
+    ("dex_text_create", C.c_int, [C.POINTER(DexTextConfig), C.POINTER(C.c_void_p)]),
+    ("dex_text_destroy", None, [C.c_void_p]),
+    ("dex_text_last_error", C.c_char_p, [C.c_void_p]),
+    ("dex_text_num_weights", C.c_int, [C.c_void_p]),
+    ("dex_text_weight_info", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    ("dex_text_load_weight_async", C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.c_void_p]),
+    ("dex_text_finalize", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("dex_text_workspace_bytes", C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
+    ("dex_text_encode", C.c_int, [C.c_void_p, C.POINTER(DexTextArgs), C.c_void_p]),
+    ("dex_text_align", C.c_int, [C.c_void_p, C.POINTER(DexAlignArgs), C.c_void_p]),
     ("dex_mel_frames", C.c_int, [C.c_int]),
     ("dex_mel_from_wav", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
 ]

@@ -336,6 +336,27 @@ void launch_row_sumsq(const float* X, float* out, long rows, int D, hipStream_t 
 struct GruP { const float* gi; const float* Whh; const float* bhh; float* out; int B, T, H; };
 void launch_gru_layer(const GruP& p, hipStream_t st);
 
+// Text encoder path (text_elem.hip; dex_text.hip) -------------------------------------------------
+void launch_embed(const int* tok, const float* emb, float* out, long rows, int C, int ld, float scale, int n_vocab, hipStream_t st);
+void launch_bcast_cols(float* X, int ld, int coff, const float* v, int B, int T, int n, hipStream_t st);
+// per-row norm over C <= 256 channels.  mode 0: LayerNorm * gamma + beta; 1: RMSNorm * gamma (gamma may be null);
+// 2: LayerNorm * gamma[b] + beta[b] (per-utterance [B][C] tables, rows = b*T + t).  Then optional ReLU, then * mask[row].
+struct RowNormP { const float* X; int ldx; float* Y; int ldy; long rows; int C; int mode; const float* gamma; const float* beta; float eps;
+                  int relu; const float* mask; int T; };
+void launch_row_norm(const RowNormP& p, hipStream_t st);
+// qkvg [rows][ld] = [q | k | v | g] (E each) -> Q, K, V [rows][ldp = heads*128]: head h at columns h*128.., kd real + zero padding;
+// q, k rotated by angle[d] * t (xPos theta_shift), k pre-scaled
+struct RetRotP { const float* qkvg; int ld; long rows; int T, heads, kd, E; const float* angle; float kscale; float *Q, *K, *V; int ldp; };
+void launch_ret_rotate(const RetRotP& p, hipStream_t st);
+struct RetGateP { const float* O; int ldo; const float* qkvg; int ld; float* out; int ldout; long rows; int heads, hd, E; float eps; };
+void launch_ret_gate(const RetGateP& p, hipStream_t st);
+void launch_glu(const float* GF, float* out, long rows, int F, hipStream_t st);
+void launch_cl_to_cf_mask(const float* X, int ldx, const float* mask, float* out, int B, int T, int C, hipStream_t st);
+void launch_durations(const float* logw, const float* mask, float length_scale, float* w_ceil, float* cum, int* y_len, int B, int T, hipStream_t st);
+void launch_cumsum_rows(const float* X, float* out, int B, int T, hipStream_t st);
+struct AlignP { const float* mu_x; const float* cum; const int* x_len; const int* y_len; int B, T, Ty, F; float* mu_y; float* y_mask; float* attn; };
+void launch_align(const AlignP& p, hipStream_t st);
+
 // STFT / mel -------------------------------------------------------------------------------------
 // clip to [-1,1] + reflect-pad n_fft/2 on both sides (stft.py:60-66, tools.py:9)
 void launch_wav_pad(const float* wav, int n, int pad, float* out, int out_len, hipStream_t st);

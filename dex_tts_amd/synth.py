@@ -157,3 +157,46 @@ def make_style_inputs(B: int, T: int, lengths=None, seed: int = 99):
     lf0[uniform01("sty_uv", B * T, seed).reshape(B, T) < 0.3] = 0.0
     lengths = np.asarray(lengths if lengths is not None else [T] * B, dtype=np.int64)
     return mel, lf0, lengths
+
+
+def make_text_weights(shapes: dict, seed: int = 0) -> dict:
+    """Portable non-degenerate weights for the text encoder (keys of ``text.param_shapes`` = the reference TextEncoder
+    state dict): Linear / Conv1d U(-a, a) with a = sqrt(3 / fan_in) (x 0.7 for the q / k projections, so the softmax is
+    neither flat nor one-hot), norm scales 1 + 0.1 u, biases and norm shifts 0.1 u, the embedding 0.6 u (x sqrt(192) at
+    use), the AdaptiveLayerNorm scale bias 1 + 0.1 u; the duration head is scaled and shifted so durations spread over
+    1..8 frames; ``retnet_rel_pos.angle`` / ``.decay`` are the reference's constants (retention.py:76-85)."""
+    out = {}
+    for name, shape in shapes.items():
+        shape = tuple(shape)
+        key = "txt." + name
+        if name.endswith("retnet_rel_pos.angle"):
+            half = shape[0] // 2
+            a = 1.0 / (10000.0 ** np.linspace(0.0, 1.0, half, dtype=np.float32))
+            w = np.repeat(a.astype(np.float32), 2)
+        elif name.endswith("retnet_rel_pos.decay"):
+            w = np.log(1.0 - 2.0 ** (-5.0 - np.arange(shape[0], dtype=np.float32))).astype(np.float32)
+        elif name == "emb.weight":
+            w = symmetric(key, shape, 0.6, seed)
+        elif name == "proj_w.proj.weight":
+            w = symmetric(key, shape, 0.12, seed)
+        elif name == "proj_w.proj.bias":
+            w = np.full(shape, 1.0, dtype=np.float32)
+        elif name.endswith((".gamma", "layer_norm.weight")) or name.endswith("W_scale.bias"):
+            w = 1.0 + symmetric(key, shape, 0.1, seed)
+        elif len(shape) >= 2:
+            fan_in = int(np.prod(shape[1:]))
+            gain = 0.7 if name.endswith(("q_proj.weight", "k_proj.weight")) else (0.3 if ".adaln_" in name else 1.0)
+            w = symmetric(key, shape, gain * float(np.sqrt(3.0 / fan_in)), seed)
+        else:
+            w = symmetric(key, shape, 0.1, seed)
+        out[name] = np.ascontiguousarray(w, dtype=np.float32).reshape(shape)
+    return out
+
+
+def make_text_inputs(B: int, L: int, lengths=None, n_vocab: int = 149, seed: int = 321):
+    """Token ids [B, L] int64 (0 beyond each length), lengths [B] int64."""
+    lengths = np.asarray(lengths if lengths is not None else [L] * B, dtype=np.int64)
+    tok = (uniform01("tokens", B * L, seed) * n_vocab).astype(np.int64).reshape(B, L) % n_vocab
+    for b in range(B):
+        tok[b, lengths[b]:] = 0
+    return tok, lengths

@@ -215,6 +215,55 @@ int  dex_style_finalize(DexStyle* sty, dex_stream_t stream);
 size_t dex_style_workspace_bytes(const DexStyle* sty, int B, int Tr, int Ts, int Tl);
 int  dex_style_encode(DexStyle* sty, const DexStyleArgs* args, dex_stream_t stream);
 
+/* ---- Text encoder + durations + alignment: TextEncoder.forward (GeDEX-TTS/model/text_encoder.py:129-146, DEX
+ * :126-142: embedding, ConvReluNorm prenet, RetNet in its parallel form with use_softmax = True / use_decay = False — the only
+ * setting the shipped configs use —, proj_m, DurationPredictor) and the lines of the TTS forward between the encoder and the
+ * decoder (tts.py:37-50: w_ceil, y_lengths, generate_path, mu_y).  Once per utterance; exact-fp32 arithmetic.  Eval mode. */
+typedef struct DexText DexText;
+typedef struct {
+    int32_t variant;                  /* DEX_VARIANT_GEDEX, or DEX_VARIANT_DEX: AdaptiveLayerNorm(sty) after both residual sums of every layer */
+    int32_t n_vocab, n_feats, n_channels, filter_channels, filter_channels_dp, n_heads, n_layers, kernel_size;
+    int32_t n_spks, spk_emb_dim;      /* n_spks > 1: the speaker embedding is concatenated to the prenet output (RetNet width n_channels + spk_emb_dim) */
+    int32_t use_softmax, use_decay;   /* must be 1, 0 */
+} DexTextConfig;
+typedef struct {
+    int32_t B, T;
+    const int32_t* tokens_dev;        /* [B,T] token ids */
+    const int32_t* lengths_dev;       /* [B], each in [1, T] */
+    const float* spk_dev;             /* [B,spk_emb_dim] speaker embedding rows (spk_emb(spk), tts.py:31) when n_spks > 1, else NULL */
+    const float* sty_dev;             /* [B,n_channels] pooled style vector (dex_style_encode's sty_enc) for DEX_VARIANT_DEX, else NULL */
+    float length_scale;               /* tts.py:38 */
+    float* mu_out_dev;                /* [B,n_feats,T]  mu_x */
+    float* logw_out_dev;              /* [B,T]          log durations */
+    float* w_ceil_out_dev;            /* [B,T]          ceil(exp(logw) * mask) * length_scale */
+    int32_t* y_lengths_out_dev;       /* [B]            clamp_min(sum w_ceil, 1) as integers: read these to size the alignment */
+    void* workspace_dev; size_t workspace_bytes;
+} DexTextArgs;
+typedef struct {
+    int32_t B, T, Ty;                 /* Ty = fix_len_compatibility(max y_lengths) */
+    const float* mu_x_dev;            /* [B,n_feats,T] */
+    const float* w_ceil_dev;          /* [B,T] */
+    const int32_t* x_lengths_dev;     /* [B] */
+    const int32_t* y_lengths_dev;     /* [B] */
+    float* mu_y_out_dev;              /* [B,n_feats,Ty] = attn^T mu_x  (the decoder's mu) */
+    float* y_mask_out_dev;            /* [B,Ty] */
+    float* attn_out_dev;              /* optional [B,T,Ty] 0/1 alignment (generate_path) */
+    void* workspace_dev; size_t workspace_bytes;     /* >= B*T floats */
+} DexAlignArgs;
+
+int  dex_text_create(const DexTextConfig* cfg, DexText** out);
+void dex_text_destroy(DexText* txt);
+const char* dex_text_last_error(const DexText* txt);
+/* Keys = the reference TextEncoder state-dict names (emb.weight, prenet.*, encoder.layers.<i>.*, encoder.layer_norm.weight,
+ * encoder.retnet_rel_pos.angle, proj_m.*, proj_w.*); encoder.retnet_rel_pos.decay is not used (use_decay = 0). */
+int  dex_text_num_weights(const DexText* txt);
+int  dex_text_weight_info(const DexText* txt, int i, const char** key, int64_t shape[4], int* ndim);
+int  dex_text_load_weight_async(DexText* txt, const char* key, const float* w_dev, const int64_t* shape, int ndim, dex_stream_t stream);
+int  dex_text_finalize(DexText* txt, dex_stream_t stream);
+size_t dex_text_workspace_bytes(const DexText* txt, int B, int T);
+int  dex_text_encode(DexText* txt, const DexTextArgs* args, dex_stream_t stream);
+int  dex_text_align(DexText* txt, const DexAlignArgs* args, dex_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -124,6 +124,52 @@ def import_reference_audio(sub: str = "DEX-TTS"):
     return importlib.import_module("audio.stft"), importlib.import_module("audio.tools")
 
 
+def import_reference_text(sub: str):
+    """The reference's ``model.text_encoder`` and ``model.utils`` modules (TextEncoder + RetNet, generate_path).
+
+    Stand-ins for what the image lacks or has moved on from (requirements.txt pins transformers==4.35.2, timm unpinned):
+    * ``timm.models.layers.drop_path`` (retention.py:9,403): stochastic depth; identity in eval mode, which is all that runs;
+    * ``transformers.top_k_top_p_filtering`` (retention.py:12): imported, never called on this path; absent from transformers 5;
+    * ``PretrainedConfig`` of transformers 5 no longer stores ``use_cache`` / ``output_hidden_states``: the attributes RetNetModel.forward
+      reads (retnet.py:74-78) are set on the instance to the values transformers 4.35 would have stored (True / False / False)."""
+    sys.dont_write_bytecode = True
+    import transformers                                   # before the timm stand-in: its availability probe needs real import specs
+    from transformers.modeling_utils import PreTrainedModel  # noqa: F401
+    _install_timm_stub()
+    timm = sys.modules["timm"]
+    layers = types.ModuleType("timm.models.layers")
+
+    def drop_path(x, drop_prob: float = 0.0, training: bool = False, scale_by_keep: bool = True):
+        if drop_prob == 0.0 or not training:
+            return x
+        raise RuntimeError("drop_path stand-in: eval mode only")
+
+    layers.drop_path = drop_path
+    timm.models.layers = layers
+    sys.modules["timm.models.layers"] = layers
+    if not hasattr(transformers, "top_k_top_p_filtering"):
+        transformers.top_k_top_p_filtering = None
+    _purge(["model"])
+    root = f"{REF_ROOT}/{sub}"
+    sys.path[:] = [p for p in sys.path if not p.startswith(REF_ROOT)]
+    sys.path.insert(0, root)
+    pkg = types.ModuleType("model"); pkg.__path__ = [f"{root}/model"]
+    sys.modules["model"] = pkg
+    return importlib.import_module("model.text_encoder"), importlib.import_module("model.utils")
+
+
+def build_reference_text_encoder(sub: str, kwargs: dict, weights: dict = None):
+    te, utils = import_reference_text(sub)
+    enc = te.TextEncoder(**kwargs).eval()
+    c = enc.encoder.config
+    for k, v in dict(use_cache=True, output_retentions=False, output_hidden_states=False).items():
+        if not hasattr(c, k):
+            setattr(c, k, v)
+    if weights is not None:
+        enc.load_state_dict({k: torch.as_tensor(v) for k, v in weights.items()}, strict=True)
+    return enc, utils
+
+
 class AttrDict(dict):
     """dit_cfg must support attribute assignment (diffusion.py:151-152) and ** unpacking."""
     __getattr__ = dict.__getitem__
