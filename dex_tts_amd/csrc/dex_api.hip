@@ -930,7 +930,9 @@ struct Runner {
         if (debug) hipMemcpyAsync(P.dbg_tok, P.tok, (size_t)B * N * hid * 4, hipMemcpyDeviceToDevice, st);
         tap("tok_in", P.dbg_tok, (long)B * N, hid, hid);
         const float scale = 1.0f / sqrtf((float)(hid / c.dit_heads));
-        const bool chain = x->lp() && dit_rowchain_supported(hid, mh) && c.dit_heads == 2 && x->frag_of().count(x->blocks[0].wproj);
+        const char* chain_env = getenv("DEX_DIT_CHAIN");          // 0: one GEMM / attention launch per operation (A/B runs)
+        const bool chain = x->lp() && dit_rowchain_supported(hid, mh) && c.dit_heads == 2 && x->frag_of().count(x->blocks[0].wproj) &&
+                           !(chain_env && chain_env[0] == '0');
         for (int k = 0; k < c.dit_depth; ++k) {
             const DitBlockW& w = x->blocks[k];
             const float* ada = P.ada[k];

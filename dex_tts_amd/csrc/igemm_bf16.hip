@@ -3,6 +3,7 @@
 // Same gather semantics and the same epilogue as igemm.hip.  LDS tiles are row-major [rows][BK+8] bf16:
 // the 16-byte pad makes every ds_read_b128 / ds_write_b128 lane group hit 64 distinct banks.
 #include "kernels.h"
+#include <cstdlib>
 #include "lp_util.h"
 #include "kernels_lp.h"
 #include "igemm_epilogue.h"
@@ -269,6 +270,209 @@ __global__ __launch_bounds__(256) void igemm_lp_ss_kernel(const IGemmP p) {
     igemm_epilogue<MT>(p, acc, m0, n0, wm * (MT * 32), wn * 32, lane, b, 0, 0, M, oh0, ow0);
 }
 
+// ---- column-walking variant of the single-shot kernel (batched synthesis).  The DiT FinalLayer + unpatchify GEMM has K = 256 and
+// N = stride^2 * C = 2048: as 64 x 64 single-shot tiles the LayerNorm + modulate staging of a 64-row A tile is redone by each of
+// the 32 column-tile workgroups, and the launch spends its time there (245 us at B=32 for 22 GFLOP and a 170 MB output whose
+// HBM floor is ~40 us).  Here a workgroup stages its A rows ONCE and walks all the column tiles; the next weight tile is
+// prefetched into registers under the MFMAs and the epilogue of the current one (single LDS tile: two workgroups per CU).
+// Its epilogue is the unpatchify scatter only (bias, output mask, crop): everything that depends on the token row is computed
+// once for the whole walk.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <int K>
+__global__ __launch_bounds__(256) void igemm_lp_nwalk_kernel(const IGemmP p) {
+    constexpr int BM = 64, BN = 64;
+    constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (WM * 32);
+    constexpr int LDS_LD = K + 8, KC = K / 8;
+    constexpr int AIT = BM * KC / 256, BIT = BN * KC / 256;
+    constexpr int ABATCH = AIT > 8 ? 8 : AIT;
+    extern __shared__ __attribute__((aligned(16))) u16 smem_ss[];
+    u16* As = smem_ss;
+    u16* Bs = smem_ss + BM * LDS_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int b = blockIdx.z;
+    const int M = p.Ho * p.Wo;
+    const int m0 = blockIdx.x * BM;
+    const int ntile_all = p.N / BN;
+    const int ntile = ntile_all / (int)gridDim.y, nt_first = blockIdx.y * ntile;      // this workgroup's share of the column tiles
+    const float* Ab = p.A + (long)b * p.a_bstride + p.a_coff;
+    const float* mrow = p.inmask ? p.inmask + (long)b * p.mask_bstride : nullptr;
+    const u16* Wb = reinterpret_cast<const u16*>(p.Wbf) + (long)b * p.w_bstride + (long)nt_first * BN * K;
+    const int step = p.step ? *p.step : 0;
+    const float* lsh = p.ln_shift ? p.ln_shift + (long)step * p.ln_step_stride : nullptr;
+    const float* lsc = p.ln_scale ? p.ln_scale + (long)step * p.ln_step_stride : nullptr;
+
+    u32x4 br[BIT];                          // (native vectors + macros, not lambdas over an array: those ended up in scratch)
+#define NW_LOAD_B(nt_)                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < BIT; ++j) {                                                              \
+        const int it = tid + 256 * j;                                                                               \
+        br[j] = *reinterpret_cast<const u32x4*>(Wb + (long)((nt_) * BN + it / KC) * K + (it % KC) * 8);            \
+    }
+#define NW_STORE_B()                                                                                                \
+    _Pragma("unroll") for (int j = 0; j < BIT; ++j) {                                                              \
+        const int it = tid + 256 * j;                                                                               \
+        *reinterpret_cast<u32x4*>(Bs + (it / KC) * LDS_LD + (it % KC) * 8) = br[j];                                 \
+    }
+    NW_LOAD_B(0)
+#pragma unroll
+    for (int a0 = 0; a0 < AIT; a0 += ABATCH) {
+        float4 f0[ABATCH], f1[ABATCH];
+        float mk[ABATCH];
+#pragma unroll
+        for (int j = 0; j < ABATCH; ++j) {
+            const int it = tid + 256 * (a0 + j);
+            const int row = it / KC, k8 = (it % KC) * 8;
+            const int m = m0 + row;
+            const int mm = m < M ? m : 0;                    // (1 x 1 taps only: row m of the A matrix)
+            const float* src = Ab + (long)mm * p.lda + k8;
+            f0[j] = *reinterpret_cast<const float4*>(src);
+            f1[j] = *reinterpret_cast<const float4*>(src + 4);
+            const float mv = mrow ? mrow[(mm % p.Wi) * p.inmask_ws] : 1.f;
+            mk[j] = m < M ? mv : 0.f;
+        }
+        if (a0 == 0) { NW_STORE_B() }
+#pragma unroll
+        for (int j = 0; j < ABATCH; ++j) {
+            const int it = tid + 256 * (a0 + j);
+            const int row = it / KC, k8 = (it % KC) * 8;
+            float4 a = f0[j], c = f1[j];
+            if (lsh) {
+                float s = (a.x + a.y) + (a.z + a.w) + (c.x + c.y) + (c.z + c.w);
+#pragma unroll
+                for (int o = 1; o < KC; o <<= 1) s += __shfl_xor(s, o);
+                const float mean = s * (1.f / (float)K);
+                a.x -= mean; a.y -= mean; a.z -= mean; a.w -= mean; c.x -= mean; c.y -= mean; c.z -= mean; c.w -= mean;
+                float q = a.x * a.x + a.y * a.y + a.z * a.z + a.w * a.w + c.x * c.x + c.y * c.y + c.z * c.z + c.w * c.w;
+#pragma unroll
+                for (int o = 1; o < KC; o <<= 1) q += __shfl_xor(q, o);
+                const float rstd = rsqrtf(q * (1.f / (float)K) + 1e-6f);
+                const float4 sc0 = *reinterpret_cast<const float4*>(lsc + k8), sc1 = *reinterpret_cast<const float4*>(lsc + k8 + 4);
+                const float4 sh0 = *reinterpret_cast<const float4*>(lsh + k8), sh1 = *reinterpret_cast<const float4*>(lsh + k8 + 4);
+                a.x = a.x * rstd * (1.f + sc0.x) + sh0.x; a.y = a.y * rstd * (1.f + sc0.y) + sh0.y;
+                a.z = a.z * rstd * (1.f + sc0.z) + sh0.z; a.w = a.w * rstd * (1.f + sc0.w) + sh0.w;
+                c.x = c.x * rstd * (1.f + sc1.x) + sh1.x; c.y = c.y * rstd * (1.f + sc1.y) + sh1.y;
+                c.z = c.z * rstd * (1.f + sc1.z) + sh1.z; c.w = c.w * rstd * (1.f + sc1.w) + sh1.w;
+            }
+            const float m_ = mk[j];
+            uint4 v;
+            v.x = pack2_lp(a.x * m_, a.y * m_); v.y = pack2_lp(a.z * m_, a.w * m_);
+            v.z = pack2_lp(c.x * m_, c.y * m_); v.w = pack2_lp(c.z * m_, c.w * m_);
+            *reinterpret_cast<uint4*>(As + row * LDS_LD + k8) = v;
+        }
+    }
+    __syncthreads();
+    const u16* ap = As + (wm * (MT * 32) + i) * LDS_LD + hh * 8;
+    const u16* bp = Bs + (wn * 32 + i) * LDS_LD + hh * 8;
+    // unpatchify scatter without activation / gate / residual (the FinalLayer): everything that depends on the ROW only - token
+    // (f, w), its pixel base, validity - is computed once for the whole column walk (the shared epilogue redoes two divisions
+    // and a 64-bit address per element and column tile: the launch was bound by that integer work and by 16 dependent mask
+    // loads per tile, not by its 170 MB of output)
+    static_assert(MT == 1, "one 32-row tile per wave");
+    int u_pix[16], u_f[16], u_w[16];
+    {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            const bool v = m < M;
+            const int mm = v ? m : 0;
+            const int f = mm / p.Wo, w = mm - f * p.Wo;
+            u_f[r] = v ? f * p.unpatch_s : 0x40000000;                    // an invalid row fails the height test below
+            u_w[r] = w * p.unpatch_s;
+            u_pix[r] = f * p.unpatch_s * p.OWf + w * p.unpatch_s;
+        }
+    }
+    const float* omask = p.outmask ? p.outmask + (long)b * p.mask_bstride : nullptr;
+    float* Cb = p.C + (long)b * p.c_bstride + p.c_coff;
+    for (int nt = 0; nt < ntile; ++nt) {
+        if (nt + 1 < ntile) { NW_LOAD_B(nt + 1) }
+        float u_mk[16];
+        int u_p1 = 0, u_p2 = 0, u_c = 0;
+        {
+            const int ng0 = (nt_first + nt) * BN + wn * 32, pp = ng0 / p.unpatch_C;
+            u_c = ng0 - pp * p.unpatch_C + i;
+            u_p1 = pp / p.unpatch_s; u_p2 = pp - u_p1 * p.unpatch_s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u_mk[r] = omask ? omask[min(u_w[r] + u_p2, p.OWf - 1) * p.outmask_ws] : 1.f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < K / 16; ++ks) {
+            const lp8 bf = *reinterpret_cast<const lp8*>(bp + ks * 16);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const lp8 af = *reinterpret_cast<const lp8*>(ap + t * 32 * LDS_LD + ks * 16);
+                acc[t] = DEX_MFMA_LP(af, bf, acc[t], 0, 0, 0);
+            }
+        }
+        {
+            const float bias = p.bias ? p.bias[(long)b * p.bias_bstride + (nt_first + nt) * BN + wn * 32 + i] : 0.f;
+            float* cp = Cb + (long)(u_p1 * p.OWf + u_p2) * p.ldc + u_c;
+            // values first (the mask loads are consumed here, once), then the stores: a store under a per-lane branch that still
+            // depends on a load gets an s_waitcnt vmcnt(0) of its own, which also drains every earlier STORE - the first version
+            // of this loop completed its 16 stores one at a time (4.9 us per column tile)
+            float val[16];
+            bool all_ok = true;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                val[r] = (acc[0][r] + bias) * u_mk[r];
+                all_ok = all_ok && (u_f[r] + u_p1 < p.OHf && u_w[r] + u_p2 < p.OWf);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (__builtin_amdgcn_ballot_w64(!all_ok) == 0) {          // the common case: nothing of this tile is cropped
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cp[(long)u_pix[r] * p.ldc] = val[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const bool ok = u_f[r] + u_p1 < p.OHf && u_w[r] + u_p2 < p.OWf;
+                    if (ok) cp[(long)u_pix[r] * p.ldc] = val[r];
+                }
+            }
+        }
+        if (nt + 1 < ntile) {
+            __syncthreads();                              // every wave is done with this weight tile
+            NW_STORE_B()
+            __syncthreads();
+        }
+    }
+}
+
+static bool nwalk_eligible(const IGemmP& p) {
+    if (p.K != 256 || p.Cin != 256 || p.KH != 1 || p.KW != 1 || p.parity || p.ksplit != 1 || p.groups != 1 || (p.N % 64) != 0) return false;
+    if (p.sh != 1 || p.sw != 1 || p.off_h != 0 || p.off_w != 0 || p.Ho != p.Hi || p.Wo != p.Wi || p.gn_stats) return false;
+    // the kernel's epilogue is the unpatchify scatter and nothing else: bias, output mask, crop
+    if (p.unpatch_s <= 0 || (p.unpatch_C % 32) != 0 || p.gate || p.res || p.act != 0 || p.stats_final) return false;
+    static const int mode = getenv("DEX_GEMM_NWALK") ? atoi(getenv("DEX_GEMM_NWALK")) : 1;       // 0: never, 2: whenever the shape allows (tests)
+    if (mode == 0) return false;
+    const long wgs = (long)((p.Ho * p.Wo + 63) / 64) * p.B;
+    return p.N / 64 >= 8 && (mode == 2 || wgs >= 256);
+}
+static void launch_nwalk(const IGemmP& p, hipStream_t st) {
+    constexpr int K = 256;
+    const size_t lds = (size_t)(64 + 64) * (K + 8) * sizeof(u16);
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_lp_nwalk_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    g_last_symbol = "igemm_lp_nwalk_kernel<256>";
+    // split the walk over 1 / 2 / 4 workgroups so that the grid is at least ~2.5 rounds of the chip's 512 slots: a workgroup's tiles
+    // run back to back behind each other's store drain, more of them in flight hide it (measured at B=32: 115 -> ? us)
+    const long wgs = (long)((p.Ho * p.Wo + 63) / 64) * p.B;
+    int nsplit = 1;
+    static const int fs = getenv("DEX_NWALK_SPLIT") ? atoi(getenv("DEX_NWALK_SPLIT")) : 0;
+    while (nsplit < 4 && wgs * nsplit < 1280 && (p.N / 64) % (nsplit * 2) == 0) nsplit *= 2;
+    if (fs > 0 && (p.N / 64) % fs == 0) nsplit = fs;
+    dim3 grid((p.Ho * p.Wo + 63) / 64, nsplit, p.B);
+    hipLaunchKernelGGL((igemm_lp_nwalk_kernel<K>), grid, dim3(256), lds, st, p);
+}
+
 template <int K>
 static void launch_ss(const IGemmP& p, hipStream_t st) {
     const size_t lds = (size_t)(64 + 64) * (K + 8) * sizeof(u16);
@@ -290,6 +494,7 @@ static bool ss_eligible(const IGemmP& p) {
 
 void launch_igemm_lp(const IGemmP& p, hipStream_t st) {
     const int M = p.Ho * p.Wo;
+    if (nwalk_eligible(p)) { launch_nwalk(p, st); return; }
     if (ss_eligible(p)) {
         if (p.K == 64) launch_ss<64>(p, st);
         else if (p.K == 128) launch_ss<128>(p, st);
