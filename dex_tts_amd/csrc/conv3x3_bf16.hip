@@ -299,6 +299,14 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_lp_kernel(const Conv3P p) {
                     f0 = make_float4(lp_lo(u0), lp_hi(u0), lp_lo(u1), lp_hi(u1));
                     f1 = make_float4(lp_lo(u2), lp_hi(u2), lp_lo(u3), lp_hi(u3));
                 } else { f0 = pf0[q]; f1 = pf1[q]; }
+#ifdef DEX_SCALAR_PROLOGUE
+                if (pro) {
+                    f0.x = cv_mish(fmaf(f0.x, sc0.x, sh0.x)) + t0.x; f0.y = cv_mish(fmaf(f0.y, sc0.y, sh0.y)) + t0.y;
+                    f0.z = cv_mish(fmaf(f0.z, sc0.z, sh0.z)) + t0.z; f0.w = cv_mish(fmaf(f0.w, sc0.w, sh0.w)) + t0.w;
+                    f1.x = cv_mish(fmaf(f1.x, sc1.x, sh1.x)) + t1.x; f1.y = cv_mish(fmaf(f1.y, sc1.y, sh1.y)) + t1.y;
+                    f1.z = cv_mish(fmaf(f1.z, sc1.z, sh1.z)) + t1.z; f1.w = cv_mish(fmaf(f1.w, sc1.w, sh1.w)) + t1.w;
+                }
+#else
                 if (pro) {       // GroupNorm-apply + Mish + time bias on fp32 pairs (packed VALU, bf16_util.h)
                     const f32x2 a0 = mish2_add(f32x2{f0.x, f0.y} * f32x2{sc0.x, sc0.y} + f32x2{sh0.x, sh0.y}, f32x2{t0.x, t0.y});
                     const f32x2 a1 = mish2_add(f32x2{f0.z, f0.w} * f32x2{sc0.z, sc0.w} + f32x2{sh0.z, sh0.w}, f32x2{t0.z, t0.w});
@@ -306,6 +314,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_lp_kernel(const Conv3P p) {
                     const f32x2 a3 = mish2_add(f32x2{f1.z, f1.w} * f32x2{sc1.z, sc1.w} + f32x2{sh1.z, sh1.w}, f32x2{t1.z, t1.w});
                     f0 = make_float4(a0.x, a0.y, a1.x, a1.y); f1 = make_float4(a2.x, a2.y, a3.x, a3.y);
                 }
+#endif
                 const float mk = pmk[q];
                 const int it = tid + NTHR * (ps * NIP + q);
                 if constexpr (PRO2) {
@@ -433,6 +442,14 @@ bool conv3x3_bf16_supported(int Cin, int Cout) {
     return (Cin == 64 || Cin == 128 || Cin == 256) && (Cout == 64 || Cout == 128);
 }
 
+// plain (no GroupNorm prologue) 16-bit INPUT: only the eight-wave 64 -> 128 form with the fused shortcut is instantiated for it
+// (the first conv after a Downsample at batch size; dex_api.hip lp_inter)
+bool conv3x3_plain_lp_in_supported(int H, int W, int B, int Cin, int Cout) {
+    static const int w8 = getenv("DEX_CONV_W8") ? atoi(getenv("DEX_CONV_W8")) : 1;
+    const long tiles4 = (long)((W + 31) / 32) * ((H + 3) / 4) * B;
+    return w8 && tiles4 >= 256 && Cin == 64 && Cout == 128;
+}
+
 void launch_conv3x3_lp(const Conv3P& p, hipStream_t st) {
     if (const int tpw = conv3x3_stream_tiles(p)) { launch_conv3x3_stream(p, tpw, st); return; }   // batched synthesis
     // few tiles (half resolution at small batch): 2-row tiles and 64-channel output slices put more, lighter
@@ -449,7 +466,10 @@ void launch_conv3x3_lp(const Conv3P& p, hipStream_t st) {
         else { tail_ ? launch_c3<128, 128, 128, 4, true, false, false, 8>(p, st) : launch_c3<128, 128, 128, 4, false, false, false, 8>(p, st); }
         return;
     }
-    if (w8 && !small && p.res_w && p.Cout == 128 && p.Cin == 64) { launch_c3<64, 128, 128, 4, false, true, false, 8>(p, st); return; }
+    if (w8 && !small && p.res_w && p.Cout == 128 && p.Cin == 64) {
+        p.x_bf16 ? launch_c3<64, 128, 128, 4, false, true, true, 8>(p, st) : launch_c3<64, 128, 128, 4, false, true, false, 8>(p, st);      // (16-bit plain input: batch regime only)
+        return;
+    }
     if (w8 && !small && p.res_w && p.Cout == 64 && p.Cin >= 128) { launch_c3<128, 64, 64, 4, false, true, false, 8>(p, st); return; }
     if (p.x_bf16) {       // raw conv output stored as bf16: the GroupNorm-prologue forms with Cin == Cout (conv3x3_bf16_xb_supported)
         if (tail_) {

@@ -729,7 +729,8 @@ bool conv3x3_res2_form(int H, int W, int B) {
     return conv3x3_stream_tiles(q) != 0 && pp_plan(q, a, b2);
 }
 int conv3x3_stream_tiles(const Conv3P& p) {
-    if (p.Cin != SC || p.Cout != SC || p.res_w || p.ldx % 8 != 0 || p.x_coff % 8 != 0 || (p.x_bf16 && !p.pro_stats)) return 0;
+    if (p.Cin != SC || p.Cout != SC || p.res_w || p.ldx % 8 != 0 || p.x_coff % 8 != 0) return 0;
+    if (p.x_bf16 && !p.pro_stats) { int a, b2; if (!pp_plan(p, a, b2)) return 0; }       // plain 16-bit input: the ping-pong form only
     const char* e = getenv("DEX_CONV_STREAM");           // 0: never, 2: whenever the shape allows (tests), default: by grid size
     const int mode = e ? atoi(e) : 1;
     if (mode == 0) return 0;
@@ -774,10 +775,12 @@ void launch_conv3x3_stream(const Conv3P& p, int tiles_per_wg, hipStream_t st) {
         const bool tail_ = p.pro_res || p.res2_w;
         g_last_symbol = p.res2_w ? (p.x_bf16 ? "conv3x3_pp64_kernel<1,2,1>" : "conv3x3_pp64_kernel<1,2,0>")
                       : tail_ ? (p.x_bf16 ? "conv3x3_pp64_kernel<1,1,1>" : "conv3x3_pp64_kernel<1,1,0>")
-                      : pro_ ? (p.x_bf16 ? "conv3x3_pp64_kernel<1,0,1>" : "conv3x3_pp64_kernel<1,0,0>") : "conv3x3_pp64_kernel<0,0,0>";
+                      : pro_ ? (p.x_bf16 ? "conv3x3_pp64_kernel<1,0,1>" : "conv3x3_pp64_kernel<1,0,0>")
+                      : (p.x_bf16 ? "conv3x3_pp64_kernel<0,0,1>" : "conv3x3_pp64_kernel<0,0,0>");
         if (p.res2_w) { p.x_bf16 ? pp_go<true, 2, true>(p, seg, nsy, nwg, st) : pp_go<true, 2, false>(p, seg, nsy, nwg, st); }
         else if (tail_) { p.x_bf16 ? pp_go<true, 1, true>(p, seg, nsy, nwg, st) : pp_go<true, 1, false>(p, seg, nsy, nwg, st); }
         else if (pro_) { p.x_bf16 ? pp_go<true, 0, true>(p, seg, nsy, nwg, st) : pp_go<true, 0, false>(p, seg, nsy, nwg, st); }
+        else if (p.x_bf16) pp_go<false, 0, true>(p, seg, nsy, nwg, st);
         else pp_go<false, 0, false>(p, seg, nsy, nwg, st);
         return;
     }

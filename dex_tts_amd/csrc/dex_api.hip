@@ -23,7 +23,7 @@ static_assert(PREC_FP32 == DEX_PREC_FP32 && PREC_BF16 == DEX_PREC_BF16 && PREC_F
 namespace {
 
 struct RawW { float* p = nullptr; std::vector<int64_t> shape; long numel = 0; bool loaded = false; };
-struct TD { float* p; int ld; int coff; int C; };          // channels-last activation view
+struct TD { float* p; int ld; int coff; int C; int lp = 0; };   // channels-last activation view; lp: 16-bit elements (1 bf16, 2 fp16)
 
 struct ResW { const float *w1, *b1, *g1, *be1, *w2, *b2, *g2, *be2, *wr, *br, *mlp_w, *mlp_b; int cin, cout; };
 constexpr int ATT_KSPLIT_MAX = 4;     // key-split attention partials kept per token (dit_rowchain.hip merges them)
@@ -738,7 +738,7 @@ struct Runner {
         auto it = x->lp_of().find(Wt);
         if (fast_conv(X.C, Cout) && it != x->lp_of().end()) {
             Conv3P c{};
-            c.x_bf16 = xb ? 1 : 0; c.y_bf16 = yb ? 1 : 0;
+            c.x_bf16 = (xb || X.lp) ? 1 : 0; c.y_bf16 = yb ? 1 : 0;
             c.X = X.p; c.ldx = X.ld; c.x_coff = X.coff; c.H = H; c.W = W; c.Cin = X.C; c.Cout = Cout;
             c.Wbf = it->second; c.bias = bias; c.Y = out; c.mask = mask; c.mask_ws = mask_ws; c.mask_bstride = P.d.T;
             if (pro) { c.pro_stats = pro->stats; c.pro_gamma = pro->gamma; c.pro_beta = pro->beta; c.pro_tadd = pro->tadd; c.pro_res = pro->res; c.pro_xout = pro->xout;
@@ -754,7 +754,7 @@ struct Runner {
             const double M = (double)H * W * P.d.B;
             // algorithmic bytes: input + output at their stored width, + the residual read and the x write-out of the PRO2 form,
             // + the shortcut output of the RES form, + the weights once
-            const double bytes = M * ((xb ? 2.0 : 4.0) * X.C + (yb ? 2.0 : 4.0) * Cout + (pro && (pro->res || pro->res2) ? (pro->res2 ? 4.0 * X.C : 8.0 * X.C) : 0.0) + (shortcut ? 4.0 * Cout : 0.0))
+            const double bytes = M * (((xb || X.lp) ? 2.0 : 4.0) * X.C + (yb ? 2.0 : 4.0) * Cout + (pro && (pro->res || pro->res2) ? (pro->res2 ? 4.0 * X.C : 8.0 * X.C) : 0.0) + (shortcut ? 4.0 * Cout : 0.0))
                                  + 2.0 * 9 * X.C * Cout;
             run(name, 2.0 * M * Cout * (9 * X.C + (shortcut ? X.C : 0)), bytes, [&] { launch_conv3x3_lp(c, x->precision, st); });
             return;
@@ -861,7 +861,7 @@ struct Runner {
 
     // Residual(Rezero(LinearAttention)) (diffusion.py:74-102)
     bool linattn_fused(int C) const { return x->lp() && (C == 64 || C == 128); }
-    void linattn(const LinW& w, const StageBuf& s, const TD& X, float* out, int ldo, int ocoff, const LinKvCtxP* tail = nullptr) {
+    void linattn(const LinW& w, const StageBuf& s, const TD& X, float* out, int ldo, int ocoff, const LinKvCtxP* tail = nullptr, bool out_lp = false) {
         const long npix = s.npix; const int B = P.d.B;
         if (x->lp() && (X.C == 64 || X.C == 128)) {
             // fused: y = x + W2 (Wq x) + g*b  with  W2 = g Wout blockdiag(ctx^T)   (linattn_fused.hip)
@@ -876,8 +876,8 @@ struct Runner {
             run("linattn_kvctx", 2.0 * npix * B * (256.0 * X.C + 128 * 32), (tail ? (tail->h2_bf16 ? 10.0 : 12.0) : 4.0) * npix * X.C * B, [&] { launch_linattn_kvctx(k, x->precision, st); });
             LinMergeP mg{s.pm, s.ps, s.pc, nblk, w.wout_raw, w.g, X.C, s.mbf, B};
             run("linattn_merge", 2.0 * 128 * 32 * X.C * B, 4.0 * nblk * 4 * 1088 * B, [&] { launch_linattn_merge(mg, x->precision, st); });
-            LinOut2P o{X.p, X.ld, X.coff, npix * X.ld, (int)npix, X.C, w.wq_frag[x->lpi()], s.mbf, w.bias_eff, out, ldo, ocoff, npix * ldo, B};
-            run("linattn_out", 4.0 * npix * B * 128.0 * X.C, 8.0 * npix * X.C * B, [&] { launch_linattn_out2(o, x->precision, st); });
+            LinOut2P o{X.p, X.ld, X.coff, npix * X.ld, (int)npix, X.C, w.wq_frag[x->lpi()], s.mbf, w.bias_eff, out, ldo, ocoff, npix * ldo, B, out_lp ? 1 : 0};
+            run("linattn_out", 4.0 * npix * B * 128.0 * X.C, (out_lp ? 6.0 : 8.0) * npix * X.C * B, [&] { launch_linattn_out2(o, x->precision, st); });
             return;
         }
         IGemmP g = base_gemm(X.p, X.ld, X.coff, s.H, s.W, X.C, w.wqkv, 384, nullptr, s.qkv, 384, 0);
@@ -1096,6 +1096,14 @@ struct Runner {
         gn_idx = 0;
         if (!stats_other) hipMemsetAsync(stats_base, 0, P.stats_bytes, st);   // single call (dex_denoise_once): clear in place
         TD cur{nullptr, 0, 0, 0};
+        // Activations whose EVERY consumer rounds them to the MFMA operand type while staging (x * mask with a 0 / 1 mask) are
+        // stored in that type: bit-identical results, half the bytes.  That is the down path's attention output into the
+        // Downsample conv, the Downsample output into the next ResnetBlock's convs, the last up stage's attention output into
+        // the Upsample, and the Upsample output into the final block's conv.  Batch regime only (the kernels that read / write
+        // 16-bit tensors are the throughput forms); never with debug taps (they read fp32); DEX_LP_INTER=0 turns it off.
+        const char* li_env = getenv("DEX_LP_INTER");
+        const bool lp_inter = x->lp() && !debug && ns >= 2 && !(li_env && li_env[0] == '0') && fast_conv(c.dim, c.dim);
+        const int lpk = x->lp_kind();
         for (int i = 0; i < ns; ++i) {
             const StageBuf& s = P.down[i];
             // block 0's tail (GN-apply + Mish + res_conv shortcut) rides in block 1's first conv when that conv has the
@@ -1109,7 +1117,9 @@ struct Runner {
             const bool defer = linattn_fused(s.C);
             resblock(x->down_res[i][1], s, r0, P.tadd_down[2 * i + 1], s.r1out, false, defer ? &tail : nullptr, defer0 ? &t0 : nullptr);
             TD r1{s.r1out, s.C, 0, s.C};
-            linattn(x->down_lin[i], s, r1, s.attn_out, s.attn_ld, s.attn_coff, defer ? &tail : nullptr);
+            // the Downsample conv is this output's only reader (the reference's hiddens.append of this level is never popped)
+            const bool t1_lp = lp_inter && i < ns - 1 && linattn_fused(s.C) && linattn_out2_lp_out_supported((int)s.npix, B) && x->lp_of().count(x->down_ds_w[i]);
+            linattn(x->down_lin[i], s, r1, s.attn_out, s.attn_ld, s.attn_coff, defer ? &tail : nullptr, t1_lp);
             char nm[16]; snprintf(nm, sizeof nm, "down%d", i);
             tap(nm, s.attn_out + s.attn_coff, B * s.npix, s.C, s.attn_ld);
             if (i < ns - 1) {
@@ -1118,8 +1128,13 @@ struct Runner {
                 g.KH = 3; g.KW = 3; g.sh = 2; g.sw = 2; g.off_h = -1; g.off_w = -1; g.K = 9 * s.C;
                 g.Ho = s.H / 2; g.Wo = s.W / 2; g.OHf = g.Ho; g.OWf = g.Wo; g.c_bstride = (long)g.Ho * g.Wo * s.C;
                 g.inmask = mask; g.inmask_ws = s.mask_ws;
+                // its output feeds the next stage's first ResnetBlock (3x3 conv + fused 1x1 shortcut) and nothing else
+                const ResW& nw = x->down_res[i + 1][0];
+                const bool t2_lp = lp_inter && x->lp_of().count(x->down_ds_w[i]) && nw.wr && fast_conv(s.C, nw.cout) && conv3x3_bf16_res_supported(s.C, nw.cout) &&
+                                   x->lp_of().count(nw.wr) && x->lp_of().count(nw.w1) && conv3x3_plain_lp_in_supported(g.Ho, g.Wo, B, s.C, nw.cout);
+                g.a_lp = t1_lp ? lpk : 0; g.c_lp = t2_lp ? lpk : 0;
                 gemm("downsample", g);
-                cur = TD{s.ds_out, s.C, 0, s.C};
+                cur = TD{s.ds_out, s.C, 0, s.C, t2_lp ? lpk : 0};
             }
         }
         const StageBuf& sm = P.down[ns - 1];
@@ -1134,6 +1149,7 @@ struct Runner {
             dit(mid_in, true, sm.mask_ws, dit_dst, dit_ld, 0);
         }
         tap("dit_out", dit_dst, B * sm.npix, sm.C, dit_ld);
+        bool up_out_lp = false;
         for (int j = 0; j < ns - 1; ++j) {
             const StageBuf& s = P.up[j];
             const int i = ns - 1 - j;
@@ -1147,7 +1163,8 @@ struct Runner {
             const bool defer = linattn_fused(s.C);
             resblock(x->up_res[j][1], s, r0, P.tadd_up[2 * j + 1], s.r1out, false, defer ? &tail : nullptr, defer0 ? &t0 : nullptr);
             TD r1{s.r1out, s.C, 0, s.C};
-            linattn(x->up_lin[j], s, r1, s.attn_out, s.C, 0, defer ? &tail : nullptr);
+            const bool t5_lp = lp_inter && linattn_fused(s.C) && linattn_out2_lp_out_supported((int)s.npix, B) && x->lp_of().count(x->up_us_w[j]);
+            linattn(x->up_lin[j], s, r1, s.attn_out, s.C, 0, defer ? &tail : nullptr, t5_lp);
             char nm[16]; snprintf(nm, sizeof nm, "up%d", j);
             tap(nm, s.attn_out, B * s.npix, s.C, s.C);
             // Upsample = ConvTranspose2d(4,2,1) on x*mask: four parity sub-convolutions with 2x2 taps
@@ -1159,11 +1176,14 @@ struct Runner {
                 g.OHf = 2 * s.H; g.OWf = 2 * s.W; g.osh = 2; g.osw = 2;
                 g.c_bstride = 4L * s.H * s.W * ldd;
                 g.inmask = mask; g.inmask_ws = s.mask_ws;
+                g.a_lp = t5_lp ? lpk : 0;
+                up_out_lp = lp_inter && j == ns - 2 && x->lp_of().count(x->up_us_w[j]) && x->lp_of().count(x->fin_w) && conv3x3_res2_form(80, P.d.T, B);
+                g.c_lp = up_out_lp ? lpk : 0;
                 gemm("upsample_convT", g);
             }
         }
         tap("up_out", P.up_out, (long)B * 80 * P.d.T, c.dim, c.dim);
-        TD U{P.up_out, c.dim, 0, c.dim};
+        TD U{P.up_out, c.dim, 0, c.dim, up_out_lp ? lpk : 0};
         gnfix_t* stf = next_stats();
         const bool hfb = h_bf16() && fast_conv(c.dim, c.dim) && x->lp_of().count(x->fin_w);
         conv3x3("conv3x3", U, 80, P.d.T, 1, true, x->fin_w, x->fin_b, c.dim, P.hF, stf, nullptr, nullptr, nullptr, false, hfb);

@@ -16,7 +16,7 @@ typedef unsigned short u16;
 
 // one K tile of global loads into a register slot: raw fp32 activations (addresses clamped, validity folded into
 // the mask factor) and bf16 weights; nothing here waits on memory
-template <int BN, int BK, bool PT, int AP, int RPP, int BP>
+template <int BN, int BK, bool PT, int AP, int RPP, int BP, bool ALP = false>
 __device__ __forceinline__ void igemm_load_tile(const IGemmP& p, float4 (&fa)[AP][2], float (&fm)[AP], float (&fo)[AP], uint4& rb0, uint4& rb1, int k0, bool live, int tk8, int trow,
                                                 const int (&bh)[AP], const int (&bw)[AP], unsigned mvbits,
                                                 const float* Ab, const float* mrow, int mws, const u16* Wb, int n0) {
@@ -28,9 +28,12 @@ __device__ __forceinline__ void igemm_load_tile(const IGemmP& p, float4 (&fa)[AP
         const int hi = bh[j] + kh * p.step_h, wi = bw[j] + kw * p.step_w;
         const bool ok = ((mvbits >> j) & 1u) && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
         const int hc = ok ? hi : 0, wc = ok ? wi : 0;
-        const float* src = Ab + ((long)hc * p.Wi + wc) * p.lda + c0;
-        fa[j][0] = *reinterpret_cast<const float4*>(src);
-        fa[j][1] = *reinterpret_cast<const float4*>(src + 4);
+        const long eo = ((long)hc * p.Wi + wc) * p.lda + c0;
+        if constexpr (ALP) fa[j][0] = *reinterpret_cast<const float4*>(reinterpret_cast<const u16*>(Ab) + eo);      // 8 raw 16-bit values
+        else {
+            fa[j][0] = *reinterpret_cast<const float4*>(Ab + eo);
+            fa[j][1] = *reinterpret_cast<const float4*>(Ab + eo + 4);
+        }
         fm[j] = mrow[wc * mws];                // raw mask value (a dummy in-bounds load when there is no mask): NO op on it here
         fo[j] = (ok && live) ? 1.f : 0.f;      // validity from indices only; tiles past the K range (ring padding) give exact zeros
     }
@@ -45,7 +48,9 @@ __device__ __forceinline__ void igemm_load_tile(const IGemmP& p, float4 (&fa)[AP
 // NKT > 0: the K-tile count is a compile-time constant and the ring loop is fully unrolled — only in straight-line
 // code does the compiler keep exact vmcnt(N) waits (inside a loop it falls back to vmcnt(0) at every LDS store,
 // which serialises the ring: measured 19 -> 24.5 us on the stride-2 downsample conv before unrolling).
-template <int BM, int BN, int BK, bool PT = false, int D = 1, int NKT = 0>
+// ALP / CLP: the A / C tensors hold 16-bit elements (IGemmP::a_lp / c_lp).  Compile-time: as runtime flags the extra branches
+// cost the ring its exact vmcnt bookkeeping (the Downsample conv went from 140 to 279 us at B=32).
+template <int BM, int BN, int BK, bool PT = false, int D = 1, int NKT = 0, bool ALP = false, bool CLP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void igemm_lp_kernel(const IGemmP p) {
     constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (WM * 32);
     constexpr int TPR = BK / 8;                 // threads per tile row (8 elements each)
@@ -75,7 +80,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const int m0 = mtile * BM, n0 = blockIdx.y * BN;
     const int Kper = p.K / p.ksplit, kbeg = s * Kper, nkt = NKT ? NKT : Kper / BK;
 
-    const float* Ab = p.A + (long)b * p.a_bstride + p.a_coff + g * p.Cin;
+    // (a_lp: 16-bit elements behind the same pointer - halve the element offsets' byte scale)
+    const float* Ab = ALP ? reinterpret_cast<const float*>(reinterpret_cast<const u16*>(p.A) + (long)b * p.a_bstride + p.a_coff + g * p.Cin)
+                          : p.A + (long)b * p.a_bstride + p.a_coff + g * p.Cin;
     // both arms are kernel-argument (global) pointers: a select against a __device__ constant would degrade the
     // mask loads to FLAT, and an outstanding FLAT load forces vmcnt(0) waits everywhere
     const float* mrow = p.inmask ? p.inmask + (long)b * p.mask_bstride : p.A;
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const int nkt_pad = (nkt + D - 1) / D * D;
 #pragma unroll
     for (int d = 0; d < D; ++d)
-        igemm_load_tile<BN, BK, PT, AP, RPP, BP>(p, fa[d], fm[d], fo[d], rb0[d], rb1[d], kbeg + min(d, nkt - 1) * BK, d < nkt, tk8, trow, bh, bw, mvbits, Ab, mrow, mws, Wb, n0);
+        igemm_load_tile<BN, BK, PT, AP, RPP, BP, ALP>(p, fa[d], fm[d], fo[d], rb0[d], rb1[d], kbeg + min(d, nkt - 1) * BK, d < nkt, tk8, trow, bh, bw, mvbits, Ab, mrow, mws, Wb, n0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll(NKT ? (NKT + D - 1) / D : 1)
     for (int kt0 = 0; kt0 < nkt_pad; kt0 += D) {
@@ -125,7 +132,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
             for (int j = 0; j < AP; ++j) {
                 const float mk = has_mask ? mul_pinned(fm[d][j], fo[d][j]) : fo[d][j];
-                const float4 f0 = fa[d][j][0], f1 = fa[d][j][1];
+                float4 f0 = fa[d][j][0], f1 = fa[d][j][1];
+                if constexpr (ALP) {       // the 16-bit values widened exactly; mask 0 / 1 leaves them on the operand grid
+                    const unsigned u0 = __float_as_uint(f0.x), u1 = __float_as_uint(f0.y), u2 = __float_as_uint(f0.z), u3 = __float_as_uint(f0.w);
+                    f0 = make_float4(lp_lo(u0), lp_hi(u0), lp_lo(u1), lp_hi(u1));
+                    f1 = make_float4(lp_lo(u2), lp_hi(u2), lp_lo(u3), lp_hi(u3));
+                }
                 uint4 v;
                 v.x = pack2_mul_lp_pinned(f0.x, f0.y, mk); v.y = pack2_mul_lp_pinned(f0.z, f0.w, mk);
                 v.z = pack2_mul_lp_pinned(f1.x, f1.y, mk); v.w = pack2_mul_lp_pinned(f1.z, f1.w, mk);
@@ -134,7 +146,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             if (BN >= RPP || trow < BN) *reinterpret_cast<uint4*>(Bs + trow * LDS_LD + tk8) = rb0[d];
             if constexpr (BP > 1) *reinterpret_cast<uint4*>(Bs + (trow + RPP) * LDS_LD + tk8) = rb1[d];
             lds_barrier();
-            igemm_load_tile<BN, BK, PT, AP, RPP, BP>(p, fa[d], fm[d], fo[d], rb0[d], rb1[d], kbeg + min(kt + D, nkt - 1) * BK, kt + D < nkt, tk8, trow, bh, bw, mvbits, Ab, mrow, mws, Wb, n0);
+            igemm_load_tile<BN, BK, PT, AP, RPP, BP, ALP>(p, fa[d], fm[d], fo[d], rb0[d], rb1[d], kbeg + min(kt + D, nkt - 1) * BK, kt + D < nkt, tk8, trow, bh, bw, mvbits, Ab, mrow, mws, Wb, n0);
             __builtin_amdgcn_sched_barrier(0);     // the scheduler otherwise sinks these loads down to their first use
             const u16* ap = As + (wm * (MT * 32) + i) * LDS_LD + hh * 8;
             const u16* bp = Bs + (wn * 32 + i) * LDS_LD + hh * 8;
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             }
         }
     }
-    igemm_epilogue<MT>(p, acc, m0, n0, wm * (MT * 32), wn * 32, lane, b, g, s, M, oh0, ow0);
+    igemm_epilogue<MT, CLP>(p, acc, m0, n0, wm * (MT * 32), wn * 32, lane, b, g, s, M, oh0, ow0);
 }
 
 // ---- single-shot variant (K <= 512): the whole K extent of the A and B tiles is staged at once, so a
@@ -444,6 +456,7 @@ __global__ __launch_bounds__(256) void igemm_lp_nwalk_kernel(const IGemmP p) {
 }
 
 static bool nwalk_eligible(const IGemmP& p) {
+    if (p.a_lp || p.c_lp) return false;
     if (p.K != 256 || p.Cin != 256 || p.KH != 1 || p.KW != 1 || p.parity || p.ksplit != 1 || p.groups != 1 || (p.N % 64) != 0) return false;
     if (p.sh != 1 || p.sw != 1 || p.off_h != 0 || p.off_w != 0 || p.Ho != p.Hi || p.Wo != p.Wi || p.gn_stats) return false;
     // the kernel's epilogue is the unpatchify scatter and nothing else: bias, output mask, crop
@@ -486,11 +499,14 @@ static void launch_ss(const IGemmP& p, hipStream_t st) {
 }
 
 static bool ss_eligible(const IGemmP& p) {
+    if (p.a_lp || p.c_lp) return false;
     if (p.ksplit != 1 || p.groups != 1 || (p.N % 64) != 0) return false;
     if (p.K != 64 && p.K != 128 && p.K != 256 && p.K != 512) return false;
     const long blocks = (long)((p.Ho * p.Wo + 63) / 64) * (p.N / 64) * p.B;
     return blocks <= 4096 || p.ln_shift != nullptr;
 }
+
+bool igemm_lp_io_supported(int Cin, int K, int N, int ksplit) { return Cin % 64 == 0 && (K / (ksplit > 0 ? ksplit : 1)) % 64 == 0 && N % 64 == 0; }
 
 void launch_igemm_lp(const IGemmP& p, hipStream_t st) {
     const int M = p.Ho * p.Wo;
@@ -504,6 +520,13 @@ void launch_igemm_lp(const IGemmP& p, hipStream_t st) {
     }
     const int zdim = p.B * p.groups * p.ksplit * (p.parity ? 4 : 1);
     const bool k64 = (p.Cin % 64 == 0) && ((p.K / p.ksplit) % 64 == 0);
+    if (p.a_lp || p.c_lp) {          // 16-bit A / C tensors: the batch tile only (igemm_lp_io_supported)
+        dim3 grid((M + 127) / 128, p.N / 64, zdim);
+        if (p.a_lp && p.c_lp) hipLaunchKernelGGL((igemm_lp_kernel<128, 64, 64, false, 1, 0, true, true>), grid, dim3(256), 0, st, p);
+        else if (p.a_lp) hipLaunchKernelGGL((igemm_lp_kernel<128, 64, 64, false, 1, 0, true, false>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((igemm_lp_kernel<128, 64, 64, false, 1, 0, false, true>), grid, dim3(256), 0, st, p);
+        return;
+    }
     if (p.N % 64 == 0) {
         const long blocks128 = (long)((M + 127) / 128) * (p.N / 64) * zdim;
         if (blocks128 < 1024) {

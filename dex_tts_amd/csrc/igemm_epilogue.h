@@ -17,7 +17,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 // rows [row0, row0 + MT*32) x cols [col0, col0+32) of the block tile belong to this wave.
-template <int MT>
+template <int MT, bool CLP = false>       // CLP: C holds 16-bit elements (IGemmP::c_lp = the type)
 __device__ __forceinline__ void igemm_epilogue(const IGemmP& p, f32x16 (&acc)[MT], int m0, int n0, int row0, int col0,
                                                int lane, int b, int g, int s, int M, int oh0, int ow0) {
     const int i = lane & 31, hh = lane >> 5;
@@ -27,7 +27,9 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmP& p, f32x16 (&acc)[MT
     const float bias = p.bias ? p.bias[(long)b * p.bias_bstride + ng] : 0.f;
     const float gate = p.gate ? p.gate[(long)step * p.gate_step_stride + (long)ng * p.gate_nstride] : 1.f;
     const float* omask = p.outmask ? p.outmask + (long)b * p.mask_bstride : nullptr;
-    float* Cb = p.C + (long)b * p.c_bstride + (long)s * p.c_sstride + p.c_coff;
+    // (c_lp: the tensor holds 16-bit elements; the same element offsets on a 16-bit pointer, kept in a float* variable)
+    float* Cb = CLP ? reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(p.C) + (long)b * p.c_bstride + (long)s * p.c_sstride + p.c_coff)
+                       : p.C + (long)b * p.c_bstride + (long)s * p.c_sstride + p.c_coff;
     const float* Rb = p.res ? p.res + (long)b * p.res_bstride + p.res_coff : nullptr;
     const bool unp = p.unpatch_s > 0;
     int up_c = 0, up_p1 = 0, up_p2 = 0;
@@ -65,7 +67,9 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmP& p, f32x16 (&acc)[MT
                 if (p.act == 1) v = gelu_erf(v); else if (p.act == 2) v = fmaxf(v, 0.f);
                 v = (v * gate + rv[r]) * mk[r];
                 if (p.stats_final) { gs += v; gss = fmaf(v, v, gss); }
-                cp[((r & 3) + 8 * (r >> 2)) * cs] = v;
+                if constexpr (CLP) reinterpret_cast<unsigned short*>(Cb)[(pix0 + ((r & 3) + 8 * (r >> 2)) * p.osw) * p.ldc + col_out] =
+                                (unsigned short)(pack2_kind(v, 0.f, p.c_lp) & 0xffffu);
+                else cp[((r & 3) + 8 * (r >> 2)) * cs] = v;
             }
             continue;
         }
@@ -100,6 +104,11 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmP& p, f32x16 (&acc)[MT
 #pragma unroll
             for (int r = 0; r < 16; ++r) mk[r] = 1.f;
         }
+        // values first - every residual / mask load is consumed here -, then the stores: a store inside a per-lane branch that
+        // still depends on a load gets its own s_waitcnt vmcnt(0), which also waits for every EARLIER STORE to complete, i.e. the
+        // 16 stores of a tile went out one write latency at a time (seen in the ISA; the unpatchify GEMM took 245 us at B=32)
+        float val[16];
+        bool all_ok = true;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             float v = acc[t][r] + bias;
@@ -108,7 +117,23 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmP& p, f32x16 (&acc)[MT
             if (p.act == 1) v = gelu_erf(v); else if (p.act == 2) v = fmaxf(v, 0.f);
             v = (v * gate + rv[r]) * mk[r];
             if (p.stats_final && ok[r]) { gs += v; gss = fmaf(v, v, gss); }
-            if (ok[r]) Cb[(long)opix[r] * p.ldc + col_out] = v;
+            val[r] = v;
+            all_ok = all_ok && ok[r];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (__builtin_amdgcn_ballot_w64(!all_ok) == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if constexpr (CLP) reinterpret_cast<unsigned short*>(Cb)[(long)opix[r] * p.ldc + col_out] = (unsigned short)(pack2_kind(val[r], 0.f, p.c_lp) & 0xffffu);
+                else Cb[(long)opix[r] * p.ldc + col_out] = val[r];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (ok[r]) {
+                    if constexpr (CLP) reinterpret_cast<unsigned short*>(Cb)[(long)opix[r] * p.ldc + col_out] = (unsigned short)(pack2_kind(val[r], 0.f, p.c_lp) & 0xffffu);
+                    else Cb[(long)opix[r] * p.ldc + col_out] = val[r];
+                }
         }
     }
     if (p.gn_stats) {

@@ -60,6 +60,10 @@ struct IGemmP {
     const float* ln_shift; const float* ln_scale; long ln_step_stride;   // fused LayerNorm(eps 1e-6)+modulate on the A rows
                                                        // (single-shot bf16 kernel only; needs K == Cin == row length)
     int B;
+    // reduced-precision tensors in HBM (1 = bf16, 2 = fp16; 0 = fp32).  a_lp: A holds 16-bit elements (same lda / strides, in
+    // elements); c_lp: C is stored as 16-bit elements.  Only the looped reduced-precision kernel implements them (igemm_bf16.hip);
+    // used for activations whose every consumer rounds them to the MFMA operand type anyway (dex_api.hip, lp_inter).
+    int a_lp, c_lp;
 };
 void launch_igemm(const IGemmP& p, int precision, hipStream_t st);
 
@@ -92,6 +96,7 @@ bool conv3x3_bf16_supported(int Cin, int Cout);
 bool conv3x3_bf16_tail_supported(int C);     // pro_res form (Cin == Cout == C)
 bool conv3x3_bf16_res_supported(int Cin, int Cout);   // res_w form (fused 1x1 shortcut)
 bool conv3x3_bf16_xb_supported(int Cin, int Cout);    // x_bf16 form (bf16 input under a GroupNorm prologue)
+bool conv3x3_plain_lp_in_supported(int H, int W, int B, int Cin, int Cout);   // a plain (no prologue) conv of this shape can read a 16-bit input
 bool conv3x3_res2_form(int H, int W, int B);           // a 64 -> 64 fused-tail conv of this grid runs on the form that implements res2_*
 void launch_conv3x3_lp(const Conv3P& p, int precision, hipStream_t st);   // picks the strip-streaming form (conv3x3_stream.hip) for large grids
 
@@ -180,8 +185,10 @@ struct LinMergeP { const float* part_m; const float* part_s; const float* part_c
                    const float* Wout; const float* g; int C; void* W2; int B; };       // Wout fp32 [C][128]
 void launch_linattn_merge(const LinMergeP& p, int precision, hipStream_t st);
 struct LinOut2P { const float* X; int ldx; int x_coff; long xb; int npix; int C; const void* Wq; const void* W2;
-                  const float* bias; float* Y; int ldy; int y_coff; long yb; int B; }; // Wq bf16 in MFMA fragment order (launch_pack_lp_frag_nk)
+                  const float* bias; float* Y; int ldy; int y_coff; long yb; int B; // Wq bf16 in MFMA fragment order (launch_pack_lp_frag_nk)
+                  int y_lp; };      // 1: Y is stored in the mode's 16-bit type (throughput form only: linattn_out2_lp_out_supported)
 void launch_linattn_out2(const LinOut2P& p, int precision, hipStream_t st);
+bool linattn_out2_lp_out_supported(int npix, int B);
 
 // Depthwise patch-embed conv + SiLU (dit.py:57-58), channels-last, zero padding incl. right pad to patch multiple.
 struct DwConvP { const float* X; int ldx; long xb; int Hi, Wi, C; int k, s, pad; const float* Wd; const float* bd;

@@ -566,9 +566,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, C == 64 
     for (int k = 0; k < NCH; ++k) {
         const int c = lane + 64 * k, px = c / (C / 4), ch = (c % (C / 4)) * 4;
         const float4 o = *reinterpret_cast<const float4*>(xs + px * LDX + ch);
-        if (px0 + px < p.npix) *reinterpret_cast<float4*>(Y + (long)(px0 + px) * p.ldy + ch) = o;
+        if (px0 + px < p.npix) {
+            if (p.y_lp) {     // every consumer of this tensor rounds it to the operand type: store it that way (half the bytes)
+                u16* yh = reinterpret_cast<u16*>(p.Y) + (long)b * p.yb + p.y_coff + (long)(px0 + px) * p.ldy + ch;
+                *reinterpret_cast<uint2*>(yh) = make_uint2(pack2_lp(o.x, o.y), pack2_lp(o.z, o.w));
+            } else *reinterpret_cast<float4*>(Y + (long)(px0 + px) * p.ldy + ch) = o;
+        }
     }
 }
+bool linattn_out2_lp_out_supported(int npix, int B) { return (long)((npix + 127) / 128) * B >= 2048; }       // == the throughput form below
 void launch_linattn_out2(const LinOut2P& p, hipStream_t st) {
     dim3 grid((p.npix + 127) / 128, p.B);
     const size_t lds = (size_t)4 * 32 * (p.C + 4) * sizeof(float);

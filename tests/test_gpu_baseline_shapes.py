@@ -183,3 +183,33 @@ def test_bitwise_repeatability(name, kw, n, prec):
         assert np.array_equal(a, g), float(np.abs(a - g).max())            # graph replay == eager, bitwise
     finally:
         eng.set_precision("fp32")
+
+
+# ---- 16-bit storage of activations that only feed reduced-precision convolutions changes no bit ------------------
+@pytest.mark.parametrize("name,kw", [
+    ("gedex_lj", dict(B=32, T=512, lengths=[512 - 9 * i for i in range(32)])),
+    ("dex_vctk", dict(B=32, T=256, lengths=[256 - 5 * i for i in range(32)], Tr=60, Ts=60)),
+])
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_lp_intermediates_bit_identical(name, kw, prec):
+    """dex_api.hip `lp_inter`: at batch size the down path's attention output, the Downsample output, the last up stage's
+    attention output and the Upsample output are stored in the mode's 16-bit type, because each of them is read only by
+    convolutions that round x * mask to that type anyway.  Rounding at the producer instead of the consumer must give the
+    same bits (DEX_LP_INTER=0 keeps the tensors fp32)."""
+    cfg, eng, w = U.engine_for(name)
+    case = U.make_case(cfg, **kw)
+    mu, mask, z = (torch.from_numpy(case[k]).cuda() for k in ("mu", "mask", "z"))
+    set_prec(eng, prec)
+    old = os.environ.get("DEX_LP_INTER")
+    try:
+        os.environ["DEX_LP_INTER"] = "0"
+        a = eng.sample(z, mask, mu, 3, **U.engine_kwargs(case)).cpu().numpy()
+        os.environ.pop("DEX_LP_INTER")
+        b = eng.sample(z, mask, mu, 3, **U.engine_kwargs(case)).cpu().numpy()
+        assert np.isfinite(a).all() and np.array_equal(a, b), float(np.abs(a - b).max())
+    finally:
+        eng.set_precision("fp32")
+        if old is not None:
+            os.environ["DEX_LP_INTER"] = old
+        else:
+            os.environ.pop("DEX_LP_INTER", None)
