@@ -3,6 +3,7 @@
 // the fused final_block tail + final_conv + EDM combine + Euler update, conditioning tables.
 #include "kernels.h"
 #include "bf16_util.h"
+#include <cstdlib>
 
 namespace dex {
 
@@ -46,18 +47,30 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const FirstConvP p) {
     for (int k = tid; k < PLANES * 9 * C; k += 256) w3s[k] = p.W3[k];
     for (int k = tid; k < PLANES * C; k += 256) w1s[k] = p.W1[k];
     if (tid < 16) red[tid] = 0;
-    const long npix = (long)p.B * p.H * p.T;
-    const long pix_raw = (long)blockIdx.x * PPB + tid / TPP;
-    const bool live = pix_raw < npix;
-    const long pix = live ? pix_raw : npix - 1;
+    // grid (blocks per utterance, B): a block walks the PPB-pixel groups bx, bx + gridDim.x, ... of ONE utterance, so the weight
+    // fill above and the statistics reduction below are paid once per block, not once per 64 pixels (at B=32: 20480 short blocks,
+    // 158 us; the GroupNorm partials stay in registers across the walk)
+    const int b = blockIdx.y;
+    const long npu = (long)p.H * p.T;                          // pixels per utterance
     const int cq = tid % TPP;                                 // channels [cq*16, cq*16+16)
-    const int w = (int)(pix % p.T);
-    const int h = (int)((pix / p.T) % p.H);
-    const int b = (int)(pix / ((long)p.T * p.H));
     const int step = p.step ? *p.step : 0;
     const float c_in = p.scal[step * p.scal_stride + 2];
     const float* mrow = p.mask + (long)b * p.T;
     const float* pl[2] = {p.mu + (long)b * p.H * p.T, p.x + (long)b * p.H * p.T};
+    constexpr int GPT = 16 / CPG;             // GroupNorm groups per thread: 2 (C = 64) or 1 (C = 128)
+    float gs[GPT], gq[GPT];
+#pragma unroll
+    for (int g = 0; g < GPT; ++g) { gs[g] = 0.f; gq[g] = 0.f; }
+    __syncthreads();
+    const long ngrp = (npu + PPB - 1) / PPB;
+    for (long grp = blockIdx.x; grp < ngrp; grp += gridDim.x) {
+    asm volatile("" ::: "memory");      // the weights stay in LDS: without this the 300+ loop-invariant LDS reads are hoisted into registers (256 VGPRs, one wave per SIMD)
+    const long pl_raw = grp * PPB + tid / TPP;
+    const bool live = pl_raw < npu;
+    const long pixl = live ? pl_raw : npu - 1;
+    const long pix = (long)b * npu + pixl;
+    const int w = (int)(pixl % p.T);
+    const int h = (int)(pixl / p.T);
     float v[PLANES][9];
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
@@ -83,7 +96,6 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const FirstConvP p) {
         a3[j] = *reinterpret_cast<const float4*>(p.b3 + cq * 16 + j * 4);
         a1[j] = *reinterpret_cast<const float4*>(p.b1 + cq * 16 + j * 4);
     }
-    __syncthreads();
 #pragma unroll
     for (int q = 0; q < PLANES; ++q) {
 #pragma unroll
@@ -119,10 +131,6 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const FirstConvP p) {
         }
     }
     if (p.gn_stats) {          // GroupNorm partials of h1: CPG channels per group -> this thread feeds 16 / CPG groups
-        constexpr int GPT = 16 / CPG;             // groups per thread: 2 (C = 64) or 1 (C = 128)
-        float gs[GPT], gq[GPT];
-#pragma unroll
-        for (int g = 0; g < GPT; ++g) { gs[g] = 0.f; gq[g] = 0.f; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int g = (j * 4) / CPG;
@@ -132,6 +140,9 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const FirstConvP p) {
                 gq[g] += (u.x * u.x + u.y * u.y) + (u.z * u.z + u.w * u.w);
             }
         }
+    }
+    }   // group walk
+    if (p.gn_stats) {
         // lanes of a wave with the same cq (stride TPP) hold the same groups: xor-reduce over the pixel index bits
 #pragma unroll
         for (int o = TPP; o < 64; o <<= 1) {
@@ -144,22 +155,185 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const FirstConvP p) {
             for (int g = 0; g < GPT; ++g) { gn_add(&red[(GPT * cq + g) * 2], gn_fix(gs[g], inv_n)); gn_add(&red[(GPT * cq + g) * 2 + 1], gn_fix(gq[g], inv_n)); }
         }
         __syncthreads();
-        // a PPB-pixel block never straddles two utterances when H*T is a multiple of PPB (T % 4 == 0, H = 80)
         if (tid < 16)
             gn_add(p.gn_stats + (((long)b * 8 + (tid >> 1)) * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * 2 + (tid & 1), red[tid]);
     }
 }
+// ---- matrix-core form.  The VALU kernel above spends 320 FMAs and 80 LDS weight reads per pixel quarter (150 us at B=32 for
+// 168 MB of output).  The same arithmetic is a GEMM with K = planes x 9 taps: per 32 pixels x 32 channels one
+// v_mfma_f32_32x32x2_f32 per tap (exact fp32 products, fp32 accumulation; the two planes ARE the K pair: lanes 0-31 feed mu,
+// lanes 32-63 c_in * x of their pixel at that tap), the 1x1 shortcut one more on the centre tap.  A wave owns 32 consecutive
+// pixels of an utterance x all C channels; the 18-27 weight registers per channel tile are loaded once per wave.
+// Accumulator layout: col = lane & 31 (channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (pixel).
+typedef float f32x16_fc __attribute__((ext_vector_type(16)));
+template <int PLANES, int C>
+__global__ __launch_bounds__(256) void first_conv_mfma_kernel(const FirstConvP p) {
+    constexpr int NT = C / 32, CPG = C / 8, KS = PLANES == 3 ? 2 : 1;       // a third plane (speaker) rides a second K pair with a zero partner
+    __shared__ long long red[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.y;
+    const long npu = (long)p.H * p.T;
+    const int step = p.step ? *p.step : 0;
+    const float c_in = p.scal[step * p.scal_stride + 2];
+    const float* mrow = p.mask + (long)b * p.T;
+    const float* plane = (hh == 0 ? p.mu : p.x) + (long)b * npu;           // this lane's K index = its plane
+    const float psc = hh == 0 ? 1.f : c_in;
+    if (tid < 16) red[tid] = 0;
+    // B operands: lane (channel i of tile nt, K index hh) holds W[(plane*9 + tap)][nt*32 + i]
+    float w3[KS][9][NT], w1[KS][NT], b3[NT], b1[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        b3[nt] = p.b3[nt * 32 + i]; b1[nt] = p.b1[nt * 32 + i];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int pln = ks * 2 + hh;                                   // 0, 1 | 2, (3 = none)
+            const bool has = pln < PLANES;
+            w1[ks][nt] = has ? p.W1[pln * C + nt * 32 + i] : 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) w3[ks][t][nt] = has ? p.W3[(pln * 9 + t) * C + nt * 32 + i] : 0.f;
+        }
+    }
+    float gs[NT], gq[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { gs[nt] = 0.f; gq[nt] = 0.f; }
+    __syncthreads();
+    const long nseg = (npu + 31) / 32;
+    // A operands: this lane's pixel at the nine taps, times the column mask (zero outside the image)
+    auto gather = [&](long seg, float (&a)[KS][9]) __attribute__((always_inline)) {
+        const long pl_raw = seg * 32 + i;
+        const long pixl = pl_raw < npu ? pl_raw : npu - 1;
+        const int w = (int)(pixl % p.T), h = (int)(pixl / p.T);
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hi = h + kh - 1;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int wi = w + kw - 1;
+                const bool inb = (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.T;
+                const int hc = inb ? hi : h, wc = inb ? wi : w;
+                const float mk = inb ? mrow[wc] : 0.f;
+                const float t0 = plane[(long)hc * p.T + wc] * psc;
+                a[0][kh * 3 + kw] = t0 * mk;
+                if constexpr (PLANES == 3) a[1][kh * 3 + kw] = hh == 0 ? p.spk[(long)b * p.H + hc] * mk : 0.f;
+            }
+        }
+    };
+    const long sstride = (long)gridDim.x * 4;
+    float a[KS][9], an[KS][9];
+    long seg = (long)blockIdx.x * 4 + wave;
+    if (seg < nseg) gather(seg, a);
+    for (; seg < nseg; seg += sstride) {
+        if (seg + sstride < nseg) gather(seg + sstride, an);            // the next segment's operands fly under this one's MFMAs and stores
+        f32x16_fc acc[NT], accr[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[nt][r] = 0.f; accr[nt][r] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks][t], w3[ks][t][nt], acc[nt], 0, 0, 0);
+        if (p.res) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) accr[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[ks][4], w1[ks][nt], accr[nt], 0, 0, 0);
+        }
+        // epilogue: + bias, statistics, stores.  Lane = one channel of 16 pixel rows; for 16-bit h1 neighbouring lanes swap half of
+        // their rows so that each stores channel PAIRS (dword stores), as in the convolution epilogues.
+        const long p0 = seg * 32 + 4 * hh;                      // pixel of accumulator row 0 of this lane
+        const bool full = seg * 32 + 32 <= npu;
+        const bool odd = (lane & 1) != 0;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int n = nt * 32 + i;
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                v[r] = acc[nt][r] + b3[nt];
+                const bool ok = full || p0 + (r & 3) + 8 * (r >> 2) < npu;
+                const float vs = ok ? v[r] : 0.f;
+                gs[nt] += vs; gq[nt] = fmaf(vs, vs, gq[nt]);
+            }
+            if (p.h1_bf16 && full) {
+                unsigned short* hp = reinterpret_cast<unsigned short*>(p.h1) + ((long)b * npu + p0) * C + n + (odd ? 16 * C - 1 : 0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float lo_r = v[j], hi_r = v[8 + j];
+                    const float recv = lane_xor1(odd ? lo_r : hi_r);
+                    const float mine = odd ? hi_r : lo_r;
+                    const unsigned pk = odd ? pack2_kind(recv, mine, p.h1_bf16) : pack2_kind(mine, recv, p.h1_bf16);
+                    *reinterpret_cast<unsigned*>(hp + ((j & 3) + 8 * (j >> 2)) * C) = pk;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long pr = p0 + (r & 3) + 8 * (r >> 2);
+                    if (pr < npu) {
+                        if (p.h1_bf16) reinterpret_cast<unsigned short*>(p.h1)[((long)b * npu + pr) * C + n] = (unsigned short)(pack2_kind(v[r], 0.f, p.h1_bf16) & 0xffffu);
+                        else p.h1[((long)b * npu + pr) * C + n] = v[r];
+                    }
+                }
+            }
+            if (p.res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long pr = p0 + (r & 3) + 8 * (r >> 2);
+                    if (pr < npu) p.res[((long)b * npu + pr) * C + n] = accr[nt][r] + b1[nt];
+                }
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) a[ks][t] = an[ks][t];
+    }
+    if (p.gn_stats) {
+        const double inv_n = 1.0 / ((double)p.H * p.T * CPG);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float a_ = gs[nt], q_ = gq[nt];
+            for (int o = 1; o < CPG; o <<= 1) { a_ += __shfl_xor(a_, o); q_ += __shfl_xor(q_, o); }
+            a_ += __shfl_xor(a_, 32); q_ += __shfl_xor(q_, 32);
+            if (hh == 0 && (i & (CPG - 1)) == 0) {        // a wave's sums come out of a fixed order; the integer adds commute
+                const int g = (nt * 32 + i) / CPG;
+                gn_add(&red[g * 2], gn_fix(a_, inv_n)); gn_add(&red[g * 2 + 1], gn_fix(q_, inv_n));
+            }
+        }
+        __syncthreads();
+        if (tid < 16) gn_add(p.gn_stats + (((long)b * 8 + (tid >> 1)) * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * 2 + (tid & 1), red[tid]);
+    }
+}
+
 void launch_first_conv(const FirstConvP& p, hipStream_t st) {
-    const long npix = (long)p.B * p.H * p.T;
-    if (p.C == 128) {
-        const unsigned blocks = (unsigned)((npix + 31) / 32);
-        if (p.planes == 3) hipLaunchKernelGGL((first_conv_kernel<3, 128>), dim3(blocks), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((first_conv_kernel<2, 128>), dim3(blocks), dim3(256), 0, st, p);
+    const long npu = (long)p.H * p.T;
+    const int ppb = p.C == 128 ? 32 : 64;
+    long blocks = (npu + ppb - 1) / ppb;                          // one group per block at small batch ...
+    static const long capt = getenv("DEX_FIRST_CAP") ? atol(getenv("DEX_FIRST_CAP")) : 4096;
+    const long cap = capt / p.B > 32 ? capt / p.B : 32;           // ... about two rounds of resident blocks at large batch
+    if (blocks > cap) blocks = cap;
+    static const int mfma = getenv("DEX_FIRST_MFMA") ? atoi(getenv("DEX_FIRST_MFMA")) : 1;       // 0: the VALU form
+    if (mfma) {
+        long nb = (npu + 127) / 128;                               // 4 waves x 32 pixels per block pass
+        static const long capm = getenv("DEX_FIRST_CAP") ? atol(getenv("DEX_FIRST_CAP")) : 1024;   // measured at B=32: 8192 blocks 122 us, 4096 112, 2048 103, 1024 99
+        const long cm = capm / p.B > 16 ? capm / p.B : 16;
+        if (nb > cm) nb = cm;
+        const dim3 g2((unsigned)nb, p.B);
+        if (p.C == 128) { if (p.planes == 3) hipLaunchKernelGGL((first_conv_mfma_kernel<3, 128>), g2, dim3(256), 0, st, p); else hipLaunchKernelGGL((first_conv_mfma_kernel<2, 128>), g2, dim3(256), 0, st, p); }
+        else { if (p.planes == 3) hipLaunchKernelGGL((first_conv_mfma_kernel<3, 64>), g2, dim3(256), 0, st, p); else hipLaunchKernelGGL((first_conv_mfma_kernel<2, 64>), g2, dim3(256), 0, st, p); }
         return;
     }
-    const unsigned blocks = (unsigned)((npix + 63) / 64);
-    if (p.planes == 3) hipLaunchKernelGGL((first_conv_kernel<3, 64>), dim3(blocks), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((first_conv_kernel<2, 64>), dim3(blocks), dim3(256), 0, st, p);
+    const dim3 grid((unsigned)blocks, p.B);
+    if (p.C == 128) {
+        if (p.planes == 3) hipLaunchKernelGGL((first_conv_kernel<3, 128>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((first_conv_kernel<2, 128>), grid, dim3(256), 0, st, p);
+        return;
+    }
+    if (p.planes == 3) hipLaunchKernelGGL((first_conv_kernel<3, 64>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((first_conv_kernel<2, 64>), grid, dim3(256), 0, st, p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -402,7 +576,11 @@ void launch_final(const FinalP& p, hipStream_t st) {
     // every block pays the GroupNorm-coefficient prologue (fp64 divide + sqrt behind a barrier, ~2 us): at large batch
     // keep the total near 16K blocks so each one streams several 16-pixel groups instead of one
     long blocks = (p.npix + 32 * FIN_U - 1) / (32 * FIN_U);      // one pass of FIN_U 32-pixel groups per block ...
-    const long cap = 8192 / p.B > 64 ? 8192 / p.B : 64;            // ... a few passes at large batch
+    // ... several passes at large batch: every block pays the GroupNorm-coefficient prologue (fp64 divide + sqrt behind a barrier,
+    // 72 coefficient loads), so about one round of resident blocks is best (measured at B=32: 16384 blocks 87 us, 8192 85, 4096 74,
+    // 2048 68)
+    static const long capt = getenv("DEX_FINAL_CAP") ? atol(getenv("DEX_FINAL_CAP")) : 2048;
+    const long cap = capt / p.B > 32 ? capt / p.B : 32;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(final_kernel, dim3((unsigned)blocks, p.B), dim3(256), 0, st, p);
 }
