@@ -278,6 +278,37 @@ def vocoder_block(device, stream, B=1, T=512, steps=10, warmup=3):
             "mfma_TFLOP/s": round(B * fl / sec / 1e12, 1), "frac_of_fp32_mfma_peak": round(B * fl / sec / 1e12 / PEAK_TFLOPS["f32"], 3)}
 
 
+def frontend_block(device, stream, steps=10, warmup=3):
+    """the stages in front of the sampler, once per utterance: DEX style encoders (348 reference frames) and the
+    text encoder + durations + alignment (100 tokens), exact-fp32 MFMA, synthetic weights of the shipped geometries."""
+    from dex_tts_amd import style as S, text as TX
+    out = {}
+    st = S.StyleEncoders()
+    st.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_style_weights(st.shapes).items()})
+    st = st.to(device).eval()
+    mel, lf0, L = synth.make_style_inputs(1, 348, [348])
+    mel, lf0, L = torch.from_numpy(mel).to(device), torch.from_numpy(lf0).to(device), torch.from_numpy(L).to(device)
+    with torch.cuda.stream(stream):
+        dt, ev, _ = timed_calls(lambda: st(mel, L, mel, L, lf0, L)[1], steps, warmup, device)
+    out["style_encoders"] = {"workload": "TIV + TV + LF0 encoders + conv_sty, B=1, 348 frames", "ms_per_call": round(dt / steps * 1e3, 3),
+                             "hip_event_median_ms": round(statistics.median(ev), 3)}
+    kw = dict(n_vocab=149, n_feats=80, n_channels=192, filter_channels=1024, filter_channels_dp=256, n_heads=2, n_layers=8, kernel_size=3)
+    te = TX.TextEncoder(**kw)
+    te.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_text_weights(te.shapes).items()})
+    te = te.to(device).eval()
+    tok, tl = synth.make_text_inputs(1, 100, [100])
+    tok, tl = torch.from_numpy(tok).to(device), torch.from_numpy(tl).to(device)
+
+    def run():
+        te(tok, tl)
+        return te.align(return_attn=False)[0]
+    with torch.cuda.stream(stream):
+        dt, ev, mu_y = timed_calls(run, steps, warmup, device)
+    out["text_encoder"] = {"workload": f"TextEncoder (8 RetNet layers, width 192) + durations + alignment, B=1, 100 tokens -> {mu_y.shape[-1]} frames",
+                           "ms_per_call": round(dt / steps * 1e3, 3), "hip_event_median_ms": round(statistics.median(ev), 3)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -429,6 +460,7 @@ def main():
             }
         if prof and args.workload == "gedex_b1" and not args.no_configs:
             res["vocoder"] = vocoder_block(device, stream)
+            res["frontend"] = frontend_block(device, stream)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, weights, B, T, n_steps, TrTs)
             res["gpu_over_cpu"] = round(frames_s / res["cpu_baseline"]["value"], 1)

@@ -54,7 +54,8 @@ __device__ __forceinline__ CvGnLoads cv_gn_issue(const Conv3P& p, int b, int tid
     }
     return l;
 }
-__device__ __forceinline__ void cv_gn_finish(const Conv3P& p, const CvGnLoads& l, int tid, float (*coef)[256]) {
+template <int CN>
+__device__ __forceinline__ void cv_gn_finish(const Conv3P& p, const CvGnLoads& l, int tid, float (*coef)[CN]) {
     if (tid >= 8 * GN_SLOTS) return;                  // 512-thread workgroups: whole waves 4..7 sit this out
     const int g = tid / GN_SLOTS, k = tid % GN_SLOTS, cpg = p.Cin / 8;
     // first touch of the loaded partials through a pinned instruction: as a plain conversion it is hoisted to right behind
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_lp_kernel(const Conv3P p) {
     constexpr int NI = (ITEMS + NTHR - 1) / NTHR;        // per thread
     constexpr int WPT = NSL * CC / 8 / NTHR;             // weight items (16 B) per thread per tap
     constexpr int RING = CC == 128 ? (PRO2 ? 1 : 2) : 3;  // taps of weights in flight ahead of the MFMAs
-    constexpr int NPASS = CC == 128 ? (PRO2 ? 5 : 2) : (PRO2 ? 3 : 1);   // patch staging passes: 128-channel chunks (or two source tensors) would need >256 registers in one
+    constexpr int NPASS = CC == 128 ? (TH == 8 ? (PRO2 ? 8 : 4) : (PRO2 ? 5 : 2)) : (PRO2 ? 3 : 1);   // patch staging passes: 128-channel chunks (or two source tensors) would need >256 registers in one
     constexpr int NIP = (NI + NPASS - 1) / NPASS;        // (1 workgroup per CU instead of 2: measured 16 -> 22 us at 40x256)
     static_assert(NT >= 1 && WPT >= 1, "tile");
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
@@ -178,7 +179,8 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_lp_kernel(const Conv3P p) {
     u16* wbuf = smem + PH * PW * LDP;                 // [2][NSL][LDP]
     u16* rbuf = wbuf + 2 * NSL * LDP;                 // [NSL][LDP]  1x1 shortcut weights of this chunk (RES)
     __shared__ long long gnred[16];
-    __shared__ __attribute__((aligned(16))) float coef[3][256];
+    constexpr int COEF_N = (TH == 8) ? 128 : 256;        // the 8-row form fills the LDS to the last KB: its table covers Cin = 128 only
+    __shared__ __attribute__((aligned(16))) float coef[3][COEF_N];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
@@ -279,7 +281,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_lp_kernel(const Conv3P p) {
 #pragma unroll
                     for (int j = 0; j < WPT; ++j) wr[s][j] = *reinterpret_cast<const u32x4*>(Wg + wofs[j] + (long)(s + 1) * p.Cin + cbase);
                 CSTAMP(0);
-                if (pro && ch == 0) cv_gn_finish(p, gnl, tid, coef);
+                if (pro && ch == 0) cv_gn_finish<COEF_N>(p, gnl, tid, coef);
                 __builtin_amdgcn_sched_barrier(0);
                 lds_barrier();                            // GN coefficients visible; previous chunk's MFMAs done with patch/wbuf
                 CSTAMP(1);
@@ -461,6 +463,15 @@ void launch_conv3x3_lp(const Conv3P& p, hipStream_t st) {
     // of the output channels) that workgroup keeps two waves per SIMD busy instead of one: +8.6 % end to end at B=32
     // (DEX_CONV_W8=0 restores the four-wave form)
     static const int w8 = getenv("DEX_CONV_W8") ? atoi(getenv("DEX_CONV_W8")) : 1;
+    // 8-row tiles for the 128 -> 128 convs at batch size: each wave owns one row x all 128 output channels, the per-tap weight
+    // slices are staged once per 256 pixels instead of once per 128 and there is one barrier per 32 MFMAs of a wave instead of
+    // per 16 (the patch + two weight taps fill the LDS to within 64 bytes).  DEX_CONV_TH8=0 keeps the 4-row form.
+    static const int th8 = getenv("DEX_CONV_TH8") ? atoi(getenv("DEX_CONV_TH8")) : 1;
+    // (measured at B=32: 156 -> 139 us; the fused-tail form needs eight staging passes at this size and loses, 207 -> 243: 4-row tiles)
+    if (th8 && w8 && !small && !tail_ && p.Cin == 128 && p.Cout == 128 && !p.res_w && p.H % 8 == 0 && (long)((p.W + 31) / 32) * (p.H / 8) * p.B >= 512) {
+        p.x_bf16 ? launch_c3<128, 128, 128, 8, false, false, true, 8>(p, st) : launch_c3<128, 128, 128, 8, false, false, false, 8>(p, st);
+        return;
+    }
     if (w8 && !small && p.Cin == 128 && p.Cout == 128 && !p.res_w) {
         if (p.x_bf16) { tail_ ? launch_c3<128, 128, 128, 4, true, false, true, 8>(p, st) : launch_c3<128, 128, 128, 4, false, false, true, 8>(p, st); }
         else { tail_ ? launch_c3<128, 128, 128, 4, true, false, false, 8>(p, st) : launch_c3<128, 128, 128, 4, false, false, false, 8>(p, st); }
@@ -468,6 +479,10 @@ void launch_conv3x3_lp(const Conv3P& p, hipStream_t st) {
     }
     if (w8 && !small && p.res_w && p.Cout == 128 && p.Cin == 64) {
         p.x_bf16 ? launch_c3<64, 128, 128, 4, false, true, true, 8>(p, st) : launch_c3<64, 128, 128, 4, false, true, false, 8>(p, st);      // (16-bit plain input: batch regime only)
+        return;
+    }
+    if (th8 && w8 && !small && p.res_w && p.Cout == 64 && p.Cin >= 128 && !p.pro_stats && p.H % 8 == 0 && (long)((p.W + 31) / 32) * (p.H / 8) * p.B >= 512) {
+        launch_c3<128, 64, 64, 8, false, true, false, 8>(p, st);      // 8-row tiles: a wave owns one row x 64 channels (32 at four rows)
         return;
     }
     if (w8 && !small && p.res_w && p.Cout == 64 && p.Cin >= 128) { launch_c3<128, 64, 64, 4, false, true, false, 8>(p, st); return; }
