@@ -15,6 +15,7 @@
 // Accumulator layout (32x32x16 bf16): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
 #include <hip/hip_runtime.h>
 #include "kernels.h"
+#include <cstdlib>
 #include "lp_util.h"
 #include "kernels_lp.h"
 
@@ -517,6 +518,194 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
 #endif
 }
 
+// ---- 64-row form (batch regime, attention as its own launch).  At batch size every workgroup of the kernel above streams the
+// block's 1.57 MB of weights for 32 token rows and the launch is bound by that L2 -> CU traffic (DEX B=32, N=1300: 1300 workgroups,
+// 97 us for 65 GFLOP).  Here a workgroup owns 64 rows: every weight tile a wave fetches feeds TWO 32-row MFMA tiles, so the weight
+// traffic per row halves.  The 64 x 512 GELU tile would not fit next to the fp32 residual rows, so the MLP runs in two halves of
+// 256 hidden columns: fc1 half -> LDS -> fc2 partial (K half) accumulated in registers.  LDS 135 KB, one workgroup per CU as before.
+constexpr size_t RC64_LDS = (size_t)64 * (A_LD + A_LD) * sizeof(u16) + (size_t)64 * X_LD * sizeof(float) + 4 * RC_H * sizeof(float);
+
+__global__ __launch_bounds__(RC_NW * 64) void dit_rowchain64_kernel(const DitChainP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_rc[];
+    u16* As = reinterpret_cast<u16*>(smem_rc);                 // [64][A_LD]
+    u16* Hs = As + 64 * A_LD;                                  // [64][A_LD]  one 256-column half of GELU(fc1)
+    float* X1 = reinterpret_cast<float*>(Hs + 64 * A_LD);      // [64][X_LD]
+    float* LNp = X1 + 64 * X_LD;                               // [4][256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int N = p.rows_per_batch, tpb = (N + 63) / 64;
+    const int b = blockIdx.x / tpb, n0 = (blockIdx.x - b * tpb) * 64;
+    const long mb = (long)b * N;
+    const int step = p.step ? *p.step : 0;
+    const float* ada = p.ada + (long)step * 6 * RC_H;
+    const bool has_q = p.next_shift != nullptr;
+    {
+        const int which = tid >> 7, c2 = (tid & 127) * 2;
+        const float* src = which == 0 ? ada + 3 * RC_H : which == 1 ? ada + 4 * RC_H
+                         : which == 2 ? (has_q ? p.next_shift + (long)step * p.next_step_stride : ada)
+                                      : (has_q ? p.next_scale + (long)step * p.next_step_stride : ada);
+        *reinterpret_cast<float2*>(LNp + which * RC_H + c2) = *reinterpret_cast<const float2*>(src + c2);
+    }
+    uint4 wa[16], wb[16];
+    const int col = wave * 32 + i;
+    const u16* a_lane = As + i * A_LD + hh * 8;
+    const u16* h_lane = Hs + i * A_LD + hh * 8;
+    f32x16 acc;
+    if (p.qkv_only) {
+        wload(wb, p.Wq, 16, wave, 0, lane);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int row = (tid >> 4) + 32 * m, seg = tid & 15;
+            const float* src = p.X + (mb + min(n0 + row, N - 1)) * RC_H + seg * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(X1 + row * X_LD + q * 64 + seg * 4) = *reinterpret_cast<const float4*>(src + q * 64);
+        }
+    } else {
+        // the attention output rows (merged from the key-split partials when there are several) -> bf16 A tile
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int row = (tid >> 4) + 32 * m, seg = tid & 15;
+            const int n = min(n0 + row, N - 1);
+            const float* src = p.O + (mb + n) * RC_H + seg * 4;
+            float4 v[4];
+            if (p.ksplit <= 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(src + q * 64);
+            } else {
+                float4 pv[4][4];
+                float2 st[4][2];
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    if (s_ < p.ksplit) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) pv[s_][q] = *reinterpret_cast<const float4*>(src + (long)s_ * p.o_sstride + q * 64);
+#pragma unroll
+                        for (int hd = 0; hd < 2; ++hd)
+                            st[s_][hd] = *reinterpret_cast<const float2*>(p.ml + ((((long)s_ * p.B + b) * p.heads + hd) * p.rows_per_batch + n) * 2);
+                    }
+                }
+#pragma unroll
+                for (int hd = 0; hd < 2; ++hd) {
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_) if (s_ < p.ksplit) mx = fmaxf(mx, st[s_][hd].x);
+                    float wsum = 0.f, w[4];
+#pragma unroll
+                    for (int s_ = 0; s_ < 4; ++s_) {
+                        w[s_] = 0.f;
+                        if (s_ < p.ksplit) { w[s_] = st[s_][hd].y * exp2f(st[s_][hd].x - mx); wsum += w[s_]; }
+                    }
+                    const float inv = 1.f / wsum;
+#pragma unroll
+                    for (int qq = 0; qq < 2; ++qq) {
+                        const int q = hd * 2 + qq;
+                        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int s_ = 0; s_ < 4; ++s_) if (s_ < p.ksplit) {
+                            a.x = fmaf(w[s_], pv[s_][q].x, a.x); a.y = fmaf(w[s_], pv[s_][q].y, a.y);
+                            a.z = fmaf(w[s_], pv[s_][q].z, a.z); a.w = fmaf(w[s_], pv[s_][q].w, a.w);
+                        }
+                        v[q] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint2 o;
+                o.x = pack2_lp(v[q].x, v[q].y); o.y = pack2_lp(v[q].z, v[q].w);
+                *reinterpret_cast<uint2*>(As + row * A_LD + q * 64 + seg * 4) = o;
+            }
+        }
+        wload(wa, p.Wp, 16, wave, 0, lane);                  // (after the merge: its 64 partial registers and this tile do not fit together)
+        const float b_p = p.bp[col], g_msa = ada[2 * RC_H + col];
+        const float b_1a = p.b1[col], b_1b = p.b1[col + 256];
+        const float b_2 = p.b2[col], g_mlp = ada[5 * RC_H + col];
+        lds_barrier();
+        // ---- x1 = x + gate_msa * (O Wproj + b)
+        wload(wb, p.W1, 16, wave, 0, lane);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            float xres[16];                                   // residual rows of this lane's column (one half at a time: registers)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int nn = min(n0 + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * hh, N - 1);
+                xres[r] = p.X[(mb + nn) * RC_H + col];
+            }
+            acc = zero16();
+            mma16(acc, wa, a_lane + m * 32 * A_LD);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                X1[row * X_LD + col] = xres[r] + g_msa * (acc[r] + b_p);
+            }
+        }
+        lds_barrier();
+        ln_to_A(X1, As, LNp, LNp + RC_H, tid);
+        ln_to_A(X1 + 32 * X_LD, As + 32 * A_LD, LNp, LNp + RC_H, tid);
+        lds_barrier();
+        // ---- MLP, hidden columns 0..255: h = GELU(A W1[:, :256] + b1), partial x2 += h W2[:256, :]
+        wload(wa, p.W2, 32, wave, 0, lane);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            acc = zero16();
+            mma16(acc, wb, a_lane + m * 32 * A_LD);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                Hs[row * A_LD + col] = (u16)(pack2_lp(gelu_erf_rc(acc[r] + b_1a), 0.f) & 0xffffu);
+            }
+        }
+        lds_barrier();
+        wload(wb, p.W1, 16, wave + 8, 0, lane);
+        f32x16 acc2[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) { acc2[m] = zero16(); mma16(acc2[m], wa, h_lane + m * 32 * A_LD); }
+        lds_barrier();                                        // every wave is done with this half of h
+        // ---- hidden columns 256..511
+        wload(wa, p.W2, 32, wave, 16, lane);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            acc = zero16();
+            mma16(acc, wb, a_lane + m * 32 * A_LD);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                Hs[row * A_LD + col] = (u16)(pack2_lp(gelu_erf_rc(acc[r] + b_1b), 0.f) & 0xffffu);
+            }
+        }
+        lds_barrier();
+        if (has_q) wload(wb, p.Wq, 16, wave, 0, lane);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            mma16(acc2[m], wa, h_lane + m * 32 * A_LD);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float x2 = X1[row * X_LD + col] + g_mlp * (acc2[m][r] + b_2);
+                X1[row * X_LD + col] = x2;
+                if (n0 + row < N) p.X[(mb + n0 + row) * RC_H + col] = x2;
+            }
+        }
+        if (!has_q) return;
+    }
+    lds_barrier();
+    ln_to_A(X1, As, LNp + 2 * RC_H, LNp + 3 * RC_H, tid);
+    ln_to_A(X1 + 32 * X_LD, As + 32 * A_LD, LNp + 2 * RC_H, LNp + 3 * RC_H, tid);
+    lds_barrier();
+    // ---- qkv of the next block: column tiles wave (q), wave+8 (k), wave+16 (v), two row halves each
+    const float bq0 = p.bq[col], bq1 = p.bq[col + 256], bq2 = p.bq[col + 512];
+    u16* scr = Hs + wave * (RC_ROWS * QK_LD);
+    wload(wa, p.Wq, 16, wave + 8, 0, lane);
+#pragma unroll
+    // (the operand buffers hold ceil(N / 32) row tiles per (utterance, head): a second half that lies wholly past them is skipped)
+    for (int m = 0; m < 2; ++m) { if (n0 + 32 * m >= p.Npad) break; acc = zero16(); mma16(acc, wb, a_lane + m * 32 * A_LD); store_qkv_tile(p, acc, wave, bq0, b, n0 + 32 * m, lane, scr); }
+    wload(wb, p.Wq, 16, wave + 16, 0, lane);
+#pragma unroll
+    for (int m = 0; m < 2; ++m) { if (n0 + 32 * m >= p.Npad) break; acc = zero16(); mma16(acc, wa, a_lane + m * 32 * A_LD); store_qkv_tile(p, acc, wave + 8, bq1, b, n0 + 32 * m, lane, scr); }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) { if (n0 + 32 * m >= p.Npad) break; acc = zero16(); mma16(acc, wb, a_lane + m * 32 * A_LD); store_qkv_tile(p, acc, wave + 16, bq2, b, n0 + 32 * m, lane, scr); }
+}
+
 bool dit_rowchain_supported(int hidden, int mlp_hidden) { return hidden == RC_H && mlp_hidden == RC_MLP; }
 
 void launch_dit_rowchain(const DitChainP& p, hipStream_t st) {
@@ -526,6 +715,20 @@ void launch_dit_rowchain(const DitChainP& p, hipStream_t st) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&dit_rowchain_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)(RC_LDS_ATTN > RC_LDS ? RC_LDS_ATTN : RC_LDS));
         attr = true;
+    }
+    {   // batch regime with the attention as its own launch: the 64-row form (DEX_ROWCHAIN64=0: never, 2: whenever attention is separate)
+        static const int m64 = getenv("DEX_ROWCHAIN64") ? atoi(getenv("DEX_ROWCHAIN64")) : 1;
+        const long wg32 = (long)p.B * ((p.rows_per_batch + RC_ROWS - 1) / RC_ROWS);
+        if (m64 && !p.attn_inline && (m64 == 2 || wg32 >= 768)) {
+            static bool attr64 = false;
+            if (!attr64) {
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&dit_rowchain64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC64_LDS);
+                attr64 = true;
+            }
+            g_last_symbol = "dit_rowchain64_kernel";
+            hipLaunchKernelGGL(dit_rowchain64_kernel, dim3(p.B * ((p.rows_per_batch + 63) / 64)), dim3(RC_NW * 64), RC64_LDS, st, p);
+            return;
+        }
     }
     dim3 grid(p.B * ((p.rows_per_batch + RC_ROWS - 1) / RC_ROWS));
     if (p.attn_inline && !p.qkv_only)
