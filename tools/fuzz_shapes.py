@@ -38,5 +38,37 @@ for name, kw in cases:
         if not ok: bad += 1
     eng.set_precision("fp32")
     print(f"{name:10s} B={kw['B']} T={kw['T']:4d} lens={kw['lengths']}  max={worst[0]:.3e} mean={worst[1]:.3e} repeat_diff={rep:.1e} {'OK' if ok else 'FAIL'}", flush=True)
+# ---- batch regime (the throughput kernels: ping-pong convolutions, 16-bit single-consumer activations, column-walking GEMM,
+# 8-row tiles, 64-row DiT block): two sampler steps in bf16 / fp16 against the library's fp32 mode
+bcases = []
+for T in (36, 132, 260, 388, 512, 516):
+    for B in (7, 13, 32):
+        if T * B > 17000: continue
+        lens = [T] + [int(rng.integers(max(1, T // 3), T + 1)) for _ in range(B - 1)]
+        bcases.append(("gedex_lj", dict(B=B, T=T, lengths=lens)))
+for T in (68, 132, 256):
+    for B in (9, 32):
+        lens = [T] + [int(rng.integers(max(1, T // 2), T + 1)) for _ in range(B - 1)]
+        Ts = int(rng.integers(20, 200))
+        bcases.append(("dex_vctk", dict(B=B, T=T, lengths=lens, Tr=Ts, Ts=Ts, sty_lengths=[Ts] + [int(rng.integers(5, Ts + 1)) for _ in range(B - 1)])))
+for name, kw in bcases:
+    cfg, eng, w = U.engine_for(name)
+    case = U.make_case(cfg, **kw)
+    mu, mask, z = (torch.from_numpy(case[k]).cuda() for k in ("mu", "mask", "z"))
+    eng.set_precision("fp32")
+    ref = eng.sample(z, mask, mu, 2, **U.engine_kwargs(case)).cpu().numpy()
+    line = []
+    ok_all = True
+    for prec in ("bf16", "fp16"):
+        eng.set_precision(prec)
+        got = eng.sample(z, mask, mu, 2, **U.engine_kwargs(case)).cpu().numpy()
+        got2 = eng.sample(z, mask, mu, 2, **U.engine_kwargs(case)).cpu().numpy()
+        e = np.abs(got - ref)
+        ok = np.isfinite(got).all() and e.max() <= (6e-2 if prec == "bf16" else 1e-2) and e.mean() <= (8e-3 if prec == "bf16" else 1.5e-3) and np.array_equal(got, got2)
+        ok_all = ok_all and ok
+        line.append(f"{prec} max={e.max():.2e} mean={e.mean():.2e}")
+    eng.set_precision("fp32")
+    if not ok_all: bad += 1
+    print(f"{name:10s} B={kw['B']:2d} T={kw['T']:4d}  {' | '.join(line)}  {'OK' if ok_all else 'FAIL'}", flush=True)
 print("violations:", bad)
 sys.exit(1 if bad else 0)
