@@ -253,11 +253,11 @@ def side_workload(name, precision, device, stream, graph_mode, steps=3, warmup=1
     return ent
 
 
-def vocoder_block(device, stream, B=1, T=512, steps=10, warmup=3):
-    """HiFi-GAN V1 generator (the step right after the sampler) on the mel of the headline workload."""
+def vocoder_block(device, stream, B=1, T=512, steps=10, warmup=3, big=False):
+    """HiFi-GAN V1 generator (the step right after the sampler) on the mel of the headline workload; big: BigVGAN-base."""
     from dex_tts_amd import vocoder as V
-    h = V.HIFIGAN_V1
-    gen = V.Generator()
+    h = V.BIGVGAN_BASE if big else V.HIFIGAN_V1
+    gen = V.Generator(V.AttrDict(h))
     gen.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_vocoder_weights(V.param_shapes(h)).items()})
     gen = gen.to(device).eval()
     mel = torch.from_numpy(synth.make_inputs(B, T, None, seed=1234)[0]).to(device)
@@ -272,7 +272,8 @@ def vocoder_block(device, stream, B=1, T=512, steps=10, warmup=3):
         dt, ev, wav = timed_calls(lambda: gen(mel), steps, warmup, device)
     assert torch.isfinite(wav).all()
     sec = dt / steps
-    return {"workload": f"HiFi-GAN V1 generator (hifigan/config.json), B={B}, T={T} mel frames -> {wav.shape[-1]} samples, exact-fp32 MFMA",
+    name = "BigVGAN-base generator (anti-aliased snakebeta activations)" if big else "HiFi-GAN V1 generator (hifigan/config.json)"
+    return {"workload": f"{name}, B={B}, T={T} mel frames -> {wav.shape[-1]} samples, exact-fp32 MFMA",
             "value": round(B * T / sec, 1), "unit": "mel-frames/s", "ms_per_call": round(sec * 1e3, 3), "hip_event_median_ms": round(statistics.median(ev), 3),
             "rtf": round(sec / (B * T * 256 / 22050.0), 6), "algorithmic_GFLOP": round(B * fl / 1e9, 1),
             "mfma_TFLOP/s": round(B * fl / sec / 1e12, 1), "frac_of_fp32_mfma_peak": round(B * fl / sec / 1e12 / PEAK_TFLOPS["f32"], 3)}
@@ -460,6 +461,7 @@ def main():
             }
         if prof and args.workload == "gedex_b1" and not args.no_configs:
             res["vocoder"] = vocoder_block(device, stream)
+            res["vocoder_bigvgan"] = vocoder_block(device, stream, big=True)
             res["frontend"] = frontend_block(device, stream)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, weights, B, T, n_steps, TrTs)

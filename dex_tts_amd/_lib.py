@@ -38,7 +38,8 @@ class DexSampleArgs(C.Structure):
 class DexVocoderConfig(C.Structure):
     _fields_ = [("num_mels", C.c_int32), ("upsample_initial_channel", C.c_int32), ("n_upsamples", C.c_int32),
                 ("upsample_rates", C.c_int32 * 6), ("upsample_kernel_sizes", C.c_int32 * 6), ("n_resblock_kernels", C.c_int32),
-                ("resblock_kernel_sizes", C.c_int32 * 3), ("resblock_dilation_sizes", (C.c_int32 * 3) * 3)]
+                ("resblock_kernel_sizes", C.c_int32 * 3), ("resblock_dilation_sizes", (C.c_int32 * 3) * 3),
+                ("activation", C.c_int32), ("snake_logscale", C.c_int32)]
 
 
 class DexStyleConfig(C.Structure):

@@ -9,6 +9,10 @@
 // exact-fp32 MFMA kernel (igemm.hip), with the leaky_relu applied while the A tile is gathered and the residual added in
 // the epilogue.  A ConvTranspose1d is one GEMM Y[l][j*Cout + co] = lrelu(x)[l][:] . w[:, co, j] followed by an overlap-add
 // (k/u terms per output).  conv_post (one output channel) and the tanh are one element-wise kernel.
+//
+// BigVGAN (DEX-TTS/bigvgan/models.py:138-211; DexVocoderConfig::activation != 0) is the same network with AMPBlock1: the leaky_relu
+// in front of every ResBlock conv and of conv_post becomes the anti-aliased Snake / SnakeBeta activation (alias_free_torch/act.py;
+// one aa_snake launch into a scratch tensor), the transposed convs take x as it is.
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
@@ -39,6 +43,10 @@ struct DexVoc {
     std::vector<VUp> ups;
     std::vector<VConv> rb;              // [stage][j][c1_0, c2_0, c1_1, c2_1, c1_2, c2_2] flattened
     const float *post_w = nullptr, *post_b = nullptr;
+    // BigVGAN: per activation layer (a, 1/b) coefficient pairs: [stage][block j][layer l] then the post activation; the shared filter
+    std::vector<const float*> act_a, act_ib;
+    const float* filt = nullptr;
+    bool big() const { return cfg.activation != 0; }
     int fail(int code, const char* fmt, ...) {
         char buf[512];
         va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
@@ -82,12 +90,15 @@ int dex_voc_create(const DexVocoderConfig* cfg, DexVoc** out) {
     }
     if (stage_ch(c, c.n_upsamples - 1) > 64) return v->fail(DEX_ERR_ARG, "conv_post kernel handles <= 64 input channels");
     for (int j = 0; j < 3; ++j) if (c.resblock_kernel_sizes[j] % 2 == 0) return v->fail(DEX_ERR_ARG, "ResBlock kernel sizes must be odd");
+    if (c.activation < 0 || c.activation > 2) return v->fail(DEX_ERR_ARG, "activation must be 0 (HiFi-GAN), 1 (BigVGAN snake) or 2 (BigVGAN snakebeta)");
+    const bool big = c.activation != 0, beta = c.activation == 2;
+    const std::string upsfx = big ? ".0" : "";                      // BigVGAN nests each transposed conv in a ModuleList
     const int c0 = c.upsample_initial_channel;
     vkey(v, "conv_pre.weight", {c0, c.num_mels, 7}); vkey(v, "conv_pre.bias", {c0});
     for (int i = 0; i < c.n_upsamples; ++i) {
         const int ci = c0 >> i, co = c0 >> (i + 1);
-        vkey(v, "ups." + std::to_string(i) + ".weight", {ci, co, c.upsample_kernel_sizes[i]});      // ConvTranspose1d: [in, out, k]
-        vkey(v, "ups." + std::to_string(i) + ".bias", {co});
+        vkey(v, "ups." + std::to_string(i) + upsfx + ".weight", {ci, co, c.upsample_kernel_sizes[i]});      // ConvTranspose1d: [in, out, k]
+        vkey(v, "ups." + std::to_string(i) + upsfx + ".bias", {co});
     }
     for (int i = 0; i < c.n_upsamples; ++i)
         for (int j = 0; j < 3; ++j) {
@@ -98,7 +109,18 @@ int dex_voc_create(const DexVocoderConfig* cfg, DexVoc** out) {
                     vkey(v, p + cs + std::to_string(m) + ".weight", {ch, ch, k});
                     vkey(v, p + cs + std::to_string(m) + ".bias", {ch});
                 }
+            if (big)
+                for (int l = 0; l < 6; ++l) {
+                    vkey(v, p + ".activations." + std::to_string(l) + ".act.alpha", {ch});
+                    if (beta) vkey(v, p + ".activations." + std::to_string(l) + ".act.beta", {ch});
+                }
         }
+    if (big) {
+        const int cl = stage_ch(c, c.n_upsamples - 1);
+        vkey(v, "activation_post.act.alpha", {cl});
+        if (beta) vkey(v, "activation_post.act.beta", {cl});
+        vkey(v, "activation_post.upsample.filter", {1, 1, 12}); vkey(v, "activation_post.downsample.lowpass.filter", {1, 1, 12});
+    }
     vkey(v, "conv_post.weight", {1, stage_ch(c, c.n_upsamples - 1), 7}); vkey(v, "conv_post.bias", {1});
     return DEX_OK;
 }
@@ -176,8 +198,9 @@ int dex_voc_finalize(DexVoc* v, dex_stream_t stream) {
         const int ci = c.upsample_initial_channel >> i, co = stage_ch(c, i), k = c.upsample_kernel_sizes[i], u = c.upsample_rates[i];
         VUp up{}; up.cin = ci; up.cout = co; up.k = k; up.u = u; up.pad = (k - u) / 2;
         float* d = alloc((long)ci * k * co);
-        if (d) launch_permute4(v->raw.at("ups." + std::to_string(i) + ".weight").p, d, ci, co, k, 1, 0, 2, 1, 3, st);   // [ci][co][k] -> [ci][k][co]
-        up.w = d; up.b = v->raw.at("ups." + std::to_string(i) + ".bias").p;
+        const std::string upn = "ups." + std::to_string(i) + (v->big() ? ".0" : "");
+        if (d) launch_permute4(v->raw.at(upn + ".weight").p, d, ci, co, k, 1, 0, 2, 1, 3, st);   // [ci][co][k] -> [ci][k][co]
+        up.w = d; up.b = v->raw.at(upn + ".bias").p;
         v->ups.push_back(up);
         for (int j = 0; j < 3; ++j) {
             const std::string p = "resblocks." + std::to_string(i * 3 + j);
@@ -186,6 +209,21 @@ int dex_voc_finalize(DexVoc* v, dex_stream_t stream) {
                 v->rb.push_back(conv(p + ".convs2." + std::to_string(m), co, co, c.resblock_kernel_sizes[j], 1, co));
             }
         }
+    }
+    v->act_a.clear(); v->act_ib.clear(); v->filt = nullptr;
+    if (v->big()) {
+        const bool beta = c.activation == 2;
+        auto coeffs = [&](const std::string& p, int ch) {
+            float* a = alloc(ch); float* ib = alloc(ch);
+            if (a && ib) launch_snake_coeffs(v->raw.at(p + ".alpha").p, v->raw.at(p + (beta ? ".beta" : ".alpha")).p, a, ib, ch, c.snake_logscale, st);
+            v->act_a.push_back(a); v->act_ib.push_back(ib);
+        };
+        for (int i = 0; i < c.n_upsamples; ++i)
+            for (int j = 0; j < 3; ++j)
+                for (int l = 0; l < 6; ++l)
+                    coeffs("resblocks." + std::to_string(i * 3 + j) + ".activations." + std::to_string(l) + ".act", stage_ch(c, i));
+        coeffs("activation_post.act", stage_ch(c, c.n_upsamples - 1));
+        v->filt = v->raw.at("activation_post.upsample.filter").p;      // (the host checks that every resampling filter of the checkpoint equals it)
     }
     {   // conv_post [1][C][7] -> [tap][c]
         const int cl = stage_ch(c, c.n_upsamples - 1);
@@ -205,7 +243,7 @@ int dex_voc_samples(const DexVoc* v, int T) { return v ? (int)(T * total_up(v->c
 }  // extern "C"
 
 namespace {
-struct VPlan { float *mel, *x, *y, *a, *q, *p[3]; size_t bytes; };
+struct VPlan { float *mel, *x, *y, *a, *q, *s, *p[3]; size_t bytes; };
 void voc_plan(const DexVoc* v, int B, int T, void* ws, VPlan& P) {
     const DexVocoderConfig& c = v->cfg;
     // largest activation [B][L][C] and ConvTranspose GEMM output [B][L_in][k*Cout] over the stages
@@ -220,6 +258,7 @@ void voc_plan(const DexVoc* v, int B, int T, void* ws, VPlan& P) {
     auto take = [&](size_t n) { off = (off + 255) & ~size_t(255); float* p = ws ? (float*)(base + off) : nullptr; off += n * sizeof(float); return p; };
     P.mel = take((size_t)B * T * MEL_LD);
     P.x = take(act); P.a = take(act); P.q = take(act);
+    P.s = v->big() ? take(act) : nullptr;                 // output of the anti-aliased activation in front of a conv
     for (int j = 0; j < 3; ++j) P.p[j] = take(act);
     P.y = take(ymax);
     P.bytes = (off + 255) & ~size_t(255);
@@ -271,7 +310,7 @@ int dex_vocode(DexVoc* v, const float* mel_dev, int B, int T, float* wav_dev, vo
             g.KH = 1; g.KW = 1; g.sh = 1; g.sw = 1; g.step_h = 1; g.step_w = 1; g.Ho = 1; g.Wo = (int)L;
             g.W = up.w; g.N = up.k * up.cout; g.K = up.cin; g.ksplit = 1; g.groups = 1;
             g.C = P.y; g.ldc = g.N; g.c_bstride = L * g.N; g.OHf = 1; g.OWf = (int)L; g.osh = 1; g.osw = 1;
-            g.inmask_ws = 1; g.outmask_ws = 1; g.gate_nstride = 1; g.act_in_slope = 0.1f; g.B = B;
+            g.inmask_ws = 1; g.outmask_ws = 1; g.gate_nstride = 1; g.act_in_slope = v->big() ? 0.f : 0.1f; g.B = B;     // BigVGAN: no activation here
             launch_igemm(g, PREC_FP32, st);
             ConvTFoldP f{P.y, up.b, P.a, (int)L, up.cout, up.k, up.u, up.pad, B};
             launch_convt_fold(f, st);
@@ -283,14 +322,30 @@ int dex_vocode(DexVoc* v, const float* mel_dev, int B, int T, float* wav_dev, vo
             const float* cur = P.a;
             for (int m = 0; m < 3; ++m) {
                 float* dst = (m == 1) ? P.q : P.p[j];                   // x -> p[j] -> q -> p[j]
-                launch_igemm(conv1d(cur, (int)L, B, cv[2 * m], 0.1f, P.x, nullptr), PREC_FP32, st);          // xt = c1(lrelu(x))
-                launch_igemm(conv1d(P.x, (int)L, B, cv[2 * m + 1], 0.1f, dst, cur), PREC_FP32, st);          // x = c2(lrelu(xt)) + x
+                if (v->big()) {      // AMPBlock1 (bigvgan/models.py:76-85): xt = c1(a_{2m}(x)); x = c2(a_{2m+1}(xt)) + x
+                    const size_t ai = ((size_t)(i * 3 + j) * 6) + 2 * m;
+                    AaSnakeP s1{cur, P.s, (int)L, up.cout, B, v->act_a[ai], v->act_ib[ai], v->filt};
+                    launch_aa_snake(s1, st);
+                    launch_igemm(conv1d(P.s, (int)L, B, cv[2 * m], 0.f, P.x, nullptr), PREC_FP32, st);
+                    AaSnakeP s2{P.x, P.s, (int)L, up.cout, B, v->act_a[ai + 1], v->act_ib[ai + 1], v->filt};
+                    launch_aa_snake(s2, st);
+                    launch_igemm(conv1d(P.s, (int)L, B, cv[2 * m + 1], 0.f, dst, cur), PREC_FP32, st);
+                } else {
+                    launch_igemm(conv1d(cur, (int)L, B, cv[2 * m], 0.1f, P.x, nullptr), PREC_FP32, st);          // xt = c1(lrelu(x))
+                    launch_igemm(conv1d(P.x, (int)L, B, cv[2 * m + 1], 0.1f, dst, cur), PREC_FP32, st);          // x = c2(lrelu(xt)) + x
+                }
                 cur = dst;
             }
         }
         launch_avg3(P.p[0], P.p[1], P.p[2], P.x, (long)B * L * up.cout, st);
     }
-    ConvPostP cp{P.x, v->post_w, v->post_b, wav_dev, (int)L, stage_ch(c, c.n_upsamples - 1), B};
+    const float* xin = P.x;
+    if (v->big()) {          // activation_post (models.py:205) replaces the leaky_relu in front of conv_post
+        AaSnakeP sp{P.x, P.s, (int)L, stage_ch(c, c.n_upsamples - 1), B, v->act_a.back(), v->act_ib.back(), v->filt};
+        launch_aa_snake(sp, st);
+        xin = P.s;
+    }
+    ConvPostP cp{xin, v->post_w, v->post_b, wav_dev, (int)L, stage_ch(c, c.n_upsamples - 1), B, v->big() ? 1.f : 0.01f};
     launch_conv_post_tanh(cp, st);
     VCHK(v, hipGetLastError());
     return DEX_OK;

@@ -312,7 +312,13 @@ void launch_convt_fold(const ConvTFoldP& p, hipStream_t st);
 // x = (a + b + c) * (1/3)  (the three ResBlocks of a stage, models.py:158-164); n floats
 void launch_avg3(const float* a, const float* b, const float* c, float* out, long n, hipStream_t st);
 // wav[t] = tanh(bias + sum_{tap<7} sum_{c<C} w[tap][c] * leaky_relu(x[t+tap-3][c], 0.01))   (models.py:165-167)
-struct ConvPostP { const float* X; const float* W; const float* bias; float* wav; int L, C, B; };
+struct ConvPostP { const float* X; const float* W; const float* bias; float* wav; int L, C, B; float slope; };   // leaky_relu slope on the input (1 = none)
+// BigVGAN anti-aliased periodic activation (alias_free_torch/act.py:23-28): y = downsample2(snake(upsample2(x))) per channel, channels-last
+// [B][L][C]; a[c] = frequency, inv_b[c] = 1 / (magnitude + 1e-9) (already exponentiated when the checkpoint is log-scale); filt = the 12-tap
+// Kaiser-sinc low-pass of both resamplers
+struct AaSnakeP { const float* X; float* Y; int L, C, B; const float* a; const float* inv_b; const float* filt; };
+void launch_aa_snake(const AaSnakeP& p, hipStream_t st);
+void launch_snake_coeffs(const float* alpha, const float* beta, float* a, float* inv_b, int C, int logscale, hipStream_t st);
 void launch_conv_post_tanh(const ConvPostP& p, hipStream_t st);
 
 // DEX style encoders (dex_style.hip; reference DEX-TTS/model/ref_encoder.py:8-140,199-237) ------------

@@ -77,8 +77,8 @@ __global__ __launch_bounds__(256) void conv_post_tanh_kernel(const ConvPostP p) 
             const float* x = p.X + ((long)b * p.L + tt) * p.C;
             for (int c = 0; c < p.C; c += 4) {
                 float4 v = *reinterpret_cast<const float4*>(x + c);
-                v.x = v.x > 0.f ? v.x : v.x * 0.01f; v.y = v.y > 0.f ? v.y : v.y * 0.01f;       // F.leaky_relu default slope
-                v.z = v.z > 0.f ? v.z : v.z * 0.01f; v.w = v.w > 0.f ? v.w : v.w * 0.01f;
+                v.x = v.x > 0.f ? v.x : v.x * p.slope; v.y = v.y > 0.f ? v.y : v.y * p.slope;     // HiFi-GAN: F.leaky_relu default slope 0.01; BigVGAN: 1
+                v.z = v.z > 0.f ? v.z : v.z * p.slope; v.w = v.w > 0.f ? v.w : v.w * p.slope;
                 const float* w = ws + tap * p.C + c;
                 acc = fmaf(v.x, w[0], acc); acc = fmaf(v.y, w[1], acc); acc = fmaf(v.z, w[2], acc); acc = fmaf(v.w, w[3], acc);
             }
@@ -89,6 +89,66 @@ __global__ __launch_bounds__(256) void conv_post_tanh_kernel(const ConvPostP p) 
 void launch_conv_post_tanh(const ConvPostP& p, hipStream_t st) {
     long blocks = ((long)p.B * p.L + 255) / 256; if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(conv_post_tanh_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+}
+
+// ---- BigVGAN Activation1d.  UpSample1d(2, 12): replicate-pad 5, transposed conv stride 2 with the filter, x2, crop 15 / 15:
+//   up[m] = 2 * sum_j x[clamp(j - 5)] * f[m + 15 - 2 j]   (the six j with 0 <= m + 15 - 2 j <= 11),  m in [0, 2L)
+// snake: s = up + inv_b * sin^2(a * up);  DownSample1d(2, 12): replicate-pad (5, 6), conv stride 2:
+//   y[t] = sum_k s[clamp(2 t + k - 5, 0, 2L - 1)] * f[k].
+// A block owns AS_T output positions x 64 channels: the 2 * AS_T + 11 activated samples it needs go through LDS once
+// (two sin per output instead of twelve).
+constexpr int AS_T = 32, AS_S = 2 * AS_T + 11;
+__global__ __launch_bounds__(256) void aa_snake_kernel(const AaSnakeP p) {
+    __shared__ float s[AS_S][64];
+    __shared__ float f[12];
+    const int tid = threadIdx.x, c = tid & 63, tl = tid >> 6;
+    const int c0 = blockIdx.x * 64, t0 = blockIdx.y * AS_T, b = blockIdx.z;
+    if (tid < 12) f[tid] = p.filt[tid];
+    __syncthreads();
+    const bool cok = c0 + c < p.C;
+    const float a = cok ? p.a[c0 + c] : 0.f, ib = cok ? p.inv_b[c0 + c] : 0.f;
+    const float* X = p.X + (long)b * p.L * p.C + (cok ? c0 + c : 0);
+    const int L2 = 2 * p.L;
+    for (int q = tl; q < AS_S; q += 4) {
+        const int m = min(max(2 * t0 - 5 + q, 0), L2 - 1);            // the down-sampler's replicate padding
+        float up = 0.f;
+        const int j0 = (m + 5) >> 1;                                  // ceil((m + 4) / 2)
+#pragma unroll
+        for (int jj = 0; jj < 6; ++jj) {
+            const int j = j0 + jj, k = m + 15 - 2 * j;                // k in [0, 11] for these six j (m + 15 - 2 j0 is 10 or 11)
+            const int xi = min(max(j - 5, 0), p.L - 1);
+            if (k >= 0) up = fmaf(X[(long)xi * p.C], f[k], up);
+        }
+        up *= 2.f;
+        const float sn = sinf(up * a);
+        s[q][c] = up + ib * (sn * sn);
+    }
+    __syncthreads();
+    if (!cok) return;
+    float* Y = p.Y + (long)b * p.L * p.C + c0 + c;
+    for (int tt = tl; tt < AS_T; tt += 4) {
+        const int t = t0 + tt;
+        if (t >= p.L) break;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) acc = fmaf(s[2 * tt + k][c], f[k], acc);
+        Y[(long)t * p.C] = acc;
+    }
+}
+void launch_aa_snake(const AaSnakeP& p, hipStream_t st) {
+    hipLaunchKernelGGL(aa_snake_kernel, dim3((p.C + 63) / 64, (p.L + AS_T - 1) / AS_T, p.B), dim3(256), 0, st, p);
+}
+// a = alpha (exp if log-scale); inv_b = 1 / (beta + 1e-9) (activations.py:52-56 / :110-116; beta == alpha for plain Snake)
+__global__ void snake_coeffs_kernel(const float* alpha, const float* beta, float* a, float* inv_b, int C, int logscale) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float al = alpha[c], be = beta[c];
+    if (logscale) { al = expf(al); be = expf(be); }
+    a[c] = al;
+    inv_b[c] = 1.0f / (be + 0.000000001f);
+}
+void launch_snake_coeffs(const float* alpha, const float* beta, float* a, float* inv_b, int C, int logscale, hipStream_t st) {
+    hipLaunchKernelGGL(snake_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, st, alpha, beta, a, inv_b, C, logscale);
 }
 
 }  // namespace dex

@@ -107,14 +107,22 @@ def make_vocoder_weights(shapes: dict, seed: int = 0) -> dict:
     out = {}
     for name, shape in shapes.items():
         shape = tuple(shape)
-        if name.endswith(".bias"):
+        if name.endswith(".filter"):          # BigVGAN resampling filter: Kaiser-windowed sinc, cutoff 0.25, half-width 0.3, 12 taps (filter.py:30-60)
+            beta = 0.1102 * ((2.285 * 5 * np.pi * 1.2 + 7.95) - 8.7)
+            t = np.arange(-6, 6) + 0.5
+            f = 0.5 * np.kaiser(12, beta) * np.sinc(0.5 * t)
+            w = (f / f.sum()).reshape(shape)
+        elif name.endswith((".act.alpha", ".act.beta")):       # log-scale frequency / magnitude of the periodic activation
+            w = symmetric("voc." + name, shape, 0.4, seed)
+        elif name.endswith(".bias"):
             w = symmetric("voc." + name, shape, 0.05, seed)
         elif name.startswith("ups."):
             cin, cout, k = shape
             w = symmetric("voc." + name, shape, float(np.sqrt(3.0 * 2.0 / (cin * 2))), seed)
         else:
             cout, cin, k = shape
-            gain = 0.5 if name.startswith("resblocks.") else (0.06 if name.startswith("conv_post") else 1.0)
+            post = 0.015 if "activation_post.act.alpha" in shapes else 0.06      # (BigVGAN's periodic activations add energy: keep tanh out of saturation)
+            gain = 0.5 if name.startswith("resblocks.") else (post if name.startswith("conv_post") else 1.0)
             w = symmetric("voc." + name, shape, gain * float(np.sqrt(3.0 / (cin * k))), seed)
         out[name] = np.ascontiguousarray(w, dtype=np.float32)
     return out

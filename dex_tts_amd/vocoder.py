@@ -19,6 +19,15 @@ HIFIGAN_V1 = dict(num_mels=80, upsample_rates=[8, 8, 2, 2], upsample_kernel_size
                   resblock="1", resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]])
 
 
+# BigVGAN-base, 22 kHz / 80 bands: the configuration src/utils.py:267 reads from bigvgan/bigvgan_base_22khz_80band/config.json (not in
+# the reference tree; these are the published values of that file).  The 112 M "bigvgan_22khz_80band" model (1536 initial channels,
+# six up-sampling stages down to 24 channels) is outside the implicit GEMM's 32-channel granule and is not built.
+BIGVGAN_BASE = dict(num_mels=80, upsample_rates=[8, 8, 2, 2], upsample_kernel_sizes=[16, 16, 4, 4], upsample_initial_channel=512,
+                    resblock="1", resblock_kernel_sizes=[3, 7, 11], resblock_dilation_sizes=[[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+                    activation="snakebeta", snake_logscale=True)
+ACTIVATION = {None: 0, "snake": 1, "snakebeta": 2}
+
+
 class AttrDict(dict):
     """hifigan/__init__.py's AttrDict: config.json keys as attributes."""
 
@@ -34,14 +43,26 @@ def _get(h, name, default=None):
 
 
 def param_shapes(h) -> Dict[str, tuple]:
-    """Generator.state_dict() after remove_weight_norm(): key -> shape (models.py:116-148)."""
+    """Generator.state_dict() after remove_weight_norm(): key -> shape (hifigan/models.py:116-148; with ``activation`` =
+    'snake' / 'snakebeta' in the config: BigVGAN, bigvgan/models.py:141-184 — nested ``ups.<i>.0``, an Activation1d per ResBlock conv
+    with its alpha [, beta] and the two resampling-filter buffers, ``activation_post``)."""
     c0 = int(_get(h, "upsample_initial_channel"))
     rates, ksz = list(_get(h, "upsample_rates")), list(_get(h, "upsample_kernel_sizes"))
     rk = list(_get(h, "resblock_kernel_sizes"))
+    act = _get(h, "activation")
+    if act not in ACTIVATION:
+        raise ValueError(f"activation {act!r}: expected 'snake' or 'snakebeta' (BigVGAN) or none (HiFi-GAN)")
+    ups = ".0" if act else ""
     out = {"conv_pre.weight": (c0, int(_get(h, "num_mels", 80)), 7), "conv_pre.bias": (c0,)}
     for i, k in enumerate(ksz):
-        out[f"ups.{i}.weight"] = (c0 >> i, c0 >> (i + 1), k)
-        out[f"ups.{i}.bias"] = (c0 >> (i + 1),)
+        out[f"ups.{i}{ups}.weight"] = (c0 >> i, c0 >> (i + 1), k)
+        out[f"ups.{i}{ups}.bias"] = (c0 >> (i + 1),)
+
+    def activation(p, ch):
+        out[f"{p}.act.alpha"] = (ch,)
+        if act == "snakebeta":
+            out[f"{p}.act.beta"] = (ch,)
+        out[f"{p}.upsample.filter"] = (1, 1, 12); out[f"{p}.downsample.lowpass.filter"] = (1, 1, 12)
     for i in range(len(rates)):
         ch = c0 >> (i + 1)
         for j, k in enumerate(rk):
@@ -49,6 +70,11 @@ def param_shapes(h) -> Dict[str, tuple]:
                 for m in range(3):
                     out[f"resblocks.{i * len(rk) + j}.{cs}.{m}.weight"] = (ch, ch, k)
                     out[f"resblocks.{i * len(rk) + j}.{cs}.{m}.bias"] = (ch,)
+            if act:
+                for l in range(6):
+                    activation(f"resblocks.{i * len(rk) + j}.activations.{l}", ch)
+    if act:
+        activation("activation_post", c0 >> len(rates))
     out["conv_post.weight"] = (1, c0 >> len(rates), 7)
     out["conv_post.bias"] = (1,)
     return out
@@ -76,7 +102,7 @@ class Generator(nn.Module):
         super().__init__()
         h = AttrDict(HIFIGAN_V1) if h is None else h
         if str(_get(h, "resblock", "1")) != "1":
-            raise ValueError("only ResBlock type '1' (hifigan/config.json, V1) is built")
+            raise ValueError("only ResBlock / AMPBlock type '1' (hifigan/config.json V1, bigvgan base) is built")
         self.h = h
         self.shapes = param_shapes(h)
         for key, shape in self.shapes.items():           # flat parameter registry under the reference's dotted names
@@ -126,6 +152,7 @@ class Generator(nn.Module):
             c.num_mels, c.upsample_initial_channel, c.n_upsamples = int(_get(h, "num_mels", 80)), int(_get(h, "upsample_initial_channel")), len(rates)
             for i, (u, k) in enumerate(zip(rates, ksz)):
                 c.upsample_rates[i], c.upsample_kernel_sizes[i] = int(u), int(k)
+            c.activation, c.snake_logscale = ACTIVATION[_get(h, "activation")], int(bool(_get(h, "snake_logscale", False)))
             c.n_resblock_kernels = len(rk)
             for j, k in enumerate(rk[:3]):
                 c.resblock_kernel_sizes[j] = int(k)
@@ -138,10 +165,19 @@ class Generator(nn.Module):
         bufs = [getattr(self, k.replace(".", "__")) for k in self.shapes]
         key = (str(device),) + tuple((b._version, b.data_ptr()) for b in bufs)
         if key != self._loaded_key:
+            # BigVGAN: the library takes ONE copy of the resampling filter (all 73 buffers are the same Kaiser-sinc constant)
+            filt = [k for k in self.shapes if k.endswith(".filter")]
+            if filt:
+                f0 = getattr(self, "activation_post.upsample.filter".replace(".", "__"))
+                for k in filt:
+                    if not torch.equal(getattr(self, k.replace(".", "__")), f0):
+                        raise RuntimeError(f"{k} differs from activation_post.upsample.filter: per-layer resampling filters are not supported")
             with torch.cuda.device(device):
                 st = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
                 keep = []
                 for name, shape in self.shapes.items():
+                    if name.endswith(".filter") and not name.startswith("activation_post."):
+                        continue
                     w = getattr(self, name.replace(".", "__")).to(device=device, dtype=torch.float32).contiguous()
                     shp = (C.c_int64 * 4)(*([int(s) for s in shape] + [0] * (4 - len(shape))))
                     self._check(self._lib.dex_voc_load_weight_async(self._ctx, name.encode(), C.c_void_p(w.data_ptr()), shp, len(shape), st))
@@ -182,8 +218,11 @@ class Generator(nn.Module):
 def get_vocoder(config_path: Optional[str] = None, ckpt: Optional[dict] = None, device="cuda") -> Generator:
     """src/utils.py:251-281 for the 'hifigan' choice: config.json -> Generator -> load ckpt['generator'] -> eval ->
     remove_weight_norm -> device."""
-    h = AttrDict(json.load(open(config_path))) if config_path else AttrDict(HIFIGAN_V1)
+    h = AttrDict(json.load(open(config_path))) if config_path else AttrDict(HIFIGAN_V1)      # a BigVGAN config.json selects BigVGAN
     g = Generator(h)
     if ckpt is not None:
         g.load_state_dict(ckpt["generator"] if "generator" in ckpt else ckpt)
     return g.eval().to(device)
+
+
+BigVGAN = Generator      # bigvgan/__init__.py: ``from .models import BigVGAN as Generator`` — Generator(AttrDict(BIGVGAN_BASE))

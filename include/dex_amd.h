@@ -161,13 +161,21 @@ typedef struct {
     int32_t n_resblock_kernels;         /* len(resblock_kernel_sizes), must be 3 (the stage average is xs / 3) */
     int32_t resblock_kernel_sizes[3];   /* [3,7,11] */
     int32_t resblock_dilation_sizes[3][3]; /* [[1,3,5]]*3 (ResBlock "1": three dilated + three plain convs each) */
+    /* 0: HiFi-GAN (leaky_relu in front of every conv).  1 / 2: BigVGAN (DEX-TTS/bigvgan/models.py:138-211, AMPBlock1) with the
+     * anti-aliased Snake / SnakeBeta activation (alias_free_torch/act.py, activations.py) in front of every ResBlock conv and of
+     * conv_post, and no activation in front of the transposed convs. */
+    int32_t activation;
+    int32_t snake_logscale;             /* BigVGAN: alpha / beta are stored as logarithms (config "snake_logscale") */
 } DexVocoderConfig;
 
 int  dex_voc_create(const DexVocoderConfig* cfg, DexVoc** out);
 void dex_voc_destroy(DexVoc* voc);
 const char* dex_voc_last_error(const DexVoc* voc);
 /* Generator.state_dict() keys AFTER remove_weight_norm() (models.py:169-173: "conv_pre.weight", "ups.0.bias",
- * "resblocks.4.convs1.2.weight", "conv_post.weight", ...), reference shapes; the host folds weight_g / weight_v pairs. */
+ * "resblocks.4.convs1.2.weight", "conv_post.weight", ...), reference shapes; the host folds weight_g / weight_v pairs.
+ * BigVGAN: "ups.<i>.0.weight" (nested ModuleList), "resblocks.<n>.activations.<l>.act.alpha" [+ ".beta"],
+ * "activation_post.act.alpha" [+ ".beta"], and ONE copy of the two (identical) 12-tap resampling filters,
+ * "activation_post.upsample.filter" / "activation_post.downsample.lowpass.filter" [1,1,12]. */
 int  dex_voc_num_weights(const DexVoc* voc);
 int  dex_voc_weight_info(const DexVoc* voc, int i, const char** key, int64_t shape[4], int* ndim);
 int  dex_voc_load_weight_async(DexVoc* voc, const char* key, const float* w_dev, const int64_t* shape, int ndim, dex_stream_t stream);

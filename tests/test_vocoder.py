@@ -105,3 +105,67 @@ def test_vocode_weight_norm_checkpoint():
     with torch.no_grad():
         ref = VO.generator({k: torch.from_numpy(v) for k, v in w.items()}, V.HIFIGAN_V1, torch.from_numpy(mel)).numpy()
     assert np.abs(got - ref).max() <= 2e-5
+
+
+# ---------------------------------------------------------------------------------------------------- BigVGAN (f1, optional part)
+def bvg_weights():
+    g = np.load(os.path.join(GOLD, "bigvgan.npz"))
+    w = synth.make_vocoder_weights(V.param_shapes(V.BIGVGAN_BASE))
+    for k in w:
+        if k.endswith(".filter"):
+            w[k] = g["filter"].copy()                 # the reference's registered buffer (torch's Kaiser window)
+    return w
+
+
+def test_bigvgan_param_shapes_match_reference_state_dict():
+    man = json.load(open(os.path.join(GOLD, "manifest_bigvgan_base.json")))
+    assert {k: tuple(v) for k, v in man["keys"].items()} == {k: tuple(v) for k, v in V.param_shapes(V.BIGVGAN_BASE).items()}
+    assert man["config"]["activation"] == "snakebeta" and len(man["keys"]) == 448
+
+
+def test_bigvgan_oracle_matches_reference_golden():
+    from oracle import bigvgan_oracle as BO
+    g = np.load(os.path.join(GOLD, "bigvgan.npz"))
+    W = {k: torch.from_numpy(v) for k, v in bvg_weights().items()}
+    with torch.no_grad():
+        wav = BO.generator(W, V.BIGVGAN_BASE, torch.from_numpy(g["mel"])).numpy()
+    assert wav.shape == g["wav"].shape and np.abs(wav - g["wav"]).max() <= 1e-6
+    assert np.abs(g["wav"]).max() < 0.98 and g["wav"].std() > 0.05          # neither saturated nor silent
+    # the resampling filter is the published Kaiser-sinc constant
+    assert np.abs(BO.kaiser_sinc_filter1d(0.25, 0.3, 12).numpy() - g["filter"].flatten()).max() <= 1e-7
+
+
+@pytest.mark.gpu
+def test_bigvgan_matches_reference_golden():
+    g = np.load(os.path.join(GOLD, "bigvgan.npz"))
+    m = V.BigVGAN(V.AttrDict(V.BIGVGAN_BASE))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in bvg_weights().items()})
+    m = m.cuda().eval()
+    wav = m(torch.from_numpy(g["mel"]).cuda()).cpu().numpy()
+    assert wav.shape == g["wav"].shape
+    assert np.isfinite(wav).all() and np.abs(wav - g["wav"]).max() <= 5e-5, float(np.abs(wav - g["wav"]).max())
+    again = m(torch.from_numpy(g["mel"]).cuda()).cpu().numpy()
+    assert np.array_equal(wav, again)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(1, 1), (1, 37), (3, 64)])
+def test_bigvgan_matches_oracle(B, T):
+    from oracle import bigvgan_oracle as BO
+    w = bvg_weights()
+    m = V.BigVGAN(V.AttrDict(V.BIGVGAN_BASE))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    m = m.cuda().eval()
+    mel = np.clip(synth.normalish("bvg_mel2", (B, 80, T), 57) * 1.5 - 5.0, -11.5, 2.5).astype(np.float32)
+    wav = m(torch.from_numpy(mel).cuda()).cpu().numpy()
+    with torch.no_grad():
+        ref = BO.generator({k: torch.from_numpy(v) for k, v in w.items()}, V.BIGVGAN_BASE, torch.from_numpy(mel)).numpy()
+    assert wav.shape == ref.shape == (B, 1, T * 256)
+    assert np.abs(wav - ref).max() <= 5e-5, float(np.abs(wav - ref).max())
+
+
+def test_bigvgan_rejects_per_layer_filters_and_large_model():
+    m = V.BigVGAN(V.AttrDict(V.BIGVGAN_BASE))
+    assert any(k.endswith("activations.3.act.beta") for k in m.state_dict())
+    with pytest.raises(ValueError):
+        V.Generator(V.AttrDict(dict(V.BIGVGAN_BASE, activation="relu")))
