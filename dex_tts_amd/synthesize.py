@@ -96,6 +96,28 @@ def decode(model: Diffusion, mu_y: torch.Tensor, y_lengths: torch.Tensor, n_time
     return out[:, :, :y_max]
 
 
+MAX_VALUE = 32768.0          # synthesize.py:13-14
+
+
+@torch.no_grad()
+def synthesize_tokens(model, vocoder, x: torch.Tensor, x_lengths: torch.Tensor, n_timesteps: int = 50, temperature: float = 1.5,
+                      spk: Optional[torch.Tensor] = None, length_scale: float = 1.0, style: Optional[dict] = None):
+    """synthesize.py:31-38 from the token sequence on (the text front-end - cleaners, CMU dictionary, ``intersperse`` - is the
+    reference's and stays on the host): ``model`` a ``dex_tts_amd.tts.GeDEXTTS`` / ``DeXTTS``, ``vocoder`` a
+    ``dex_tts_amd.vocoder.Generator``; DEX takes ``style = dict(ref, ref_lengths, sty, sty_lengths, lf0, lf0_lengths)``
+    (DEX-TTS/synthesize.py:47-95).  Returns (list of int16 waveforms cut to each utterance's length, y_dec [B,80,Ty], attn)."""
+    if style is not None:
+        y_enc, y_dec, attn = model(x, x_lengths, style["ref"], style["ref_lengths"], style["sty"], style["sty_lengths"], style["lf0"],
+                                   style["lf0_lengths"], n_timesteps=n_timesteps, temperature=temperature, spk=spk, length_scale=length_scale)
+    else:
+        y_enc, y_dec, attn = model(x, x_lengths, n_timesteps=n_timesteps, temperature=temperature, spk=spk, length_scale=length_scale)
+    wav = vocoder(y_dec).squeeze(1).clamp(-1, 1)                                          # [B, Ty * hop]
+    hop = wav.shape[-1] // y_dec.shape[-1]
+    y_len = model.encoder._last["y_len"].to(torch.int64).cpu()
+    audio = (wav.cpu().numpy() * MAX_VALUE).astype(np.int16)
+    return [audio[b, : int(y_len[b]) * hop] for b in range(audio.shape[0])], y_dec, attn
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
     ap.add_argument("--config", required=True, help="a reference base.yaml (GeDEX-TTS/config/*/base.yaml, DEX-TTS/config/*/base.yaml)")

@@ -91,3 +91,25 @@ def test_text_to_mel_equals_its_stages(which):
     # frames past an utterance's length carry nothing
     for b in range(2):
         assert float(enc_out[b, :, int(y_len[b]):].abs().max() if int(y_len[b]) < y_max else 0.0) == 0.0
+
+
+@pytest.mark.gpu
+def test_tokens_to_waveform():
+    """synthesize.py:31-38 end to end on the GPU: tokens -> text encoder -> alignment -> 10 sampler steps -> HiFi-GAN -> int16 audio."""
+    from dex_tts_amd import synthesize as SY, vocoder as V
+    m = tts.GeDEXTTS(model_cfg("gedex_lj"))
+    m.load_state_dict(full_state_dict(m, "gedex_lj"))
+    m = m.cuda().eval()
+    voc = V.Generator()
+    voc.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_vocoder_weights(V.param_shapes(V.HIFIGAN_V1)).items()})
+    voc = voc.cuda().eval()
+    tok, lengths = synth.make_text_inputs(2, 21, [21, 12], 149)
+    SY.seed_init(100)
+    audio, y_dec, attn = SY.synthesize_tokens(m, voc, torch.from_numpy(tok).cuda(), torch.from_numpy(lengths).cuda(), n_timesteps=10)
+    y_len = m.encoder._last["y_len"].cpu().numpy()
+    assert len(audio) == 2 and all(a.dtype == np.int16 for a in audio)
+    assert [len(a) for a in audio] == [int(n) * 256 for n in y_len]
+    assert torch.isfinite(y_dec).all() and all(np.abs(a.astype(np.int32)).max() > 0 for a in audio)
+    SY.seed_init(100)                                   # same seed, same waveform (bitwise)
+    audio2, _, _ = SY.synthesize_tokens(m, voc, torch.from_numpy(tok).cuda(), torch.from_numpy(lengths).cuda(), n_timesteps=10)
+    assert all(np.array_equal(a, b) for a, b in zip(audio, audio2))
