@@ -195,7 +195,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_lp_kernel(const Conv3P p) {
 #endif
     const int w0 = blockIdx.x * 32, h0 = blockIdx.y * TH;
     const int b = blockIdx.z / NSLICE, slice = blockIdx.z % NSLICE;
-    const int step = p.step ? *p.step : 0;
+    const int step = p.step;
     const float* X = p.X + (long)b * p.H * p.W * p.ldx + p.x_coff;
     const u16* Xh = reinterpret_cast<const u16*>(p.X) + (long)b * p.H * p.W * p.ldx + p.x_coff;   // XB: the input is bf16
     const float* mrow = p.mask + (long)b * p.mask_bstride;

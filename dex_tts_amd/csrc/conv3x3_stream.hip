@@ -75,7 +75,7 @@ __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, c
     const int t0 = blockIdx.y * tiles_per_wg;
     const int nt = min(tiles_per_wg, ntile_total - t0);
     const int hs = t0 * STR;
-    const int step = p.step ? *p.step : 0;
+    const int step = p.step;
     const float* X = p.X + (long)b * p.H * p.W * p.ldx + p.x_coff;
     const u16* Xh = reinterpret_cast<const u16*>(p.X) + (long)b * p.H * p.W * p.ldx + p.x_coff;      // XB: bf16 input
     const float* R = PRO2 ? p.pro_res + (long)b * p.H * p.W * SC : nullptr;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(SNT) void conv3x3_pp64_kernel(const Conv3P p, const
     const int t0 = sy * seg_tiles;
     const int nt = live ? min(seg_tiles, ntile_total - t0) : 0;
     const int hs = t0 * PR;
-    const int step = p.step ? *p.step : 0;
+    const int step = p.step;
     const float* X = p.X + (long)b * p.H * p.W * p.ldx + p.x_coff;
     const u16* Xh = reinterpret_cast<const u16*>(p.X) + (long)b * p.H * p.W * p.ldx + p.x_coff;      // XB: bf16 input
     const float* R = (PRO2 && !r2) ? p.pro_res + (long)b * p.H * p.W * SC : nullptr;

@@ -675,7 +675,7 @@ struct Runner {
     const DexSampleArgs* args;
     bool debug;
     int gn_idx = 0;
-    const int* sp = nullptr;        // device pointer to the current Euler-step index
+    int sp = 0;                     // index of the current network evaluation (a by-value launch argument of every kernel)
     gnfix_t* stats_base = nullptr;  // statistics arena of this step
     gnfix_t* stats_other = nullptr;   // arena to clear for the next step (eager mode), or null
     int fin_mode = 0;               // FinalP::mode of this network evaluation (Heun predictor / corrector)
@@ -1285,7 +1285,6 @@ int enqueue_heun(DexCtx* x, const DexSampleArgs* a, hipStream_t st) {
     Plan P; Dims d{a->B, a->T, a->Tr, a->Ts, E};
     make_plan(x, d, a->workspace_dev, P);
     Runner R{x, P, st, a->mask_dev, a->mu_dev, P.xbuf, a, false};
-    launch_iota(P.step_tab, E, st);
     launch_churn_tables(a->sigmas_dev, n, a->S_churn, a->S_min, a->S_max, a->S_noise, P.that, P.hstep, P.ncoef, st);
     launch_heun_expand(P.that, P.hstep, n, P.hsig, P.htab, st);
     R.prepare(P.hsig, E);
@@ -1298,7 +1297,7 @@ int enqueue_heun(DexCtx* x, const DexSampleArgs* a, hipStream_t st) {
     R.fin_htab = P.htab;
     for (int e = 0; e < E; ++e) {
         const bool corrector = (e & 1) != 0, last = (e == E - 1);
-        R.sp = P.step_tab + e; R.stats_base = arena[e & 1]; R.stats_other = arena[(e + 1) & 1];
+        R.sp = e; R.stats_base = arena[e & 1]; R.stats_other = arena[(e + 1) & 1];
         if (churn && !corrector)        // x_hat = x_cur + sqrt(t_hat^2 - t_cur^2) S_noise randn_like(x_cur), in place (edm.py:196)
             R.run("churn_noise", 2.0 * nx, 12.0 * nx, [&] { launch_add_noise(P.xbuf, a->noise_dev + (long)(e / 2) * nx, P.ncoef + e / 2, nx, st); });
         R.xcur = corrector ? P.xprime : P.xbuf;
@@ -1309,14 +1308,13 @@ int enqueue_heun(DexCtx* x, const DexSampleArgs* a, hipStream_t st) {
     return DEX_OK;
 }
 
-// ablation_sampler(solver='euler') — edm.py:186-208.  The step index comes from a device table and the GroupNorm statistics
+// ablation_sampler(solver='euler') — edm.py:186-208.  The step index is a launch argument and the GroupNorm statistics
 // alternate between two arenas; each step's last kernel clears the arena of the next step.
 int enqueue_euler(DexCtx* x, const DexSampleArgs* a, hipStream_t st) {
     Plan P; Dims d{a->B, a->T, a->Tr, a->Ts, a->n_steps};
     make_plan(x, d, a->workspace_dev, P);
     Runner R{x, P, st, a->mask_dev, a->mu_dev, P.xbuf, a, false};
-    launch_iota(P.step_tab, a->n_steps, st);
-    R.sp = P.step_tab;
+    R.sp = 0;
     const bool churn = a->S_churn > 0.f;
     const long nx = (long)a->B * 80 * a->T;
     if (churn) {        // the network sees t_hat_i, the update uses h_i = t_{i+1} - t_hat_i (edm.py:194-199)
@@ -1331,7 +1329,7 @@ int enqueue_euler(DexCtx* x, const DexSampleArgs* a, hipStream_t st) {
     gnfix_t* arena[2] = {P.stats, P.stats + P.stats_bytes / (long)sizeof(gnfix_t)};
     hipMemsetAsync(P.stats, 0, 2 * P.stats_bytes, st);
     for (int i = 0; i < a->n_steps; ++i) {
-        R.sp = P.step_tab + i; R.stats_base = arena[i & 1]; R.stats_other = arena[(i + 1) & 1];
+        R.sp = i; R.stats_base = arena[i & 1]; R.stats_other = arena[(i + 1) & 1];
         if (churn)          // x_hat = x_cur + sqrt(t_hat^2 - t_cur^2) S_noise randn_like(x_cur), in place (edm.py:196)
             R.run("churn_noise", 2.0 * nx, 12.0 * nx, [&] { launch_add_noise(P.xbuf, a->noise_dev + (long)i * nx, P.ncoef + i, nx, st); });
         R.step(nullptr, P.xbuf);
@@ -1378,9 +1376,8 @@ int dex_denoise_once(DexCtx* x, const DexDenoiseArgs* da, dex_stream_t stream) {
     make_plan(x, d, a->workspace_dev, P);
     x->taps.clear();
     Runner R{x, P, st, a->mask_dev, a->mu_dev, da->x_dev, a, true};
-    R.sp = P.step; R.stats_base = P.stats; R.stats_other = nullptr;
+    R.sp = 0; R.stats_base = P.stats; R.stats_other = nullptr;
     hipLaunchKernelGGL(set_sigma_pair, dim3(1), dim3(1), 0, st, a->sigmas_dev, P.sig2);
-    launch_step_reset(P.step, st);
     R.prepare(P.sig2, 1);
     R.step(a->out_dev, nullptr);
     HIPCHK(x, hipGetLastError());

@@ -191,7 +191,7 @@ void launch_in_fold(const InFoldP& p, hipStream_t st) {
 __global__ __launch_bounds__(256) void tiv_apply_kernel(const TivApplyP p) {
     __shared__ float sa[256], sb[256];
     const int tid = threadIdx.x, b = blockIdx.y;
-    const int step = p.step ? *p.step : 0;
+    const int step = p.step;
     if (tid < p.C) {
         float mean, rstd;
         in_mean_rstd(p.stats, (long)b * p.C + tid, p.npix, p.eps, mean, rstd);
@@ -223,7 +223,7 @@ void launch_tiv_apply(const TivApplyP& p, hipStream_t st) {
 
 __global__ void tv_row0_kernel(const TvRow0P p) {
     const int b = blockIdx.x, c = threadIdx.x;
-    const int step = p.step ? *p.step : 0;
+    const int step = p.step;
     if (p.zero_ptr) for (long i = (long)b * blockDim.x + c; i < p.zero_n; i += (long)gridDim.x * blockDim.x) p.zero_ptr[i] = 0.f;
     if (c < p.C) {
         p.K[(long)b * p.kvb + c] = p.k0[(long)step * p.C + c];

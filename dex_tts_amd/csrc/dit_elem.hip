@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const LnModP p) {
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long rows = (long)p.B * p.rows_per_batch;
     if (row >= rows) return;
-    const int step = p.step ? *p.step : 0;
+    const int step = p.step;
     const float* x = p.X + row * p.D;
     const int per = p.D >> 6;
     float v[8];

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
     const int N = p.rows_per_batch, tpb = (N + RC_ROWS - 1) / RC_ROWS;
     const int b = blockIdx.x / tpb, n0 = (blockIdx.x - b * tpb) * RC_ROWS;
     const long mb = (long)b * N;                               // first global row of this batch element
-    const int step = p.step ? *p.step : 0;
+    const int step = p.step;
     const float* ada = p.ada + (long)step * 6 * RC_H;
     const bool has_q = p.next_shift != nullptr;
 
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain64_kernel(const DitCha
     const int N = p.rows_per_batch, tpb = (N + 63) / 64;
     const int b = blockIdx.x / tpb, n0 = (blockIdx.x - b * tpb) * 64;
     const long mb = (long)b * N;
-    const int step = p.step ? *p.step : 0;
+    const int step = p.step;
     const float* ada = p.ada + (long)step * 6 * RC_H;
     const bool has_q = p.next_shift != nullptr;
     {

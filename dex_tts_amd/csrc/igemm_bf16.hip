@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void igemm_lp_ss_kernel(const IGemmP p) {
     const float* Ab = p.A + (long)b * p.a_bstride + p.a_coff;
     const float* mrow = p.inmask ? p.inmask + (long)b * p.mask_bstride : nullptr;
     const u16* Wb = reinterpret_cast<const u16*>(p.Wbf) + (long)b * p.w_bstride + (long)par * K * p.N;
-    const int step = p.step ? *p.step : 0;
+    const int step = p.step;
     const float* lsh = p.ln_shift ? p.ln_shift + (long)step * p.ln_step_stride : nullptr;
     const float* lsc = p.ln_scale ? p.ln_scale + (long)step * p.ln_step_stride : nullptr;
 
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void igemm_lp_nwalk_kernel(const IGemmP p) {
     const float* Ab = p.A + (long)b * p.a_bstride + p.a_coff;
     const float* mrow = p.inmask ? p.inmask + (long)b * p.mask_bstride : nullptr;
     const u16* Wb = reinterpret_cast<const u16*>(p.Wbf) + (long)b * p.w_bstride + (long)nt_first * BN * K;
-    const int step = p.step ? *p.step : 0;
+    const int step = p.step;
     const float* lsh = p.ln_shift ? p.ln_shift + (long)step * p.ln_step_stride : nullptr;
     const float* lsc = p.ln_scale ? p.ln_scale + (long)step * p.ln_step_stride : nullptr;
 

@@ -23,7 +23,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmP& p, f32x16 (&acc)[MT
     const int i = lane & 31, hh = lane >> 5;
     const int n = n0 + col0 + i;                 // column within the group
     const int ng = g * p.N + n;                  // global output channel
-    const int step = p.step ? *p.step : 0;
+    const int step = p.step;
     const float bias = p.bias ? p.bias[(long)b * p.bias_bstride + ng] : 0.f;
     const float gate = p.gate ? p.gate[(long)step * p.gate_step_stride + (long)ng * p.gate_nstride] : 1.f;
     const float* omask = p.outmask ? p.outmask + (long)b * p.mask_bstride : nullptr;

@@ -1,7 +1,8 @@
 // kernels.h — launch interfaces of the hand-written gfx950 kernels behind libdexamd.so.
 // Activations are channels-last fp32: element (b,h,w,c) at base[b*bstride + (h*W + w)*ld + coff + c].
-// "step" pointers are a device-resident Euler-step counter so one captured hipGraph of a step can be
-// replayed for every step: per-step conditioning tables are indexed as table[step*stride + ...].
+// "step" is the index of the network evaluation inside one sampler call: per-step conditioning tables are indexed as
+// table[step*stride + ...].  It is a by-value launch argument (the whole call is one hipGraph with a node per launch; round 1
+// replayed a one-step graph and read the index from device memory - a dependent load at the head of every kernel).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -50,7 +51,7 @@ struct IGemmP {
                                                        // the vocoder's "x = leaky_relu(x); x = conv(x)", hifigan/models.py:98-103)
     const float* gate; int gate_nstride; long gate_step_stride;
     const float* res; int ldres; long res_bstride; int res_coff;
-    const int* step;
+    int step;
     int unpatch_s, unpatch_C;                          // >0: scatter rows (f,w) x cols (p1,p2,c) -> NHWC image
     int parity;                                        // 1: blockIdx.z = b*4 + (ph*2+pw): ConvTranspose2d(4,2,1) as four 2x2-tap
                                                        // sub-convolutions in ONE launch (off/oh0/ow0 = parity, weights += par*K*N)
@@ -86,7 +87,7 @@ struct Conv3P {
     // fused 1x1 shortcut of the ResnetBlock (res_conv(x * mask), diffusion.py:70): a second output computed from the
     // patch's centre tap; res_w = bf16 [Cout][Cin], res_y = [H*W][Cout] fp32
     const void* res_w; const float* res_b; float* res_y;
-    const int* step; gnfix_t* gn_stats; int B;
+    int step; gnfix_t* gn_stats; int B;
     long long* dbg;                                          // optional phase timestamps (tools/kbench)
     // raw conv outputs that only a GroupNorm prologue reads next (h1, h2 of a ResnetBlock) may live in HBM as bf16:
     // x_bf16: X is bf16 [.. ldx] (PRO / PRO2 forms only); y_bf16: Y is written as bf16.  Statistics stay fp32.
@@ -107,7 +108,7 @@ struct FirstConvP {
     const float* mask; int B, H, T, planes, C;
     const float* W3; const float* b3;                     // [planes*9][C], [C]
     const float* W1; const float* b1;                     // [planes][C], [C]
-    const float* scal; int scal_stride; const int* step;  // per-step scalars; scal[step*stride + 2] = c_in
+    const float* scal; int scal_stride; int step;  // per-step scalars; scal[step*stride + 2] = c_in
     float* h1; float* res;                                // [B,H,T,C] each
     int h1_bf16;                                          // h1 stored as bf16 (1) / fp16 (2): its only reader is the next conv's GN prologue
     gnfix_t* gn_stats;                                    // fused GroupNorm partials of h1 (8 groups, slot-spread) or null
@@ -124,7 +125,7 @@ struct GnApplyP {
     float* Y; int ldy; long yb; int y_coff;
     int npix, W, C, groups; const gnfix_t* stats; const float* gamma; const float* beta;
     const float* mask; int mask_ws; long mask_bstride;
-    const float* tadd; long tadd_step_stride; const int* step;
+    const float* tadd; long tadd_step_stride; int step;
     const float* res; int ldres; long resb; int res_under_mask;   // 1: y = mask*(mish + tadd + res)
     int B;
 };
@@ -138,7 +139,7 @@ struct FinalP {
     const float* xcur;                                    // [B,80,T] current sampler state (x_hat)
     float* denoised;                                      // optional D_x out
     float* xnext;                                         // optional Euler update out (may alias xcur)
-    const float* scal; int scal_stride; const int* step;
+    const float* scal; int scal_stride; int step;
     float* zero_ptr; long zero_n;                         // optional: clear the OTHER parity's GroupNorm statistics arena
     int B;
     // Heun (edm.py:207-214).  mode 0: Euler update with h = sigma_next - sigma (or htab[step] when given);
@@ -212,7 +213,7 @@ void launch_group_pad(const float* src, float* dst, long rows, int G, int cg, in
 
 // LayerNorm(eps 1e-6, no affine) + modulate (dit.py:78-79,288-289,330)
 struct LnModP { const float* X; float* Y; int rows_per_batch; int D; const float* shift; const float* scale;
-                long step_stride; const int* step; int B; };
+                long step_stride; int step; int B; };
 void launch_ln_mod(const LnModP& p, hipStream_t st);
 
 // Row-local remainder of a DiT block + the next block's qkv projection in one launch (dit_rowchain.hip; bf16 mode,
@@ -226,7 +227,7 @@ struct DitChainP { const float* O; int ksplit; long o_sstride; const float* ml; 
                                                                         // buffer set than the one written (workgroups of one launch overlap)
                    int qkv_only;                                        // 1: only LN+modulate+qkv of X (first block)
                    int attn_inline;                                     // 1: the attention core runs inside this launch (O / ml unused)
-                   const int* step; int M; int B; long long* dbg; };   // M = B * rows_per_batch
+                   int step; int M; int B; long long* dbg; };   // M = B * rows_per_batch
 bool dit_rowchain_supported(int hidden, int mlp_hidden);
 // Softmax attention on the row chain's bf16 operands (2 heads x 128): no staging, K / V^T / Q fragments are read
 // straight from global memory.  O: fp32 [ksplit][B][N][256] partials + ml (merged by the next row chain launch).
@@ -293,10 +294,10 @@ struct InFoldP { const gnfix_t* stats; int npix; float eps; const float* Wq; int
 void launch_in_fold(const InFoldP& p, hipStream_t st);
 // TIV: y = IN2d(x)*s + m  (ref_encoder.py:271); s,m indexed [step][b][C]
 struct TivApplyP { const float* X; int ld; long xb; float* Y; int ldy; long yb; int npix; int C; const gnfix_t* stats;
-                   float eps; const float* s_tab; const float* m_tab; const int* step; int B; };
+                   float eps; const float* s_tab; const float* m_tab; int step; int B; };
 void launch_tiv_apply(const TivApplyP& p, hipStream_t st);
 // write per-step time-token rows into K/V row 0 (ref_encoder.py:157)
-struct TvRow0P { const float* k0; const float* v0; const int* step; float* K; float* V; long kvb; int C; int B;
+struct TvRow0P { const float* k0; const float* v0; int step; float* K; float* V; long kvb; int C; int B;
                  float* zero_ptr; long zero_n; };          // optional: clear the IN2d statistics for their next use
 void launch_tv_row0(const TvRow0P& p, hipStream_t st);
 // transpose [B,C,L] -> [B, L(+row_off), C]

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void first_conv_kernel(const FirstConvP p) {
     const int b = blockIdx.y;
     const long npu = (long)p.H * p.T;                          // pixels per utterance
     const int cq = tid % TPP;                                 // channels [cq*16, cq*16+16)
-    const int step = p.step ? *p.step : 0;
+    const int step = p.step;
     const float c_in = p.scal[step * p.scal_stride + 2];
     const float* mrow = p.mask + (long)b * p.T;
     const float* pl[2] = {p.mu + (long)b * p.H * p.T, p.x + (long)b * p.H * p.T};
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void first_conv_mfma_kernel(const FirstConvP p
     const int i = lane & 31, hh = lane >> 5;
     const int b = blockIdx.y;
     const long npu = (long)p.H * p.T;
-    const int step = p.step ? *p.step : 0;
+    const int step = p.step;
     const float c_in = p.scal[step * p.scal_stride + 2];
     const float* mrow = p.mask + (long)b * p.T;
     const float* plane = (hh == 0 ? p.mu : p.x) + (long)b * npu;           // this lane's K index = its plane
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnApplyP p) {
     const int C4 = p.C >> 2, cpg = p.C / p.groups;
     gn_mean_rstd(p.stats, b, p.groups, smean, srstd, tid);
     __syncthreads();
-    const int step = p.step ? *p.step : 0;
+    const int step = p.step;
     const long total = (long)p.npix * C4;
     const float* X = p.X + (long)b * p.xb;
     float* Y = p.Y + (long)b * p.yb + p.y_coff;
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void final_kernel(const FinalP p) {
     const int cpg = p.C / p.groups;
     gn_mean_rstd(p.stats, b, p.groups, smean, srstd, tid);
     __syncthreads();
-    const int step = p.step ? *p.step : 0;
+    const int step = p.step;
     const float* sc = p.scal + (long)step * p.scal_stride;
     const float sigma = sc[0], sigma_next = sc[1], c_skip = sc[3], c_out = sc[4];
     const float* X = p.X + (long)b * p.xb;
