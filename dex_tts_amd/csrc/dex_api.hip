@@ -470,6 +470,7 @@ extern "C" int dex_ctx_finalize(DexCtx* x, dex_stream_t stream) {
         if (wt) {
             hipLaunchKernelGGL(pack_convt_kernel, dim3(256), dim3(256), 0, st, P.raw(p + ".3.conv.weight"), wt, ci, ci);
             P.twin(wt, 4, 4 * ci, ci);
+            if (convt_up_supported(ci, 1, 1, ci, ci)) for (int par = 0; par < 4; ++par) P.frag(wt + (long)par * 4 * ci * ci, 4 * ci, ci);   // convt_up.hip
         }
         x->up_us_w.push_back(wt); x->up_us_b.push_back(P.raw(p + ".3.conv.bias"));
     }
@@ -1179,7 +1180,18 @@ struct Runner {
                 g.a_lp = t5_lp ? lpk : 0;
                 up_out_lp = lp_inter && j == ns - 2 && x->lp_of().count(x->up_us_w[j]) && x->lp_of().count(x->fin_w) && conv3x3_res2_form(80, P.d.T, B);
                 g.c_lp = up_out_lp ? lpk : 0;
-                gemm("upsample_convT", g);
+                static const bool strip_off = [] { const char* e = getenv("DEX_CONVT_UP"); return e && e[0] == '0'; }();
+                if (x->lp() && x->frag_of().count(x->up_us_w[j]) && !strip_off && convt_up_supported(s.C, s.H, s.W, s.C, ldd)) {
+                    ConvTUpP u{};
+                    u.X = s.attn_out; u.a_lp = g.a_lp; u.ldx = s.C; u.xb = (long)s.H * s.W * s.C; u.x_coff = 0; u.H = s.H; u.W = s.W;
+                    for (int par = 0; par < 4; ++par) u.Wfrag[par] = x->frag_of().at(x->up_us_w[j] + (long)par * 4 * s.C * s.C);
+                    u.bias = x->up_us_b[j];
+                    u.Y = dst; u.c_lp = g.c_lp; u.ldy = ldd; u.y_coff = 0;
+                    u.inmask = mask; u.inmask_ws = s.mask_ws; u.mask_bstride = P.d.T; u.B = B;
+                    const double M = 4.0 * s.H * s.W * B;
+                    run("upsample_convT", 2.0 * M * s.C * 4 * s.C, M * s.C * (g.c_lp ? 2.0 : 4.0) + 0.25 * M * s.C * (g.a_lp ? 2.0 : 4.0),
+                        [&] { launch_convt_up(u, x->precision, st); });
+                } else gemm("upsample_convT", g);
             }
         }
         tap("up_out", P.up_out, (long)B * 80 * P.d.T, c.dim, c.dim);

@@ -68,6 +68,17 @@ struct IGemmP {
 };
 void launch_igemm(const IGemmP& p, int precision, hipStream_t st);
 
+// Upsample = ConvTranspose2d(64, 64, 4, 2, 1) on x * mask as a strip-walking kernel (convt_up.hip, reduced-precision modes).
+// X [B][H][W][ldx] (fp32, or 16-bit when a_lp), Y [B][2H][2W][ldy] (fp32, or 16-bit when c_lp); strides / offsets in elements.
+// Wfrag[par] = the parity's matrix [K = (th*2+tw)*64 + ci][64 co] (pack_convt_kernel) in MFMA fragment order (launch_pack_lp_frag).
+struct ConvTUpP { const void* X; int a_lp; int ldx; long xb; int x_coff; int H, W;
+                  const void* Wfrag[4]; const float* bias;
+                  void* Y; int c_lp; int ldy; int y_coff;
+                  const float* inmask; int inmask_ws; long mask_bstride; int B;
+                  int nseg, rows_per_wg; };               // filled by the launcher
+bool convt_up_supported(int C, int H, int W, int ldx, int ldy);
+void launch_convt_up(const ConvTUpP& p, int precision, hipStream_t st);
+
 // Patch-staged 3x3/s1/p1 Block convolution on bf16 MFMA (conv3x3_bf16.hip).  Input transform while staging:
 // x*mask, or mask*(Mish(GroupNorm(x)) + tadd[step]) when pro_stats != null (the fused tail of block1).
 struct Conv3P {

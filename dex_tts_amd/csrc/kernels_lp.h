@@ -20,6 +20,9 @@ bool conv3x3_plain_lp_in_supported(int H, int W, int B, int Cin, int Cout);
 bool conv3x3_res2_form(int H, int W, int B);          // the ping-pong strip form (the only one that implements Conv3P::res2_*) takes this grid
 // implicit GEMM on the low-precision MFMA (igemm_bf16.hip)
 void launch_igemm_lp(const IGemmP& p, hipStream_t st);
+// Upsample (ConvTranspose2d 4/2/1) strip kernel (convt_up.hip)
+bool convt_up_supported(int C, int H, int W, int ldx, int ldy);
+void launch_convt_up(const ConvTUpP& p, hipStream_t st);
 // softmax attention (attention_bf16.hip: fp32 q/k/v in HBM; attention_direct.hip: fragment-ordered operands)
 void launch_attention_lp(const AttnP& p, hipStream_t st);
 void launch_attention_direct(const AttnDirectP& p, hipStream_t st);
