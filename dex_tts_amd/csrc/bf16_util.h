@@ -43,6 +43,23 @@ __device__ __forceinline__ float mul_pinned(float x, float y) {
 // Mish prologues of the convolutions are VALU-bound at batch size (phase counters: the conversion of a row chunk costs
 // more cycles than its 72 MFMAs), so they run on pairs; only v_exp_f32 / v_rcp_f32 / the clamp stay per value.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+// DEX_NO_PK (per translation unit): the same arithmetic on single values.  A packed fp32 VALU instruction beside a wave's
+// MFMAs is not free the way a plain one is: tools/mfmabench measures 32.1 cycles per v_mfma_f32_32x32x16_bf16 alone, 32.8 with
+// two v_fma_f32 per MFMA, 43.3 with ONE v_pk_fma_f32 per MFMA - kernels whose prologue arithmetic runs on the SIMDs that are
+// issuing MFMAs (the ping-pong strip convolution, the weights-in-registers convolution) take the single-value form.
+#ifdef DEX_NO_PK
+__device__ __forceinline__ f32x2 pk_fma_pinned(f32x2 x, f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm volatile("v_fma_f32 %0, %2, %4, %6\n\tv_fma_f32 %1, %3, %5, %7" : "=&v"(r.x), "=&v"(r.y) : "v"(x.x), "v"(x.y), "v"(a.x), "v"(a.y), "v"(b.x), "v"(b.y));
+    return r;
+}
+__device__ __forceinline__ float mish1_add(float t, float add) {
+    const float e = __builtin_amdgcn_exp2f(fminf(t * 1.44269504088896f, 28.8539008f));
+    const float n = e * (e + 2.f);
+    return fmaf(t, n * __builtin_amdgcn_rcpf(n + 2.f), add);
+}
+__device__ __forceinline__ f32x2 mish2_add(f32x2 t, f32x2 add) { f32x2 r; r.x = mish1_add(t.x, add.x); r.y = mish1_add(t.y, add.y); return r; }
+#else
 __device__ __forceinline__ f32x2 pk_fma_pinned(f32x2 x, f32x2 a, f32x2 b) {     // opaque: stays where it is written (see fma_pinned)
     f32x2 r;
     asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(a), "v"(b));
@@ -58,6 +75,7 @@ __device__ __forceinline__ f32x2 mish2_add(f32x2 t, f32x2 add) {
     f32x2 r; r.x = __builtin_amdgcn_rcpf(d.x); r.y = __builtin_amdgcn_rcpf(d.y);
     return t * (n * r) + add;
 }
+#endif
 
 __device__ __forceinline__ unsigned mov_pinned(unsigned x) {
     unsigned r;

@@ -84,6 +84,7 @@ void launch_convt_up(const ConvTUpP& p, int precision, hipStream_t st);
 struct Conv3P {
     const float* X; int ldx; int x_coff; int H, W, Cin, Cout;
     const void* Wbf; const float* bias; float* Y;            // bf16 [Cout][9*Cin]; Y is [B,H,W,Cout] contiguous
+    const void* Wfrag;                                       // the same weights in MFMA fragment order ([K = 9*Cin][Cout] through launch_pack_lp_frag), or null
     const float* mask; int mask_ws; long mask_bstride;
     const gnfix_t* pro_stats; const float* pro_gamma; const float* pro_beta; const float* pro_tadd;   // tadd may be null
     // second prologue form (pro_res != null): the input is the preceding ResnetBlock's tail,

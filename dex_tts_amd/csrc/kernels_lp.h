@@ -15,6 +15,8 @@ bool conv3x3_bf16_xb_supported(int Cin, int Cout);    // x_bf16 form (low-precis
 void launch_conv3x3_lp(const Conv3P& p, hipStream_t st);
 int conv3x3_stream_tiles(const Conv3P& p);            // iterations per workgroup of the throughput form, 0 = not applicable
 void launch_conv3x3_stream(const Conv3P& p, int tiles_per_wg, hipStream_t st);
+bool conv3x3_regw_form(const Conv3P& p);                 // weights-in-registers strip form (conv3x3_regw.hip) takes this launch
+void launch_conv3x3_regw(const Conv3P& p, hipStream_t st);
 bool linattn_out2_lp_out_supported(int npix, int B);
 bool conv3x3_plain_lp_in_supported(int H, int W, int B, int Cin, int Cout);
 bool conv3x3_res2_form(int H, int W, int B);          // the ping-pong strip form (the only one that implements Conv3P::res2_*) takes this grid
