@@ -33,12 +33,22 @@ LP_SOURCES = ("conv3x3_bf16.hip", "conv3x3_stream.hip", "igemm_bf16.hip", "atten
 FILE_FLAGS = {"conv3x3_regw.hip": ["-fno-slp-vectorize"]}
 
 
+def _env_file_flags():
+    """DEX_FILE_FLAGS="a.hip=-DX -fY;b.hip=-DZ": extra per-file flags for experiments (tools/pkab.sh)."""
+    out = {}
+    for item in os.environ.get("DEX_FILE_FLAGS", "").split(";"):
+        if "=" in item:
+            f, fl = item.split("=", 1)
+            out[f.strip()] = fl.split()
+    return out
+
+
 def sources():
     """(source file, extra flags, object suffix) per compilation."""
     out = []
     for f in sorted(os.listdir(CSRC)):
         if f.endswith(".hip"):
-            ff = FILE_FLAGS.get(f, [])
+            ff = FILE_FLAGS.get(f, []) + _env_file_flags().get(f, [])
             out.append((f, list(ff), ""))
             if f in LP_SOURCES:
                 out.append((f, ["-DDEX_LP_F16", *ff], ".f16"))

@@ -42,7 +42,15 @@ __device__ __forceinline__ float mul_pinned(float x, float y) {
 // Packed fp32 pairs (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two lanes' worth of fp32 per VALU issue).  The GroupNorm +
 // Mish prologues of the convolutions are VALU-bound at batch size (phase counters: the conversion of a row chunk costs
 // more cycles than its 72 MFMAs), so they run on pairs; only v_exp_f32 / v_rcp_f32 / the clamp stay per value.
+#ifdef DEX_NO_PK
+struct f32x2 { float x, y; };      // same layout, single-value arithmetic
+__device__ __forceinline__ f32x2 operator*(f32x2 a, f32x2 b) { return f32x2{a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ f32x2 operator+(f32x2 a, f32x2 b) { return f32x2{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ f32x2 operator*(f32x2 a, float b) { return f32x2{a.x * b, a.y * b}; }
+__device__ __forceinline__ f32x2 operator+(f32x2 a, float b) { return f32x2{a.x + b, a.y + b}; }
+#else
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#endif
 // DEX_NO_PK (per translation unit): the same arithmetic on single values.  A packed fp32 VALU instruction beside a wave's
 // MFMAs is not free the way a plain one is: tools/mfmabench measures 32.1 cycles per v_mfma_f32_32x32x16_bf16 alone, 32.8 with
 // two v_fma_f32 per MFMA, 43.3 with ONE v_pk_fma_f32 per MFMA - kernels whose prologue arithmetic runs on the SIMDs that are
