@@ -213,7 +213,8 @@ void launch_dwconv_silu(const DwConvP& p, hipStream_t st);
 // Direct grouped 16x16 positional convolution (pos_conv.hip): X = patch embedding [B][Hf][Wt][hid] fp32, Wf = bf16
 // weights in MFMA fragment order per group ([g][tap][ks][lane][8], launch_pack_lp_frag of each group's [K][32]
 // matrix), Y = raw convolution sums [B][Hf*Wt][hid].
-struct PosConvP { const float* X; const void* Wf; float* Y; int Hf, Wt, hid, G, B; };
+struct PosConvP { const float* X; const void* Wf; float* Y; int Hf, Wt, hid, G, B;
+                  int ncol; };      // filled by the launcher: 1 = the last column is computed by column workgroups (pos_conv.hip)
 bool pos_conv_direct_supported(int hid, int groups, int kernel, int Hf);
 void launch_pos_conv_direct(const PosConvP& p, int precision, hipStream_t st);
 struct PosFinishP { const float* part; int nsplit; long split_stride; const float* bias; const float* emb;

@@ -10,7 +10,14 @@
 // straight from L2 into MFMA B-operand registers through a 4-deep register ring (weights are host-packed in
 // fragment order, 1 KB contiguous per wave per K-step); the waves' accumulators are summed through LDS at the end.
 // Output: raw convolution sums [B][N][hid]; bias + GELU + the mean over frequency stay in pos_finish (dit_elem.hip).
+//
+// Column workgroups (p.ncol > 0).  The token grids of the shipped configs are 65 columns wide (T/patch + 1): as 32-column
+// tiles every row needs a third tile for ONE column, and as row chunks a whole extra workgroup that streams the row's 400 KB
+// of weights for it.  With ncol = 1 the row workgroups cover the first Wt - 1 columns and one extra workgroup per (batch,
+// group) computes the LAST column of all rows as a single tile whose 32 rows are the token rows ho (lane stride = one patch
+// row of 17 positions: the chunk swizzle below stays conflict-free); its taps are the 16 x 9 with a column inside the grid.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "kernels.h"
 #include "lp_util.h"
 #include "kernels_lp.h"
@@ -28,8 +35,8 @@ constexpr int KP = 16, PAD = 8, CG = 32, LDP = CG;         // LDS pixel = 64 B, 
                                                             // then cover all 64 banks for any fixed chunk (conflict-free b128)
 }
 
-template <int CT>
-__global__ __launch_bounds__(256) void pos_conv_direct_kernel(const PosConvP p) {
+template <int CT, bool COL>
+__device__ __forceinline__ void pos_conv_body(const PosConvP& p, int rest) {
     constexpr int CW = 32 * CT, PW = CW + KP - 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_pc[];
     u16* patch = reinterpret_cast<u16*>(smem_pc);          // [nrows][PW][LDP]
@@ -39,15 +46,20 @@ __global__ __launch_bounds__(256) void pos_conv_direct_kernel(const PosConvP p) 
     // the group index lives in the low bits — an XCD then only ever fetches ONE group's 512 KB of weights (with the
     // group in grid.z every XCD pulled all 4 MB: PMC FETCH_SIZE showed 38 MB per launch at B=1).
     const int Hf = p.Hf, Wt = p.Wt;
-    const int nchunk = (Wt + CW - 1) / CW;
+    const int Wrow = Wt - p.ncol;                                           // columns covered by the row workgroups
+    const int nchunk = (Wrow + CW - 1) / CW;
     const int g = blockIdx.x % p.G;
-    int rest = blockIdx.x / p.G;
-    const int w0 = (rest % nchunk) * CW; rest /= nchunk;
-    const int ho = rest % Hf, b = rest / Hf;
-    const int hi_lo = max(0, ho - PAD), hi_hi = min(Hf, ho + PAD);          // input rows [hi_lo, hi_hi)
+    constexpr bool col = COL;                                               // a column workgroup (see the header)
+    constexpr int CPW = KP + 1, CKW = PAD + 1;                              // its patch row stride (positions) and live kw count
+    int w0, ho, b;
+    if (col) { b = rest - nchunk * Hf * p.B; ho = 0; w0 = Wt - 1; }
+    else { w0 = (rest % nchunk) * CW; rest /= nchunk; ho = rest % Hf; b = rest / Hf; }
+    const int hi_lo = col ? -PAD : max(0, ho - PAD), hi_hi = col ? Hf + PAD - 1 : min(Hf, ho + PAD);   // input rows [hi_lo, hi_hi)
     const int nrows = hi_hi - hi_lo;
-    const int kh_lo = hi_lo - ho + PAD;                                     // kh of input row hi: hi - ho + PAD
-    const int ntaps = nrows * KP;                                           // multiple of 16: every wave gets ntaps/4
+    const int kh_lo = col ? 0 : hi_lo - ho + PAD;                           // kh of input row hi: hi - ho + PAD
+    const int ntaps = col ? KP * CKW : nrows * KP;                          // multiple of 16: every wave gets ntaps/4
+    constexpr int tdiv = col ? CKW : KP;                                    // tap t = (kh_lo + t / tdiv, t % tdiv)
+    constexpr int pw = col ? CPW : PW;                                      // patch row stride
 
     // ---- weight ring: taps wave, wave+4, wave+8, wave+12 in flight before the patch is staged
     const u32x4* Wf = reinterpret_cast<const u32x4*>(p.Wf) + (long)g * (KP * KP * 2 * 64) + lane;
@@ -55,14 +67,14 @@ __global__ __launch_bounds__(256) void pos_conv_direct_kernel(const PosConvP p) 
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
         const int t = wave + 4 * d;                         // < 16 <= ntaps
-        const int tap = (kh_lo + t / KP) * KP + (t % KP);
+        const int tap = (kh_lo + t / tdiv) * KP + (t % tdiv);
         wr[d][0] = Wf[(tap * 2 + 0) * 64];
         wr[d][1] = Wf[(tap * 2 + 1) * 64];
     }
     // ---- stage the patch: item = (row, patch column, 8-channel chunk); zero outside the token grid
     {
         const float* X = p.X + ((long)b * Hf * Wt) * p.hid + g * CG;
-        const int items = nrows * PW * 4;
+        const int items = nrows * pw * 4;
         for (int it0 = 0; it0 < items; it0 += 256 * 9) {
             float4 f0[9], f1[9];
             bool ok[9];
@@ -70,10 +82,10 @@ __global__ __launch_bounds__(256) void pos_conv_direct_kernel(const PosConvP p) 
             for (int q = 0; q < 9; ++q) {
                 const int it = min(it0 + tid + 256 * q, items - 1);
                 const int c8 = (it & 3) * 8, px = it >> 2;
-                const int pc = px % PW, pr = px / PW;
-                const int wi = w0 + pc - PAD;
-                ok[q] = (unsigned)wi < (unsigned)Wt;
-                const float* src = X + ((long)(hi_lo + pr) * Wt + (ok[q] ? wi : 0)) * p.hid + c8;
+                const int pc = px % pw, pr = px / pw;
+                const int wi = w0 + pc - PAD, hi = hi_lo + pr;
+                ok[q] = (unsigned)wi < (unsigned)Wt && (unsigned)hi < (unsigned)Hf;
+                const float* src = X + ((long)(ok[q] ? hi : 0) * Wt + (ok[q] ? wi : 0)) * p.hid + c8;
                 f0[q] = *reinterpret_cast<const float4*>(src);
                 f1[q] = *reinterpret_cast<const float4*>(src + 4);
             }
@@ -104,12 +116,14 @@ __global__ __launch_bounds__(256) void pos_conv_direct_kernel(const PosConvP p) 
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const int t = wave + 4 * (n0 + d);
-            const int pr = t / KP, kw = t % KP;
-            const int px = pr * PW + i + kw;                // patch pixel of column tile 0 (tile ct: + 32*ct, same swizzle phase)
+            const int pr = t / tdiv, kw = t % tdiv;
+            // patch pixel of column tile 0 (tile ct: + 32*ct, same swizzle phase); column workgroup: lane = token row
+            const int px = col ? (i + pr) * CPW + kw : pr * PW + i + kw;
             const lp8 b0 = __builtin_bit_cast(lp8, wr[d][0]);
             const lp8 b1 = __builtin_bit_cast(lp8, wr[d][1]);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
+                if (ct > 0 && col) break;                     // (one tile)
                 const int sw = (px >> 2) & 3;                 // (px + 32*ct) >> 2 has the same low two bits
                 const u16* ap = patch + (long)(px + 32 * ct) * LDP;
                 const lp8 a0 = *reinterpret_cast<const lp8*>(ap + ((hh ^ sw) * 8));
@@ -118,7 +132,7 @@ __global__ __launch_bounds__(256) void pos_conv_direct_kernel(const PosConvP p) 
                 acc[ct] = DEX_MFMA_LP(a1, b1, acc[ct], 0, 0, 0);
             }
             const int tn = min(t + 16, ntaps - 4 + wave);   // refill (clamped re-read at the tail, never consumed)
-            const int tap = (kh_lo + tn / KP) * KP + (tn % KP);
+            const int tap = (kh_lo + tn / tdiv) * KP + (tn % tdiv);
             wr[d][0] = Wf[(tap * 2 + 0) * 64];
             wr[d][1] = Wf[(tap * 2 + 1) * 64];
         }
@@ -132,15 +146,32 @@ __global__ __launch_bounds__(256) void pos_conv_direct_kernel(const PosConvP p) 
         for (int r = 0; r < 16; ++r) red[((wave * CT + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + i] = acc[ct][r];
     lds_barrier();
     float* Y = p.Y + ((long)b * Hf * Wt + (long)ho * Wt) * p.hid + g * CG;
+    if (col) {                                              // tile row = token row ho, one column
+        for (int idx = tid; idx < 1024; idx += 256) {
+            const int n = idx & 31, row = idx >> 5;
+            if (row < Hf)
+                Y[((long)row * Wt + w0) * p.hid + n] = (red[((0 * CT) * 32 + row) * 33 + n] + red[((1 * CT) * 32 + row) * 33 + n]) +
+                                                        (red[((2 * CT) * 32 + row) * 33 + n] + red[((3 * CT) * 32 + row) * 33 + n]);
+        }
+        return;
+    }
     for (int idx = tid; idx < CT * 1024; idx += 256) {
         const int n = idx & 31, row = (idx >> 5) & 31, ct = idx >> 10;
         const int w = w0 + ct * 32 + row;
-        if (w < Wt) {
+        if (w < Wrow) {
             const float v = (red[((0 * CT + ct) * 32 + row) * 33 + n] + red[((1 * CT + ct) * 32 + row) * 33 + n]) +
                             (red[((2 * CT + ct) * 32 + row) * 33 + n] + red[((3 * CT + ct) * 32 + row) * 33 + n]);
             Y[(long)w * p.hid + n] = v;
         }
     }
+}
+
+template <int CT>
+__global__ __launch_bounds__(256) void pos_conv_direct_kernel(const PosConvP p) {
+    const int rest = blockIdx.x / p.G;
+    const int nrow_wgs = ((p.Wt - p.ncol + 32 * CT - 1) / (32 * CT)) * p.Hf * p.B;
+    if (rest >= nrow_wgs) pos_conv_body<CT, true>(p, rest);                // (workgroup-uniform)
+    else pos_conv_body<CT, false>(p, rest);
 }
 
 bool pos_conv_direct_supported(int hid, int groups, int kernel, int Hf) {
@@ -154,28 +185,39 @@ static void launch_pc(const PosConvP& p, hipStream_t st) {
     size_t lds = (size_t)nrows * PW * LDP * sizeof(u16);
     const size_t lds_red = (size_t)4 * CT * 32 * 33 * sizeof(float);
     if (lds < lds_red) lds = lds_red;
+    const size_t lds_col = p.ncol ? (size_t)(32 + 2 * PAD - 1) * (KP + 1) * LDP * sizeof(u16) : 0;     // (lanes past the last token row read, and discard, up to row 31 + 15)
+    if (lds < lds_col) lds = lds_col;
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&pos_conv_direct_kernel<CT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    dim3 grid((unsigned)(((p.Wt + 32 * CT - 1) / (32 * CT)) * p.Hf * p.B * p.G));
+    dim3 grid((unsigned)((((p.Wt - p.ncol + 32 * CT - 1) / (32 * CT)) * p.Hf + (p.ncol ? 1 : 0)) * p.B * p.G));
     hipLaunchKernelGGL(pos_conv_direct_kernel<CT>, grid, dim3(256), lds, st, p);
 }
 
-void launch_pos_conv_direct(const PosConvP& p, hipStream_t st) {
+void launch_pos_conv_direct(const PosConvP& p0, hipStream_t st) {
+    PosConvP p = p0;
+    // one live column in the last 32-column tile (Wt = 65 in every shipped config at the BASELINE shapes) and enough row
+    // workgroups that the extra column workgroups are noise: the column form (see the header).  DEX_POS_COL=0 disables it.
+    static const bool col_off = [] { const char* e = getenv("DEX_POS_COL"); return e && e[0] == '0'; }();
+    p.ncol = (!col_off && p.Wt > 32 && p.Wt % 32 == 1 && p.Hf <= 32 && (long)p.Hf * p.B * p.G >= 512) ? 1 : 0;
     // widest chunk (fewest halo columns) whose patch still lets two workgroups share a CU (three when the grid is
     // large), but never so wide that a small batch leaves CUs idle.  Measured (us, CT = 3 / 2 / 1):
     // GeDEX B=32 (10 rows) 94 / 124 / 132;  DEX B=32 (20 rows) 381 / 348 / 321;  DEX B=1 39 / 27 / 28.
-    const int tiles = (p.Wt + 31) / 32;
+    const int tiles = (p.Wt - p.ncol + 31) / 32;
     const long rows = (long)p.Hf * p.B * p.G;
     const int nrows = p.Hf < 2 * PAD ? p.Hf : 2 * PAD;
     auto lds_of = [&](int c) { return (long)nrows * (32 * c + KP - 1) * LDP * 2; };
     auto wgs_of = [&](int c) { return rows * ((tiles + c - 1) / c); };
     int ct = tiles >= 3 ? 3 : tiles;
     while (ct > 1 && lds_of(ct) > 80 * 1024) --ct;
-    if (wgs_of(ct) >= 2048) while (ct > 1 && lds_of(ct) > 53 * 1024) --ct;
+    // (with column workgroups the two remaining tiles of a row stay ONE workgroup - half the weight streams - although its patch
+    // then allows two, not three, workgroups per CU: DEX B=32 166 vs 210 us, GeDEX B=32 66 vs 85)
+    if (wgs_of(ct) >= 2048 && !(p.ncol && tiles == 2)) while (ct > 1 && lds_of(ct) > 53 * 1024) --ct;
     while (ct > 1 && wgs_of(ct) < 192) --ct;
+    static const int ct_env = [] { const char* e = getenv("DEX_POS_CT"); return e ? atoi(e) : 0; }();
+    if (ct_env >= 1 && ct_env <= 3 && ct_env <= tiles) ct = ct_env;
     if (ct == 3) launch_pc<3>(p, st);
     else if (ct == 2) launch_pc<2>(p, st);
     else launch_pc<1>(p, st);
