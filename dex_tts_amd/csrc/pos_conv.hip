@@ -201,7 +201,8 @@ void launch_pos_conv_direct(const PosConvP& p0, hipStream_t st) {
     // one live column in the last 32-column tile (Wt = 65 in every shipped config at the BASELINE shapes) and enough row
     // workgroups that the extra column workgroups are noise: the column form (see the header).  DEX_POS_COL=0 disables it.
     static const bool col_off = [] { const char* e = getenv("DEX_POS_COL"); return e && e[0] == '0'; }();
-    p.ncol = (!col_off && p.Wt > 32 && p.Wt % 32 == 1 && p.Hf <= 32 && (long)p.Hf * p.B * p.G >= 512) ? 1 : 0;
+    static const long col_min = [] { const char* e = getenv("DEX_POS_COL_MIN"); return e ? atol(e) : 512L; }();
+    p.ncol = (!col_off && p.Wt > 32 && p.Wt % 32 == 1 && p.Hf <= 32 && (long)p.Hf * p.B * p.G >= col_min) ? 1 : 0;
     // widest chunk (fewest halo columns) whose patch still lets two workgroups share a CU (three when the grid is
     // large), but never so wide that a small batch leaves CUs idle.  Measured (us, CT = 3 / 2 / 1):
     // GeDEX B=32 (10 rows) 94 / 124 / 132;  DEX B=32 (20 rows) 381 / 348 / 321;  DEX B=1 39 / 27 / 28.
