@@ -458,7 +458,10 @@ extern "C" int dex_ctx_finalize(DexCtx* x, dex_stream_t stream) {
         x->down_res[i].push_back(P.resnet(p + ".0", ci, co, i == 0));
         x->down_res[i].push_back(P.resnet(p + ".1", co, co, false));
         x->down_lin.push_back(P.linattn(p + ".2", co));
-        if (i < c.n_stages - 1) { x->down_ds_w.push_back(P.kn(p + ".3.conv.weight")); x->down_ds_b.push_back(P.raw(p + ".3.conv.bias")); }
+        if (i < c.n_stages - 1) {
+            x->down_ds_w.push_back(P.kn(p + ".3.conv.weight")); x->down_ds_b.push_back(P.raw(p + ".3.conv.bias"));
+            if (conv_down_supported(co, 2, 2, co, co, 0)) P.frag(x->down_ds_w.back(), 9 * co, co);      // conv_down.hip
+        }
     }
     x->up_res.assign(c.n_stages - 1, {}); x->up_lin.clear(); x->up_us_w.clear(); x->up_us_b.clear();
     for (int j = 0; j < c.n_stages - 1; ++j) {
@@ -1136,6 +1139,16 @@ struct Runner {
                 const bool t2_lp = lp_inter && x->lp_of().count(x->down_ds_w[i]) && nw.wr && fast_conv(s.C, nw.cout) && conv3x3_bf16_res_supported(s.C, nw.cout) &&
                                    x->lp_of().count(nw.wr) && x->lp_of().count(nw.w1) && conv3x3_plain_lp_in_supported(g.Ho, g.Wo, B, s.C, nw.cout);
                 g.a_lp = t1_lp ? lpk : 0; g.c_lp = t2_lp ? lpk : 0;
+                static const bool strip_off = [] { const char* e = getenv("DEX_CONV_DOWN"); return e && e[0] == '0'; }();
+                if (x->lp() && t1_lp && !strip_off && x->frag_of().count(x->down_ds_w[i]) && conv_down_supported(s.C, s.H, s.W, a.ld, s.C, a.coff)) {
+                    ConvDownP d{};
+                    d.X = a.p; d.ldx = a.ld; d.xb = (long)s.H * s.W * a.ld; d.x_coff = a.coff; d.H = s.H; d.W = s.W;
+                    d.Wfrag = x->frag_of().at(x->down_ds_w[i]); d.bias = x->down_ds_b[i];
+                    d.Y = s.ds_out; d.c_lp = g.c_lp; d.ldy = s.C; d.y_coff = 0;
+                    d.inmask = mask; d.inmask_ws = s.mask_ws; d.mask_bstride = P.d.T; d.B = B;
+                    const double M = 0.25 * s.H * s.W * B;
+                    run("downsample", 2.0 * M * s.C * 9 * s.C, 4.0 * M * s.C * 2.0 + M * s.C * (g.c_lp ? 2.0 : 4.0), [&] { launch_conv_down(d, x->precision, st); });
+                } else
                 gemm("downsample", g);
                 cur = TD{s.ds_out, s.C, 0, s.C, t2_lp ? lpk : 0};
             }

@@ -25,6 +25,9 @@ void launch_igemm_lp(const IGemmP& p, hipStream_t st);
 // Upsample (ConvTranspose2d 4/2/1) strip kernel (convt_up.hip)
 bool convt_up_supported(int C, int H, int W, int ldx, int ldy);
 void launch_convt_up(const ConvTUpP& p, hipStream_t st);
+// Downsample (Conv2d 3/2/1) strip kernel (conv_down.hip)
+bool conv_down_supported(int C, int H, int W, int ldx, int ldy, int x_coff);
+void launch_conv_down(const ConvDownP& p, hipStream_t st);
 // softmax attention (attention_bf16.hip: fp32 q/k/v in HBM; attention_direct.hip: fragment-ordered operands)
 void launch_attention_lp(const AttnP& p, hipStream_t st);
 void launch_attention_direct(const AttnDirectP& p, hipStream_t st);

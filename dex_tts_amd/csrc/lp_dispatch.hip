@@ -23,6 +23,7 @@ bool conv3x3_res2_form(int H, int W, int B) { return bf16::conv3x3_res2_form(H, 
 bool pos_conv_direct_supported(int hid, int groups, int kernel, int Hf) { return bf16::pos_conv_direct_supported(hid, groups, kernel, Hf); }
 bool attention_direct_batch_regime(int N, int B) { return bf16::attention_direct_batch_regime(N, B); }
 int attention_direct_ksplit(int N, int B) { return bf16::attention_direct_ksplit(N, B); }
+bool conv_down_supported(int C, int H, int W, int ldx, int ldy, int x_coff) { return bf16::conv_down_supported(C, H, W, ldx, ldy, x_coff); }
 bool convt_up_supported(int C, int H, int W, int ldx, int ldy) { return bf16::convt_up_supported(C, H, W, ldx, ldy); }
 bool dit_rowchain_supported(int hidden, int mlp_hidden) { return bf16::dit_rowchain_supported(hidden, mlp_hidden); }
 
@@ -31,6 +32,7 @@ bool dit_rowchain_supported(int hidden, int mlp_hidden) { return bf16::dit_rowch
 void launch_conv3x3_lp(const Conv3P& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_conv3x3_lp, p, st); }
 void launch_igemm_lp(const IGemmP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_igemm_lp, p, st); }
 void launch_convt_up(const ConvTUpP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_convt_up, p, st); }
+void launch_conv_down(const ConvDownP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_conv_down, p, st); }
 void launch_attention_lp(const AttnP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_attention_lp, p, st); }
 void launch_attention_direct(const AttnDirectP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_attention_direct, p, st); }
 void launch_dit_rowchain(const DitChainP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_dit_rowchain, p, st); }
