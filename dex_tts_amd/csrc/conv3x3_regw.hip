@@ -458,10 +458,196 @@ __global__ __launch_bounds__(256) void conv3x3_rw_kernel(const Conv3P p, const i
     }
 }
 
+// ---- 64 -> 128 channels with the fused 1x1 shortcut (the first conv of the half-resolution stage: conv3x3(x * mask) and
+// res_conv(x * mask) of the Downsample output, diffusion.py:66-71).  2.9 KB of HBM traffic per output pixel (16-bit h1, fp32
+// shortcut) against 83 kFLOP: HBM-bound (the patch kernel moved it at 2.4 TB/s, 120 us at B = 32).  Same strip walker, the plain
+// way round: wave ct owns output-channel tile ct of both outputs with its full-K weights in registers (36 + 4 K-steps,
+// 160 VGPRs, compiler-visible MFMAs), both 32-pixel tiles of the 64-column strip; no K split, no exchange; the two outputs leave
+// through two LDS stages as contiguous runs.
+template <bool XB>
+__global__ __launch_bounds__(256) void conv3x3_rw_res128_kernel(const Conv3P p, const int nseg, const int rows_per_wg) {
+    constexpr int CIN = 64, COUT = 128;
+    constexpr int MPX = 64, PC = MPX + 2, PXB = CIN * 2 + 16, ROWB = PC * PXB, RING = 4 * ROWB;
+    constexpr int SPB = COUT * 2 + 16, STG = MPX * SPB, SPBR = COUT * 4 + 16, STGR = MPX * SPBR;
+    constexpr int KSH = CIN / 16, KST = 9 * KSH, CH = CIN / 8, NL = (PC * CH + 255) / 256;
+    constexpr int OCH = COUT * 2 / 16, NS = MPX * OCH / 256, OCHR = COUT * 4 / 16, NSR = MPX * OCHR / 256;
+    using Row = RwRow<NL, XB, false>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_rw[];
+    unsigned char* ring = smem_rw;
+    unsigned char* stage = smem_rw + RING;
+    unsigned char* stager = stage + STG;
+    float* bs = reinterpret_cast<float*>(stager + STGR);                        // [COUT] bias, [COUT] shortcut bias
+    long long* gnred = reinterpret_cast<long long*>(bs + 2 * COUT);             // [8][2]
+    const int DUMMY = RING + STG + STGR + 2 * COUT * 4 + 16 * 8;                // ring writes of lanes without a column
+    const int tid = threadIdx.x, lane = tid & 63, ct = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int seg = blockIdx.x % nseg, chunk = blockIdx.x / nseg, b = blockIdx.y;
+    const int iw0 = seg * MPX;
+    const int r0 = chunk * rows_per_wg, r1 = min(p.H, r0 + rows_per_wg);
+    const bool full_strip = iw0 + MPX <= p.W;
+    const float* X = p.X + (long)b * p.H * p.W * p.ldx + p.x_coff;
+    const u16* Xh = reinterpret_cast<const u16*>(p.X) + (long)b * p.H * p.W * p.ldx + p.x_coff;
+    const float* mrow = p.mask + (long)b * p.mask_bstride;
+    const int c8 = (tid % CH) * 8, px0 = tid / CH;
+    int coff[NL], roff[NL]; float cmask[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+        const int px = px0 + j * (256 / CH), wi = iw0 - 1 + px;
+        const bool ok = px < PC && (unsigned)wi < (unsigned)p.W;
+        const int wc = ok ? wi : 0;
+        coff[j] = wc * p.ldx + c8;
+        cmask[j] = ok ? mrow[wc * p.mask_ws] : 0.f;
+        roff[j] = px < PC ? px * PXB + c8 * 2 : -1;
+    }
+    auto row_load = [&](int row, Row& R) __attribute__((always_inline)) {
+        const bool rok = (unsigned)row < (unsigned)p.H;
+        const int rc = __builtin_amdgcn_readfirstlane(rok ? row : 0);
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            if constexpr (XB) R.a[j] = *reinterpret_cast<const uint4*>(Xh + (long)rc * p.W * p.ldx + coff[j]);
+            else { const float* xf = X + (long)rc * p.W * p.ldx + coff[j]; R.a[j] = *reinterpret_cast<const uint4*>(xf); R.b[j] = *reinterpret_cast<const uint4*>(xf + 4); }
+            R.m[j] = rok ? cmask[j] : 0.f;
+        }
+    };
+    auto row_store = [&](int row, const Row& R) __attribute__((always_inline)) {      // x * mask -> ring slot (row + 1) & 3, branch-free
+        const int slot = ((row + 1) & 3) * ROWB;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const float m = R.m[j];
+            uint4 v;
+            if constexpr (XB) {
+                v.x = pack2_lp(lp_lo(R.a[j].x) * m, lp_hi(R.a[j].x) * m); v.y = pack2_lp(lp_lo(R.a[j].y) * m, lp_hi(R.a[j].y) * m);
+                v.z = pack2_lp(lp_lo(R.a[j].z) * m, lp_hi(R.a[j].z) * m); v.w = pack2_lp(lp_lo(R.a[j].w) * m, lp_hi(R.a[j].w) * m);
+            } else {
+                v.x = pack2_lp(__uint_as_float(R.a[j].x) * m, __uint_as_float(R.a[j].y) * m); v.y = pack2_lp(__uint_as_float(R.a[j].z) * m, __uint_as_float(R.a[j].w) * m);
+                v.z = pack2_lp(__uint_as_float(R.b[j].x) * m, __uint_as_float(R.b[j].y) * m); v.w = pack2_lp(__uint_as_float(R.b[j].z) * m, __uint_as_float(R.b[j].w) * m);
+            }
+            *reinterpret_cast<uint4*>(smem_rw + (roff[j] >= 0 ? slot + roff[j] : DUMMY)) = v;
+        }
+    };
+
+    // ---- prologue
+    Row Ra, Rb;
+    row_load(r0 - 1, Ra);
+    row_load(r0, Rb);
+    uint4 wr[KST], wq[KSH];
+    {
+        const uint4* Wf = reinterpret_cast<const uint4*>(p.Wfrag) + (long)ct * KST * 64 + lane;      // [ct][tap * 4 + ks][lane] x 16 B
+#pragma unroll
+        for (int ks = 0; ks < KST; ++ks) wr[ks] = Wf[ks * 64];
+        const uint4* Rf = reinterpret_cast<const uint4*>(p.res_wfrag) + (long)ct * KSH * 64 + lane;  // [ct][ks][lane]
+#pragma unroll
+        for (int ks = 0; ks < KSH; ++ks) wq[ks] = Rf[ks * 64];
+    }
+    if (tid < COUT) { bs[tid] = p.bias[tid]; bs[COUT + tid] = p.res_b[tid]; }
+    if (tid < 16) gnred[tid] = 0;
+    row_store(r0 - 1, Ra);
+    row_store(r0, Rb);
+    row_load(r0 + 1, Ra);
+    row_load(r0 + 2 <= r1 ? r0 + 2 : -1, Rb);
+    row_store(r0 + 1, Ra);
+    lds_barrier();
+
+    constexpr int cpg = COUT / 8, NG = 32 / cpg;
+    float gs[NG], gq[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) { gs[g] = 0.f; gq[g] = 0.f; }
+
+    for (int ih = r0; ih < r1; ++ih) {
+        // input row ih + 2 (in flight since the previous tile) -> the free ring slot; then the loads of row ih + 3
+        row_store(ih + 2, Rb);
+        row_load(ih + 3 <= r1 ? ih + 3 : -1, Rb);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 acc[2], accr[2];
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[pt][r] = 0.f; accr[pt][r] = 0.f; }
+        lp8 xq[2][KSH * 2];
+#define RWC_XLOAD(tap_, buf_) do { \
+            const int kh_ = (tap_) / 3, kw_ = (tap_) - kh_ * 3; \
+            const unsigned char* xr_ = ring + ((ih + kh_) & 3) * ROWB + (i + kw_) * PXB + hh * 16; \
+            _Pragma("unroll") for (int ks_ = 0; ks_ < KSH; ++ks_) \
+                _Pragma("unroll") for (int pt_ = 0; pt_ < 2; ++pt_) xq[buf_][ks_ * 2 + pt_] = *reinterpret_cast<const lp8*>(xr_ + pt_ * 32 * PXB + ks_ * 32); \
+        } while (0)
+        RWC_XLOAD(0, 0);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap + 1 < 9) RWC_XLOAD(tap + 1, (tap + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < KSH; ++ks)
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) {
+                    acc[pt] = DEX_MFMA_LP(__builtin_bit_cast(lp8, wr[tap * KSH + ks]), xq[tap & 1][ks * 2 + pt], acc[pt], 0, 0, 0);
+                    if (tap == 4) accr[pt] = DEX_MFMA_LP(__builtin_bit_cast(lp8, wq[ks]), xq[tap & 1][ks * 2 + pt], accr[pt], 0, 0, 0);   // the 1x1 shortcut: centre tap
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef RWC_XLOAD
+        lds_barrier();              // every wave is past the previous tile's reads of the output stages
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const bool live = iw0 + pt * 32 + i < p.W;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bs + ct * 32 + 8 * g + 4 * hh), r4 = *reinterpret_cast<const float4*>(bs + COUT + ct * 32 + 8 * g + 4 * hh);
+                const float v0 = acc[pt][4 * g] + b4.x, v1 = acc[pt][4 * g + 1] + b4.y, v2 = acc[pt][4 * g + 2] + b4.z, v3 = acc[pt][4 * g + 3] + b4.w;
+                const int gi = (8 * g) / cpg;                // statistics of the raw conv output (lane = pixel: columns past the image edge do not count)
+                if (live) { gs[gi] += (v0 + v1) + (v2 + v3); gq[gi] = fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, fmaf(v3, v3, gq[gi])))); }
+                *reinterpret_cast<uint2*>(stage + (pt * 32 + i) * SPB + (ct * 32 + 8 * g + 4 * hh) * 2) = make_uint2(pack2_lp(v0, v1), pack2_lp(v2, v3));
+                *reinterpret_cast<float4*>(stager + (pt * 32 + i) * SPBR + (ct * 32 + 8 * g + 4 * hh) * 4) =
+                    make_float4(accr[pt][4 * g] + r4.x, accr[pt][4 * g + 1] + r4.y, accr[pt][4 * g + 2] + r4.z, accr[pt][4 * g + 3] + r4.w);
+            }
+        }
+        lds_barrier();
+        {   // output stages -> HBM, 16 B per lane
+            const long rowpix = ((long)b * p.H + ih) * p.W;          // wave-uniform
+#define RWC_OUT(pred_) do { \
+                _Pragma("unroll") for (int h0 = 0; h0 < NS; h0 += 4) { \
+                    uint4 ov[4]; \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) { const int q = tid + 256 * (h0 + j); ov[j] = *reinterpret_cast<const uint4*>(stage + (q / OCH) * SPB + (q % OCH) * 16); } \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) { const int q = tid + 256 * (h0 + j), wo = iw0 + q / OCH, e = wo * COUT + (q % OCH) * 8; \
+                        if (pred_) *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(p.Y) + rowpix * COUT + e) = ov[j]; } \
+                } \
+                _Pragma("unroll") for (int h0 = 0; h0 < NSR; h0 += 4) { \
+                    uint4 ov[4]; \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) { const int q = tid + 256 * (h0 + j); ov[j] = *reinterpret_cast<const uint4*>(stager + (q / OCHR) * SPBR + (q % OCHR) * 16); } \
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) { const int q = tid + 256 * (h0 + j), wo = iw0 + q / OCHR, e = wo * COUT + (q % OCHR) * 4; \
+                        if (pred_) *reinterpret_cast<uint4*>(p.res_y + rowpix * COUT + e) = ov[j]; } \
+                } \
+            } while (0)
+            if (full_strip) RWC_OUT(true); else RWC_OUT(wo < p.W);
+#undef RWC_OUT
+        }
+    }
+    if (p.gn_stats) {
+        const double inv_n = 1.0 / ((double)p.H * p.W * cpg);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            float a_ = gs[g], q_ = gq[g];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { a_ += __shfl_xor(a_, o); q_ += __shfl_xor(q_, o); }
+            if (lane == 0) { gn_add(&gnred[((ct * 32) / cpg + g) * 2], gn_fix(a_, inv_n)); gn_add(&gnred[((ct * 32) / cpg + g) * 2 + 1], gn_fix(q_, inv_n)); }
+        }
+        __syncthreads();
+        if (tid < 16) {
+            const long long v = gnred[tid];
+            if (v != 0) gn_add(p.gn_stats + (((long)b * 8 + (tid >> 1)) * GN_SLOTS + blockIdx.x % GN_SLOTS) * 2 + (tid & 1), v);
+        }
+    }
+}
+
 // the batch regime of the 128-channel layers: enough strips x rows for one full round of workgroups with long strips
 bool conv3x3_regw_form(const Conv3P& p) {
     static const bool off = [] { const char* e = getenv("DEX_CONV_REGW"); return e && e[0] == '0'; }();
-    if (off || !p.Wfrag || p.res_w || p.res2_w) return false;
+    if (off || !p.Wfrag || p.res2_w) return false;
+    static const long min_tiles_r = [] { const char* e = getenv("DEX_REGW_MIN_TILES"); return e ? atol(e) : 1024L; }();
+    if (p.res_w) {      // 64 -> 128 + 1x1 shortcut on the plain Downsample output (conv3x3_rw_res128_kernel)
+        static const bool res_off = [] { const char* e = getenv("DEX_CONV_REGW_RES"); return e && e[0] == '0'; }();
+        return !res_off && p.res_wfrag && p.Cin == 64 && p.Cout == 128 && (p.ldx % 8) == 0 && (p.x_coff % 8) == 0 && !p.pro_stats && !p.pro_res && p.y_bf16 &&
+               (long)p.H * ((p.W + 63) / 64) * p.B >= min_tiles_r;
+    }
     if (!(p.Cin == 128 && p.Cout == 128 && p.ldx == 128 && p.x_coff == 0)) return false;
     if (!p.y_bf16) return false;
     if (p.pro_stats ? !p.x_bf16 : true) return false;         // instantiated: the two GroupNorm-prologue forms on 16-bit h
@@ -484,7 +670,22 @@ static void rw_launch(const Conv3P& p, hipStream_t st) {
     hipLaunchKernelGGL((conv3x3_rw_kernel<CIN, COUT, PROF, XB, YB>), dim3(nseg * nchunk, p.B), dim3(G::NTHR), G::LDS, st, p, nseg, R);
 }
 
+template <bool XB>
+static void rw_launch_res128(const Conv3P& p, hipStream_t st) {
+    constexpr int LDS = 4 * 66 * 144 + 64 * (128 * 2 + 16) + 64 * (128 * 4 + 16) + 2 * 128 * 4 + 16 * 8 + 16;
+    const int nseg = (p.W + 63) / 64;
+    int nchunk = (256 + nseg * p.B - 1) / (nseg * p.B);
+    if (nchunk < 1) nchunk = 1;
+    if (nchunk > p.H) nchunk = p.H;
+    const int R = (p.H + nchunk - 1) / nchunk;
+    nchunk = (p.H + R - 1) / R;
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_rw_res128_kernel<XB>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS); attr = true; }
+    hipLaunchKernelGGL((conv3x3_rw_res128_kernel<XB>), dim3(nseg * nchunk, p.B), dim3(256), LDS, st, p, nseg, R);
+}
+
 void launch_conv3x3_regw(const Conv3P& p, hipStream_t st) {
+    if (p.res_w) { g_last_symbol = "conv3x3_rw_res128_kernel"; p.x_bf16 ? rw_launch_res128<true>(p, st) : rw_launch_res128<false>(p, st); return; }
     g_last_symbol = "conv3x3_rw_kernel";
     if (p.pro_res) rw_launch<128, 128, 2, true, true>(p, st);
     else rw_launch<128, 128, 1, true, true>(p, st);

@@ -360,7 +360,8 @@ struct Packer {
         const int o = (int)s[0], i = (int)s[1], kh = s.size() > 2 ? (int)s[2] : 1, kw = s.size() > 3 ? (int)s[3] : 1;
         const float* f = perm(k, o, i, kh, kw, 2, 3, 1, 0);
         twin(f, 1, i * kh * kw, o);
-        if (kh == 3 && kw == 3 && i == 128 && o == 128) frag(f, 9 * i, o);      // weights-in-registers strip convolution (conv3x3_regw.hip)
+        if (kh == 3 && kw == 3 && ((i == 128 && o == 128) || (i == 64 && o == 128))) frag(f, 9 * i, o);      // weights-in-registers strip convolutions (conv3x3_regw.hip)
+        if (kh == 1 && kw == 1 && i == 64 && o == 128) frag(f, i, o);                                          // ... and the 1x1 shortcut fused into the 64 -> 128 one
         return f;
     }
     ResW resnet(const std::string& p, int cin, int cout, bool first) {
@@ -756,6 +757,7 @@ struct Runner {
             { auto itf = x->frag_of().find(Wt); c.Wfrag = itf != x->frag_of().end() ? itf->second : nullptr; }   // conv3x3_regw.hip
             if (shortcut) {       // the block's 1x1 res_conv rides on the centre tap of this conv
                 c.res_w = x->lp_of().at(shortcut->wr); c.res_b = shortcut->br; c.res_y = shortcut_out;
+                { auto itf = x->frag_of().find(shortcut->wr); c.res_wfrag = itf != x->frag_of().end() ? itf->second : nullptr; }
             }
             const double M = (double)H * W * P.d.B;
             // algorithmic bytes: input + output at their stored width, + the residual read and the x write-out of the PRO2 form,

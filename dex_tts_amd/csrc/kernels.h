@@ -109,6 +109,7 @@ struct Conv3P {
     // fused 1x1 shortcut of the ResnetBlock (res_conv(x * mask), diffusion.py:70): a second output computed from the
     // patch's centre tap; res_w = bf16 [Cout][Cin], res_y = [H*W][Cout] fp32
     const void* res_w; const float* res_b; float* res_y;
+    const void* res_wfrag;                                   // res_w in MFMA fragment order ([K = Cin][Cout] through launch_pack_lp_frag), or null
     int step; gnfix_t* gn_stats; int B;
     long long* dbg;                                          // optional phase timestamps (tools/kbench)
     // raw conv outputs that only a GroupNorm prologue reads next (h1, h2 of a ResnetBlock) may live in HBM as bf16:
