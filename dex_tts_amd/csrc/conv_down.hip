@@ -1,5 +1,5 @@
 // conv_down.hip — Downsample = Conv2d(64, 64, 3, stride 2, pad 1) on x * mask (diffusion.py:22-28, call site diffusion.py:189)
-// as a strip-walking kernel (reduced-precision MFMA modes, batch regime: 16-bit input).
+// as a strip-walking kernel (reduced-precision MFMA modes; 16-bit input at batch size, fp32 input otherwise).
 //
 // As an implicit GEMM (igemm_bf16.hip) every workgroup re-gathers the nine taps of its 128 output pixels from L2 and the A tile
 // goes global -> registers -> LDS per K tile: 102 us at B = 32 for 210 MB of HBM traffic (~2 TB/s).  Here, as in convt_up.hip:
@@ -29,9 +29,13 @@ constexpr int CD_PL = CD_MPX + 1, CD_ROWB = 2 * CD_PL * CD_PXB;      // pixels p
 constexpr int CD_NIT = (2 * CD_MPX + 1) * 8, CD_NL = (CD_NIT + 255) / 256;     // 16 B items per input row / per thread
 }
 
+template <bool ALP> struct CdRow;                                   // registers of one input row in flight
+template <> struct CdRow<true> { uint4 a[CD_NL]; float m[CD_NL]; };
+template <> struct CdRow<false> { uint4 a[CD_NL]; uint4 c[CD_NL]; float m[CD_NL]; };
+
 // grid (nseg * nchunk, B); 256 threads
-template <bool CLP>
-__global__ __launch_bounds__(256) void conv_down_kernel(const ConvDownP p) {
+template <bool ALP, bool CLP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ALP ? 2 : 1, ALP ? 2 : 1))) void conv_down_kernel(const ConvDownP p) {
     constexpr int SPB = CLP ? 144 : 272, STG = CD_MPX * SPB, OCH = CLP ? 8 : 16, NS = CD_MPX * OCH / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_cd[];
     unsigned char* ring = smem_cd;                                   // [3 slots][2 planes][CD_PL] pixels
@@ -45,7 +49,8 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const ConvDownP p) {
     const int ow0 = seg * CD_MPX, Ho = p.H / 2, Wo = p.W / 2;
     const int r0 = chunk * p.rows_per_wg, r1 = min(Ho, r0 + p.rows_per_wg);
     const bool full_strip = ow0 + CD_MPX <= Wo;
-    const u16* Xb = reinterpret_cast<const u16*>(p.X) + (long)b * p.xb + p.x_coff;
+    const u16* Xb = reinterpret_cast<const u16*>(p.X) + (long)b * p.xb + p.x_coff;                 // ALP: 16-bit input
+    const float* Xf = reinterpret_cast<const float*>(p.X) + (long)b * p.xb + p.x_coff;
     const float* mrow = p.inmask + (long)b * p.mask_bstride;
 
     // per-thread constants of the row loads: element offset inside an image row (column clamped), column mask, ring offset
@@ -61,13 +66,16 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const ConvDownP p) {
         cmask[j] = ok ? mrow[wc * p.inmask_ws] : 0.f;
         roff[j] = q < CD_NIT ? ((pc & 1) * CD_PL + (pc >> 1)) * CD_PXB + c8 * 2 : -1;
     }
-    struct Row { uint4 a[CD_NL]; float m[CD_NL]; };
+    using Row = CdRow<ALP>;
     auto row_load = [&](int row, Row& R) __attribute__((always_inline)) {
         const bool rok = (unsigned)row < (unsigned)p.H;
         const int rc = __builtin_amdgcn_readfirstlane(rok ? row : 0);
-        const u16* xr = Xb + (long)rc * p.W * p.ldx;
 #pragma unroll
-        for (int j = 0; j < CD_NL; ++j) { R.a[j] = *reinterpret_cast<const uint4*>(xr + coff[j]); R.m[j] = rok ? cmask[j] : 0.f; }
+        for (int j = 0; j < CD_NL; ++j) {
+            if constexpr (ALP) R.a[j] = *reinterpret_cast<const uint4*>(Xb + (long)rc * p.W * p.ldx + coff[j]);
+            else { const float* xf = Xf + (long)rc * p.W * p.ldx + coff[j]; R.a[j] = *reinterpret_cast<const uint4*>(xf); R.c[j] = *reinterpret_cast<const uint4*>(xf + 4); }
+            R.m[j] = rok ? cmask[j] : 0.f;
+        }
     };
     auto row_store = [&](int row, const Row& R) __attribute__((always_inline)) {      // ring slot of input row r: (r + 1) mod 3
         const int slot = __builtin_amdgcn_readfirstlane((row + 1) % 3) * CD_ROWB;
@@ -75,8 +83,13 @@ __global__ __launch_bounds__(256) void conv_down_kernel(const ConvDownP p) {
         for (int j = 0; j < CD_NL; ++j) {
             const float m = R.m[j];          // the 16-bit values widened exactly; a 0 / 1 mask leaves them on the operand grid
             uint4 v;
-            v.x = pack2_lp(lp_lo(R.a[j].x) * m, lp_hi(R.a[j].x) * m); v.y = pack2_lp(lp_lo(R.a[j].y) * m, lp_hi(R.a[j].y) * m);
-            v.z = pack2_lp(lp_lo(R.a[j].z) * m, lp_hi(R.a[j].z) * m); v.w = pack2_lp(lp_lo(R.a[j].w) * m, lp_hi(R.a[j].w) * m);
+            if constexpr (ALP) {
+                v.x = pack2_lp(lp_lo(R.a[j].x) * m, lp_hi(R.a[j].x) * m); v.y = pack2_lp(lp_lo(R.a[j].y) * m, lp_hi(R.a[j].y) * m);
+                v.z = pack2_lp(lp_lo(R.a[j].z) * m, lp_hi(R.a[j].z) * m); v.w = pack2_lp(lp_lo(R.a[j].w) * m, lp_hi(R.a[j].w) * m);
+            } else {
+                v.x = pack2_lp(__uint_as_float(R.a[j].x) * m, __uint_as_float(R.a[j].y) * m); v.y = pack2_lp(__uint_as_float(R.a[j].z) * m, __uint_as_float(R.a[j].w) * m);
+                v.z = pack2_lp(__uint_as_float(R.c[j].x) * m, __uint_as_float(R.c[j].y) * m); v.w = pack2_lp(__uint_as_float(R.c[j].z) * m, __uint_as_float(R.c[j].w) * m);
+            }
             *reinterpret_cast<uint4*>(smem_cd + (roff[j] >= 0 ? slot + roff[j] : DUMMY)) = v;
         }
     };
@@ -168,12 +181,16 @@ void launch_conv_down(const ConvDownP& p0, hipStream_t st) {
     const int lds = 3 * CD_ROWB + CD_MPX * (p.c_lp ? 144 : 272) + CD_C * 4 + 16;
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_down_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * CD_ROWB + CD_MPX * 272 + CD_C * 4 + 16);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_down_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * CD_ROWB + CD_MPX * 272 + CD_C * 4 + 16);
+        constexpr int LMAX = 3 * CD_ROWB + CD_MPX * 272 + CD_C * 4 + 16;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_down_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LMAX);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_down_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LMAX);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_down_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LMAX);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_down_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LMAX);
         attr = true;
     }
-    if (p.c_lp) hipLaunchKernelGGL((conv_down_kernel<true>), dim3(p.nseg * nchunk, p.B), dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((conv_down_kernel<false>), dim3(p.nseg * nchunk, p.B), dim3(256), lds, st, p);
+    const dim3 grid(p.nseg * nchunk, p.B);
+    if (p.a_lp) { if (p.c_lp) hipLaunchKernelGGL((conv_down_kernel<true, true>), grid, dim3(256), lds, st, p); else hipLaunchKernelGGL((conv_down_kernel<true, false>), grid, dim3(256), lds, st, p); }
+    else { if (p.c_lp) hipLaunchKernelGGL((conv_down_kernel<false, true>), grid, dim3(256), lds, st, p); else hipLaunchKernelGGL((conv_down_kernel<false, false>), grid, dim3(256), lds, st, p); }
 }
 
 }  // namespace DEX_LP_NS

@@ -1142,14 +1142,14 @@ struct Runner {
                                    x->lp_of().count(nw.wr) && x->lp_of().count(nw.w1) && conv3x3_plain_lp_in_supported(g.Ho, g.Wo, B, s.C, nw.cout);
                 g.a_lp = t1_lp ? lpk : 0; g.c_lp = t2_lp ? lpk : 0;
                 static const bool strip_off = [] { const char* e = getenv("DEX_CONV_DOWN"); return e && e[0] == '0'; }();
-                if (x->lp() && t1_lp && !strip_off && x->frag_of().count(x->down_ds_w[i]) && conv_down_supported(s.C, s.H, s.W, a.ld, s.C, a.coff)) {
+                if (x->lp() && !strip_off && x->frag_of().count(x->down_ds_w[i]) && conv_down_supported(s.C, s.H, s.W, a.ld, s.C, a.coff)) {
                     ConvDownP d{};
-                    d.X = a.p; d.ldx = a.ld; d.xb = (long)s.H * s.W * a.ld; d.x_coff = a.coff; d.H = s.H; d.W = s.W;
+                    d.X = a.p; d.a_lp = g.a_lp; d.ldx = a.ld; d.xb = (long)s.H * s.W * a.ld; d.x_coff = a.coff; d.H = s.H; d.W = s.W;
                     d.Wfrag = x->frag_of().at(x->down_ds_w[i]); d.bias = x->down_ds_b[i];
                     d.Y = s.ds_out; d.c_lp = g.c_lp; d.ldy = s.C; d.y_coff = 0;
                     d.inmask = mask; d.inmask_ws = s.mask_ws; d.mask_bstride = P.d.T; d.B = B;
                     const double M = 0.25 * s.H * s.W * B;
-                    run("downsample", 2.0 * M * s.C * 9 * s.C, 4.0 * M * s.C * 2.0 + M * s.C * (g.c_lp ? 2.0 : 4.0), [&] { launch_conv_down(d, x->precision, st); });
+                    run("downsample", 2.0 * M * s.C * 9 * s.C, 4.0 * M * s.C * (g.a_lp ? 2.0 : 4.0) + M * s.C * (g.c_lp ? 2.0 : 4.0), [&] { launch_conv_down(d, x->precision, st); });
                 } else
                 gemm("downsample", g);
                 cur = TD{s.ds_out, s.C, 0, s.C, t2_lp ? lpk : 0};

@@ -78,9 +78,9 @@ struct ConvTUpP { const void* X; int a_lp; int ldx; long xb; int x_coff; int H, 
                   int nseg, rows_per_wg; };               // filled by the launcher
 bool convt_up_supported(int C, int H, int W, int ldx, int ldy);
 // Downsample = Conv2d(64, 64, 3, 2, 1) on x * mask as a strip-walking kernel (conv_down.hip; reduced-precision modes, 16-bit input).
-// X [B][H][W][ldx] 16-bit (+ x_coff), Y [B][H/2][W/2][ldy] (fp32, or 16-bit when c_lp); strides / offsets in elements.
+// X [B][H][W][ldx] (fp32, or 16-bit when a_lp; + x_coff), Y [B][H/2][W/2][ldy] (fp32, or 16-bit when c_lp); strides / offsets in elements.
 // Wfrag = the weight matrix [K = (kh*3+kw)*64 + ci][64 co] in MFMA fragment order (launch_pack_lp_frag).
-struct ConvDownP { const void* X; int ldx; long xb; int x_coff; int H, W;
+struct ConvDownP { const void* X; int a_lp; int ldx; long xb; int x_coff; int H, W;
                    const void* Wfrag; const float* bias;
                    void* Y; int c_lp; int ldy; int y_coff;
                    const float* inmask; int inmask_ws; long mask_bstride; int B;
