@@ -219,12 +219,53 @@ __global__ __launch_bounds__(256) void first_conv_mfma_kernel(const FirstConvP p
             }
         }
     };
-    const long sstride = (long)gridDim.x * 4;
+    // Strip mode (T a multiple of 32, enough waves: the batch regime).  A wave owns the 32 columns cs*32.. of a band of rows and
+    // walks DOWN it: the column masks of its three taps are loaded once, and a new output row needs only the three taps of ONE new
+    // input row per plane - 3 load instructions per segment instead of 18-27 (the generic gather above is load-issue-bound: 100 us at
+    // B = 32 for a 168 MB output).  The other six taps are the previous segment's, shifted.
+    const long nwaves = (long)gridDim.x * 4, wv = (long)blockIdx.x * 4 + wave;
+    const int nstrip = p.T / 32;
+    const bool strip = (p.T % 32) == 0 && nwaves >= nstrip;
+    const int cs = strip ? (int)(wv % nstrip) : 0;
+    float mkc[3] = {0.f, 0.f, 0.f};
+    if (strip) {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) { const int wi = cs * 32 + i + kw - 1; mkc[kw] = (unsigned)wi < (unsigned)p.T ? mrow[wi] : 0.f; }
+    }
+    auto gather_row = [&](int hi, float (&a)[KS][9], int slot) __attribute__((always_inline)) {      // taps of input row hi -> a[.][slot*3 .. +3]
+        const bool rin = (unsigned)hi < (unsigned)p.H;
+        const int hc = rin ? hi : 0;
+        const float sp = (PLANES == 3 && hh == 0) ? p.spk[(long)b * p.H + hc] : 0.f;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int wi = cs * 32 + i + kw - 1;
+            const int wc = (unsigned)wi < (unsigned)p.T ? wi : cs * 32 + i;
+            const float mk = rin ? mkc[kw] : 0.f;
+            a[0][slot * 3 + kw] = (plane[(long)hc * p.T + wc] * psc) * mk;
+            if constexpr (PLANES == 3) a[1][slot * 3 + kw] = sp * mk;
+        }
+    };
+    long seg, seg_end, sstride;
+    if (strip) {
+        const int nrc = (int)(nwaves / nstrip), rc = (int)(wv / nstrip);
+        const int R = (p.H + nrc - 1) / nrc, h0 = rc * R, h1 = rc < nrc ? min(p.H, h0 + R) : h0;
+        seg = (long)h0 * nstrip + cs; seg_end = (long)h1 * nstrip; sstride = nstrip;
+    } else { seg = wv; seg_end = nseg; sstride = nwaves; }
     float a[KS][9], an[KS][9];
-    long seg = (long)blockIdx.x * 4 + wave;
-    if (seg < nseg) gather(seg, a);
-    for (; seg < nseg; seg += sstride) {
-        if (seg + sstride < nseg) gather(seg + sstride, an);            // the next segment's operands fly under this one's MFMAs and stores
+    if (seg < seg_end) {
+        if (strip) { const int h = (int)(seg / nstrip); gather_row(h - 1, a, 0); gather_row(h, a, 1); gather_row(h + 1, a, 2); }
+        else gather(seg, a);
+    }
+    for (; seg < seg_end; seg += sstride) {
+        if (seg + sstride < seg_end) {                                      // the next segment's operands fly under this one's MFMAs and stores
+            if (strip) {
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) an[ks][t] = a[ks][t + 3];
+                gather_row((int)(seg / nstrip) + 2, an, 2);
+            } else gather(seg + sstride, an);
+        }
         f32x16_fc acc[NT], accr[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
@@ -266,7 +307,7 @@ __global__ __launch_bounds__(256) void first_conv_mfma_kernel(const FirstConvP p
                     const float recv = lane_xor1(odd ? lo_r : hi_r);
                     const float mine = odd ? hi_r : lo_r;
                     const unsigned pk = odd ? pack2_kind(recv, mine, p.h1_bf16) : pack2_kind(mine, recv, p.h1_bf16);
-                    *reinterpret_cast<unsigned*>(hp + ((j & 3) + 8 * (j >> 2)) * C) = pk;
+                    *reinterpret_cast<unsigned*>(hp + ((j & 3) + 8 * (j >> 2)) * C) = pk;        // (an LDS-staged, 16 B per lane store was measured: 89 -> 93 us)
                 }
             } else {
 #pragma unroll
