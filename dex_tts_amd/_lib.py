@@ -148,6 +148,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} not found: the HIP extension is required (python -m dex_tts_amd.build); "
                            "there is no CPU fallback in the product path")
+    # torch (when installed) goes first: it ships its own HIP runtime, and a process that binds /opt/rocm's through this library
+    # before importing torch ends up with a torch that sees no device
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, res, args in SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
