@@ -14,6 +14,7 @@
 //   SPLIT=true : NW waves share ONE 32-query tile and split the keys (wave-private 32-key tiles, partial
 //                (m, l, O) merged through LDS) — keeps small token counts (N=650 at B=1) spread over the chip.
 #include "kernels.h"
+#include <cstdlib>
 #include "lp_util.h"
 #include "kernels_lp.h"
 
@@ -158,14 +159,17 @@ __device__ __forceinline__ void load_q(Frag (&qf)[8], const float* Qb, int ldq, 
     }
 }
 
-// ---- SPLIT=false: 4 waves, 4 query tiles, shared K/V tiles of 64 keys ---------------------------------
-__global__ __launch_bounds__(256) void attn_lp_shared_kernel(const AttnP p) {
+// ---- SPLIT=false: NWS waves = NWS query tiles sharing the K/V tiles of 64 keys ---------------------------
+// (NWS = 8: the staging of a K/V tile - 64 KB of fp32 converted and transposed into LDS - is shared by 256 queries instead of 128;
+// with few keys per utterance, the DEX TV adaptor's <= 349, that staging is most of the kernel)
+template <int NWS>
+__global__ __launch_bounds__(64 * NWS) void attn_lp_shared_kernel(const AttnP p) {
     constexpr int KT = 64, V_LD = KT + 8;
     constexpr int KBUF = KT * K_LD, VBUF = AHD * V_LD;
     extern __shared__ __attribute__((aligned(16))) u16 smem_b[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
-    const int q0 = blockIdx.x * 128 + wave * 32, h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * (32 * NWS) + wave * 32, h = blockIdx.y, b = blockIdx.z;
     int Nk = p.Nk;
     if (p.kv_len) Nk = min(p.Nk, p.kv_len[b] + p.kv_len_add);
     const float* Qb = p.Q + (long)b * p.qb + h * AHD;
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(256) void attn_lp_shared_kernel(const AttnP p) {
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     const int ntiles = (Nk + KT - 1) / KT;
-    Stager<KT, 256> sg;
+    Stager<KT, 64 * NWS> sg;
     sg.load(Kb, p.ldk, Vb, p.ldv, 0, Nk, tid);
     sg.store(smem_b, smem_b + 2 * KBUF, tid);
     for (int kt = 0; kt < ntiles; ++kt) {
@@ -333,11 +337,17 @@ void launch_attention_lp(const AttnP& p, hipStream_t st) {
         const size_t lds = (size_t)(2 * KT * K_LD + 2 * AHD * (KT + 8)) * sizeof(u16);
         static bool attr = false;
         if (!attr) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_lp_shared_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_lp_shared_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_lp_shared_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr = true;
         }
+        static const int w8 = getenv("DEX_ATTN_SHARED_W8") ? atoi(getenv("DEX_ATTN_SHARED_W8")) : 1;
+        if (w8 && (long)((p.Nq + 255) / 256) * p.heads * p.B >= 512) {
+            hipLaunchKernelGGL(attn_lp_shared_kernel<8>, dim3((p.Nq + 255) / 256, p.heads, p.B), dim3(512), lds, st, p);
+            return;
+        }
         dim3 grid((p.Nq + 127) / 128, p.heads, p.B);
-        hipLaunchKernelGGL(attn_lp_shared_kernel, grid, dim3(256), lds, st, p);
+        hipLaunchKernelGGL(attn_lp_shared_kernel<4>, grid, dim3(256), lds, st, p);
         return;
     }
     const long blocks32 = (long)((p.Nq + 31) / 32) * p.heads * p.B;
