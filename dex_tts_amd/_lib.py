@@ -134,6 +134,12 @@ SYMBOLS = [
     ("dex_text_align", C.c_int, [C.c_void_p, C.POINTER(DexAlignArgs), C.c_void_p]),
     ("dex_mel_frames", C.c_int, [C.c_int]),
     ("dex_mel_from_wav", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("dex_mel_create", C.c_int, [C.POINTER(C.c_void_p)]),
+    ("dex_mel_destroy", None, [C.c_void_p]),
+    ("dex_mel_last_error", C.c_char_p, [C.c_void_p]),
+    ("dex_mel_workspace_bytes", C.c_size_t, [C.c_int, C.c_int]),
+    ("dex_mel_spectrogram", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("dex_lf0_normalize", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
 ]
 
 _lib = None

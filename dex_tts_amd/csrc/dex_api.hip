@@ -1447,7 +1447,7 @@ int dex_sample(DexCtx* x, const DexSampleArgs* a, dex_stream_t stream) {
                                  (uint64_t)(uintptr_t)(a->S_churn > 0.f ? a->noise_dev : nullptr)};
     for (float v : {a->S_churn, a->S_min, a->S_max, a->S_noise}) { uint32_t u; memcpy(&u, &v, 4); key.push_back(u); }
     for (int j = 0; j < a->n_ref; ++j) key.push_back((uint64_t)(uintptr_t)a->ref_skips_dev[j]);
-    for (const char* e : {"DEX_CONV_STREAM", "DEX_H_BF16", "DEX_ATTN_SEPARATE"}) {     // knobs read at enqueue time
+    for (const char* e : {"DEX_CONV_STREAM", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN"}) {     // knobs read at enqueue time
         const char* v = getenv(e);
         key.push_back(v ? (uint64_t)atoi(v) + 1 : 0);
     }
@@ -1530,6 +1530,72 @@ int dex_profile_get(const DexCtx* x, int i, const char** name, int* calls, doubl
 // ---- STFT / mel front-end -------------------------------------------------------------------------
 int dex_mel_frames(int n_samples) { return n_samples / 256 + 1; }
 
+// standalone mel context: the DFT basis and the Slaney filterbank, nothing else (a preprocess job needs no score network)
+struct DexMel { float* basis = nullptr; float* filt = nullptr; std::string err; };
+
+int dex_mel_create(DexMel** out) {
+    if (!out) return DEX_ERR_ARG;
+    DexMel* m = new DexMel();
+    std::vector<float> basis, filt;
+    build_mel_constants(basis, filt);
+    if (hipMalloc((void**)&m->basis, basis.size() * sizeof(float)) != hipSuccess || hipMalloc((void**)&m->filt, filt.size() * sizeof(float)) != hipSuccess ||
+        hipMemcpy(m->basis, basis.data(), basis.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(m->filt, filt.data(), filt.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+        if (m->basis) hipFree(m->basis);
+        if (m->filt) hipFree(m->filt);
+        delete m;
+        return DEX_ERR_HIP;
+    }
+    *out = m;
+    return DEX_OK;
+}
+void dex_mel_destroy(DexMel* m) { if (m) { hipFree(m->basis); hipFree(m->filt); delete m; } }
+const char* dex_mel_last_error(const DexMel* m) { return m ? m->err.c_str() : "null mel context"; }
+
+static size_t mel_pad_stride(int n) { return ((size_t)(dex_mel_frames(n) - 1) * 256 + 1024 + 256 + 63) & ~size_t(63); }
+size_t dex_mel_workspace_bytes(int B, int n) {
+    if (B < 1 || n < 1) return 0;
+    return ((size_t)B * mel_pad_stride(n) + (size_t)B * dex_mel_frames(n) * 1152) * sizeof(float) + 512;
+}
+
+// the whole front-end for B equally long rows: pad/clip -> windowed DFT as ONE batched implicit GEMM -> magnitude / mel / log
+static int mel_enqueue(const float* basis, const float* filt, const float* wav_dev, int B, int n, float* mel_dev, float* energy_dev, void* ws, hipStream_t st) {
+    const int frames = dex_mel_frames(n), NP = 1152;
+    const size_t pstride = mel_pad_stride(n);
+    float* ypad = (float*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    float* spec = ypad + (size_t)B * pstride;
+    launch_wav_pad(wav_dev, n, 512, ypad, (int)pstride, st, B, (long)pstride);
+    // per utterance: frames x 1152 = (frames x 1024 overlapping-row view, row stride = hop) x basis[1024][1152]
+    IGemmP g{};
+    g.A = ypad; g.lda = 256; g.a_bstride = (long)pstride; g.a_coff = 0; g.Hi = 1; g.Wi = frames; g.Cin = 1024;
+    g.KH = 1; g.KW = 1; g.sh = 1; g.sw = 1; g.step_h = 1; g.step_w = 1; g.Ho = 1; g.Wo = frames;
+    g.W = basis; g.N = NP; g.K = 1024; g.ksplit = 1; g.groups = 1;
+    g.C = spec; g.ldc = NP; g.c_bstride = (long)frames * NP; g.OHf = 1; g.OWf = frames; g.osh = 1; g.osw = 1; g.gate_nstride = 1; g.B = B;
+    launch_igemm(g, DEX_PREC_FP32, st);
+    MagMelP m{spec, NP, 576, frames, 513, filt, 80, mel_dev, energy_dev};
+    launch_magmel(m, st, B);
+    return hipGetLastError() == hipSuccess ? DEX_OK : DEX_ERR_HIP;
+}
+
+int dex_mel_spectrogram(DexMel* m, const float* wav_dev, int B, int n, float* mel_dev, float* energy_dev, void* workspace_dev,
+                        size_t workspace_bytes, dex_stream_t stream) {
+    if (!m) return DEX_ERR_ARG;
+    auto fail = [&](const char* msg) { m->err = msg; return DEX_ERR_ARG; };
+    if (!wav_dev || !mel_dev || !energy_dev || !workspace_dev) return fail("null pointer argument");
+    if (B < 1) return fail("B must be >= 1");
+    if (n < 513) return fail("reflect padding needs at least 513 samples per row");
+    if (workspace_bytes < dex_mel_workspace_bytes(B, n)) return fail("workspace too small (dex_mel_workspace_bytes)");
+    const int rc = mel_enqueue(m->basis, m->filt, wav_dev, B, n, mel_dev, energy_dev, workspace_dev, (hipStream_t)stream);
+    if (rc) m->err = "kernel launch failed";
+    return rc;
+}
+
+int dex_lf0_normalize(const float* f0_dev, const int* lengths_dev, int B, int T, float* lf0_dev, dex_stream_t stream) {
+    if (!f0_dev || !lf0_dev || B < 1 || T < 1 || T > 16384) return DEX_ERR_ARG;       // (the voiced frames of an utterance are staged in 64 KB of LDS)
+    launch_lf0_normalize(f0_dev, lengths_dev, B, T, lf0_dev, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? DEX_OK : DEX_ERR_HIP;
+}
+
 int dex_mel_from_wav(DexCtx* x, const float* wav_dev, int n, float* mel_dev, float* energy_dev, dex_stream_t stream) {
     if (!x || !wav_dev || !mel_dev || !energy_dev) return DEX_ERR_ARG;
     if (n < 513) return x->fail(DEX_ERR_ARG, "reflect padding needs at least 513 samples (got %d)", n);
@@ -1542,28 +1608,14 @@ int dex_mel_from_wav(DexCtx* x, const float* wav_dev, int n, float* mel_dev, flo
         HIPCHK(x, hipMemcpy(x->mel_basis, basis.data(), basis.size() * sizeof(float), hipMemcpyHostToDevice));
         HIPCHK(x, hipMemcpy(x->mel_filt, filt.data(), filt.size() * sizeof(float), hipMemcpyHostToDevice));
     }
-    const int frames = dex_mel_frames(n), NP = 1152;
-    const size_t pad_len = (size_t)(frames - 1) * 256 + 1024 + 256;
-    const size_t need = (pad_len + (size_t)frames * NP) * sizeof(float) + 512;
+    const size_t need = dex_mel_workspace_bytes(1, n);
     if (need > x->mel_ws_bytes) {       // grow-only scratch, single-stream use (documented in include/dex_amd.h)
         if (x->mel_ws) { HIPCHK(x, hipStreamSynchronize(st)); hipFree(x->mel_ws); }
         x->mel_ws = nullptr; x->mel_ws_bytes = 0;
         HIPCHK(x, hipMalloc(&x->mel_ws, need));
         x->mel_ws_bytes = need;
     }
-    float* ypad = (float*)x->mel_ws;
-    float* spec = ypad + ((pad_len + 63) & ~size_t(63));
-    launch_wav_pad(wav_dev, n, 512, ypad, (int)pad_len, st);
-    // frames x 1152 = (frames x 1024 overlapping-row view, row stride = hop) x basis[1024][1152]
-    IGemmP g{};
-    g.A = ypad; g.lda = 256; g.a_bstride = 0; g.a_coff = 0; g.Hi = 1; g.Wi = frames; g.Cin = 1024;
-    g.KH = 1; g.KW = 1; g.sh = 1; g.sw = 1; g.step_h = 1; g.step_w = 1; g.Ho = 1; g.Wo = frames;
-    g.W = x->mel_basis; g.N = NP; g.K = 1024; g.ksplit = 1; g.groups = 1;
-    g.C = spec; g.ldc = NP; g.c_bstride = 0; g.OHf = 1; g.OWf = frames; g.osh = 1; g.osw = 1; g.gate_nstride = 1; g.B = 1;
-    launch_igemm(g, DEX_PREC_FP32, st);
-    MagMelP m{spec, NP, 576, frames, 513, x->mel_filt, 80, mel_dev, energy_dev};
-    launch_magmel(m, st);
-    HIPCHK(x, hipGetLastError());
+    if (mel_enqueue(x->mel_basis, x->mel_filt, wav_dev, 1, n, mel_dev, energy_dev, x->mel_ws, st)) return x->fail(DEX_ERR_HIP, "mel front-end launch failed");
     return DEX_OK;
 }
 

@@ -397,11 +397,13 @@ void launch_align(const AlignP& p, hipStream_t st);
 
 // STFT / mel -------------------------------------------------------------------------------------
 // clip to [-1,1] + reflect-pad n_fft/2 on both sides (stft.py:60-66, tools.py:9)
-void launch_wav_pad(const float* wav, int n, int pad, float* out, int out_len, hipStream_t st);
+void launch_wav_pad(const float* wav, int n, int pad, float* out, int out_len, hipStream_t st, int B = 1, long out_bstride = 0);
 // spec [frames][ld] holds re at cols [0,513) and im at cols [im_off, im_off+513) ->
 // mel[j][f] = log(max(sum_k melW[j][k]*|spec|, 1e-5)), energy[f] = ||mag||_2   (stft.py:172-176)
 struct MagMelP { const float* spec; int ld; int im_off; int frames; int nbins; const float* melW; int nmel;
                  float* mel; float* energy; };
-void launch_magmel(const MagMelP& p, hipStream_t st);
+void launch_magmel(const MagMelP& p, hipStream_t st, int B = 1);
+// DEX style front-end: log-f0 + per-utterance normalisation (DEX-TTS/synthesize.py:26-38,55-58); lengths may be null
+void launch_lf0_normalize(const float* f0, const int* lengths, int B, int T, float* out, hipStream_t st);
 
 }  // namespace dex

@@ -5,7 +5,8 @@
 
 namespace dex {
 
-__global__ void wav_pad_kernel(const float* wav, int n, int pad, float* out, int out_len) {
+__global__ void wav_pad_kernel(const float* wav, int n, int pad, float* out, int out_len, long out_bstride) {
+    wav += (long)blockIdx.y * n; out += (long)blockIdx.y * out_bstride;           // blockIdx.y = utterance
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < out_len; i += gridDim.x * blockDim.x) {
         int j = i - pad;
         float v = 0.f;
@@ -17,9 +18,9 @@ __global__ void wav_pad_kernel(const float* wav, int n, int pad, float* out, int
         out[i] = v;
     }
 }
-void launch_wav_pad(const float* wav, int n, int pad, float* out, int out_len, hipStream_t st) {
+void launch_wav_pad(const float* wav, int n, int pad, float* out, int out_len, hipStream_t st, int B, long out_bstride) {
     int blocks = (out_len + 255) / 256; if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(wav_pad_kernel, dim3(blocks), dim3(256), 0, st, wav, n, pad, out, out_len);
+    hipLaunchKernelGGL(wav_pad_kernel, dim3(blocks, B), dim3(256), 0, st, wav, n, pad, out, out_len, out_bstride);
 }
 
 // one block per frame: magnitudes into LDS, then 80 mel rows (one wave-strided dot each) and the energy.
@@ -27,7 +28,10 @@ __global__ __launch_bounds__(256) void magmel_kernel(const MagMelP p) {
     __shared__ float mag[544];
     __shared__ float esum[4];
     const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* row = p.spec + (long)f * p.ld;
+    const int b = blockIdx.y;                                                    // utterance
+    const float* row = p.spec + ((long)b * p.frames + f) * p.ld;
+    float* mel = p.mel + (long)b * p.nmel * p.frames;
+    float* energy = p.energy + (long)b * p.frames;
     float e = 0.f;
     for (int k = tid; k < p.nbins; k += 256) {
         const float re = row[k], im = row[p.im_off + k];
@@ -38,17 +42,85 @@ __global__ __launch_bounds__(256) void magmel_kernel(const MagMelP p) {
     for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o);
     if (lane == 0) esum[wave] = e;
     __syncthreads();
-    if (tid == 0) p.energy[f] = sqrtf((esum[0] + esum[1]) + (esum[2] + esum[3]));
+    if (tid == 0) energy[f] = sqrtf((esum[0] + esum[1]) + (esum[2] + esum[3]));
     for (int j = wave; j < p.nmel; j += 4) {
         const float* w = p.melW + (long)j * p.nbins;
         float a = 0.f;
         for (int k = lane; k < p.nbins; k += 64) a = fmaf(w[k], mag[k], a);
         for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
-        if (lane == 0) p.mel[(long)j * p.frames + f] = logf(fmaxf(a, 1e-5f));
+        if (lane == 0) mel[(long)j * p.frames + f] = logf(fmaxf(a, 1e-5f));
     }
 }
-void launch_magmel(const MagMelP& p, hipStream_t st) {
-    hipLaunchKernelGGL(magmel_kernel, dim3(p.frames), dim3(256), 0, st, p);
+void launch_magmel(const MagMelP& p, hipStream_t st, int B) {
+    hipLaunchKernelGGL(magmel_kernel, dim3(p.frames, B), dim3(256), 0, st, p);
+}
+
+// log-f0 normalisation of the DEX style front-end (DEX-TTS/synthesize.py:26-38,55-58): lf0 = log(f0) where f0 != 0, then over the
+// entries with lf0 != 0 (an f0 of exactly 1 Hz counts as unvoiced, as in the reference): (lf0 - mean) / (std + 1e-8), or lf0 - mean
+// when std == 0; unvoiced entries and everything past the utterance's length stay 0.
+// The statistics repeat numpy's fp32 arithmetic OPERATION BY OPERATION — np.mean / np.std of a contiguous float32 array reduce as
+// a[0] + pairwise_sum(a[1:]) with numpy's 8-accumulator / 128-element-block pairwise scheme, the variance from the separately
+// rounded (a - mean)^2 — because on a (nearly) constant pitch track the reference's std is nothing BUT that round-off (a constant
+// 200 Hz track normalises to -0.979, not 0), so only the same operation order reproduces it.  One wave per utterance: the voiced
+// values are compacted in order into LDS by ballot, lane 0 runs the two reductions (T is a few hundred frames), all lanes write.
+__device__ float np_pairwise_sum_f32(const float* a, int n) {
+    if (n < 8) {
+        float r = -0.0f;
+        for (int i = 0; i < n; ++i) r = __fadd_rn(r, a[i]);
+        return r;
+    }
+    if (n <= 128) {
+        float r[8];
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        int i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], a[i + j]);
+        float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])), __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+        for (; i < n; ++i) res = __fadd_rn(res, a[i]);
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return __fadd_rn(np_pairwise_sum_f32(a, n2), np_pairwise_sum_f32(a + n2, n - n2));
+}
+__device__ float np_add_reduce_f32(const float* a, int n) {       // np.add.reduce: the first element is the initial value
+    return n == 1 ? a[0] : __fadd_rn(a[0], np_pairwise_sum_f32(a + 1, n - 1));
+}
+
+__global__ __launch_bounds__(64) void lf0_normalize_kernel(const float* __restrict__ f0, const int* __restrict__ lengths, int T, float* __restrict__ out) {
+    extern __shared__ float lf0_buf[];                      // [T] compacted voiced log-f0, then their squared deviations
+    __shared__ float stat[2];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int len = lengths ? min(max(lengths[b], 0), T) : T;
+    f0 += (long)b * T; out += (long)b * T;
+    auto lf = [&](int i) { const float v = f0[i]; return v != 0.f ? logf(v) : 0.f; };
+    int c = 0;
+    for (int base = 0; base < len; base += 64) {
+        const int i = base + lane;
+        const float v = i < len ? lf(i) : 0.f;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(v != 0.f);
+        if (v != 0.f) lf0_buf[c + __popcll(m & ((1ull << lane) - 1ull))] = v;
+        c += __popcll(m);
+    }
+    __syncthreads();
+    if (lane == 0 && c > 0) {
+        const float fc = (float)c;
+        const float mean = __fdiv_rn(np_add_reduce_f32(lf0_buf, c), fc);
+        for (int i = 0; i < c; ++i) { const float d = __fsub_rn(lf0_buf[i], mean); lf0_buf[i] = __fmul_rn(d, d); }
+        stat[0] = mean;
+        stat[1] = __fsqrt_rn(__fdiv_rn(np_add_reduce_f32(lf0_buf, c), fc));
+    }
+    __syncthreads();
+    const float mean = stat[0], sd = stat[1];
+    const float den = __fadd_rn(sd, 1e-8f);
+    for (int i = lane; i < T; i += 64) {
+        float v = i < len ? lf(i) : 0.f;
+        if (v != 0.f && c > 0) v = sd == 0.f ? __fsub_rn(v, mean) : __fdiv_rn(__fsub_rn(v, mean), den);
+        out[i] = v;
+    }
+}
+void launch_lf0_normalize(const float* f0, const int* lengths, int B, int T, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(lf0_normalize_kernel, dim3(B), dim3(64), (size_t)T * sizeof(float), st, f0, lengths, T, out);
 }
 
 }  // namespace dex

@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from .config import DiTConfig, ScoreNetConfig, param_shapes
+from .edm import EDMLoss
 from .engine import ScoreNetEngine
 
 
@@ -80,7 +81,8 @@ class Diffusion(nn.Module):
         self.loss_type = loss_type
         self.denoise_fn = _build_tree(param_shapes(self.cfg))
         self.precond_model = _Precond(self.denoise_fn)
-        self.loss_fn = None                      # EDMLoss is training-only (edm.py:22-68): out of scope
+        self.loss_fn = EDMLoss(n_feats=n_feats, loss_type=loss_type)       # diffusion.py:215: forward-only here (dex_tts_amd/edm.py)
+        self.precond_model._denoise_once = lambda x, sigma, mask, mu, **kw: self.engine(x.device).denoise_once(x, sigma, mask, mu, **kw)
         self.precision = "fp32"
         self.use_graph = False
         self.solver = "euler"                    # the reference wires 'euler' (diffusion.py:216); 'heun' = edm.py:207-214
@@ -146,9 +148,9 @@ class Diffusion(nn.Module):
             raise TypeError("too many positional arguments")
         for n, v in zip(names, args):
             vals[n] = v
-        if not vals["infer"]:
-            raise NotImplementedError("the training-loss branch (EDMLoss, edm.py:22-68) is out of scope of the "
-                                      "MI355X sampler; use the reference module for training")
+        if not vals["infer"]:                     # diffusion.py:222-224 / :252-254: the EDM training-loss VALUE (no backward on this path)
+            dex = (vals["ref"], vals["ref_lengths"], vals["sty"], vals["sty_lengths"]) if self.cfg.variant == "dex" else ()
+            return self.loss_fn(self.precond_model, x, mask, mu, *dex, spk=vals["spk"], mask_ratio=vals["mask_ratio"])
         shape = (mu.shape[0], 80, mu.shape[2])
         z = torch.randn(shape, device=x.device) / vals["temperature"] + mu            # diffusion.py:227
         if self.cfg.variant == "dex":

@@ -13,7 +13,7 @@ partition is a pure function of the lengths, so every rank derives the same deal
 """
 from __future__ import annotations
 
-from typing import Callable, List, Sequence
+from typing import Callable, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -40,8 +40,11 @@ def _world_rank(group):
     return 1, 0
 
 
-def take_shard(t: torch.Tensor, lengths: Sequence[int], group=None) -> torch.Tensor:
-    """Rows of a full-batch tensor that belong to this rank, in shard order (what ``local=True`` expects)."""
+def take_shard(t, lengths: Sequence[int], group=None):
+    """Rows of a full-batch tensor (or of every tensor of a list) that belong to this rank, in shard order (what
+    ``local=True`` expects)."""
+    if isinstance(t, (list, tuple)):
+        return [take_shard(u, lengths, group) for u in t]
     world, rank = _world_rank(group)
     idx = torch.as_tensor(partition(lengths, world)[rank], dtype=torch.long, device=t.device)
     return t.index_select(0, idx)
@@ -65,33 +68,45 @@ def _all_gather(out_local: torch.Tensor, world: int, group) -> torch.Tensor:
 
 def sample_sharded(sample_fn: Callable[[torch.Tensor, torch.Tensor, torch.Tensor], torch.Tensor],
                    mu: torch.Tensor, mask: torch.Tensor, z: torch.Tensor, lengths: Sequence[int],
-                   group=None, local: bool = False) -> torch.Tensor:
+                   group=None, local: bool = False, extras: Optional[dict] = None) -> torch.Tensor:
     """Sample a batch of ``len(lengths)`` utterances over the ranks of ``group``.
 
     ``lengths`` lists ALL utterances (identical on every rank); T of the tensors is already the global padded
     length.  With ``local=False`` every rank passes the full batch (mu, z: [B,80,T], mask: [B,1,T]) and its rows are
     selected here; with ``local=True`` a rank passes only its own utterances in shard order (``take_shard``).
     Each rank runs ``sample_fn(z, mask, mu) -> [b,80,T]`` on its shard; ONE all-gather exchanges the finished mels
-    and one ``index_copy_`` puts them back in input order.  Returns the full [B,80,T] on every rank."""
+    and one ``index_copy_`` puts them back in input order.  Returns the full [B,80,T] on every rank.
+
+    ``extras``: further per-utterance inputs of the sampler, name -> tensor or list of tensors with the utterance on dim 0
+    (DEX: ``ref`` = the six [B,mid,Tr] TIV skips, ``sty`` [B,mid,Ts], ``sty_lengths`` [B]; GeDEX-VCTK: ``spk`` [B,64]).  They
+    are sharded exactly like mu / mask / z and handed to ``sample_fn`` as keyword arguments."""
     world, rank = _world_rank(group)
     B = len(lengths)
     shards = partition(lengths, world)
     per = max(len(s) for s in shards)
     mine = shards[rank]
+    extras = dict(extras or {})
     if not local and world > 1:
         idx = torch.as_tensor(mine, dtype=torch.long, device=mu.device)
         mu, mask, z = mu.index_select(0, idx), mask.index_select(0, idx), z.index_select(0, idx)
+        sel = lambda t: t.index_select(0, idx.to(t.device))
+        extras = {k: ([sel(t) for t in v] if isinstance(v, (list, tuple)) else sel(v)) for k, v in extras.items()}
+    for k, v in extras.items():
+        for t in (v if isinstance(v, (list, tuple)) else [v]):
+            if t.shape[0] != len(mine):
+                raise ValueError(f"rank {rank}: extras[{k!r}] holds {t.shape[0]} utterances, its shard has {len(mine)}")
     if mu.shape[0] != len(mine):
         raise ValueError(f"rank {rank} holds {mu.shape[0]} utterances, its shard has {len(mine)}")
     F, T = mu.shape[1], mu.shape[2]
     if len(mine) == per:
-        out_local = sample_fn(z, mask, mu)
+        out_local = sample_fn(z, mask, mu, **extras)
     else:                                   # uneven deal: pad the gather slot, not the sampler batch
         out_local = torch.zeros(per, F, T, dtype=torch.float32, device=mu.device)
         if mine:
-            out_local[: len(mine)] = sample_fn(z, mask, mu)
-    if world == 1:
-        return out_local
+            out_local[: len(mine)] = sample_fn(z, mask, mu, **extras)
+    if world == 1 and not local:
+        return out_local                    # full batch in, sampled in input order: nothing to exchange or permute
+    # (world == 1 with local=True: the caller handed the rows in SHARD order — length-sorted — so the un-permute below still runs)
     gathered = _all_gather(out_local, world, group)                     # [world * per, F, T], slot r*per + s
     src = [r * per + s for r, sh in enumerate(shards) for s in range(len(sh))]
     dst = [i for sh in shards for i in sh]

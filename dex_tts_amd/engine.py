@@ -167,10 +167,14 @@ class ScoreNetEngine:
         shape a hit in the library's graph cache."""
         bufs = self._stage.get(key)
         if bufs is None:
-            if len(self._stage) >= 8:
-                self._stage.pop(next(iter(self._stage)))
+            if len(self._stage) >= 8:                       # least recently used shape goes, together with its output buffer
+                old = next(iter(self._stage))
+                self._stage.pop(old)
+                self._stage_out.pop(old, None)
             bufs = [torch.empty_like(t) for t in tensors]
             self._stage[key] = bufs
+        else:
+            self._stage[key] = self._stage.pop(key)          # dicts keep insertion order: re-insert = most recently used
         for b, t in zip(bufs, tensors):
             b.copy_(t, non_blocking=True)
         return bufs

@@ -137,7 +137,10 @@ def main(argv=None):
     cfg = load_reference_config(a.config)
     model = from_config(cfg)
     if a.ckpt:
-        model.load_state_dict(decoder_state_dict(torch.load(a.ckpt, map_location="cpu")), strict=False)
+        sd = decoder_state_dict(torch.load(a.ckpt, map_location="cpu"))
+        if not sd:
+            raise SystemExit(f"{a.ckpt}: no 'decoder.*' entries — not a DEX-TTS / GeDEX-TTS model checkpoint")
+        model.load_state_dict(sd, strict=True)             # as the reference does (synthesize.py:20-24): a partial load must not pass silently
     else:
         from . import synth
         from .config import param_shapes

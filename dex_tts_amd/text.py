@@ -6,7 +6,8 @@ lines of the TTS forward (tts.py:37-50) as ``TextEncoder.align``.  Inference onl
     enc = TextEncoder(**cfg.encoder, n_vocab=.., n_feats=80, n_spks=.., spk_emb_dim=64)      # as tts.py:24 builds it
     enc.load_state_dict({k[len("encoder."):]: v for k, v in ckpt.items() if k.startswith("encoder.")})
     mu_x, logw, x_mask = enc(x, x_lengths, spk=spk)                 # DEX: enc(x, x_lengths, sty_enc)
-    mu_y, y_mask, attn, y_lengths, y_max_length = enc.align(length_scale=1.0)
+    mu_x, logw, x_mask = enc(x, x_lengths, spk=spk, length_scale=1.0)   # the duration scale belongs to forward (tts.py:37)
+    mu_y, y_mask, attn, y_lengths, y_max_length = enc.align()       # alignment of the LAST forward
 """
 from __future__ import annotations
 
@@ -162,6 +163,9 @@ class TextEncoder(nn.Module):
             B, T = tok.shape
             if int(x_lengths.max()) > T or int(x_lengths.min()) < 1:
                 raise ValueError("x_lengths must lie in [1, x.shape[1]]")
+            lo, hi = int(tok.min()), int(tok.max())
+            if lo < 0 or hi >= self.n_vocab:                 # nn.Embedding raises (text_encoder.py:130); the kernel would clamp silently
+                raise IndexError(f"token id out of range: [{lo}, {hi}] outside [0, {self.n_vocab})")
             f = lambda t: None if t is None else t.to(device=dev, dtype=torch.float32).contiguous()
             spk, sty = f(spk if self.n_spks > 1 else None), f(sty)
             if self.n_spks > 1 and (spk is None or tuple(spk.shape) != (B, self.spk_emb_dim)):

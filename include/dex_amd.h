@@ -148,6 +148,23 @@ int  dex_mel_frames(int n_samples);
 int  dex_mel_from_wav(DexCtx* ctx, const float* wav_dev, int n_samples, float* mel_dev, float* energy_dev,
                       dex_stream_t stream);
 
+/* The same front-end without a score-network context and for a batch — replaces TacotronSTFT.mel_spectrogram(y [B,L])
+ * (audio/stft.py:159-178, called by preprocess/preprocessor/preprocessor.py:100 and audio/tools.py:8-15): B equally long rows
+ * in ONE pass (pad/clip kernel, one batched windowed-DFT GEMM, one magnitude/mel/log kernel).  wav [B,L] fp32 (clipped to
+ * [-1,1] here) -> mel [B,80,frames], energy [B,frames]; the caller owns the workspace (dex_mel_workspace_bytes). */
+typedef struct DexMel DexMel;
+int  dex_mel_create(DexMel** out);
+void dex_mel_destroy(DexMel* mel);
+const char* dex_mel_last_error(const DexMel* mel);
+size_t dex_mel_workspace_bytes(int B, int n_samples);
+int  dex_mel_spectrogram(DexMel* mel, const float* wav_dev, int B, int n_samples, float* mel_dev, float* energy_dev,
+                         void* workspace_dev, size_t workspace_bytes, dex_stream_t stream);
+
+/* Deterministic tail of the DEX f0 front-end (DEX-TTS/synthesize.py:26-38,55-58): f0 [B,T] in Hz (0 = unvoiced; from the
+ * host's DIO/StoneMask, a third-party CPU algorithm that stays on the host) -> lf0 [B,T] = normalize_lf0(log f0), what
+ * dex_style_encode takes as lf0_dev.  lengths_dev [B] int32 or NULL (= T); positions past an utterance's length are 0. */
+int  dex_lf0_normalize(const float* f0_dev, const int* lengths_dev, int B, int T, float* lf0_dev, dex_stream_t stream);
+
 /* ---- Vocoder: HiFi-GAN generator (GeDEX-TTS/hifigan/models.py:112-173, built by src/utils.py:251-281 from
  * hifigan/config.json) — the step right after the sampler: mel [B,80,T] -> waveform [B, T * prod(upsample_rates)].
  * A separate context: it shares nothing with the score network. */

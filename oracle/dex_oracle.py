@@ -313,6 +313,54 @@ def edm_precond(W, cfg, x: Tensor, sigma: Tensor, mask: Tensor, mu: Tensor, **kw
     return c_skip * x + c_out * f
 
 
+def edm_loss_weight(sigma: Tensor, loss_type: str = "base") -> Tensor:
+    """The per-utterance weight lambda(sigma) of EDMLoss.forward — edm.py:37-63, branch by branch (note the reference's
+    if / if / if-elif chain: 'base_min_*' computes its weight in the second ``if`` and then falls through the third chain
+    untouched, which is what happens here too)."""
+    snr = 1 / sigma ** 2
+    base = (sigma ** 2 + SIGMA_DATA ** 2) / (sigma * SIGMA_DATA) ** 2
+    if loss_type == "base":
+        return base
+    if loss_type.startswith("base_min_"):
+        k = float(loss_type.split("base_min_")[-1])
+        return torch.minimum(base, k * torch.ones_like(sigma))
+    if loss_type.startswith("base_log_"):
+        k = float(loss_type.split("base_log_")[-1])
+        w = base.clone()
+        hit = w >= k
+        w[hit] = torch.log(w[hit]) + (k - np.log(k))
+        return w
+    if loss_type.startswith("min_snr_"):
+        return torch.minimum(snr, float(loss_type.split("min_snr_")[-1]) * torch.ones_like(sigma))
+    if loss_type.startswith("max_snr_"):
+        return torch.maximum(snr, float(loss_type.split("max_snr_")[-1]) * torch.ones_like(sigma))
+    if loss_type == "snr":
+        return snr
+    if loss_type == "inv_snr":
+        return 1.0 / snr
+    raise ValueError(f"loss_type {loss_type!r}: the reference would leave `weight` undefined (edm.py:37-63)")
+
+
+def edm_loss(W, cfg, x0: Tensor, mask: Tensor, mu: Tensor, rnd_normal: Tensor, eps: Tensor, loss_type: str = "base",
+             P_mean: float = -1.2, P_std: float = 1.2, n_feats: int = 80, **kw) -> Tensor:
+    """EDMLoss.forward — edm.py:31-68 — with its two draws as inputs (``rnd_normal`` = randn([B,1,1]), ``eps`` = randn_like(x0)):
+    sigma = exp(rnd P_std + P_mean) per utterance; n = (eps + mu) sigma; D = EDMPrecond(x0 + n, sigma);
+    loss = sum(weight (D - x0)^2) / sum(mask n_feats).  The denoiser is evaluated utterance by utterance (every normalisation
+    and attention of the net is per utterance, and the DEX adaptors of the reference only broadcast a single t)."""
+    sigma = (rnd_normal * P_std + P_mean).exp()
+    weight = edm_loss_weight(sigma, loss_type)
+    n = (eps + mu) * sigma
+    B = x0.shape[0]
+    d = []
+    for b in range(B):
+        kb = {}
+        for k, v in kw.items():
+            kb[k] = [r[b:b + 1] for r in v] if isinstance(v, (list, tuple)) else v[b:b + 1]
+        d.append(edm_precond(W, cfg, (x0 + n)[b:b + 1], sigma[b].reshape(()), mask[b:b + 1], mu[b:b + 1], **kb))
+    D = torch.cat(d, 0)
+    return torch.sum(weight * ((D - x0) ** 2)) / torch.sum(mask * n_feats)
+
+
 def churn_step(x: Tensor, t_cur: Tensor, n_steps: int, noise_i: Optional[Tensor], S_churn: float, S_min: float, S_max: float,
                S_noise: float):
     """"Increase noise temporarily" — edm.py:194-196 with schedule='linear', scaling='none' (sigma(t) = t, s(t) = 1):

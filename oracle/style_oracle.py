@@ -129,3 +129,19 @@ def style_forward(W: Dict[str, Tensor], ref: Tensor, ref_lengths: Tensor, sty: T
     sty_dec = F.conv1d(sty_dec, W["conv_sty.weight"], W["conv_sty.bias"])
     _, skips = tiv_encoder(W, ref, ref_mask)
     return {"sty_enc": sty_enc, "sty_dec": sty_dec, "ref_skips": skips, "vq_idx": idx}
+
+
+def lf0_from_f0(f0):
+    """DEX-TTS/synthesize.py:55-58 + normalize_lf0 (:26-38): log of the voiced frames, then over the entries with lf0 != 0
+    (lf0 - mean) / (std + 1e-8) — or lf0 - mean when std == 0 —, the others 0.  f0: 1-D float32 numpy array in Hz."""
+    import numpy as np
+    f0 = np.asarray(f0, dtype=np.float32)
+    lf0 = f0.copy()
+    nz = np.nonzero(f0)
+    lf0[nz] = np.log(f0[nz])
+    zero = lf0 == 0
+    if (~zero).any():
+        mean, std = np.mean(lf0[~zero]), np.std(lf0[~zero])
+        lf0 = (lf0 - mean) if std == 0 else (lf0 - mean) / (std + 1e-8)
+        lf0[zero] = 0.0
+    return lf0.astype(np.float32)

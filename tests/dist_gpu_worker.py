@@ -31,11 +31,18 @@ def main():
     mu, mask, z, _ = synth.make_inputs(len(lengths), T, lengths)
     full_in = [torch.from_numpy(a).to(dev) for a in (mu, mask, z)]
     mu_l, mask_l, z_l = (D.take_shard(t, lengths) for t in full_in)          # what a rank would hold in production
-    fn = lambda zz, mm, uu: eng.sample(zz, mm, uu, n_steps)
-    got = D.sample_sharded(fn, mu_l, mask_l, z_l, lengths, local=True)
+    extras_full, extras_l = {}, {}
+    if cfg.variant == "dex":                                                 # the style inputs shard with their utterances
+        B = len(lengths)
+        ref, _, sty, sl = synth.make_dex_style(B, 44, 52, cfg.mid_dim, sty_lengths=[52 - 7 * (i % 5) for i in range(B)])
+        extras_full = {"ref": [torch.from_numpy(r).to(dev) for r in ref], "sty": torch.from_numpy(sty).to(dev),
+                       "sty_lengths": torch.from_numpy(np.asarray(sl)).to(dev)}
+        extras_l = {k: D.take_shard(v, lengths) for k, v in extras_full.items()}
+    fn = lambda zz, mm, uu, **kw: eng.sample(zz, mm, uu, n_steps, **kw)
+    got = D.sample_sharded(fn, mu_l, mask_l, z_l, lengths, local=True, extras=extras_l)
     res = {"rank": rank, "world": world, "shape": list(got.shape)}
     if rank == 0:
-        ref = eng.sample(full_in[2], full_in[1], full_in[0], n_steps)
+        ref = eng.sample(full_in[2], full_in[1], full_in[0], n_steps, **extras_full)
         res["bitwise_equal"] = bool(torch.equal(got, ref))
         res["max_abs_diff"] = float((got - ref).abs().max())
         res["finite"] = bool(torch.isfinite(got).all())

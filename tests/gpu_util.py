@@ -26,6 +26,31 @@ def record(tag, **vals):
             f.write(json.dumps({"tag": tag, **{k: float(v) for k, v in vals.items()}}) + "\n")
     except OSError:
         pass
+
+
+def fp32_call_ok(tag, got, ref):
+    """fp32 mode, one EDMPrecond call: max|d| <= FP32_CALL_REL * max(1, |y|max) (tests/tolerances.py); records the measurement."""
+    from tests.tolerances import FP32_CALL_REL
+    e = np.abs(got - ref)
+    record(f"{tag}:fp32:call", max=e.max(), mean=e.mean(), ref_absmax=np.abs(ref).max())
+    assert np.isfinite(got).all() and e.max() <= FP32_CALL_REL * max(1.0, np.abs(ref).max()), (tag, float(e.max()), float(np.abs(ref).max()))
+
+
+def fp32_sampler_ok(tag, got, ref):
+    """fp32 mode, a whole sampler call: max|d| <= FP32_SAMPLER_MAX and mean|d| <= FP32_SAMPLER_MEAN; records the measurement."""
+    from tests.tolerances import FP32_SAMPLER_MAX, FP32_SAMPLER_MEAN
+    e = np.abs(got - ref)
+    record(f"{tag}:fp32:sampler", max=e.max(), mean=e.mean(), ref_absmax=np.abs(ref).max())
+    assert np.isfinite(got).all() and e.max() <= FP32_SAMPLER_MAX and e.mean() <= FP32_SAMPLER_MEAN, (tag, float(e.max()), float(e.mean()))
+
+
+def fp32_taps_ok(tag, terr):
+    from tests.tolerances import FP32_TAP_REL
+    for k, (err, mx) in terr.items():
+        record(f"{tag}.{k}:fp32:tap", max=err, ref_absmax=mx)
+        assert err <= FP32_TAP_REL * max(1.0, mx), (tag, k, err, mx)
+
+
 _ORACLE = {}          # oracle outputs are mode-independent: computed once per (case, sigma / n) and reused across precisions
 
 

@@ -22,15 +22,29 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, lengths, T, q, local=False):
+def fake_dex_sampler(z, mask, mu, ref=None, sty=None, sty_lengths=None):
+    # the DEX inputs enter per utterance, like the style adaptors: a wrong row in any of them changes that utterance's result
+    s = sum(r.mean(dim=(1, 2)) * (j + 1) for j, r in enumerate(ref)) + sty.amax(dim=(1, 2)) + sty_lengths.to(torch.float32) * 0.01
+    return fake_sampler(z, mask, mu) + s[:, None, None]
+
+
+def _dex_extras(B):
+    ref, _, sty, sl = synth.make_dex_style(B, 12, 16, 8, sty_lengths=[16 - (i % 5) for i in range(B)])
+    return {"ref": [torch.from_numpy(r) for r in ref], "sty": torch.from_numpy(sty), "sty_lengths": torch.from_numpy(sl)}
+
+
+def _worker(rank, world, port, lengths, T, q, local=False, dex=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     mu, mask, z, _ = synth.make_inputs(len(lengths), T, lengths)
     mu, mask, z = map(torch.from_numpy, (mu, mask, z))
+    extras = _dex_extras(len(lengths)) if dex else None
     if local:       # a rank holds only its own utterances (in shard order) plus the lengths of all of them
         mu, mask, z = (D.take_shard(t, lengths) for t in (mu, mask, z))
         assert mu.shape[0] == len(D.partition(lengths, world)[rank])
-    full = D.sample_sharded(fake_sampler, mu, mask, z, lengths, local=local)
+        if dex:
+            extras = {k: D.take_shard(v, lengths) for k, v in extras.items()}
+    full = D.sample_sharded(fake_dex_sampler if dex else fake_sampler, mu, mask, z, lengths, local=local, extras=extras)
     q.put((rank, full.numpy()))
     dist.barrier()
     dist.destroy_process_group()
@@ -45,15 +59,16 @@ def test_partition_balanced():
     assert D.padded_length(lengths) == 300 and D.padded_length([301]) == 304
 
 
-@pytest.mark.parametrize("lengths,local", [([64, 40, 52, 30, 64], False), ([16], False), ([64, 40, 52, 30, 64], True),
-                                           ([48, 48, 20, 36], True)])
-def test_sharded_equals_unsharded(lengths, local):
+@pytest.mark.parametrize("lengths,local,dex", [([64, 40, 52, 30, 64], False, False), ([16], False, False), ([64, 40, 52, 30, 64], True, False),
+                                               ([48, 48, 20, 36], True, False),
+                                               ([64, 40, 52, 30, 64], False, True), ([20, 48, 36, 48, 8], True, True)])   # DEX style inputs ride `extras`
+def test_sharded_equals_unsharded(lengths, local, dex):
     T = D.padded_length(lengths)
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, lengths, T, q, local)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, lengths, T, q, local, dex)) for r in range(world)]
     for p in procs:
         p.start()
     got = dict(q.get(timeout=120) for _ in range(world))
@@ -61,6 +76,26 @@ def test_sharded_equals_unsharded(lengths, local):
         p.join(timeout=60)
         assert p.exitcode == 0
     mu, mask, z, _ = synth.make_inputs(len(lengths), T, lengths)
-    ref = fake_sampler(*map(torch.from_numpy, (z, mask, mu))).numpy()
+    if dex:
+        ref = fake_dex_sampler(*map(torch.from_numpy, (z, mask, mu)), **_dex_extras(len(lengths))).numpy()
+    else:
+        ref = fake_sampler(*map(torch.from_numpy, (z, mask, mu))).numpy()
     for r in range(world):
         np.testing.assert_array_equal(got[r], ref)
+
+
+@pytest.mark.parametrize("local", [False, True])
+def test_single_process_keeps_input_order(local):
+    """world == 1 (no process group): with ``local=True`` the caller hands the rows in SHARD order (length-sorted, what
+    ``take_shard`` returns) and the result must still come back in INPUT order (it came back sorted)."""
+    lengths = [20, 64, 36, 64, 8, 52]                     # deliberately not sorted
+    T = D.padded_length(lengths)
+    mu, mask, z, _ = synth.make_inputs(len(lengths), T, lengths)
+    mu, mask, z = map(torch.from_numpy, (mu, mask, z))
+    ref = fake_sampler(z, mask, mu).numpy()
+    if local:
+        order = D.partition(lengths, 1)[0]
+        assert order != sorted(order)
+        mu, mask, z = (D.take_shard(t, lengths) for t in (mu, mask, z))
+    got = D.sample_sharded(fake_sampler, mu, mask, z, lengths, local=local).numpy()
+    np.testing.assert_array_equal(got, ref)

@@ -4,7 +4,11 @@
 Tolerances (fp32 mode).  The reference's own fp32 round-off floor — fp64 vs fp32 evaluation of the same
 net — is up to 2.1e-4 for one denoiser call at sigma=80 and 4.7e-4 for the 4-step sampler
 (tests/test_oracle_golden.py), so:  single EDMPrecond call  max|d| <= 1e-3 * max(1,|y|max);
-sampler  max|d| <= 2e-3, mean|d| <= 2e-4 on mels whose range is about [-11.5, 4]."""
+sampler  max|d| <= 2e-3, mean|d| <= 2e-4 on mels whose range is about [-11.5, 4] WOULD sit just above that floor — but
+the library in fp32 mode tracks the fp32 oracle far more closely than the fp64/fp32 gap (it performs the same fp32
+operations in nearly the same order), so since round 3 the bounds are <= 10x what is MEASURED on MI355X
+(tests/tolerances.py: call 1e-4 * max(1,|y|max), sampler 5e-5 / 1e-5, taps 2e-4 * max(1,|tap|max)); every comparison
+records its measurement (profiles/round3_parity_measured.jsonl)."""
 import os
 
 import numpy as np
@@ -42,13 +46,11 @@ def test_golden_precond_and_sampler(name, preset):
     for s in (80.0, 1.0, 0.002):
         got = eng.denoise_once(mu + s * eps, s, mask, mu, **kw).cpu().numpy()
         ref = g[f"precond_sigma{s}"]
-        assert np.isfinite(got).all()
-        assert np.abs(got - ref).max() <= 1e-3 * max(1.0, np.abs(ref).max()), (s, np.abs(got - ref).max())
+        U.fp32_call_ok(f"golden_{name}_sigma{s}", got, ref)
     for key in [k for k in g if k.startswith("sampler_n")]:
         n = int(key[len("sampler_n"):])
         got = eng.sample(z, mask, mu, n, **kw).cpu().numpy()
-        err = np.abs(got - g[key])
-        assert err.max() <= 2e-3 and err.mean() <= 2e-4, (key, err.max(), err.mean())
+        U.fp32_sampler_ok(f"golden_{name}_{key}", got, g[key])
 
 
 @pytest.mark.parametrize("name,kw", [
@@ -65,10 +67,9 @@ def test_oracle_precond_taps(name, kw):
     case = U.make_case(cfg, **kw)
     for sigma in (80.0, 0.7, 0.002):
         got, ref, terr = U.run_precond(name, case, sigma)
-        assert np.isfinite(got).all()
-        assert np.abs(got - ref).max() <= 1e-3 * max(1.0, np.abs(ref).max()), (sigma, np.abs(got - ref).max())
-        for k, (err, mx) in terr.items():
-            assert err <= 2e-3 * max(1.0, mx), (k, err, mx)
+        tag = f"taps_{name}_B{kw['B']}_T{kw['T']}_sigma{sigma}"
+        U.fp32_call_ok(tag, got, ref)
+        U.fp32_taps_ok(tag, terr)
 
 
 @pytest.mark.parametrize("name,kw,n", [
@@ -81,8 +82,7 @@ def test_oracle_sampler(name, kw, n):
     cfg, eng, w = U.engine_for(name)
     case = U.make_case(cfg, **kw)
     got, ref = U.run_sampler(name, case, n)
-    err = np.abs(got - ref)
-    assert err.max() <= 2e-3 and err.mean() <= 2e-4, (err.max(), err.mean())
+    U.fp32_sampler_ok(f"parity1_" + os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0], got, ref)
 
 
 @pytest.mark.parametrize("key", ["gedex_lj_n4", "gedex_lj_n7", "dex_vctk_n4"])
@@ -93,8 +93,7 @@ def test_heun_golden(key):
     cfg, eng, w = U.engine_for(name)
     mu, mask, z = (torch.from_numpy(g[k]) for k in ("mu", "mask", "z"))
     got = eng.sample(z, mask, mu, int(n), solver="heun", **U.engine_kwargs(g)).cpu().numpy()
-    err = np.abs(got - h[key])
-    assert err.max() <= 2e-3 and err.mean() <= 2e-4, (key, err.max(), err.mean())
+    U.fp32_sampler_ok(f"parity2_" + os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0], got, h[key])
 
 
 @pytest.mark.parametrize("name,kw,n", [
@@ -106,12 +105,10 @@ def test_heun_oracle(name, kw, n):
     cfg, eng, w = U.engine_for(name)
     case = U.make_case(cfg, **kw)
     got, ref = U.run_sampler(name, case, n, solver="heun")
-    err = np.abs(got - ref)
-    assert err.max() <= 2e-3 and err.mean() <= 2e-4, (err.max(), err.mean())
+    U.fp32_sampler_ok(f"parity3_" + os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0], got, ref)
     # the same engine goes straight back to Euler (table sizes and modes are per call)
     got, ref = U.run_sampler(name, case, n)
-    err = np.abs(got - ref)
-    assert err.max() <= 2e-3 and err.mean() <= 2e-4, (err.max(), err.mean())
+    U.fp32_sampler_ok(f"parity4_" + os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0], got, ref)
 
 
 @pytest.mark.parametrize("tag", ["euler_n6", "heun_n4"])
@@ -123,8 +120,7 @@ def test_churn_golden(tag):
     cfg, eng, w = U.engine_for("gedex_lj")
     mu, mask, z = (torch.from_numpy(g[k]) for k in ("mu", "mask", "z"))
     got = eng.sample(z, mask, mu, n, solver=solver, noise=torch.from_numpy(noise), **sp).cpu().numpy()
-    err = np.abs(got - want)
-    assert err.max() <= 2e-3 and err.mean() <= 2e-4, (tag, err.max(), err.mean())
+    U.fp32_sampler_ok(f"parity5_" + os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0], got, want)
     rep = eng.sample(z, mask, mu, n, solver=solver, noise=torch.from_numpy(noise), use_graph=True, **sp).cpu().numpy()
     assert np.array_equal(got, rep)
     with pytest.raises(ValueError):
@@ -157,8 +153,7 @@ def test_churn_module_rng_stream():
     assert torch.cuda.default_generators[0].get_offset() == off
     ref = O.diffusion_infer(O.as_torch(w), cfg, torch.from_numpy(mask), torch.from_numpy(mu), 5, z.cpu(), noise=noise.cpu(),
                             S_churn=20.0, S_min=0.01, S_max=60.0, S_noise=1.0).numpy()
-    err = np.abs(out - ref)
-    assert err.max() <= 2e-3 and err.mean() <= 2e-4, (err.max(), err.mean())
+    U.fp32_sampler_ok(f"parity6_" + os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0], out, ref)
 
 
 def test_heun_bf16_mode_and_module_switch():
@@ -184,8 +179,7 @@ def test_heun_bf16_mode_and_module_switch():
     mu, mask, z = (torch.from_numpy(case[k]).cuda() for k in ("mu", "mask", "z"))
     m.solver = "heun"
     y = m.sampler(z, mask, mu, None, 6).cpu().numpy()
-    err = np.abs(y - ref)
-    assert err.max() <= 2e-3 and err.mean() <= 2e-4
+    U.fp32_sampler_ok(f"parity7_" + os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0], y, ref)
     with pytest.raises(ValueError):
         eng.sample(z, mask, mu, 4, solver="rk4")
 
@@ -244,8 +238,7 @@ def test_diffusion_module_forward_seeded():
     torch.manual_seed(100)
     z = torch.randn((2, 80, 64), device="cuda") / 1.5 + mu_t
     ref = O.diffusion_infer(O.as_torch(w), cfg, torch.from_numpy(mask), torch.from_numpy(mu), 4, z.cpu()).numpy()
-    err = np.abs(out.cpu().numpy() - ref)
-    assert err.max() <= 2e-3 and err.mean() <= 2e-4
+    U.fp32_sampler_ok(f"parity8_" + os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0], out.cpu().numpy(), ref)
     # generator state evolves like the reference's: one randn + n_timesteps randn_like draws
     for _ in range(4):
         torch.randn_like(z)
@@ -263,7 +256,7 @@ def test_generic_head_dim_attention_kernel_at_128():
         gen, _, _ = U.run_precond("gedex_lj", case, 0.7, with_taps=False)
     finally:
         del os.environ["DEX_ATTN_GENERIC"]
-    assert np.abs(gen - ref).max() <= 1e-3 * max(1.0, np.abs(ref).max())
+    U.fp32_call_ok("attn_generic_gedex_lj", gen, ref)
     assert np.abs(gen - got).max() <= 1e-4 and not np.array_equal(gen, got)       # another kernel really ran
 
 
@@ -329,8 +322,7 @@ def test_bf16_mode_full_size_shapes(name, kw):
         for sigma in (80.0, 0.5):
             eng.set_precision("fp32")
             got, ref, _ = U.run_precond(name, case, sigma, with_taps=False)
-            e = np.abs(got - ref)
-            assert np.isfinite(got).all() and e.max() <= 1e-3 * max(1.0, np.abs(ref).max()), (sigma, float(e.max()))
+            U.fp32_call_ok(f"full_{name}_B{kw['B']}_T{kw['T']}_{sigma}", got, ref)
             for prec in ("bf16", "fp16"):
                 eng.set_precision(prec)
                 got, ref, _ = U.run_precond(name, case, sigma, with_taps=False)

@@ -104,11 +104,11 @@ def test_style_matches_oracle(B, Tr, Ts, Tl, lens):
     W = {k: t(v) for k, v in weights().items()}
     with torch.no_grad():
         o = SO.style_forward(W, t(ref), rl, t(sty), sl, t(lf0), ll)
-    assert (idx.cpu().numpy() == o["vq_idx"].numpy()).mean() >= 0.995          # an exact tie may flip a code: none expected
+    flips = int((idx.cpu().numpy() != o["vq_idx"].numpy()).sum())             # fixed seeds: no exact tie between two codes
+    assert flips == 0, f"{flips} VQ code flips"
     _close(sty_enc.cpu().numpy(), o["sty_enc"].numpy(), "sty_enc")
     _close(np.stack([s.cpu().numpy() for s in skips]), np.stack([s.numpy() for s in o["ref_skips"]]), "ref_skips")
-    if (idx.cpu().numpy() == o["vq_idx"].numpy()).all():
-        _close(sty_dec.cpu().numpy(), o["sty_dec"].numpy(), "sty_dec")
+    _close(sty_dec.cpu().numpy(), o["sty_dec"].numpy(), "sty_dec")
 
 
 @pytest.mark.gpu

@@ -5,11 +5,16 @@ net — is 2.1e-4 for one denoiser call at sigma = 80 and 4.7e-4 for a 4-step sa
 Reduced-precision modes (bf16 / fp16 operands on the MFMA, fp32 accumulation, norms, softmax state and residual
 streams) have no reference counterpart; their bounds are <= 2x the worst value measured on MI355X against the fp32
 CPU oracle over every case of tests/test_gpu_parity.py and tests/test_gpu_baseline_shapes.py
-(profiles/round2_parity_measured.jsonl holds the measurements)."""
+(profiles/round3_parity_measured.jsonl holds the measurements; every GPU comparison appends to gpurun_out/parity_measured.jsonl)."""
 
-FP32_CALL_REL = 1e-3          # single EDMPrecond call: max|d| <= FP32_CALL_REL * max(1, |y|max)
-FP32_SAMPLER_MAX = 2e-3       # sampler: max|d|
-FP32_SAMPLER_MEAN = 2e-4      # sampler: mean|d|
+# round 3: the fp32 bounds are <= 10x the worst value MEASURED on MI355X (the library repeats the oracle's fp32 operations in
+# nearly the same order, so it sits 1-2 orders of magnitude inside the fp64-vs-fp32 floor quoted above): worst measured call
+# 1.5e-5 (1.1e-5 relative to |y|max; B=8 T=512 sigma=80), worst sampler 5.3e-6 / 6.1e-7 (100-step DEX), taps <= 3e-5.
+# (rounds 1-2 had 1e-3 / 2e-3 / 2e-4 here: a 100x regression of the parity mode would have passed.)
+FP32_CALL_REL = 1e-4          # single EDMPrecond call: max|d| <= FP32_CALL_REL * max(1, |y|max)
+FP32_SAMPLER_MAX = 5e-5       # sampler: max|d|
+FP32_SAMPLER_MEAN = 1e-5      # sampler: mean|d|
+FP32_TAP_REL = 2e-4           # stage taps (down0 / down1 / dit_in / dit_out / up0 ...): max|d| <= FP32_TAP_REL * max(1, |tap|max)
 
 # (max|d|, mean|d|) on mels of range about [-11.5, 4], RMS 2.7
 # worst measured (round 2, 71 GPU tests): bf16 call 2.9e-2 / 3.5e-3 (strip-streaming conv forced onto a 3-utterance ragged batch,
