@@ -129,6 +129,7 @@ def pmc_traffic(workload, row_name):
 
 
 _STATS = {}
+PROFILE_DTYPE = {"gedex_b1": "bf16", "gedex_b32": "bf16", "dex_b32": "bf16", "dex_esd_b32_n100": "bf16", "gedex_long": "f16"}
 
 
 def rocprof_avg_us(workload, row_name, attention=False):
@@ -178,7 +179,9 @@ def roof(r, dtype_key, workload=None, force_mfma=False):
         if t:
             ent["traffic"] = t.get("hbm_bytes_per_launch")
             ent["traffic_source"] = t.get("source")
-        us, src = rocprof_avg_us(workload, r["name"], attention=force_mfma and r["name"] == "dit_attention")
+        # (the committed profiles were taken in the mode each config names: bf16, long-form fp16 - other modes launch other kernels)
+        us, src = (rocprof_avg_us(workload, r["name"], attention=force_mfma and r["name"] == "dit_attention")
+                   if dtype_key == PROFILE_DTYPE.get(workload) else (None, None))
         if us:
             ent["rocprof_avg_launch_us"] = round(us, 2)
             ent["rocprof_source"] = src

@@ -78,6 +78,7 @@ struct DexCtx {
     const float *tv_wq_raw = nullptr, *tv_wk = nullptr, *tv_wv = nullptr, *tv_wl = nullptr;
     // mel front-end constants
     float *mel_basis = nullptr, *mel_filt = nullptr; void* mel_ws = nullptr; size_t mel_ws_bytes = 0;
+    const int* last_xerr = nullptr;     // time-out word of the last call's cluster row chain (inside that call's workspace)
     // taps of the last call
     struct Tap { std::string name; const float* p; std::vector<int64_t> shape; };
     std::vector<Tap> taps;
@@ -577,6 +578,7 @@ struct Plan {
     float *up_out, *hF;
     int Hm, Wm, Hf, Wt, N;
     float *pe0, *emb, *emb_pad, *pos_part, *tok, *xn, *qkv, *ao, *att_ml, *hmlp, *dbg_tok;
+    float* xslab; unsigned* xflag; size_t xflag_bytes;      // cluster form of the DiT row chain (small grids): exchange slabs + flag words
     void *qh, *kh, *vt, *qh2, *kh2, *vt2; int Npad; size_t vt_bytes;   // bf16 attention operands of the row-chain path (two sets:
                                                                         // a fused block reads one while its workgroups write the other)
     float *tv_keys, *tv_K, *tv_V, *tv_q, *tv_ao, *tv_out, *tiv_out, *tv_weff, *tv_beff; gnfix_t *tv_stats, *tiv_stats; void* tv_wbf;
@@ -660,6 +662,13 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
     P.qh = A.take(P.vt_bytes); P.kh = A.take(P.vt_bytes); P.vt = A.take(P.vt_bytes);    // all three padded to Npad rows
     P.qh2 = A.take(P.vt_bytes); P.kh2 = A.take(P.vt_bytes); P.vt2 = A.take(P.vt_bytes);
     P.hmlp = A.f(tok * mlp_hidden(c));
+    P.xslab = nullptr; P.xflag = nullptr; P.xflag_bytes = 0;
+    if (dit_rowchain_supported(hid, mlp_hidden(c)) && dit_rowchain_cluster_form(P.N, B)) {
+        const size_t tiles = (size_t)B * ((P.N + 31) / 32);
+        P.xslab = A.f(tiles * DIT_CLUSTER_SLAB_FLOATS);
+        P.xflag_bytes = tiles * DIT_CLUSTER_FLAG_WORDS * sizeof(unsigned) + sizeof(int);      // + the time-out word
+        P.xflag = (unsigned*)A.take(P.xflag_bytes);
+    }
     P.dbg_tok = A.f(tok * hid * (c.dit_depth + 1));
     P.tv_keys = P.tv_K = P.tv_V = P.tv_q = P.tv_ao = P.tv_out = P.tiv_out = P.tv_weff = P.tv_beff = nullptr; P.tv_wbf = nullptr;
     P.tv_stats = P.tiv_stats = nullptr;
@@ -953,6 +962,11 @@ struct Runner {
                 ch.Qin = (k & 1) ? P.qh2 : P.qh; ch.Kin = (k & 1) ? P.kh2 : P.kh; ch.Vin = (k & 1) ? P.vt2 : P.vt;
                 ch.Npad = P.Npad;
                 ch.qscale = scale * 1.4426950408889634f;      // log2(e) folded in: the attention kernels use exp2
+                if (P.xflag) {                                // cluster form: slabs, flags, an epoch unique within the call (never 0)
+                    ch.xslab = P.xslab; ch.xflag = P.xflag; ch.epoch = (unsigned)(sp * (c.dit_depth + 1) + k + 1);
+                    ch.xerr = reinterpret_cast<int*>(P.xflag + (P.xflag_bytes - sizeof(int)) / sizeof(unsigned));
+                    x->last_xerr = ch.xerr;
+                }
             }
             if (chain && k == 0) {                                   // first block: LN + modulate + qkv only
                 ch.qkv_only = 1; ch.Wq = x->frag_of().at(w.wqkv); ch.bq = w.bqkv;
@@ -1236,6 +1250,7 @@ struct Runner {
             run("cond_mlp", 2.0 * rows * K * N, 4.0 * K * N, [&] { launch_small_linear(s, st); });
         };
         if (P.tv_stats) hipMemsetAsync(P.tv_stats, 0, (size_t)B * mid_dim(c) * IN_SLOTS * 2 * 2 * sizeof(gnfix_t), st);
+        if (P.xflag) hipMemsetAsync(P.xflag, 0, P.xflag_bytes, st);     // hand-off flags of the cluster row chain: zero before every call (epochs count within it)
         hipMemsetAsync(P.vt, 0, P.vt_bytes, st);      // key padding of the transposed V operand (attention_direct.hip)
         hipMemsetAsync(P.vt2, 0, P.vt_bytes, st);
         CondPrepP cp{sigmas_dev, n, c.pe_scale, dim, P.scal, SCAL_STRIDE, P.t_unet, P.t_dit};
@@ -1447,7 +1462,7 @@ int dex_sample(DexCtx* x, const DexSampleArgs* a, dex_stream_t stream) {
                                  (uint64_t)(uintptr_t)(a->S_churn > 0.f ? a->noise_dev : nullptr)};
     for (float v : {a->S_churn, a->S_min, a->S_max, a->S_noise}) { uint32_t u; memcpy(&u, &v, 4); key.push_back(u); }
     for (int j = 0; j < a->n_ref; ++j) key.push_back((uint64_t)(uintptr_t)a->ref_skips_dev[j]);
-    for (const char* e : {"DEX_CONV_STREAM", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN"}) {     // knobs read at enqueue time
+    for (const char* e : {"DEX_CONV_STREAM", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN", "DEX_DIT_CLUSTER"}) {     // knobs read at enqueue time
         const char* v = getenv(e);
         key.push_back(v ? (uint64_t)atoi(v) + 1 : 0);
     }
@@ -1529,6 +1544,14 @@ int dex_profile_get(const DexCtx* x, int i, const char** name, int* calls, doubl
 
 // ---- STFT / mel front-end -------------------------------------------------------------------------
 int dex_mel_frames(int n_samples) { return n_samples / 256 + 1; }
+
+int dex_debug_handoff_timeouts(DexCtx* x, dex_stream_t stream) {
+    if (!x) return DEX_ERR_ARG;
+    if (!x->last_xerr) return 0;
+    int v = 0;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipMemcpy(&v, x->last_xerr, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return v;
+}
 
 // standalone mel context: the DFT basis and the Slaney filterbank, nothing else (a preprocess job needs no score network)
 struct DexMel { float* basis = nullptr; float* filt = nullptr; std::string err; };

@@ -706,9 +706,413 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain64_kernel(const DitCha
     for (int m = 0; m < 2; ++m) { if (n0 + 32 * m >= p.Npad) break; acc = zero16(); mma16(acc, wb, a_lane + m * 32 * A_LD); store_qkv_tile(p, acc, wave + 16, bq2, b, n0 + 32 * m, lane, scr); }
 }
 
+// ---- cluster form (small grids: B x ceil(N / 32) row tiles <= 64).  At B = 1 the kernels above run 21 workgroups, each streaming
+// the K / V^T of both heads and every weight matrix of the block (1.7 MB) through ONE CU's L2 -> register path: 22 us of which no
+// phase is bound by anything but that path.  Here a 32-row tile belongs to a CLUSTER of DIT_CLUSTER = 4 workgroups
+// (member c = blockIdx & 3) and every stage is cut so that a member streams a quarter of its bytes:
+//     attention   head c >> 1, key half c & 1 (8 waves split its key tiles; merged in LDS, normalised by the member's own row sum)
+//     proj        K-split by head: P_c = O_c Wp[128 (c >> 1) .. +128, :]                      -> fp32 partial [32, 256]
+//       exchange 0  every member publishes P_c + its softmax (max, sum); all read the other three:
+//                   x1 = x + gate_msa (sum_c w_c P_c + b),  w_c = the flash merge weight of (head, half) c          (redundantly: 4x)
+//     LN + modulate (redundantly)
+//     fc1 + GELU  hidden columns 128 c .. +128 (4 column tiles x 2 K halves over the 8 waves, halves summed through LDS)
+//     fc2         K-split: its OWN 128 hidden columns, all 256 outputs: P2_c                 -> fp32 partial [32, 256]
+//       exchange 1  x2 = x1 + gate_mlp (sum_c P2_c + b2); member c writes columns 64 c .. +64 of X
+//     LN + modulate (redundantly), next block's qkv: column tiles 6 c .. 6 c + 5 of the 24 (waves 0-5)
+// Two hand-offs per block instead of none, but 0.45 MB instead of 1.7 MB through each CU.  A hand-off follows the guide's R1 form:
+// 16-byte write-through (sc1) payload stores, every storing wave drains (vmcnt(0)), workgroup barrier, ONE lane stores the flag
+// (= the launch's epoch, unique within the call; the flag words are zeroed by a memset node at the start of every call); consumers
+// poll with relaxed agent-scope loads from one lane per peer, then read the peers' slabs with sc1 loads.  Results do not depend on
+// placement or timing: every sum runs in a fixed member order.  A wait is bounded (~50 ms): on time-out the launch finishes with
+// garbage and sets *xerr instead of hanging the GPU.
+namespace {
+constexpr int CL_AH_LD = 128 + 8;     // attention-output / GELU tile row stride (bf16): 272 B
+constexpr int CL_RED_LD = 33;
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void wload8(uint4 (&w)[8], const void* W, int ksteps_total, int nt, int ks0, int lane) {
+    const uint4* src = reinterpret_cast<const uint4*>(W) + ((long)nt * ksteps_total + ks0) * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = src[j * 64];
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void mma8(f32x16& acc, const uint4 (&w)[8], const u16* a_lane) {
+    u32x4 a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = *reinterpret_cast<const u32x4*>(a_lane + j * 16);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = DEX_MFMA_LP(__builtin_bit_cast(lp8, a[j]), __builtin_bit_cast(lp8, w[j]), acc, 0, 0, 0);
+}
+// one lane per peer polls that peer's flag until it shows this launch's epoch (relaxed agent-scope loads + s_sleep)
+__device__ __forceinline__ void cluster_wait(const unsigned* flags, int member, unsigned epoch, int tid, int* xerr) {
+    if (tid < DIT_CLUSTER && tid != member) {
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > 5000000LL) { if (xerr) *xerr = 1; break; }       // 50 ms at 100 MHz: never in a healthy launch
+        }
+    }
+    __syncthreads();
+}
+}  // namespace
+
+__global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const DitChainP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_rc[];
+    // chain buffers (they overlay the attention scratch, which is dead once the partials are merged)
+    float* X1 = reinterpret_cast<float*>(smem_rc);                       // [32][X_LD] fp32: partial staging, then the residual stream
+    float* P2 = X1 + RC_ROWS * X_LD;                                     // [32][X_LD] fp32: second partial staging
+    float* PRM = P2 + RC_ROWS * X_LD;                                    // [8][256]: shift_mlp, scale_mlp, next shift, next scale, gate_msa, b_proj, gate_mlp, b_fc2
+    float* RED = PRM + 8 * RC_H;                                         // [4][32][CL_RED_LD] fc1 K-half partials
+    u16* As = reinterpret_cast<u16*>(RED + 4 * RC_ROWS * CL_RED_LD);     // [32][A_LD] bf16 A operand (LN outputs)
+    u16* Ah = As + RC_ROWS * A_LD;                                       // [32][CL_AH_LD] attention output of this member's head, then its GELU(fc1) slice
+    u16* QS = Ah + RC_ROWS * CL_AH_LD;                                   // [8][32][QK_LD] wave-private qkv store scratch
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int N = p.rows_per_batch, tpb = (N + RC_ROWS - 1) / RC_ROWS;
+    const int cluster = blockIdx.x / DIT_CLUSTER, member = blockIdx.x % DIT_CLUSTER;
+    const int b = cluster / tpb, n0 = (cluster - b * tpb) * RC_ROWS;
+    const long mb = (long)b * N;
+    const int step = p.step;
+    const float* ada = p.ada + (long)step * 6 * RC_H;
+    const bool has_q = p.next_shift != nullptr;
+    float* slab = p.xslab + (long)cluster * DIT_CLUSTER_SLAB_FLOATS;     // [e][member][32*256 + 256]
+    unsigned* flags = p.xflag + (long)cluster * DIT_CLUSTER_FLAG_WORDS;   // [e][member]
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(slab, 0, (unsigned)(DIT_CLUSTER_SLAB_FLOATS * 4), 0x00020000);
+    constexpr unsigned SLAB_B = (32 * 256 + 256) * 4;
+    const int row = tid >> 4, seg = tid & 15;                            // the row-wise phases: 16 threads per row, 4 float4 each
+    const int nrow = min(n0 + row, N - 1);
+
+    float4 prm;                                                          // the parameter table entry this thread fetches
+    {
+        const int which = tid >> 6, c4 = (tid & 63) * 4;
+        const float* src = which == 0 ? ada + 3 * RC_H : which == 1 ? ada + 4 * RC_H
+                         : which == 2 ? (has_q ? p.next_shift + (long)step * p.next_step_stride : ada)
+                         : which == 3 ? (has_q ? p.next_scale + (long)step * p.next_step_stride : ada)
+                         : which == 4 ? ada + 2 * RC_H : which == 5 ? (p.qkv_only ? ada : p.bp) : which == 6 ? ada + 5 * RC_H : (p.qkv_only ? ada : p.b2);
+        prm = *reinterpret_cast<const float4*>(src + c4);
+    }
+    float4 xr[4];                                                        // residual rows x of this thread's 16 columns
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xr[q] = *reinterpret_cast<const float4*>(p.X + (mb + nrow) * RC_H + q * 64 + seg * 4);
+
+    uint4 w8[8];
+    f32x16 acc;
+    if (!p.qkv_only) {
+        const int head = member >> 1, half = member & 1;
+        // ---- attention of (head, key half): the 8 waves split the half's key tiles (attention_direct.hip's wave body)
+        f32x16 ao[4];
+        float am = -INFINITY, al = 0.f;
+        {
+            union DFr { uint4 u; lp8 v; };
+            const long hbq = ((long)b * 2 + head) * p.Npad * 16;
+            const uint4* Qg = reinterpret_cast<const uint4*>(p.Qin) + hbq + lane;
+            const uint4* Kg = reinterpret_cast<const uint4*>(p.Kin) + hbq + lane;
+            const uint4* Vg = reinterpret_cast<const uint4*>(p.Vin) + hbq + lane;
+            const int ntiles = (N + 31) / 32;
+            const int t_lo = half ? (ntiles + 1) / 2 : 0, t_hi = half ? ntiles : (ntiles + 1) / 2;
+            DFr qf[8], kf[8], vf[4][2];
+            int kt = t_lo + wave;
+            {
+                const uint4* qp = Qg + (long)(n0 >> 5) * 512;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) qf[ks].u = qp[ks * 64];
+                const long t0 = min(kt, ntiles - 1);
+                const uint4* kp = Kg + t0 * 512;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) kf[ks].u = kp[ks * 64];
+                const uint4* vp = Vg + t0 * 512;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int k2 = 0; k2 < 2; ++k2) vf[t][k2].u = vp[(t * 2 + k2) * 64];
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ao[t][r] = 0.f;
+            while (kt < t_hi) {
+                const int k0 = kt * 32, kn = kt + RC_NW;
+                f32x16 sc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[r] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) sc = DEX_MFMA_LP(kf[ks].v, qf[ks].v, sc, 0, 0, 0);
+                if (kn < t_hi) {
+                    const uint4* kp = Kg + (long)kn * 512;
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks) kf[ks].u = kp[ks * 64];
+                }
+                if (k0 + 32 > N) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) if (k0 + (r & 3) + 8 * (r >> 2) + 4 * hh >= N) sc[r] = -INFINITY;
+                }
+                float mx = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                if (__builtin_amdgcn_ballot_w64(mx > am + 8.f) != 0) {       // lazy rescale (attention_direct.hip)
+                    const float m_new = fmaxf(am, mx);
+                    const float alpha = exp2f(am - m_new);
+                    al *= alpha;
+                    am = m_new;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ao[t][r] *= alpha;
+                }
+                float psum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sc[r] = __builtin_amdgcn_exp2f(sc[r] - am); psum += sc[r]; }
+                al += psum;
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    DFr pb;
+                    pb.u.x = pack2_lp(sc[8 * k2 + 0], sc[8 * k2 + 1]); pb.u.y = pack2_lp(sc[8 * k2 + 2], sc[8 * k2 + 3]);
+                    pb.u.z = pack2_lp(sc[8 * k2 + 4], sc[8 * k2 + 5]); pb.u.w = pack2_lp(sc[8 * k2 + 6], sc[8 * k2 + 7]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) ao[t] = DEX_MFMA_LP(vf[t][k2].v, pb.v, ao[t], 0, 0, 0);
+                }
+                if (kn < t_hi) {
+                    const uint4* vp = Vg + (long)kn * 512;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int k2 = 0; k2 < 2; ++k2) vf[t][k2].u = vp[(t * 2 + k2) * 64];
+                }
+                kt = kn;
+            }
+            al += __shfl_xor(al, 32);
+        }
+        wload8(w8, p.Wp, 16, wave, 8 * head, lane);               // proj weights: output tile `wave`, the head's K half
+        // partial (m, l, O[query][d]) of this wave -> LDS scratch
+        float* scr = reinterpret_cast<float*>(smem_rc);
+        {
+            float* oS = scr + wave * (32 * AT_LD);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq)
+                    *reinterpret_cast<float4*>(oS + i * AT_LD + t * 32 + 8 * rq + 4 * hh) =
+                        make_float4(ao[t][rq * 4 + 0], ao[t][rq * 4 + 1], ao[t][rq * 4 + 2], ao[t][rq * 4 + 3]);
+            if (hh == 0) { scr[RC_NW * 32 * AT_LD + (wave * 2 + 0) * 32 + i] = am; scr[RC_NW * 32 * AT_LD + (wave * 2 + 1) * 32 + i] = al; }
+        }
+        lds_barrier();
+        // merge the 8 wave partials of this member: O_c = sum_w f_w O_w / L_c (normalised by the member's own sum), (M_c, L_c) kept
+        float myM, myL;
+        float4 ov[2];
+        {
+            const float* stat = scr + RC_NW * 32 * AT_LD;
+            float mw[RC_NW], M = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < RC_NW; ++w) { mw[w] = stat[(w * 2) * 32 + row]; M = fmaxf(M, mw[w]); }
+            float L = 0.f, f[RC_NW];
+#pragma unroll
+            for (int w = 0; w < RC_NW; ++w) { f[w] = (mw[w] == -INFINITY) ? 0.f : exp2f(mw[w] - M); L += f[w] * stat[(w * 2 + 1) * 32 + row]; }
+            const float inv = L > 0.f ? 1.f / L : 0.f;
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int w = 0; w < RC_NW; ++w) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(scr + (w * 32 + row) * AT_LD + qq * 64 + seg * 4);
+                    a.x = fmaf(f[w], t4.x, a.x); a.y = fmaf(f[w], t4.y, a.y); a.z = fmaf(f[w], t4.z, a.z); a.w = fmaf(f[w], t4.w, a.w);
+                }
+                ov[qq] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
+            }
+            myM = M; myL = L;
+        }
+        lds_barrier();                                   // scratch fully read: the chain's buffers may now be written
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            uint2 o;
+            o.x = pack2_lp(ov[qq].x, ov[qq].y); o.y = pack2_lp(ov[qq].z, ov[qq].w);
+            *reinterpret_cast<uint2*>(Ah + row * CL_AH_LD + qq * 64 + seg * 4) = o;
+        }
+        *reinterpret_cast<float4*>(PRM + (tid >> 6) * RC_H + (tid & 63) * 4) = prm;
+        lds_barrier();
+        // ---- proj partial: P_c = O_c Wp[head rows, :]  (raw: bias, gate and residual are applied after the exchange)
+        acc = zero16();
+        mma8(acc, w8, Ah + i * CL_AH_LD + hh * 8);
+        wload8(w8, p.W1, 16, 4 * member + (wave & 3), 8 * (wave >> 2), lane);      // fc1: column tile wave & 3 of this member's four, K half wave >> 2
+        const int col = wave * 32 + i;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) X1[((r & 3) + 8 * (r >> 2) + 4 * hh) * X_LD + col] = acc[r];
+        lds_barrier();
+        // ---- exchange 0: publish P_c and (M_c, L_c)
+        {
+            const unsigned base = (0 * DIT_CLUSTER + member) * SLAB_B;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(X1 + row * X_LD + q * 64 + seg * 4);
+                const u32x4v u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+                __builtin_amdgcn_raw_buffer_store_b128(u, srs, base + (unsigned)(q * 512 + tid) * 16u, 0, 16);      // aux 16 = sc1: write-through
+            }
+            if (seg == 0) {
+                const unsigned long long ml = (unsigned long long)__float_as_uint(myM) | ((unsigned long long)__float_as_uint(myL) << 32);
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(slab + (0 * DIT_CLUSTER + member) * (SLAB_B / 4) + 32 * 256) + row, ml,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every storing wave drains its write-through stores
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flags + 0 * DIT_CLUSTER + member, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        cluster_wait(flags + 0 * DIT_CLUSTER, member, p.epoch, tid, p.xerr);
+        {
+            // every peer's partial of this thread's 16 columns + its row statistics: all loads first
+            u32x4v pv[DIT_CLUSTER][4];
+            float pm[DIT_CLUSTER], pl[DIT_CLUSTER];
+#pragma unroll
+            for (int c = 0; c < DIT_CLUSTER; ++c) {
+                if (c == member) continue;
+                const unsigned base = (0 * DIT_CLUSTER + c) * SLAB_B;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pv[c][q] = __builtin_amdgcn_raw_buffer_load_b128(srs, base + (unsigned)(q * 512 + tid) * 16u, 0, 16);
+                const unsigned long long ml = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(slab + (0 * DIT_CLUSTER + c) * (SLAB_B / 4) + 32 * 256) + row,
+                                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pm[c] = __uint_as_float((unsigned)ml); pl[c] = __uint_as_float((unsigned)(ml >> 32));
+            }
+            pm[member] = myM; pl[member] = myL;
+            // flash merge weights of the two key halves of each head (fixed member order: results do not depend on arrival)
+            float wgt[DIT_CLUSTER];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float M = fmaxf(pm[2 * h], pm[2 * h + 1]);
+                const float fa = pl[2 * h] > 0.f ? pl[2 * h] * exp2f(pm[2 * h] - M) : 0.f, fb = pl[2 * h + 1] > 0.f ? pl[2 * h + 1] * exp2f(pm[2 * h + 1] - M) : 0.f;
+                const float inv = 1.f / (fa + fb);
+                wgt[2 * h] = fa * inv; wgt[2 * h + 1] = fb * inv;
+            }
+            float4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 own = *reinterpret_cast<const float4*>(X1 + row * X_LD + q * 64 + seg * 4);
+                float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int c = 0; c < DIT_CLUSTER; ++c) {
+                    const float4 pc = c == member ? own : make_float4(__uint_as_float(pv[c][q].x), __uint_as_float(pv[c][q].y), __uint_as_float(pv[c][q].z), __uint_as_float(pv[c][q].w));
+                    sacc.x = fmaf(wgt[c], pc.x, sacc.x); sacc.y = fmaf(wgt[c], pc.y, sacc.y); sacc.z = fmaf(wgt[c], pc.z, sacc.z); sacc.w = fmaf(wgt[c], pc.w, sacc.w);
+                }
+                const float4 g = *reinterpret_cast<const float4*>(PRM + 4 * RC_H + q * 64 + seg * 4);
+                const float4 bb = *reinterpret_cast<const float4*>(PRM + 5 * RC_H + q * 64 + seg * 4);
+                v[q] = make_float4(xr[q].x + g.x * (sacc.x + bb.x), xr[q].y + g.y * (sacc.y + bb.y), xr[q].z + g.z * (sacc.z + bb.z), xr[q].w + g.w * (sacc.w + bb.w));
+                *reinterpret_cast<float4*>(X1 + row * X_LD + q * 64 + seg * 4) = v[q];      // x1 (in place: this thread owns these elements)
+            }
+        }
+        lds_barrier();
+        ln_to_A(X1, As, PRM, PRM + RC_H, tid);
+        lds_barrier();
+        // ---- fc1 + GELU for hidden columns 128 member .. +128: (column tile ct, K half kh) per wave
+        {
+            const int ct = wave & 3, kh = wave >> 2;
+            acc = zero16();
+            mma8(acc, w8, As + i * A_LD + hh * 8 + kh * 128);
+            wload8(w8, p.W2, 32, wave, 8 * member, lane);                 // fc2: output tile `wave`, K = this member's hidden slice
+            if (kh == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) RED[(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * CL_RED_LD + i] = acc[r];
+            }
+            lds_barrier();
+            if (kh == 0) {
+                const float b1v = p.b1[128 * member + ct * 32 + i];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    Ah[rr * CL_AH_LD + ct * 32 + i] = (u16)(pack2_lp(gelu_erf_rc(acc[r] + RED[(ct * 32 + rr) * CL_RED_LD + i] + b1v), 0.f) & 0xffffu);
+                }
+            }
+            lds_barrier();
+        }
+        // ---- fc2 partial over this member's hidden slice
+        acc = zero16();
+        mma8(acc, w8, Ah + i * CL_AH_LD + hh * 8);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) P2[((r & 3) + 8 * (r >> 2) + 4 * hh) * X_LD + col] = acc[r];
+        lds_barrier();
+        {
+            const unsigned base = (1 * DIT_CLUSTER + member) * SLAB_B;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(P2 + row * X_LD + q * 64 + seg * 4);
+                const u32x4v u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+                __builtin_amdgcn_raw_buffer_store_b128(u, srs, base + (unsigned)(q * 512 + tid) * 16u, 0, 16);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(flags + 1 * DIT_CLUSTER + member, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        cluster_wait(flags + 1 * DIT_CLUSTER, member, p.epoch, tid, p.xerr);
+        {
+            u32x4v pv[DIT_CLUSTER][4];
+#pragma unroll
+            for (int c = 0; c < DIT_CLUSTER; ++c) {
+                if (c == member) continue;
+                const unsigned base = (1 * DIT_CLUSTER + c) * SLAB_B;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) pv[c][q] = __builtin_amdgcn_raw_buffer_load_b128(srs, base + (unsigned)(q * 512 + tid) * 16u, 0, 16);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 own = *reinterpret_cast<const float4*>(P2 + row * X_LD + q * 64 + seg * 4);
+                float4 sacc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int c = 0; c < DIT_CLUSTER; ++c) {
+                    const float4 pc = c == member ? own : make_float4(__uint_as_float(pv[c][q].x), __uint_as_float(pv[c][q].y), __uint_as_float(pv[c][q].z), __uint_as_float(pv[c][q].w));
+                    sacc.x += pc.x; sacc.y += pc.y; sacc.z += pc.z; sacc.w += pc.w;
+                }
+                const float4 g = *reinterpret_cast<const float4*>(PRM + 6 * RC_H + q * 64 + seg * 4);
+                const float4 bb = *reinterpret_cast<const float4*>(PRM + 7 * RC_H + q * 64 + seg * 4);
+                const float4 x1 = *reinterpret_cast<const float4*>(X1 + row * X_LD + q * 64 + seg * 4);
+                const float4 x2 = make_float4(x1.x + g.x * (sacc.x + bb.x), x1.y + g.y * (sacc.y + bb.y), x1.z + g.z * (sacc.z + bb.z), x1.w + g.w * (sacc.w + bb.w));
+                *reinterpret_cast<float4*>(X1 + row * X_LD + q * 64 + seg * 4) = x2;
+                if (q == member && n0 + row < N) *reinterpret_cast<float4*>(p.X + (mb + n0 + row) * RC_H + q * 64 + seg * 4) = x2;    // member c owns columns 64 c .. +64 of X
+            }
+        }
+        if (!has_q) return;
+    } else {
+        // first block: LN + modulate + qkv of the incoming token rows only
+        *reinterpret_cast<float4*>(PRM + (tid >> 6) * RC_H + (tid & 63) * 4) = prm;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(X1 + row * X_LD + q * 64 + seg * 4) = xr[q];
+    }
+    // ---- next block's qkv: column tiles 6 member .. 6 member + 5 on waves 0-5 (full K)
+    uint4 wq[16];
+    const int nt = 6 * member + wave;
+    if (wave < 6) wload(wq, p.Wq, 16, nt, 0, lane);
+    lds_barrier();
+    ln_to_A(X1, As, PRM + 2 * RC_H, PRM + 3 * RC_H, tid);
+    lds_barrier();
+    if (wave < 6) {
+        const float bq = p.bq[nt * 32 + i];
+        acc = zero16();
+        mma16(acc, wq, As + i * A_LD + hh * 8);
+        store_qkv_tile(p, acc, nt, bq, b, n0, lane, QS + wave * (RC_ROWS * QK_LD));
+    }
+}
+constexpr size_t RC_LDS_CLUSTER_CHAIN = (size_t)(2 * RC_ROWS * X_LD + 8 * RC_H + 4 * RC_ROWS * CL_RED_LD) * sizeof(float)
+                                        + (size_t)(RC_ROWS * A_LD + RC_ROWS * CL_AH_LD + RC_NW * RC_ROWS * QK_LD) * sizeof(u16);
+constexpr size_t RC_LDS_CLUSTER = RC_LDS_CLUSTER_CHAIN > RC_LDS_ATTN ? RC_LDS_CLUSTER_CHAIN : RC_LDS_ATTN;
+
+// the cluster form needs every workgroup of the launch resident at once (<= one per CU, 256 CUs): B x tiles x 4 <= 256
+bool dit_rowchain_cluster_form(int rows_per_batch, int B) {
+    const char* e = getenv("DEX_DIT_CLUSTER");          // read per call (A/B tests flip it; part of the graph cache key)
+    const int on = e ? atoi(e) : 1;
+    return on && (long)B * ((rows_per_batch + RC_ROWS - 1) / RC_ROWS) * DIT_CLUSTER <= 256;
+}
+
 bool dit_rowchain_supported(int hidden, int mlp_hidden) { return hidden == RC_H && mlp_hidden == RC_MLP; }
 
 void launch_dit_rowchain(const DitChainP& p, hipStream_t st) {
+    if (p.xslab && (p.attn_inline || p.qkv_only) && dit_rowchain_cluster_form(p.rows_per_batch, p.B)) {
+        static bool attrc = false;
+        if (!attrc) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&dit_rowchain_cluster_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC_LDS_CLUSTER);
+            attrc = true;
+        }
+        if (!p.qkv_only) g_last_symbol = "dit_rowchain_cluster_kernel";
+        hipLaunchKernelGGL(dit_rowchain_cluster_kernel, dim3(p.B * ((p.rows_per_batch + RC_ROWS - 1) / RC_ROWS) * DIT_CLUSTER), dim3(RC_NW * 64),
+                           RC_LDS_CLUSTER, st, p);
+        return;
+    }
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&dit_rowchain_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC_LDS);

@@ -251,7 +251,16 @@ struct DitChainP { const float* O; int ksplit; long o_sstride; const float* ml; 
                                                                         // buffer set than the one written (workgroups of one launch overlap)
                    int qkv_only;                                        // 1: only LN+modulate+qkv of X (first block)
                    int attn_inline;                                     // 1: the attention core runs inside this launch (O / ml unused)
-                   int step; int M; int B; long long* dbg; };   // M = B * rows_per_batch
+                   int step; int M; int B; long long* dbg;     // M = B * rows_per_batch
+                   // cluster form (small grids, dit_rowchain_cluster_kernel): exchange slabs, flags (zeroed once per call) and the
+                   // launch's epoch (unique within the call, never 0); err: device word set when a hand-off wait timed out
+                   float* xslab; unsigned* xflag; unsigned epoch; int* xerr; };
+// cluster form of the row chain: workgroups per 32-row tile, bytes of exchange slab / flag words per tile, and whether a launch
+// of B x N rows takes it (all workgroups co-resident: <= one per CU)
+constexpr int DIT_CLUSTER = 4;
+constexpr size_t DIT_CLUSTER_SLAB_FLOATS = 2 * DIT_CLUSTER * (32 * 256 + 256);
+constexpr size_t DIT_CLUSTER_FLAG_WORDS = 2 * DIT_CLUSTER;
+bool dit_rowchain_cluster_form(int rows_per_batch, int B);
 bool dit_rowchain_supported(int hidden, int mlp_hidden);
 // Softmax attention on the row chain's bf16 operands (2 heads x 128): no staging, K / V^T / Q fragments are read
 // straight from global memory.  O: fp32 [ksplit][B][N][256] partials + ml (merged by the next row chain launch).

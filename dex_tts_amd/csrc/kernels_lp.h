@@ -35,6 +35,7 @@ bool attention_direct_batch_regime(int N, int B);
 int attention_direct_ksplit(int N, int B);
 // DiT row chain (dit_rowchain.hip) and its weight packing
 bool dit_rowchain_supported(int hidden, int mlp_hidden);
+bool dit_rowchain_cluster_form(int rows_per_batch, int B);
 void launch_dit_rowchain(const DitChainP& p, hipStream_t st);
 void launch_pack_lp_frag(const float* src, void* dst, int K, int N, hipStream_t st);
 void launch_pack_lp_frag_nk(const float* src, void* dst, int K, int N, hipStream_t st);   // source [N][K]

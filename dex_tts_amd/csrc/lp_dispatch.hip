@@ -26,6 +26,7 @@ int attention_direct_ksplit(int N, int B) { return bf16::attention_direct_ksplit
 bool conv_down_supported(int C, int H, int W, int ldx, int ldy, int x_coff) { return bf16::conv_down_supported(C, H, W, ldx, ldy, x_coff); }
 bool convt_up_supported(int C, int H, int W, int ldx, int ldy) { return bf16::convt_up_supported(C, H, W, ldx, ldy); }
 bool dit_rowchain_supported(int hidden, int mlp_hidden) { return bf16::dit_rowchain_supported(hidden, mlp_hidden); }
+bool dit_rowchain_cluster_form(int rows_per_batch, int B) { return bf16::dit_rowchain_cluster_form(rows_per_batch, B); }
 
 #define DEX_LP_CALL(fn, ...) do { if (precision == PREC_FP16) f16::fn(__VA_ARGS__); else bf16::fn(__VA_ARGS__); } while (0)
 

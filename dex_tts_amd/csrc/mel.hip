@@ -93,7 +93,9 @@ __global__ __launch_bounds__(64) void lf0_normalize_kernel(const float* __restri
     const int b = blockIdx.x, lane = threadIdx.x;
     const int len = lengths ? min(max(lengths[b], 0), T) : T;
     f0 += (long)b * T; out += (long)b * T;
-    auto lf = [&](int i) { const float v = f0[i]; return v != 0.f ? logf(v) : 0.f; };
+    // log through fp64, rounded once: the correctly rounded fp32 logarithm (what numpy / torch return for these inputs; the fp32
+    // library logf is one ulp off for some, and on a constant track one ulp moves the normalised value by 1 %)
+    auto lf = [&](int i) { const float v = f0[i]; return v != 0.f ? (float)log((double)v) : 0.f; };
     int c = 0;
     for (int base = 0; base < len; base += 64) {
         const int i = base + lane;

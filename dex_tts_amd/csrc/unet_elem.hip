@@ -554,15 +554,19 @@ __global__ __launch_bounds__(256) void final_kernel(const FinalP p) {
             if (sub == 0 && pr < p.npix) {
                 const float f = (acc * mk[u] + bfc) * mk[u];
                 const long o = (long)b * p.npix + pr;            // [B,80,T] has the same (h*T + w) linear order
-                const float D = c_skip * xc[u] + c_out * f;
+                // The sampler's scalar arithmetic repeats the reference's fp32 operations ONE ROUNDING AT A TIME (edm.py:96-97,
+                // 199-214: every product and sum is its own torch op; no fused multiply-add).  It matters: the Heun corrector
+                // evaluates the network at sigma' = 0.002 with a step h of the previous noise level, so one ulp of D' enters
+                // x_next multiplied by h / (2 sigma') ~ 1e2 (measured before: 3e-4 against the oracle at n = 4, now ~1e-5).
+                const float D = __fadd_rn(__fmul_rn(c_skip, xc[u]), __fmul_rn(c_out, f));
                 if (p.denoised) p.denoised[o] = D;
                 if (p.xnext) {
-                    const float d = inv * xc[u] - inv * D;
+                    const float d = __fsub_rn(__fmul_rn(inv, xc[u]), __fmul_rn(inv, D));
                     if (p.mode == 2) {
-                        p.xnext[o] = xa[u] + h * (0.5f * xd[u] + 0.5f * d);
+                        p.xnext[o] = __fadd_rn(xa[u], __fmul_rn(h, __fadd_rn(__fmul_rn(0.5f, xd[u]), __fmul_rn(0.5f, d))));
                     } else {
                         if (p.mode == 1) p.dbuf[o] = d;
-                        p.xnext[o] = xc[u] + h * d;
+                        p.xnext[o] = __fadd_rn(xc[u], __fmul_rn(h, d));
                     }
                 }
             }
@@ -640,7 +644,7 @@ __global__ void cond_prep_kernel(const CondPrepP p) {
         const float s2 = sigma * sigma + sd * sd;
         sc[0] = sigma; sc[1] = sigma_next;
         sc[2] = 1.f / sqrtf(s2);                 // c_in
-        sc[3] = (sd * sd) / s2;                  // c_skip
+        sc[3] = __fmul_rn(__frcp_rn(s2), sd * sd);   // c_skip = sigma_data^2 / (..): python float / tensor = tensor.reciprocal() * float in torch (two roundings)
         sc[4] = sigma * sd / sqrtf(s2);          // c_out
         sc[5] = c_noise;
     }

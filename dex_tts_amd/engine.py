@@ -288,6 +288,11 @@ class ScoreNetEngine:
         return rows
 
     # mel front-end ----------------------------------------------------------------------------
+    def handoff_timeouts(self) -> int:
+        """Debug: did a workgroup hand-off of the last sample / denoise_once call time out (cluster form of the DiT row chain)?"""
+        with torch.cuda.device(self.device):
+            return int(self.lib.dex_debug_handoff_timeouts(self.h, self._stream()))
+
     def mel_from_wav(self, wav: torch.Tensor):
         with torch.cuda.device(self.device):
             wav = wav.to(device=self.device, dtype=torch.float32).contiguous().reshape(-1)

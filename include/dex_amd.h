@@ -142,6 +142,11 @@ int  dex_profile_num(const DexCtx* ctx);
 int  dex_profile_get(const DexCtx* ctx, int i, const char** name, int* calls, double* total_ms,
                      double* flops, double* bytes);
 
+/* Debug: 1 if a workgroup hand-off of the LAST dex_sample / dex_denoise_once call on this context timed out (small-grid DiT
+ * blocks run as clusters of co-operating workgroups; a wait is bounded so a lost hand-off cannot hang the GPU), 0 if none did or
+ * the call used no hand-offs, < 0 on a HIP error.  Synchronises the stream; the call's workspace must still be alive. */
+int  dex_debug_handoff_timeouts(DexCtx* ctx, dex_stream_t stream);
+
 /* STFT/mel front-end (audio/tools.py:8-15): wav [L] fp32 in [-1,1] (clipped here) -> mel [80,frames],
  * energy [frames]; frames = L/256 + 1.  n_fft=1024, hop=256, 80 mels, 22050 Hz, fmin 0, fmax 8000. */
 int  dex_mel_frames(int n_samples);

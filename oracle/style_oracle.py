@@ -131,17 +131,24 @@ def style_forward(W: Dict[str, Tensor], ref: Tensor, ref_lengths: Tensor, sty: T
     return {"sty_enc": sty_enc, "sty_dec": sty_dec, "ref_skips": skips, "vq_idx": idx}
 
 
-def lf0_from_f0(f0):
-    """DEX-TTS/synthesize.py:55-58 + normalize_lf0 (:26-38): log of the voiced frames, then over the entries with lf0 != 0
-    (lf0 - mean) / (std + 1e-8) — or lf0 - mean when std == 0 —, the others 0.  f0: 1-D float32 numpy array in Hz."""
+def normalize_lf0(lf0):
+    """normalize_lf0 — DEX-TTS/synthesize.py:26-38 — on a 1-D float32 array of log-f0 (0 = unvoiced): over the entries != 0
+    (lf0 - mean) / (std + 1e-8), or lf0 - mean when std == 0; the others stay 0.  numpy float32 arithmetic, as in the reference."""
     import numpy as np
-    f0 = np.asarray(f0, dtype=np.float32)
-    lf0 = f0.copy()
-    nz = np.nonzero(f0)
-    lf0[nz] = np.log(f0[nz])
+    lf0 = np.asarray(lf0, dtype=np.float32).copy()
     zero = lf0 == 0
     if (~zero).any():
         mean, std = np.mean(lf0[~zero]), np.std(lf0[~zero])
         lf0 = (lf0 - mean) if std == 0 else (lf0 - mean) / (std + 1e-8)
         lf0[zero] = 0.0
     return lf0.astype(np.float32)
+
+
+def lf0_from_f0(f0):
+    """DEX-TTS/synthesize.py:55-58: log of the voiced frames of an f0 track in Hz (1-D float32), then normalize_lf0."""
+    import numpy as np
+    f0 = np.asarray(f0, dtype=np.float32)
+    lf0 = f0.copy()
+    nz = np.nonzero(f0)
+    lf0[nz] = np.log(f0[nz])
+    return normalize_lf0(lf0)

@@ -29,11 +29,20 @@ def test_constant_track_is_roundoff_in_the_reference():
 @pytest.mark.gpu
 @pytest.mark.parametrize("k", TRACKS)
 def test_gpu_lf0_matches_reference_golden(k):
+    """Against the reference's own outputs, and — operation by operation — against numpy's float32 arithmetic on the DEVICE's
+    log values.  The second check is what pins the constant track: there the reference's std is pure summation round-off
+    (5e-7 instead of 0), so its output (-0.979...) moves by 1 % when ONE log value moves by one ulp, as the device's logf does
+    (measured: -0.9896); given the same log values the kernel and numpy agree to the last bits."""
     from dex_tts_amd.audio import lf0_from_f0
-    got = lf0_from_f0(torch.from_numpy(LF0[f"{k}_f0"]).cuda()).cpu().numpy()
+    f0 = torch.from_numpy(LF0[f"{k}_f0"]).cuda()
+    got = lf0_from_f0(f0).cpu().numpy()
     want = LF0[f"{k}_lf0"]
     assert np.array_equal(got == 0, want == 0)
-    assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max()), float(np.abs(got - want).max())
+    if k != "constant":
+        assert np.abs(got - want).max() <= 1e-5 * max(1.0, np.abs(want).max()), float(np.abs(got - want).max())
+    dev_log = torch.where(f0 != 0, torch.log(f0), torch.zeros_like(f0)).cpu().numpy()
+    same = SO.normalize_lf0(dev_log)
+    assert np.abs(got - same).max() <= 2e-6 * max(1.0, np.abs(same).max()), float(np.abs(got - same).max())
 
 
 @pytest.mark.gpu

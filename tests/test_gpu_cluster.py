@@ -1,0 +1,73 @@
+"""The cluster form of the fused DiT block (dit_rowchain_cluster_kernel): four workgroups per 32-row tile exchange split-K partial
+sums inside ONE launch (write-through stores + flags).  What can go wrong is visibility — a stale slab or flag — so the tests
+hammer it: many back-to-back calls must be bitwise identical, eager == graph replay, results equal the one-workgroup form to
+reduced-precision rounding and the oracle to the stated tolerance, and no hand-off wait ever times out."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import gpu_util as U
+from tests.tolerances import LOWP
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(eng, case, n, graph=False):
+    mu, mask, z = (torch.from_numpy(case[k]).cuda() for k in ("mu", "mask", "z"))
+    return eng.sample(z, mask, mu, n, use_graph=graph, **U.engine_kwargs(case)).cpu().numpy()
+
+
+@pytest.mark.parametrize("name,kw,n", [
+    ("gedex_lj", dict(B=1, T=512), 6),                                    # the headline shape: 21 clusters of 4
+    ("gedex_lj", dict(B=3, T=512, lengths=[512, 300, 77]), 3),            # 63 clusters: the largest grid that takes the cluster form
+    ("gedex_lj", dict(B=2, T=100, lengths=[100, 61]), 4),                 # N not a multiple of 32, ragged
+    ("dex_vctk", dict(B=1, T=64, lengths=[57], Tr=40, Ts=40, sty_lengths=[33]), 4),
+])
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_cluster_form_repeatable_and_equal_to_single_workgroup_form(name, kw, n, prec):
+    cfg, eng, w = U.engine_for(name)
+    case = U.make_case(cfg, **kw)
+    eng.set_precision(prec)
+    try:
+        a = _run(eng, case, n)
+        assert eng.handoff_timeouts() == 0
+        for _ in range(12):                                               # stale slabs / flags would show up as a changed bit
+            assert np.array_equal(a, _run(eng, case, n))
+        assert np.array_equal(a, _run(eng, case, n, graph=True))
+        assert np.array_equal(a, _run(eng, case, n, graph=True))          # second replay: flags re-zeroed by the replayed memset node
+        assert eng.handoff_timeouts() == 0
+        os.environ["DEX_DIT_CLUSTER"] = "0"
+        try:
+            single = _run(eng, case, n)
+        finally:
+            del os.environ["DEX_DIT_CLUSTER"]
+        assert not np.array_equal(single, a)                              # another kernel really ran
+        got, ref = U.run_sampler(name, case, n)
+        for tag, y in (("cluster", a), ("single", single)):
+            e = np.abs(y - ref)
+            U.record(f"clusterAB_{name}_B{kw['B']}_T{kw['T']}_{tag}:{prec}:sampler", max=e.max(), mean=e.mean())
+            assert e.max() <= LOWP[prec]["sampler"][0] and e.mean() <= LOWP[prec]["sampler"][1], (tag, float(e.max()), float(e.mean()))
+    finally:
+        eng.set_precision("fp32")
+
+
+def test_cluster_form_under_concurrent_load():
+    """Hand-offs under UNEVEN load (the guide's advice): a second stream streams memory while the sampler runs; bits unchanged."""
+    cfg, eng, w = U.engine_for("gedex_lj")
+    case = U.make_case(cfg, B=1, T=512)
+    eng.set_precision("bf16")
+    try:
+        a = _run(eng, case, 4)
+        big = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+        side = torch.cuda.Stream()
+        for _ in range(6):
+            with torch.cuda.stream(side):
+                for _ in range(8):
+                    big.mul_(1.0001)
+            assert np.array_equal(a, _run(eng, case, 4))
+        torch.cuda.synchronize()
+        assert eng.handoff_timeouts() == 0
+    finally:
+        eng.set_precision("fp32")
