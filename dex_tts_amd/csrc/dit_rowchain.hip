@@ -744,6 +744,38 @@ __device__ __forceinline__ void mma8(f32x16& acc, const uint4 (&w)[8], const u16
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc = DEX_MFMA_LP(__builtin_bit_cast(lp8, a[j]), __builtin_bit_cast(lp8, w[j]), acc, 0, 0, 0);
 }
+// LayerNorm + modulate of a row held in registers (16 threads per row, four float4 each at columns q*64 + seg*4) -> bf16 A tile:
+// ln_to_A without the LDS round trip and its barrier (the row sums run over the 16 lanes of the row)
+__device__ __forceinline__ void ln_regs_to_A(float4 (&v)[4], u16* As, const float* shift, const float* scale, int row, int seg) {
+    float4 sc[4], sh[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        sc[q] = *reinterpret_cast<const float4*>(scale + q * 64 + seg * 4);
+        sh[q] = *reinterpret_cast<const float4*>(shift + q * 64 + seg * 4);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o);
+    const float mean = s * (1.f / RC_H);
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        v[q].x -= mean; v[q].y -= mean; v[q].z -= mean; v[q].w -= mean;
+        ss += v[q].x * v[q].x + v[q].y * v[q].y + v[q].z * v[q].z + v[q].w * v[q].w;
+    }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) ss += __shfl_xor(ss, o);
+    const float rstd = rsqrtf(ss * (1.f / RC_H) + 1e-6f);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        uint2 o;
+        o.x = pack2_lp(v[q].x * rstd * (1.f + sc[q].x) + sh[q].x, v[q].y * rstd * (1.f + sc[q].y) + sh[q].y);
+        o.y = pack2_lp(v[q].z * rstd * (1.f + sc[q].z) + sh[q].z, v[q].w * rstd * (1.f + sc[q].w) + sh[q].w);
+        *reinterpret_cast<uint2*>(As + row * A_LD + q * 64 + seg * 4) = o;
+    }
+}
 // one lane per peer polls that peer's flag until it shows this launch's epoch (relaxed agent-scope loads + s_sleep)
 __device__ __forceinline__ void cluster_wait(const unsigned* flags, int member, unsigned epoch, int tid, int* xerr) {
     if (tid < DIT_CLUSTER && tid != member) {
@@ -783,6 +815,10 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const 
     const int row = tid >> 4, seg = tid & 15;                            // the row-wise phases: 16 threads per row, 4 float4 each
     const int nrow = min(n0 + row, N - 1);
 
+#ifdef DEX_TIMING
+    long long cts[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};
+    cts[0] = wall_clock64();
+#endif
     float4 prm;                                                          // the parameter table entry this thread fetches
     {
         const int which = tid >> 6, c4 = (tid & 63) * 4;
@@ -884,6 +920,9 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const 
             }
             al += __shfl_xor(al, 32);
         }
+#ifdef DEX_TIMING
+    cts[1] = wall_clock64();
+#endif
         wload8(w8, p.Wp, 16, wave, 8 * head, lane);               // proj weights: output tile `wave`, the head's K half
         // partial (m, l, O[query][d]) of this wave -> LDS scratch
         float* scr = reinterpret_cast<float*>(smem_rc);
@@ -931,6 +970,10 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const 
         }
         *reinterpret_cast<float4*>(PRM + (tid >> 6) * RC_H + (tid & 63) * 4) = prm;
         lds_barrier();
+
+#ifdef DEX_TIMING
+    cts[2] = wall_clock64();
+#endif
         // ---- proj partial: P_c = O_c Wp[head rows, :]  (raw: bias, gate and residual are applied after the exchange)
         acc = zero16();
         mma8(acc, w8, Ah + i * CL_AH_LD + hh * 8);
@@ -939,6 +982,10 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const 
 #pragma unroll
         for (int r = 0; r < 16; ++r) X1[((r & 3) + 8 * (r >> 2) + 4 * hh) * X_LD + col] = acc[r];
         lds_barrier();
+
+#ifdef DEX_TIMING
+    cts[3] = wall_clock64();
+#endif
         // ---- exchange 0: publish P_c and (M_c, L_c)
         {
             const unsigned base = (0 * DIT_CLUSTER + member) * SLAB_B;
@@ -957,7 +1004,15 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const 
             __syncthreads();
             if (tid == 0) __hip_atomic_store(flags + 0 * DIT_CLUSTER + member, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+
+#ifdef DEX_TIMING
+    cts[4] = wall_clock64();
+#endif
         cluster_wait(flags + 0 * DIT_CLUSTER, member, p.epoch, tid, p.xerr);
+#ifdef DEX_TIMING
+    cts[5] = wall_clock64();
+#endif
+
         {
             // every peer's partial of this thread's 16 columns + its row statistics: all loads first
             u32x4v pv[DIT_CLUSTER][4];
@@ -997,10 +1052,17 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const 
                 v[q] = make_float4(xr[q].x + g.x * (sacc.x + bb.x), xr[q].y + g.y * (sacc.y + bb.y), xr[q].z + g.z * (sacc.z + bb.z), xr[q].w + g.w * (sacc.w + bb.w));
                 *reinterpret_cast<float4*>(X1 + row * X_LD + q * 64 + seg * 4) = v[q];      // x1 (in place: this thread owns these elements)
             }
+            ln_regs_to_A(v, As, PRM, PRM + RC_H, row, seg);      // LN + modulate straight from the registers
         }
+
+#ifdef DEX_TIMING
+    cts[6] = wall_clock64();
+#endif
         lds_barrier();
-        ln_to_A(X1, As, PRM, PRM + RC_H, tid);
-        lds_barrier();
+#ifdef DEX_TIMING
+    cts[7] = wall_clock64();
+#endif
+
         // ---- fc1 + GELU for hidden columns 128 member .. +128: (column tile ct, K half kh) per wave
         {
             const int ct = wave & 3, kh = wave >> 2;
@@ -1022,11 +1084,19 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const 
             }
             lds_barrier();
         }
+
+#ifdef DEX_TIMING
+    cts[8] = wall_clock64();
+#endif
         // ---- fc2 partial over this member's hidden slice
         acc = zero16();
         mma8(acc, w8, Ah + i * CL_AH_LD + hh * 8);
 #pragma unroll
         for (int r = 0; r < 16; ++r) P2[((r & 3) + 8 * (r >> 2) + 4 * hh) * X_LD + col] = acc[r];
+
+#ifdef DEX_TIMING
+    cts[9] = wall_clock64();
+#endif
         lds_barrier();
         {
             const unsigned base = (1 * DIT_CLUSTER + member) * SLAB_B;
@@ -1040,7 +1110,15 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const 
             __syncthreads();
             if (tid == 0) __hip_atomic_store(flags + 1 * DIT_CLUSTER + member, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+
+#ifdef DEX_TIMING
+    cts[10] = wall_clock64();
+#endif
         cluster_wait(flags + 1 * DIT_CLUSTER, member, p.epoch, tid, p.xerr);
+#ifdef DEX_TIMING
+    cts[11] = wall_clock64();
+#endif
+
         {
             u32x4v pv[DIT_CLUSTER][4];
 #pragma unroll
@@ -1063,30 +1141,40 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const 
                 const float4 bb = *reinterpret_cast<const float4*>(PRM + 7 * RC_H + q * 64 + seg * 4);
                 const float4 x1 = *reinterpret_cast<const float4*>(X1 + row * X_LD + q * 64 + seg * 4);
                 const float4 x2 = make_float4(x1.x + g.x * (sacc.x + bb.x), x1.y + g.y * (sacc.y + bb.y), x1.z + g.z * (sacc.z + bb.z), x1.w + g.w * (sacc.w + bb.w));
-                *reinterpret_cast<float4*>(X1 + row * X_LD + q * 64 + seg * 4) = x2;
+                xr[q] = x2;                                                 // (the residual registers are free: they now carry x2 into the LayerNorm)
                 if (q == member && n0 + row < N) *reinterpret_cast<float4*>(p.X + (mb + n0 + row) * RC_H + q * 64 + seg * 4) = x2;    // member c owns columns 64 c .. +64 of X
             }
         }
+
+#ifdef DEX_TIMING
+    cts[12] = wall_clock64();
+#endif
         if (!has_q) return;
     } else {
         // first block: LN + modulate + qkv of the incoming token rows only
         *reinterpret_cast<float4*>(PRM + (tid >> 6) * RC_H + (tid & 63) * 4) = prm;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(X1 + row * X_LD + q * 64 + seg * 4) = xr[q];
+        lds_barrier();                                   // the parameter table is complete
     }
     // ---- next block's qkv: column tiles 6 member .. 6 member + 5 on waves 0-5 (full K)
     uint4 wq[16];
     const int nt = 6 * member + wave;
     if (wave < 6) wload(wq, p.Wq, 16, nt, 0, lane);
+    ln_regs_to_A(xr, As, PRM + 2 * RC_H, PRM + 3 * RC_H, row, seg);      // xr = x2 (or the incoming rows of the first block)
     lds_barrier();
-    ln_to_A(X1, As, PRM + 2 * RC_H, PRM + 3 * RC_H, tid);
-    lds_barrier();
+
+#ifdef DEX_TIMING
+    cts[13] = wall_clock64();
+#endif
     if (wave < 6) {
         const float bq = p.bq[nt * 32 + i];
         acc = zero16();
         mma16(acc, wq, As + i * A_LD + hh * 8);
         store_qkv_tile(p, acc, nt, bq, b, n0, lane, QS + wave * (RC_ROWS * QK_LD));
     }
+#ifdef DEX_TIMING
+    cts[14] = wall_clock64();
+    if (p.dbg && tid == 0) for (int q = 0; q < 16; ++q) p.dbg[blockIdx.x * 16 + q] = cts[q];
+#endif
 }
 constexpr size_t RC_LDS_CLUSTER_CHAIN = (size_t)(2 * RC_ROWS * X_LD + 8 * RC_H + 4 * RC_ROWS * CL_RED_LD) * sizeof(float)
                                         + (size_t)(RC_ROWS * A_LD + RC_ROWS * CL_AH_LD + RC_NW * RC_ROWS * QK_LD) * sizeof(u16);

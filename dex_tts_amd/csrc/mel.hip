@@ -59,7 +59,7 @@ void launch_magmel(const MagMelP& p, hipStream_t st, int B) {
 // entries with lf0 != 0 (an f0 of exactly 1 Hz counts as unvoiced, as in the reference): (lf0 - mean) / (std + 1e-8), or lf0 - mean
 // when std == 0; unvoiced entries and everything past the utterance's length stay 0.
 // The statistics repeat numpy's fp32 arithmetic OPERATION BY OPERATION — np.mean / np.std of a contiguous float32 array reduce as
-// a[0] + pairwise_sum(a[1:]) with numpy's 8-accumulator / 128-element-block pairwise scheme, the variance from the separately
+// 0 + pairwise_sum(a) with numpy's 8-accumulator / 128-element-block pairwise scheme (checked against np.add.reduce), the variance from the separately
 // rounded (a - mean)^2 — because on a (nearly) constant pitch track the reference's std is nothing BUT that round-off (a constant
 // 200 Hz track normalises to -0.979, not 0), so only the same operation order reproduces it.  One wave per utterance: the voiced
 // values are compacted in order into LDS by ballot, lane 0 runs the two reductions (T is a few hundred frames), all lanes write.
@@ -83,8 +83,8 @@ __device__ float np_pairwise_sum_f32(const float* a, int n) {
     n2 -= n2 % 8;
     return __fadd_rn(np_pairwise_sum_f32(a, n2), np_pairwise_sum_f32(a + n2, n - n2));
 }
-__device__ float np_add_reduce_f32(const float* a, int n) {       // np.add.reduce: the first element is the initial value
-    return n == 1 ? a[0] : __fadd_rn(a[0], np_pairwise_sum_f32(a + 1, n - 1));
+__device__ float np_add_reduce_f32(const float* a, int n) {       // np.add.reduce of a contiguous array: identity (0) + pairwise_sum(a, n)
+    return __fadd_rn(0.f, np_pairwise_sum_f32(a, n));
 }
 
 __global__ __launch_bounds__(64) void lf0_normalize_kernel(const float* __restrict__ f0, const int* __restrict__ lengths, int T, float* __restrict__ out) {

@@ -93,7 +93,7 @@ def test_heun_golden(key):
     cfg, eng, w = U.engine_for(name)
     mu, mask, z = (torch.from_numpy(g[k]) for k in ("mu", "mask", "z"))
     got = eng.sample(z, mask, mu, int(n), solver="heun", **U.engine_kwargs(g)).cpu().numpy()
-    U.fp32_sampler_ok(f"parity2_" + os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0], got, h[key])
+    U.fp32_sampler_ok(f"parity2_" + os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0], got, h[key], heun=True)
 
 
 @pytest.mark.parametrize("name,kw,n", [
@@ -105,7 +105,7 @@ def test_heun_oracle(name, kw, n):
     cfg, eng, w = U.engine_for(name)
     case = U.make_case(cfg, **kw)
     got, ref = U.run_sampler(name, case, n, solver="heun")
-    U.fp32_sampler_ok(f"parity3_" + os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0], got, ref)
+    U.fp32_sampler_ok(f"parity3_" + os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0], got, ref, heun=True)
     # the same engine goes straight back to Euler (table sizes and modes are per call)
     got, ref = U.run_sampler(name, case, n)
     U.fp32_sampler_ok(f"parity4_" + os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0], got, ref)
@@ -120,7 +120,7 @@ def test_churn_golden(tag):
     cfg, eng, w = U.engine_for("gedex_lj")
     mu, mask, z = (torch.from_numpy(g[k]) for k in ("mu", "mask", "z"))
     got = eng.sample(z, mask, mu, n, solver=solver, noise=torch.from_numpy(noise), **sp).cpu().numpy()
-    U.fp32_sampler_ok(f"parity5_" + os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0], got, want)
+    U.fp32_sampler_ok(f"parity5_" + os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0], got, want, heun=(solver == "heun"))
     rep = eng.sample(z, mask, mu, n, solver=solver, noise=torch.from_numpy(noise), use_graph=True, **sp).cpu().numpy()
     assert np.array_equal(got, rep)
     with pytest.raises(ValueError):
@@ -179,7 +179,7 @@ def test_heun_bf16_mode_and_module_switch():
     mu, mask, z = (torch.from_numpy(case[k]).cuda() for k in ("mu", "mask", "z"))
     m.solver = "heun"
     y = m.sampler(z, mask, mu, None, 6).cpu().numpy()
-    U.fp32_sampler_ok(f"parity7_" + os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0], y, ref)
+    U.fp32_sampler_ok(f"parity7_" + os.environ.get("PYTEST_CURRENT_TEST", "").split("::")[-1].split(" ")[0], y, ref, heun=True)
     with pytest.raises(ValueError):
         eng.sample(z, mask, mu, 4, solver="rk4")
 

@@ -14,6 +14,12 @@ CPU oracle over every case of tests/test_gpu_parity.py and tests/test_gpu_baseli
 FP32_CALL_REL = 1e-4          # single EDMPrecond call: max|d| <= FP32_CALL_REL * max(1, |y|max)
 FP32_SAMPLER_MAX = 5e-5       # sampler: max|d|
 FP32_SAMPLER_MEAN = 1e-5      # sampler: mean|d|
+# Heun (edm.py:207-214) with FEW steps is ill-conditioned in the reference itself: step i = n-2 evaluates the corrector at
+# sigma' = 0.002 after a step h ~ sigma_(n-2) (0.47 at n = 4), and d' = (x' - D')/sigma' enters x_next times h/2 — one fp32 ulp of
+# D' (the network's own summation-order noise, 5e-7) is amplified by h / (2 sigma') ~ 1e2.  Measured (round 3, fp32 mode vs oracle /
+# reference goldens): n = 3..5: 1.1e-4 .. 7.0e-4 max, 1.0e-5 .. 9.4e-5 mean; n = 7: 3.2e-5 / 3.5e-6.  Bounds = 3x the worst.
+FP32_HEUN_MAX = 2e-3
+FP32_HEUN_MEAN = 3e-4
 FP32_TAP_REL = 2e-4           # stage taps (down0 / down1 / dit_in / dit_out / up0 ...): max|d| <= FP32_TAP_REL * max(1, |tap|max)
 
 # (max|d|, mean|d|) on mels of range about [-11.5, 4], RMS 2.7
@@ -22,5 +28,6 @@ FP32_TAP_REL = 2e-4           # stage taps (down0 / down1 / dit_in / dit_out / u
 # call and 6.9e-3 / 1.5e-3 for the 50-step sampler at T=512.  fp16: call 3.1e-3 / 3.8e-4, sampler 9.5e-4 / 1.6e-4.
 LOWP = {
     "bf16": {"call": (5e-2, 6.5e-3), "sampler": (5e-2, 7.5e-3)},
-    "fp16": {"call": (6e-3, 7.5e-4), "sampler": (4e-3, 6e-4)},
+    # (round 3: the 3-utterance ragged batch with a 77-frame utterance of tests/test_gpu_cluster.py reaches 4.6e-3 max in BOTH forms of the DiT block)
+    "fp16": {"call": (6e-3, 7.5e-4), "sampler": (7e-3, 6e-4)},
 }
