@@ -287,13 +287,14 @@ def side_workload(name, precision, device, stream, graph_mode, steps=3, warmup=1
     return ent
 
 
-def vocoder_block(device, stream, B=1, T=512, steps=10, warmup=3, big=False):
+def vocoder_block(device, stream, B=1, T=512, steps=10, warmup=3, big=False, precision="fp32"):
     """HiFi-GAN V1 generator (the step right after the sampler) on the mel of the headline workload; big: BigVGAN-base."""
     from dex_tts_amd import vocoder as V
     h = V.BIGVGAN_BASE if big else V.HIFIGAN_V1
     gen = V.Generator(V.AttrDict(h))
     gen.load_state_dict({k: torch.from_numpy(v) for k, v in synth.make_vocoder_weights(V.param_shapes(h)).items()})
     gen = gen.to(device).eval()
+    gen.precision = precision
     mel = torch.from_numpy(synth.make_inputs(B, T, None, seed=1234)[0]).to(device)
     # algorithmic work: every Conv1d / ConvTranspose1d as 2 * L_out * Cin * Cout * taps-per-output
     fl, L, c = 2.0 * T * 80 * h["upsample_initial_channel"] * 7, T, h["upsample_initial_channel"]
@@ -307,10 +308,12 @@ def vocoder_block(device, stream, B=1, T=512, steps=10, warmup=3, big=False):
     assert torch.isfinite(wav).all()
     sec = dt / steps
     name = "BigVGAN-base generator (anti-aliased snakebeta activations)" if big else "HiFi-GAN V1 generator (hifigan/config.json)"
-    return {"workload": f"{name}, B={B}, T={T} mel frames -> {wav.shape[-1]} samples, exact-fp32 MFMA",
+    mode = "exact-fp32 MFMA" if precision == "fp32" else f"{precision} MFMA operands, fp32 accumulation"
+    peak = PEAK_TFLOPS[DTYPE_KEY[precision]]
+    return {"workload": f"{name}, B={B}, T={T} mel frames -> {wav.shape[-1]} samples, {mode}",
             "value": round(B * T / sec, 1), "unit": "mel-frames/s", "ms_per_call": round(sec * 1e3, 3), "hip_event_median_ms": round(statistics.median(ev), 3),
             "rtf": round(sec / (B * T * 256 / 22050.0), 6), "algorithmic_GFLOP": round(B * fl / 1e9, 1),
-            "mfma_TFLOP/s": round(B * fl / sec / 1e12, 1), "frac_of_fp32_mfma_peak": round(B * fl / sec / 1e12 / PEAK_TFLOPS["f32"], 3)}
+            "mfma_TFLOP/s": round(B * fl / sec / 1e12, 1), f"frac_of_{DTYPE_KEY[precision]}_mfma_peak": round(B * fl / sec / 1e12 / peak, 3)}
 
 
 def frontend_block(device, stream, steps=10, warmup=3):
@@ -517,6 +520,8 @@ def main():
             }
         if prof and args.workload == "gedex_b1" and not args.no_configs:
             res["vocoder"] = vocoder_block(device, stream)
+            res["vocoder_bf16"] = vocoder_block(device, stream, precision="bf16")
+            res["vocoder_fp16"] = vocoder_block(device, stream, precision="fp16")
             res["vocoder_bigvgan"] = vocoder_block(device, stream, big=True)
             res["frontend"] = frontend_block(device, stream)
         if world == 1 and not args.no_cpu_baseline:

@@ -112,6 +112,7 @@ SYMBOLS = [
     ("dex_voc_finalize", C.c_int, [C.c_void_p, C.c_void_p]),
     ("dex_voc_workspace_bytes", C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     ("dex_voc_samples", C.c_int, [C.c_void_p, C.c_int]),
+    ("dex_voc_set_precision", C.c_int, [C.c_void_p, C.c_int]),
     ("dex_vocode", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("dex_style_create", C.c_int, [C.POINTER(DexStyleConfig), C.POINTER(C.c_void_p)]),
     ("dex_style_destroy", None, [C.c_void_p]),

@@ -27,8 +27,9 @@ using namespace dex;
 
 namespace {
 struct VRaw { float* p = nullptr; std::vector<int64_t> shape; long numel = 0; bool loaded = false; };
-struct VConv { const float* w = nullptr; const float* b = nullptr; int cin, cout, k, dil; };     // packed [k*cin][cout]
-struct VUp { const float* w = nullptr; const float* b = nullptr; int cin, cout, k, u, pad; };    // packed [cin][k*cout]
+// (wlp: the same matrix as bf16 [0] / fp16 [1], [N][K] with K contiguous - the reduced-precision GEMM's weight operand)
+struct VConv { const float* w = nullptr; const float* b = nullptr; int cin, cout, k, dil; const void* wlp[2] = {nullptr, nullptr}; };     // packed [k*cin][cout]
+struct VUp { const float* w = nullptr; const float* b = nullptr; int cin, cout, k, u, pad; const void* wlp[2] = {nullptr, nullptr}; };    // packed [cin][k*cout]
 constexpr int MEL_LD = 96;          // num_mels padded to a multiple of 32 (K tiles of the implicit GEMM do not straddle taps)
 }  // namespace
 
@@ -39,6 +40,7 @@ struct DexVoc {
     std::map<std::string, VRaw> raw;
     std::vector<void*> owned;
     bool finalized = false;
+    int precision = DEX_PREC_FP32;      // DEX_PREC_BF16 / DEX_PREC_FP16: the convolutions' operands (fp32 accumulation, fp32 activations in HBM)
     VConv pre;
     std::vector<VUp> ups;
     std::vector<VConv> rb;              // [stage][j][c1_0, c2_0, c1_1, c2_1, c1_2, c2_2] flattened
@@ -171,6 +173,14 @@ int dex_voc_finalize(DexVoc* v, dex_stream_t stream) {
         v->owned.push_back(p);
         return p;
     };
+    // reduced-precision copies of a packed fp32 [K][N] matrix: bf16 and fp16, [N][K]
+    auto lp_copies = [&](const float* w, int K, int N, const void* (&out)[2]) {
+        for (int t = 0; t < 2; ++t) {
+            void* d = alloc(((long)K * N + 1) / 2);
+            if (d) launch_pack_lp_nk(w, d, K, N, t ? DEX_PREC_FP16 : DEX_PREC_BF16, st);
+            out[t] = d;
+        }
+    };
     // Conv1d [Cout][Cin][k] -> [(tap*Cin_pad + ci)][Cout]
     auto conv = [&](const std::string& name, int cin, int cout, int k, int dil, int cin_pad) {
         VConv o{}; o.cin = cin_pad; o.cout = cout; o.k = k; o.dil = dil;
@@ -190,6 +200,7 @@ int dex_voc_finalize(DexVoc* v, dex_stream_t stream) {
             o.w = d;
         }
         o.b = v->raw.at(name + ".bias").p;
+        if (o.w) lp_copies(o.w, k * cin_pad, cout, o.wlp);
         return o;
     };
     v->pre = conv("conv_pre", c.num_mels, c.upsample_initial_channel, 7, 1, MEL_LD);
@@ -201,6 +212,7 @@ int dex_voc_finalize(DexVoc* v, dex_stream_t stream) {
         const std::string upn = "ups." + std::to_string(i) + (v->big() ? ".0" : "");
         if (d) launch_permute4(v->raw.at(upn + ".weight").p, d, ci, co, k, 1, 0, 2, 1, 3, st);   // [ci][co][k] -> [ci][k][co]
         up.w = d; up.b = v->raw.at(upn + ".bias").p;
+        if (d) lp_copies(d, ci, k * co, up.wlp);
         v->ups.push_back(up);
         for (int j = 0; j < 3; ++j) {
             const std::string p = "resblocks." + std::to_string(i * 3 + j);
@@ -240,6 +252,13 @@ int dex_voc_finalize(DexVoc* v, dex_stream_t stream) {
 
 int dex_voc_samples(const DexVoc* v, int T) { return v ? (int)(T * total_up(v->cfg)) : 0; }
 
+int dex_voc_set_precision(DexVoc* v, int precision) {
+    if (!v) return DEX_ERR_ARG;
+    if (precision != DEX_PREC_FP32 && precision != DEX_PREC_BF16 && precision != DEX_PREC_FP16) return v->fail(DEX_ERR_ARG, "unknown precision %d", precision);
+    v->precision = precision;
+    return DEX_OK;
+}
+
 }  // extern "C"
 
 namespace {
@@ -263,13 +282,14 @@ void voc_plan(const DexVoc* v, int B, int T, void* ws, VPlan& P) {
     P.y = take(ymax);
     P.bytes = (off + 255) & ~size_t(255);
 }
+thread_local int g_voc_lp = -1;        // -1: fp32 operands; 0 / 1: bf16 / fp16 weight copies (set by dex_vocode for the duration of its enqueue)
 IGemmP conv1d(const float* X, int L, int B, const VConv& c, float slope, float* out, const float* res) {
     IGemmP g{};
     g.A = X; g.lda = c.cin; g.a_bstride = (long)L * c.cin; g.a_coff = 0;
     g.Hi = 1; g.Wi = L; g.Cin = c.cin;
     g.KH = 1; g.KW = c.k; g.sh = 1; g.sw = 1; g.off_h = 0; g.off_w = -c.dil * (c.k - 1) / 2; g.step_h = 1; g.step_w = c.dil;
     g.Ho = 1; g.Wo = L;
-    g.W = c.w; g.Wbf = nullptr; g.N = c.cout; g.K = c.k * c.cin; g.ksplit = 1; g.groups = 1;
+    g.W = c.w; g.Wbf = g_voc_lp >= 0 ? c.wlp[g_voc_lp] : nullptr; g.N = c.cout; g.K = c.k * c.cin; g.ksplit = 1; g.groups = 1;
     g.bias = c.b;
     g.C = out; g.ldc = c.cout; g.c_bstride = (long)L * c.cout; g.c_coff = 0;
     g.OHf = 1; g.OWf = L; g.osh = 1; g.osw = 1;
@@ -299,8 +319,10 @@ int dex_vocode(DexVoc* v, const float* mel_dev, int B, int T, float* wav_dev, vo
     voc_plan(v, B, T, ws, P);
     hipStream_t st = (hipStream_t)stream;
     const DexVocoderConfig& c = v->cfg;
+    const int prec = v->precision;
+    g_voc_lp = prec == DEX_PREC_BF16 ? 0 : prec == DEX_PREC_FP16 ? 1 : -1;
     launch_mel_to_cl(mel_dev, P.mel, B, c.num_mels, T, MEL_LD, st);
-    launch_igemm(conv1d(P.mel, T, B, v->pre, 0.f, P.x, nullptr), PREC_FP32, st);                  // conv_pre
+    launch_igemm(conv1d(P.mel, T, B, v->pre, 0.f, P.x, nullptr), prec, st);                  // conv_pre
     long L = T;
     for (int i = 0; i < c.n_upsamples; ++i) {
         const VUp& up = v->ups[i];
@@ -308,10 +330,10 @@ int dex_vocode(DexVoc* v, const float* mel_dev, int B, int T, float* wav_dev, vo
             IGemmP g{};
             g.A = P.x; g.lda = up.cin; g.a_bstride = L * up.cin; g.Hi = 1; g.Wi = (int)L; g.Cin = up.cin;
             g.KH = 1; g.KW = 1; g.sh = 1; g.sw = 1; g.step_h = 1; g.step_w = 1; g.Ho = 1; g.Wo = (int)L;
-            g.W = up.w; g.N = up.k * up.cout; g.K = up.cin; g.ksplit = 1; g.groups = 1;
+            g.W = up.w; g.Wbf = g_voc_lp >= 0 ? up.wlp[g_voc_lp] : nullptr; g.N = up.k * up.cout; g.K = up.cin; g.ksplit = 1; g.groups = 1;
             g.C = P.y; g.ldc = g.N; g.c_bstride = L * g.N; g.OHf = 1; g.OWf = (int)L; g.osh = 1; g.osw = 1;
             g.inmask_ws = 1; g.outmask_ws = 1; g.gate_nstride = 1; g.act_in_slope = v->big() ? 0.f : 0.1f; g.B = B;     // BigVGAN: no activation here
-            launch_igemm(g, PREC_FP32, st);
+            launch_igemm(g, prec, st);
             ConvTFoldP f{P.y, up.b, P.a, (int)L, up.cout, up.k, up.u, up.pad, B};
             launch_convt_fold(f, st);
         }
@@ -326,13 +348,13 @@ int dex_vocode(DexVoc* v, const float* mel_dev, int B, int T, float* wav_dev, vo
                     const size_t ai = ((size_t)(i * 3 + j) * 6) + 2 * m;
                     AaSnakeP s1{cur, P.s, (int)L, up.cout, B, v->act_a[ai], v->act_ib[ai], v->filt};
                     launch_aa_snake(s1, st);
-                    launch_igemm(conv1d(P.s, (int)L, B, cv[2 * m], 0.f, P.x, nullptr), PREC_FP32, st);
+                    launch_igemm(conv1d(P.s, (int)L, B, cv[2 * m], 0.f, P.x, nullptr), prec, st);
                     AaSnakeP s2{P.x, P.s, (int)L, up.cout, B, v->act_a[ai + 1], v->act_ib[ai + 1], v->filt};
                     launch_aa_snake(s2, st);
-                    launch_igemm(conv1d(P.s, (int)L, B, cv[2 * m + 1], 0.f, dst, cur), PREC_FP32, st);
+                    launch_igemm(conv1d(P.s, (int)L, B, cv[2 * m + 1], 0.f, dst, cur), prec, st);
                 } else {
-                    launch_igemm(conv1d(cur, (int)L, B, cv[2 * m], 0.1f, P.x, nullptr), PREC_FP32, st);          // xt = c1(lrelu(x))
-                    launch_igemm(conv1d(P.x, (int)L, B, cv[2 * m + 1], 0.1f, dst, cur), PREC_FP32, st);          // x = c2(lrelu(xt)) + x
+                    launch_igemm(conv1d(cur, (int)L, B, cv[2 * m], 0.1f, P.x, nullptr), prec, st);          // xt = c1(lrelu(x))
+                    launch_igemm(conv1d(P.x, (int)L, B, cv[2 * m + 1], 0.1f, dst, cur), prec, st);          // x = c2(lrelu(xt)) + x
                 }
                 cur = dst;
             }

@@ -50,7 +50,9 @@ __device__ __forceinline__ void igemm_load_tile(const IGemmP& p, float4 (&fa)[AP
 // which serialises the ring: measured 19 -> 24.5 us on the stride-2 downsample conv before unrolling).
 // ALP / CLP: the A / C tensors hold 16-bit elements (IGemmP::a_lp / c_lp).  Compile-time: as runtime flags the extra branches
 // cost the ring its exact vmcnt bookkeeping (the Downsample conv went from 140 to 279 us at B=32).
-template <int BM, int BN, int BK, bool PT = false, int D = 1, int NKT = 0, bool ALP = false, bool CLP = false>
+// LR: leaky_relu(x, IGemmP::act_in_slope) on the gathered A elements (the vocoder's activation in front of every convolution),
+// compile-time for the same reason.
+template <int BM, int BN, int BK, bool PT = false, int D = 1, int NKT = 0, bool ALP = false, bool CLP = false, bool LR = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void igemm_lp_kernel(const IGemmP p) {
     constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (WM * 32);
     constexpr int TPR = BK / 8;                 // threads per tile row (8 elements each)
@@ -137,6 +139,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                     const unsigned u0 = __float_as_uint(f0.x), u1 = __float_as_uint(f0.y), u2 = __float_as_uint(f0.z), u3 = __float_as_uint(f0.w);
                     f0 = make_float4(lp_lo(u0), lp_hi(u0), lp_lo(u1), lp_hi(u1));
                     f1 = make_float4(lp_lo(u2), lp_hi(u2), lp_lo(u3), lp_hi(u3));
+                }
+                if constexpr (LR) {        // leaky_relu = max(x, slope x) for 0 < slope < 1
+                    const float sl = p.act_in_slope;
+                    f0 = make_float4(fmaxf(f0.x, f0.x * sl), fmaxf(f0.y, f0.y * sl), fmaxf(f0.z, f0.z * sl), fmaxf(f0.w, f0.w * sl));
+                    f1 = make_float4(fmaxf(f1.x, f1.x * sl), fmaxf(f1.y, f1.y * sl), fmaxf(f1.z, f1.z * sl), fmaxf(f1.w, f1.w * sl));
                 }
                 uint4 v;
                 v.x = pack2_mul_lp_pinned(f0.x, f0.y, mk); v.y = pack2_mul_lp_pinned(f0.z, f0.w, mk);
@@ -456,7 +463,7 @@ __global__ __launch_bounds__(256) void igemm_lp_nwalk_kernel(const IGemmP p) {
 }
 
 static bool nwalk_eligible(const IGemmP& p) {
-    if (p.a_lp || p.c_lp) return false;
+    if (p.a_lp || p.c_lp || p.act_in_slope != 0.f) return false;
     if (p.K != 256 || p.Cin != 256 || p.KH != 1 || p.KW != 1 || p.parity || p.ksplit != 1 || p.groups != 1 || (p.N % 64) != 0) return false;
     if (p.sh != 1 || p.sw != 1 || p.off_h != 0 || p.off_w != 0 || p.Ho != p.Hi || p.Wo != p.Wi || p.gn_stats) return false;
     // the kernel's epilogue is the unpatchify scatter and nothing else: bias, output mask, crop
@@ -499,7 +506,7 @@ static void launch_ss(const IGemmP& p, hipStream_t st) {
 }
 
 static bool ss_eligible(const IGemmP& p) {
-    if (p.a_lp || p.c_lp) return false;
+    if (p.a_lp || p.c_lp || p.act_in_slope != 0.f) return false;
     if (p.ksplit != 1 || p.groups != 1 || (p.N % 64) != 0) return false;
     if (p.K != 64 && p.K != 128 && p.K != 256 && p.K != 512) return false;
     const long blocks = (long)((p.Ho * p.Wo + 63) / 64) * (p.N / 64) * p.B;
@@ -521,6 +528,24 @@ void launch_igemm_lp(const IGemmP& p, hipStream_t st) {
     }
     const int zdim = p.B * p.groups * p.ksplit * (p.parity ? 4 : 1);
     const bool k64 = (p.Cin % 64 == 0) && ((p.K / p.ksplit) % 64 == 0);
+    if (p.act_in_slope != 0.f) {       // vocoder convolutions: leaky_relu while the A tile is staged (looped kernel, three tilings)
+        if (p.N % 64 == 0) {
+            const long blocks128 = (long)((M + 127) / 128) * (p.N / 64) * zdim;
+            if (blocks128 < 1024) {
+                dim3 grid((M + 63) / 64, p.N / 64, zdim);
+                if (k64) hipLaunchKernelGGL((igemm_lp_kernel<64, 64, 64, false, 1, 0, false, false, true>), grid, dim3(256), 0, st, p);
+                else hipLaunchKernelGGL((igemm_lp_kernel<64, 64, 32, false, 1, 0, false, false, true>), grid, dim3(256), 0, st, p);
+            } else {
+                dim3 grid((M + 127) / 128, p.N / 64, zdim);
+                if (k64) hipLaunchKernelGGL((igemm_lp_kernel<128, 64, 64, false, 1, 0, false, false, true>), grid, dim3(256), 0, st, p);
+                else hipLaunchKernelGGL((igemm_lp_kernel<128, 64, 32, false, 1, 0, false, false, true>), grid, dim3(256), 0, st, p);
+            }
+        } else {
+            dim3 grid((M + 127) / 128, p.N / 32, zdim);
+            hipLaunchKernelGGL((igemm_lp_kernel<128, 32, 32, false, 1, 0, false, false, true>), grid, dim3(256), 0, st, p);
+        }
+        return;
+    }
     if (p.a_lp || p.c_lp) {          // 16-bit A / C tensors: the batch tile only (igemm_lp_io_supported)
         dim3 grid((M + 127) / 128, p.N / 64, zdim);
         if (p.a_lp && p.c_lp) hipLaunchKernelGGL((igemm_lp_kernel<128, 64, 64, false, 1, 0, true, true>), grid, dim3(256), 0, st, p);

@@ -47,7 +47,7 @@ struct IGemmP {
     const float* outmask; int outmask_ws;
     long mask_bstride;
     int act;                                           // 0 none, 1 GELU(erf), 2 ReLU
-    float act_in_slope;                                // != 0: leaky_relu(x, slope) on the gathered A elements (fp32 kernel only:
+    float act_in_slope;                                // != 0: leaky_relu(x, slope) on the gathered A elements (fp32 kernel and the looped lp kernel:
                                                        // the vocoder's "x = leaky_relu(x); x = conv(x)", hifigan/models.py:98-103)
     const float* gate; int gate_nstride; long gate_step_stride;
     const float* res; int ldres; long res_bstride; int res_coff;

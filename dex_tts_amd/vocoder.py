@@ -198,6 +198,8 @@ class Generator(nn.Module):
         dev = x.device
         self._engine(dev)
         with torch.cuda.device(dev):
+            # operand precision of the convolutions: 'fp32' (default, the parity mode), 'bf16' or 'fp16' (attribute ``precision``)
+            self._check(self._lib.dex_voc_set_precision(self._ctx, _lib.PRECISION[getattr(self, "precision", "fp32")]))
             mel = x.to(dtype=torch.float32).contiguous()
             B, M, T = mel.shape
             if M != int(_get(self.h, "num_mels", 80)):

@@ -204,6 +204,10 @@ int  dex_voc_load_weight_async(DexVoc* voc, const char* key, const float* w_dev,
 int  dex_voc_finalize(DexVoc* voc, dex_stream_t stream);
 size_t dex_voc_workspace_bytes(const DexVoc* voc, int B, int T);
 int  dex_voc_samples(const DexVoc* voc, int T);          /* T * prod(upsample_rates) */
+/* Operand precision of the generator's convolutions (DexPrecision): DEX_PREC_FP32 (default; exact-fp32 MFMA, the parity mode) or
+ * DEX_PREC_BF16 / DEX_PREC_FP16 (operands rounded while staged, fp32 accumulation, fp32 activations in HBM, weights packed for
+ * both at dex_voc_finalize).  Takes effect at the next dex_vocode. */
+int  dex_voc_set_precision(DexVoc* voc, int precision);
 /* Generator.forward (models.py:150-167): mel_dev [B,num_mels,T] fp32 -> wav_dev [B, dex_voc_samples(T)] fp32 in [-1,1].
  * Exact-fp32 MFMA contractions (the reference's arithmetic).  Asynchronous on `stream`. */
 int  dex_vocode(DexVoc* voc, const float* mel_dev, int B, int T, float* wav_dev, void* workspace_dev, size_t workspace_bytes,

@@ -87,6 +87,39 @@ def test_vocode_matches_oracle(B, T):
     assert np.array_equal(got, again)                       # no atomics anywhere: bitwise repeatable
 
 
+# reduced-precision operand modes of the generator (round 3): (max|d|, RMS of d) on waveforms of std ~0.14 in [-1, 1] against the
+# reference golden / the fp32 oracle; bounds <= 2x the worst value measured on MI355X (gpurun_out/parity_measured.jsonl)
+VOC_LOWP = {"bf16": (1.4e-2, 2.5e-3), "fp16": (1.5e-3, 3e-4)}      # measured: bf16 6.6e-3 / 1.2e-3, fp16 7.1e-4 / 1.4e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_vocode_reduced_precision_modes(prec):
+    """``Generator.precision`` = 'bf16' / 'fp16': the same implicit-GEMM convolutions with operands rounded while staged (fp32
+    accumulation, fp32 activations in HBM) against the reference golden and the fp32 oracle; repeatable; fp32 mode untouched."""
+    from tests import gpu_util as U
+    g = dict(np.load(os.path.join(GOLD, "vocoder.npz")))
+    gen = _gpu_gen()
+    exact = gen(torch.from_numpy(g["mel"]).cuda()).cpu().numpy()
+    gen.precision = prec
+    wav = gen(torch.from_numpy(g["mel"]).cuda()).cpu().numpy()
+    mx, rms = VOC_LOWP[prec]
+    e = wav - g["wav"]
+    U.record(f"vocoder_golden:{prec}:call", max=np.abs(e).max(), mean=np.sqrt((e * e).mean()))
+    assert np.isfinite(wav).all() and not np.array_equal(wav, exact)
+    assert np.abs(e).max() <= mx and np.sqrt((e * e).mean()) <= rms, (float(np.abs(e).max()), float(np.sqrt((e * e).mean())))
+    mel = np.clip(synth.normalish("voc_mel_t", (2, 80, 64), 7 + 64) * 1.5 - 5.0, -11.5, 2.5).astype(np.float32)
+    got = gen(torch.from_numpy(mel).cuda()).cpu().numpy()
+    assert np.array_equal(got, gen(torch.from_numpy(mel).cuda()).cpu().numpy())
+    with torch.no_grad():
+        ref = VO.generator({k: torch.from_numpy(v) for k, v in weights().items()}, V.HIFIGAN_V1, torch.from_numpy(mel)).numpy()
+    e = got - ref
+    U.record(f"vocoder_oracle_B2_T64:{prec}:call", max=np.abs(e).max(), mean=np.sqrt((e * e).mean()))
+    assert np.abs(e).max() <= mx and np.sqrt((e * e).mean()) <= rms, (float(np.abs(e).max()), float(np.sqrt((e * e).mean())))
+    gen.precision = "fp32"
+    assert np.array_equal(exact, gen(torch.from_numpy(g["mel"]).cuda()).cpu().numpy())
+
+
 @pytest.mark.gpu
 def test_vocode_weight_norm_checkpoint():
     """A training-style checkpoint (weight_g / weight_v pairs) loads like the reference's generator_*.pth.tar."""
