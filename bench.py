@@ -44,6 +44,7 @@ WORKLOADS = {
     "dex_b32": ("dex_vctk", 32, 256, 50, 348, None),             # configs[2]
     "dex_esd_b32_n100": ("dex_esd", 32, 256, 100, 348, None),    # per-GPU share of configs[3] (256 utterances / 8 GPUs)
     "gedex_long": ("gedex_lj", 1, 4000, 50, 0, None),            # configs[4] shape
+    "dex_libritts_b8": ("dex_libritts", 8, 256, 50, 348, None),  # not a BASELINE config: the dim-128 / hidden-384 geometry (per-operation reduced precision)
 }
 CONFIG_TAG = {"gedex_b1": "BASELINE.json configs[1]", "dex_b32": "BASELINE.json configs[2]",
               "dex_esd_b32_n100": "BASELINE.json configs[3], per-GPU share (256 utterances / 8 GPUs)",

@@ -305,9 +305,12 @@ int dex_ctx_load_weight_async(DexCtx* x, const char* key, const float* w_dev, co
 
 int dex_ctx_set_precision(DexCtx* x, int precision) {
     if (!x || (precision != DEX_PREC_FP32 && precision != DEX_PREC_BF16 && precision != DEX_PREC_FP16)) return DEX_ERR_ARG;
-    if (precision != DEX_PREC_FP32 && !x->tuned)
-        return x->fail(DEX_ERR_ARG, "the bf16 / fp16 kernels are specialised for dim 64, DiT hidden 256 (2 x 128), 32-channel pos-conv groups; "
-                                    "this geometry (dim %d, hidden %d, %d heads) runs DEX_PREC_FP32 only", x->cfg.dim, x->cfg.dit_hidden, x->cfg.dit_heads);
+    // Geometries the tuned reduced-precision kernels do not cover (DEX-LibriTTS: dim 128 -> 128 / 256-channel stages, DiT hidden 384 =
+    // 2 x 192, 48-channel pos-conv groups, 256-channel TVAdaptor; DexCtx::tuned == false) run the same modes PER OPERATION: every
+    // convolution / linear layer with a packed 16-bit weight twin goes through the generic reduced-precision implicit GEMM (or the
+    // tuned kernel where its shape predicate holds: the 128 -> 128 convolutions, the 128-channel linear attention), and whatever has
+    // no 16-bit form for the shape - softmax attention at head_dim 192 / 256, the padded 48-channel pos-conv groups, GroupNorm as
+    // its own pass - stays on the exact-fp32 kernels.  Slower than a tuned geometry, same operand rounding.
     x->precision = precision;
     return DEX_OK;
 }
@@ -745,6 +748,7 @@ struct Runner {
                  bool res2 = false; FirstConvP res2f{}; };     // res2: `res` is not stored - recomputed from the first conv's inputs (res2f)
     // raw conv outputs read only by a fused GroupNorm prologue (h1, h2 of a ResnetBlock, the final block's conv) are kept
     // in HBM as bf16 in bf16 mode: half the bytes of the largest tensors of the step.  DEX_H_BF16=0 keeps them fp32.
+    static bool ln_fusable(int K) { return K == 64 || K == 128 || K == 256 || K == 512; }
     bool h_bf16() const { const char* e = getenv("DEX_H_BF16"); return x->lp() && !(e && e[0] == '0'); }
     bool fast_conv(int cin, int cout) const { return x->lp() && conv3x3_bf16_supported(cin, cout); }
     void conv3x3(const char* name, const TD& X, int H, int W, int mask_ws, bool inmask, const float* Wt, const float* bias, int Cout, float* out,
@@ -953,7 +957,7 @@ struct Runner {
         for (int k = 0; k < c.dit_depth; ++k) {
             const DitBlockW& w = x->blocks[k];
             const float* ada = P.ada[k];
-            const bool fuse_ln = x->lp();      // LayerNorm+modulate inside the GEMM's A staging
+            const bool fuse_ln = x->lp() && ln_fusable(hid);      // LayerNorm+modulate inside the GEMM's A staging (single-shot K: 64 / 128 / 256 / 512)
             DitChainP ch{};
             if (chain) {
                 ch.ksplit = 0; ch.heads = c.dit_heads; ch.rows_per_batch = N; ch.X = P.tok; ch.ada = ada; ch.step = sp; ch.M = B * N; ch.B = B;
@@ -1060,7 +1064,7 @@ struct Runner {
                 tap(nm, dst, (long)B * N, hid, hid);
             }
         }
-        const bool fuse_lnf = x->lp();
+        const bool fuse_lnf = x->lp() && ln_fusable(hid);
         const int s2c = c.dit_stride * c.dit_stride * mid;
         IGemmP fl = base_gemm(fuse_lnf ? P.tok : P.xn, hid, 0, P.Hf, P.Wt, hid, x->fl_w, s2c, x->fl_b, out, ldo, ocoff);
         if (fuse_lnf) { fl.ln_shift = P.fin_mod; fl.ln_scale = P.fin_mod + hid; fl.ln_step_stride = 2L * hid; }

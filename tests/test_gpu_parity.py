@@ -39,6 +39,30 @@ def gold(name):
                                          ("gedex_vctk", "gedex_vctk"), ("dex_vctk", "dex_vctk"),
                                          ("dex_libritts", "dex_libritts")])      # dim 128, hidden 384 = 2 x 192: the generic fp32 path
 def test_golden_precond_and_sampler(name, preset):
+    _golden_precond_and_sampler(name, preset)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_golden_libritts_reduced_precision(prec):
+    """DEX-LibriTTS against the real reference's golden in the reduced-precision modes."""
+    g = gold("dex_libritts")
+    cfg, eng, w = U.engine_for("dex_libritts")
+    mu, mask, z, eps = (torch.from_numpy(g[k]) for k in ("mu", "mask", "z", "eps"))
+    kw = U.engine_kwargs(g)
+    eng.set_precision(prec)
+    try:
+        for s in (80.0, 1.0, 0.002):
+            got = eng.denoise_once(mu + s * eps, s, mask, mu, **kw).cpu().numpy()
+            lowp_ok(f"golden_dex_libritts_sigma{s}", prec, "call", got, g[f"precond_sigma{s}"])
+        for key in [k for k in g if k.startswith("sampler_n")]:
+            got = eng.sample(z, mask, mu, int(key[len("sampler_n"):]), **kw).cpu().numpy()
+            lowp_ok(f"golden_dex_libritts_{key}", prec, "sampler", got, g[key])
+            assert np.array_equal(got, eng.sample(z, mask, mu, int(key[len("sampler_n"):]), **kw).cpu().numpy())      # repeatable
+    finally:
+        eng.set_precision("fp32")
+
+
+def _golden_precond_and_sampler(name, preset):
     g = gold(name)
     cfg, eng, w = U.engine_for(preset)
     mu, mask, z, eps = (torch.from_numpy(g[k]) for k in ("mu", "mask", "z", "eps"))
@@ -285,6 +309,7 @@ def test_mel_frontend_golden():
     ("gedex_lj", dict(B=2, T=64, lengths=[64, 44])),
     ("gedex_lj", dict(B=1, T=100)),
     ("dex_vctk", dict(B=1, T=64, lengths=[57], Tr=40, Ts=40, sty_lengths=[33])),
+    ("dex_libritts", dict(B=2, T=68, lengths=[68, 41], Tr=37, Ts=50, sty_lengths=[50, 13])),     # dim 128, hidden 384 = 2 x 192: per-operation reduced precision
 ])
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 def test_bf16_mfma_mode_tolerance(name, kw, prec):
