@@ -522,7 +522,10 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
 // measured in round 3: 124 vs 106 us at B=32, N=1300 and 64.5 vs 62.1 us at N=650 (profiles/round3_rowchain_128row_form_negative.txt).
 // Per 128-row workgroup 57 us against 18 us of MFMA: the LayerNorm / GELU / staging / qkv-layout phases between the GEMMs are
 // what a workgroup spends its time in, all eight waves are in the same phase at the same time, and halving the weight traffic
-// per row does not touch them.  Dropped.)
+// per row does not touch them.  Dropped.  The follow-up — the same 64 rows on FOUR waves with a 72 KB footprint, so that TWO
+// workgroups share a CU and one's MFMA chains run under the other's row-wise phases — was built too (244 VGPRs, no spills, parity
+// green) and measured +0.7 % end to end at DEX B=32 (48.7k vs 48.4k frames/s, profiles/round3_rowchain_four_wave_form.txt): phase
+// lock-step is not what bounds the launch either.  Dropped as well.)
 // ---- 64-row form (batch regime, attention as its own launch).  At batch size every workgroup of the kernel above streams the
 // block's 1.57 MB of weights for 32 token rows and the launch is bound by that L2 -> CU traffic (DEX B=32, N=1300: 1300 workgroups,
 // 97 us for 65 GFLOP).  Here a workgroup owns 64 rows: every weight tile a wave fetches feeds TWO 32-row MFMA tiles, so the weight
