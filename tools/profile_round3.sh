@@ -37,5 +37,21 @@ for w in $WL; do
     python $R/tools/pmc_mfma.py $w $sep $(find /tmp/pq_${w}_$sep -name "*counter_collection.csv" | head -1) $O/mfma_util.json > $O/${w}_mfma_util_sep$sep.txt 2>&1
   done
 done
+# diagnostic counter sets for the batch row chain / attention (dex_b32 only)
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_ANY SQ_INST_CYCLES_VMEM"; do
+  n=$(echo $set | cut -d' ' -f1)
+  rm -rf /tmp/pd_$n
+  rocprofv3 --pmc $set --output-format csv -d /tmp/pd_$n -o pmc -- python $R/bench.py --workload dex_b32 --precision bf16 --steps 1 --warmup 0 --graph off $B > /dev/null 2>&1
+  python - "$(find /tmp/pd_$n -name "*counter_collection.csv" | head -1)" >> $O/dex_b32_diag_counters.txt <<'PY'
+import collections, csv, sys
+agg = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r["Kernel_Name"].replace("dex::", "").split("(")[0][:60]
+    if not any(t in k for t in ("dit_rowchain", "attn_direct", "conv3x3_rw", "pos_conv")): continue
+    agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+for k, c in agg.items():
+    print(k, {a: round(b / 1e6, 2) for a, b in sorted(c.items())})
+PY
+done
 python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
 ls -la $O
