@@ -419,7 +419,8 @@ void launch_conv3x3_lp(const Conv3P& p, hipStream_t st) {
     // workgroups on the chip (per-tap weight traffic per workgroup halves, two workgroups fit per CU)
     const bool tail_ = p.pro_res != nullptr;     // (Conv3P::res2_* is served by the ping-pong strip kernel only: conv3x3_res2_form)
     const long tiles4 = (long)((p.W + 31) / 32) * ((p.H + 3) / 4) * p.B;
-    const bool small = tiles4 < 256;       // (at B=32 the 4-row tiles win despite one workgroup per CU: 189 vs 218 us)
+    static const long small_max = getenv("DEX_CONV_SMALL_MAX") ? atol(getenv("DEX_CONV_SMALL_MAX")) : 256;
+    const bool small = tiles4 < small_max;       // (at B=32 the 4-row tiles win despite one workgroup per CU: 189 vs 218 us)
     // the 128-channel-wide forms at 4-row tiles fill the LDS with ONE workgroup per CU; as eight waves (4 rows x 2 halves
     // of the output channels) that workgroup keeps two waves per SIMD busy instead of one: +8.6 % end to end at B=32
     // (DEX_CONV_W8=0 restores the four-wave form)
