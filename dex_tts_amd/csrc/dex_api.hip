@@ -970,6 +970,7 @@ struct Runner {
                     ch.xslab = P.xslab; ch.xflag = P.xflag; ch.epoch = (unsigned)(sp * (c.dit_depth + 1) + k + 1);
                     ch.xerr = reinterpret_cast<int*>(P.xflag + (P.xflag_bytes - sizeof(int)) / sizeof(unsigned));
                     x->last_xerr = ch.xerr;
+                    { const char* de = getenv("DEX_DEBUG_DROP_HANDOFF"); ch.xdrop = (de && de[0] == '1') ? 1 : 0; }
                 }
             }
             if (chain && k == 0) {                                   // first block: LN + modulate + qkv only
@@ -1240,6 +1241,7 @@ struct Runner {
         f.gamma = x->fin_g; f.beta = x->fin_be; f.mask = mask; f.mask_bstride = P.d.T; f.wfc = x->fconv_w; f.bfc = x->fconv_b;
         f.xcur = xcur; f.denoised = denoised; f.xnext = xnext; f.scal = P.scal; f.scal_stride = SCAL_STRIDE; f.step = sp; f.B = B;
         f.zero_ptr = reinterpret_cast<float*>(stats_other); f.zero_n = P.stats_bytes / (long)sizeof(float);
+        f.poison = P.xflag ? reinterpret_cast<const int*>(P.xflag + (P.xflag_bytes - sizeof(int)) / sizeof(unsigned)) : nullptr;
         f.mode = fin_mode; f.htab = fin_htab; f.dbuf = P.dbuf; f.xhat = P.xbuf;
         run("final_conv_euler", 14.0 * 80 * P.d.T * c.dim * B, 80.0 * P.d.T * ((hfb ? 2.0 : 4.0) * c.dim + 12.0) * B, [&] { launch_final(f, st); });
     }
@@ -1466,7 +1468,7 @@ int dex_sample(DexCtx* x, const DexSampleArgs* a, dex_stream_t stream) {
                                  (uint64_t)(uintptr_t)(a->S_churn > 0.f ? a->noise_dev : nullptr)};
     for (float v : {a->S_churn, a->S_min, a->S_max, a->S_noise}) { uint32_t u; memcpy(&u, &v, 4); key.push_back(u); }
     for (int j = 0; j < a->n_ref; ++j) key.push_back((uint64_t)(uintptr_t)a->ref_skips_dev[j]);
-    for (const char* e : {"DEX_CONV_STREAM", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN", "DEX_DIT_CLUSTER"}) {     // knobs read at enqueue time
+    for (const char* e : {"DEX_CONV_STREAM", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN", "DEX_DIT_CLUSTER", "DEX_DEBUG_DROP_HANDOFF"}) {     // knobs read at enqueue time
         const char* v = getenv(e);
         key.push_back(v ? (uint64_t)atoi(v) + 1 : 0);
     }

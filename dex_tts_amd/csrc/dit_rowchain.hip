@@ -732,7 +732,8 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain64_kernel(const DitCha
 // (= the launch's epoch, unique within the call; the flag words are zeroed by a memset node at the start of every call); consumers
 // poll with relaxed agent-scope loads from one lane per peer, then read the peers' slabs with sc1 loads.  Results do not depend on
 // placement or timing: every sum runs in a fixed member order.  A wait is bounded (~50 ms): on time-out the launch finishes with
-// garbage and sets *xerr instead of hanging the GPU.
+// garbage and sets *xerr instead of hanging the GPU; the call's final kernel then turns every output into NaN (FinalP::poison), so a
+// lost hand-off can never pass as a plausible mel.
 namespace {
 constexpr int CL_AH_LD = 128 + 8;     // attention-output / GELU tile row stride (bf16): 272 B
 constexpr int CL_RED_LD = 33;
@@ -1010,7 +1011,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const 
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every storing wave drains its write-through stores
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(flags + 0 * DIT_CLUSTER + member, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0 && !(p.xdrop && member == 3)) __hip_atomic_store(flags + 0 * DIT_CLUSTER + member, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 
 #ifdef DEX_TIMING
@@ -1116,7 +1117,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const 
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0) __hip_atomic_store(flags + 1 * DIT_CLUSTER + member, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0 && !(p.xdrop && member == 3)) __hip_atomic_store(flags + 1 * DIT_CLUSTER + member, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 
 #ifdef DEX_TIMING

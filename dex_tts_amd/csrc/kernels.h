@@ -170,6 +170,7 @@ struct FinalP {
     // mode 2: corrector - xcur is x', xhat the state the step started from: xnext = xhat + h (0.5 d_cur + 0.5 d').
     int mode; const float* htab; float* dbuf; const float* xhat;
     int x_bf16;                                           // X (the final conv's raw output) is bf16 (1) / fp16 (2)
+    const int* poison;                                    // optional device word: non-zero (a workgroup hand-off of this call timed out) -> the outputs are NaN
 };
 void launch_final(const FinalP& p, hipStream_t st);
 // "Increase noise temporarily" tables (edm.py:194-196, schedule 'linear', scaling 'none'): for the schedule t_0..t_N
@@ -254,7 +255,8 @@ struct DitChainP { const float* O; int ksplit; long o_sstride; const float* ml; 
                    int step; int M; int B; long long* dbg;     // M = B * rows_per_batch
                    // cluster form (small grids, dit_rowchain_cluster_kernel): exchange slabs, flags (zeroed once per call) and the
                    // launch's epoch (unique within the call, never 0); err: device word set when a hand-off wait timed out
-                   float* xslab; unsigned* xflag; unsigned epoch; int* xerr; };
+                   float* xslab; unsigned* xflag; unsigned epoch; int* xerr;
+                   int xdrop; };                            // tests only (DEX_DEBUG_DROP_HANDOFF=1): member 3 never raises its flags -> the peers' waits time out
 // cluster form of the row chain: workgroups per 32-row tile, bytes of exchange slab / flag words per tile, and whether a launch
 // of B x N rows takes it (all workgroups co-resident: <= one per CU)
 constexpr int DIT_CLUSTER = 4;

@@ -502,6 +502,9 @@ __global__ __launch_bounds__(256) void final_kernel(const FinalP p) {
         }
     }
     const float bfc = p.bfc[0];
+    // a lost workgroup hand-off earlier in this call (cluster form of the DiT block: bounded wait, dit_rowchain.hip) must not pass
+    // as a plausible mel: every output of the call becomes NaN
+    const bool poisoned = p.poison && *p.poison;
     const float inv = 1.f / sigma;
     const float h = p.htab ? p.htab[step] : sigma_next - sigma;
     const long stride = (long)gridDim.x * 32 * FIN_U;
@@ -558,7 +561,7 @@ __global__ __launch_bounds__(256) void final_kernel(const FinalP p) {
                 // 199-214: every product and sum is its own torch op; no fused multiply-add).  It matters: the Heun corrector
                 // evaluates the network at sigma' = 0.002 with a step h of the previous noise level, so one ulp of D' enters
                 // x_next multiplied by h / (2 sigma') ~ 1e2 (measured before: 3e-4 against the oracle at n = 4, now ~1e-5).
-                const float D = __fadd_rn(__fmul_rn(c_skip, xc[u]), __fmul_rn(c_out, f));
+                const float D = poisoned ? __builtin_nanf("") : __fadd_rn(__fmul_rn(c_skip, xc[u]), __fmul_rn(c_out, f));
                 if (p.denoised) p.denoised[o] = D;
                 if (p.xnext) {
                     const float d = __fsub_rn(__fmul_rn(inv, xc[u]), __fmul_rn(inv, D));

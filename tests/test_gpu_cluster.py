@@ -71,3 +71,24 @@ def test_cluster_form_under_concurrent_load():
         assert eng.handoff_timeouts() == 0
     finally:
         eng.set_precision("fp32")
+
+
+def test_lost_handoff_is_loud():
+    """A hand-off that never arrives (DEX_DEBUG_DROP_HANDOFF=1: member 3 of every cluster keeps its flags down) must neither hang
+    the GPU nor pass as a mel: the bounded waits time out, the device word is set, and every output of the call is NaN."""
+    cfg, eng, w = U.engine_for("gedex_lj")
+    case = U.make_case(cfg, B=1, T=64)
+    eng.set_precision("bf16")
+    try:
+        good = _run(eng, case, 2)
+        assert np.isfinite(good).all() and eng.handoff_timeouts() == 0
+        os.environ["DEX_DEBUG_DROP_HANDOFF"] = "1"
+        try:
+            bad = _run(eng, case, 2)
+            assert eng.handoff_timeouts() == 1
+        finally:
+            del os.environ["DEX_DEBUG_DROP_HANDOFF"]
+        assert np.isnan(bad).all()
+        assert np.array_equal(good, _run(eng, case, 2)) and eng.handoff_timeouts() == 0      # the next call is clean again
+    finally:
+        eng.set_precision("fp32")
