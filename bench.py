@@ -39,6 +39,8 @@ WORKLOADS = {
     # name: (preset, B per GPU, T, n_timesteps, Tr/Ts, precision or None = --precision)
     "gedex_b1": ("gedex_lj", 1, 512, 50, 0, None),               # BASELINE.json configs[1]
     "gedex_b1_t800": ("gedex_lj", 1, 800, 50, 0, None),
+    "gedex_b2": ("gedex_lj", 2, 512, 50, 0, None),               # small batches: the cluster form of the DiT block covers B x 21 <= 64 row tiles
+    "gedex_b3": ("gedex_lj", 3, 512, 50, 0, None),
     "gedex_b32": ("gedex_lj", 32, 512, 50, 0, None),
     "dex_b1": ("dex_vctk", 1, 512, 50, 348, None),
     "dex_b32": ("dex_vctk", 32, 256, 50, 348, None),             # configs[2]
