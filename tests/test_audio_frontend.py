@@ -83,3 +83,15 @@ def test_gpu_batched_mel_spectrogram():
         st.mel_spectrogram(torch.from_numpy(y * 3.0))
     with pytest.raises(ValueError):
         TacotronSTFT(2048, 256, 1024, 80, 22050, 0, 8000)
+
+
+def test_front_end_argument_errors_need_no_gpu():
+    """Configuration errors are raised before anything touches the device; the product path has no CPU fallback."""
+    from dex_tts_amd.audio import TacotronSTFT, lf0_from_f0
+    with pytest.raises(ValueError):
+        TacotronSTFT(2048, 256, 1024, 80, 22050, 0, 8000)
+    with pytest.raises(RuntimeError):
+        lf0_from_f0(torch.zeros(8))                      # CPU tensor: refused, not emulated
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception):
+            TacotronSTFT(1024, 256, 1024, 80, 22050, 0, 8000, device="cpu")

@@ -121,6 +121,40 @@ def test_vocode_reduced_precision_modes(prec):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("B,T", [(1, 1), (2, 37)])
+def test_vocode_reduced_precision_edge_lengths(prec, B, T):
+    """One-frame and odd-length inputs through the reduced-precision convolutions (row tiles mostly padding)."""
+    gen = _gpu_gen()
+    gen.precision = prec
+    mel = np.clip(synth.normalish("voc_mel_t", (B, 80, T), 7 + T) * 1.5 - 5.0, -11.5, 2.5).astype(np.float32)
+    got = gen(torch.from_numpy(mel).cuda()).cpu().numpy()
+    with torch.no_grad():
+        ref = VO.generator({k: torch.from_numpy(v) for k, v in weights().items()}, V.HIFIGAN_V1, torch.from_numpy(mel)).numpy()
+    e = got - ref
+    mx, rms = VOC_LOWP[prec]
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    assert np.abs(e).max() <= mx and np.sqrt((e * e).mean()) <= rms, (float(np.abs(e).max()), float(np.sqrt((e * e).mean())))
+
+
+@pytest.mark.gpu
+def test_bigvgan_reduced_precision_mode():
+    """BigVGAN with bf16 convolution operands (its anti-aliased activations stay fp32 kernels) against the reference golden."""
+    from tests import gpu_util as U
+    g = dict(np.load(os.path.join(GOLD, "bigvgan.npz")))
+    gen = V.Generator(V.AttrDict(V.BIGVGAN_BASE))
+    gen.load_state_dict({k: torch.from_numpy(v) for k, v in bvg_weights().items()})
+    gen = gen.cuda().eval()
+    exact = gen(torch.from_numpy(g["mel"]).cuda()).cpu().numpy()
+    gen.precision = "bf16"
+    wav = gen(torch.from_numpy(g["mel"]).cuda()).cpu().numpy()
+    e = wav - g["wav"]
+    U.record("bigvgan_golden:bf16:call", max=np.abs(e).max(), mean=np.sqrt((e * e).mean()), ref_absmax=np.abs(g["wav"]).max())
+    assert np.isfinite(wav).all() and not np.array_equal(wav, exact)
+    assert np.abs(e).max() <= 1.4e-2 and np.sqrt((e * e).mean()) <= 3.2e-3          # measured 6.8e-3 / 1.6e-3
+
+
+@pytest.mark.gpu
 def test_vocode_weight_norm_checkpoint():
     """A training-style checkpoint (weight_g / weight_v pairs) loads like the reference's generator_*.pth.tar."""
     w = weights()
