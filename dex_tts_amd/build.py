@@ -25,7 +25,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
 # the MFMA-heavy kernel files of the reduced-precision modes are compiled twice: operands bf16 (namespace dex::bf16) and,
 # with -DDEX_LP_F16, fp16 (namespace dex::f16) — csrc/lp_config.h
 LP_SOURCES = ("conv3x3_bf16.hip", "conv3x3_stream.hip", "igemm_bf16.hip", "attention_bf16.hip", "attention_direct.hip",
-              "dit_rowchain.hip", "linattn_fused.hip", "pos_conv.hip", "convt_up.hip", "conv3x3_regw.hip", "conv_down.hip")
+              "dit_rowchain.hip", "linattn_fused.hip", "pos_conv.hip", "convt_up.hip", "conv3x3_regw.hip", "conv_down.hip", "patch_embed.hip")
 
 
 # per-file flags.  -fno-slp-vectorize: the SLP vectorizer turns adjacent fp32 multiplies / adds into v_pk_*_f32, and a packed fp32

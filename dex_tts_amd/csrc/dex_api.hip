@@ -922,9 +922,17 @@ struct Runner {
         dw.k = c.dit_patch; dw.s = c.dit_stride; dw.pad = c.dit_patch / 2; dw.Wd = x->pe_dw; dw.bd = x->pe_db;
         dw.mask = mask_input ? mask : nullptr; dw.mask_ws = mask_ws; dw.mask_bstride = P.d.T;
         dw.Y = P.pe0; dw.Hf = P.Hf; dw.Wt = P.Wt; dw.B = B;
-        run("patch_dwconv_silu", 2.0 * B * N * mid * c.dit_patch * c.dit_patch, 4.0 * B * (P.Hm * P.Wm + N) * mid, [&] { launch_dwconv_silu(dw, st); });
-        IGemmP pe = base_gemm(P.pe0, mid, 0, P.Hf, P.Wt, mid, x->pe_pw, hid, x->pe_pb, P.emb, hid, 0);
-        gemm("patch_pointwise", pe);
+        const char* pf_env = getenv("DEX_PATCH_FUSED");
+        auto pw_lp = x->lp_of().find(x->pe_pw);
+        if (x->lp() && !debug && !(pf_env && pf_env[0] == '0') && pw_lp != x->lp_of().end() && patch_embed_fused_supported(c.dit_patch, mid, hid, (long)B * N)) {
+            // small grids: depthwise conv + SiLU + pointwise GEMM in ONE launch (bit-identical to the two-kernel form below)
+            run("patch_embed", 2.0 * B * N * mid * (c.dit_patch * c.dit_patch + hid), 4.0 * B * (P.Hm * P.Wm * mid + N * hid),
+                [&] { launch_patch_embed_fused(dw, pw_lp->second, x->pe_pb, P.emb, hid, x->precision, st); });
+        } else {
+            run("patch_dwconv_silu", 2.0 * B * N * mid * c.dit_patch * c.dit_patch, 4.0 * B * (P.Hm * P.Wm + N) * mid, [&] { launch_dwconv_silu(dw, st); });
+            IGemmP pe = base_gemm(P.pe0, mid, 0, P.Hf, P.Wt, mid, x->pe_pw, hid, x->pe_pb, P.emb, hid, 0);
+            gemm("patch_pointwise", pe);
+        }
         // grouped 16x16 pos-conv, split-K partials (bias added in the tail)
         const int G = c.dit_conv_pos_groups, kp = c.dit_conv_pos, cg = hid / G;
         int nsplit = POS_SPLIT, pcg = 0, pcgp = 0;
@@ -1468,7 +1476,7 @@ int dex_sample(DexCtx* x, const DexSampleArgs* a, dex_stream_t stream) {
                                  (uint64_t)(uintptr_t)(a->S_churn > 0.f ? a->noise_dev : nullptr)};
     for (float v : {a->S_churn, a->S_min, a->S_max, a->S_noise}) { uint32_t u; memcpy(&u, &v, 4); key.push_back(u); }
     for (int j = 0; j < a->n_ref; ++j) key.push_back((uint64_t)(uintptr_t)a->ref_skips_dev[j]);
-    for (const char* e : {"DEX_CONV_STREAM", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN", "DEX_DIT_CLUSTER", "DEX_DEBUG_DROP_HANDOFF"}) {     // knobs read at enqueue time
+    for (const char* e : {"DEX_CONV_STREAM", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN", "DEX_DIT_CLUSTER", "DEX_DEBUG_DROP_HANDOFF", "DEX_PATCH_FUSED"}) {     // knobs read at enqueue time
         const char* v = getenv(e);
         key.push_back(v ? (uint64_t)atoi(v) + 1 : 0);
     }

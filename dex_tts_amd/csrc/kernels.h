@@ -220,6 +220,10 @@ struct DwConvP { const float* X; int ldx; long xb; int Hi, Wi, C; int k, s, pad;
                  const float* mask; int mask_ws; long mask_bstride;
                  float* Y; int Hf, Wt; int B; };
 void launch_dwconv_silu(const DwConvP& p, hipStream_t st);
+// the depthwise conv + SiLU + pointwise GEMM of PatchEmbed2D as ONE launch (reduced-precision modes, small grids: patch_embed.hip);
+// Wb = the pointwise weight's 16-bit [hidden][C] twin
+bool patch_embed_fused_supported(int k, int C, int hid, long ntok);
+void launch_patch_embed_fused(const DwConvP& p, const void* Wb, const float* bias, float* emb, int hid, int precision, hipStream_t st);
 
 // pos-conv tail: sum split-K partials + bias -> GELU -> mean over freq -> tokens = emb + pos + freq_pos (dit.py:450-454)
 // Direct grouped 16x16 positional convolution (pos_conv.hip): X = patch embedding [B][Hf][Wt][hid] fp32, Wf = bf16

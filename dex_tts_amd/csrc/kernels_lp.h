@@ -43,6 +43,9 @@ void launch_pack_lp_frag_nk(const float* src, void* dst, int K, int N, hipStream
 void launch_linattn_kvctx(const LinKvCtxP& p, hipStream_t st);
 void launch_linattn_merge(const LinMergeP& p, hipStream_t st);
 void launch_linattn_out2(const LinOut2P& p, hipStream_t st);
+// PatchEmbed2D as one launch at small grids (patch_embed.hip)
+bool patch_embed_fused_supported(int k, int C, int hid, long ntok);
+void launch_patch_embed_fused(const DwConvP& p, const void* Wb, const float* bias, float* emb, int hid, hipStream_t st);
 // direct grouped positional convolution (pos_conv.hip)
 bool pos_conv_direct_supported(int hid, int groups, int kernel, int Hf);
 void launch_pos_conv_direct(const PosConvP& p, hipStream_t st);

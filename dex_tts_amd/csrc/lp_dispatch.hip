@@ -25,6 +25,7 @@ bool attention_direct_batch_regime(int N, int B) { return bf16::attention_direct
 int attention_direct_ksplit(int N, int B) { return bf16::attention_direct_ksplit(N, B); }
 bool conv_down_supported(int C, int H, int W, int ldx, int ldy, int x_coff) { return bf16::conv_down_supported(C, H, W, ldx, ldy, x_coff); }
 bool convt_up_supported(int C, int H, int W, int ldx, int ldy) { return bf16::convt_up_supported(C, H, W, ldx, ldy); }
+bool patch_embed_fused_supported(int k, int C, int hid, long ntok) { return bf16::patch_embed_fused_supported(k, C, hid, ntok); }
 bool dit_rowchain_supported(int hidden, int mlp_hidden) { return bf16::dit_rowchain_supported(hidden, mlp_hidden); }
 bool dit_rowchain_cluster_form(int rows_per_batch, int B) { return bf16::dit_rowchain_cluster_form(rows_per_batch, B); }
 
@@ -43,5 +44,6 @@ void launch_linattn_kvctx(const LinKvCtxP& p, int precision, hipStream_t st) { D
 void launch_linattn_merge(const LinMergeP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_linattn_merge, p, st); }
 void launch_linattn_out2(const LinOut2P& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_linattn_out2, p, st); }
 void launch_pos_conv_direct(const PosConvP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_pos_conv_direct, p, st); }
+void launch_patch_embed_fused(const DwConvP& p, const void* Wb, const float* bias, float* emb, int hid, int precision, hipStream_t st) { DEX_LP_CALL(launch_patch_embed_fused, p, Wb, bias, emb, hid, st); }
 
 }  // namespace dex

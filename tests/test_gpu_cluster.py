@@ -92,3 +92,26 @@ def test_lost_handoff_is_loud():
         assert np.array_equal(good, _run(eng, case, 2)) and eng.handoff_timeouts() == 0      # the next call is clean again
     finally:
         eng.set_precision("fp32")
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("gedex_lj", dict(B=1, T=512)),                                        # 7 x 7 / stride 4 patches
+    ("gedex_lj", dict(B=2, T=100, lengths=[100, 61])),                     # width not a multiple of the patch: right zero padding
+    ("dex_vctk", dict(B=1, T=64, lengths=[57], Tr=40, Ts=40, sty_lengths=[33])),      # 3 x 3 / stride 2 patches
+])
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_fused_patch_embed_is_bit_identical(name, kw, prec):
+    """PatchEmbed2D as one launch at small grids (patch_embed.hip) against the two-kernel form (DEX_PATCH_FUSED=0): same bits."""
+    cfg, eng, w = U.engine_for(name)
+    case = U.make_case(cfg, **kw)
+    eng.set_precision(prec)
+    try:
+        a = _run(eng, case, 3)
+        os.environ["DEX_PATCH_FUSED"] = "0"
+        try:
+            b = _run(eng, case, 3)
+        finally:
+            del os.environ["DEX_PATCH_FUSED"]
+        assert np.isfinite(a).all() and np.array_equal(a, b), float(np.abs(a - b).max())
+    finally:
+        eng.set_precision("fp32")
