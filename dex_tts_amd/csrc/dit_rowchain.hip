@@ -798,6 +798,8 @@ __device__ __forceinline__ void cluster_wait(const unsigned* flags, int member, 
 }
 }  // namespace
 
+// QKV_ONLY: the first block's launch (LN + modulate + qkv of the incoming rows, no hand-off) as its own symbol
+template <bool QKV_ONLY>
 __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const DitChainP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_rc[];
     // chain buffers (they overlay the attention scratch, which is dead once the partials are merged)
@@ -834,7 +836,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const 
         const float* src = which == 0 ? ada + 3 * RC_H : which == 1 ? ada + 4 * RC_H
                          : which == 2 ? (has_q ? p.next_shift + (long)step * p.next_step_stride : ada)
                          : which == 3 ? (has_q ? p.next_scale + (long)step * p.next_step_stride : ada)
-                         : which == 4 ? ada + 2 * RC_H : which == 5 ? (p.qkv_only ? ada : p.bp) : which == 6 ? ada + 5 * RC_H : (p.qkv_only ? ada : p.b2);
+                         : which == 4 ? ada + 2 * RC_H : which == 5 ? (QKV_ONLY ? ada : p.bp) : which == 6 ? ada + 5 * RC_H : (QKV_ONLY ? ada : p.b2);
         prm = *reinterpret_cast<const float4*>(src + c4);
     }
     float4 xr[4];                                                        // residual rows x of this thread's 16 columns
@@ -843,7 +845,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const 
 
     uint4 w8[8];
     f32x16 acc;
-    if (!p.qkv_only) {
+    if constexpr (!QKV_ONLY) {
         const int head = member >> 1, half = member & 1;
         // ---- attention of (head, key half): the 8 waves split the half's key tiles (attention_direct.hip's wave body)
         f32x16 ao[4];
@@ -1202,12 +1204,16 @@ void launch_dit_rowchain(const DitChainP& p, hipStream_t st) {
     if (p.xslab && (p.attn_inline || p.qkv_only) && dit_rowchain_cluster_form(p.rows_per_batch, p.B)) {
         static bool attrc = false;
         if (!attrc) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&dit_rowchain_cluster_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC_LDS_CLUSTER);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&dit_rowchain_cluster_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC_LDS_CLUSTER);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&dit_rowchain_cluster_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC_LDS_CLUSTER);
             attrc = true;
         }
-        if (!p.qkv_only) g_last_symbol = "dit_rowchain_cluster_kernel";
-        hipLaunchKernelGGL(dit_rowchain_cluster_kernel, dim3(p.B * ((p.rows_per_batch + RC_ROWS - 1) / RC_ROWS) * DIT_CLUSTER), dim3(RC_NW * 64),
-                           RC_LDS_CLUSTER, st, p);
+        const dim3 gridc(p.B * ((p.rows_per_batch + RC_ROWS - 1) / RC_ROWS) * DIT_CLUSTER);
+        if (p.qkv_only) hipLaunchKernelGGL(dit_rowchain_cluster_kernel<true>, gridc, dim3(RC_NW * 64), RC_LDS_CLUSTER, st, p);
+        else {
+            g_last_symbol = "dit_rowchain_cluster_kernel<false>";
+            hipLaunchKernelGGL(dit_rowchain_cluster_kernel<false>, gridc, dim3(RC_NW * 64), RC_LDS_CLUSTER, st, p);
+        }
         return;
     }
     static bool attr = false;
