@@ -134,6 +134,7 @@ SYMBOLS = [
     ("dex_text_encode", C.c_int, [C.c_void_p, C.POINTER(DexTextArgs), C.c_void_p]),
     ("dex_text_align", C.c_int, [C.c_void_p, C.POINTER(DexAlignArgs), C.c_void_p]),
     ("dex_debug_handoff_timeouts", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("dex_debug_xcd_local", C.c_int, []),
     ("dex_mel_frames", C.c_int, [C.c_int]),
     ("dex_mel_from_wav", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("dex_mel_create", C.c_int, [C.POINTER(C.c_void_p)]),

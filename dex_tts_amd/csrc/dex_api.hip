@@ -38,9 +38,11 @@ struct Arena {                                             // bump allocator ove
     void* take(size_t bytes) {
         off = (off + 255) & ~size_t(255);
         void* p = dry ? nullptr : (void*)(base + off);
+        if (!dry && trace) fprintf(stderr, "plan[%d] off %zu bytes %zu\n", trace++, off, bytes);     // DEX_DEBUG_PLAN=1: allocation order = make_plan's source order
         off += bytes;
         return p;
     }
+    int trace = 0;
     float* f(size_t n) { return (float*)take(n * sizeof(float)); }
 };
 
@@ -582,15 +584,66 @@ struct Plan {
     int Hm, Wm, Hf, Wt, N;
     float *pe0, *emb, *emb_pad, *pos_part, *tok, *xn, *qkv, *ao, *att_ml, *hmlp, *dbg_tok;
     float* xslab; unsigned* xflag; size_t xflag_bytes;      // cluster form of the DiT row chain (small grids): exchange slabs + flag words
+    int xlocal;                                             // ... with the members of a cluster on one XCD (xcd_map_ok())
     void *qh, *kh, *vt, *qh2, *kh2, *vt2; int Npad; size_t vt_bytes;   // bf16 attention operands of the row-chain path (two sets:
                                                                         // a fused block reads one while its workgroups write the other)
     float *tv_keys, *tv_K, *tv_V, *tv_q, *tv_ao, *tv_out, *tiv_out, *tv_weff, *tv_beff; gnfix_t *tv_stats, *tiv_stats; void* tv_wbf;
     size_t bytes;
 };
 
+// Zero-fill as a KERNEL node.  hipMemsetAsync inside a captured call becomes a memset node, and replays of such a graph were
+// measured to go wrong after unrelated eager work on the legacy null stream (rocm 7.2: the first Euler step then sees late
+// zeroes - flags, statistics, key padding); a kernel node is ordered like every other kernel of the chain.
+__global__ __launch_bounds__(256) void zero_fill_kernel(uint4* p16, size_t n16, unsigned char* tail, int ntail) {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p16[i] = z;
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+static void zero_fill(void* p, size_t bytes, hipStream_t st) {
+    if (!p || !bytes) return;
+    const size_t n16 = bytes / 16;
+    size_t blocks = (n16 + 255) / 256; if (blocks > 1024) blocks = 1024; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, st, reinterpret_cast<uint4*>(p), n16,
+                       reinterpret_cast<unsigned char*>(p) + n16 * 16, (int)(bytes - n16 * 16));
+}
+
+// Does workgroup b of a launch run on XCD b % 8?  The XCD-local cluster form of the DiT row chain (dit_rowchain.hip) places the
+// four members of a cluster by that rule so that their hand-offs stay inside one L2.  Probed once per process with launches of
+// the same shape (256 workgroups x 512 threads, 64 KB of LDS) that record HW_REG_XCC_ID; run from the public entry points
+// BEFORE any stream capture (it allocates).  The kernel re-checks every hand-off (flag words carry the writer's XCC id).
+static int g_xcd_map = -1;          // -1 not probed, 0 no, 1 yes
+__global__ __launch_bounds__(512) void xcc_probe_kernel(unsigned* out) {
+    extern __shared__ unsigned char probe_lds[];
+    if (threadIdx.x == 0) {
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        probe_lds[0] = (unsigned char)x;
+        out[blockIdx.x] = x & 15u;
+    }
+}
+static void xcd_map_probe() {
+    if (g_xcd_map >= 0) return;
+    g_xcd_map = 0;
+    { const char* e = getenv("DEX_DIT_CLUSTER_LOCAL"); if (e && atoi(e) == 0) return; }
+    unsigned* d = nullptr;
+    if (hipMalloc(&d, 256 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return; }
+    bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcc_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536) == hipSuccess;
+    unsigned h[256];
+    for (int rep = 0; rep < 3 && ok; ++rep) {
+        const int nb = rep == 0 ? 256 : rep == 1 ? 96 : 192;
+        hipLaunchKernelGGL(xcc_probe_kernel, dim3(nb), dim3(512), 65536, 0, d);
+        ok = hipMemcpy(h, d, nb * sizeof(unsigned), hipMemcpyDeviceToHost) == hipSuccess;
+        for (int b = 8; b < nb && ok; ++b) ok = h[b] == h[b & 7];
+    }
+    hipFree(d);
+    g_xcd_map = ok ? 1 : 0;
+}
+extern "C" int dex_debug_xcd_local() { xcd_map_probe(); return g_xcd_map; }
+
 void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
     const DexConfig& c = x->cfg;
     Arena A; A.base = (char*)ws; A.dry = (ws == nullptr);
+    { static const bool tr = getenv("DEX_DEBUG_PLAN") != nullptr; A.trace = tr ? 1 : 0; }
     P.d = d;
     const int n = d.n_steps, dim = c.dim, hid = c.dit_hidden, mid = mid_dim(c), B = d.B;
     P.sig2 = A.f(64);
@@ -665,12 +718,13 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
     P.qh = A.take(P.vt_bytes); P.kh = A.take(P.vt_bytes); P.vt = A.take(P.vt_bytes);    // all three padded to Npad rows
     P.qh2 = A.take(P.vt_bytes); P.kh2 = A.take(P.vt_bytes); P.vt2 = A.take(P.vt_bytes);
     P.hmlp = A.f(tok * mlp_hidden(c));
-    P.xslab = nullptr; P.xflag = nullptr; P.xflag_bytes = 0;
+    P.xslab = nullptr; P.xflag = nullptr; P.xflag_bytes = 0; P.xlocal = 0;
     if (dit_rowchain_supported(hid, mlp_hidden(c)) && dit_rowchain_cluster_form(P.N, B)) {
-        const size_t tiles = (size_t)B * ((P.N + 31) / 32);
+        const size_t tiles = ((size_t)B * ((P.N + 31) / 32) + 7) / 8 * 8;                      // (whole rounds of 8 clusters: the XCD-local grid)
         P.xslab = A.f(tiles * DIT_CLUSTER_SLAB_FLOATS);
         P.xflag_bytes = tiles * DIT_CLUSTER_FLAG_WORDS * sizeof(unsigned) + sizeof(int);      // + the time-out word
         P.xflag = (unsigned*)A.take(P.xflag_bytes);
+        P.xlocal = (dit_rowchain_cluster_local_fits(P.N, B) && g_xcd_map == 1) ? 1 : 0;
     }
     P.dbg_tok = A.f(tok * hid * (c.dit_depth + 1));
     P.tv_keys = P.tv_K = P.tv_V = P.tv_q = P.tv_ao = P.tv_out = P.tiv_out = P.tv_weff = P.tv_beff = nullptr; P.tv_wbf = nullptr;
@@ -978,7 +1032,8 @@ struct Runner {
                     ch.xslab = P.xslab; ch.xflag = P.xflag; ch.epoch = (unsigned)(sp * (c.dit_depth + 1) + k + 1);
                     ch.xerr = reinterpret_cast<int*>(P.xflag + (P.xflag_bytes - sizeof(int)) / sizeof(unsigned));
                     x->last_xerr = ch.xerr;
-                    { const char* de = getenv("DEX_DEBUG_DROP_HANDOFF"); ch.xdrop = (de && de[0] == '1') ? 1 : 0; }
+                    { const char* de = getenv("DEX_DEBUG_DROP_HANDOFF"); ch.xdrop = de ? atoi(de) : 0; }
+                    ch.xlocal = (P.xlocal && ch.epoch < (1u << 24)) ? 1 : 0;
                 }
             }
             if (chain && k == 0) {                                   // first block: LN + modulate + qkv only
@@ -1129,7 +1184,7 @@ struct Runner {
         const DexConfig& c = x->cfg;
         const int B = P.d.B, ns = c.n_stages;
         gn_idx = 0;
-        if (!stats_other) hipMemsetAsync(stats_base, 0, P.stats_bytes, st);   // single call (dex_denoise_once): clear in place
+        if (!stats_other) zero_fill(stats_base, P.stats_bytes, st);   // single call (dex_denoise_once): clear in place
         TD cur{nullptr, 0, 0, 0};
         // Activations whose EVERY consumer rounds them to the MFMA operand type while staging (x * mask with a 0 / 1 mask) are
         // stored in that type: bit-identical results, half the bytes.  That is the down path's attention output into the
@@ -1263,10 +1318,10 @@ struct Runner {
             SmallLinP s{X, ldx, rows, K, R(w + ".weight"), bias ? R(w + ".bias") : nullptr, N, Y, N, ai, ao};
             run("cond_mlp", 2.0 * rows * K * N, 4.0 * K * N, [&] { launch_small_linear(s, st); });
         };
-        if (P.tv_stats) hipMemsetAsync(P.tv_stats, 0, (size_t)B * mid_dim(c) * IN_SLOTS * 2 * 2 * sizeof(gnfix_t), st);
-        if (P.xflag) hipMemsetAsync(P.xflag, 0, P.xflag_bytes, st);     // hand-off flags of the cluster row chain: zero before every call (epochs count within it)
-        hipMemsetAsync(P.vt, 0, P.vt_bytes, st);      // key padding of the transposed V operand (attention_direct.hip)
-        hipMemsetAsync(P.vt2, 0, P.vt_bytes, st);
+        if (P.tv_stats) zero_fill(P.tv_stats, (size_t)B * mid_dim(c) * IN_SLOTS * 2 * 2 * sizeof(gnfix_t), st);
+        if (P.xflag) zero_fill(P.xflag, P.xflag_bytes, st);     // hand-off flags of the cluster row chain: zero before every call (epochs count within it)
+        zero_fill(P.vt, P.vt_bytes, st);      // key padding of the transposed V operand (attention_direct.hip)
+        zero_fill(P.vt2, P.vt_bytes, st);
         CondPrepP cp{sigmas_dev, n, c.pe_scale, dim, P.scal, SCAL_STRIDE, P.t_unet, P.t_dit};
         run("cond_prep", 0, 0, [&] { launch_cond_prep(cp, st); });
         lin(P.t_unet, dim, n, dim, "mlp.0", true, 4 * dim, P.tmp_u, 0, 1);
@@ -1351,7 +1406,7 @@ int enqueue_heun(DexCtx* x, const DexSampleArgs* a, hipStream_t st) {
     // x_0 = z * t_0 (edm.py:188-189; t_0, not t_hat_0)
     R.run("init_scale", 0, 8.0 * nx, [&] { launch_scale_copy(a->z_dev, P.xbuf, nx, a->sigmas_dev, st); });
     gnfix_t* arena[2] = {P.stats, P.stats + P.stats_bytes / (long)sizeof(gnfix_t)};
-    hipMemsetAsync(P.stats, 0, 2 * P.stats_bytes, st);
+    zero_fill(P.stats, 2 * P.stats_bytes, st);
     R.fin_htab = P.htab;
     for (int e = 0; e < E; ++e) {
         const bool corrector = (e & 1) != 0, last = (e == E - 1);
@@ -1385,7 +1440,7 @@ int enqueue_euler(DexCtx* x, const DexSampleArgs* a, hipStream_t st) {
     // x_0 = z * t_0 (edm.py:188-189)
     R.run("init_scale", 0, 8.0 * nx, [&] { launch_scale_copy(a->z_dev, P.xbuf, nx, a->sigmas_dev, st); });
     gnfix_t* arena[2] = {P.stats, P.stats + P.stats_bytes / (long)sizeof(gnfix_t)};
-    hipMemsetAsync(P.stats, 0, 2 * P.stats_bytes, st);
+    zero_fill(P.stats, 2 * P.stats_bytes, st);
     for (int i = 0; i < a->n_steps; ++i) {
         R.sp = i; R.stats_base = arena[i & 1]; R.stats_other = arena[(i + 1) & 1];
         if (churn)          // x_hat = x_cur + sqrt(t_hat^2 - t_cur^2) S_noise randn_like(x_cur), in place (edm.py:196)
@@ -1427,6 +1482,7 @@ int dex_denoise_once(DexCtx* x, const DexDenoiseArgs* da, dex_stream_t stream) {
     int rc = validate(x, a, false);
     if (rc) return rc;
     if (!da->x_dev) return x->fail(DEX_ERR_ARG, "x_dev is null");
+    xcd_map_probe();
     hipStream_t st = (hipStream_t)stream;
     Plan P; Dims d{a->B, a->T, a->Tr, a->Ts, 1};
     make_plan(x, d, nullptr, P);
@@ -1446,6 +1502,7 @@ int dex_sample(DexCtx* x, const DexSampleArgs* a, dex_stream_t stream) {
     int rc = validate(x, a, true);
     if (rc) return rc;
     if (a->solver != DEX_SOLVER_EULER && a->solver != DEX_SOLVER_HEUN) return x->fail(DEX_ERR_ARG, "solver must be DEX_SOLVER_EULER or DEX_SOLVER_HEUN (edm.py:107)");
+    xcd_map_probe();                    // (once per process, before any capture)
     hipStream_t st = (hipStream_t)stream;
     const bool heun = a->solver == DEX_SOLVER_HEUN;
     {
@@ -1476,7 +1533,7 @@ int dex_sample(DexCtx* x, const DexSampleArgs* a, dex_stream_t stream) {
                                  (uint64_t)(uintptr_t)(a->S_churn > 0.f ? a->noise_dev : nullptr)};
     for (float v : {a->S_churn, a->S_min, a->S_max, a->S_noise}) { uint32_t u; memcpy(&u, &v, 4); key.push_back(u); }
     for (int j = 0; j < a->n_ref; ++j) key.push_back((uint64_t)(uintptr_t)a->ref_skips_dev[j]);
-    for (const char* e : {"DEX_CONV_STREAM", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN", "DEX_DIT_CLUSTER", "DEX_DEBUG_DROP_HANDOFF", "DEX_PATCH_FUSED"}) {     // knobs read at enqueue time
+    for (const char* e : {"DEX_CONV_STREAM", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN", "DEX_DIT_CLUSTER", "DEX_DIT_CLUSTER_LOCAL", "DEX_DEBUG_DROP_HANDOFF", "DEX_PATCH_FUSED"}) {     // knobs read at enqueue time
         const char* v = getenv(e);
         key.push_back(v ? (uint64_t)atoi(v) + 1 : 0);
     }
@@ -1564,6 +1621,7 @@ int dex_debug_handoff_timeouts(DexCtx* x, dex_stream_t stream) {
     if (!x->last_xerr) return 0;
     int v = 0;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipMemcpy(&v, x->last_xerr, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (v == 2 && !getenv("DEX_DEBUG_DROP_HANDOFF")) { g_xcd_map = 0; x->drop_graphs(); }        // members of a cluster met on different XCDs: the XCD-local form is off from here on
     return v;
 }
 

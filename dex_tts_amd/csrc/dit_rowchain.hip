@@ -785,22 +785,62 @@ __device__ __forceinline__ void ln_regs_to_A(float4 (&v)[4], u16* As, const floa
         *reinterpret_cast<uint2*>(As + row * A_LD + q * 64 + seg * 4) = o;
     }
 }
-// one lane per peer polls that peer's flag until it shows this launch's epoch (relaxed agent-scope loads + s_sleep)
-__device__ __forceinline__ void cluster_wait(const unsigned* flags, int member, unsigned epoch, int tid, int* xerr) {
+// hand-off scope.  LOCAL = false: the members of a cluster may sit on different XCDs (non-coherent L2s): payload stores are
+// write-through (sc1), loads and flags go to memory (agent scope).  LOCAL = true: the launcher placed the four members of a
+// cluster on ONE XCD (workgroup b runs on XCD b % 8; checked by a probe launch when the context is created and again here: every
+// flag carries its writer's XCC id, a mismatch sets *xerr and poisons the call like a time-out): the XCD's L2 is the coherence
+// point, payload stores are plain (the L1 is write-through), loads and flag polls bypass only the L1 (sc0) - an L2 round trip
+// instead of a fabric one on each of the three legs of a hand-off (drain, poll, peer loads).
+template <bool LOCAL> struct ClScope {
+    static constexpr int ST_AUX = LOCAL ? 0 : 16, LD_AUX = LOCAL ? 1 : 16;
+    // flag poll.  LOCAL: a workgroup-scope LOAD may be served by this CU's L1 (the coherence point of a workgroup), which would
+    // keep returning the first value it fetched; a read-modify-write executes in the L2: fetch_or with 0 is the L2-scope load
+    static __device__ __forceinline__ unsigned poll(unsigned* p) {
+        if constexpr (LOCAL) {      // (as assembly: the compiler folds an idempotent fetch_or back into a load; sc0 on an atomic = return the old value)
+            unsigned v;
+            asm volatile("global_atomic_or %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p), "v"(0u) : "memory");
+            return v;
+        } else return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    static __device__ __forceinline__ void st(unsigned* p, unsigned v) {
+        if constexpr (LOCAL) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    static __device__ __forceinline__ unsigned long long ld64(const unsigned long long* p) {
+        if constexpr (LOCAL) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    static __device__ __forceinline__ void st64(unsigned long long* p, unsigned long long v) {
+        if constexpr (LOCAL) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+__device__ __forceinline__ unsigned xcc_id() {
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return x & 15u;
+}
+// flag word = epoch (24 bits) | writer's XCC id << 24
+// one lane per peer polls that peer's flag until it shows this launch's epoch (relaxed loads + s_sleep)
+template <bool LOCAL>
+__device__ __forceinline__ void cluster_wait(unsigned* flags, int member, unsigned epoch, unsigned my_xcc, int tid, int* xerr) {
     if (tid < DIT_CLUSTER && tid != member) {
         const long long t0 = wall_clock64();
-        while (__hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-            __builtin_amdgcn_s_sleep(2);
-            if (wall_clock64() - t0 > 5000000LL) { if (xerr) *xerr = 1; break; }       // 50 ms at 100 MHz: never in a healthy launch
+        unsigned v;
+        while (((v = ClScope<LOCAL>::poll(flags + tid)) & 0xffffffu) != epoch) {
+            __builtin_amdgcn_s_sleep(LOCAL ? 1 : 2);
+            if (wall_clock64() - t0 > 5000000LL) { if (xerr) *xerr = 1; v = epoch | (my_xcc << 24); break; }       // 50 ms at 100 MHz: never in a healthy launch
         }
+        if (LOCAL && (v >> 24) != my_xcc && xerr) *xerr = 2;          // a peer on another XCD: its payload is not in this L2
     }
     __syncthreads();
 }
 }  // namespace
 
 // QKV_ONLY: the first block's launch (LN + modulate + qkv of the incoming rows, no hand-off) as its own symbol
-template <bool QKV_ONLY>
+template <bool QKV_ONLY, bool LOCAL = false>
 __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const DitChainP p) {
+    using Sc = ClScope<LOCAL>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_rc[];
     // chain buffers (they overlay the attention scratch, which is dead once the partials are merged)
     float* X1 = reinterpret_cast<float*>(smem_rc);                       // [32][X_LD] fp32: partial staging, then the residual stream
@@ -813,7 +853,13 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
     const int N = p.rows_per_batch, tpb = (N + RC_ROWS - 1) / RC_ROWS;
-    const int cluster = blockIdx.x / DIT_CLUSTER, member = blockIdx.x % DIT_CLUSTER;
+    // p.xlocal: the four members of a cluster share blockIdx % 8, i.e. their XCD (clusters are dealt to the XCDs in rounds of 8;
+    // the grid is padded to whole rounds and the clusters past the last tile leave here)
+    const int cluster = p.xlocal ? (int)(blockIdx.x & 7) + 8 * (int)(blockIdx.x / (8 * DIT_CLUSTER)) : (int)blockIdx.x / DIT_CLUSTER;
+    const int member = p.xlocal ? (int)(blockIdx.x >> 3) % DIT_CLUSTER : (int)blockIdx.x % DIT_CLUSTER;
+    if (cluster >= p.B * tpb) return;
+    const unsigned my_xcc = LOCAL ? xcc_id() : 0u;
+    const unsigned flagv = p.epoch | (my_xcc << 24);
     const int b = cluster / tpb, n0 = (cluster - b * tpb) * RC_ROWS;
     const long mb = (long)b * N;
     const int step = p.step;
@@ -1004,22 +1050,21 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const 
             for (int q = 0; q < 4; ++q) {
                 const float4 v = *reinterpret_cast<const float4*>(X1 + row * X_LD + q * 64 + seg * 4);
                 const u32x4v u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-                __builtin_amdgcn_raw_buffer_store_b128(u, srs, base + (unsigned)(q * 512 + tid) * 16u, 0, 16);      // aux 16 = sc1: write-through
+                __builtin_amdgcn_raw_buffer_store_b128(u, srs, base + (unsigned)(q * 512 + tid) * 16u, 0, Sc::ST_AUX);      // aux 16 = sc1: write-through
             }
             if (seg == 0) {
                 const unsigned long long ml = (unsigned long long)__float_as_uint(myM) | ((unsigned long long)__float_as_uint(myL) << 32);
-                __hip_atomic_store(reinterpret_cast<unsigned long long*>(slab + (0 * DIT_CLUSTER + member) * (SLAB_B / 4) + 32 * 256) + row, ml,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                Sc::st64(reinterpret_cast<unsigned long long*>(slab + (0 * DIT_CLUSTER + member) * (SLAB_B / 4) + 32 * 256) + row, ml);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // every storing wave drains its write-through stores
             __syncthreads();
-            if (tid == 0 && !(p.xdrop && member == 3)) __hip_atomic_store(flags + 0 * DIT_CLUSTER + member, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0 && !(p.xdrop == 1 && member == 3)) Sc::st(flags + 0 * DIT_CLUSTER + member, flagv);
         }
 
 #ifdef DEX_TIMING
     cts[4] = wall_clock64();
 #endif
-        cluster_wait(flags + 0 * DIT_CLUSTER, member, p.epoch, tid, p.xerr);
+        cluster_wait<LOCAL>(flags + 0 * DIT_CLUSTER, member, p.epoch, my_xcc, tid, p.xerr);
 #ifdef DEX_TIMING
     cts[5] = wall_clock64();
 #endif
@@ -1033,9 +1078,8 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const 
                 if (c == member) continue;
                 const unsigned base = (0 * DIT_CLUSTER + c) * SLAB_B;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) pv[c][q] = __builtin_amdgcn_raw_buffer_load_b128(srs, base + (unsigned)(q * 512 + tid) * 16u, 0, 16);
-                const unsigned long long ml = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(slab + (0 * DIT_CLUSTER + c) * (SLAB_B / 4) + 32 * 256) + row,
-                                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int q = 0; q < 4; ++q) pv[c][q] = __builtin_amdgcn_raw_buffer_load_b128(srs, base + (unsigned)(q * 512 + tid) * 16u, 0, Sc::LD_AUX);
+                const unsigned long long ml = Sc::ld64(reinterpret_cast<const unsigned long long*>(slab + (0 * DIT_CLUSTER + c) * (SLAB_B / 4) + 32 * 256) + row);
                 pm[c] = __uint_as_float((unsigned)ml); pl[c] = __uint_as_float((unsigned)(ml >> 32));
             }
             pm[member] = myM; pl[member] = myL;
@@ -1115,17 +1159,17 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const 
             for (int q = 0; q < 4; ++q) {
                 const float4 v = *reinterpret_cast<const float4*>(P2 + row * X_LD + q * 64 + seg * 4);
                 const u32x4v u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-                __builtin_amdgcn_raw_buffer_store_b128(u, srs, base + (unsigned)(q * 512 + tid) * 16u, 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(u, srs, base + (unsigned)(q * 512 + tid) * 16u, 0, Sc::ST_AUX);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (tid == 0 && !(p.xdrop && member == 3)) __hip_atomic_store(flags + 1 * DIT_CLUSTER + member, p.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (tid == 0 && !(p.xdrop == 1 && member == 3)) Sc::st(flags + 1 * DIT_CLUSTER + member, flagv);
         }
 
 #ifdef DEX_TIMING
     cts[10] = wall_clock64();
 #endif
-        cluster_wait(flags + 1 * DIT_CLUSTER, member, p.epoch, tid, p.xerr);
+        cluster_wait<LOCAL>(flags + 1 * DIT_CLUSTER, member, p.epoch, my_xcc, tid, p.xerr);
 #ifdef DEX_TIMING
     cts[11] = wall_clock64();
 #endif
@@ -1137,7 +1181,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const 
                 if (c == member) continue;
                 const unsigned base = (1 * DIT_CLUSTER + c) * SLAB_B;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) pv[c][q] = __builtin_amdgcn_raw_buffer_load_b128(srs, base + (unsigned)(q * 512 + tid) * 16u, 0, 16);
+                for (int q = 0; q < 4; ++q) pv[c][q] = __builtin_amdgcn_raw_buffer_load_b128(srs, base + (unsigned)(q * 512 + tid) * 16u, 0, Sc::LD_AUX);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1198,21 +1242,37 @@ bool dit_rowchain_cluster_form(int rows_per_batch, int B) {
     return on && (long)B * ((rows_per_batch + RC_ROWS - 1) / RC_ROWS) * DIT_CLUSTER <= 256;
 }
 
+// XCD-local clusters (DitChainP::xlocal): the grid is padded to whole rounds of 8 clusters, still one workgroup per CU at most
+bool dit_rowchain_cluster_local_fits(int rows_per_batch, int B) {
+    const char* e = getenv("DEX_DIT_CLUSTER_LOCAL");    // read per call (part of the graph cache key)
+    const int on = e ? atoi(e) : 1;
+    const long tiles = (long)B * ((rows_per_batch + RC_ROWS - 1) / RC_ROWS);
+    return on && dit_rowchain_cluster_form(rows_per_batch, B) && (tiles + 7) / 8 * 8 * DIT_CLUSTER <= 256;
+}
+
 bool dit_rowchain_supported(int hidden, int mlp_hidden) { return hidden == RC_H && mlp_hidden == RC_MLP; }
 
 void launch_dit_rowchain(const DitChainP& p, hipStream_t st) {
     if (p.xslab && (p.attn_inline || p.qkv_only) && dit_rowchain_cluster_form(p.rows_per_batch, p.B)) {
         static bool attrc = false;
         if (!attrc) {
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&dit_rowchain_cluster_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC_LDS_CLUSTER);
-            hipFuncSetAttribute(reinterpret_cast<const void*>(&dit_rowchain_cluster_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC_LDS_CLUSTER);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&dit_rowchain_cluster_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC_LDS_CLUSTER);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&dit_rowchain_cluster_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC_LDS_CLUSTER);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&dit_rowchain_cluster_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC_LDS_CLUSTER);
             attrc = true;
         }
-        const dim3 gridc(p.B * ((p.rows_per_batch + RC_ROWS - 1) / RC_ROWS) * DIT_CLUSTER);
-        if (p.qkv_only) hipLaunchKernelGGL(dit_rowchain_cluster_kernel<true>, gridc, dim3(RC_NW * 64), RC_LDS_CLUSTER, st, p);
-        else {
-            g_last_symbol = "dit_rowchain_cluster_kernel<false>";
-            hipLaunchKernelGGL(dit_rowchain_cluster_kernel<false>, gridc, dim3(RC_NW * 64), RC_LDS_CLUSTER, st, p);
+        const int tiles = p.B * ((p.rows_per_batch + RC_ROWS - 1) / RC_ROWS);
+        const dim3 gridc((p.xlocal ? (tiles + 7) / 8 * 8 : tiles) * DIT_CLUSTER);
+        if (p.qkv_only) hipLaunchKernelGGL((dit_rowchain_cluster_kernel<true, false>), gridc, dim3(RC_NW * 64), RC_LDS_CLUSTER, st, p);
+        else if (p.xdrop == 2) {        // tests only: L2-scope hand-offs between members dealt to DIFFERENT XCDs - must end as an error, never as a mel
+            DitChainP q = p; q.xlocal = 0;
+            hipLaunchKernelGGL((dit_rowchain_cluster_kernel<false, true>), dim3(tiles * DIT_CLUSTER), dim3(RC_NW * 64), RC_LDS_CLUSTER, st, q);
+        } else if (p.xlocal) {
+            g_last_symbol = "dit_rowchain_cluster_kernel<false,true>";
+            hipLaunchKernelGGL((dit_rowchain_cluster_kernel<false, true>), gridc, dim3(RC_NW * 64), RC_LDS_CLUSTER, st, p);
+        } else {
+            g_last_symbol = "dit_rowchain_cluster_kernel<false,false>";
+            hipLaunchKernelGGL((dit_rowchain_cluster_kernel<false, false>), gridc, dim3(RC_NW * 64), RC_LDS_CLUSTER, st, p);
         }
         return;
     }

@@ -260,13 +260,15 @@ struct DitChainP { const float* O; int ksplit; long o_sstride; const float* ml; 
                    // cluster form (small grids, dit_rowchain_cluster_kernel): exchange slabs, flags (zeroed once per call) and the
                    // launch's epoch (unique within the call, never 0); err: device word set when a hand-off wait timed out
                    float* xslab; unsigned* xflag; unsigned epoch; int* xerr;
-                   int xdrop; };                            // tests only (DEX_DEBUG_DROP_HANDOFF=1): member 3 never raises its flags -> the peers' waits time out
+                   int xlocal;                              // 1: the members of a cluster share an XCD (hand-offs through its L2; grid padded to rounds of 8 clusters)
+                   int xdrop; };                            // tests only (DEX_DEBUG_DROP_HANDOFF): 1 member 3 never raises its flags -> the peers' waits time out; 2 L2-scope hand-offs across XCDs
 // cluster form of the row chain: workgroups per 32-row tile, bytes of exchange slab / flag words per tile, and whether a launch
 // of B x N rows takes it (all workgroups co-resident: <= one per CU)
 constexpr int DIT_CLUSTER = 4;
 constexpr size_t DIT_CLUSTER_SLAB_FLOATS = 2 * DIT_CLUSTER * (32 * 256 + 256);
 constexpr size_t DIT_CLUSTER_FLAG_WORDS = 2 * DIT_CLUSTER;
 bool dit_rowchain_cluster_form(int rows_per_batch, int B);
+bool dit_rowchain_cluster_local_fits(int rows_per_batch, int B);
 bool dit_rowchain_supported(int hidden, int mlp_hidden);
 // Softmax attention on the row chain's bf16 operands (2 heads x 128): no staging, K / V^T / Q fragments are read
 // straight from global memory.  O: fp32 [ksplit][B][N][256] partials + ml (merged by the next row chain launch).

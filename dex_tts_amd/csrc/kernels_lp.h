@@ -36,6 +36,7 @@ int attention_direct_ksplit(int N, int B);
 // DiT row chain (dit_rowchain.hip) and its weight packing
 bool dit_rowchain_supported(int hidden, int mlp_hidden);
 bool dit_rowchain_cluster_form(int rows_per_batch, int B);
+bool dit_rowchain_cluster_local_fits(int rows_per_batch, int B);
 void launch_dit_rowchain(const DitChainP& p, hipStream_t st);
 void launch_pack_lp_frag(const float* src, void* dst, int K, int N, hipStream_t st);
 void launch_pack_lp_frag_nk(const float* src, void* dst, int K, int N, hipStream_t st);   // source [N][K]

@@ -175,8 +175,11 @@ class ScoreNetEngine:
             self._stage[key] = bufs
         else:
             self._stage[key] = self._stage.pop(key)          # dicts keep insertion order: re-insert = most recently used
+        cur = torch.cuda.current_stream(self.device)
         for b, t in zip(bufs, tensors):
             b.copy_(t, non_blocking=True)
+            if t.is_cuda:
+                t.record_stream(cur)       # the caller's tensor may be freed (and its block reused on ITS stream) before this copy has run
         return bufs
 
     def sample(self, z, mask, mu, n_steps, spk=None, ref=None, sty=None, sty_lengths=None, use_graph=False,
@@ -292,6 +295,11 @@ class ScoreNetEngine:
         """Debug: did a workgroup hand-off of the last sample / denoise_once call time out (cluster form of the DiT row chain)?"""
         with torch.cuda.device(self.device):
             return int(self.lib.dex_debug_handoff_timeouts(self.h, self._stream()))
+
+    def xcd_local(self) -> int:
+        """Debug: 1 if this device deals workgroup b to XCD b % 8 (the cluster row chain then keeps its hand-offs inside one L2)."""
+        with torch.cuda.device(self.device):
+            return int(self.lib.dex_debug_xcd_local())
 
     def mel_from_wav(self, wav: torch.Tensor):
         with torch.cuda.device(self.device):

@@ -146,6 +146,11 @@ int  dex_profile_get(const DexCtx* ctx, int i, const char** name, int* calls, do
  * blocks run as clusters of co-operating workgroups; a wait is bounded so a lost hand-off cannot hang the GPU), 0 if none did or
  * the call used no hand-offs, < 0 on a HIP error.  Synchronises the stream; the call's workspace must still be alive. */
 int  dex_debug_handoff_timeouts(DexCtx* ctx, dex_stream_t stream);
+/* Debug: 1 if workgroup b of a launch runs on XCD b % 8 on this device (probed once per process with launches that record
+ * HW_REG_XCC_ID), which lets the clusters above keep their hand-offs inside one XCD's L2; 0 if not (or DEX_DIT_CLUSTER_LOCAL=0):
+ * the hand-offs then go through memory.  Every hand-off of the XCD-local form re-checks its peers' XCC ids; a mismatch poisons the
+ * call like a time-out (dex_debug_handoff_timeouts returns 2 and switches the form off for the process). */
+int  dex_debug_xcd_local(void);
 
 /* STFT/mel front-end (audio/tools.py:8-15): wav [L] fp32 in [-1,1] (clipped here) -> mel [80,frames],
  * energy [frames]; frames = L/256 + 1.  n_fft=1024, hop=256, 80 mels, 22050 Hz, fmin 0, fmax 8000. */

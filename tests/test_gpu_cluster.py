@@ -94,6 +94,67 @@ def test_lost_handoff_is_loud():
         eng.set_precision("fp32")
 
 
+@pytest.mark.parametrize("name,kw,n", [
+    ("gedex_lj", dict(B=1, T=512), 6),                                    # 21 clusters in 3 rounds of 8 (3 idle cluster slots)
+    ("gedex_lj", dict(B=3, T=512, lengths=[512, 300, 77]), 3),            # 63 clusters -> 64 slots = 256 workgroups: the largest XCD-local grid
+    ("gedex_lj", dict(B=2, T=100, lengths=[100, 61]), 4),
+    ("dex_vctk", dict(B=1, T=64, lengths=[57], Tr=40, Ts=40, sty_lengths=[33]), 4),
+])
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_xcd_local_clusters_equal_cross_xcd_clusters_bitwise(name, kw, n, prec):
+    """The members of a cluster on ONE XCD (hand-offs through its L2: plain stores, sc0 loads) against the members dealt across
+    XCDs (write-through stores, memory-scope loads; DEX_DIT_CLUSTER_LOCAL=0): the arithmetic and its order are the same, so the
+    bits are; repeated and replayed calls stay identical (a stale L2 line would show), and no hand-off reports an error."""
+    cfg, eng, w = U.engine_for(name)
+    if eng.xcd_local() != 1:
+        pytest.skip("this device does not deal workgroup b to XCD b % 8: the XCD-local form is off")
+    case = U.make_case(cfg, **kw)
+    eng.set_precision(prec)
+    try:
+        a = _run(eng, case, n)
+        assert eng.handoff_timeouts() == 0
+        for _ in range(12):
+            assert np.array_equal(a, _run(eng, case, n)), eng.handoff_timeouts()
+        for _ in range(2):
+            g = _run(eng, case, n, graph=True)
+            assert np.array_equal(a, g), (eng.handoff_timeouts(), int(np.isnan(g).sum()))
+        assert eng.handoff_timeouts() == 0
+        os.environ["DEX_DIT_CLUSTER_LOCAL"] = "0"
+        try:
+            b = _run(eng, case, n)
+            assert eng.handoff_timeouts() == 0
+        finally:
+            del os.environ["DEX_DIT_CLUSTER_LOCAL"]
+        assert np.isfinite(a).all() and np.array_equal(a, b), float(np.abs(a - b).max())
+    finally:
+        eng.set_precision("fp32")
+
+
+def test_l2_scope_handoff_across_xcds_is_loud():
+    """DEX_DEBUG_DROP_HANDOFF=2 runs the XCD-local protocol on clusters whose members sit on DIFFERENT XCDs (what a device with
+    another workgroup placement rule would do to it): the peers' plain stores never reach this XCD's L2 in time (time-out, 1) or
+    arrive with a foreign XCC id in the flag (2) - either way the device word is set and the call's outputs are NaN."""
+    cfg, eng, w = U.engine_for("gedex_lj")
+    if eng.xcd_local() != 1:
+        pytest.skip("XCD-local form off on this device")
+    case = U.make_case(cfg, B=1, T=64)
+    eng.set_precision("bf16")
+    try:
+        good = _run(eng, case, 2)
+        assert np.isfinite(good).all() and eng.handoff_timeouts() == 0
+        os.environ["DEX_DEBUG_DROP_HANDOFF"] = "2"
+        try:
+            bad = _run(eng, case, 2)
+            assert eng.handoff_timeouts() in (1, 2)
+        finally:
+            del os.environ["DEX_DEBUG_DROP_HANDOFF"]
+        assert np.isnan(bad).all()
+        assert eng.xcd_local() == 1                                        # (the debug run does not switch the form off)
+        assert np.array_equal(good, _run(eng, case, 2)) and eng.handoff_timeouts() == 0
+    finally:
+        eng.set_precision("fp32")
+
+
 @pytest.mark.parametrize("name,kw", [
     ("gedex_lj", dict(B=1, T=512)),                                        # 7 x 7 / stride 4 patches
     ("gedex_lj", dict(B=2, T=100, lengths=[100, 61])),                     # width not a multiple of the patch: right zero padding

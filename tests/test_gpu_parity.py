@@ -228,6 +228,38 @@ def test_graph_replay_matches_eager():
     assert np.array_equal(h0, h1)
 
 
+@pytest.mark.parametrize("name,kw", [
+    ("gedex_vctk", dict(B=2, T=64, lengths=[57, 64])),                                          # speaker plane
+    ("dex_vctk", dict(B=1, T=64, lengths=[57], Tr=40, Ts=40, sty_lengths=[33])),               # + adaptors
+    ("gedex_lj", dict(B=2, T=64, lengths=[64, 50])),
+])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_cached_graph_survives_eager_calls_in_between(name, kw, prec):
+    """replay -> eager call on the default stream -> replay of the SAME cached graph.  With hipMemsetAsync nodes in the captured
+    call (flags, statistics, key padding) the second replay came out wrong on rocm 7.2 - silently, or as NaN - once any eager
+    call of the library had run on the null stream in between; every zero-fill is a kernel node now (dex_api.hip zero_fill)."""
+    cfg, eng, w = U.engine_for(name)
+    c1 = U.make_case(cfg, **kw)
+    c2 = dict(c1); c2["z"] = (c1["z"][:, :, ::-1] * 0.9).copy(); c2["mu"] = (c1["mu"] * 0.5).copy()
+
+    def run(c, graph):
+        mu, mask, z = (torch.from_numpy(c[k]).cuda() for k in ("mu", "mask", "z"))
+        return eng.sample(z, mask, mu, 3, use_graph=graph, **U.engine_kwargs(c)).cpu().numpy()
+    eng.set_precision(prec)
+    try:
+        a1, a2 = run(c1, False), run(c2, False)
+        assert not np.array_equal(a1, a2)
+        assert np.array_equal(a1, run(c1, True)) and np.array_equal(a2, run(c2, True))
+        for _ in range(3):
+            assert np.array_equal(a2, run(c2, False))                        # eager, default stream
+            assert np.array_equal(a1, run(c1, True))                         # cached graph, other inputs
+            mu, mask, x = (torch.from_numpy(c2[k]) for k in ("mu", "mask", "z"))
+            eng.denoise_once(x, 1.0, mask, mu, **U.engine_kwargs(c2)).cpu()  # another eager entry point
+            assert np.array_equal(a2, run(c2, True))
+    finally:
+        eng.set_precision("fp32")
+
+
 def test_batch_independence_at_equal_padding():
     """Utterances in a batch do not interact (same padded T): B=2 equals two B=1 runs."""
     cfg, eng, w = U.engine_for("gedex_lj")
