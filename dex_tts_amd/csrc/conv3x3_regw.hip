@@ -96,7 +96,8 @@ struct RwRow { uint4 a[NL]; uint4 b[XB ? 1 : NL]; float4 r0[RES2 ? NL : 1], r1[R
 
 // PROF: 0 plain x * mask, 1 producer tail mask * (Mish(GN(x)) + tadd) (pro_stats), 2 resnet tail x' = mask * Mish(GN(x)) + pro_res
 // (x' also written to pro_xout for this workgroup's pixels), then x' * mask.
-template <int CIN, int COUT, int PROF, bool XB, bool YB>
+// XOL: x' (PROF == 2) leaves in the mode's 16-bit type (Conv3P::xout_lp).
+template <int CIN, int COUT, int PROF, bool XB, bool YB, bool XOL = false>
 __global__ __launch_bounds__(256) void conv3x3_rw_kernel(const Conv3P p, const int nseg, const int rows_per_wg) {
     using G = RwGeom<CIN, COUT, YB>;
     using Row = RwRow<G::NL, XB, false>;             // (the residual of the PROF == 2 form travels separately: res_ring below)
@@ -208,7 +209,8 @@ __global__ __launch_bounds__(256) void conv3x3_rw_kernel(const Conv3P p, const i
     // column write a dummy LDS slot; lanes that do not own their pixel (halo columns / rows, image border) give the x' store an
     // out-of-range offset, which a raw buffer store drops.
     const __amdgpu_buffer_rsrc_t xo_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(PROF == 2 ? p.pro_xout + (long)b * p.H * p.W * CIN : p.bias), 0, PROF == 2 ? (unsigned)((long)p.H * p.W * CIN * 4) : 0u, 0x00020000);
+        const_cast<float*>(PROF == 2 ? (XOL ? reinterpret_cast<const float*>(reinterpret_cast<const u16*>(p.pro_xout) + (long)b * p.H * p.W * CIN) : p.pro_xout + (long)b * p.H * p.W * CIN) : p.bias),
+        0, PROF == 2 ? (unsigned)((long)p.H * p.W * CIN * (XOL ? 2 : 4)) : 0u, 0x00020000);
     int xoff[G::NL];                     // byte offset of item j inside an image row of x', or "out of range" for columns this thread does not own
 #pragma unroll
     for (int j = 0; j < G::NL; ++j) {
@@ -222,9 +224,16 @@ __global__ __launch_bounds__(256) void conv3x3_rw_kernel(const Conv3P p, const i
         *reinterpret_cast<uint2*>(ring + ((j < G::NL - 1 || px < G::PC) ? slot_off : G::RING + G::STG + G::EXCH + G::TAIL)) = sl.v;
         if constexpr (PROF == 2) {
             const bool own_row = row >= r0 && row < r1;                    // (uniform)
-            const unsigned off = own_row ? (unsigned)(row * (p.W * CIN * 4) + xoff[j] + 16 * hq) : 0xffffffffu;
-            const rw_u32x4 v = {__float_as_uint(sl.f.x), __float_as_uint(sl.f.y), __float_as_uint(sl.f.z), __float_as_uint(sl.f.w)};
-            __builtin_amdgcn_raw_buffer_store_b128(v, xo_rsrc, off, 0, 0);
+            if constexpr (XOL) {
+                typedef unsigned rw_u32x2 __attribute__((ext_vector_type(2)));
+                const unsigned off = own_row ? (unsigned)(row * (p.W * CIN * 2) + (xoff[j] >> 1) + 8 * hq) : 0xffffffffu;
+                const rw_u32x2 v = {pack2_lp(sl.f.x, sl.f.y), pack2_lp(sl.f.z, sl.f.w)};
+                __builtin_amdgcn_raw_buffer_store_b64(v, xo_rsrc, off, 0, 0);
+            } else {
+                const unsigned off = own_row ? (unsigned)(row * (p.W * CIN * 4) + xoff[j] + 16 * hq) : 0xffffffffu;
+                const rw_u32x4 v = {__float_as_uint(sl.f.x), __float_as_uint(sl.f.y), __float_as_uint(sl.f.z), __float_as_uint(sl.f.w)};
+                __builtin_amdgcn_raw_buffer_store_b128(v, xo_rsrc, off, 0, 0);
+            }
         }
     };
     auto row_store = [&](int row, const Row& R) __attribute__((always_inline)) {
@@ -655,7 +664,7 @@ bool conv3x3_regw_form(const Conv3P& p) {
     return (long)p.H * ((p.W + 63) / 64) * p.B >= min_tiles;
 }
 
-template <int CIN, int COUT, int PROF, bool XB, bool YB>
+template <int CIN, int COUT, int PROF, bool XB, bool YB, bool XOL = false>
 static void rw_launch(const Conv3P& p, hipStream_t st) {
     using G = RwGeom<CIN, COUT, YB>;
     const int nseg = (p.W + G::MPX - 1) / G::MPX;
@@ -666,8 +675,8 @@ static void rw_launch(const Conv3P& p, hipStream_t st) {
     const int R = (p.H + nchunk - 1) / nchunk;
     nchunk = (p.H + R - 1) / R;
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_rw_kernel<CIN, COUT, PROF, XB, YB>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS); attr = true; }
-    hipLaunchKernelGGL((conv3x3_rw_kernel<CIN, COUT, PROF, XB, YB>), dim3(nseg * nchunk, p.B), dim3(G::NTHR), G::LDS, st, p, nseg, R);
+    if (!attr) { hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_rw_kernel<CIN, COUT, PROF, XB, YB, XOL>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS); attr = true; }
+    hipLaunchKernelGGL((conv3x3_rw_kernel<CIN, COUT, PROF, XB, YB, XOL>), dim3(nseg * nchunk, p.B), dim3(G::NTHR), G::LDS, st, p, nseg, R);
 }
 
 template <bool XB>
@@ -687,7 +696,8 @@ static void rw_launch_res128(const Conv3P& p, hipStream_t st) {
 void launch_conv3x3_regw(const Conv3P& p, hipStream_t st) {
     if (p.res_w) { g_last_symbol = "conv3x3_rw_res128_kernel"; p.x_bf16 ? rw_launch_res128<true>(p, st) : rw_launch_res128<false>(p, st); return; }
     g_last_symbol = "conv3x3_rw_kernel";
-    if (p.pro_res) rw_launch<128, 128, 2, true, true>(p, st);
+    if (p.pro_res && p.xout_lp) rw_launch<128, 128, 2, true, true, true>(p, st);
+    else if (p.pro_res) rw_launch<128, 128, 2, true, true>(p, st);
     else rw_launch<128, 128, 1, true, true>(p, st);
 }
 

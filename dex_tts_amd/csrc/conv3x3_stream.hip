@@ -179,9 +179,15 @@ __global__ __launch_bounds__(SNT) void conv3x3_stream64_kernel(const Conv3P p, c
                     const int j = pxi / SPW, pw = pxi - j * SPW;
                     const int hi = hs - 1 + STR * c + j;
                     if (pxi < STR * SPW && hi >= row_lo && hi < row_hi && pw >= 1 && pw <= 32 && w0 + pw - 1 < p.W) {
-                        float* xo = p.pro_xout + ((long)b * p.H * p.W + (long)hi * p.W + (w0 + pw - 1)) * SC + c8;
-                        *reinterpret_cast<float4*>(xo) = make_float4(v[0], v[1], v[2], v[3]);
-                        *reinterpret_cast<float4*>(xo + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                        const long eo = ((long)b * p.H * p.W + (long)hi * p.W + (w0 + pw - 1)) * SC + c8;
+                        if (p.xout_lp) {       // (uniform) 16-bit x for its one reader, the attention's context pass
+                            *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(p.pro_xout) + eo) =
+                                make_uint4(pack2_lp(v[0], v[1]), pack2_lp(v[2], v[3]), pack2_lp(v[4], v[5]), pack2_lp(v[6], v[7]));
+                        } else {
+                            float* xo = p.pro_xout + eo;
+                            *reinterpret_cast<float4*>(xo) = make_float4(v[0], v[1], v[2], v[3]);
+                            *reinterpret_cast<float4*>(xo + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                        }
                     }
                 }
 #pragma unroll
@@ -525,9 +531,15 @@ __global__ __launch_bounds__(SNT) void conv3x3_pp64_kernel(const Conv3P p, const
                     for (int k = 0; k < 4; ++k) { v[2 * k] = w[k].x; v[2 * k + 1] = w[k].y; }
                     const int hi = hs - 1 + PR * c + q_row[q];
                     if (q_wr[q] && hi >= row_lo && hi < row_hi) {
-                        float* xo = p.pro_xout + ((long)b * p.H * p.W + hi * p.W + q_eo[q]) * SC + c8;
-                        *reinterpret_cast<float4*>(xo) = make_float4(v[0], v[1], v[2], v[3]);
-                        *reinterpret_cast<float4*>(xo + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                        const long eo = ((long)b * p.H * p.W + hi * p.W + q_eo[q]) * SC + c8;
+                        if (p.xout_lp) {       // (uniform) 16-bit x for its one reader, the attention's context pass
+                            *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(p.pro_xout) + eo) =
+                                make_uint4(pack2_lp(v[0], v[1]), pack2_lp(v[2], v[3]), pack2_lp(v[4], v[5]), pack2_lp(v[6], v[7]));
+                        } else {
+                            float* xo = p.pro_xout + eo;
+                            *reinterpret_cast<float4*>(xo) = make_float4(v[0], v[1], v[2], v[3]);
+                            *reinterpret_cast<float4*>(xo + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                        }
                     }
                 }
 #pragma unroll

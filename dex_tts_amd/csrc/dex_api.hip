@@ -799,7 +799,9 @@ struct Runner {
     // Block conv (diffusion.py:44).  pro != null fuses the producer's GN-apply + Mish + time bias into the load
     // (bf16 patch kernel only).
     struct Pro { const gnfix_t* stats; const float *gamma, *beta, *tadd; const float* res = nullptr; float* xout = nullptr; bool x_bf16 = false;
-                 bool res2 = false; FirstConvP res2f{}; };     // res2: `res` is not stored - recomputed from the first conv's inputs (res2f)
+                 bool res2 = false; FirstConvP res2f{};
+                 mutable bool xout_lp_ok = false;    // in: xout's one reader (the attention's context pass) can take it in the mode's 16-bit type
+                 mutable bool xout_lp = false; };   // out: the conv that wrote xout did store it that way     // res2: `res` is not stored - recomputed from the first conv's inputs (res2f)
     // raw conv outputs read only by a fused GroupNorm prologue (h1, h2 of a ResnetBlock, the final block's conv) are kept
     // in HBM as bf16 in bf16 mode: half the bytes of the largest tensors of the step.  DEX_H_BF16=0 keeps them fp32.
     static bool ln_fusable(int K) { return K == 64 || K == 128 || K == 256 || K == 512; }
@@ -822,14 +824,16 @@ struct Runner {
                 } }
             c.step = sp; c.gn_stats = gn; c.B = P.d.B;
             { auto itf = x->frag_of().find(Wt); c.Wfrag = itf != x->frag_of().end() ? itf->second : nullptr; }   // conv3x3_regw.hip
+            const bool want_xout_lp = pro && pro->xout && pro->xout_lp_ok;
             if (shortcut) {       // the block's 1x1 res_conv rides on the centre tap of this conv
                 c.res_w = x->lp_of().at(shortcut->wr); c.res_b = shortcut->br; c.res_y = shortcut_out;
                 { auto itf = x->frag_of().find(shortcut->wr); c.res_wfrag = itf != x->frag_of().end() ? itf->second : nullptr; }
             }
+            if (want_xout_lp && (c.pro_res || c.res2_w) && conv3x3_strip_form(c)) { c.xout_lp = 1; pro->xout_lp = true; }
             const double M = (double)H * W * P.d.B;
             // algorithmic bytes: input + output at their stored width, + the residual read and the x write-out of the PRO2 form,
             // + the shortcut output of the RES form, + the weights once
-            const double bytes = M * (((xb || X.lp) ? 2.0 : 4.0) * X.C + (yb ? 2.0 : 4.0) * Cout + (pro && (pro->res || pro->res2) ? (pro->res2 ? 4.0 * X.C : 8.0 * X.C) : 0.0) + (shortcut ? 4.0 * Cout : 0.0))
+            const double bytes = M * (((xb || X.lp) ? 2.0 : 4.0) * X.C + (yb ? 2.0 : 4.0) * Cout + (pro && (pro->res || pro->res2) ? (pro->res2 ? 4.0 * X.C : 8.0 * X.C) - (c.xout_lp ? 2.0 * X.C : 0.0) : 0.0) + (shortcut ? 4.0 * Cout : 0.0))
                                  + 2.0 * 9 * X.C * Cout;
             run(name, 2.0 * M * Cout * (9 * X.C + (shortcut ? X.C : 0)), bytes, [&] { launch_conv3x3_lp(c, x->precision, st); });
             return;
@@ -891,6 +895,11 @@ struct Runner {
             bool fused_res = false;
             if (head) {
                 TD H2{s.h2, X.C, 0, X.C};                  // previous block's raw conv2 output
+                // the previous block's output x (head->xout == X) is written by this conv for ONE later reader when this block's own
+                // tail rides in the attention's context pass with the identity shortcut: it may then leave in the mode's 16-bit type
+                // (the residual term of x' = Mish(GN(h2)) + x carries that rounding: not bit-neutral, DEX_RES_X_LP=0 keeps fp32)
+                { const char* e = getenv("DEX_RES_X_LP");
+                  head->xout_lp_ok = tail != nullptr && !w.wr && lp_inter_cur && head->xout == X.p && X.coff == 0 && X.ld == X.C && !(e && e[0] == '0'); }
                 conv3x3("conv3x3", H2, s.H, s.W, s.mask_ws, true, w.w1, w.b1, w.cout, s.h1, st1, head, nullptr, nullptr, head->x_bf16, h1b);
             } else {
                 fused_res = w.wr && fast_conv(X.C, w.cout) && conv3x3_bf16_res_supported(X.C, w.cout) && x->lp_of().count(w.wr);
@@ -927,6 +936,7 @@ struct Runner {
         if (tail) {
             tail->H2 = s.h2; tail->gn_stats = st2; tail->gamma = w.g2; tail->beta = w.be2;
             tail->res = resptr; tail->ldres = ldres; tail->resb = resb; tail->res_under_mask = under ? 1 : 0;
+            tail->res_lp = (head && head->xout_lp && resptr == X.p) ? 1 : 0;
             tail->mask = mask; tail->mask_ws = s.mask_ws; tail->mask_bstride = P.d.T; tail->W = s.W; tail->Xout = out;
             tail->h2_bf16 = h2b ? 1 : 0;
             return;
@@ -935,6 +945,7 @@ struct Runner {
     }
 
     // Residual(Rezero(LinearAttention)) (diffusion.py:74-102)
+    bool lp_inter_cur = false;             // this step stores single-consumer activations in the mode's 16-bit type (step())
     bool linattn_fused(int C) const { return x->lp() && (C == 64 || C == 128); }
     void linattn(const LinW& w, const StageBuf& s, const TD& X, float* out, int ldo, int ocoff, const LinKvCtxP* tail = nullptr, bool out_lp = false) {
         const long npix = s.npix; const int B = P.d.B;
@@ -948,11 +959,18 @@ struct Runner {
             if (tail) k = *tail;
             k.X = X.p; k.ldx = X.ld; k.x_coff = X.coff; k.xb = npix * X.ld; k.npix = (int)npix; k.C = X.C; k.Wkv = w.wkv_lp[x->lpi()];
             k.nsub = nsub; k.nblk = nblk; k.part_m = s.pm; k.part_s = s.ps; k.part_c = s.pc; k.B = B;
-            run("linattn_kvctx", 2.0 * npix * B * (256.0 * X.C + 128 * 32), (tail ? (tail->h2_bf16 ? 10.0 : 12.0) : 4.0) * npix * X.C * B, [&] { launch_linattn_kvctx(k, x->precision, st); });
+            // x = the ResnetBlock output the context pass materialises has ONE reader, the tail kernel below, which rounds it to the
+            // operand type for its q GEMM anyway and adds it back as the residual term: at batch size it is stored in that type
+            // (half of the write + read; the residual term then carries the operand rounding - NOT bit-identical to the fp32
+            // store, measured in DESIGN.md; DEX_ATTN_X_LP=0 keeps it fp32)
+            const char* xe = getenv("DEX_ATTN_X_LP");
+            const bool xlp = k.H2 && k.Xout && lp_inter_cur && linattn_out2_lp_out_supported((int)npix, B) && !(xe && xe[0] == '0');
+            k.xout_lp = xlp ? 1 : 0;
+            run("linattn_kvctx", 2.0 * npix * B * (256.0 * X.C + 128 * 32), (tail ? (tail->h2_bf16 ? 10.0 : 12.0) - (xlp ? 2.0 : 0.0) : 4.0) * npix * X.C * B, [&] { launch_linattn_kvctx(k, x->precision, st); });
             LinMergeP mg{s.pm, s.ps, s.pc, nblk, w.wout_raw, w.g, X.C, s.mbf, B};
             run("linattn_merge", 2.0 * 128 * 32 * X.C * B, 4.0 * nblk * 4 * 1088 * B, [&] { launch_linattn_merge(mg, x->precision, st); });
-            LinOut2P o{X.p, X.ld, X.coff, npix * X.ld, (int)npix, X.C, w.wq_frag[x->lpi()], s.mbf, w.bias_eff, out, ldo, ocoff, npix * ldo, B, out_lp ? 1 : 0};
-            run("linattn_out", 4.0 * npix * B * 128.0 * X.C, (out_lp ? 6.0 : 8.0) * npix * X.C * B, [&] { launch_linattn_out2(o, x->precision, st); });
+            LinOut2P o{X.p, X.ld, X.coff, npix * X.ld, (int)npix, X.C, w.wq_frag[x->lpi()], s.mbf, w.bias_eff, out, ldo, ocoff, npix * ldo, B, out_lp ? 1 : 0, xlp ? 1 : 0};
+            run("linattn_out", 4.0 * npix * B * 128.0 * X.C, ((out_lp ? 6.0 : 8.0) - (xlp ? 2.0 : 0.0)) * npix * X.C * B, [&] { launch_linattn_out2(o, x->precision, st); });
             return;
         }
         IGemmP g = base_gemm(X.p, X.ld, X.coff, s.H, s.W, X.C, w.wqkv, 384, nullptr, s.qkv, 384, 0);
@@ -1193,6 +1211,7 @@ struct Runner {
         // 16-bit tensors are the throughput forms); never with debug taps (they read fp32); DEX_LP_INTER=0 turns it off.
         const char* li_env = getenv("DEX_LP_INTER");
         const bool lp_inter = x->lp() && !debug && ns >= 2 && !(li_env && li_env[0] == '0') && fast_conv(c.dim, c.dim);
+        lp_inter_cur = lp_inter;
         const int lpk = x->lp_kind();
         for (int i = 0; i < ns; ++i) {
             const StageBuf& s = P.down[i];
@@ -1533,7 +1552,7 @@ int dex_sample(DexCtx* x, const DexSampleArgs* a, dex_stream_t stream) {
                                  (uint64_t)(uintptr_t)(a->S_churn > 0.f ? a->noise_dev : nullptr)};
     for (float v : {a->S_churn, a->S_min, a->S_max, a->S_noise}) { uint32_t u; memcpy(&u, &v, 4); key.push_back(u); }
     for (int j = 0; j < a->n_ref; ++j) key.push_back((uint64_t)(uintptr_t)a->ref_skips_dev[j]);
-    for (const char* e : {"DEX_CONV_STREAM", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN", "DEX_DIT_CLUSTER", "DEX_DIT_CLUSTER_LOCAL", "DEX_DEBUG_DROP_HANDOFF", "DEX_PATCH_FUSED"}) {     // knobs read at enqueue time
+    for (const char* e : {"DEX_CONV_STREAM", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN", "DEX_DIT_CLUSTER", "DEX_DIT_CLUSTER_LOCAL", "DEX_ATTN_X_LP", "DEX_RES_X_LP", "DEX_DEBUG_DROP_HANDOFF", "DEX_PATCH_FUSED"}) {     // knobs read at enqueue time
         const char* v = getenv(e);
         key.push_back(v ? (uint64_t)atoi(v) + 1 : 0);
     }

@@ -101,6 +101,7 @@ struct Conv3P {
     //   x = mask * Mish(GN(X)) + pro_res   (res_conv shortcut, diffusion.py:67-71), [H*W][Cin] like X;
     // the kernel also writes x for its own output pixels to pro_xout ([H*W][Cin]) for the later consumers.
     const float* pro_res; float* pro_xout;
+    int xout_lp;                                             // pro_xout is written in the mode's 16-bit type (strip forms only: its reader is LinKvCtxP::res_lp)
     // pro_res recomputed instead of read (res2_w != null, pro_res == null; Cin == 64): the shortcut of the U-Net's FIRST
     // ResnetBlock is res_conv((mu, c_in*x[, spk]) * mask), a 1x1 conv of 2-3 input planes (diffusion.py:70,171-175) - two or
     // three FMAs per value from planes that stay in cache, against 4 B written by the first conv and read back here.
@@ -121,6 +122,7 @@ bool conv3x3_bf16_tail_supported(int C);     // pro_res form (Cin == Cout == C)
 bool conv3x3_bf16_res_supported(int Cin, int Cout);   // res_w form (fused 1x1 shortcut)
 bool conv3x3_bf16_xb_supported(int Cin, int Cout);    // x_bf16 form (bf16 input under a GroupNorm prologue)
 bool conv3x3_plain_lp_in_supported(int H, int W, int B, int Cin, int Cout);   // a plain (no prologue) conv of this shape can read a 16-bit input
+bool conv3x3_strip_form(const Conv3P& p);              // this launch runs on one of the strip-walking throughput forms (the ones that implement Conv3P::xout_lp)
 bool conv3x3_res2_form(int H, int W, int B);           // a 64 -> 64 fused-tail conv of this grid runs on the form that implements res2_*
 void launch_conv3x3_lp(const Conv3P& p, int precision, hipStream_t st);   // picks the strip-streaming form (conv3x3_stream.hip) for large grids
 
@@ -204,14 +206,17 @@ struct LinKvCtxP { const float* X; int ldx; int x_coff; long xb; int npix; int C
                    const float* H2; const gnfix_t* gn_stats; const float* gamma; const float* beta;
                    const float* res; int ldres; long resb; int res_under_mask;
                    const float* mask; int mask_ws; long mask_bstride; int W; float* Xout;
-                   int h2_bf16; };                          // H2 is bf16 [npix][C]
+                   int h2_bf16;                             // H2 is bf16 [npix][C]
+                   int res_lp;                              // res is stored in the mode's 16-bit type [npix][C] (written by Conv3P::xout_lp)
+                   int xout_lp; };                          // Xout is written in the mode's 16-bit type (its one reader, the tail kernel, takes LinOut2P::x_lp)
 void launch_linattn_kvctx(const LinKvCtxP& p, int precision, hipStream_t st);
 struct LinMergeP { const float* part_m; const float* part_s; const float* part_c; int nblk;
                    const float* Wout; const float* g; int C; void* W2; int B; };       // Wout fp32 [C][128]
 void launch_linattn_merge(const LinMergeP& p, int precision, hipStream_t st);
 struct LinOut2P { const float* X; int ldx; int x_coff; long xb; int npix; int C; const void* Wq; const void* W2;
                   const float* bias; float* Y; int ldy; int y_coff; long yb; int B; // Wq bf16 in MFMA fragment order (launch_pack_lp_frag_nk)
-                  int y_lp; };      // 1: Y is stored in the mode's 16-bit type (throughput form only: linattn_out2_lp_out_supported)
+                  int y_lp;         // 1: Y is stored in the mode's 16-bit type (throughput form only: linattn_out2_lp_out_supported)
+                  int x_lp; };      // 1: X is stored in the mode's 16-bit type [npix][C] (throughput form only; written by LinKvCtxP::xout_lp)
 void launch_linattn_out2(const LinOut2P& p, int precision, hipStream_t st);
 bool linattn_out2_lp_out_supported(int npix, int B);
 

@@ -68,6 +68,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 ? 2
     float ga_pre = 0.f, be_pre = 0.f;                       // GroupNorm affine of channel tid, requested with the first loads
     if constexpr (PRO) { if (tid < C) { ga_pre = p.gamma[tid]; be_pre = p.beta[tid]; } }
     const bool hb = PRO && p.h2_bf16 != 0;                 // H2 stored as bf16: xa holds the 8 raw values until they are used
+    const bool rlp = PRO && p.res_lp != 0;                 // the residual rows likewise (ra holds 8 raw 16-bit values)
+    const unsigned short* Rh = (PRO && p.res) ? reinterpret_cast<const unsigned short*>(p.res) + (long)b * p.resb : nullptr;
     const unsigned short* Xh = PRO ? reinterpret_cast<const unsigned short*>(p.H2) + (long)b * p.npix * C : nullptr;
     {
         const int pxr = min(px_base + i, p.npix - 1);
@@ -84,11 +86,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 ? 2
         }
         if constexpr (PRO) {
             if (R) {
-                const float* rr = R + (long)pxr * p.ldres + hh * 8;
+                if (rlp) {
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    ra[ks] = *reinterpret_cast<const float4*>(rr + ks * 16);
-                    rc[ks] = *reinterpret_cast<const float4*>(rr + ks * 16 + 4);
+                    for (int ks = 0; ks < KS; ++ks) { ra[ks] = *reinterpret_cast<const float4*>(Rh + (long)pxr * p.ldres + hh * 8 + ks * 16); rc[ks] = ra[ks]; }
+                } else {
+                    const float* rr = R + (long)pxr * p.ldres + hh * 8;
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) {
+                        ra[ks] = *reinterpret_cast<const float4*>(rr + ks * 16);
+                        rc[ks] = *reinterpret_cast<const float4*>(rr + ks * 16 + 4);
+                    }
                 }
             }
             mkv = mrow[(pxr % p.W) * p.mask_ws];
@@ -135,7 +142,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 ? 2
                 const float4 sh0 = *reinterpret_cast<const float4*>(gsh_s + ks * 16 + hh * 8), sh1 = *reinterpret_cast<const float4*>(gsh_s + ks * 16 + hh * 8 + 4);
                 const float gsc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
                 const float gsh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
-                if (R) { r_[0] = ra[ks].x; r_[1] = ra[ks].y; r_[2] = ra[ks].z; r_[3] = ra[ks].w; r_[4] = rc[ks].x; r_[5] = rc[ks].y; r_[6] = rc[ks].z; r_[7] = rc[ks].w; }
+                if (R) {
+                    if (rlp) {
+                        const unsigned u0 = __float_as_uint(ra[ks].x), u1 = __float_as_uint(ra[ks].y), u2 = __float_as_uint(ra[ks].z), u3 = __float_as_uint(ra[ks].w);
+                        r_[0] = lp_lo(u0); r_[1] = lp_hi(u0); r_[2] = lp_lo(u1); r_[3] = lp_hi(u1); r_[4] = lp_lo(u2); r_[5] = lp_hi(u2); r_[6] = lp_lo(u3); r_[7] = lp_hi(u3);
+                    } else { r_[0] = ra[ks].x; r_[1] = ra[ks].y; r_[2] = ra[ks].z; r_[3] = ra[ks].w; r_[4] = rc[ks].x; r_[5] = rc[ks].y; r_[6] = rc[ks].z; r_[7] = rc[ks].w; }
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const float t = fmaf(v[j], gsc[j], gsh[j]);
@@ -146,8 +158,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 ? 2
                 }
                 xa[ks] = make_float4(v[0], v[1], v[2], v[3]); xc[ks] = make_float4(v[4], v[5], v[6], v[7]);
                 if (live) {
-                    *reinterpret_cast<float4*>(xo + ks * 16) = xa[ks];
-                    *reinterpret_cast<float4*>(xo + ks * 16 + 4) = xc[ks];
+                    if (p.xout_lp) {       // 16-bit x for the tail kernel: its q operand rounds x the same way, its residual term reads the rounded value
+                        u16* xh = reinterpret_cast<u16*>(p.Xout) + ((long)b * p.npix + min(px0 + i, p.npix - 1)) * C + hh * 8 + ks * 16;
+                        *reinterpret_cast<uint4*>(xh) = make_uint4(pack2_lp(v[0], v[1]), pack2_lp(v[2], v[3]), pack2_lp(v[4], v[5]), pack2_lp(v[6], v[7]));
+                    } else {
+                        *reinterpret_cast<float4*>(xo + ks * 16) = xa[ks];
+                        *reinterpret_cast<float4*>(xo + ks * 16 + 4) = xc[ks];
+                    }
                 }
             }
         }
@@ -173,11 +190,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 ? 2
             }
             if constexpr (PRO) {
                 if (R) {
-                    const float* rr = R + (long)pxr * p.ldres + hh * 8;
+                    if (rlp) {
 #pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) {
-                        ra[ks] = *reinterpret_cast<const float4*>(rr + ks * 16);
-                        rc[ks] = *reinterpret_cast<const float4*>(rr + ks * 16 + 4);
+                        for (int ks = 0; ks < KS; ++ks) { ra[ks] = *reinterpret_cast<const float4*>(Rh + (long)pxr * p.ldres + hh * 8 + ks * 16); rc[ks] = ra[ks]; }
+                    } else {
+                        const float* rr = R + (long)pxr * p.ldres + hh * 8;
+#pragma unroll
+                        for (int ks = 0; ks < KS; ++ks) {
+                            ra[ks] = *reinterpret_cast<const float4*>(rr + ks * 16);
+                            rc[ks] = *reinterpret_cast<const float4*>(rr + ks * 16 + 4);
+                        }
                     }
                 }
                 mkv = mrow[(pxr % p.W) * p.mask_ws];
@@ -490,10 +512,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, C == 64 
     const float* X = p.X + (long)b * p.xb + p.x_coff;
     // coalesced tile load: chunk c = lane + 64k covers pixel c / (C/4), channels (c % (C/4)) * 4 .. +4
     float4 xin[NCH];
+    const bool xlp = p.x_lp != 0;                       // 16-bit X: chunk c = lane + 64k (k < NCH / 2) covers pixel c / (C/8), channels (c % (C/8)) * 8 .. +8
+    if (xlp) {
+        const u16* Xh = reinterpret_cast<const u16*>(p.X) + (long)b * p.xb + p.x_coff;
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-        const int c = lane + 64 * k, px = c / (C / 4), ch = (c % (C / 4)) * 4;
-        xin[k] = *reinterpret_cast<const float4*>(X + (long)min(px0 + px, p.npix - 1) * p.ldx + ch);
+        for (int k = 0; k < NCH / 2; ++k) {
+            const int c = lane + 64 * k, px = c / (C / 8), ch = (c % (C / 8)) * 8;
+            xin[k] = *reinterpret_cast<const float4*>(Xh + (long)min(px0 + px, p.npix - 1) * p.ldx + ch);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = lane + 64 * k, px = c / (C / 4), ch = (c % (C / 4)) * 4;
+            xin[k] = *reinterpret_cast<const float4*>(X + (long)min(px0 + px, p.npix - 1) * p.ldx + ch);
+        }
     }
     // A fragments of GEMM2 (all of W2 for this utterance: CT x 8 K-steps)
     const uint4* w2 = reinterpret_cast<const uint4*>(p.W2) + (long)b * CT * 8 * 64 + lane;
@@ -502,10 +534,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, C == 64 
     for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) w2f[ct][ks] = w2[(ct * 8 + ks) * 64];
+    if (xlp) {
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-        const int c = lane + 64 * k, px = c / (C / 4), ch = (c % (C / 4)) * 4;
-        *reinterpret_cast<float4*>(xs + px * LDX + ch) = xin[k];
+        for (int k = 0; k < NCH / 2; ++k) {
+            const int c = lane + 64 * k, px = c / (C / 8), ch = (c % (C / 8)) * 8;
+            const unsigned u0 = __float_as_uint(xin[k].x), u1 = __float_as_uint(xin[k].y), u2 = __float_as_uint(xin[k].z), u3 = __float_as_uint(xin[k].w);
+            *reinterpret_cast<float4*>(xs + px * LDX + ch) = make_float4(lp_lo(u0), lp_hi(u0), lp_lo(u1), lp_hi(u1));
+            *reinterpret_cast<float4*>(xs + px * LDX + ch + 4) = make_float4(lp_lo(u2), lp_hi(u2), lp_lo(u3), lp_hi(u3));
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = lane + 64 * k, px = c / (C / 4), ch = (c % (C / 4)) * 4;
+            *reinterpret_cast<float4*>(xs + px * LDX + ch) = xin[k];
+        }
     }
     __builtin_amdgcn_wave_barrier();
     // B fragments of GEMM1: lane (pixel column i, half hh) holds x[px][ks*16 + hh*8 .. +8]
