@@ -202,12 +202,20 @@ __global__ __launch_bounds__(256, 3) void attn_direct_ring_kernel(const AttnDire
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
     const int ksplit = p.ksplit > 1 ? p.ksplit : 1;
-    const int h = blockIdx.y, b = blockIdx.z / ksplit, sp = blockIdx.z % ksplit;
     const int N = p.N;
     const int ntiles = (N + 31) / 32;
+    // p.xcd_map (launcher: 1-D grid, 2 B ksplit a multiple of 8): workgroup L runs on XCD L % 8; all query groups of one
+    // (batch element, split, head) go to ONE XCD, so its K and V^T (665 KB at N = 1300) are fetched into one L2 instead of all
+    // eight (PMC at DEX B = 32: 411 MB per launch against ~ 90 MB algorithmic before)
+    int h, z, qg;
+    if (p.xcd_map) {
+        const int nq = (ntiles + 3) / 4, slot = (int)blockIdx.x >> 3, g = ((int)blockIdx.x & 7) + 8 * (slot / nq);
+        qg = slot % nq; h = g & 1; z = g >> 1;
+    } else { qg = blockIdx.x; h = blockIdx.y; z = blockIdx.z; }
+    const int b = z / ksplit, sp = z % ksplit;
     const int t_lo = (int)((long)ntiles * sp / ksplit), t_hi = (int)((long)ntiles * (sp + 1) / ksplit);
-    const int qt = min((int)blockIdx.x * 4 + wave, ntiles - 1);
-    const bool live_wave = (int)blockIdx.x * 4 + wave < ntiles;
+    const int qt = min(qg * 4 + wave, ntiles - 1);
+    const bool live_wave = qg * 4 + wave < ntiles;
     const int q0 = qt * 32;
     const long hb = (long)b * 2 + h;
     const uint4* Qg = reinterpret_cast<const uint4*>(p.Qh) + hb * p.Npad * (HD / 8) + lane;
@@ -337,7 +345,11 @@ void launch_attention_direct(const AttnDirectP& p, hipStream_t st) {
     }
     if (attention_direct_batch_regime(p.N, p.B)) {          // batch regime (the caller sized ksplit with attention_direct_ksplit)
         dim3 grid(((p.N + 31) / 32 + 3) / 4, 2, p.B * (p.ksplit > 1 ? p.ksplit : 1));
-        hipLaunchKernelGGL(attn_direct_ring_kernel, grid, dim3(256), 0, st, p);
+        AttnDirectP q = p;
+        const char* e = getenv("DEX_XCD_MAP");               // read per call (part of the graph cache key); 0: the plain 3-D grid
+        q.xcd_map = ((2 * grid.z) % 8 == 0 && !(e && e[0] == '0')) ? 1 : 0;
+        if (q.xcd_map) grid = dim3(grid.x * 2 * grid.z);
+        hipLaunchKernelGGL(attn_direct_ring_kernel, grid, dim3(256), 0, st, q);
         return;
     }
     dim3 grid((p.N + 31) / 32, 2, p.B * (p.ksplit > 1 ? p.ksplit : 1));

@@ -1552,7 +1552,7 @@ int dex_sample(DexCtx* x, const DexSampleArgs* a, dex_stream_t stream) {
                                  (uint64_t)(uintptr_t)(a->S_churn > 0.f ? a->noise_dev : nullptr)};
     for (float v : {a->S_churn, a->S_min, a->S_max, a->S_noise}) { uint32_t u; memcpy(&u, &v, 4); key.push_back(u); }
     for (int j = 0; j < a->n_ref; ++j) key.push_back((uint64_t)(uintptr_t)a->ref_skips_dev[j]);
-    for (const char* e : {"DEX_CONV_STREAM", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN", "DEX_DIT_CLUSTER", "DEX_DIT_CLUSTER_LOCAL", "DEX_ATTN_X_LP", "DEX_RES_X_LP", "DEX_DEBUG_DROP_HANDOFF", "DEX_PATCH_FUSED"}) {     // knobs read at enqueue time
+    for (const char* e : {"DEX_CONV_STREAM", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN", "DEX_DIT_CLUSTER", "DEX_DIT_CLUSTER_LOCAL", "DEX_ATTN_X_LP", "DEX_RES_X_LP", "DEX_XCD_MAP", "DEX_DEBUG_DROP_HANDOFF", "DEX_PATCH_FUSED"}) {     // knobs read at enqueue time
         const char* v = getenv(e);
         key.push_back(v ? (uint64_t)atoi(v) + 1 : 0);
     }

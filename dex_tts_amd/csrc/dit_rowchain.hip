@@ -183,7 +183,12 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
     const int i = lane & 31, hh = lane >> 5;
     // row tiles are per batch element (never across utterances): tile t of element b covers tokens [32 t, 32 t + 32)
     const int N = p.rows_per_batch, tpb = (N + RC_ROWS - 1) / RC_ROWS;
-    const int b = blockIdx.x / tpb, n0 = (blockIdx.x - b * tpb) * RC_ROWS;
+    // p.xcd_map (launcher: in-kernel attention, B a multiple of 8): workgroup L runs on XCD L % 8, so element b's row tiles go to
+    // XCD b % 8 - the K / V^T of an utterance (665 KB at N = 650) are fetched into ONE L2 instead of all eight (PMC at GeDEX B = 32:
+    // 286 MB per launch against 113 MB algorithmic before)
+    int b, n0;
+    if (p.xcd_map) { const int slot = (int)blockIdx.x >> 3; b = ((int)blockIdx.x & 7) + 8 * (slot / tpb); n0 = (slot % tpb) * RC_ROWS; }
+    else { b = blockIdx.x / tpb; n0 = (blockIdx.x - b * tpb) * RC_ROWS; }
     const long mb = (long)b * N;                               // first global row of this batch element
     const int step = p.step;
     const float* ada = p.ada + (long)step * 6 * RC_H;
@@ -1298,8 +1303,12 @@ void launch_dit_rowchain(const DitChainP& p, hipStream_t st) {
         }
     }
     dim3 grid(p.B * ((p.rows_per_batch + RC_ROWS - 1) / RC_ROWS));
-    if (p.attn_inline && !p.qkv_only)
-        hipLaunchKernelGGL(dit_rowchain_kernel<true>, grid, dim3(RC_NW * 64), RC_LDS_ATTN > RC_LDS ? RC_LDS_ATTN : RC_LDS, st, p);
+    if (p.attn_inline && !p.qkv_only) {
+        DitChainP q = p;
+        const char* e = getenv("DEX_XCD_MAP");               // read per call (part of the graph cache key); 0: the plain b-major order
+        q.xcd_map = (p.B % 8 == 0 && !(e && e[0] == '0')) ? 1 : 0;
+        hipLaunchKernelGGL(dit_rowchain_kernel<true>, grid, dim3(RC_NW * 64), RC_LDS_ATTN > RC_LDS ? RC_LDS_ATTN : RC_LDS, st, q);
+    }
     else
         hipLaunchKernelGGL(dit_rowchain_kernel<false>, grid, dim3(RC_NW * 64), RC_LDS, st, p);
 }

@@ -265,6 +265,7 @@ struct DitChainP { const float* O; int ksplit; long o_sstride; const float* ml; 
                    // cluster form (small grids, dit_rowchain_cluster_kernel): exchange slabs, flags (zeroed once per call) and the
                    // launch's epoch (unique within the call, never 0); err: device word set when a hand-off wait timed out
                    float* xslab; unsigned* xflag; unsigned epoch; int* xerr;
+                   int xcd_map;                             // set by the launcher: row tiles of batch element b run on XCD b % 8 (in-kernel attention, B % 8 == 0)
                    int xlocal;                              // 1: the members of a cluster share an XCD (hand-offs through its L2; grid padded to rounds of 8 clusters)
                    int xdrop; };                            // tests only (DEX_DEBUG_DROP_HANDOFF): 1 member 3 never raises its flags -> the peers' waits time out; 2 L2-scope hand-offs across XCDs
 // cluster form of the row chain: workgroups per 32-row tile, bytes of exchange slab / flag words per tile, and whether a launch
@@ -277,7 +278,8 @@ bool dit_rowchain_cluster_local_fits(int rows_per_batch, int B);
 bool dit_rowchain_supported(int hidden, int mlp_hidden);
 // Softmax attention on the row chain's bf16 operands (2 heads x 128): no staging, K / V^T / Q fragments are read
 // straight from global memory.  O: fp32 [ksplit][B][N][256] partials + ml (merged by the next row chain launch).
-struct AttnDirectP { const void *Qh, *Kh, *Vt; int N, Npad, B; float* O; long o_sstride; float* ml; int ksplit; long long* dbg; };
+struct AttnDirectP { const void *Qh, *Kh, *Vt; int N, Npad, B; float* O; long o_sstride; float* ml; int ksplit; long long* dbg;
+                     int xcd_map; };        // set by the launcher (shared-ring kernel): 1-D grid, the query groups of one (element, split, head) share an XCD
 void launch_attention_direct(const AttnDirectP& p, int precision, hipStream_t st);
 bool attention_direct_batch_regime(int N, int B);     // shared-ring kernel (many query tiles) vs key-splitting waves (few)
 int attention_direct_ksplit(int N, int B);             // key split the batch regime wants for an even load

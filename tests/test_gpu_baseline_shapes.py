@@ -285,3 +285,26 @@ def test_residual_stream_16bit_stores_error(name, kw, prec):
     assert len({err["00"], err["10"], err["11"]}) == 3                      # each store really changed form
     assert err["11"][0] <= LOWP[prec]["sampler"][0] and err["11"][1] <= LOWP[prec]["sampler"][1], err
     assert err["11"][1] <= 1.15 * err["00"][1], err
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("gedex_lj", dict(B=32, T=512, lengths=[512 - 9 * i for i in range(32)])),      # fused DiT block with the in-kernel attention: element b's row tiles on XCD b % 8
+    ("dex_vctk", dict(B=32, T=512, lengths=[512 - 9 * i for i in range(32)], Tr=60, Ts=60)),   # N = 1300: the attention as its own launch (shared-ring kernel, 1-D grid)
+    ("gedex_lj", dict(B=8, T=512, lengths=[512 - 30 * i for i in range(8)])),       # one element per XCD
+])
+def test_xcd_aware_block_order_is_bit_identical(name, kw):
+    """DEX_XCD_MAP (default on where 8 divides the number of (element, head) items): the workgroups that stream one utterance's K
+    and V^T run on one XCD, so the operands cross the fabric once instead of eight times.  Only the order of the work changes."""
+    cfg, eng, w = U.engine_for(name)
+    case = U.make_case(cfg, **kw)
+    mu, mask, z = (torch.from_numpy(case[k]).cuda() for k in ("mu", "mask", "z"))
+    set_prec(eng, "bf16")
+    try:
+        ys = []
+        for flag in ("0", "1"):
+            os.environ["DEX_XCD_MAP"] = flag
+            ys.append(eng.sample(z, mask, mu, 3, **U.engine_kwargs(case)).cpu().numpy())
+    finally:
+        os.environ.pop("DEX_XCD_MAP", None)
+        eng.set_precision("fp32")
+    assert np.isfinite(ys[0]).all() and np.array_equal(ys[0], ys[1]), float(np.abs(ys[0] - ys[1]).max())
