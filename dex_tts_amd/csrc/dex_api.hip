@@ -1436,7 +1436,7 @@ int enqueue_heun(DexCtx* x, const DexSampleArgs* a, hipStream_t st) {
         R.fin_mode = corrector ? 2 : (last ? 0 : 1);
         R.step(nullptr, (corrector || last) ? P.xbuf : P.xprime);
     }
-    HIPCHK(x, hipMemcpyAsync(a->out_dev, P.xbuf, (size_t)a->B * 80 * a->T * sizeof(float), hipMemcpyDeviceToDevice, st));
+    R.run("copy_out", 0, 8.0 * nx, [&] { launch_scale_copy(P.xbuf, a->out_dev, nx, nullptr, st); });      // (a kernel node like every other link of a captured call: see zero_fill)
     return DEX_OK;
 }
 
@@ -1466,7 +1466,7 @@ int enqueue_euler(DexCtx* x, const DexSampleArgs* a, hipStream_t st) {
             R.run("churn_noise", 2.0 * nx, 12.0 * nx, [&] { launch_add_noise(P.xbuf, a->noise_dev + (long)i * nx, P.ncoef + i, nx, st); });
         R.step(nullptr, P.xbuf);
     }
-    HIPCHK(x, hipMemcpyAsync(a->out_dev, P.xbuf, (size_t)a->B * 80 * a->T * sizeof(float), hipMemcpyDeviceToDevice, st));
+    R.run("copy_out", 0, 8.0 * nx, [&] { launch_scale_copy(P.xbuf, a->out_dev, nx, nullptr, st); });      // (a kernel node like every other link of a captured call: see zero_fill)
     return DEX_OK;
 }
 
