@@ -312,12 +312,22 @@ __global__ __launch_bounds__(256, 3) void attn_direct_ring_kernel(const AttnDire
     if (live_wave && q0 + i < N) {
         const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
         float* op = p.O + (long)sp * p.o_sstride + ((long)b * N + q0 + i) * (2 * HD) + h * HD + 4 * hh;
+        if (p.o_lp) {          // (uniform; ksplit == 1) the projection GEMM of the row chain rounds O to the operand type: store it so
+            unsigned short* oh = reinterpret_cast<unsigned short*>(p.O) + ((long)b * N + q0 + i) * (2 * HD) + h * HD + 4 * hh;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq)
-                *reinterpret_cast<float4*>(op + t * 32 + 8 * rq) =
-                    make_float4(o[t][rq * 4 + 0] * inv, o[t][rq * 4 + 1] * inv, o[t][rq * 4 + 2] * inv, o[t][rq * 4 + 3] * inv);
+                for (int rq = 0; rq < 4; ++rq)
+                    *reinterpret_cast<uint2*>(oh + t * 32 + 8 * rq) =
+                        make_uint2(pack2_lp(o[t][rq * 4 + 0] * inv, o[t][rq * 4 + 1] * inv), pack2_lp(o[t][rq * 4 + 2] * inv, o[t][rq * 4 + 3] * inv));
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq)
+                    *reinterpret_cast<float4*>(op + t * 32 + 8 * rq) =
+                        make_float4(o[t][rq * 4 + 0] * inv, o[t][rq * 4 + 1] * inv, o[t][rq * 4 + 2] * inv, o[t][rq * 4 + 3] * inv);
+        }
         if (p.ml && hh == 0) {
             float* ml = p.ml + ((((long)sp * p.B + b) * 2 + h) * N + q0 + i) * 2;
             ml[0] = m_run; ml[1] = l_run;

@@ -1086,15 +1086,21 @@ struct Runner {
                 // rings and pay for the extra launch and the fp32 O round trip, so the automatic switch wants N >= 1024 too)
                 const bool separate = sep_env ? atoi(sep_env) != 0 : (batch_regime && N >= 1024);
                 int ks = 1;
+                bool o_lp = false;
                 if (separate) {
                     const long blocks = (long)((N + 31) / 32) * 2 * B;
                     const int ntiles = (N + 31) / 32;
                     ks = batch_regime ? attention_direct_ksplit(N, B)
                                       : (int)std::max<long>(1, std::min<long>(std::min<long>(768 / blocks, (ntiles + 7) / 8), ATT_KSPLIT_MAX));
                     AttnDirectP ad{ch.Qin, ch.Kin, ch.Vin, N, P.Npad, B, P.ao, (long)B * N * hid, ks > 1 ? P.att_ml : nullptr, ks, nullptr};
-                    run("dit_attention", 4.0 * B * (double)N * N * hid, 2.0 * 3 * B * N * hid + 4.0 * B * N * hid * ks, [&] { launch_attention_direct(ad, x->precision, st); });
+                    // O has one reader, the row chain's projection GEMM, which rounds it to the operand type: with one key split on the
+                    // batch forms (shared-ring attention -> 64-row chain) it is stored in that type - same bits, half the bytes
+                    // (DEX_LP_INTER=0 keeps fp32)
+                    o_lp = batch_regime && ks == 1 && lp_inter_cur && dit_rowchain64_form(N, B, 0);
+                    ad.o_lp = o_lp ? 1 : 0;
+                    run("dit_attention", 4.0 * B * (double)N * N * hid, 2.0 * 3 * B * N * hid + (o_lp ? 2.0 : 4.0) * B * N * hid * ks, [&] { launch_attention_direct(ad, x->precision, st); });
                 }
-                ch.attn_inline = separate ? 0 : 1;
+                ch.attn_inline = separate ? 0 : 1; ch.o_lp = o_lp ? 1 : 0;
                 const bool last = k + 1 == c.dit_depth;
                 ch.O = P.ao; ch.ksplit = ks; ch.o_sstride = (long)B * N * hid; ch.ml = P.att_ml;
                 ch.Wp = x->frag_of().at(w.wproj); ch.W1 = x->frag_of().at(w.wfc1); ch.W2 = x->frag_of().at(w.wfc2);

@@ -581,6 +581,15 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain64_kernel(const DitCha
             const int n = min(n0 + row, N - 1);
             const float* src = p.O + (mb + n) * RC_H + seg * 4;
             float4 v[4];
+            if (p.o_lp) {              // (uniform) already in the operand type: straight into the A tile
+                const u16* sh_ = reinterpret_cast<const u16*>(p.O) + (mb + n) * RC_H + seg * 4;
+                uint2 o4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o4[q] = *reinterpret_cast<const uint2*>(sh_ + q * 64);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(As + row * A_LD + q * 64 + seg * 4) = o4[q];
+                continue;
+            }
             if (p.ksplit <= 1) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(src + q * 64);
@@ -1256,6 +1265,11 @@ bool dit_rowchain_cluster_local_fits(int rows_per_batch, int B) {
 }
 
 bool dit_rowchain_supported(int hidden, int mlp_hidden) { return hidden == RC_H && mlp_hidden == RC_MLP; }
+bool dit_rowchain64_form(int rows_per_batch, int B, int attn_inline) {
+    static const int m64 = getenv("DEX_ROWCHAIN64") ? atoi(getenv("DEX_ROWCHAIN64")) : 1;
+    const long wg32 = (long)B * ((rows_per_batch + RC_ROWS - 1) / RC_ROWS);
+    return m64 && !attn_inline && (m64 == 2 || wg32 >= 768);
+}
 
 void launch_dit_rowchain(const DitChainP& p, hipStream_t st) {
     if (p.xslab && (p.attn_inline || p.qkv_only) && dit_rowchain_cluster_form(p.rows_per_batch, p.B)) {
@@ -1289,9 +1303,7 @@ void launch_dit_rowchain(const DitChainP& p, hipStream_t st) {
         attr = true;
     }
     {   // batch regime with the attention as its own launch: the 64-row form (DEX_ROWCHAIN64=0: never, 2: whenever attention is separate)
-        static const int m64 = getenv("DEX_ROWCHAIN64") ? atoi(getenv("DEX_ROWCHAIN64")) : 1;
-        const long wg32 = (long)p.B * ((p.rows_per_batch + RC_ROWS - 1) / RC_ROWS);
-        if (m64 && !p.attn_inline && (m64 == 2 || wg32 >= 768)) {
+        if (dit_rowchain64_form(p.rows_per_batch, p.B, p.attn_inline)) {
             static bool attr64 = false;
             if (!attr64) {
                 hipFuncSetAttribute(reinterpret_cast<const void*>(&dit_rowchain64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC64_LDS);

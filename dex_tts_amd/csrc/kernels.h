@@ -265,6 +265,7 @@ struct DitChainP { const float* O; int ksplit; long o_sstride; const float* ml; 
                    // cluster form (small grids, dit_rowchain_cluster_kernel): exchange slabs, flags (zeroed once per call) and the
                    // launch's epoch (unique within the call, never 0); err: device word set when a hand-off wait timed out
                    float* xslab; unsigned* xflag; unsigned epoch; int* xerr;
+                   int o_lp;                                // O is stored in the mode's 16-bit type [M][hidden] (ksplit == 1, 64-row form; AttnDirectP::o_lp)
                    int xcd_map;                             // set by the launcher: row tiles of batch element b run on XCD b % 8 (in-kernel attention, B % 8 == 0)
                    int xlocal;                              // 1: the members of a cluster share an XCD (hand-offs through its L2; grid padded to rounds of 8 clusters)
                    int xdrop; };                            // tests only (DEX_DEBUG_DROP_HANDOFF): 1 member 3 never raises its flags -> the peers' waits time out; 2 L2-scope hand-offs across XCDs
@@ -273,12 +274,14 @@ struct DitChainP { const float* O; int ksplit; long o_sstride; const float* ml; 
 constexpr int DIT_CLUSTER = 4;
 constexpr size_t DIT_CLUSTER_SLAB_FLOATS = 2 * DIT_CLUSTER * (32 * 256 + 256);
 constexpr size_t DIT_CLUSTER_FLAG_WORDS = 2 * DIT_CLUSTER;
+bool dit_rowchain64_form(int rows_per_batch, int B, int attn_inline);     // the 64-row batch form takes this launch (the one that implements DitChainP::o_lp)
 bool dit_rowchain_cluster_form(int rows_per_batch, int B);
 bool dit_rowchain_cluster_local_fits(int rows_per_batch, int B);
 bool dit_rowchain_supported(int hidden, int mlp_hidden);
 // Softmax attention on the row chain's bf16 operands (2 heads x 128): no staging, K / V^T / Q fragments are read
 // straight from global memory.  O: fp32 [ksplit][B][N][256] partials + ml (merged by the next row chain launch).
 struct AttnDirectP { const void *Qh, *Kh, *Vt; int N, Npad, B; float* O; long o_sstride; float* ml; int ksplit; long long* dbg;
+                     int o_lp;              // O (ksplit == 1, shared-ring kernel) is written in the mode's 16-bit type: its reader, the 64-row chain, rounds it so anyway (DitChainP::o_lp)
                      int xcd_map; };        // set by the launcher (shared-ring kernel): 1-D grid, the query groups of one (element, split, head) share an XCD
 void launch_attention_direct(const AttnDirectP& p, int precision, hipStream_t st);
 bool attention_direct_batch_regime(int N, int B);     // shared-ring kernel (many query tiles) vs key-splitting waves (few)

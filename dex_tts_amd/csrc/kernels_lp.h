@@ -35,6 +35,7 @@ bool attention_direct_batch_regime(int N, int B);
 int attention_direct_ksplit(int N, int B);
 // DiT row chain (dit_rowchain.hip) and its weight packing
 bool dit_rowchain_supported(int hidden, int mlp_hidden);
+bool dit_rowchain64_form(int rows_per_batch, int B, int attn_inline);
 bool dit_rowchain_cluster_form(int rows_per_batch, int B);
 bool dit_rowchain_cluster_local_fits(int rows_per_batch, int B);
 void launch_dit_rowchain(const DitChainP& p, hipStream_t st);

@@ -28,6 +28,7 @@ bool conv_down_supported(int C, int H, int W, int ldx, int ldy, int x_coff) { re
 bool convt_up_supported(int C, int H, int W, int ldx, int ldy) { return bf16::convt_up_supported(C, H, W, ldx, ldy); }
 bool patch_embed_fused_supported(int k, int C, int hid, long ntok) { return bf16::patch_embed_fused_supported(k, C, hid, ntok); }
 bool dit_rowchain_supported(int hidden, int mlp_hidden) { return bf16::dit_rowchain_supported(hidden, mlp_hidden); }
+bool dit_rowchain64_form(int rows_per_batch, int B, int attn_inline) { return bf16::dit_rowchain64_form(rows_per_batch, B, attn_inline); }
 bool dit_rowchain_cluster_form(int rows_per_batch, int B) { return bf16::dit_rowchain_cluster_form(rows_per_batch, B); }
 bool dit_rowchain_cluster_local_fits(int rows_per_batch, int B) { return bf16::dit_rowchain_cluster_local_fits(rows_per_batch, B); }
 
