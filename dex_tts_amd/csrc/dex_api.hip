@@ -1232,8 +1232,9 @@ struct Runner {
             const bool defer = linattn_fused(s.C);
             resblock(x->down_res[i][1], s, r0, P.tadd_down[2 * i + 1], s.r1out, false, defer ? &tail : nullptr, defer0 ? &t0 : nullptr);
             TD r1{s.r1out, s.C, 0, s.C};
-            // the Downsample conv is this output's only reader (the reference's hiddens.append of this level is never popped)
-            const bool t1_lp = lp_inter && i < ns - 1 && linattn_fused(s.C) && linattn_out2_lp_out_supported((int)s.npix, B) && x->lp_of().count(x->down_ds_w[i]);
+            // the Downsample conv is this output's only reader at level 0 (the reference's hiddens.append of this level is never
+            // popped; deeper levels live in the up path's concatenation buffer, which is read as fp32)
+            const bool t1_lp = lp_inter && i == 0 && i < ns - 1 && linattn_fused(s.C) && linattn_out2_lp_out_supported((int)s.npix, B) && x->lp_of().count(x->down_ds_w[i]);
             linattn(x->down_lin[i], s, r1, s.attn_out, s.attn_ld, s.attn_coff, defer ? &tail : nullptr, t1_lp);
             char nm[16]; snprintf(nm, sizeof nm, "down%d", i);
             tap(nm, s.attn_out + s.attn_coff, B * s.npix, s.C, s.attn_ld);
