@@ -412,6 +412,16 @@ bool conv3x3_plain_lp_in_supported(int H, int W, int B, int Cin, int Cout) {
     return w8 && tiles4 >= 256 && Cin == 64 && Cout == 128;
 }
 
+// the up path's first conv (2C -> C with the fused 1x1 shortcut, plain input) reads a 16-bit concatenation buffer only on the
+// eight-wave patch forms below (same conditions as launch_conv3x3_lp's branches for res_w, Cout == 64, Cin >= 128)
+bool conv3x3_cat_lp_in_supported(int H, int W, int B, int Cin, int Cout) {
+    if (Cout != 64 || Cin < 128 || Cin % 128 != 0) return false;
+    static const int w8 = getenv("DEX_CONV_W8") ? atoi(getenv("DEX_CONV_W8")) : 1;
+    static const long small_max = getenv("DEX_CONV_SMALL_MAX") ? atol(getenv("DEX_CONV_SMALL_MAX")) : 256;
+    const long tiles4 = (long)((W + 31) / 32) * ((H + 3) / 4) * B;
+    return w8 && tiles4 >= small_max;
+}
+
 void launch_conv3x3_lp(const Conv3P& p, hipStream_t st) {
     if (const int tpw = conv3x3_stream_tiles(p)) { launch_conv3x3_stream(p, tpw, st); return; }   // batched synthesis
     if (conv3x3_regw_form(p)) { launch_conv3x3_regw(p, st); return; }                              // 128-channel layers, batched synthesis
@@ -444,10 +454,14 @@ void launch_conv3x3_lp(const Conv3P& p, hipStream_t st) {
         return;
     }
     if (th8 && w8 && !small && p.res_w && p.Cout == 64 && p.Cin >= 128 && !p.pro_stats && p.H % 8 == 0 && (long)((p.W + 31) / 32) * (p.H / 8) * p.B >= 512) {
-        launch_c3<128, 64, 64, 8, false, true, false, 8>(p, st);      // 8-row tiles: a wave owns one row x 64 channels (32 at four rows)
+        // 8-row tiles: a wave owns one row x 64 channels (32 at four rows); x_bf16: the concatenation buffer in the mode's 16-bit type
+        p.x_bf16 ? launch_c3<128, 64, 64, 8, false, true, true, 8>(p, st) : launch_c3<128, 64, 64, 8, false, true, false, 8>(p, st);
         return;
     }
-    if (w8 && !small && p.res_w && p.Cout == 64 && p.Cin >= 128) { launch_c3<128, 64, 64, 4, false, true, false, 8>(p, st); return; }
+    if (w8 && !small && p.res_w && p.Cout == 64 && p.Cin >= 128) {
+        p.x_bf16 ? launch_c3<128, 64, 64, 4, false, true, true, 8>(p, st) : launch_c3<128, 64, 64, 4, false, true, false, 8>(p, st);
+        return;
+    }
     if (p.x_bf16) {       // raw conv output stored as bf16: the GroupNorm-prologue forms with Cin == Cout (conv3x3_bf16_xb_supported)
         if (tail_) {
             if (p.Cin == 64) { small ? launch_c3<64, 64, 64, 2, true, false, true>(p, st) : launch_c3<64, 64, 64, 4, true, false, true>(p, st); }

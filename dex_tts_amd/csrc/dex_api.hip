@@ -580,6 +580,7 @@ struct Plan {
     float *that, *hstep, *ncoef;             // churn tables per STEP: t_hat, h = t_next - t_hat, noise coefficient (edm.py:194-196)
     std::vector<StageBuf> down, up;
     std::vector<float*> cat;
+    void* cat16;                                             // 16-bit twin of cat[0] (n_stages == 2, batch regime: Runner::cat_lp)
     float *up_out, *hF;
     int Hm, Wm, Hf, Wt, N;
     float *pe0, *emb, *emb_pad, *pos_part, *tok, *xn, *qkv, *ao, *att_ml, *hmlp, *dbg_tok;
@@ -673,6 +674,8 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
     P.hsig = A.f((size_t)n + 2); P.htab = A.f((size_t)n + 2);
     P.that = A.f((size_t)n + 2); P.hstep = A.f((size_t)n + 2); P.ncoef = A.f((size_t)n + 2);
     P.cat.assign(c.n_stages - 1, nullptr);
+    P.cat16 = nullptr;
+    if (c.n_stages == 2) P.cat16 = A.take((size_t)B * (c.n_feats >> 1) * (d.T >> 1) * 2 * stage_dim(c, 1) * 2);
     for (int j = 0; j < c.n_stages - 1; ++j) {
         const int i = c.n_stages - 1 - j;
         P.cat[j] = A.f((size_t)B * (c.n_feats >> i) * (d.T >> i) * 2 * stage_dim(c, i));
@@ -946,8 +949,27 @@ struct Runner {
 
     // Residual(Rezero(LinearAttention)) (diffusion.py:74-102)
     bool lp_inter_cur = false;             // this step stores single-consumer activations in the mode's 16-bit type (step())
+    // The up path's concatenation buffer [skip | DiT output] has one reader that matters for bytes, the 2C -> C conv with its fused
+    // shortcut, which rounds x * mask to the operand type: at batch size (n_stages == 2) the attention tail writes a 16-bit copy of the
+    // skip half next to its fp32 output (the DiT front-end reads that one) and the unpatchify GEMM writes its half in 16 bit only -
+    // same bits, 0.25 GB less traffic per Euler step at GeDEX B = 32.  DEX_CAT_LP=0 keeps the fp32 buffer.
+    bool cat_lp = false;
+    // FinalLayer + unpatchify GEMM of the DiT (dit.py:97-110, 457-461)
+    IGemmP final_gemm(int mask_ws, float* out, int ldo, int ocoff) {
+        const DexConfig& c = x->cfg;
+        const int hid = c.dit_hidden, mid = mid_dim(c);
+        const bool fuse_lnf = x->lp() && ln_fusable(hid);
+        const int s2c = c.dit_stride * c.dit_stride * mid;
+        IGemmP fl = base_gemm(fuse_lnf ? P.tok : P.xn, hid, 0, P.Hf, P.Wt, hid, x->fl_w, s2c, x->fl_b, out, ldo, ocoff);
+        if (fuse_lnf) { fl.ln_shift = P.fin_mod; fl.ln_scale = P.fin_mod + hid; fl.ln_step_stride = 2L * hid; }
+        fl.unpatch_s = c.dit_stride; fl.unpatch_C = mid; fl.OHf = P.Hm; fl.OWf = P.Wm;
+        fl.c_bstride = (long)P.Hm * P.Wm * ldo;
+        fl.outmask = mask; fl.outmask_ws = mask_ws;
+        return fl;
+    }
     bool linattn_fused(int C) const { return x->lp() && (C == 64 || C == 128); }
-    void linattn(const LinW& w, const StageBuf& s, const TD& X, float* out, int ldo, int ocoff, const LinKvCtxP* tail = nullptr, bool out_lp = false) {
+    void linattn(const LinW& w, const StageBuf& s, const TD& X, float* out, int ldo, int ocoff, const LinKvCtxP* tail = nullptr, bool out_lp = false,
+                 void* out2_lp = nullptr, int ldo2 = 0, int ocoff2 = 0) {
         const long npix = s.npix; const int B = P.d.B;
         if (x->lp() && (X.C == 64 || X.C == 128)) {
             // fused: y = x + W2 (Wq x) + g*b  with  W2 = g Wout blockdiag(ctx^T)   (linattn_fused.hip)
@@ -969,8 +991,9 @@ struct Runner {
             run("linattn_kvctx", 2.0 * npix * B * (256.0 * X.C + 128 * 32), (tail ? (tail->h2_bf16 ? 10.0 : 12.0) - (xlp ? 2.0 : 0.0) : 4.0) * npix * X.C * B, [&] { launch_linattn_kvctx(k, x->precision, st); });
             LinMergeP mg{s.pm, s.ps, s.pc, nblk, w.wout_raw, w.g, X.C, s.mbf, B};
             run("linattn_merge", 2.0 * 128 * 32 * X.C * B, 4.0 * nblk * 4 * 1088 * B, [&] { launch_linattn_merge(mg, x->precision, st); });
-            LinOut2P o{X.p, X.ld, X.coff, npix * X.ld, (int)npix, X.C, w.wq_frag[x->lpi()], s.mbf, w.bias_eff, out, ldo, ocoff, npix * ldo, B, out_lp ? 1 : 0, xlp ? 1 : 0};
-            run("linattn_out", 4.0 * npix * B * 128.0 * X.C, ((out_lp ? 6.0 : 8.0) - (xlp ? 2.0 : 0.0)) * npix * X.C * B, [&] { launch_linattn_out2(o, x->precision, st); });
+            LinOut2P o{X.p, X.ld, X.coff, npix * X.ld, (int)npix, X.C, w.wq_frag[x->lpi()], s.mbf, w.bias_eff, out, ldo, ocoff, npix * ldo, B, out_lp ? 1 : 0,
+                       out2_lp, ldo2, ocoff2, npix * ldo2, xlp ? 1 : 0};
+            run("linattn_out", 4.0 * npix * B * 128.0 * X.C, ((out_lp ? 6.0 : 8.0) - (xlp ? 2.0 : 0.0) + (out2_lp ? 2.0 : 0.0)) * npix * X.C * B, [&] { launch_linattn_out2(o, x->precision, st); });
             return;
         }
         IGemmP g = base_gemm(X.p, X.ld, X.coff, s.H, s.W, X.C, w.wqkv, 384, nullptr, s.qkv, 384, 0);
@@ -1153,16 +1176,12 @@ struct Runner {
             }
         }
         const bool fuse_lnf = x->lp() && ln_fusable(hid);
-        const int s2c = c.dit_stride * c.dit_stride * mid;
-        IGemmP fl = base_gemm(fuse_lnf ? P.tok : P.xn, hid, 0, P.Hf, P.Wt, hid, x->fl_w, s2c, x->fl_b, out, ldo, ocoff);
-        if (fuse_lnf) { fl.ln_shift = P.fin_mod; fl.ln_scale = P.fin_mod + hid; fl.ln_step_stride = 2L * hid; }
-        else {
+        if (!fuse_lnf) {
             LnModP lf{P.tok, P.xn, N, hid, P.fin_mod, P.fin_mod + hid, 2L * hid, sp, B};
             run("ln_modulate", 8.0 * B * N * hid, 8.0 * B * N * hid, [&] { launch_ln_mod(lf, st); });
         }
-        fl.unpatch_s = c.dit_stride; fl.unpatch_C = mid; fl.OHf = P.Hm; fl.OWf = P.Wm;
-        fl.c_bstride = (long)P.Hm * P.Wm * ldo;
-        fl.outmask = mask; fl.outmask_ws = mask_ws;
+        IGemmP fl = final_gemm(mask_ws, out, ldo, ocoff);
+        if (cat_lp) { fl.C = reinterpret_cast<float*>(P.cat16); fl.c_lp = x->lp_kind(); }     // (same ld / offset, in 16-bit elements)
         gemm("dit_final_unpatchify", fl);
     }
 
@@ -1218,6 +1237,18 @@ struct Runner {
         const char* li_env = getenv("DEX_LP_INTER");
         const bool lp_inter = x->lp() && !debug && ns >= 2 && !(li_env && li_env[0] == '0') && fast_conv(c.dim, c.dim);
         lp_inter_cur = lp_inter;
+        cat_lp = false;
+        if (lp_inter && ns == 2 && P.cat16) {
+            const char* ce = getenv("DEX_CAT_LP");
+            const StageBuf& sm_ = P.down[ns - 1];
+            const ResW& uw = x->up_res[0][0];
+            const bool tail_ok = linattn_fused(sm_.C) && linattn_out2_lp_out_supported((int)sm_.npix, B);
+            const bool conv_ok = uw.wr && fast_conv(2 * sm_.C, uw.cout) && conv3x3_bf16_res_supported(2 * sm_.C, uw.cout) && x->lp_of().count(uw.wr) &&
+                                 x->lp_of().count(uw.w1) && conv3x3_cat_lp_in_supported(P.up[0].H, P.up[0].W, B, 2 * sm_.C, uw.cout);
+            IGemmP fl = final_gemm(sm_.mask_ws, P.cat[0], 2 * sm_.C, 0);
+            fl.c_lp = x->lp_kind();
+            cat_lp = !(ce && ce[0] == '0') && tail_ok && conv_ok && fl.Wbf && igemm_nwalk_form(fl);
+        }
         const int lpk = x->lp_kind();
         for (int i = 0; i < ns; ++i) {
             const StageBuf& s = P.down[i];
@@ -1235,7 +1266,9 @@ struct Runner {
             // the Downsample conv is this output's only reader at level 0 (the reference's hiddens.append of this level is never
             // popped; deeper levels live in the up path's concatenation buffer, which is read as fp32)
             const bool t1_lp = lp_inter && i == 0 && i < ns - 1 && linattn_fused(s.C) && linattn_out2_lp_out_supported((int)s.npix, B) && x->lp_of().count(x->down_ds_w[i]);
-            linattn(x->down_lin[i], s, r1, s.attn_out, s.attn_ld, s.attn_coff, defer ? &tail : nullptr, t1_lp);
+            const bool skip16 = cat_lp && i == ns - 1;          // the mid stage's output is also the skip half of the up path's concatenation buffer
+            linattn(x->down_lin[i], s, r1, s.attn_out, s.attn_ld, s.attn_coff, defer ? &tail : nullptr, t1_lp,
+                    skip16 ? P.cat16 : nullptr, s.attn_ld, s.attn_coff);
             char nm[16]; snprintf(nm, sizeof nm, "down%d", i);
             tap(nm, s.attn_out + s.attn_coff, B * s.npix, s.C, s.attn_ld);
             if (i < ns - 1) {
@@ -1280,6 +1313,7 @@ struct Runner {
             const StageBuf& s = P.up[j];
             const int i = ns - 1 - j;
             TD X{P.cat[j], 2 * stage_dim(c, i), 0, 2 * stage_dim(c, i)};
+            if (cat_lp && j == 0) X = TD{reinterpret_cast<float*>(P.cat16), 2 * stage_dim(c, i), 0, 2 * stage_dim(c, i), lpk};
             Pro t0{};
             const bool defer0 = x->lp() && conv3x3_bf16_tail_supported(s.C) && fast_conv(s.C, s.C) &&
                                 x->up_res[j][0].wr != nullptr;
@@ -1559,7 +1593,7 @@ int dex_sample(DexCtx* x, const DexSampleArgs* a, dex_stream_t stream) {
                                  (uint64_t)(uintptr_t)(a->S_churn > 0.f ? a->noise_dev : nullptr)};
     for (float v : {a->S_churn, a->S_min, a->S_max, a->S_noise}) { uint32_t u; memcpy(&u, &v, 4); key.push_back(u); }
     for (int j = 0; j < a->n_ref; ++j) key.push_back((uint64_t)(uintptr_t)a->ref_skips_dev[j]);
-    for (const char* e : {"DEX_CONV_STREAM", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN", "DEX_DIT_CLUSTER", "DEX_DIT_CLUSTER_LOCAL", "DEX_ATTN_X_LP", "DEX_RES_X_LP", "DEX_XCD_MAP", "DEX_DEBUG_DROP_HANDOFF", "DEX_PATCH_FUSED"}) {     // knobs read at enqueue time
+    for (const char* e : {"DEX_CONV_STREAM", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN", "DEX_DIT_CLUSTER", "DEX_DIT_CLUSTER_LOCAL", "DEX_ATTN_X_LP", "DEX_RES_X_LP", "DEX_CAT_LP", "DEX_XCD_MAP", "DEX_DEBUG_DROP_HANDOFF", "DEX_PATCH_FUSED"}) {     // knobs read at enqueue time
         const char* v = getenv(e);
         key.push_back(v ? (uint64_t)atoi(v) + 1 : 0);
     }

@@ -443,7 +443,19 @@ __global__ __launch_bounds__(256) void igemm_lp_nwalk_kernel(const IGemmP p) {
                 all_ok = all_ok && (u_f[r] + u_p1 < p.OHf && u_w[r] + u_p2 < p.OWf);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (__builtin_amdgcn_ballot_w64(!all_ok) == 0) {          // the common case: nothing of this tile is cropped
+            if (p.c_lp) {             // (uniform) C in the mode's 16-bit type: its reader rounds it so anyway (the up path's 3x3 conv)
+                u16* cph = reinterpret_cast<u16*>(p.C) + (long)b * p.c_bstride + p.c_coff + (long)(u_p1 * p.OWf + u_p2) * p.ldc + u_c;
+                if (__builtin_amdgcn_ballot_w64(!all_ok) == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) cph[(long)u_pix[r] * p.ldc] = lp_bits(val[r]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const bool ok = u_f[r] + u_p1 < p.OHf && u_w[r] + u_p2 < p.OWf;
+                        if (ok) cph[(long)u_pix[r] * p.ldc] = lp_bits(val[r]);
+                    }
+                }
+            } else if (__builtin_amdgcn_ballot_w64(!all_ok) == 0) {          // the common case: nothing of this tile is cropped
 #pragma unroll
                 for (int r = 0; r < 16; ++r) cp[(long)u_pix[r] * p.ldc] = val[r];
             } else {
@@ -463,7 +475,7 @@ __global__ __launch_bounds__(256) void igemm_lp_nwalk_kernel(const IGemmP p) {
 }
 
 static bool nwalk_eligible(const IGemmP& p) {
-    if (p.a_lp || p.c_lp || p.act_in_slope != 0.f) return false;
+    if (p.a_lp || p.act_in_slope != 0.f) return false;         // (c_lp: implemented in the column walker's scatter)
     if (p.K != 256 || p.Cin != 256 || p.KH != 1 || p.KW != 1 || p.parity || p.ksplit != 1 || p.groups != 1 || (p.N % 64) != 0) return false;
     if (p.sh != 1 || p.sw != 1 || p.off_h != 0 || p.off_w != 0 || p.Ho != p.Hi || p.Wo != p.Wi || p.gn_stats) return false;
     // the kernel's epilogue is the unpatchify scatter and nothing else: bias, output mask, crop
@@ -473,6 +485,7 @@ static bool nwalk_eligible(const IGemmP& p) {
     const long wgs = (long)((p.Ho * p.Wo + 63) / 64) * p.B;
     return p.N / 64 >= 8 && (mode == 2 || wgs >= 256);
 }
+bool igemm_nwalk_form(const IGemmP& p) { return nwalk_eligible(p); }
 static void launch_nwalk(const IGemmP& p, hipStream_t st) {
     constexpr int K = 256;
     const size_t lds = (size_t)(64 + 64) * (K + 8) * sizeof(u16);

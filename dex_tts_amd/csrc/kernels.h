@@ -122,6 +122,8 @@ bool conv3x3_bf16_tail_supported(int C);     // pro_res form (Cin == Cout == C)
 bool conv3x3_bf16_res_supported(int Cin, int Cout);   // res_w form (fused 1x1 shortcut)
 bool conv3x3_bf16_xb_supported(int Cin, int Cout);    // x_bf16 form (bf16 input under a GroupNorm prologue)
 bool conv3x3_plain_lp_in_supported(int H, int W, int B, int Cin, int Cout);   // a plain (no prologue) conv of this shape can read a 16-bit input
+bool igemm_nwalk_form(const IGemmP& p);                // the column-walking unpatchify GEMM takes this launch (implements IGemmP::c_lp for the scatter)
+bool conv3x3_cat_lp_in_supported(int H, int W, int B, int Cin, int Cout);   // the up path's fused-shortcut conv has a 16-bit-input form at this grid
 bool conv3x3_strip_form(const Conv3P& p);              // this launch runs on one of the strip-walking throughput forms (the ones that implement Conv3P::xout_lp)
 bool conv3x3_res2_form(int H, int W, int B);           // a 64 -> 64 fused-tail conv of this grid runs on the form that implements res2_*
 void launch_conv3x3_lp(const Conv3P& p, int precision, hipStream_t st);   // picks the strip-streaming form (conv3x3_stream.hip) for large grids
@@ -216,6 +218,7 @@ void launch_linattn_merge(const LinMergeP& p, int precision, hipStream_t st);
 struct LinOut2P { const float* X; int ldx; int x_coff; long xb; int npix; int C; const void* Wq; const void* W2;
                   const float* bias; float* Y; int ldy; int y_coff; long yb; int B; // Wq bf16 in MFMA fragment order (launch_pack_lp_frag_nk)
                   int y_lp;         // 1: Y is stored in the mode's 16-bit type (throughput form only: linattn_out2_lp_out_supported)
+                  void* Y2; int ldy2; int y2_coff; long y2b;   // optional second copy of Y in the mode's 16-bit type (throughput form only): the skip half of the up path's concatenation buffer
                   int x_lp; };      // 1: X is stored in the mode's 16-bit type [npix][C] (throughput form only; written by LinKvCtxP::xout_lp)
 void launch_linattn_out2(const LinOut2P& p, int precision, hipStream_t st);
 bool linattn_out2_lp_out_supported(int npix, int B);

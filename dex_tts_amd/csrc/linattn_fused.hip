@@ -613,6 +613,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, C == 64 
                 u16* yh = reinterpret_cast<u16*>(p.Y) + (long)b * p.yb + p.y_coff + (long)(px0 + px) * p.ldy + ch;
                 *reinterpret_cast<uint2*>(yh) = make_uint2(pack2_lp(o.x, o.y), pack2_lp(o.z, o.w));
             } else *reinterpret_cast<float4*>(Y + (long)(px0 + px) * p.ldy + ch) = o;
+            if (p.Y2) {       // (uniform) a 16-bit copy for the reader that rounds it anyway (the up path's conv reads the concatenation buffer)
+                u16* y2 = reinterpret_cast<u16*>(p.Y2) + (long)b * p.y2b + p.y2_coff + (long)(px0 + px) * p.ldy2 + ch;
+                *reinterpret_cast<uint2*>(y2) = make_uint2(pack2_lp(o.x, o.y), pack2_lp(o.z, o.w));
+            }
         }
     }
 }

@@ -20,6 +20,8 @@ bool conv3x3_bf16_xb_supported(int Cin, int Cout) { return bf16::conv3x3_bf16_xb
 bool conv3x3_plain_lp_in_supported(int H, int W, int B, int Cin, int Cout) { return bf16::conv3x3_plain_lp_in_supported(H, W, B, Cin, Cout); }
 bool linattn_out2_lp_out_supported(int npix, int B) { return bf16::linattn_out2_lp_out_supported(npix, B); }
 bool conv3x3_res2_form(int H, int W, int B) { return bf16::conv3x3_res2_form(H, W, B); }
+bool igemm_nwalk_form(const IGemmP& p) { return bf16::igemm_nwalk_form(p); }
+bool conv3x3_cat_lp_in_supported(int H, int W, int B, int Cin, int Cout) { return bf16::conv3x3_cat_lp_in_supported(H, W, B, Cin, Cout); }
 bool conv3x3_strip_form(const Conv3P& p) { return bf16::conv3x3_stream_tiles(p) != 0 || bf16::conv3x3_regw_form(p); }
 bool pos_conv_direct_supported(int hid, int groups, int kernel, int Hf) { return bf16::pos_conv_direct_supported(hid, groups, kernel, Hf); }
 bool attention_direct_batch_regime(int N, int B) { return bf16::attention_direct_batch_regime(N, B); }
