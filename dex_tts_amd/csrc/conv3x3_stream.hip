@@ -488,6 +488,16 @@ __global__ __launch_bounds__(SNT) void conv3x3_pp64_kernel(const Conv3P p, const
             for (int k = 0; k < 4; ++k) { t2[k][0] = r2_at(k, c8); t2[k][1] = r2_at(k, c8 + 4); }
         }
         auto t2_at = [&](int k, int c) -> float4 { return t2[k][(c >> 2) & 1]; };
+        // this thread's eight channels are the same for every item: their GroupNorm coefficients are read ONCE per chunk (inside the
+        // item loop the compiler has to re-read them behind every patch store - 30 LDS reads per thread and chunk on the resource the
+        // matrix role of the other group is bound by)
+        constexpr bool HOIST = XB || TAIL != 2;        // (the fp32-input form with the recomputed shortcut has no registers left for it)
+        f32x2 sc[4], sh[4], ta[4];
+        if constexpr (PRO && HOIST) {
+            *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(&coef[g][0][c8]); *reinterpret_cast<float4*>(sc + 2) = *reinterpret_cast<const float4*>(&coef[g][0][c8 + 4]);
+            *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(&coef[g][1][c8]); *reinterpret_cast<float4*>(sh + 2) = *reinterpret_cast<const float4*>(&coef[g][1][c8 + 4]);
+            *reinterpret_cast<float4*>(ta) = *reinterpret_cast<const float4*>(&coef[g][2][c8]); *reinterpret_cast<float4*>(ta + 2) = *reinterpret_cast<const float4*>(&coef[g][2][c8 + 4]);
+        }
 #pragma unroll
         for (int q = 0; q < PNI; ++q) {
             const int pxi = (gtid >> 3) + (PGT / 8) * q;
@@ -505,10 +515,12 @@ __global__ __launch_bounds__(SNT) void conv3x3_pp64_kernel(const Conv3P p, const
             }
             uint4 o;
             if constexpr (PRO) {
-                f32x2 sc[4], sh[4], ta[4], w[4];
-                *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(&coef[g][0][c8]); *reinterpret_cast<float4*>(sc + 2) = *reinterpret_cast<const float4*>(&coef[g][0][c8 + 4]);
-                *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(&coef[g][1][c8]); *reinterpret_cast<float4*>(sh + 2) = *reinterpret_cast<const float4*>(&coef[g][1][c8 + 4]);
-                *reinterpret_cast<float4*>(ta) = *reinterpret_cast<const float4*>(&coef[g][2][c8]); *reinterpret_cast<float4*>(ta + 2) = *reinterpret_cast<const float4*>(&coef[g][2][c8 + 4]);
+                f32x2 w[4];
+                if constexpr (!HOIST) {
+                    *reinterpret_cast<float4*>(sc) = *reinterpret_cast<const float4*>(&coef[g][0][c8]); *reinterpret_cast<float4*>(sc + 2) = *reinterpret_cast<const float4*>(&coef[g][0][c8 + 4]);
+                    *reinterpret_cast<float4*>(sh) = *reinterpret_cast<const float4*>(&coef[g][1][c8]); *reinterpret_cast<float4*>(sh + 2) = *reinterpret_cast<const float4*>(&coef[g][1][c8 + 4]);
+                    *reinterpret_cast<float4*>(ta) = *reinterpret_cast<const float4*>(&coef[g][2][c8]); *reinterpret_cast<float4*>(ta + 2) = *reinterpret_cast<const float4*>(&coef[g][2][c8 + 4]);
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     f32x2 in; in.x = v[2 * k]; in.y = v[2 * k + 1];
