@@ -7,7 +7,9 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <atomic>
 #include <cstdio>
+#include <mutex>
 #include <cstring>
 #include <map>
 #include <unordered_map>
@@ -612,7 +614,8 @@ static void zero_fill(void* p, size_t bytes, hipStream_t st) {
 // four members of a cluster by that rule so that their hand-offs stay inside one L2.  Probed once per process with launches of
 // the same shape (256 workgroups x 512 threads, 64 KB of LDS) that record HW_REG_XCC_ID; run from the public entry points
 // BEFORE any stream capture (it allocates).  The kernel re-checks every hand-off (flag words carry the writer's XCC id).
-static int g_xcd_map = -1;          // -1 not probed, 0 no, 1 yes
+static std::atomic<int> g_xcd_map{-1};      // -1 not probed, 0 no, 1 yes
+static std::mutex g_xcd_probe_mutex;         // (hosts with one context per thread: the probe runs once)
 __global__ __launch_bounds__(512) void xcc_probe_kernel(unsigned* out) {
     extern __shared__ unsigned char probe_lds[];
     if (threadIdx.x == 0) {
@@ -623,11 +626,12 @@ __global__ __launch_bounds__(512) void xcc_probe_kernel(unsigned* out) {
     }
 }
 static void xcd_map_probe() {
-    if (g_xcd_map >= 0) return;
-    g_xcd_map = 0;
-    { const char* e = getenv("DEX_DIT_CLUSTER_LOCAL"); if (e && atoi(e) == 0) return; }
+    if (g_xcd_map.load(std::memory_order_acquire) >= 0) return;
+    std::lock_guard<std::mutex> lk(g_xcd_probe_mutex);
+    if (g_xcd_map.load(std::memory_order_relaxed) >= 0) return;
+    { const char* e = getenv("DEX_DIT_CLUSTER_LOCAL"); if (e && atoi(e) == 0) { g_xcd_map.store(0, std::memory_order_release); return; } }
     unsigned* d = nullptr;
-    if (hipMalloc(&d, 256 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (hipMalloc(&d, 256 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); g_xcd_map.store(0, std::memory_order_release); return; }
     bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcc_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536) == hipSuccess;
     unsigned h[256];
     for (int rep = 0; rep < 3 && ok; ++rep) {
@@ -637,9 +641,9 @@ static void xcd_map_probe() {
         for (int b = 8; b < nb && ok; ++b) ok = h[b] == h[b & 7];
     }
     hipFree(d);
-    g_xcd_map = ok ? 1 : 0;
+    g_xcd_map.store(ok ? 1 : 0, std::memory_order_release);
 }
-extern "C" int dex_debug_xcd_local() { xcd_map_probe(); return g_xcd_map; }
+extern "C" int dex_debug_xcd_local() { xcd_map_probe(); return g_xcd_map.load(); }
 
 void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
     const DexConfig& c = x->cfg;
@@ -727,7 +731,7 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
         P.xslab = A.f(tiles * DIT_CLUSTER_SLAB_FLOATS);
         P.xflag_bytes = tiles * DIT_CLUSTER_FLAG_WORDS * sizeof(unsigned) + sizeof(int);      // + the time-out word
         P.xflag = (unsigned*)A.take(P.xflag_bytes);
-        P.xlocal = (dit_rowchain_cluster_local_fits(P.N, B) && g_xcd_map == 1) ? 1 : 0;
+        P.xlocal = (dit_rowchain_cluster_local_fits(P.N, B) && g_xcd_map.load(std::memory_order_relaxed) == 1) ? 1 : 0;
     }
     P.dbg_tok = A.f(tok * hid * (c.dit_depth + 1));
     P.tv_keys = P.tv_K = P.tv_V = P.tv_q = P.tv_ao = P.tv_out = P.tiv_out = P.tv_weff = P.tv_beff = nullptr; P.tv_wbf = nullptr;
@@ -1681,7 +1685,7 @@ int dex_debug_handoff_timeouts(DexCtx* x, dex_stream_t stream) {
     if (!x->last_xerr) return 0;
     int v = 0;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipMemcpy(&v, x->last_xerr, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    if (v == 2 && !getenv("DEX_DEBUG_DROP_HANDOFF")) { g_xcd_map = 0; x->drop_graphs(); }        // members of a cluster met on different XCDs: the XCD-local form is off from here on
+    if (v == 2 && !getenv("DEX_DEBUG_DROP_HANDOFF")) { g_xcd_map.store(0); x->drop_graphs(); }        // members of a cluster met on different XCDs: the XCD-local form is off from here on
     return v;
 }
 
