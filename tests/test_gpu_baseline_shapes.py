@@ -291,6 +291,7 @@ def test_residual_stream_16bit_stores_error(name, kw, prec):
     ("gedex_lj", dict(B=32, T=512, lengths=[512 - 9 * i for i in range(32)])),      # fused DiT block with the in-kernel attention: element b's row tiles on XCD b % 8
     ("dex_vctk", dict(B=32, T=512, lengths=[512 - 9 * i for i in range(32)], Tr=60, Ts=60)),   # N = 1300: the attention as its own launch (shared-ring kernel, 1-D grid)
     ("gedex_lj", dict(B=8, T=512, lengths=[512 - 30 * i for i in range(8)])),       # one element per XCD
+    ("dex_vctk", dict(B=16, T=256, lengths=[256 - 9 * i for i in range(16)], Tr=60, Ts=60)),   # shared-ring kernel with TWO key splits per (element, head)
 ])
 def test_xcd_aware_block_order_is_bit_identical(name, kw):
     """DEX_XCD_MAP (default on where 8 divides the number of (element, head) items): the workgroups that stream one utterance's K
