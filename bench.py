@@ -53,6 +53,9 @@ CONFIG_TAG = {"gedex_b1": "BASELINE.json configs[1]", "dex_b32": "BASELINE.json 
               "gedex_long": "BASELINE.json configs[4] shape"}
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+# what the chip SUSTAINS on dense 16-bit MFMA with random operands on all CUs (tools/mfmaceil, profiles/round3_mfma_ceiling_random_operands.txt):
+# it clocks down to ~1.7 GHz under that load.  Reported next to the nominal-peak fraction, never instead of it.
+MEASURED_MFMA_CEILING_TFLOPS = {"bf16": 1772.0, "f16": 1642.0}
 DTYPE_KEY = {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}
 # library profile row -> rocprofv3 kernel symbol (rows of the conv kernels already carry their symbol)
 SYMBOL_OF = {"dit_block": "dit_rowchain_kernel<true>", "dit_qkv": "dit_rowchain_kernel<false>", "dit_rowchain": "dit_rowchain_kernel<false>",
@@ -173,6 +176,8 @@ def roof(r, dtype_key, workload=None, force_mfma=False):
         ach = r["flops"] / sec / 1e12
         ent.update({"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_TFLOPS[dtype_key], "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_TFLOPS[dtype_key], 4)})
+        if dtype_key in MEASURED_MFMA_CEILING_TFLOPS:
+            ent["frac_of_measured_mfma_ceiling"] = round(ach / MEASURED_MFMA_CEILING_TFLOPS[dtype_key], 4)
     else:
         ach = r["bytes"] / sec / 1e9
         ent.update({"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
