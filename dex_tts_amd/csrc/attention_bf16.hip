@@ -199,12 +199,22 @@ __global__ __launch_bounds__(64 * NWS) void attn_lp_shared_kernel(const AttnP p)
     if (qrow < p.Nq) {
         const float inv = 1.f / l_run;
         float* op = p.O + (long)b * p.ob + (long)qrow * p.ldo + h * AHD;
+        if (p.o_lp) {          // (uniform) O in the mode's 16-bit type: its one reader, a GEMM, rounds it so anyway
+            u16* oh = reinterpret_cast<u16*>(p.O) + (long)b * p.ob + (long)qrow * p.ldo + h * AHD;
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq)
-                *reinterpret_cast<float4*>(op + t * 32 + 8 * rq + 4 * hh) =
-                    make_float4(o[t][rq * 4 + 0] * inv, o[t][rq * 4 + 1] * inv, o[t][rq * 4 + 2] * inv, o[t][rq * 4 + 3] * inv);
+                for (int rq = 0; rq < 4; ++rq)
+                    *reinterpret_cast<uint2*>(oh + t * 32 + 8 * rq + 4 * hh) =
+                        make_uint2(pack2_lp(o[t][rq * 4 + 0] * inv, o[t][rq * 4 + 1] * inv), pack2_lp(o[t][rq * 4 + 2] * inv, o[t][rq * 4 + 3] * inv));
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq)
+                    *reinterpret_cast<float4*>(op + t * 32 + 8 * rq + 4 * hh) =
+                        make_float4(o[t][rq * 4 + 0] * inv, o[t][rq * 4 + 1] * inv, o[t][rq * 4 + 2] * inv, o[t][rq * 4 + 3] * inv);
+        }
     }
 }
 
@@ -329,6 +339,9 @@ static void launch_split(const AttnP& p, hipStream_t st) {
     dim3 grid((p.Nq + 31) / 32, p.heads, p.B * (p.ksplit > 1 ? p.ksplit : 1));
     hipLaunchKernelGGL((attn_lp_split_kernel<NW>), grid, dim3(NW * 64), lds, st, p);
 }
+
+// the shared-K/V form (the only one that implements AttnP::o_lp) takes a launch of this size
+bool attention_lp_shared_form(int Nq, int heads, int B, int ksplit) { return (long)((Nq + 127) / 128) * heads * B >= 256 && ksplit <= 1; }
 
 void launch_attention_lp(const AttnP& p, hipStream_t st) {
     const long blocks128 = (long)((p.Nq + 127) / 128) * p.heads * p.B;

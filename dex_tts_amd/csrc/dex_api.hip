@@ -1213,8 +1213,13 @@ struct Runner {
         a.V = P.tv_V; a.ldv = mid; a.vb = a.kb; a.O = P.tv_ao; a.ldo = mid; a.ob = npix * mid;
         a.Nq = (int)npix; a.Nk = P.d.Ts + 1; a.kv_len = args->sty_lengths_dev; a.kv_len_add = 1; a.heads = 1;
         a.scale = 1.0f / sqrtf((float)mid); a.B = B; a.head_dim = mid;
-        run("tv_attention", 4.0 * B * (double)npix * (P.d.Ts + 1) * mid, 4.0 * B * (2 * npix + 2 * (P.d.Ts + 1)) * mid, [&] { launch_attention(a, x->precision, st); });
+        // the attention output has one reader, the output projection below, which rounds it to the operand type: at batch size it is
+        // stored in that type (same bits, half the bytes of one 84 MB tensor written and read per Euler step at B = 32)
+        const bool ao_lp = lp_inter_cur && mid == 128 && x->lp_of().count(x->tv_wl) && attention_lp_shared_form((int)npix, 1, B, 1);
+        a.o_lp = ao_lp ? 1 : 0;
+        run("tv_attention", 4.0 * B * (double)npix * (P.d.Ts + 1) * mid, (ao_lp ? 2.0 : 4.0) * B * npix * mid + 4.0 * B * (npix + 2 * (P.d.Ts + 1)) * mid, [&] { launch_attention(a, x->precision, st); });
         IGemmP o = base_gemm(P.tv_ao, mid, 0, P.Hm, P.Wm, mid, x->tv_wl, mid, nullptr, P.tv_out, mid, 0);
+        if (ao_lp) o.a_lp = x->lp_kind();
         o.res = X.p; o.ldres = X.ld; o.res_coff = X.coff; o.res_bstride = npix * X.ld;
         o.outmask = mask; o.outmask_ws = mask_ws;
         // the TIV adaptor's InstanceNorm statistics of this output ride in the epilogue (per-channel = groups of one)

@@ -175,7 +175,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // workgroup makes ONE global round trip before its MFMA chain instead of one per K tile (at B=1 the DiT linears
 // are pure latency: 4-8 exposed round trips at ~1.2 us each).  Optional fused prologue on the A rows:
 // LayerNorm(eps 1e-6, no affine) + adaLN modulate (dit.py:78-79,288-289) when the row IS the K extent.
-template <int BM, int BN, int K>
+// ALP: A holds 16-bit elements (IGemmP::a_lp; no LayerNorm staging): one 16-byte load per item, rounded once at its producer.
+template <int BM, int BN, int K, bool ALP = false>
 __global__ __launch_bounds__(256) void igemm_lp_ss_kernel(const IGemmP p) {
     constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (WM * 32);
     constexpr int LDS_LD = K + 8, KC = K / 8;               // KC: 8-element chunks per row (power of two <= 64)
@@ -225,9 +226,15 @@ __global__ __launch_bounds__(256) void igemm_lp_ss_kernel(const IGemmP p) {
             const int hi = ho * p.sh + off_h + kh * p.step_h, wi = wo * p.sw + off_w + kw * p.step_w;
             const bool ok = m < M && (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
             const int hc = ok ? hi : 0, wc = ok ? wi : 0;
-            const float* src = Ab + ((long)hc * p.Wi + wc) * p.lda + c0;
-            f0[j] = *reinterpret_cast<const float4*>(src);
-            f1[j] = *reinterpret_cast<const float4*>(src + 4);
+            if constexpr (ALP) {
+                const u16* srch = reinterpret_cast<const u16*>(p.A) + (long)b * p.a_bstride + p.a_coff + ((long)hc * p.Wi + wc) * p.lda + c0;
+                f0[j] = *reinterpret_cast<const float4*>(srch);          // 8 raw 16-bit values
+                f1[j] = f0[j];
+            } else {
+                const float* src = Ab + ((long)hc * p.Wi + wc) * p.lda + c0;
+                f0[j] = *reinterpret_cast<const float4*>(src);
+                f1[j] = *reinterpret_cast<const float4*>(src + 4);
+            }
             const float mv = mrow ? mrow[wc * p.inmask_ws] : 1.f;
             mk[j] = ok ? mv : 0.f;
         }
@@ -244,6 +251,10 @@ __global__ __launch_bounds__(256) void igemm_lp_ss_kernel(const IGemmP p) {
             const int it = tid + 256 * (a0 + j);
             const int row = it / KC, k8 = (it % KC) * 8;
             float4 a = f0[j], c = f1[j];
+            if constexpr (ALP) {
+                const unsigned u0 = __float_as_uint(f0[j].x), u1 = __float_as_uint(f0[j].y), u2 = __float_as_uint(f0[j].z), u3 = __float_as_uint(f0[j].w);
+                a = make_float4(lp_lo(u0), lp_hi(u0), lp_lo(u1), lp_hi(u1)); c = make_float4(lp_lo(u2), lp_hi(u2), lp_lo(u3), lp_hi(u3));
+            }
             if (lsh) {
                 // row statistics over the KC lanes that share this row (lanes contiguous, KC a power of two)
                 float s = (a.x + a.y) + (a.z + a.w) + (c.x + c.y) + (c.z + c.w);
@@ -512,14 +523,17 @@ static void launch_ss(const IGemmP& p, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_lp_ss_kernel<64, 64, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_lp_ss_kernel<64, 64, K, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     dim3 grid((p.Ho * p.Wo + 63) / 64, p.N / 64, p.B * (p.parity ? 4 : 1));
-    hipLaunchKernelGGL((igemm_lp_ss_kernel<64, 64, K>), grid, dim3(256), lds, st, p);
+    if (p.a_lp) hipLaunchKernelGGL((igemm_lp_ss_kernel<64, 64, K, true>), grid, dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((igemm_lp_ss_kernel<64, 64, K>), grid, dim3(256), lds, st, p);
 }
 
 static bool ss_eligible(const IGemmP& p) {
-    if (p.a_lp || p.c_lp || p.act_in_slope != 0.f) return false;
+    if (p.c_lp || p.act_in_slope != 0.f) return false;
+    if (p.a_lp && (p.ln_shift || p.KH != 1 || p.KW != 1 || (p.Cin % 8) != 0)) return false;      // 16-bit A: plain 1x1 rows only
     if (p.ksplit != 1 || p.groups != 1 || (p.N % 64) != 0) return false;
     if (p.K != 64 && p.K != 128 && p.K != 256 && p.K != 512) return false;
     const long blocks = (long)((p.Ho * p.Wo + 63) / 64) * (p.N / 64) * p.B;

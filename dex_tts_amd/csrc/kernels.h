@@ -302,7 +302,9 @@ struct AttnP { const float* Q; int ldq; long qb; const float* K; int ldk; long k
                int ksplit; long o_sstride; float* ml;
                long long* dbg;                               // DEX_TIMING builds only
                int head_dim;                                 // 0 = 128 (the tuned kernels); 64 / 192 / 256 run the generic fp32 kernel
-               int force_generic; };                         // tests: the generic kernel at head_dim 128 too
+               int force_generic;                            // tests: the generic kernel at head_dim 128 too
+               int o_lp; };                                  // O is written in the mode's 16-bit type (shared-K/V reduced-precision form only: attention_lp_shared_form)
+bool attention_lp_shared_form(int Nq, int heads, int B, int ksplit);
 bool attention_head_dim_supported(int hd);
 void launch_attention(const AttnP& p, int precision, hipStream_t st);
 

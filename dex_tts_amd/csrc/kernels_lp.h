@@ -22,6 +22,7 @@ bool conv3x3_plain_lp_in_supported(int H, int W, int B, int Cin, int Cout);
 bool conv3x3_res2_form(int H, int W, int B);          // the ping-pong strip form (the only one that implements Conv3P::res2_*) takes this grid
 // implicit GEMM on the low-precision MFMA (igemm_bf16.hip)
 void launch_igemm_lp(const IGemmP& p, hipStream_t st);
+bool attention_lp_shared_form(int Nq, int heads, int B, int ksplit);
 bool igemm_nwalk_form(const IGemmP& p);               // the column-walking unpatchify GEMM takes this launch (the form that implements c_lp for the scatter)
 bool conv3x3_cat_lp_in_supported(int H, int W, int B, int Cin, int Cout);   // the fused-shortcut conv of the up path has a 16-bit-input form at this grid
 // Upsample (ConvTranspose2d 4/2/1) strip kernel (convt_up.hip)

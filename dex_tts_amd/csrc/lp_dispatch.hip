@@ -20,6 +20,7 @@ bool conv3x3_bf16_xb_supported(int Cin, int Cout) { return bf16::conv3x3_bf16_xb
 bool conv3x3_plain_lp_in_supported(int H, int W, int B, int Cin, int Cout) { return bf16::conv3x3_plain_lp_in_supported(H, W, B, Cin, Cout); }
 bool linattn_out2_lp_out_supported(int npix, int B) { return bf16::linattn_out2_lp_out_supported(npix, B); }
 bool conv3x3_res2_form(int H, int W, int B) { return bf16::conv3x3_res2_form(H, W, B); }
+bool attention_lp_shared_form(int Nq, int heads, int B, int ksplit) { return bf16::attention_lp_shared_form(Nq, heads, B, ksplit); }
 bool igemm_nwalk_form(const IGemmP& p) { return bf16::igemm_nwalk_form(p); }
 bool conv3x3_cat_lp_in_supported(int H, int W, int B, int Cin, int Cout) { return bf16::conv3x3_cat_lp_in_supported(H, W, B, Cin, Cout); }
 bool conv3x3_strip_form(const Conv3P& p) { return bf16::conv3x3_stream_tiles(p) != 0 || bf16::conv3x3_regw_form(p); }
