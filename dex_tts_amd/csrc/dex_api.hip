@@ -806,9 +806,9 @@ struct Runner {
     // Block conv (diffusion.py:44).  pro != null fuses the producer's GN-apply + Mish + time bias into the load
     // (bf16 patch kernel only).
     struct Pro { const gnfix_t* stats; const float *gamma, *beta, *tadd; const float* res = nullptr; float* xout = nullptr; bool x_bf16 = false;
-                 bool res2 = false; FirstConvP res2f{};
+                 bool res2 = false; FirstConvP res2f{};   // res2: `res` is not stored - recomputed from the first conv's inputs (res2f)
                  mutable bool xout_lp_ok = false;    // in: xout's one reader (the attention's context pass) can take it in the mode's 16-bit type
-                 mutable bool xout_lp = false; };   // out: the conv that wrote xout did store it that way     // res2: `res` is not stored - recomputed from the first conv's inputs (res2f)
+                 mutable bool xout_lp = false; };   // out: the conv that wrote xout did store it that way
     // raw conv outputs read only by a fused GroupNorm prologue (h1, h2 of a ResnetBlock, the final block's conv) are kept
     // in HBM as bf16 in bf16 mode: half the bytes of the largest tensors of the step.  DEX_H_BF16=0 keeps them fp32.
     static bool ln_fusable(int K) { return K == 64 || K == 128 || K == 256 || K == 512; }
