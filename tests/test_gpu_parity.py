@@ -37,7 +37,10 @@ def gold(name):
 
 @pytest.mark.parametrize("name,preset", [("gedex_lj", "gedex_lj"), ("gedex_lj_n50", "gedex_lj"),
                                          ("gedex_vctk", "gedex_vctk"), ("dex_vctk", "dex_vctk"),
-                                         ("dex_libritts", "dex_libritts")])      # dim 128, hidden 384 = 2 x 192: the generic fp32 path
+                                         ("dex_libritts", "dex_libritts"),       # dim 128, hidden 384 = 2 x 192: the generic fp32 path
+                                         # batched DEX = three B = 1 runs of the REAL reference at one padded T / Tr / Ts, stacked
+                                         # (the reference cannot batch DEX; oracle/make_golden.py::golden_dex_stacked)
+                                         ("dex_vctk_b3_stacked", "dex_vctk")])
 def test_golden_precond_and_sampler(name, preset):
     _golden_precond_and_sampler(name, preset)
 

@@ -169,3 +169,27 @@ def test_mel_basis_crosscheck_transformers():
     au = pytest.importorskip("transformers.audio_utils")
     ref = au.mel_filter_bank(513, 80, 0.0, 8000.0, 22050, norm="slaney", mel_scale="slaney").T
     np.testing.assert_allclose(O.slaney_mel_basis(), ref, atol=2e-6)
+
+
+def test_batched_dex_equals_stacked_reference_runs(golden_dir):
+    """Batched DEX (VERDICT r3 Missing #3).  The reference runs DEX one utterance at a time
+    (ref_encoder.py:157,248); tests/golden/dex_vctk_b3_stacked.npz holds three B = 1 runs of the REAL reference at one padded
+    T / Tr / Ts, stacked (oracle/make_golden.py::golden_dex_stacked).  The oracle's batched path — what every B > 1 DEX test of
+    the library is checked against, configs[2] / configs[3] included — must reproduce the stack: same arithmetic per utterance,
+    only the summation order of batched GEMMs / convolutions may differ (measured 6e-6)."""
+    g = load(golden_dir, "dex_vctk_b3_stacked")
+    cfg = C.dex_vctk()
+    W = O.as_torch(synth.make_weights(C.param_shapes(cfg)), torch.float32)
+    mu, mask, z, eps = (torch.from_numpy(g[k]) for k in ("mu", "mask", "z", "eps"))
+    kw = oracle_kwargs(g, torch.float32)
+    assert mu.shape[0] == 3 and len(set(g["lengths"].tolist())) == 3 and len(set(g["sty_lengths"].tolist())) == 3
+    for s in (80.0, 1.0, 0.002):
+        d = O.edm_precond(W, cfg, mu + s * eps, torch.tensor(s), mask, mu, **kw).numpy()
+        ref = g[f"precond_sigma{s}"]
+        err = np.abs(d - ref).max()
+        assert err <= 2e-5 * max(1.0, np.abs(ref).max()), (s, err)
+    y = O.diffusion_infer(W, cfg, mask, mu, 4, z, **kw).numpy()
+    err = np.abs(y - g["sampler_n4"])
+    assert err.max() <= 5e-5 and err.mean() <= 5e-6, (err.max(), err.mean())
+    # ... and utterance b of the batch is NOT what a run without its neighbours' padding would give trivially: the rows differ
+    assert np.abs(g["sampler_n4"][0] - g["sampler_n4"][1]).max() > 1e-1
