@@ -88,7 +88,7 @@ int main(int argc, char** argv) {
             std::vector<float> g(on * ks), hml((size_t)ks * c.B * 2 * c.N * 2);
             hipMemcpy(g.data(), O2, on * 4 * ks, hipMemcpyDeviceToHost);
             if (ks > 1) hipMemcpy(hml.data(), ml, hml.size() * 4, hipMemcpyDeviceToHost);
-            double mx = 0, ref = 0; size_t bad = 0;
+            double mx = 0, ref = 0; size_t bad = 0, nbad = 0; int ndiag = 0; std::vector<size_t> badrow((c.N + 31) / 32 + 1, 0), badd(4, 0);
             for (int b = 0; b < c.B; ++b)
                 for (int n = 0; n < c.N; ++n)
                     for (int h = 0; h < 2; ++h) {
@@ -108,9 +108,16 @@ int main(int argc, char** argv) {
                             }
                             const double dlt = fabs(val - r[idx]);
                             if (!(dlt <= 1e30)) ++bad;
+                            if (getenv("Q64_DIAG") && !(dlt <= 2e-2) && ndiag < 24) { ++ndiag; printf("        diag b=%d n=%d h=%d d=%d got %.5g want %.5g\n", b, n, h, d, val, (double)r[idx]); }
+                            if (!(dlt <= 2e-2)) { ++nbad; badrow[n >> 5]++; badd[d >> 5]++; }
                             mx = std::max(mx, dlt); ref = std::max(ref, (double)fabsf(r[idx]));
                         }
                     }
+            if (nbad && getenv("Q64_DIAG")) {
+                printf("        %zu bad elements of %zu; by d-tile: %zu %zu %zu %zu; by 32-row tile:", nbad, on, badd[0], badd[1], badd[2], badd[3]);
+                for (size_t t = 0; t < badrow.size() && t < 48; ++t) printf(" %zu", badrow[t]);
+                printf("\n");
+            }
             printf("      %s vs shipped: max|d| = %.3e (|O|max %.3f)%s\n", label, mx, ref, bad ? "  NON-FINITE VALUES" : (mx > 2e-2 * std::max(ref, 1e-3) ? "  MISMATCH" : ""));
 #ifdef Q64_STAMP
             if (c.bench) {

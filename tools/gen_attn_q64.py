@@ -1,0 +1,631 @@
+#!/usr/bin/env python3
+"""Generator of dex_tts_amd/csrc/attention_q64_core.inc — the hand-scheduled gfx950 instruction streams of the
+64-queries-per-wave attention (attention_q64.hip): the per-unit core (first tile, software-pipelined tile loop, last tile),
+the unit prologue (LDS-DMA of the first tiles + Q straight into the accumulation file) and the output stage.
+
+Why a generator: the core owns the register file — fixed physical registers, every MFMA gap's fillers placed by hand.  As
+inline asm with compiler-allocated operands (the first form of this kernel) hipcc copied 16-register score tuples around
+element updates, spilled the Q fragments to scratch once the arch VGPRs ran out, padded statements with s_nop and moved
+plain C++ fillers out of their gaps; as one statement with a fixed register map none of that can happen.
+
+    python tools/gen_attn_q64.py            # rewrites the .inc (committed; tests/test_cabi.py checks it is up to date)
+
+Register map (core):
+  a[0:127]   O^T accumulators: block A d-tile td = a[16 td ..], block B = a[64 + 16 td ..]
+  a[128:191] Q fragments: QA[s] = a[128 + 4 s ..], QB[s] = a[160 + 4 s ..]
+  a[192:223] K / V^T fragment staging: fr[set][q] = a[192 + 16 set + 4 q ..]
+  v[0:63]    score buffer 0: array a = 2 X + kb (query block X, key block kb) = v[16 a ..];  v[64:127] score buffer 1
+  v[128:143] -m seeds of block A, v[144:159] of block B
+  v160.. scalars (row sums, reference maxima, running maxima, addresses)
+"""
+import os
+import sys
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dex_tts_amd", "csrc", "attention_q64_core.inc")
+
+TILE = 16384
+V_RING = 4 * TILE
+STAGE_ROW = 272
+
+# ---- register map
+def OA(td): return 16 * td
+def OB(td): return 64 + 16 * td
+def QA(s): return 128 + 4 * s
+def QB(s): return 160 + 4 * s
+def FR(st, q): return 192 + 16 * st + 4 * q
+def S(buf, a): return 64 * buf + 16 * a
+NEGM = (128, 144)
+V_LA, V_LB, V_MA, V_MB = 160, 161, 162, 163
+V_C = (164, 165, 166, 167)          # running maxima: c0 (A kb0), c1 (A kb1), c2 (B kb0), c3 (B kb1)
+V_MXA, V_MXB, V_T0, V_T1, V_ALA, V_ALB = 168, 169, 170, 171, 172, 173
+V_KA, V_VA, V_KA2, V_VOFF, V_L16, V_HH4, V_NINF = 174, 175, 176, 177, 178, 179, 180
+V_TOP = 183                          # highest arch VGPR the core owns
+# owned SGPRs
+S_IT, S_T, S_X0, S_X1, S_X2, S_PEND, S_SOFFK, S_SOFFV, S_KDST, S_VDST = 40, 41, 42, 43, 44, 45, 46, 47, 48, 49
+S_VS0, S_VS1, S_VS2, S_HK, S_HV, S_NT32M1 = 50, 51, 52, 53, 54, 55
+S_TOP = 57
+
+
+def vr(i, n=1): return f"v{i}" if n == 1 else f"v[{i}:{i + n - 1}]"
+def ar(i, n=1): return f"a{i}" if n == 1 else f"a[{i}:{i + n - 1}]"
+def sr(i): return f"s{i}"
+
+
+class Prog:
+    """instruction list; cold(): blocks that almost never run are collected and emitted behind the hot stream (the hot path stays
+    dense in the instruction cache and falls through its branches)"""
+    def __init__(self):
+        self.out = []
+        self.hot = self.out
+        self.cold_blocks = []
+
+    def begin_cold(self, entry, back):
+        self._cold = []
+        self._back = back
+        self.out = self._cold
+        self.label(entry)
+
+    def end_cold(self):
+        self.br("s_branch", self._back)
+        self.cold_blocks.append(self._cold)
+        self.out = self.hot
+
+    def finish(self):
+        for b in self.cold_blocks:
+            self.hot.extend(b)
+        self.cold_blocks = []
+
+    def e(self, text):
+        """one instruction; MFMA / PK are C macros holding the mnemonic of the operand type"""
+        if text.startswith("MFMA "):
+            self.out.append(f'Q64_MFMA " {text[5:]}\\n\\t"')
+        elif text.startswith("PK "):
+            self.out.append(f'Q64_PK " {text[3:]}\\n\\t"')
+        else:
+            self.out.append(f'"{text}\\n\\t"')
+
+    def label(self, name):
+        self.out.append(f'"{name}_%=:\\n\\t"')
+
+    def br(self, op, name):
+        self.e(f"{op} {name}_%=")
+
+    def text(self):
+        self.finish()
+        return "\n    ".join(self.hot)
+
+
+def VOFF(kk, td): return ((kk >> 1) * 8 + td * 2 + (kk & 1)) * 1024
+
+
+# ------------------------------------------------------------------------------------------------------------------ phases
+def qk_phase(p, dst, first, fill, last4):
+    """32 S^T MFMAs into score buffer dst, key block 0 first; group 0's fragments already requested into fr[0]"""
+    for n in range(32):
+        kb, s, x = n >> 4, (n >> 1) & 7, n & 1
+        j = n >> 1
+        grp, q = j >> 2, j & 3
+        if n & 7 == 0:
+            p.e("s_waitcnt lgkmcnt(0)")
+        acc = vr(S(dst, x * 2 + kb), 16)
+        c = ("0" if first else vr(NEGM[x], 16)) if s == 0 else acc
+        p.e(f"MFMA {acc}, {ar(FR(grp & 1, q), 4)}, {ar((QB if x else QA)(s), 4)}, {c}")
+        if (n & 7) < 4:
+            if grp < 3:
+                p.e(f"ds_read_b128 {ar(FR((grp + 1) & 1, n & 7), 4)}, {vr(V_KA)} offset:{((grp + 1) * 4 + (n & 7)) * 1024}")
+            else:
+                last4(p, n & 7)
+        fill(p, n)
+
+
+def pv_phase(p, pbuf, fill, last4):
+    """32 O^T MFMAs; P sits in place in score buffer pbuf (register quads [8 k2, 8 k2 + 4) of array 2 X + kb)"""
+    for n in range(32):
+        kk, td, x = n >> 3, (n >> 1) & 3, n & 1
+        if n & 7 == 0:
+            p.e("s_waitcnt lgkmcnt(0)")
+        acc = ar((OB if x else OA)(td), 16)
+        pb = vr(S(pbuf, x * 2 + (kk >> 1)) + 8 * (kk & 1), 4)
+        p.e(f"MFMA {acc}, {ar(FR(kk & 1, td), 4)}, {pb}, {acc}")
+        if (n & 7) < 4:
+            if kk < 3:
+                p.e(f"ds_read_b128 {ar(FR((kk + 1) & 1, n & 7), 4)}, {vr(V_VA)} offset:{VOFF(kk + 1, n & 7)}")
+            else:
+                last4(p, n & 7)
+        fill(p, n)
+
+
+def k_group0(p, vaddr):
+    for q in range(4):
+        p.e(f"ds_read_b128 {ar(FR(0, q), 4)}, {vr(vaddr)} offset:{q * 1024}")
+
+
+def v_group0(p, vaddr):
+    for q in range(4):
+        p.e(f"ds_read_b128 {ar(FR(0, q), 4)}, {vr(vaddr)} offset:{VOFF(0, q)}")
+
+
+# ---- softmax shadow (see attention_q64.hip for the schedule)
+def fill_a(p, buf, n):
+    """gap n of phase A: late exponential n (n < 24) + its row sum, pack n (in place)"""
+    pa = 0 if n < 8 else 2 if n < 16 else 1 if n < 24 else 3
+    pi = n & 7
+    lo = S(buf, pa) + 2 * pi
+    dst = S(buf, pa) + 8 * (pi >> 2) + (pi & 3)
+    if n < 24:
+        ea, er = (1, 8 + n) if n < 8 else (3, n - 8)
+        ev = S(buf, ea) + er
+        p.e(f"v_exp_f32 {vr(ev)}, {vr(ev)}")
+        p.e(f"PK {vr(dst)}, {vr(lo)}, {vr(lo + 1)}")
+        p.e(f"v_add_f32 {vr(V_LA if ea == 1 else V_LB)}, {vr(V_LA if ea == 1 else V_LB)}, {vr(ev)}")
+    else:
+        p.e(f"PK {vr(dst)}, {vr(lo)}, {vr(lo + 1)}")
+
+
+def fill_b(p, buf, e):
+    """early exponentials, pair e = 0..19: (A, kb 0) 0..7, (B, kb 0) 8..15, (A, kb 1, registers 0..7) 16..19"""
+    a = 0 if e < 8 else 2 if e < 16 else 1
+    r = S(buf, a) + 2 * (e & 7)
+    l = V_LB if a == 2 else V_LA
+    p.e(f"v_exp_f32 {vr(r)}, {vr(r)}")
+    p.e(f"v_exp_f32 {vr(r + 1)}, {vr(r + 1)}")
+    p.e(f"v_add_f32 {vr(l)}, {vr(l)}, {vr(r)}")
+    p.e(f"v_add_f32 {vr(l)}, {vr(l)}, {vr(r + 1)}")
+
+
+def max_step(p, buf, kb, k):
+    """running maxima of key block kb (arrays kb and 2 + kb), step k = 0..6 over registers 0..14"""
+    for X in (0, 1):
+        c = V_C[2 * X + kb]
+        b = S(buf, 2 * X + kb)
+        if k == 0:
+            p.e(f"v_max3_f32 {vr(c)}, {vr(b)}, {vr(b + 1)}, {vr(b + 2)}")
+        else:
+            p.e(f"v_max3_f32 {vr(c)}, {vr(c)}, {vr(b + 2 * k + 1)}, {vr(b + 2 * k + 2)}")
+
+
+def max_last(p, buf, dA, dB):
+    p.e(f"v_max3_f32 {vr(dA)}, {vr(V_C[0])}, {vr(V_C[1])}, {vr(S(buf, 0) + 15)}")
+    p.e(f"v_max3_f32 {vr(dB)}, {vr(V_C[2])}, {vr(V_C[3])}, {vr(S(buf, 2) + 15)}")
+    p.e(f"v_max_f32 {vr(dA)}, {vr(dA)}, {vr(S(buf, 1) + 15)}")
+    p.e(f"v_max_f32 {vr(dB)}, {vr(dB)}, {vr(S(buf, 3) + 15)}")
+
+
+def xhalf_max(p, x, tmp):
+    """max over the two 32-lane halves, result in every lane"""
+    p.e(f"v_mov_b32 {vr(tmp)}, {vr(x)}")
+    p.e("s_nop 1")
+    p.e(f"v_permlane32_swap_b32 {vr(x)}, {vr(tmp)}")
+    p.e("s_nop 1")
+    p.e(f"v_max_f32 {vr(x)}, {vr(x)}, {vr(tmp)}")
+
+
+def mask_tile(p, buf, s_tile64, uid):
+    """keys >= N of the tile whose first key is s_tile64 (an SGPR): -inf.  key = tile64 + kb*32 + (r&3) + 8 (r>>2) + 4 hh"""
+    p.e(f"v_mov_b32 {vr(V_NINF)}, 0xff800000")
+    p.e(f"s_sub_i32 {sr(S_X1)}, %[N], {sr(s_tile64)}")                 # key >= N  <=>  4 hh >= N - tile64 - const
+    for kb in range(2):
+        for r in range(16):
+            const = kb * 32 + (r & 3) + 8 * (r >> 2)
+            p.e(f"s_sub_i32 {sr(S_X2)}, {sr(S_X1)}, {const}")
+            p.e(f"v_cmp_ge_i32 vcc, {vr(V_HH4)}, {sr(S_X2)}")
+            for X in (0, 1):
+                reg = S(buf, 2 * X + kb) + r
+                p.e(f"v_cndmask_b32 {vr(reg)}, {vr(reg)}, {vr(V_NINF)}, vcc")
+
+
+def dma_piece(p, rs, s_soff, j):
+    p.e(f"buffer_load_dwordx4 {vr(V_VOFF)}, {rs}, {sr(s_soff)} offen offset:{j * 1024} lds")
+
+
+def soff_of(p, dst, s_tile, add):
+    """dst = min(2 (tile + add) + wh, nt32 - 1) * 8192 + wq"""
+    p.e(f"s_add_i32 {sr(dst)}, {sr(s_tile)}, {add}")
+    p.e(f"s_lshl_b32 {sr(dst)}, {sr(dst)}, 1")
+    p.e(f"s_add_i32 {sr(dst)}, {sr(dst)}, %[wh]")
+    p.e(f"s_min_i32 {sr(dst)}, {sr(dst)}, {sr(S_NT32M1)}")
+    p.e(f"s_lshl_b32 {sr(dst)}, {sr(dst)}, 13")
+    p.e(f"s_add_i32 {sr(dst)}, {sr(dst)}, %[wq]")
+
+
+def kslot_addr(p, vdst, add):
+    """vdst = lane16 + ((T + add) & 3) * 16 KB"""
+    p.e(f"s_add_i32 {sr(S_X0)}, {sr(S_T)}, {add}")
+    p.e(f"s_and_b32 {sr(S_X0)}, {sr(S_X0)}, 3")
+    p.e(f"s_lshl_b32 {sr(S_X0)}, {sr(S_X0)}, 14")
+    p.e(f"v_add_u32_e32 {vr(vdst)}, {sr(S_X0)}, {vr(V_L16)}")
+
+
+# ------------------------------------------------------------------------------------------------------------------ iteration
+def iteration(p, cb, nb, steady, tag):
+    """tile T (scores in buffer cb) is current, T + 1 (buffer nb) is next"""
+    # addresses and DMA operands of this iteration
+    kslot_addr(p, V_KA, 1)
+    p.e(f"v_add_u32_e32 {vr(V_VA)}, {sr(S_VS0)}, {vr(V_L16)}")
+    kslot_addr(p, V_KA2, 2)
+    soff_of(p, S_SOFFK, S_T, 4)
+    soff_of(p, S_SOFFV, S_T, 2)
+    p.e(f"s_and_b32 {sr(S_KDST)}, {sr(S_T)}, 3")
+    p.e(f"s_lshl_b32 {sr(S_KDST)}, {sr(S_KDST)}, 14")
+    p.e(f"s_add_i32 {sr(S_KDST)}, {sr(S_KDST)}, %[dbase]")              # LDS base + wave * 4 KB
+    p.e(f"s_add_i32 {sr(S_VDST)}, {sr(S_VS2)}, %[dbase]")
+    if not steady:
+        p.e(f"s_sub_i32 {sr(S_X0)}, %[nt], {sr(S_IT)}")                 # nt - it
+        p.e(f"s_cmp_gt_i32 {sr(S_X0)}, 4")
+        p.e(f"s_cselect_b32 {sr(S_HK)}, 1, 0")
+        p.e(f"s_cmp_gt_i32 {sr(S_X0)}, 2")
+        p.e(f"s_cselect_b32 {sr(S_HV)}, 1, 0")
+    p.e(f"s_mov_b32 m0, {sr(S_KDST)}")
+
+    def dma_guarded(p, rs, soff, j, flag, name):
+        if steady:
+            dma_piece(p, rs, soff, j)
+        else:
+            p.e(f"s_cmp_eq_u32 {sr(flag)}, 0")
+            p.br("s_cbranch_scc1", name)
+            dma_piece(p, rs, soff, j)
+            p.label(name)
+
+    def fa(p, n):
+        fill_a(p, cb, n)
+        if 20 <= n <= 26:
+            max_step(p, nb, 0, n - 20)
+        if n in (5, 13, 29, 31):
+            j = {5: 0, 13: 1, 29: 2, 31: 3}[n]
+            dma_guarded(p, "%[rk]", S_SOFFK, j, S_HK, f"SKK{tag}{j}")
+
+    def last4_a(p, q):
+        p.e(f"ds_read_b128 {ar(FR(0, q), 4)}, {vr(V_VA)} offset:{VOFF(0, q)}")
+
+    qk_phase(p, nb, False, fa, last4_a)
+
+    def fb(p, n):
+        if n == 0:
+            p.e(f"s_mov_b32 m0, {sr(S_VDST)}")
+        if 4 <= n <= 7:
+            dma_guarded(p, "%[rv]", S_SOFFV, n - 4, S_HV, f"SKV{tag}{n - 4}")
+        if n == 2:
+            # the next tile is the last of the sequence and ragged: mask its keys >= N (scores are complete: >= 2 gaps behind the MFMAs)
+            p.e(f"s_add_i32 {sr(S_X0)}, {sr(S_T)}, 1")
+            p.e(f"s_lshl_b32 {sr(S_X0)}, {sr(S_X0)}, 6")
+            p.e(f"s_add_i32 {sr(S_X1)}, {sr(S_X0)}, 64")
+            p.e(f"s_cmp_gt_i32 {sr(S_X1)}, %[N]")
+            p.br("s_cbranch_scc1", f"MASK{tag}")
+            p.label(f"NOMASK{tag}")
+            p.begin_cold(f"MASK{tag}", f"NOMASK{tag}")
+            p.e("s_nop 7")
+            mask_tile(p, nb, S_X0, tag)
+            p.end_cold()
+        if 2 <= n <= 8:
+            max_step(p, nb, 1, n - 2)
+        if n == 9:
+            max_last(p, nb, V_MXA, V_MXB)
+        if n == 10:
+            xhalf_max(p, V_MXA, V_T0)
+            xhalf_max(p, V_MXB, V_T1)
+        if n == 11:
+            p.e(f"v_max_f32 {vr(V_T0)}, {vr(V_MXA)}, {vr(V_MXB)}")
+            p.e(f"v_cmp_lt_f32 vcc, 0x41000000, {vr(V_T0)}")           # 8.0 < max
+            p.br("s_cbranch_vccnz", f"MOVE{tag}")
+            p.label(f"NOMOVE{tag}")
+            p.begin_cold(f"MOVE{tag}", f"NOMOVE{tag}")
+            # ---- the reference maximum moves (rare): scores of tile T+1, seeds, row sums now; O^T after this phase's MFMAs
+            p.e(f"v_max_f32 {vr(V_T0)}, 0, {vr(V_MXA)}")
+            p.e(f"v_max_f32 {vr(V_T1)}, 0, {vr(V_MXB)}")
+            p.e(f"v_add_f32 {vr(V_MA)}, {vr(V_MA)}, {vr(V_T0)}")
+            p.e(f"v_add_f32 {vr(V_MB)}, {vr(V_MB)}, {vr(V_T1)}")
+            p.e(f"v_exp_f32 {vr(V_ALA)}, -{vr(V_T0)}")
+            p.e(f"v_exp_f32 {vr(V_ALB)}, -{vr(V_T1)}")
+            p.e("s_nop 0")
+            p.e(f"v_mul_f32 {vr(V_LA)}, {vr(V_LA)}, {vr(V_ALA)}")
+            p.e(f"v_mul_f32 {vr(V_LB)}, {vr(V_LB)}, {vr(V_ALB)}")
+            for a in range(4):
+                for r in range(16):
+                    reg = S(nb, a) + r
+                    p.e(f"v_sub_f32 {vr(reg)}, {vr(reg)}, {vr(V_T0 if a < 2 else V_T1)}")
+            for r in range(16):
+                p.e(f"v_sub_f32 {vr(NEGM[0] + r)}, 0, {vr(V_MA)}")
+                p.e(f"v_sub_f32 {vr(NEGM[1] + r)}, 0, {vr(V_MB)}")
+            p.e(f"s_mov_b32 {sr(S_PEND)}, 1")
+            p.end_cold()
+        if n >= 12:
+            fill_b(p, nb, n - 12)
+
+    def last4_b(p, q):
+        p.e(f"ds_read_b128 {ar(FR(0, q), 4)}, {vr(V_KA2)} offset:{q * 1024}")
+
+    pv_phase(p, cb, fb, last4_b)
+    # pending rescale of O^T
+    p.e(f"s_cmp_lg_u32 {sr(S_PEND)}, 0")
+    p.br("s_cbranch_scc1", f"PEND{tag}")
+    p.label(f"NOPEND{tag}")
+    p.begin_cold(f"PEND{tag}", f"NOPEND{tag}")
+    p.e("s_nop 15")
+    p.e("s_nop 7")
+    for k in range(128):
+        p.e(f"v_accvgpr_read_b32 {vr(V_T0)}, {ar(k)}")
+        p.e(f"v_mul_f32 {vr(V_T0)}, {vr(V_T0)}, {vr(V_ALA if k < 64 else V_ALB)}")
+        p.e(f"v_accvgpr_write_b32 {ar(k)}, {vr(V_T0)}")
+    p.e("s_nop 3")
+    p.e(f"s_mov_b32 {sr(S_PEND)}, 0")
+    p.end_cold()
+    # everything issued before this iteration has landed; this iteration's pieces fly on
+    if steady:
+        p.e("s_waitcnt vmcnt(8)")
+    else:
+        p.e(f"s_cmp_eq_u32 {sr(S_HK)}, 0")
+        p.br("s_cbranch_scc1", f"W4{tag}")
+        p.e("s_waitcnt vmcnt(8)")
+        p.br("s_branch", f"WD{tag}")
+        p.label(f"W4{tag}")
+        p.e(f"s_cmp_eq_u32 {sr(S_HV)}, 0")
+        p.br("s_cbranch_scc1", f"W0{tag}")
+        p.e("s_waitcnt vmcnt(4)")
+        p.br("s_branch", f"WD{tag}")
+        p.label(f"W0{tag}")
+        p.e("s_waitcnt vmcnt(0)")
+        p.label(f"WD{tag}")
+    p.e("s_barrier")
+    p.e(f"s_mov_b32 {sr(S_X0)}, {sr(S_VS0)}")
+    p.e(f"s_mov_b32 {sr(S_VS0)}, {sr(S_VS1)}")
+    p.e(f"s_mov_b32 {sr(S_VS1)}, {sr(S_VS2)}")
+    p.e(f"s_mov_b32 {sr(S_VS2)}, {sr(S_X0)}")
+    p.e(f"s_add_i32 {sr(S_IT)}, {sr(S_IT)}, 1")
+    p.e(f"s_add_i32 {sr(S_T)}, {sr(S_T)}, 1")
+
+
+def tail(p, cb):
+    """the sequence's last tile: late exponentials + packs, then its O^T MFMAs"""
+    for n in range(32):
+        fill_a(p, cb, n)
+    p.e(f"v_add_u32_e32 {vr(V_VA)}, {sr(S_VS0)}, {vr(V_L16)}")
+    v_group0(p, V_VA)
+    pv_phase(p, cb, lambda p, n: None, lambda p, q: None)
+
+
+def core():
+    p = Prog()
+    p.e(f"v_mov_b32 {vr(V_L16)}, %[lane16]")
+    p.e(f"v_mov_b32 {vr(V_VOFF)}, %[vlane]")
+    p.e(f"v_mov_b32 {vr(V_HH4)}, %[hh4]")
+    p.e(f"v_mov_b32 {vr(V_LA)}, 0")
+    p.e(f"v_mov_b32 {vr(V_LB)}, 0")
+    p.e(f"s_mov_b32 {sr(S_IT)}, 0")
+    p.e(f"s_mov_b32 {sr(S_T)}, %[tlo]")
+    p.e(f"s_mov_b32 {sr(S_PEND)}, 0")
+    p.e(f"s_sub_i32 {sr(S_NT32M1)}, %[nt32], 1")
+    p.e(f"s_mov_b32 {sr(S_VS0)}, {V_RING}")
+    p.e(f"s_mov_b32 {sr(S_VS1)}, {V_RING + TILE}")
+    p.e(f"s_mov_b32 {sr(S_VS2)}, {V_RING + 2 * TILE}")
+    # ---- the unit's first requests but K(3) have landed (Q too); a finished unit's stores (>= 16, issued after them) may fly on
+    p.e("s_cmp_eq_u32 %[first], 0")
+    p.br("s_cbranch_scc1", "WNF")
+    p.e("s_cmp_gt_i32 %[nt], 3")
+    p.br("s_cbranch_scc1", "WF4")
+    p.e("s_waitcnt vmcnt(0)")
+    p.br("s_branch", "WDONE")
+    p.label("WF4")
+    p.e("s_waitcnt vmcnt(4)")
+    p.br("s_branch", "WDONE")
+    p.label("WNF")
+    p.e("s_cmp_gt_i32 %[nt], 3")
+    p.br("s_cbranch_scc1", "WN4")
+    p.e("s_waitcnt vmcnt(16)")
+    p.br("s_branch", "WDONE")
+    p.label("WN4")
+    p.e("s_waitcnt vmcnt(20)")
+    p.label("WDONE")
+    p.e("s_barrier")
+    # ---- tile 0: scores with a zero seed (the O^T accumulators are zeroed in its gaps), first reference maximum, early exponentials
+    kslot_addr(p, V_KA, 0)
+    k_group0(p, V_KA)
+
+    def f0(p, n):
+        for k in range(4):
+            p.e(f"v_accvgpr_write_b32 {ar(4 * n + k)}, 0")
+
+    qk_phase(p, 0, True, f0, lambda p, q: None)
+    p.e("s_nop 15")
+    p.e("s_nop 7")
+    p.e(f"s_lshl_b32 {sr(S_X0)}, {sr(S_T)}, 6")
+    p.e(f"s_add_i32 {sr(S_X1)}, {sr(S_X0)}, 64")
+    p.e(f"s_cmp_gt_i32 {sr(S_X1)}, %[N]")
+    p.br("s_cbranch_scc1", "MASK0")
+    p.label("NOMASK0")
+    p.begin_cold("MASK0", "NOMASK0")
+    mask_tile(p, 0, S_X0, "0")
+    p.end_cold()
+    for k in range(7):
+        max_step(p, 0, 0, k)
+        max_step(p, 0, 1, k)
+    max_last(p, 0, V_MA, V_MB)
+    xhalf_max(p, V_MA, V_T0)
+    xhalf_max(p, V_MB, V_T1)
+    for a in range(4):
+        for r in range(16):
+            reg = S(0, a) + r
+            p.e(f"v_sub_f32 {vr(reg)}, {vr(reg)}, {vr(V_MA if a < 2 else V_MB)}")
+    for r in range(16):
+        p.e(f"v_sub_f32 {vr(NEGM[0] + r)}, 0, {vr(V_MA)}")
+        p.e(f"v_sub_f32 {vr(NEGM[1] + r)}, 0, {vr(V_MB)}")
+    for e in range(20):
+        fill_b(p, 0, e)
+    p.e("s_barrier")                                                       # every wave has read K(0): its slot may take K(4)
+    # group 0 of K(1) for the first iteration
+    p.e("s_cmp_lt_i32 %[nt], 2")
+    p.br("s_cbranch_scc1", "TAIL_E")
+    kslot_addr(p, V_KA, 1)
+    k_group0(p, V_KA)
+    # ---- the loop: even iterations have the current tile in buffer 0, odd ones in buffer 1
+    for par, (cb, nb) in enumerate(((0, 1), (1, 0))):
+        me, other = "EO"[par], "OE"[par]
+        p.label(f"LOOP_{me}")
+        p.e(f"s_add_i32 {sr(S_X0)}, {sr(S_IT)}, 1")
+        p.e(f"s_cmp_ge_i32 {sr(S_X0)}, %[nt]")
+        p.br("s_cbranch_scc1", f"TAIL_{me}")
+        p.e(f"s_add_i32 {sr(S_X0)}, {sr(S_IT)}, 4")
+        p.e(f"s_cmp_ge_i32 {sr(S_X0)}, %[nt]")
+        p.br("s_cbranch_scc1", f"DRAIN_{me}")
+        iteration(p, cb, nb, True, f"S{me}")
+        p.br("s_branch", f"LOOP_{other}")
+        p.label(f"DRAIN_{me}")
+        iteration(p, cb, nb, False, f"D{me}")
+        p.br("s_branch", f"LOOP_{other}")
+    p.label("TAIL_E")
+    tail(p, 0)
+    p.br("s_branch", "END")
+    p.label("TAIL_O")
+    tail(p, 1)
+    p.label("END")
+    p.e("s_barrier")                                                       # the rings are free for the next unit's first requests
+    p.e("s_nop 15")
+    p.e("s_nop 7")
+    p.e(f"v_mov_b32 %[o_la], {vr(V_LA)}")
+    p.e(f"v_mov_b32 %[o_lb], {vr(V_LB)}")
+    p.e(f"v_mov_b32 %[o_ma], {vr(V_MA)}")
+    p.e(f"v_mov_b32 %[o_mb], {vr(V_MB)}")
+    p.br("s_branch", "EXIT")
+    p.finish()
+    p.label("EXIT")
+    return p
+
+
+def prologue():
+    """a unit's first requests: K(0), Q (straight into a[128:191]), V(0), K(1), V(1), K(2), K(3)"""
+    p = Prog()
+    X0, X1, X2 = 40, 41, 42
+
+    def tile(rs, add, slot_expr_reg):
+        # soffset of tile tlo + add for this wave, LDS destination in slot_expr_reg (already computed)
+        p.e(f"s_add_i32 {sr(X0)}, %[tlo], {add}")
+        p.e(f"s_lshl_b32 {sr(X0)}, {sr(X0)}, 1")
+        p.e(f"s_add_i32 {sr(X0)}, {sr(X0)}, %[wh]")
+        p.e(f"s_min_i32 {sr(X0)}, {sr(X0)}, {sr(X2)}")
+        p.e(f"s_lshl_b32 {sr(X0)}, {sr(X0)}, 13")
+        p.e(f"s_add_i32 {sr(X0)}, {sr(X0)}, %[wq]")
+        p.e(f"s_mov_b32 m0, {sr(slot_expr_reg)}")
+        p.e("s_nop 0")
+        for j in range(4):
+            p.e(f"buffer_load_dwordx4 %[vlane], {rs}, {sr(X0)} offen offset:{j * 1024} lds")
+
+    def kdst(add):
+        p.e(f"s_add_i32 {sr(X1)}, %[tlo], {add}")
+        p.e(f"s_and_b32 {sr(X1)}, {sr(X1)}, 3")
+        p.e(f"s_lshl_b32 {sr(X1)}, {sr(X1)}, 14")
+        p.e(f"s_add_i32 {sr(X1)}, {sr(X1)}, %[dbase]")
+
+    def vdst(slot):
+        p.e(f"s_add_i32 {sr(X1)}, %[dbase], {V_RING + slot * TILE}")
+
+    p.e(f"s_sub_i32 {sr(X2)}, %[nt32], 1")
+    kdst(0); tile("%[rk]", 0, X1)
+    p.e("v_add_u32_e32 v0, 0x1000, %[qa]")
+    p.e("v_add_u32_e32 v1, 0x1000, %[qb]")
+    for s in range(8):
+        va = "%[qa]" if s < 4 else "v0"
+        vb = "%[qb]" if s < 4 else "v1"
+        p.e(f"global_load_dwordx4 {ar(QA(s), 4)}, {va}, %[qbase] offset:{(s & 3) * 1024}")
+        p.e(f"global_load_dwordx4 {ar(QB(s), 4)}, {vb}, %[qbase] offset:{(s & 3) * 1024}")
+    vdst(0); tile("%[rv]", 0, X1)
+    p.e("s_cmp_lt_i32 %[nt], 2")
+    p.br("s_cbranch_scc1", "PDONE")
+    kdst(1); tile("%[rk]", 1, X1)
+    vdst(1); tile("%[rv]", 1, X1)
+    p.e("s_cmp_lt_i32 %[nt], 3")
+    p.br("s_cbranch_scc1", "PDONE")
+    kdst(2); tile("%[rk]", 2, X1)
+    p.e("s_cmp_lt_i32 %[nt], 4")
+    p.br("s_cbranch_scc1", "PDONE")
+    kdst(3); tile("%[rk]", 3, X1)
+    p.label("PDONE")
+    return p
+
+
+def epilogue(which, lp):
+    """block `which` of the finished unit: a[64 which ..] * inv -> this wave's LDS rows -> 256-byte row segments to memory.
+    fp32: two passes (64 d each); 16-bit: one pass.  Temps v0..v63."""
+    p = Prog()
+    base = 64 * which
+    if lp:
+        # 16 ds_write_b64: (t, rq) -> row i, bytes (t*32 + 8*rq + 4*hh)*2 ; the per-lane part (i, hh) is in %[sw]
+        for t in range(4):
+            for rq in range(4):
+                k = t * 4 + rq
+                tmp = 4 * (k % 8)           # 8 rotating quads v0..v31
+                for e in range(4):
+                    p.e(f"v_accvgpr_read_b32 {vr(tmp + e)}, {ar(base + 16 * t + 4 * rq + e)}")
+                for e in range(4):
+                    p.e(f"v_mul_f32 {vr(tmp + e)}, {vr(tmp + e)}, %[inv]")
+                p.e(f"PK {vr(32 + 2 * (k % 8))}, {vr(tmp)}, {vr(tmp + 1)}")
+                p.e(f"PK {vr(33 + 2 * (k % 8))}, {vr(tmp + 2)}, {vr(tmp + 3)}")
+                p.e(f"ds_write_b64 %[sw], {vr(32 + 2 * (k % 8), 2)} offset:{(t * 32 + 8 * rq) * 2}")
+                if k % 8 == 7:
+                    p.e("s_waitcnt lgkmcnt(0)")
+        for k in range(8):
+            p.e(f"ds_read_b128 {vr(4 * k, 4)}, %[sr] offset:{k * 4 * STAGE_ROW}")
+        p.e("s_waitcnt lgkmcnt(0)")
+        for k in range(8):
+            p.e(f"buffer_store_dwordx4 {vr(4 * k, 4)}, %[o{k}], %[ro], 0 offen")
+        p.e("s_nop 1")
+    else:
+        for half in range(2):
+            for t2 in range(2):
+                for rq in range(4):
+                    k = t2 * 4 + rq
+                    tmp = 32 + 4 * k        # 8 quads v32..v63
+                    for e in range(4):
+                        p.e(f"v_accvgpr_read_b32 {vr(tmp + e)}, {ar(base + 16 * (2 * half + t2) + 4 * rq + e)}")
+                    for e in range(4):
+                        p.e(f"v_mul_f32 {vr(tmp + e)}, {vr(tmp + e)}, %[inv]")
+                    p.e(f"ds_write_b128 %[sw], {vr(tmp, 4)} offset:{(t2 * 32 + 8 * rq) * 4}")
+            p.e("s_waitcnt lgkmcnt(0)")
+            for k in range(8):
+                p.e(f"ds_read_b128 {vr(4 * k, 4)}, %[sr] offset:{k * 4 * STAGE_ROW}")
+            p.e("s_waitcnt lgkmcnt(0)")
+            for k in range(8):
+                p.e(f"buffer_store_dwordx4 {vr(4 * k, 4)}, %[o{k}], %[ro], 0 offen offset:{half * 256}")
+            p.e("s_nop 1")
+    return p
+
+
+def clobbers(vtop, stop, agprs, extra=()):
+    items = [f'"v{i}"' for i in range(vtop + 1)] + [f'"a{i}"' for i in agprs] + [f'"s{i}"' for i in range(40, stop + 1)]
+    items += [f'"{x}"' for x in extra]
+    lines, cur = [], ""
+    for it in items:
+        if len(cur) + len(it) > 120:
+            lines.append(cur); cur = ""
+        cur += it + ", "
+    lines.append(cur.rstrip(", "))
+    return " \\\n    ".join(lines)
+
+
+def main():
+    parts = []
+    parts.append("// GENERATED by tools/gen_attn_q64.py — do not edit (the generator holds the register map and the schedule).\n"
+                 "// Instruction streams of the 64-queries-per-wave attention (attention_q64.hip); Q64_MFMA / Q64_PK are the mnemonics of the\n"
+                 "// operand type (bf16 / fp16 build).\n")
+
+    def macro(name, prog):
+        body = prog.text().replace("\n", " \\\n")
+        parts.append(f"#define {name} \\\n    {body}\n")
+
+    macro("Q64_ASM_CORE", core())
+    macro("Q64_ASM_PROLOGUE", prologue())
+    for which in (0, 1):
+        macro(f"Q64_ASM_EPI_F32_{'AB'[which]}", epilogue(which, False))
+        macro(f"Q64_ASM_EPI_LP_{'AB'[which]}", epilogue(which, True))
+    parts.append("#define Q64_CLOBBER_CORE \\\n    " + clobbers(V_TOP, S_TOP, range(256), ("vcc", "scc", "memory")) + "\n")
+    parts.append("#define Q64_CLOBBER_PROLOGUE \\\n    " + clobbers(1, 42, range(128, 192), ("scc", "memory")) + "\n")
+    parts.append("#define Q64_CLOBBER_EPI \\\n    " + clobbers(63, 39, (), ("memory",)) + "\n")
+    text = "\n".join(parts)
+    if "--check" in sys.argv:
+        cur = open(OUT).read() if os.path.exists(OUT) else ""
+        sys.exit(0 if cur == text else 1)
+    open(OUT, "w").write(text)
+    n_inst = text.count("\\n\\t")
+    print(f"wrote {os.path.normpath(OUT)}: {len(text)} bytes, {n_inst} instructions")
+
+
+if __name__ == "__main__":
+    main()
