@@ -44,11 +44,13 @@ WORKLOADS = {
     "gedex_b32": ("gedex_lj", 32, 512, 50, 0, None),
     "dex_b1": ("dex_vctk", 1, 512, 50, 348, None),
     "dex_b32": ("dex_vctk", 32, 256, 50, 348, None),             # configs[2]
+    "dex_b32_t512": ("dex_vctk", 32, 512, 50, 348, None),        # SURVEY 8(d) C3, the longer utterances
     "dex_esd_b32_n100": ("dex_esd", 32, 256, 100, 348, None),    # per-GPU share of configs[3] (256 utterances / 8 GPUs)
     "gedex_long": ("gedex_lj", 1, 4000, 50, 0, None),            # configs[4] shape
     "dex_libritts_b8": ("dex_libritts", 8, 256, 50, 348, None),  # not a BASELINE config: the dim-128 / hidden-384 geometry (per-operation reduced precision)
 }
-CONFIG_TAG = {"gedex_b1": "BASELINE.json configs[1]", "dex_b32": "BASELINE.json configs[2]",
+CONFIG_TAG = {"gedex_b1": "BASELINE.json configs[1]", "dex_b32": "BASELINE.json configs[2]", "dex_b32_t512": "SURVEY 8(d) C3 at T=512",
+              "gedex_b1_t800": "SURVEY 8(d) C2 at T=800", "gedex_b32": "BASELINE.json metric: batch = 32",
               "dex_esd_b32_n100": "BASELINE.json configs[3], per-GPU share (256 utterances / 8 GPUs)",
               "gedex_long": "BASELINE.json configs[4] shape"}
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
@@ -81,6 +83,30 @@ def make_inputs(cfg, lengths, T, TrTs, device, seed):
     return t(mu), t(mask), t(z), kw
 
 
+def host_cpu():
+    """What the CPU baseline ran on: logical CPUs visible to this process, physical cores and the model string (north_star: "core count stated")."""
+    info = {"logical_cpus": os.cpu_count(), "affinity_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+            "physical_cores": None, "model": None}
+    try:
+        cores, model = set(), None
+        phys = core = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name" and model is None:
+                model = v
+            elif k == "physical id":
+                phys = v
+            elif k == "core id":
+                core = v
+            elif not k and phys is not None:
+                cores.add((phys, core)); phys = core = None
+        info["physical_cores"], info["model"] = (len(cores) or None), model
+    except OSError:
+        pass
+    return info
+
+
 def cpu_baseline(cfg, weights, B, T, n_timesteps, TrTs):
     """Oracle (CPU restatement of the reference, torch ops on the host cores) on a bounded sample:
     a 3-step sampler of the same workload, scaled to n_timesteps."""
@@ -109,7 +135,7 @@ def cpu_baseline(cfg, weights, B, T, n_timesteps, TrTs):
     torch.set_num_threads(nt)
     per_step = dt / nsub
     frames_s = B * T / (per_step * n_timesteps)
-    return {"value": round(frames_s, 2), "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port",
+    return {"value": round(frames_s, 2), "unit": "mel-frames/s", "cores": torch.get_num_threads(), "kind": "port", "host": host_cpu(),
             "sample": f"{nsub} of {n_timesteps} Euler steps of the same workload (B={B}, T={T}), scaled x{n_timesteps}/{nsub}; "
                       f"{per_step * 1e3:.1f} ms/Euler-step on {torch.get_num_threads()} threads"}
 

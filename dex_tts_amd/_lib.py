@@ -133,6 +133,7 @@ SYMBOLS = [
     ("dex_text_workspace_bytes", C.c_size_t, [C.c_void_p, C.c_int, C.c_int]),
     ("dex_text_encode", C.c_int, [C.c_void_p, C.POINTER(DexTextArgs), C.c_void_p]),
     ("dex_text_align", C.c_int, [C.c_void_p, C.POINTER(DexAlignArgs), C.c_void_p]),
+    ("dex_call_status", C.c_int, [C.c_void_p, C.c_void_p]),
     ("dex_debug_handoff_timeouts", C.c_int, [C.c_void_p, C.c_void_p]),
     ("dex_debug_xcd_local", C.c_int, []),
     ("dex_mel_frames", C.c_int, [C.c_int]),

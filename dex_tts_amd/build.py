@@ -25,7 +25,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
 # the MFMA-heavy kernel files of the reduced-precision modes are compiled twice: operands bf16 (namespace dex::bf16) and,
 # with -DDEX_LP_F16, fp16 (namespace dex::f16) — csrc/lp_config.h
 LP_SOURCES = ("conv3x3_bf16.hip", "conv3x3_stream.hip", "igemm_bf16.hip", "attention_bf16.hip", "attention_direct.hip",
-              "dit_rowchain.hip", "linattn_fused.hip", "pos_conv.hip", "convt_up.hip", "conv3x3_regw.hip", "conv_down.hip", "patch_embed.hip")
+              "attention_q64.hip", "dit_rowchain.hip", "linattn_fused.hip", "pos_conv.hip", "convt_up.hip", "conv3x3_regw.hip", "conv_down.hip", "patch_embed.hip")
 
 
 # per-file flags.  -fno-slp-vectorize: the SLP vectorizer turns adjacent fp32 multiplies / adds into v_pk_*_f32, and a packed fp32
@@ -66,6 +66,7 @@ def _compile(job, force):
     src, extra, suffix = job
     obj = os.path.join(OBJ, src[:-4] + suffix + ".o")
     deps = [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    deps += [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".inc")]
     deps.append(os.path.join(HERE, "..", "include", "dex_amd.h"))
     if force or _stale(obj, deps):
         cmd = [HIPCC, *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]

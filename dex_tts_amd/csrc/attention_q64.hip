@@ -199,14 +199,20 @@ __global__ __launch_bounds__(256, 1) void attn_q64_kernel(const AttnDirectP p, c
     }
 }
 
-// Key split for the 64-query form: pick the split (1..max_split) that minimises  rounds of workgroups x (key tiles + overhead)
+// Key split for the 64-query form: the split (1..max_split) that minimises  rounds of workgroups x (key tiles + per-unit overhead)
+// + what every extra partial costs the consumer.  The row chain merges the partials while it loads its A tile: per extra partial
+// one more fp32 read of the whole O (and O itself leaves as fp32 instead of the 16-bit form a single split allows) - measured at DEX
+// B = 32, N = 1300: the 64-row chain 78 -> 94 us with two partials while the attention gained 4 us, so at batch size a split only
+// pays when it fills an otherwise idle chip (long-form: one utterance, 40 workgroup-sized query groups for 256 CUs).
 int attention_q64_ksplit(int N, int B, int max_split) {
     const int nt32 = (N + 31) / 32, nT = (nt32 + 1) / 2, ng = (nt32 + 7) / 8;
+    const double tile_us = 1.35, unit_us = 5.0;                              // per 64-key tile of a unit / per unit (first tile, last tile, output)
+    const double merge_us = (double)B * N * 256 * 4 / 4.0e6 + 1.0;           // one more partial through the consumer at ~4 TB/s
     int best = 1; double best_cost = 1e30;
     for (int ks = 1; ks <= max_split && ks <= nT; ++ks) {
         const long units = 2L * B * ng * ks;
         const long rounds = (units + 255) / 256;
-        const double cost = rounds * ((nT + ks - 1) / ks + 2.5) + 0.75 * (ks - 1);       // (+ the consumer's merge of every extra partial)
+        const double cost = rounds * (((nT + ks - 1) / ks) * tile_us + unit_us) + (ks > 1 ? merge_us * ks : 0.0);
         if (cost < best_cost - 1e-9) { best_cost = cost; best = ks; }
     }
     return best;

@@ -23,12 +23,23 @@ using namespace dex;
 static_assert(PREC_FP32 == DEX_PREC_FP32 && PREC_BF16 == DEX_PREC_BF16 && PREC_FP16 == DEX_PREC_FP16, "kernels.h mirrors DexPrecision");
 
 namespace {
+void xcd_map_probe();       // (defined with the cluster launch plan below)
 
 struct RawW { float* p = nullptr; std::vector<int64_t> shape; long numel = 0; bool loaded = false; };
 struct TD { float* p; int ld; int coff; int C; int lp = 0; };   // channels-last activation view; lp: 16-bit elements (1 bf16, 2 fp16)
 
 struct ResW { const float *w1, *b1, *g1, *be1, *w2, *b2, *g2, *be2, *wr, *br, *mlp_w, *mlp_b; int cin, cout; };
-constexpr int ATT_KSPLIT_MAX = 4;     // key-split attention partials kept per token (dit_rowchain.hip merges them)
+constexpr int ATT_KSPLIT_MAX = 4;     // key-split attention partials kept per token by the 32-query forms (dit_rowchain.hip merges them)
+// The 64-query form (attention_q64.hip) may split further where there are few tokens (long-form: one utterance, thousands of tokens, 40
+// workgroup-sized query groups for 256 CUs): up to 8 partials there, 4 at batch size (the partial buffer is tokens x hidden x cap fp32).
+static int att_split_cap(long tokens) { return tokens <= 20480 ? 8 : ATT_KSPLIT_MAX; }
+// ... and takes the attention of a launch when it can fill the chip: >= 1024 tokens per element and >= 128 work units at its best split
+static bool attention_q64_regime(int N, int B) {
+    if (N < 1024) return false;
+    const int ks = attention_q64_ksplit(N, B, att_split_cap((long)B * N));
+    const int nt32 = (N + 31) / 32, ng = (nt32 + 7) / 8;
+    return 2L * B * ng * ks >= 128;
+}
 struct LinW { const float *wqkv, *wqkv_raw, *wout_raw, *bias_eff, *g; const void *wq_lp[2], *wkv_lp[2], *wq_frag[2]; int C; };   // [0] bf16, [1] fp16
 struct DitBlockW { const float *wqkv, *bqkv, *wproj, *bproj, *wfc1, *bfc1, *wfc2, *bfc2, *ada_w, *ada_b; };
 
@@ -254,6 +265,7 @@ int dex_ctx_create(const DexConfig* cfg, DexCtx** out) {
     x->tuned = c.dim == 64 && c.dit_hidden == 256 && c.dit_heads == 2 && c.dit_hidden / c.dit_conv_pos_groups == 32 &&
                (c.variant != DEX_VARIANT_DEX || mid_dim(c) == 128);
     build_inventory(x);
+    xcd_map_probe();          // per device, outside any stream capture of the caller (it allocates and synchronises)
     return DEX_OK;
 }
 
@@ -614,8 +626,22 @@ static void zero_fill(void* p, size_t bytes, hipStream_t st) {
 // four members of a cluster by that rule so that their hand-offs stay inside one L2.  Probed once per process with launches of
 // the same shape (256 workgroups x 512 threads, 64 KB of LDS) that record HW_REG_XCC_ID; run from the public entry points
 // BEFORE any stream capture (it allocates).  The kernel re-checks every hand-off (flag words carry the writer's XCC id).
-static std::atomic<int> g_xcd_map{-1};      // -1 not probed, 0 no, 1 yes
-static std::mutex g_xcd_probe_mutex;         // (hosts with one context per thread: the probe runs once)
+// State is PER DEVICE ORDINAL (a process driving several GPUs or partitions must not reuse the first device's answer) and carries a
+// generation that is part of every graph-cache key: when a hand-off reports an XCC mismatch the form is switched off for the device
+// and the generation moves, so EVERY context stops hitting graphs captured with the XCD-local form.
+constexpr int MAX_DEVICES = 64;
+static std::atomic<int> g_xcd_map_dev[MAX_DEVICES];      // 0 not probed, 1 no, 2 yes  (zero-initialised)
+static std::atomic<int> g_xcd_gen{0};
+static std::mutex g_xcd_probe_mutex;         // (hosts with one context per thread: the probe runs once per device)
+static int cur_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; } return (d >= 0 && d < MAX_DEVICES) ? d : 0; }
+struct XcdMapRef {           // drop-in for the old process-wide atomic: load() = -1 not probed / 0 no / 1 yes of the CURRENT device
+    int load(std::memory_order = std::memory_order_seq_cst) const { return g_xcd_map_dev[cur_device()].load(std::memory_order_acquire) - 1; }
+    void store(int v, std::memory_order = std::memory_order_seq_cst) const {
+        const int old = g_xcd_map_dev[cur_device()].exchange(v + 1, std::memory_order_acq_rel);
+        if (old != v + 1) g_xcd_gen.fetch_add(1, std::memory_order_acq_rel);
+    }
+};
+static const XcdMapRef g_xcd_map;
 __global__ __launch_bounds__(512) void xcc_probe_kernel(unsigned* out) {
     extern __shared__ unsigned char probe_lds[];
     if (threadIdx.x == 0) {
@@ -625,7 +651,7 @@ __global__ __launch_bounds__(512) void xcc_probe_kernel(unsigned* out) {
         out[blockIdx.x] = x & 15u;
     }
 }
-static void xcd_map_probe() {
+void xcd_map_probe() {
     if (g_xcd_map.load(std::memory_order_acquire) >= 0) return;
     std::lock_guard<std::mutex> lk(g_xcd_probe_mutex);
     if (g_xcd_map.load(std::memory_order_relaxed) >= 0) return;
@@ -720,7 +746,7 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
     const int cg_ = hid / c.dit_conv_pos_groups, cgp_ = (cg_ % 32) ? 64 : cg_;      // pos-conv group width, padded to the GEMM's granule
     P.pe0 = A.f(tok * mid); P.emb = A.f(tok * hid); P.pos_part = A.f(tok * (size_t)c.dit_conv_pos_groups * cgp_ * POS_SPLIT); P.tok = A.f(tok * hid);
     P.emb_pad = cgp_ != cg_ ? A.f(tok * (size_t)c.dit_conv_pos_groups * cgp_) : nullptr;
-    P.xn = A.f(tok * hid); P.qkv = A.f(tok * 3 * hid); P.ao = A.f(tok * hid * ATT_KSPLIT_MAX); P.att_ml = A.f(tok * c.dit_heads * 2 * ATT_KSPLIT_MAX);
+    P.xn = A.f(tok * hid); P.qkv = A.f(tok * 3 * hid); P.ao = A.f(tok * hid * att_split_cap((long)tok)); P.att_ml = A.f(tok * c.dit_heads * 2 * att_split_cap((long)tok));
     P.Npad = (P.N + 31) / 32 * 32; P.vt_bytes = (size_t)B * hid * P.Npad * 2;
     P.qh = A.take(P.vt_bytes); P.kh = A.take(P.vt_bytes); P.vt = A.take(P.vt_bytes);    // all three padded to Npad rows
     P.qh2 = A.take(P.vt_bytes); P.kh2 = A.take(P.vt_bytes); P.vt2 = A.take(P.vt_bytes);
@@ -1111,21 +1137,30 @@ struct Runner {
                 const bool batch_regime = attention_direct_batch_regime(N, B);
                 // (measured end to end: DEX B=32 N=1300 +0.6 %, GeDEX B=32 N=650 -0.9 % — short key loops gain nothing from the
                 // rings and pay for the extra launch and the fp32 O round trip, so the automatic switch wants N >= 1024 too)
-                const bool separate = sep_env ? atoi(sep_env) != 0 : (batch_regime && N >= 1024);
+                // Round 4: the 64-queries-per-wave form (attention_q64.hip: 4 waves x 64 queries, persistent units, generated instruction
+                // streams) takes the separate launch wherever it can fill the chip - batched DEX (N = 1300: 0.31 of the MFMA peak against
+                // 0.28 for the shared-ring kernel) and long-form synthesis (N = 5010, one utterance: 0.33 against 0.19 fused into the block).
+                // DEX_ATTN_Q64=0 / 1 forces either (A/B, tests).
+                const char* q64_env = getenv("DEX_ATTN_Q64");
+                const bool q64_ok = q64_env ? atoi(q64_env) != 0 : attention_q64_regime(N, B);
+                const bool separate = sep_env ? atoi(sep_env) != 0 : ((batch_regime && N >= 1024) || q64_ok);
+                const bool q64 = separate && q64_ok;
                 int ks = 1;
                 bool o_lp = false;
                 if (separate) {
                     const long blocks = (long)((N + 31) / 32) * 2 * B;
                     const int ntiles = (N + 31) / 32;
-                    ks = batch_regime ? attention_direct_ksplit(N, B)
+                    ks = q64 ? attention_q64_ksplit(N, B, att_split_cap((long)B * N))
+                       : batch_regime ? attention_direct_ksplit(N, B)
                                       : (int)std::max<long>(1, std::min<long>(std::min<long>(768 / blocks, (ntiles + 7) / 8), ATT_KSPLIT_MAX));
                     AttnDirectP ad{ch.Qin, ch.Kin, ch.Vin, N, P.Npad, B, P.ao, (long)B * N * hid, ks > 1 ? P.att_ml : nullptr, ks, nullptr};
                     // O has one reader, the row chain's projection GEMM, which rounds it to the operand type: with one key split on the
-                    // batch forms (shared-ring attention -> 64-row chain) it is stored in that type - same bits, half the bytes
+                    // batch forms (shared-ring / 64-query attention -> 64-row chain) it is stored in that type - same bits, half the bytes
                     // (DEX_LP_INTER=0 keeps fp32)
-                    o_lp = batch_regime && ks == 1 && lp_inter_cur && dit_rowchain64_form(N, B, 0);
+                    o_lp = (batch_regime || q64) && ks == 1 && lp_inter_cur && dit_rowchain64_form(N, B, 0);
                     ad.o_lp = o_lp ? 1 : 0;
-                    run("dit_attention", 4.0 * B * (double)N * N * hid, 2.0 * 3 * B * N * hid + (o_lp ? 2.0 : 4.0) * B * N * hid * ks, [&] { launch_attention_direct(ad, x->precision, st); });
+                    run("dit_attention", 4.0 * B * (double)N * N * hid, 2.0 * 3 * B * N * hid + (o_lp ? 2.0 : 4.0) * B * N * hid * ks,
+                        [&] { if (q64) launch_attention_q64(ad, x->precision, st); else launch_attention_direct(ad, x->precision, st); });
                 }
                 ch.attn_inline = separate ? 0 : 1; ch.o_lp = o_lp ? 1 : 0;
                 const bool last = k + 1 == c.dit_depth;
@@ -1571,7 +1606,8 @@ int dex_sample(DexCtx* x, const DexSampleArgs* a, dex_stream_t stream) {
     int rc = validate(x, a, true);
     if (rc) return rc;
     if (a->solver != DEX_SOLVER_EULER && a->solver != DEX_SOLVER_HEUN) return x->fail(DEX_ERR_ARG, "solver must be DEX_SOLVER_EULER or DEX_SOLVER_HEUN (edm.py:107)");
-    xcd_map_probe();                    // (once per process, before any capture)
+    xcd_map_probe();                    // (once per device, before any capture; normally already done by dex_ctx_create)
+    x->last_xerr = nullptr;             // set again by this call if it uses in-launch hand-offs (dex_call_status)
     hipStream_t st = (hipStream_t)stream;
     const bool heun = a->solver == DEX_SOLVER_HEUN;
     {
@@ -1600,9 +1636,10 @@ int dex_sample(DexCtx* x, const DexSampleArgs* a, dex_stream_t stream) {
                                  (uint64_t)(uintptr_t)a->sigmas_dev, (uint64_t)(uintptr_t)a->spk_dev, (uint64_t)(uintptr_t)a->sty_dev,
                                  (uint64_t)(uintptr_t)a->sty_lengths_dev, (uint64_t)(uintptr_t)a->out_dev, (uint64_t)(uintptr_t)a->workspace_dev,
                                  (uint64_t)(uintptr_t)(a->S_churn > 0.f ? a->noise_dev : nullptr)};
+    key.push_back((uint64_t)g_xcd_gen.load(std::memory_order_acquire));          // placement rule of the cluster hand-offs (see g_xcd_map)
     for (float v : {a->S_churn, a->S_min, a->S_max, a->S_noise}) { uint32_t u; memcpy(&u, &v, 4); key.push_back(u); }
     for (int j = 0; j < a->n_ref; ++j) key.push_back((uint64_t)(uintptr_t)a->ref_skips_dev[j]);
-    for (const char* e : {"DEX_CONV_STREAM", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN", "DEX_DIT_CLUSTER", "DEX_DIT_CLUSTER_LOCAL", "DEX_ATTN_X_LP", "DEX_RES_X_LP", "DEX_CAT_LP", "DEX_XCD_MAP", "DEX_DEBUG_DROP_HANDOFF", "DEX_PATCH_FUSED"}) {     // knobs read at enqueue time
+    for (const char* e : {"DEX_CONV_STREAM", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN", "DEX_DIT_CLUSTER", "DEX_DIT_CLUSTER_LOCAL", "DEX_ATTN_X_LP", "DEX_RES_X_LP", "DEX_CAT_LP", "DEX_XCD_MAP", "DEX_DEBUG_DROP_HANDOFF", "DEX_PATCH_FUSED", "DEX_ATTN_Q64"}) {     // knobs read at enqueue time
         const char* v = getenv(e);
         key.push_back(v ? (uint64_t)atoi(v) + 1 : 0);
     }
@@ -1684,6 +1721,22 @@ int dex_profile_get(const DexCtx* x, int i, const char** name, int* calls, doubl
 
 // ---- STFT / mel front-end -------------------------------------------------------------------------
 int dex_mel_frames(int n_samples) { return n_samples / 256 + 1; }
+
+// Status of the last dex_sample / dex_denoise_once call of this context on `stream`: waits for the stream, reads the call's hand-off
+// word.  DEX_OK, or DEX_ERR_HANDOFF when an in-launch hand-off of the cluster row chain timed out (1) or met a peer on another XCD
+// (2) - the call's outputs are NaN in that case.  An XCC mismatch switches the XCD-local form off for the device (all contexts:
+// the graph-cache generation moves), so simply repeating the call takes the placement-independent form.
+int dex_call_status(DexCtx* x, dex_stream_t stream) {
+    if (!x) return DEX_ERR_ARG;
+    if (!x->last_xerr) return DEX_OK;
+    int v = 0;
+    if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipMemcpy(&v, x->last_xerr, sizeof v, hipMemcpyDeviceToHost) != hipSuccess)
+        return x->fail(DEX_ERR_HIP, "dex_call_status: could not read the hand-off word");
+    if (v == 0) return DEX_OK;
+    if (v == 2 && !getenv("DEX_DEBUG_DROP_HANDOFF")) { g_xcd_map.store(0); x->drop_graphs(); }
+    return x->fail(DEX_ERR_HANDOFF, v == 2 ? "a cluster hand-off met its peer on another XCD (outputs poisoned); the XCD-local form is now off for this device - repeat the call"
+                                           : "a cluster hand-off timed out (outputs poisoned)");
+}
 
 int dex_debug_handoff_timeouts(DexCtx* x, dex_stream_t stream) {
     if (!x) return DEX_ERR_ARG;

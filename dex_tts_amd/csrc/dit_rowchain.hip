@@ -172,6 +172,63 @@ __device__ __forceinline__ void store_qkv_tile(const DitChainP& p, const f32x16&
 // ATTN: the attention core of the block runs INSIDE this launch (no attention kernel, no partials in HBM): waves 0-3 take
 // head 0, waves 4-7 head 1, each group splits the key tiles four ways (attention_direct.hip's wave body), the partial
 // (m, l, O) are merged through LDS straight into the bf16 A tile of the projection.
+// Merge of the key-split attention partials of token n of element b for this thread's columns (seg * 4 .. + 3 of each 64-column
+// block q; block q belongs to head q / 2, head_dim 128):  O = sum_s w_s O_s / sum_s w_s,  w_s = l_s 2^(m_s - max m)  (log2-domain
+// maxima).  Up to RC_MAX_SPLITS splits, four at a time (16 loads in flight per round; one round = the <= 4 splits of the 32-query
+// attention forms, same operation order as before; the 64-query form takes up to 8 at long-form shapes).
+constexpr int RC_MAX_SPLITS = 8;
+__device__ __forceinline__ void rc_merge_splits(const DitChainP& p, const float* src, int b, int n, float4 (&v)[4]) {
+    float w[2][RC_MAX_SPLITS], inv[2];
+    {
+        float2 st[RC_MAX_SPLITS][2];
+#pragma unroll
+        for (int s_ = 0; s_ < RC_MAX_SPLITS; ++s_)
+            if (s_ < p.ksplit) {
+#pragma unroll
+                for (int hd = 0; hd < 2; ++hd)
+                    st[s_][hd] = *reinterpret_cast<const float2*>(p.ml + ((((long)s_ * p.B + b) * p.heads + hd) * p.rows_per_batch + n) * 2);
+            }
+#pragma unroll
+        for (int hd = 0; hd < 2; ++hd) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int s_ = 0; s_ < RC_MAX_SPLITS; ++s_) if (s_ < p.ksplit) mx = fmaxf(mx, st[s_][hd].x);
+            float wsum = 0.f;
+#pragma unroll
+            for (int s_ = 0; s_ < RC_MAX_SPLITS; ++s_) {
+                w[hd][s_] = 0.f;
+                if (s_ < p.ksplit) { w[hd][s_] = st[s_][hd].y * exp2f(st[s_][hd].x - mx); wsum += w[hd][s_]; }
+            }
+            inv[hd] = 1.f / wsum;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int r0 = 0; r0 < RC_MAX_SPLITS; r0 += 4) {
+        if (r0 < p.ksplit) {                                  // (uniform)
+            float4 pv[4][4];
+#pragma unroll
+            for (int s_ = 0; s_ < 4; ++s_)
+                if (r0 + s_ < p.ksplit) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) pv[s_][q] = *reinterpret_cast<const float4*>(src + (long)(r0 + s_) * p.o_sstride + q * 64);
+                }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_)
+                    if (r0 + s_ < p.ksplit) {
+                        const float ws = w[q >> 1][r0 + s_];
+                        v[q].x = fmaf(ws, pv[s_][q].x, v[q].x); v[q].y = fmaf(ws, pv[s_][q].y, v[q].y);
+                        v[q].z = fmaf(ws, pv[s_][q].z, v[q].z); v[q].w = fmaf(ws, pv[s_][q].w, v[q].w);
+                    }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const float iv = inv[q >> 1]; v[q] = make_float4(v[q].x * iv, v[q].y * iv, v[q].z * iv, v[q].w * iv); }
+}
+
 template <bool ATTN>
 __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChainP p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_rc[];
@@ -368,45 +425,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(src + q * 64);
         } else {
-            // merge the key-split attention partials: O = sum_s w_s O_s / sum_s w_s,  w_s = l_s 2^(m_s - max m)
-            // (column block q belongs to head q / 2: head_dim 128)
-            const int bb = b, nbat = p.B;
-            float4 pv[4][4];
-            float2 st[4][2];
-#pragma unroll
-            for (int s_ = 0; s_ < 4; ++s_) {
-                if (s_ < p.ksplit) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) pv[s_][q] = *reinterpret_cast<const float4*>(src + (long)s_ * p.o_sstride + q * 64);
-#pragma unroll
-                    for (int hd = 0; hd < 2; ++hd)
-                        st[s_][hd] = *reinterpret_cast<const float2*>(p.ml + ((((long)s_ * nbat + bb) * p.heads + hd) * p.rows_per_batch + n) * 2);
-                }
-            }
-#pragma unroll
-            for (int hd = 0; hd < 2; ++hd) {
-                float mx = -INFINITY;
-#pragma unroll
-                for (int s_ = 0; s_ < 4; ++s_) if (s_ < p.ksplit) mx = fmaxf(mx, st[s_][hd].x);
-                float wsum = 0.f, w[4];
-#pragma unroll
-                for (int s_ = 0; s_ < 4; ++s_) {
-                    w[s_] = 0.f;
-                    if (s_ < p.ksplit) { w[s_] = st[s_][hd].y * exp2f(st[s_][hd].x - mx); wsum += w[s_]; }   // log2-domain maxima
-                }
-                const float inv = 1.f / wsum;
-#pragma unroll
-                for (int qq = 0; qq < 2; ++qq) {
-                    const int q = hd * 2 + qq;
-                    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                    for (int s_ = 0; s_ < 4; ++s_) if (s_ < p.ksplit) {
-                        a.x = fmaf(w[s_], pv[s_][q].x, a.x); a.y = fmaf(w[s_], pv[s_][q].y, a.y);
-                        a.z = fmaf(w[s_], pv[s_][q].z, a.z); a.w = fmaf(w[s_], pv[s_][q].w, a.w);
-                    }
-                    v[q] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
-                }
-            }
+            rc_merge_splits(p, src, b, n, v);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -594,42 +613,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain64_kernel(const DitCha
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(src + q * 64);
             } else {
-                float4 pv[4][4];
-                float2 st[4][2];
-#pragma unroll
-                for (int s_ = 0; s_ < 4; ++s_) {
-                    if (s_ < p.ksplit) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) pv[s_][q] = *reinterpret_cast<const float4*>(src + (long)s_ * p.o_sstride + q * 64);
-#pragma unroll
-                        for (int hd = 0; hd < 2; ++hd)
-                            st[s_][hd] = *reinterpret_cast<const float2*>(p.ml + ((((long)s_ * p.B + b) * p.heads + hd) * p.rows_per_batch + n) * 2);
-                    }
-                }
-#pragma unroll
-                for (int hd = 0; hd < 2; ++hd) {
-                    float mx = -INFINITY;
-#pragma unroll
-                    for (int s_ = 0; s_ < 4; ++s_) if (s_ < p.ksplit) mx = fmaxf(mx, st[s_][hd].x);
-                    float wsum = 0.f, w[4];
-#pragma unroll
-                    for (int s_ = 0; s_ < 4; ++s_) {
-                        w[s_] = 0.f;
-                        if (s_ < p.ksplit) { w[s_] = st[s_][hd].y * exp2f(st[s_][hd].x - mx); wsum += w[s_]; }
-                    }
-                    const float inv = 1.f / wsum;
-#pragma unroll
-                    for (int qq = 0; qq < 2; ++qq) {
-                        const int q = hd * 2 + qq;
-                        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                        for (int s_ = 0; s_ < 4; ++s_) if (s_ < p.ksplit) {
-                            a.x = fmaf(w[s_], pv[s_][q].x, a.x); a.y = fmaf(w[s_], pv[s_][q].y, a.y);
-                            a.z = fmaf(w[s_], pv[s_][q].z, a.z); a.w = fmaf(w[s_], pv[s_][q].w, a.w);
-                        }
-                        v[q] = make_float4(a.x * inv, a.y * inv, a.z * inv, a.w * inv);
-                    }
-                }
+                rc_merge_splits(p, src, b, n, v);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -839,11 +823,21 @@ __device__ __forceinline__ unsigned xcc_id() {
 template <bool LOCAL>
 __device__ __forceinline__ void cluster_wait(unsigned* flags, int member, unsigned epoch, unsigned my_xcc, int tid, int* xerr) {
     if (tid < DIT_CLUSTER && tid != member) {
-        const long long t0 = wall_clock64();
+        long long t0 = wall_clock64(), last = t0;
         unsigned v;
         while (((v = ClScope<LOCAL>::poll(flags + tid)) & 0xffffffu) != epoch) {
             __builtin_amdgcn_s_sleep(LOCAL ? 1 : 2);
-            if (wall_clock64() - t0 > 5000000LL) { if (xerr) *xerr = 1; v = epoch | (my_xcc << 24); break; }       // 50 ms at 100 MHz: never in a healthy launch
+            const long long now = wall_clock64();
+            // a poll-to-poll gap of > 1 ms means THIS wave was off the CU (queue pre-empted, CWSR, debugger): the deadline measures
+            // waiting, not being descheduled, so it restarts (a healthy launch must not be poisoned by a 50 ms preemption)
+            if (now - last > 100000LL) t0 = now;
+            last = now;
+            if (now - t0 > 5000000LL) {                                       // 50 ms at 100 MHz of actual polling: never in a healthy launch
+                if (((v = ClScope<LOCAL>::poll(flags + tid)) & 0xffffffu) == epoch) break;      // one last look before giving up
+                if (xerr) *xerr = 1;
+                v = epoch | (my_xcc << 24);
+                break;
+            }
         }
         if (LOCAL && (v >> 24) != my_xcc && xerr) *xerr = 2;          // a peer on another XCD: its payload is not in this L2
     }

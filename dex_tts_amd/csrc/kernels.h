@@ -289,6 +289,8 @@ struct AttnDirectP { const void *Qh, *Kh, *Vt; int N, Npad, B; float* O; long o_
 void launch_attention_direct(const AttnDirectP& p, int precision, hipStream_t st);
 bool attention_direct_batch_regime(int N, int B);     // shared-ring kernel (many query tiles) vs key-splitting waves (few)
 int attention_direct_ksplit(int N, int B);             // key split the batch regime wants for an even load
+void launch_attention_q64(const AttnDirectP& p, int precision, hipStream_t st);     // attention_q64.hip: the batch / long-form form (64 queries per wave)
+int attention_q64_ksplit(int N, int B, int max_split);
 void launch_dit_rowchain(const DitChainP& p, int precision, hipStream_t st);
 void launch_pack_lp_frag(const float* src, void* dst, int K, int N, int precision, hipStream_t st);
 void launch_pack_lp_frag_nk(const float* src, void* dst, int K, int N, int precision, hipStream_t st);   // source [N][K]

@@ -36,6 +36,9 @@ void launch_attention_lp(const AttnP& p, hipStream_t st);
 void launch_attention_direct(const AttnDirectP& p, hipStream_t st);
 bool attention_direct_batch_regime(int N, int B);
 int attention_direct_ksplit(int N, int B);
+// 64-queries-per-wave form (attention_q64.hip): 4 waves x 64 queries, persistent work units, up to max_split key splits
+void launch_attention_q64(const AttnDirectP& p, hipStream_t st);
+int attention_q64_ksplit(int N, int B, int max_split);
 // DiT row chain (dit_rowchain.hip) and its weight packing
 bool dit_rowchain_supported(int hidden, int mlp_hidden);
 bool dit_rowchain64_form(int rows_per_batch, int B, int attn_inline);

@@ -27,6 +27,7 @@ bool conv3x3_strip_form(const Conv3P& p) { return bf16::conv3x3_stream_tiles(p) 
 bool pos_conv_direct_supported(int hid, int groups, int kernel, int Hf) { return bf16::pos_conv_direct_supported(hid, groups, kernel, Hf); }
 bool attention_direct_batch_regime(int N, int B) { return bf16::attention_direct_batch_regime(N, B); }
 int attention_direct_ksplit(int N, int B) { return bf16::attention_direct_ksplit(N, B); }
+int attention_q64_ksplit(int N, int B, int max_split) { return bf16::attention_q64_ksplit(N, B, max_split); }
 bool conv_down_supported(int C, int H, int W, int ldx, int ldy, int x_coff) { return bf16::conv_down_supported(C, H, W, ldx, ldy, x_coff); }
 bool convt_up_supported(int C, int H, int W, int ldx, int ldy) { return bf16::convt_up_supported(C, H, W, ldx, ldy); }
 bool patch_embed_fused_supported(int k, int C, int hid, long ntok) { return bf16::patch_embed_fused_supported(k, C, hid, ntok); }
@@ -43,6 +44,7 @@ void launch_convt_up(const ConvTUpP& p, int precision, hipStream_t st) { DEX_LP_
 void launch_conv_down(const ConvDownP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_conv_down, p, st); }
 void launch_attention_lp(const AttnP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_attention_lp, p, st); }
 void launch_attention_direct(const AttnDirectP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_attention_direct, p, st); }
+void launch_attention_q64(const AttnDirectP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_attention_q64, p, st); }
 void launch_dit_rowchain(const DitChainP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_dit_rowchain, p, st); }
 void launch_pack_lp_frag(const float* src, void* dst, int K, int N, int precision, hipStream_t st) { DEX_LP_CALL(launch_pack_lp_frag, src, dst, K, N, st); }
 void launch_pack_lp_frag_nk(const float* src, void* dst, int K, int N, int precision, hipStream_t st) { DEX_LP_CALL(launch_pack_lp_frag_nk, src, dst, K, N, st); }

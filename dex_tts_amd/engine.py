@@ -54,6 +54,8 @@ class ScoreNetEngine:
         self.loaded_version = None
 
     # ---------------------------------------------------------------------------------------
+    check_handoffs = True        # sample(): verify the in-launch hand-offs of a call before returning its result (see dex_call_status)
+
     def _check(self, rc: int):
         if rc != 0:
             msg = self.lib.dex_last_error(self.h)
@@ -239,7 +241,18 @@ class ScoreNetEngine:
                 a = _lib.DexSampleArgs()
                 keep = self._fill_args(a, mu, mask, sig, out, n_steps, spk, ref, sty, sty_lengths, use_graph, solver, noise, churn)
                 a.z_dev = z.data_ptr()
-                self._check(self.lib.dex_sample(self.h, C.byref(a), self._stream()))
+                for attempt in (0, 1):
+                    self._check(self.lib.dex_sample(self.h, C.byref(a), self._stream()))
+                    # calls that used in-launch hand-offs (small grids: the cluster form of the DiT block) are checked before their
+                    # result is handed out: a lost hand-off poisons the outputs with NaN, and a NaN mel must not leave silently
+                    # (ADVICE r3).  dex_call_status returns at once, without waiting, for calls that used none.
+                    rc = self.lib.dex_call_status(self.h, self._stream()) if self.check_handoffs else 0
+                    if rc == 0:
+                        break
+                    msg = self.lib.dex_last_error(self.h) or b""
+                    if attempt == 0 and b"another XCD" in msg:
+                        continue                   # the XCD-local form was just switched off for this device: the repeat is placement-independent
+                    raise RuntimeError(f"libdexamd error {rc}: {msg.decode()}")
                 self._keep = keep + [z]           # keep inputs alive until the stream work is enqueued & consumed
                 if use_graph:
                     out = out.clone()             # the staging output is overwritten by the next replay

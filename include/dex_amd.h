@@ -35,7 +35,8 @@ typedef enum {
     DEX_ERR_ARG = -1,      /* bad argument / shape (e.g. T % 4 != 0, unknown key, wrong weight shape) */
     DEX_ERR_STATE = -2,    /* call order (weights missing, not finalized) */
     DEX_ERR_HIP = -3,      /* a HIP runtime call failed */
-    DEX_ERR_WORKSPACE = -4 /* workspace too small */
+    DEX_ERR_WORKSPACE = -4,/* workspace too small */
+    DEX_ERR_HANDOFF = -5   /* dex_call_status: an in-launch hand-off of the small-batch DiT block failed; the call's outputs are NaN */
 } DexStatus;
 
 typedef enum { DEX_VARIANT_GEDEX = 0, DEX_VARIANT_DEX = 1 } DexVariant;
@@ -142,6 +143,13 @@ int  dex_profile_num(const DexCtx* ctx);
 int  dex_profile_get(const DexCtx* ctx, int i, const char** name, int* calls, double* total_ms,
                      double* flops, double* bytes);
 
+/* Status of the LAST dex_sample / dex_denoise_once call of this context on `stream`.  Small-grid DiT blocks run as clusters of
+ * co-operating workgroups whose in-launch hand-offs are bounded waits: a lost hand-off cannot hang the GPU, it turns every output of
+ * the call into NaN and sets a device word.  This call waits for the stream and reads that word: DEX_OK, or DEX_ERR_HANDOFF (the
+ * outputs are NaN).  When the cause was a peer on another XCD the XCD-local form is switched off for the device - for every
+ * context - so repeating the call succeeds.  Calls that used no hand-offs return DEX_OK without waiting.  The Python mirror
+ * (ScoreNetEngine.sample) checks every call that could use hand-offs and raises. */
+int  dex_call_status(DexCtx* ctx, dex_stream_t stream);
 /* Debug: 1 if a workgroup hand-off of the LAST dex_sample / dex_denoise_once call on this context timed out (small-grid DiT
  * blocks run as clusters of co-operating workgroups; a wait is bounded so a lost hand-off cannot hang the GPU), 0 if none did or
  * the call used no hand-offs, < 0 on a HIP error.  Synchronises the stream; the call's workspace must still be alive. */

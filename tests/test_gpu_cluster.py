@@ -84,7 +84,13 @@ def test_lost_handoff_is_loud():
         assert np.isfinite(good).all() and eng.handoff_timeouts() == 0
         os.environ["DEX_DEBUG_DROP_HANDOFF"] = "1"
         try:
-            bad = _run(eng, case, 2)
+            with pytest.raises(RuntimeError, match="hand-off timed out"):       # the host mirror checks every call that uses hand-offs
+                _run(eng, case, 2)
+            eng.check_handoffs = False                                           # ... unless told not to: the poisoned result itself
+            try:
+                bad = _run(eng, case, 2)
+            finally:
+                eng.check_handoffs = True
             assert eng.handoff_timeouts() == 1
         finally:
             del os.environ["DEX_DEBUG_DROP_HANDOFF"]
@@ -144,7 +150,13 @@ def test_l2_scope_handoff_across_xcds_is_loud():
         assert np.isfinite(good).all() and eng.handoff_timeouts() == 0
         os.environ["DEX_DEBUG_DROP_HANDOFF"] = "2"
         try:
-            bad = _run(eng, case, 2)
+            with pytest.raises(RuntimeError, match="hand-off"):
+                _run(eng, case, 2)
+            eng.check_handoffs = False
+            try:
+                bad = _run(eng, case, 2)
+            finally:
+                eng.check_handoffs = True
             assert eng.handoff_timeouts() in (1, 2)
         finally:
             del os.environ["DEX_DEBUG_DROP_HANDOFF"]
