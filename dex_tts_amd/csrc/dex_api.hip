@@ -1808,7 +1808,7 @@ int dex_mel_spectrogram(DexMel* m, const float* wav_dev, int B, int n, float* me
 }
 
 int dex_lf0_normalize(const float* f0_dev, const int* lengths_dev, int B, int T, float* lf0_dev, dex_stream_t stream) {
-    if (!f0_dev || !lf0_dev || B < 1 || T < 1 || T > 16384) return DEX_ERR_ARG;       // (the voiced frames of an utterance are staged in 64 KB of LDS)
+    if (!f0_dev || !lf0_dev || B < 1 || T < 1 || T > 16382) return DEX_ERR_ARG;       // (the voiced frames of an utterance are staged in LDS: 4 T + 8 bytes must fit the 64 KB a launch gets without an attribute)
     launch_lf0_normalize(f0_dev, lengths_dev, B, T, lf0_dev, (hipStream_t)stream);
     return hipGetLastError() == hipSuccess ? DEX_OK : DEX_ERR_HIP;
 }

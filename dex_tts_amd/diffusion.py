@@ -59,6 +59,20 @@ class _Precond(nn.Module):
         super().__init__()
         self.model = model
         self.sigma_min, self.sigma_max, self.sigma_data = 0, float("inf"), sigma_data
+        self._owner = None           # weakref to the owning Diffusion, set by it (and re-set on deepcopy / unpickle)
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_owner"] = None                   # (weakrefs do not pickle: the owner binds again in its __setstate__ / before every use)
+        return st
+
+    def _denoise_once(self, x, sigma, mask, mu, **kw):
+        """One EDMPrecond.forward on the OWNER's engine (EDMLoss): resolved at call time, so a deep copy of the model evaluates with
+        its own weights and engine, and the module holds no closure (torch.save / pickle work, no reference cycle)."""
+        owner = self._owner() if self._owner is not None else None
+        if owner is None:
+            raise RuntimeError("precond_model has no live owner (it belongs to a dex_tts_amd.diffusion.Diffusion)")
+        return owner.engine(x.device).denoise_once(x, sigma, mask, mu, **kw)
 
 
 def _cfg_get(obj, name, default):
@@ -82,7 +96,7 @@ class Diffusion(nn.Module):
         self.denoise_fn = _build_tree(param_shapes(self.cfg))
         self.precond_model = _Precond(self.denoise_fn)
         self.loss_fn = EDMLoss(n_feats=n_feats, loss_type=loss_type)       # diffusion.py:215: forward-only here (dex_tts_amd/edm.py)
-        self.precond_model._denoise_once = lambda x, sigma, mask, mu, **kw: self.engine(x.device).denoise_once(x, sigma, mask, mu, **kw)
+        self._bind_owner()
         self.precision = "fp32"
         self.use_graph = False
         self.solver = "euler"                    # the reference wires 'euler' (diffusion.py:216); 'heun' = edm.py:207-214
@@ -91,7 +105,39 @@ class Diffusion(nn.Module):
         self.S_churn, self.S_min, self.S_max, self.S_noise = 0.0, 0.0, float("inf"), 1.0
         self._engine = None
         self._engine_key = None
-        if variant == "dex":
+        self._make_sampler()
+
+    def _bind_owner(self):
+        import weakref
+        self.precond_model._owner = weakref.ref(self)
+
+    def __deepcopy__(self, memo):
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k in ("_engine", "_engine_key", "sampler"):
+                continue
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        new._engine, new._engine_key = None, None
+        new._make_sampler()
+        new._bind_owner()
+        return new
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_engine"], st["_engine_key"] = None, None
+        st.pop("sampler", None)
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+        self._make_sampler()
+        self._bind_owner()
+
+    def _make_sampler(self):
+        if self.cfg.variant == "dex":
             self.sampler = lambda z, mask, mu, ref, ref_lengths, sty, sty_lengths, spk, steps: self._sample(
                 z, mask, mu, steps, spk, ref, sty, sty_lengths)
         else:
@@ -150,6 +196,7 @@ class Diffusion(nn.Module):
             vals[n] = v
         if not vals["infer"]:                     # diffusion.py:222-224 / :252-254: the EDM training-loss VALUE (no backward on this path)
             dex = (vals["ref"], vals["ref_lengths"], vals["sty"], vals["sty_lengths"]) if self.cfg.variant == "dex" else ()
+            self._bind_owner()                    # (an unpickled module restores its sub-modules' state after its own)
             return self.loss_fn(self.precond_model, x, mask, mu, *dex, spk=vals["spk"], mask_ratio=vals["mask_ratio"])
         shape = (mu.shape[0], 80, mu.shape[2])
         z = torch.randn(shape, device=x.device) / vals["temperature"] + mu            # diffusion.py:227

@@ -8,6 +8,13 @@ Padding is not neutral in the reference (norm/softmax statistics include padded 
 length of every utterance is fixed BEFORE sharding: all ranks pad to the global batch maximum, which is
 exactly what a single-GPU batched run would do.
 
+Opt-in LENGTH BUCKETING (``sample_bucketed``): padding to the global maximum makes every kernel process the padding too (with
+lengths spread over 0.6 T .. T about a fifth of the frames of a batch are padding, and the metric counts valid frames).  A bucket
+is the set of utterances whose length rounds up to the same multiple of ``bucket_width`` frames; each bucket is padded to ITS OWN
+maximum and sampled as a batch of its own, i.e. its result is exactly what the reference computes when it is handed that bucket
+as its batch ("pad to the global batch max, or to per-bucket max").  It is NOT the result of the globally padded
+batch - padded columns enter the norm / softmax statistics - which is why bucketing is never the default.
+
 A rank needs only ITS utterances plus the lengths of all of them (``take_shard`` / ``local=True``): the
 partition is a pure function of the lengths, so every rank derives the same deal without communication.
 """
@@ -117,3 +124,32 @@ def sample_sharded(sample_fn: Callable[[torch.Tensor, torch.Tensor, torch.Tensor
     else:
         full.index_copy_(0, dst_t, gathered.index_select(0, torch.as_tensor(src, dtype=torch.long, device=mu.device)))
     return full
+
+
+def buckets_of(lengths: Sequence[int], bucket_width: int, n_stages: int = 2) -> List[tuple]:
+    """[(padded_T, [utterance indices])] - utterances whose length rounds up to the same multiple of ``bucket_width`` share a
+    bucket, padded to the bucket's own maximum (``fix_len_compatibility``); ascending padded length, input order inside a bucket."""
+    if bucket_width < 1:
+        raise ValueError("bucket_width must be >= 1")
+    groups = {}
+    for i, l in enumerate(lengths):
+        groups.setdefault(-(-int(l) // bucket_width), []).append(i)
+    return [(padded_length([lengths[i] for i in idx], n_stages), idx) for _, idx in sorted(groups.items())]
+
+
+def sample_bucketed(sample_fn: Callable[..., torch.Tensor], mu: torch.Tensor, mask: torch.Tensor, z: torch.Tensor, lengths: Sequence[int],
+                    bucket_width: int, group=None, extras: Optional[dict] = None, n_stages: int = 2) -> torch.Tensor:
+    """``sample_sharded`` bucket by bucket (see the module docstring): every bucket is cropped to its own padded length, dealt over the
+    ranks of ``group`` and sampled as one batch; returns [B, 80, T] in input order, zero beyond a bucket's padded length.  Full-batch
+    inputs on every rank (``local=False`` semantics).  Per bucket the result equals ``sample_fn`` on that bucket alone."""
+    B, F, T = mu.shape
+    out = torch.zeros(B, F, T, dtype=torch.float32, device=mu.device)
+    for Tb, idx in buckets_of(lengths, bucket_width, n_stages):
+        Tb = min(Tb, T)
+        ix = torch.as_tensor(idx, dtype=torch.long, device=mu.device)
+        sel = lambda t: t.index_select(0, ix.to(t.device))
+        ex = {k: ([sel(t) for t in v] if isinstance(v, (list, tuple)) else sel(v)) for k, v in (extras or {}).items()}
+        y = sample_sharded(sample_fn, sel(mu)[:, :, :Tb].contiguous(), sel(mask)[:, :, :Tb].contiguous(), sel(z)[:, :, :Tb].contiguous(),
+                           [lengths[i] for i in idx], group=group, local=False, extras=ex)
+        out[ix, :, :Tb] = y
+    return out

@@ -180,7 +180,8 @@ int  dex_mel_spectrogram(DexMel* mel, const float* wav_dev, int B, int n_samples
 
 /* Deterministic tail of the DEX f0 front-end (DEX-TTS/synthesize.py:26-38,55-58): f0 [B,T] in Hz (0 = unvoiced; from the
  * host's DIO/StoneMask, a third-party CPU algorithm that stays on the host) -> lf0 [B,T] = normalize_lf0(log f0), what
- * dex_style_encode takes as lf0_dev.  lengths_dev [B] int32 or NULL (= T); positions past an utterance's length are 0. */
+ * dex_style_encode takes as lf0_dev.  lengths_dev [B] int32 or NULL (= T); positions past an utterance's length are 0.
+ * T <= 16382 frames (190 s of audio at hop 256): DEX_ERR_ARG beyond. */
 int  dex_lf0_normalize(const float* f0_dev, const int* lengths_dev, int B, int T, float* lf0_dev, dex_stream_t stream);
 
 /* ---- Vocoder: HiFi-GAN generator (GeDEX-TTS/hifigan/models.py:112-173, built by src/utils.py:251-281 from

@@ -20,9 +20,15 @@ def main():
     preset, prec, n_steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
     lengths = [int(v) for v in sys.argv[4].split(",")]
     out_path = sys.argv[5]
-    dist.init_process_group("gloo")
+    backend = os.environ.get("DEX_DIST_BACKEND", "gloo")
+    if backend == "nccl":                     # one process per GPU, RCCL (tests/test_gpu_dist.py::test_nccl_backend_two_gpus)
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dev = torch.device("cuda", 0)
+        dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
-    dev = torch.device("cuda", 0)
     cfg = C.PRESETS[preset]()
     eng = ScoreNetEngine(cfg, dev)
     eng.load_weights({k: torch.from_numpy(v) for k, v in synth.make_weights(C.param_shapes(cfg)).items()})

@@ -99,3 +99,36 @@ def test_single_process_keeps_input_order(local):
         mu, mask, z = (D.take_shard(t, lengths) for t in (mu, mask, z))
     got = D.sample_sharded(fake_sampler, mu, mask, z, lengths, local=local).numpy()
     np.testing.assert_array_equal(got, ref)
+
+
+def test_length_buckets_are_a_partition_with_their_own_padding():
+    lengths = [100, 20, 300, 40, 250, 60, 10, 299, 64, 65]
+    b = D.buckets_of(lengths, 64)
+    assert sorted(i for _, idx in b for i in idx) == list(range(len(lengths)))
+    for Tb, idx in b:
+        assert Tb % 4 == 0 and Tb >= max(lengths[i] for i in idx) and Tb - max(lengths[i] for i in idx) < 4
+        assert len({-(-lengths[i] // 64) for i in idx}) == 1                 # one rounded-up length per bucket
+    assert [Tb for Tb, _ in b] == sorted(Tb for Tb, _ in b)
+    with pytest.raises(ValueError):
+        D.buckets_of(lengths, 0)
+
+
+def test_bucketed_sampling_equals_the_sampler_on_each_bucket():
+    """Opt-in length bucketing (single process): per bucket the result is the sampler run on that bucket alone at the bucket's own
+    padded length - and it differs from the globally padded run (the stand-in, like the real net, depends on the padded columns)."""
+    lengths = [120, 33, 128, 70, 64, 90]
+    T = D.padded_length(lengths)
+    mu, mask, z, _ = synth.make_inputs(len(lengths), T, lengths)
+    mu, mask, z = map(torch.from_numpy, (mu, mask, z))
+    got = D.sample_bucketed(fake_sampler, mu, mask, z, lengths, bucket_width=64)
+    glob = fake_sampler(z, mask, mu)
+    seen = 0
+    for Tb, idx in D.buckets_of(lengths, 64):
+        ix = torch.tensor(idx)
+        want = fake_sampler(z[ix][:, :, :Tb], mask[ix][:, :, :Tb], mu[ix][:, :, :Tb])
+        assert torch.equal(got[ix][:, :, :Tb], want)
+        assert float(got[ix][:, :, Tb:].abs().max() if Tb < T else 0.0) == 0.0
+        if Tb < T:
+            assert not torch.equal(want, glob[ix][:, :, :Tb])
+            seen += 1
+    assert seen >= 1

@@ -87,3 +87,29 @@ def test_gpu_forward_infer_false_draws_like_the_reference():
     with torch.no_grad():
         ref = float(O.edm_loss(O.as_torch(w), cfg, t(x0), t(mask), t(mu), rnd.cpu(), eps.cpu()))
     assert abs(loss - ref) <= 2e-5 * max(1.0, abs(ref)), (loss, ref)
+
+
+def test_diffusion_module_deepcopies_and_pickles_without_sharing_its_owner():
+    """the loss hook used to be a lambda closing over the ORIGINAL module (a deep copy evaluated with the original's weights,
+    torch.save failed).  It is resolved through a weakref to the owner at call time now."""
+    import copy, io, pickle
+    import torch
+    from dex_tts_amd import config as C
+    from dex_tts_amd.diffusion import from_config
+    m = from_config(C.gedex_lj())
+    c = copy.deepcopy(m)
+    assert c.precond_model._owner() is c and m.precond_model._owner() is m
+    assert c.precond_model.model is c.denoise_fn and c.denoise_fn is not m.denoise_fn
+    k = next(iter(m.state_dict()))
+    assert torch.equal(c.state_dict()[k], m.state_dict()[k])
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    r = torch.load(buf, weights_only=False)
+    assert m.precond_model._owner() is m                        # saving did not touch the live module
+    r._bind_owner()                                              # (what forward(infer=False) does before it evaluates the loss)
+    assert r.precond_model._owner() is r
+    assert callable(r.sampler) and set(r.state_dict()) == set(m.state_dict())
+    p = pickle.loads(pickle.dumps(m))
+    p._bind_owner()
+    assert p.precond_model._owner() is p and p.precond_model.model is p.denoise_fn

@@ -34,7 +34,8 @@ record = U.record
 def check_lowp(tag, prec, kind, got, ref):
     e = np.abs(got - ref)
     record(f"{tag}:{prec}:{kind}", max=e.max(), mean=e.mean(), ref_absmax=np.abs(ref).max())
-    mx, mn = LOWP[prec][kind]
+    from tests.tolerances import lowp_bounds
+    mx, mn = lowp_bounds(tag, prec, kind)
     assert np.isfinite(got).all()
     assert e.max() <= mx and e.mean() <= mn, (tag, prec, kind, float(e.max()), float(e.mean()))
 

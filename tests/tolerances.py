@@ -31,3 +31,36 @@ LOWP = {
     # (round 3: the 3-utterance ragged batch with a 77-frame utterance of tests/test_gpu_cluster.py reaches 4.6e-3 max in BOTH forms of the DiT block)
     "fp16": {"call": (6e-3, 7.5e-4), "sampler": (7e-3, 6e-4)},
 }
+
+
+# Round 4 (VERDICT r3 Weak #7): at the BASELINE shapes the reduced-precision modes are held to bounds <= 2x what was MEASURED at
+# that shape in that mode (profiles/round3_parity_measured.jsonl / round4_parity_measured.jsonl) - under the global pair above a 7-8x
+# accuracy regression at the benchmarked shape (bf16 7.2e-3 measured against 5e-2 allowed) would have passed.  Keyed by the test's tag
+# prefix; the global pair stays for the small fuzz shapes.  (max|d|, mean|d|) against the fp32 CPU oracle.
+LOWP_AT = {
+    # configs[1]: GeDEX-LJ B=1 T=512 - the 50-step job the bench times, and single calls at sigma = 80 / 1 / 0.002
+    ("cfg1_T512_n50", "bf16", "sampler"): (1.5e-2, 3.0e-3),      # measured 7.24e-3 / 1.51e-3
+    ("cfg1_T512_n50", "fp16", "sampler"): (1.8e-3, 3.3e-4),      # measured 8.66e-4 / 1.64e-4
+    ("cfg1_T512_sigma", "bf16", "call"): (2.7e-2, 5.1e-3),       # worst of the three sigmas: 1.34e-2 / 2.53e-3
+    ("cfg1_T512_sigma", "fp16", "call"): (3.6e-3, 6.2e-4),       # 1.80e-3 / 3.07e-4
+    # configs[2]: DEX-VCTK B=32 T=256 Tr=Ts=348
+    ("cfg2_dex_b32_n4", "bf16", "sampler"): (4.3e-2, 5.4e-3),    # 2.12e-2 / 2.68e-3
+    ("cfg2_dex_b32_n4", "fp16", "sampler"): (6.0e-3, 6.8e-4),    # 2.96e-3 / 3.39e-4
+    ("cfg2_dex_b32_sigma", "bf16", "call"): (5.0e-2, 6.1e-3),    # 2.55e-2 / 3.04e-3
+    ("cfg2_dex_b32_sigma", "fp16", "call"): (6.0e-3, 7.5e-4),    # 3.23e-3 / 3.79e-4
+    # configs[3]: the 100-step DEX-ESD job
+    ("cfg3_n100", "bf16", "sampler"): (2.0e-2, 3.3e-3),          # 9.76e-3 / 1.63e-3
+    # configs[4]: T=4000 (N=5010 tokens)
+    ("cfg4_T4000_n4", "bf16", "sampler"): (2.3e-2, 3.9e-3),      # 1.13e-2 / 1.95e-3
+    ("cfg4_T4000_n4", "fp16", "sampler"): (2.9e-3, 4.7e-4),      # 1.45e-3 / 2.32e-4
+    ("cfg4_T4000_sigma", "bf16", "call"): (3.3e-2, 5.2e-3),      # 1.63e-2 / 2.56e-3
+    ("cfg4_T4000_sigma", "fp16", "call"): (3.9e-3, 6.2e-4),      # 1.91e-3 / 3.08e-4
+}
+
+
+def lowp_bounds(tag: str, prec: str, kind: str):
+    """(max, mean) bound of a reduced-precision comparison: the per-shape entry whose prefix the tag starts with, else the global pair."""
+    for (pfx, p, k), b in LOWP_AT.items():
+        if p == prec and k == kind and tag.startswith(pfx):
+            return b
+    return LOWP[prec][kind]
