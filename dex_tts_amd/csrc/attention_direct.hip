@@ -356,8 +356,7 @@ void launch_attention_direct(const AttnDirectP& p, hipStream_t st) {
     if (attention_direct_batch_regime(p.N, p.B)) {          // batch regime (the caller sized ksplit with attention_direct_ksplit)
         dim3 grid(((p.N + 31) / 32 + 3) / 4, 2, p.B * (p.ksplit > 1 ? p.ksplit : 1));
         AttnDirectP q = p;
-        const char* e = getenv("DEX_XCD_MAP");               // read per call (part of the graph cache key); 0: the plain 3-D grid
-        q.xcd_map = ((2 * grid.z) % 8 == 0 && !(e && e[0] == '0')) ? 1 : 0;
+        q.xcd_map = ((2 * grid.z) % 8 == 0 && !knob_off("DEX_XCD_MAP")) ? 1 : 0;      // 0: the plain 3-D grid
         if (q.xcd_map) grid = dim3(grid.x * 2 * grid.z);
         hipLaunchKernelGGL(attn_direct_ring_kernel, grid, dim3(256), 0, st, q);
         return;

@@ -755,8 +755,7 @@ bool conv3x3_res2_form(int H, int W, int B) {
 int conv3x3_stream_tiles(const Conv3P& p) {
     if (p.Cin != SC || p.Cout != SC || p.res_w || p.ldx % 8 != 0 || p.x_coff % 8 != 0) return 0;
     if (p.x_bf16 && !p.pro_stats) { int a, b2; if (!pp_plan(p, a, b2)) return 0; }       // plain 16-bit input: the ping-pong form only
-    const char* e = getenv("DEX_CONV_STREAM");           // 0: never, 2: whenever the shape allows (tests), default: by grid size
-    const int mode = e ? atoi(e) : 1;
+    const int mode = knob_or("DEX_CONV_STREAM", 1);      // 0: never, 2: whenever the shape allows (tests), default: by grid size
     if (mode == 0) return 0;
     const int tiles = (p.H + STR - 1) / STR;
     const long strips = (long)((p.W + 31) / 32) * p.B;
@@ -778,8 +777,7 @@ static void pp_go(const Conv3P& p, int seg_tiles, int nseg_y, unsigned nwg, hipS
 
 // Ping-pong plan: strip segments of `seg` 4-row tiles, two segments per workgroup; wanted: at least one workgroup per CU.
 static bool pp_plan(const Conv3P& p, int& seg, int& nseg_y) {
-    const char* e = getenv("DEX_CONV_PP");               // 0: never, 2: whenever the shape allows (tests), default: by grid size
-    const int mode = e ? atoi(e) : 1;
+    const int mode = knob_or("DEX_CONV_PP", 1);          // 0: never, 2: whenever the shape allows (tests), default: by grid size
     if (mode == 0) return false;
     const int tiles = (p.H + PR - 1) / PR;
     const long cols = (long)((p.W + 31) / 32) * p.B;

@@ -20,6 +20,37 @@
 #include "kernels.h"
 
 using namespace dex;
+
+// ---- knob snapshot (kernels.h: knob()).  Every DEX_* variable the library consults while it ENQUEUES a call is listed here; a call
+// reads them all once (one getenv each), keeps the values for its whole enqueue and hashes them into its graph-cache key.
+namespace dex {
+namespace {
+const char* const KNOB_NAMES[] = {
+    "DEX_CONV_STREAM", "DEX_CONV_PP", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_ATTN_Q64", "DEX_ATTN_GENERIC", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN",
+    "DEX_DIT_CLUSTER", "DEX_DIT_CLUSTER_LOCAL", "DEX_ATTN_X_LP", "DEX_RES_X_LP", "DEX_CAT_LP", "DEX_XCD_MAP", "DEX_DEBUG_DROP_HANDOFF", "DEX_PATCH_FUSED",
+    "DEX_CONV_DOWN", "DEX_CONVT_UP", "DEX_DEBUG_PLAN"};
+constexpr int N_KNOBS = (int)(sizeof(KNOB_NAMES) / sizeof(KNOB_NAMES[0]));
+struct KnobSnapshot {
+    int v[N_KNOBS];
+    KnobSnapshot() { for (int i = 0; i < N_KNOBS; ++i) { const char* e = getenv(KNOB_NAMES[i]); v[i] = e ? atoi(e) : KNOB_UNSET; } }
+};
+thread_local const KnobSnapshot* t_knobs = nullptr;
+struct KnobScope {            // installs a snapshot for the calls below it on this thread
+    const KnobSnapshot* prev;
+    explicit KnobScope(const KnobSnapshot* k) : prev(t_knobs) { t_knobs = k; }
+    ~KnobScope() { t_knobs = prev; }
+};
+}  // namespace
+int knob(const char* name) {
+    for (int i = 0; i < N_KNOBS; ++i)
+        if (!strcmp(KNOB_NAMES[i], name)) {
+            if (t_knobs) return t_knobs->v[i];
+            break;
+        }
+    const char* e = getenv(name);              // outside a call (tools that launch kernels directly), or a knob nobody registered
+    return e ? atoi(e) : KNOB_UNSET;
+}
+}  // namespace dex
 static_assert(PREC_FP32 == DEX_PREC_FP32 && PREC_BF16 == DEX_PREC_BF16 && PREC_FP16 == DEX_PREC_FP16, "kernels.h mirrors DexPrecision");
 
 namespace {
@@ -655,7 +686,7 @@ void xcd_map_probe() {
     if (g_xcd_map.load(std::memory_order_acquire) >= 0) return;
     std::lock_guard<std::mutex> lk(g_xcd_probe_mutex);
     if (g_xcd_map.load(std::memory_order_relaxed) >= 0) return;
-    { const char* e = getenv("DEX_DIT_CLUSTER_LOCAL"); if (e && atoi(e) == 0) { g_xcd_map.store(0, std::memory_order_release); return; } }
+    if (knob_off("DEX_DIT_CLUSTER_LOCAL")) { g_xcd_map.store(0, std::memory_order_release); return; }
     unsigned* d = nullptr;
     if (hipMalloc(&d, 256 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); g_xcd_map.store(0, std::memory_order_release); return; }
     bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&xcc_probe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536) == hipSuccess;
@@ -674,7 +705,7 @@ extern "C" int dex_debug_xcd_local() { xcd_map_probe(); return g_xcd_map.load();
 void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
     const DexConfig& c = x->cfg;
     Arena A; A.base = (char*)ws; A.dry = (ws == nullptr);
-    { static const bool tr = getenv("DEX_DEBUG_PLAN") != nullptr; A.trace = tr ? 1 : 0; }
+    A.trace = knob_set("DEX_DEBUG_PLAN") ? 1 : 0;
     P.d = d;
     const int n = d.n_steps, dim = c.dim, hid = c.dit_hidden, mid = mid_dim(c), B = d.B;
     P.sig2 = A.f(64);
@@ -838,7 +869,7 @@ struct Runner {
     // raw conv outputs read only by a fused GroupNorm prologue (h1, h2 of a ResnetBlock, the final block's conv) are kept
     // in HBM as bf16 in bf16 mode: half the bytes of the largest tensors of the step.  DEX_H_BF16=0 keeps them fp32.
     static bool ln_fusable(int K) { return K == 64 || K == 128 || K == 256 || K == 512; }
-    bool h_bf16() const { const char* e = getenv("DEX_H_BF16"); return x->lp() && !(e && e[0] == '0'); }
+    bool h_bf16() const { return x->lp() && !knob_off("DEX_H_BF16"); }
     bool fast_conv(int cin, int cout) const { return x->lp() && conv3x3_bf16_supported(cin, cout); }
     void conv3x3(const char* name, const TD& X, int H, int W, int mask_ws, bool inmask, const float* Wt, const float* bias, int Cout, float* out,
                  gnfix_t* gn = nullptr, const Pro* pro = nullptr, const ResW* shortcut = nullptr, float* shortcut_out = nullptr,
@@ -918,8 +949,7 @@ struct Runner {
             // the 1x1 shortcut of this block is two or three FMAs per value from the input planes: when the consumer is the next
             // block's fused-tail convolution it recomputes it, and the fp32 [B,H,T,64] tensor is neither written nor read
             // (DEX_RES2=0 stores it as before)
-            { const char* e = getenv("DEX_RES2");
-              if (ctail && h2b && w.cout == 64 && conv3x3_res2_form(s.H, s.W, P.d.B) && !(e && e[0] == '0')) { f.res = nullptr; ctail->res2 = true; ctail->res2f = f; } }
+            { if (ctail && h2b && w.cout == 64 && conv3x3_res2_form(s.H, s.W, P.d.B) && !knob_off("DEX_RES2")) { f.res = nullptr; ctail->res2 = true; ctail->res2f = f; } }
             st1 = next_stats(); f.gn_stats = st1;
             run("first_conv", 2.0 * npix * P.d.B * w.cout * (w.cin * 10), npix * P.d.B * ((h1b ? 2.0 : 4.0) * w.cout + (f.res ? 4.0 * w.cout : 0.0) + 4.0 * w.cin), [&] { launch_first_conv(f, st); });
             resptr = s.rbuf; ldres = w.cout; resb = npix * w.cout;
@@ -931,8 +961,7 @@ struct Runner {
                 // the previous block's output x (head->xout == X) is written by this conv for ONE later reader when this block's own
                 // tail rides in the attention's context pass with the identity shortcut: it may then leave in the mode's 16-bit type
                 // (the residual term of x' = Mish(GN(h2)) + x carries that rounding: not bit-neutral, DEX_RES_X_LP=0 keeps fp32)
-                { const char* e = getenv("DEX_RES_X_LP");
-                  head->xout_lp_ok = tail != nullptr && !w.wr && lp_inter_cur && head->xout == X.p && X.coff == 0 && X.ld == X.C && !(e && e[0] == '0'); }
+                head->xout_lp_ok = tail != nullptr && !w.wr && lp_inter_cur && head->xout == X.p && X.coff == 0 && X.ld == X.C && !knob_off("DEX_RES_X_LP");
                 conv3x3("conv3x3", H2, s.H, s.W, s.mask_ws, true, w.w1, w.b1, w.cout, s.h1, st1, head, nullptr, nullptr, head->x_bf16, h1b);
             } else {
                 fused_res = w.wr && fast_conv(X.C, w.cout) && conv3x3_bf16_res_supported(X.C, w.cout) && x->lp_of().count(w.wr);
@@ -1015,8 +1044,7 @@ struct Runner {
             // operand type for its q GEMM anyway and adds it back as the residual term: at batch size it is stored in that type
             // (half of the write + read; the residual term then carries the operand rounding - NOT bit-identical to the fp32
             // store, measured in DESIGN.md; DEX_ATTN_X_LP=0 keeps it fp32)
-            const char* xe = getenv("DEX_ATTN_X_LP");
-            const bool xlp = k.H2 && k.Xout && lp_inter_cur && linattn_out2_lp_out_supported((int)npix, B) && !(xe && xe[0] == '0');
+            const bool xlp = k.H2 && k.Xout && lp_inter_cur && linattn_out2_lp_out_supported((int)npix, B) && !knob_off("DEX_ATTN_X_LP");
             k.xout_lp = xlp ? 1 : 0;
             run("linattn_kvctx", 2.0 * npix * B * (256.0 * X.C + 128 * 32), (tail ? (tail->h2_bf16 ? 10.0 : 12.0) - (xlp ? 2.0 : 0.0) : 4.0) * npix * X.C * B, [&] { launch_linattn_kvctx(k, x->precision, st); });
             LinMergeP mg{s.pm, s.ps, s.pc, nblk, w.wout_raw, w.g, X.C, s.mbf, B};
@@ -1047,9 +1075,8 @@ struct Runner {
         dw.k = c.dit_patch; dw.s = c.dit_stride; dw.pad = c.dit_patch / 2; dw.Wd = x->pe_dw; dw.bd = x->pe_db;
         dw.mask = mask_input ? mask : nullptr; dw.mask_ws = mask_ws; dw.mask_bstride = P.d.T;
         dw.Y = P.pe0; dw.Hf = P.Hf; dw.Wt = P.Wt; dw.B = B;
-        const char* pf_env = getenv("DEX_PATCH_FUSED");
         auto pw_lp = x->lp_of().find(x->pe_pw);
-        if (x->lp() && !debug && !(pf_env && pf_env[0] == '0') && pw_lp != x->lp_of().end() && patch_embed_fused_supported(c.dit_patch, mid, hid, (long)B * N)) {
+        if (x->lp() && !debug && !knob_off("DEX_PATCH_FUSED") && pw_lp != x->lp_of().end() && patch_embed_fused_supported(c.dit_patch, mid, hid, (long)B * N)) {
             // small grids: depthwise conv + SiLU + pointwise GEMM in ONE launch (bit-identical to the two-kernel form below)
             run("patch_embed", 2.0 * B * N * mid * (c.dit_patch * c.dit_patch + hid), 4.0 * B * (P.Hm * P.Wm * mid + N * hid),
                 [&] { launch_patch_embed_fused(dw, pw_lp->second, x->pe_pb, P.emb, hid, x->precision, st); });
@@ -1084,9 +1111,8 @@ struct Runner {
         if (debug) hipMemcpyAsync(P.dbg_tok, P.tok, (size_t)B * N * hid * 4, hipMemcpyDeviceToDevice, st);
         tap("tok_in", P.dbg_tok, (long)B * N, hid, hid);
         const float scale = 1.0f / sqrtf((float)(hid / c.dit_heads));
-        const char* chain_env = getenv("DEX_DIT_CHAIN");          // 0: one GEMM / attention launch per operation (A/B runs)
         const bool chain = x->lp() && dit_rowchain_supported(hid, mh) && c.dit_heads == 2 && x->frag_of().count(x->blocks[0].wproj) &&
-                           !(chain_env && chain_env[0] == '0');
+                           !knob_off("DEX_DIT_CHAIN");          // 0: one GEMM / attention launch per operation (A/B runs)
         for (int k = 0; k < c.dit_depth; ++k) {
             const DitBlockW& w = x->blocks[k];
             const float* ada = P.ada[k];
@@ -1103,7 +1129,7 @@ struct Runner {
                     ch.xslab = P.xslab; ch.xflag = P.xflag; ch.epoch = (unsigned)(sp * (c.dit_depth + 1) + k + 1);
                     ch.xerr = reinterpret_cast<int*>(P.xflag + (P.xflag_bytes - sizeof(int)) / sizeof(unsigned));
                     x->last_xerr = ch.xerr;
-                    { const char* de = getenv("DEX_DEBUG_DROP_HANDOFF"); ch.xdrop = de ? atoi(de) : 0; }
+                    ch.xdrop = knob_or("DEX_DEBUG_DROP_HANDOFF", 0);
                     ch.xlocal = (P.xlocal && ch.epoch < (1u << 24)) ? 1 : 0;
                 }
             }
@@ -1133,7 +1159,7 @@ struct Runner {
                 // Large grids (batched synthesis: >= 1024 (query tile, head) items) run the attention as its OWN launch on the
                 // shared-ring kernel (attention_direct.hip): K / V^T tiles are read from L2 once per 128 queries instead of
                 // once per 32, 0.25 vs 0.20 of the MFMA peak.  DEX_ATTN_SEPARATE=0 / 1 forces either form (A/B, profiling).
-                const char* sep_env = getenv("DEX_ATTN_SEPARATE");     // read per call: bench.py flips it for one profiling pass
+                const int sep_env = knob("DEX_ATTN_SEPARATE");          // (bench.py flips it for one profiling pass)
                 const bool batch_regime = attention_direct_batch_regime(N, B);
                 // (measured end to end: DEX B=32 N=1300 +0.6 %, GeDEX B=32 N=650 -0.9 % — short key loops gain nothing from the
                 // rings and pay for the extra launch and the fp32 O round trip, so the automatic switch wants N >= 1024 too)
@@ -1141,9 +1167,9 @@ struct Runner {
                 // streams) takes the separate launch wherever it can fill the chip - batched DEX (N = 1300: 0.31 of the MFMA peak against
                 // 0.28 for the shared-ring kernel) and long-form synthesis (N = 5010, one utterance: 0.33 against 0.19 fused into the block).
                 // DEX_ATTN_Q64=0 / 1 forces either (A/B, tests).
-                const char* q64_env = getenv("DEX_ATTN_Q64");
-                const bool q64_ok = q64_env ? atoi(q64_env) != 0 : attention_q64_regime(N, B);
-                const bool separate = sep_env ? atoi(sep_env) != 0 : ((batch_regime && N >= 1024) || q64_ok);
+                const int q64_env = knob("DEX_ATTN_Q64");
+                const bool q64_ok = q64_env != KNOB_UNSET ? q64_env != 0 : attention_q64_regime(N, B);
+                const bool separate = sep_env != KNOB_UNSET ? sep_env != 0 : ((batch_regime && N >= 1024) || q64_ok);
                 const bool q64 = separate && q64_ok;
                 int ks = 1;
                 bool o_lp = false;
@@ -1189,7 +1215,7 @@ struct Runner {
             a.K = P.qkv + hid; a.ldk = 3 * hid; a.kb = a.qb; a.V = P.qkv + 2 * hid; a.ldv = 3 * hid; a.vb = a.qb;
             a.O = P.ao; a.ldo = hid; a.ob = (long)N * hid; a.Nq = N; a.Nk = N; a.kv_len = nullptr; a.kv_len_add = 0;
             a.heads = c.dit_heads; a.scale = scale; a.B = B; a.head_dim = hid / c.dit_heads;
-            { const char* ge = getenv("DEX_ATTN_GENERIC"); a.force_generic = (ge && atoi(ge) && x->precision == DEX_PREC_FP32) ? 1 : 0; }   // tests
+            a.force_generic = (knob_or("DEX_ATTN_GENERIC", 0) && x->precision == DEX_PREC_FP32) ? 1 : 0;   // tests
             run("dit_attention", 4.0 * B * (double)N * N * hid, 4.0 * 4 * B * N * hid, [&] { launch_attention(a, x->precision, st); });
             IGemmP pr = base_gemm(P.ao, hid, 0, 1, N, hid, w.wproj, hid, w.bproj, P.tok, hid, 0);
             pr.gate = ada + 2 * hid; pr.gate_nstride = 1; pr.gate_step_stride = 6L * hid;
@@ -1278,12 +1304,10 @@ struct Runner {
         // Downsample conv, the Downsample output into the next ResnetBlock's convs, the last up stage's attention output into
         // the Upsample, and the Upsample output into the final block's conv.  Batch regime only (the kernels that read / write
         // 16-bit tensors are the throughput forms); never with debug taps (they read fp32); DEX_LP_INTER=0 turns it off.
-        const char* li_env = getenv("DEX_LP_INTER");
-        const bool lp_inter = x->lp() && !debug && ns >= 2 && !(li_env && li_env[0] == '0') && fast_conv(c.dim, c.dim);
+        const bool lp_inter = x->lp() && !debug && ns >= 2 && !knob_off("DEX_LP_INTER") && fast_conv(c.dim, c.dim);
         lp_inter_cur = lp_inter;
         cat_lp = false;
         if (lp_inter && ns == 2 && P.cat16) {
-            const char* ce = getenv("DEX_CAT_LP");
             const StageBuf& sm_ = P.down[ns - 1];
             const ResW& uw = x->up_res[0][0];
             const bool tail_ok = linattn_fused(sm_.C) && linattn_out2_lp_out_supported((int)sm_.npix, B);
@@ -1291,7 +1315,7 @@ struct Runner {
                                  x->lp_of().count(uw.w1) && conv3x3_cat_lp_in_supported(P.up[0].H, P.up[0].W, B, 2 * sm_.C, uw.cout);
             IGemmP fl = final_gemm(sm_.mask_ws, P.cat[0], 2 * sm_.C, 0);
             fl.c_lp = x->lp_kind();
-            cat_lp = !(ce && ce[0] == '0') && tail_ok && conv_ok && fl.Wbf && igemm_nwalk_form(fl);
+            cat_lp = !knob_off("DEX_CAT_LP") && tail_ok && conv_ok && fl.Wbf && igemm_nwalk_form(fl);
         }
         const int lpk = x->lp_kind();
         for (int i = 0; i < ns; ++i) {
@@ -1326,7 +1350,7 @@ struct Runner {
                 const bool t2_lp = lp_inter && x->lp_of().count(x->down_ds_w[i]) && nw.wr && fast_conv(s.C, nw.cout) && conv3x3_bf16_res_supported(s.C, nw.cout) &&
                                    x->lp_of().count(nw.wr) && x->lp_of().count(nw.w1) && conv3x3_plain_lp_in_supported(g.Ho, g.Wo, B, s.C, nw.cout);
                 g.a_lp = t1_lp ? lpk : 0; g.c_lp = t2_lp ? lpk : 0;
-                static const bool strip_off = [] { const char* e = getenv("DEX_CONV_DOWN"); return e && e[0] == '0'; }();
+                const bool strip_off = knob_off("DEX_CONV_DOWN");
                 if (x->lp() && !strip_off && x->frag_of().count(x->down_ds_w[i]) && conv_down_supported(s.C, s.H, s.W, a.ld, s.C, a.coff)) {
                     ConvDownP d{};
                     d.X = a.p; d.a_lp = g.a_lp; d.ldx = a.ld; d.xb = (long)s.H * s.W * a.ld; d.x_coff = a.coff; d.H = s.H; d.W = s.W;
@@ -1383,7 +1407,7 @@ struct Runner {
                 g.a_lp = t5_lp ? lpk : 0;
                 up_out_lp = lp_inter && j == ns - 2 && x->lp_of().count(x->up_us_w[j]) && x->lp_of().count(x->fin_w) && conv3x3_res2_form(80, P.d.T, B);
                 g.c_lp = up_out_lp ? lpk : 0;
-                static const bool strip_off = [] { const char* e = getenv("DEX_CONVT_UP"); return e && e[0] == '0'; }();
+                const bool strip_off = knob_off("DEX_CONVT_UP");
                 if (x->lp() && x->frag_of().count(x->up_us_w[j]) && !strip_off && convt_up_supported(s.C, s.H, s.W, s.C, ldd)) {
                     ConvTUpP u{};
                     u.X = s.attn_out; u.a_lp = g.a_lp; u.ldx = s.C; u.xb = (long)s.H * s.W * s.C; u.x_coff = 0; u.H = s.H; u.W = s.W;
@@ -1586,7 +1610,10 @@ int dex_denoise_once(DexCtx* x, const DexDenoiseArgs* da, dex_stream_t stream) {
     int rc = validate(x, a, false);
     if (rc) return rc;
     if (!da->x_dev) return x->fail(DEX_ERR_ARG, "x_dev is null");
+    const KnobSnapshot knobs;
+    const KnobScope knob_scope(&knobs);
     xcd_map_probe();
+    x->last_xerr = nullptr;
     hipStream_t st = (hipStream_t)stream;
     Plan P; Dims d{a->B, a->T, a->Tr, a->Ts, 1};
     make_plan(x, d, nullptr, P);
@@ -1606,6 +1633,8 @@ int dex_sample(DexCtx* x, const DexSampleArgs* a, dex_stream_t stream) {
     int rc = validate(x, a, true);
     if (rc) return rc;
     if (a->solver != DEX_SOLVER_EULER && a->solver != DEX_SOLVER_HEUN) return x->fail(DEX_ERR_ARG, "solver must be DEX_SOLVER_EULER or DEX_SOLVER_HEUN (edm.py:107)");
+    const KnobSnapshot knobs;            // one reading of every knob for this call (graph-cache key below)
+    const KnobScope knob_scope(&knobs);
     xcd_map_probe();                    // (once per device, before any capture; normally already done by dex_ctx_create)
     x->last_xerr = nullptr;             // set again by this call if it uses in-launch hand-offs (dex_call_status)
     hipStream_t st = (hipStream_t)stream;
@@ -1639,10 +1668,7 @@ int dex_sample(DexCtx* x, const DexSampleArgs* a, dex_stream_t stream) {
     key.push_back((uint64_t)g_xcd_gen.load(std::memory_order_acquire));          // placement rule of the cluster hand-offs (see g_xcd_map)
     for (float v : {a->S_churn, a->S_min, a->S_max, a->S_noise}) { uint32_t u; memcpy(&u, &v, 4); key.push_back(u); }
     for (int j = 0; j < a->n_ref; ++j) key.push_back((uint64_t)(uintptr_t)a->ref_skips_dev[j]);
-    for (const char* e : {"DEX_CONV_STREAM", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN", "DEX_DIT_CLUSTER", "DEX_DIT_CLUSTER_LOCAL", "DEX_ATTN_X_LP", "DEX_RES_X_LP", "DEX_CAT_LP", "DEX_XCD_MAP", "DEX_DEBUG_DROP_HANDOFF", "DEX_PATCH_FUSED", "DEX_ATTN_Q64"}) {     // knobs read at enqueue time
-        const char* v = getenv(e);
-        key.push_back(v ? (uint64_t)atoi(v) + 1 : 0);
-    }
+    for (int v : knobs.v) key.push_back((uint64_t)(uint32_t)v);          // EVERY registered knob, as this call sees it
     DexCtx::GraphEntry* hit = nullptr;
     for (auto& g : x->graphs) if (g.key == key) { hit = &g; break; }
     if (!hit) {
@@ -1733,7 +1759,7 @@ int dex_call_status(DexCtx* x, dex_stream_t stream) {
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipMemcpy(&v, x->last_xerr, sizeof v, hipMemcpyDeviceToHost) != hipSuccess)
         return x->fail(DEX_ERR_HIP, "dex_call_status: could not read the hand-off word");
     if (v == 0) return DEX_OK;
-    if (v == 2 && !getenv("DEX_DEBUG_DROP_HANDOFF")) { g_xcd_map.store(0); x->drop_graphs(); }
+    if (v == 2 && !knob_set("DEX_DEBUG_DROP_HANDOFF")) { g_xcd_map.store(0); x->drop_graphs(); }
     return x->fail(DEX_ERR_HANDOFF, v == 2 ? "a cluster hand-off met its peer on another XCD (outputs poisoned); the XCD-local form is now off for this device - repeat the call"
                                            : "a cluster hand-off timed out (outputs poisoned)");
 }
@@ -1743,7 +1769,7 @@ int dex_debug_handoff_timeouts(DexCtx* x, dex_stream_t stream) {
     if (!x->last_xerr) return 0;
     int v = 0;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipMemcpy(&v, x->last_xerr, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    if (v == 2 && !getenv("DEX_DEBUG_DROP_HANDOFF")) { g_xcd_map.store(0); x->drop_graphs(); }        // members of a cluster met on different XCDs: the XCD-local form is off from here on
+    if (v == 2 && !knob_set("DEX_DEBUG_DROP_HANDOFF")) { g_xcd_map.store(0); x->drop_graphs(); }        // members of a cluster met on different XCDs: the XCD-local form is off from here on
     return v;
 }
 

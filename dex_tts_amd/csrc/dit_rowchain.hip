@@ -1245,15 +1245,13 @@ constexpr size_t RC_LDS_CLUSTER = RC_LDS_CLUSTER_CHAIN > RC_LDS_ATTN ? RC_LDS_CL
 
 // the cluster form needs every workgroup of the launch resident at once (<= one per CU, 256 CUs): B x tiles x 4 <= 256
 bool dit_rowchain_cluster_form(int rows_per_batch, int B) {
-    const char* e = getenv("DEX_DIT_CLUSTER");          // read per call (A/B tests flip it; part of the graph cache key)
-    const int on = e ? atoi(e) : 1;
+    const int on = knob_or("DEX_DIT_CLUSTER", 1);       // (A/B tests flip it)
     return on && (long)B * ((rows_per_batch + RC_ROWS - 1) / RC_ROWS) * DIT_CLUSTER <= 256;
 }
 
 // XCD-local clusters (DitChainP::xlocal): the grid is padded to whole rounds of 8 clusters, still one workgroup per CU at most
 bool dit_rowchain_cluster_local_fits(int rows_per_batch, int B) {
-    const char* e = getenv("DEX_DIT_CLUSTER_LOCAL");    // read per call (part of the graph cache key)
-    const int on = e ? atoi(e) : 1;
+    const int on = knob_or("DEX_DIT_CLUSTER_LOCAL", 1);
     const long tiles = (long)B * ((rows_per_batch + RC_ROWS - 1) / RC_ROWS);
     return on && dit_rowchain_cluster_form(rows_per_batch, B) && (tiles + 7) / 8 * 8 * DIT_CLUSTER <= 256;
 }
@@ -1311,8 +1309,7 @@ void launch_dit_rowchain(const DitChainP& p, hipStream_t st) {
     dim3 grid(p.B * ((p.rows_per_batch + RC_ROWS - 1) / RC_ROWS));
     if (p.attn_inline && !p.qkv_only) {
         DitChainP q = p;
-        const char* e = getenv("DEX_XCD_MAP");               // read per call (part of the graph cache key); 0: the plain b-major order
-        q.xcd_map = (p.B % 8 == 0 && !(e && e[0] == '0')) ? 1 : 0;
+        q.xcd_map = (p.B % 8 == 0 && !knob_off("DEX_XCD_MAP")) ? 1 : 0;      // 0: the plain b-major order
         hipLaunchKernelGGL(dit_rowchain_kernel<true>, grid, dim3(RC_NW * 64), RC_LDS_ATTN > RC_LDS ? RC_LDS_ATTN : RC_LDS, st, q);
     }
     else

@@ -9,6 +9,17 @@
 
 namespace dex {
 
+// ---- run-time knobs (A/B switches, test hooks): DEX_* environment variables.  The public entry points take ONE snapshot of every
+// registered knob per call (dex_api.hip: KnobSnapshot) and install it for the duration of the enqueue; knob() reads that snapshot,
+// so a call sees one consistent setting, nothing calls getenv per launch, and the snapshot as a whole is part of the graph-cache key
+// (no hand-kept list of "knobs that matter to captured graphs").  Outside a call (bench tools that launch kernels directly) knob()
+// reads the environment.  KNOB_UNSET = the variable is not set.
+constexpr int KNOB_UNSET = -2147483647 - 1;
+int knob(const char* name);                                  // atoi of the value, or KNOB_UNSET
+inline int knob_or(const char* name, int dflt) { const int v = knob(name); return v == KNOB_UNSET ? dflt : v; }
+inline bool knob_off(const char* name) { return knob(name) == 0; }          // set to 0: the optional form is switched off
+inline bool knob_set(const char* name) { return knob(name) != KNOB_UNSET; }
+
 // GroupNorm / InstanceNorm statistics: [B][groups][GN_SLOTS][2] partial (mean, mean-of-squares) contributions as 64-bit
 // FIXED-POINT integers (2^-36 resolution, see bf16_util.h gn_fix): integer addition is associative, so the native L2
 // atomics that accumulate them give the same bits whatever order the workgroups arrive in — every sampler call is bitwise
