@@ -53,7 +53,10 @@ constexpr int LDS_BYTES = STAGE + 4 * STAGE_WAVE;
 #define Q64_MFMA "v_mfma_f32_32x32x16_bf16"
 #define Q64_PK "v_cvt_pk_bf16_f32"
 #endif
-#include "attention_q64_core.inc"
+#ifndef Q64_CORE_INC
+#define Q64_CORE_INC "attention_q64_core.inc"
+#endif
+#include Q64_CORE_INC
 
 struct Q64Unit { int bh, g, sp, T_lo, nt; };
 

@@ -5,7 +5,11 @@
 // namespace dex::f16).  Both have the same fragment layouts, one-instruction packed converts (v_cvt_pk_bf16_f32 /
 // v_cvt_pk_f16_f32) and fp32 accumulation; lp_dispatch.hip picks the namespace from the context's precision mode.
 #pragma once
-#ifdef DEX_LP_F16
+#if defined(DEX_LP_NS_OVERRIDE)
+// (bench tools that compile a kernel file of their own next to the library's copy: a namespace - and so a kernel symbol - of their own;
+// two modules registering one kernel name resolve to whichever the runtime saw first)
+#define DEX_LP_NS DEX_LP_NS_OVERRIDE
+#elif defined(DEX_LP_F16)
 #define DEX_LP_NS f16
 #else
 #define DEX_LP_NS bf16

@@ -91,3 +91,13 @@ def test_product_path_has_no_oracle_or_cpu_fallback():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "import oracle" not in src and "from oracle" not in src, fn
+
+
+def test_generated_attention_streams_are_up_to_date():
+    """dex_tts_amd/csrc/attention_q64_core.inc is GENERATED (tools/gen_attn_q64.py holds the register map and the schedule of the
+    64-queries-per-wave attention): the committed file must be what the committed generator writes."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("Q64GEN_")}
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_attn_q64.py"), "--check"], env=env)
+    assert r.returncode == 0, "run python tools/gen_attn_q64.py and commit the .inc"

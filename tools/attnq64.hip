@@ -11,6 +11,7 @@
 #include <vector>
 #include <functional>
 #include <algorithm>
+#define DEX_LP_NS_OVERRIDE q64tool
 #include "../dex_tts_amd/csrc/attention_q64.hip"
 
 using namespace dex;
@@ -68,7 +69,7 @@ int main(int argc, char** argv) {
         hipDeviceSynchronize();
         std::vector<float> r(on); hipMemcpy(r.data(), O, on * 4, hipMemcpyDeviceToHost);
         const int nt32 = (c.N + 31) / 32, nT = (nt32 + 1) / 2;
-        const int auto_ks = dex::bf16::attention_q64_ksplit(c.N, c.B, KSMAX);
+        const int auto_ks = dex::q64tool::attention_q64_ksplit(c.N, c.B, KSMAX);
         std::vector<int> splits = {1};
         if (nT >= 2) splits.push_back(2);
         if (nT >= 3) splits.push_back(3);
@@ -82,8 +83,8 @@ int main(int argc, char** argv) {
 #endif
             hipMemset(O2, 0, on * 4 * ks);
             char label[96]; snprintf(label, sizeof label, "q64 ksplit=%d%s", ks, ks == auto_ks ? " (auto)" : "");
-            if (c.bench) timeit(label, 20, fl, [&] { dex::bf16::launch_attention_q64(a2, 0); });
-            else dex::bf16::launch_attention_q64(a2, 0);
+            if (c.bench) timeit(label, 20, fl, [&] { dex::q64tool::launch_attention_q64(a2, 0); });
+            else dex::q64tool::launch_attention_q64(a2, 0);
             if (hipDeviceSynchronize() != hipSuccess) { printf("      %s: LAUNCH FAILED: %s\n", label, hipGetErrorString(hipGetLastError())); return 1; }
             std::vector<float> g(on * ks), hml((size_t)ks * c.B * 2 * c.N * 2);
             hipMemcpy(g.data(), O2, on * 4 * ks, hipMemcpyDeviceToHost);

@@ -21,7 +21,20 @@ Register map (core):
 import os
 import sys
 
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dex_tts_amd", "csrc", "attention_q64_core.inc")
+OUT = os.environ.get("Q64GEN_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dex_tts_amd", "csrc", "attention_q64_core.inc")
+# ---- experiment switches (tools/attnq64 A/B builds: Q64GEN_OUT=/tmp/x.inc Q64GEN_DMA=... python tools/gen_attn_q64.py, then
+# -DQ64_CORE_INC='"/tmp/x.inc"').  The committed .inc is generated with none of them set.
+OPT_DMA = os.environ.get("Q64GEN_DMA", "default")        # where the 4 + 4 LDS-DMA pieces of an iteration sit: see DMA_PLANS
+OPT_QK = os.environ.get("Q64GEN_QK", "kb")             # order of the 32 S^T MFMAs: "kb" key block 0 first, "ks" K-step major (4 accumulators rotate)
+OPT_DROP = set(filter(None, os.environ.get("Q64GEN_DROP", "").split(",")))     # anatomy: fill, dma, lds, bar (results are wrong without them)
+DMA_PLANS = {            # (gaps of phase A for K pieces 0..3, gaps of phase B for V pieces 0..3)
+    "default": ((13, 15, 29, 31), (4, 5, 6, 7)),
+    "a_late": ((28, 29, 30, 31), (4, 5, 6, 7)),
+    "a_spread": ((6, 14, 22, 30), (5, 6, 7, 9)),
+    "b_all": ((), (0, 1, 4, 5, 6, 7, 8, 9)),              # all eight in phase B (K first)
+    "burst": ((29, 29, 29, 29), (5, 5, 5, 5)),
+    "a_all": ((4, 5, 6, 7, 12, 13, 14, 15), ()),          # all eight in phase A (K first)
+}
 
 TILE = 16384
 V_RING = 4 * TILE
@@ -77,6 +90,8 @@ class Prog:
 
     def e(self, text):
         """one instruction; MFMA / PK are C macros holding the mnemonic of the operand type"""
+        if "lds" in OPT_DROP and text.startswith("ds_read_b128 a["):
+            return
         if text.startswith("MFMA "):
             self.out.append(f'Q64_MFMA " {text[5:]}\\n\\t"')
         elif text.startswith("PK "):
@@ -102,8 +117,11 @@ def VOFF(kk, td): return ((kk >> 1) * 8 + td * 2 + (kk & 1)) * 1024
 def qk_phase(p, dst, first, fill, last4):
     """32 S^T MFMAs into score buffer dst, key block 0 first; group 0's fragments already requested into fr[0]"""
     for n in range(32):
-        kb, s, x = n >> 4, (n >> 1) & 7, n & 1
-        j = n >> 1
+        if OPT_QK == "ks":
+            s, kb, x = n >> 2, (n >> 1) & 1, n & 1
+        else:
+            kb, s, x = n >> 4, (n >> 1) & 7, n & 1
+        j = n >> 1                                                       # fragment j is read from byte frag_off(j) of the slot
         grp, q = j >> 2, j & 3
         if n & 7 == 0:
             p.e("s_waitcnt lgkmcnt(0)")
@@ -112,7 +130,7 @@ def qk_phase(p, dst, first, fill, last4):
         p.e(f"MFMA {acc}, {ar(FR(grp & 1, q), 4)}, {ar((QB if x else QA)(s), 4)}, {c}")
         if (n & 7) < 4:
             if grp < 3:
-                p.e(f"ds_read_b128 {ar(FR((grp + 1) & 1, n & 7), 4)}, {vr(V_KA)} offset:{((grp + 1) * 4 + (n & 7)) * 1024}")
+                p.e(f"ds_read_b128 {ar(FR((grp + 1) & 1, n & 7), 4)}, {vr(V_KA)} offset:{frag_off((grp + 1) * 4 + (n & 7))}")
             else:
                 last4(p, n & 7)
         fill(p, n)
@@ -135,9 +153,17 @@ def pv_phase(p, pbuf, fill, last4):
         fill(p, n)
 
 
+def frag_off(j):
+    """LDS byte offset of the j-th K fragment an S^T phase consumes: (kb, s) at (kb * 8 + s) KB"""
+    if OPT_QK == "ks":
+        s_, kb = j >> 1, j & 1
+        return (kb * 8 + s_) * 1024
+    return j * 1024
+
+
 def k_group0(p, vaddr):
     for q in range(4):
-        p.e(f"ds_read_b128 {ar(FR(0, q), 4)}, {vr(vaddr)} offset:{q * 1024}")
+        p.e(f"ds_read_b128 {ar(FR(0, q), 4)}, {vr(vaddr)} offset:{frag_off(q)}")
 
 
 def v_group0(p, vaddr):
@@ -239,23 +265,47 @@ def kslot_addr(p, vdst, add):
 # ------------------------------------------------------------------------------------------------------------------ iteration
 def iteration(p, cb, nb, steady, tag):
     """tile T (scores in buffer cb) is current, T + 1 (buffer nb) is next"""
-    # addresses and DMA operands of this iteration
-    kslot_addr(p, V_KA, 1)
-    p.e(f"v_add_u32_e32 {vr(V_VA)}, {sr(S_VS0)}, {vr(V_L16)}")
-    kslot_addr(p, V_KA2, 2)
-    soff_of(p, S_SOFFK, S_T, 4)
-    soff_of(p, S_SOFFV, S_T, 2)
-    p.e(f"s_and_b32 {sr(S_KDST)}, {sr(S_T)}, 3")
-    p.e(f"s_lshl_b32 {sr(S_KDST)}, {sr(S_KDST)}, 14")
-    p.e(f"s_add_i32 {sr(S_KDST)}, {sr(S_KDST)}, %[dbase]")              # LDS base + wave * 4 KB
-    p.e(f"s_add_i32 {sr(S_VDST)}, {sr(S_VS2)}, %[dbase]")
+    # The iteration's addresses and DMA operands are computed INSIDE its MFMA gaps, each just before its first use (as a burst in
+    # front of the first MFMA they were ~45 instructions = ~150 cycles per tile with nothing to hide behind): setup_a / setup_b below.
+    # K(T+1)'s read address is last iteration's look-ahead address.
+    p.e(f"v_mov_b32 {vr(V_KA)}, {vr(V_KA2)}")
     if not steady:
         p.e(f"s_sub_i32 {sr(S_X0)}, %[nt], {sr(S_IT)}")                 # nt - it
         p.e(f"s_cmp_gt_i32 {sr(S_X0)}, 4")
         p.e(f"s_cselect_b32 {sr(S_HK)}, 1, 0")
         p.e(f"s_cmp_gt_i32 {sr(S_X0)}, 2")
         p.e(f"s_cselect_b32 {sr(S_HV)}, 1, 0")
-    p.e(f"s_mov_b32 m0, {sr(S_KDST)}")
+
+    def setup_a(p, n):
+        if n == 4:          # soffset of K(T+4): min(2 (T + 4) + wh, nt32 - 1) * 8192 + wq
+            p.e(f"s_add_i32 {sr(S_SOFFK)}, {sr(S_T)}, 4")
+            p.e(f"s_lshl_b32 {sr(S_SOFFK)}, {sr(S_SOFFK)}, 1")
+            p.e(f"s_add_i32 {sr(S_SOFFK)}, {sr(S_SOFFK)}, %[wh]")
+        if n == 5:
+            p.e(f"s_min_i32 {sr(S_SOFFK)}, {sr(S_SOFFK)}, {sr(S_NT32M1)}")
+            p.e(f"s_lshl_b32 {sr(S_SOFFK)}, {sr(S_SOFFK)}, 13")
+            p.e(f"s_add_i32 {sr(S_SOFFK)}, {sr(S_SOFFK)}, %[wq]")
+        if n == 6:          # its LDS destination: slot (T + 4) & 3 = T & 3
+            p.e(f"s_and_b32 {sr(S_KDST)}, {sr(S_T)}, 3")
+            p.e(f"s_lshl_b32 {sr(S_KDST)}, {sr(S_KDST)}, 14")
+            p.e(f"s_add_i32 {sr(S_KDST)}, {sr(S_KDST)}, %[dbase]")      # LDS base + wave * 4 KB
+        if n == 7:
+            p.e(f"s_mov_b32 m0, {sr(S_KDST)}")
+            p.e(f"v_add_u32_e32 {vr(V_VA)}, {sr(S_VS0)}, {vr(V_L16)}")  # V(T) read address (first use: gap 24)
+        if n == 12:         # look-ahead address: K(T+2) (first use: gap 24 of phase B)
+            p.e(f"s_add_i32 {sr(S_X0)}, {sr(S_T)}, 2")
+            p.e(f"s_and_b32 {sr(S_X0)}, {sr(S_X0)}, 3")
+            p.e(f"s_lshl_b32 {sr(S_X0)}, {sr(S_X0)}, 14")
+            p.e(f"v_add_u32_e32 {vr(V_KA2)}, {sr(S_X0)}, {vr(V_L16)}")
+        if n == 28:         # soffset of V(T+2)
+            p.e(f"s_add_i32 {sr(S_SOFFV)}, {sr(S_T)}, 2")
+            p.e(f"s_lshl_b32 {sr(S_SOFFV)}, {sr(S_SOFFV)}, 1")
+            p.e(f"s_add_i32 {sr(S_SOFFV)}, {sr(S_SOFFV)}, %[wh]")
+        if n == 30:
+            p.e(f"s_min_i32 {sr(S_SOFFV)}, {sr(S_SOFFV)}, {sr(S_NT32M1)}")
+            p.e(f"s_lshl_b32 {sr(S_SOFFV)}, {sr(S_SOFFV)}, 13")
+            p.e(f"s_add_i32 {sr(S_SOFFV)}, {sr(S_SOFFV)}, %[wq]")
+            p.e(f"s_add_i32 {sr(S_VDST)}, {sr(S_VS2)}, %[dbase]")
 
     def dma_guarded(p, rs, soff, j, flag, name):
         if steady:
@@ -266,13 +316,36 @@ def iteration(p, cb, nb, steady, tag):
             dma_piece(p, rs, soff, j)
             p.label(name)
 
+    ka_gaps, vb_gaps = DMA_PLANS[OPT_DMA]
+    # pieces 0..3 = K(T+4), 4..7 = V(T+2); a plan lists the gaps of phase A, then of phase B (M0 switches where the V pieces start)
+    seq_a = list(ka_gaps)
+    seq_b = list(vb_gaps)
+    n_k_in_b = 4 - min(4, len(seq_a))          # K pieces that a plan moved into phase B
+    n_v_in_a = max(0, len(seq_a) - 4)          # V pieces that a plan moved into phase A
+
+    def dma_at(p, phase, n):
+        if "dma" in OPT_DROP:
+            return
+        seq = seq_a if phase == 0 else seq_b
+        for idx, g in enumerate(seq):
+            if g != n:
+                continue
+            piece = idx if phase == 0 else idx + len(seq_a)          # 0..7 in issue order
+            if piece < 4:
+                dma_guarded(p, "%[rk]", S_SOFFK, piece, S_HK, f"SKK{tag}{piece}")
+            else:
+                if piece == 4:
+                    p.e(f"s_mov_b32 m0, {sr(S_VDST)}")
+                    p.e("s_nop 0")
+                dma_guarded(p, "%[rv]", S_SOFFV, piece - 4, S_HV, f"SKV{tag}{piece - 4}")
+
     def fa(p, n):
-        fill_a(p, cb, n)
-        if 20 <= n <= 26:
-            max_step(p, nb, 0, n - 20)
-        if n in (5, 13, 29, 31):
-            j = {5: 0, 13: 1, 29: 2, 31: 3}[n]
-            dma_guarded(p, "%[rk]", S_SOFFK, j, S_HK, f"SKK{tag}{j}")
+        if "fill" not in OPT_DROP:
+            fill_a(p, cb, n)
+            if 20 <= n <= 26 and OPT_QK == "kb":
+                max_step(p, nb, 0, n - 20)
+        setup_a(p, n)
+        dma_at(p, 0, n)
 
     def last4_a(p, q):
         p.e(f"ds_read_b128 {ar(FR(0, q), 4)}, {vr(V_VA)} offset:{VOFF(0, q)}")
@@ -280,10 +353,9 @@ def iteration(p, cb, nb, steady, tag):
     qk_phase(p, nb, False, fa, last4_a)
 
     def fb(p, n):
-        if n == 0:
-            p.e(f"s_mov_b32 m0, {sr(S_VDST)}")
-        if 4 <= n <= 7:
-            dma_guarded(p, "%[rv]", S_SOFFV, n - 4, S_HV, f"SKV{tag}{n - 4}")
+        dma_at(p, 1, n)
+        if "fill" in OPT_DROP:
+            return
         if n == 2:
             # the next tile is the last of the sequence and ragged: mask its keys >= N (scores are complete: >= 2 gaps behind the MFMAs)
             p.e(f"s_add_i32 {sr(S_X0)}, {sr(S_T)}, 1")
@@ -297,6 +369,8 @@ def iteration(p, cb, nb, steady, tag):
             mask_tile(p, nb, S_X0, tag)
             p.end_cold()
         if 2 <= n <= 8:
+            if OPT_QK != "kb":
+                max_step(p, nb, 0, n - 2)
             max_step(p, nb, 1, n - 2)
         if n == 9:
             max_last(p, nb, V_MXA, V_MXB)
@@ -332,7 +406,7 @@ def iteration(p, cb, nb, steady, tag):
             fill_b(p, nb, n - 12)
 
     def last4_b(p, q):
-        p.e(f"ds_read_b128 {ar(FR(0, q), 4)}, {vr(V_KA2)} offset:{q * 1024}")
+        p.e(f"ds_read_b128 {ar(FR(0, q), 4)}, {vr(V_KA2)} offset:{frag_off(q)}")
 
     pv_phase(p, cb, fb, last4_b)
     # pending rescale of O^T
@@ -365,7 +439,8 @@ def iteration(p, cb, nb, steady, tag):
         p.label(f"W0{tag}")
         p.e("s_waitcnt vmcnt(0)")
         p.label(f"WD{tag}")
-    p.e("s_barrier")
+    if "bar" not in OPT_DROP:
+        p.e("s_barrier")
     p.e(f"s_mov_b32 {sr(S_X0)}, {sr(S_VS0)}")
     p.e(f"s_mov_b32 {sr(S_VS0)}, {sr(S_VS1)}")
     p.e(f"s_mov_b32 {sr(S_VS1)}, {sr(S_VS2)}")
@@ -454,8 +529,8 @@ def core():
     # group 0 of K(1) for the first iteration
     p.e("s_cmp_lt_i32 %[nt], 2")
     p.br("s_cbranch_scc1", "TAIL_E")
-    kslot_addr(p, V_KA, 1)
-    k_group0(p, V_KA)
+    kslot_addr(p, V_KA2, 1)
+    k_group0(p, V_KA2)
     # ---- the loop: even iterations have the current tile in buffer 0, odd ones in buffer 1
     for par, (cb, nb) in enumerate(((0, 1), (1, 0))):
         me, other = "EO"[par], "OE"[par]
