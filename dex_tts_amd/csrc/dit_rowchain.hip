@@ -77,6 +77,22 @@ __device__ __forceinline__ void mma16(f32x16& acc, const uint4 (&w)[16], const u
     }
 }
 
+// The same product TRANSPOSED (weights as the A operand, activations as B): acc[r] = C[feature (r&3) + 8 (r>>2) + 4 hh][token lane&31].
+// Same products, same K order per output element: the values are those of mma16, only their placement over lanes / registers differs
+// - it is the placement from which the q / k fragment layouts can be written without a transpose (store_qkv_tile_d).
+__device__ __forceinline__ void mma16t(f32x16& acc, const uint4 (&w)[16], const u16* a_lane) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        u32x4 a[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = *reinterpret_cast<const u32x4*>(a_lane + (h * 8 + j) * 16);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            acc = DEX_MFMA_LP(__builtin_bit_cast(lp8, w[h * 8 + j]), __builtin_bit_cast(lp8, a[j]), acc, 0, 0, 0);
+    }
+}
+
 // LayerNorm(eps 1e-6, no affine) + modulate of the 32 fp32 rows in X1 -> bf16 A tile.  16 threads per row, each
 // owning four float4 at columns q*64 + seg*4 (64 contiguous floats per 16 lanes: conflict-free).
 __device__ __forceinline__ void ln_to_A(const float* X1, u16* As, const float* shift, const float* scale, int tid) {
@@ -167,6 +183,66 @@ __device__ __forceinline__ void store_qkv_tile(const DitChainP& p, const f32x16&
     __builtin_amdgcn_wave_barrier();                     // scratch is reused by the next tile
 }
 
+
+// Round 4: the same tile WITHOUT the LDS round trip (the scatter of 16 two-byte LDS writes, two wave barriers and the gather back were a
+// large part of the row chain's 12 VALU instructions per MFMA, profiles/round3_dex_b32_diag_counters.txt).
+//   KIND 0 / 1 (q / k): `acc` comes from mma16t (features in registers, token = lane & 31).  A lane packs its 16 features into four
+//     2-dword pieces (features 8 j + 4 hh .. + 3); one v_permlane32_swap per dword pairs the pieces of the two halves of a token into
+//     whole 8-feature chunks - chunk 2 pr + hh ends up in lane (hh, token), which is exactly lane `lane` of K-step (d0 / 16 + pr) of
+//     the fragment layout: two lane-linear 1-KB stores.
+//   KIND 2 (v^T): `acc` comes from mma16 (feature = lane & 31, tokens in registers).  The v^T layout's position order (bits 2 / 3 of the
+//     key index swapped) IS the accumulator's row order: registers 8 half .. + 7 of lane (hh, d) are position group hh + 2 half, in
+//     order: pack and store, nothing to exchange.
+// Values are bit-identical to store_qkv_tile's ((acc + bias) * scale, rounded once).
+struct QkvBias { float4 f[4]; };      // KIND 0 / 1: features 8 j + 4 hh .. + 3 of the tile (j = 0..3); KIND 2: f[0].x = the lane's feature
+template <int KIND>
+__device__ __forceinline__ QkvBias qkv_bias(const DitChainP& p, int nt, int lane) {
+    QkvBias q;
+    const int i = lane & 31, hh = lane >> 5;
+    if constexpr (KIND < 2) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q.f[j] = *reinterpret_cast<const float4*>(p.bq + nt * 32 + 8 * j + 4 * hh);
+    } else {
+        q.f[0] = make_float4(p.bq[nt * 32 + i], 0.f, 0.f, 0.f);
+        q.f[1] = q.f[2] = q.f[3] = q.f[0];
+    }
+    return q;
+}
+template <int KIND>
+__device__ __forceinline__ void store_qkv_tile_d(const DitChainP& p, const f32x16& acc, const QkvBias& qb, int nt, int b, int n0, int lane) {
+    const int i = lane & 31, hh = lane >> 5;
+    const int head = (nt >> 2) & 1, d0 = (nt & 3) * 32;
+    u16* base = (KIND == 0 ? reinterpret_cast<u16*>(p.Qh) : KIND == 1 ? reinterpret_cast<u16*>(p.Kh) : reinterpret_cast<u16*>(p.Vt))
+                + ((long)b * 2 + head) * p.Npad * 128 + (long)(n0 >> 5) * 4096;
+    if constexpr (KIND < 2) {
+        const float sc = KIND == 0 ? p.qscale : 1.f;
+        unsigned D[4][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 bj = qb.f[j];
+            D[j][0] = pack2_lp((acc[4 * j + 0] + bj.x) * sc, (acc[4 * j + 1] + bj.y) * sc);
+            D[j][1] = pack2_lp((acc[4 * j + 2] + bj.z) * sc, (acc[4 * j + 3] + bj.w) * sc);
+        }
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+            const u32x2v s0 = __builtin_amdgcn_permlane32_swap(D[2 * pr][0], D[2 * pr + 1][0], false, false);
+            const u32x2v s1 = __builtin_amdgcn_permlane32_swap(D[2 * pr][1], D[2 * pr + 1][1], false, false);
+            const int ks = (d0 >> 4) + pr;
+            *reinterpret_cast<uint4*>(base + ((ks * 64 + lane) << 3)) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        }
+    } else {
+        const float bias = qb.f[0].x;
+        const int t = d0 >> 5;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            unsigned w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = pack2_lp(acc[8 * half + 2 * j] + bias, acc[8 * half + 2 * j + 1] + bias);
+            *reinterpret_cast<uint4*>(base + (((t * 2 + half) * 64 + lane) << 3)) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+}
 }  // namespace
 
 // ATTN: the attention core of the block runs INSIDE this launch (no attention kernel, no partials in HBM): waves 0-3 take
@@ -520,23 +596,25 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
     long long u1 = wall_clock64();
 #endif
     acc = zero16();
-    mma16(acc, wb, a_lane);
+    QkvBias qb = qkv_bias<0>(p, wave, lane);
+    mma16t(acc, wb, a_lane);
 #ifdef DEX_TIMING
     asm volatile("s_nop 0" :: "v"(acc[0]), "v"(acc[15])); long long u2 = wall_clock64();
 #endif
-    u16* scr = Hs + wave * (RC_ROWS * QK_LD);              // H is dead here (and unused in qkv-only mode)
-    store_qkv_tile(p, acc, wave, bq0, b, n0, lane, scr);
+    store_qkv_tile_d<0>(p, acc, qb, wave, b, n0, lane);
 #ifdef DEX_TIMING
     long long u3 = wall_clock64();
     if (p.dbg && tid == 0) { p.dbg[256 + blockIdx.x * 4 + 0] = u1 - u0; p.dbg[256 + blockIdx.x * 4 + 1] = u2 - u1; p.dbg[256 + blockIdx.x * 4 + 2] = u3 - u2; }
 #endif
     wload(wb, p.Wq, 16, wave + 16, 0, lane);
     acc = zero16();
-    mma16(acc, wa, a_lane);
-    store_qkv_tile(p, acc, wave + 8, bq1, b, n0, lane, scr);
+    qb = qkv_bias<1>(p, wave + 8, lane);
+    mma16t(acc, wa, a_lane);
+    store_qkv_tile_d<1>(p, acc, qb, wave + 8, b, n0, lane);
     acc = zero16();
+    qb = qkv_bias<2>(p, wave + 16, lane);
     mma16(acc, wb, a_lane);
-    store_qkv_tile(p, acc, wave + 16, bq2, b, n0, lane, scr);
+    store_qkv_tile_d<2>(p, acc, qb, wave + 16, b, n0, lane);
 #ifdef DEX_TIMING
     if (p.dbg && tid == 0) { tst[7] = wall_clock64(); for (int k = 0; k < 8; ++k) p.dbg[blockIdx.x * 8 + k] = tst[k]; for (int k = 8; k < 12; ++k) p.dbg[1024 + blockIdx.x * 4 + k - 8] = tst[k]; }
 #endif
@@ -698,18 +776,20 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain64_kernel(const DitCha
     ln_to_A(X1, As, LNp + 2 * RC_H, LNp + 3 * RC_H, tid);
     ln_to_A(X1 + 32 * X_LD, As + 32 * A_LD, LNp + 2 * RC_H, LNp + 3 * RC_H, tid);
     lds_barrier();
-    // ---- qkv of the next block: column tiles wave (q), wave+8 (k), wave+16 (v), two row halves each
-    const float bq0 = p.bq[col], bq1 = p.bq[col + 256], bq2 = p.bq[col + 512];
-    u16* scr = Hs + wave * (RC_ROWS * QK_LD);
+    // ---- qkv of the next block: column tiles wave (q), wave+8 (k), wave+16 (v), two row halves each; q and k are computed transposed
+    // so that their fragment layouts leave the accumulators without an LDS transpose (store_qkv_tile_d)
     wload(wa, p.Wq, 16, wave + 8, 0, lane);
+    QkvBias qb = qkv_bias<0>(p, wave, lane);
 #pragma unroll
     // (the operand buffers hold ceil(N / 32) row tiles per (utterance, head): a second half that lies wholly past them is skipped)
-    for (int m = 0; m < 2; ++m) { if (n0 + 32 * m >= p.Npad) break; acc = zero16(); mma16(acc, wb, a_lane + m * 32 * A_LD); store_qkv_tile(p, acc, wave, bq0, b, n0 + 32 * m, lane, scr); }
+    for (int m = 0; m < 2; ++m) { if (n0 + 32 * m >= p.Npad) break; acc = zero16(); mma16t(acc, wb, a_lane + m * 32 * A_LD); store_qkv_tile_d<0>(p, acc, qb, wave, b, n0 + 32 * m, lane); }
     wload(wb, p.Wq, 16, wave + 16, 0, lane);
+    qb = qkv_bias<1>(p, wave + 8, lane);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) { if (n0 + 32 * m >= p.Npad) break; acc = zero16(); mma16(acc, wa, a_lane + m * 32 * A_LD); store_qkv_tile(p, acc, wave + 8, bq1, b, n0 + 32 * m, lane, scr); }
+    for (int m = 0; m < 2; ++m) { if (n0 + 32 * m >= p.Npad) break; acc = zero16(); mma16t(acc, wa, a_lane + m * 32 * A_LD); store_qkv_tile_d<1>(p, acc, qb, wave + 8, b, n0 + 32 * m, lane); }
+    qb = qkv_bias<2>(p, wave + 16, lane);
 #pragma unroll
-    for (int m = 0; m < 2; ++m) { if (n0 + 32 * m >= p.Npad) break; acc = zero16(); mma16(acc, wb, a_lane + m * 32 * A_LD); store_qkv_tile(p, acc, wave + 16, bq2, b, n0 + 32 * m, lane, scr); }
+    for (int m = 0; m < 2; ++m) { if (n0 + 32 * m >= p.Npad) break; acc = zero16(); mma16(acc, wb, a_lane + m * 32 * A_LD); store_qkv_tile_d<2>(p, acc, qb, wave + 16, b, n0 + 32 * m, lane); }
 }
 
 // ---- cluster form (small grids: B x ceil(N / 32) row tiles <= 64).  At B = 1 the kernels above run 21 workgroups, each streaming
@@ -1229,10 +1309,16 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const 
     cts[13] = wall_clock64();
 #endif
     if (wave < 6) {
-        const float bq = p.bq[nt * 32 + i];
         acc = zero16();
-        mma16(acc, wq, As + i * A_LD + hh * 8);
-        store_qkv_tile(p, acc, nt, bq, b, n0, lane, QS + wave * (RC_ROWS * QK_LD));
+        if (nt < 16) {                 // (wave-uniform) q / k tiles: transposed product, fragment layout straight from the accumulators
+            const QkvBias qb = qkv_bias<0>(p, nt, lane);
+            mma16t(acc, wq, As + i * A_LD + hh * 8);
+            if (nt < 8) store_qkv_tile_d<0>(p, acc, qb, nt, b, n0, lane); else store_qkv_tile_d<1>(p, acc, qb, nt, b, n0, lane);
+        } else {
+            const QkvBias qb = qkv_bias<2>(p, nt, lane);
+            mma16(acc, wq, As + i * A_LD + hh * 8);
+            store_qkv_tile_d<2>(p, acc, qb, nt, b, n0, lane);
+        }
     }
 #ifdef DEX_TIMING
     cts[14] = wall_clock64();
