@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("DEX_AMD_LIB") or os.path.join(HERE, "lib", "libdexamd
 
 DEX_OK = 0
 VARIANT = {"gedex": 0, "dex": 1}
-PRECISION = {"fp32": 0, "bf16": 1, "fp16": 2}
+PRECISION = {"fp32": 0, "bf16": 1, "fp16": 2, "fp16x2": 3}
 SOLVER = {"euler": 0, "heun": 1}
 
 

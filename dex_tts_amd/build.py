@@ -23,7 +23,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-ato
 
 
 # the MFMA-heavy kernel files of the reduced-precision modes are compiled twice: operands bf16 (namespace dex::bf16) and,
-# with -DDEX_LP_F16, fp16 (namespace dex::f16) — csrc/lp_config.h
+# with -DDEX_LP_F16, fp16 (namespace dex::f16), and -DDEX_LP_F16 -DDEX_LP_WSPLIT (namespace dex::f16w: weights as hi + lo) — csrc/lp_config.h
 LP_SOURCES = ("conv3x3_bf16.hip", "conv3x3_stream.hip", "igemm_bf16.hip", "attention_bf16.hip", "attention_direct.hip",
               "attention_q64.hip", "dit_rowchain.hip", "linattn_fused.hip", "pos_conv.hip", "convt_up.hip", "conv3x3_regw.hip", "conv_down.hip", "patch_embed.hip")
 
@@ -52,6 +52,7 @@ def sources():
             out.append((f, list(ff), ""))
             if f in LP_SOURCES:
                 out.append((f, ["-DDEX_LP_F16", *ff], ".f16"))
+                out.append((f, ["-DDEX_LP_F16", "-DDEX_LP_WSPLIT", *ff], ".f16w"))
     return out
 
 

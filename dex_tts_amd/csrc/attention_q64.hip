@@ -31,6 +31,7 @@
 //   wave-private LDS stage so that every store instruction writes whole 256-byte row segments.
 // Output: normalised O per key split (+ (m, l) for the consumer's merge), the format attn_direct_ring_kernel writes.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "kernels.h"
 #include "lp_util.h"
 #include "kernels_lp.h"
@@ -58,7 +59,7 @@ constexpr int LDS_BYTES = STAGE + 4 * STAGE_WAVE;
 #endif
 #include Q64_CORE_INC
 
-struct Q64Unit { int bh, g, sp, T_lo, nt; };
+struct Q64Unit { int bh, g, sp, T_lo, nt, tail; };
 
 __device__ __forceinline__ float xhalf_sum(float x) {
     const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
@@ -72,7 +73,11 @@ __device__ __forceinline__ float xhalf_sum(float x) {
 #define Q64_T(k) do { } while (0)
 #endif
 
-// ng = groups of 256 queries per (element, head); nunits = 2 B ng ksplit; xcd_mode: unit u -> XCD u % 8 owns (element, head) pairs
+// ng = groups of 256 queries per (element, head); nunits = 2 B ng ksplit; xcd_mode: unit u -> XCD u % 8 owns (element, head) pairs.
+// Tail split (p.tail_ks > 1, p.ksplit == 1): the query groups g < p.tail_g are whole units and come FIRST in the unit order, the
+// groups from tail_g on are split tail_ks ways over the keys and follow - a persistent workgroup then runs one long and one short unit
+// instead of two long ones when the whole units alone fill the chip once (DEX B = 32, N = 1300: 384 whole units were two rounds of
+// 256 CUs with the second half empty).  Whole units write O slot 0 (16-bit when o_lp), tail partials write fp32 slots 1 + sp and (m, l).
 __global__ __launch_bounds__(256, 1) void attn_q64_kernel(const AttnDirectP p, const int ng, const int nunits, const int xcd_mode) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char q64_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -90,15 +95,20 @@ __global__ __launch_bounds__(256, 1) void attn_q64_kernel(const AttnDirectP p, c
     long long tst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
+    const int tks = p.tail_ks > 1 ? p.tail_ks : 1, tail_g = tks > 1 ? p.tail_g : ng;
+    const int nwhole = 2 * p.B * tail_g * ks;                 // units of the whole groups (all of them without a tail split)
     auto decode = [&](int unit) __attribute__((always_inline)) -> Q64Unit {
         Q64Unit u;
-        const int per = ng * ks;
-        int r = unit;
+        u.tail = unit >= nwhole ? 1 : 0;
+        const int uks = u.tail ? tks : ks;
+        const int per = (u.tail ? ng - tail_g : tail_g) * uks;
+        int r = u.tail ? unit - nwhole : unit;
         if (xcd_mode) { const int x = r & 7, s = r >> 3; u.bh = x + 8 * (s / per); r = s % per; }
         else { u.bh = r / per; r = r % per; }
-        u.g = r / ks; u.sp = r % ks;
-        u.T_lo = (int)((long)nT * u.sp / ks);
-        u.nt = (int)((long)nT * (u.sp + 1) / ks) - u.T_lo;
+        u.g = r / uks + (u.tail ? tail_g : 0); u.sp = r % uks;
+        u.T_lo = (int)((long)nT * u.sp / uks);
+        u.nt = (int)((long)nT * (u.sp + 1) / uks) - u.T_lo;
+        u.tail = __builtin_amdgcn_readfirstlane(u.tail);
         u.bh = __builtin_amdgcn_readfirstlane(u.bh); u.g = __builtin_amdgcn_readfirstlane(u.g); u.sp = __builtin_amdgcn_readfirstlane(u.sp);
         u.T_lo = __builtin_amdgcn_readfirstlane(u.T_lo); u.nt = __builtin_amdgcn_readfirstlane(u.nt);
         return u;
@@ -124,7 +134,7 @@ __global__ __launch_bounds__(256, 1) void attn_q64_kernel(const AttnDirectP p, c
     issue_prologue(cur);
     int first_unit = 1;
     for (int unit = blockIdx.x;;) {
-        const int bh = cur.bh, sp = cur.sp;
+        const int bh = cur.bh, sp = cur.sp, oslot = cur.tail ? 1 + cur.sp : cur.sp;
         const int b = bh >> 1, h = bh & 1;
         const int q64 = cur.g * 4 + wave;                      // this wave's 64-query block
         Q64_T(0); Q64_T(1); Q64_T(2);
@@ -156,7 +166,7 @@ __global__ __launch_bounds__(256, 1) void attn_q64_kernel(const AttnDirectP p, c
             const long orow = (long)N * 1024;                                   // one element's output: N rows x 256 fp32
             const unsigned sread = stg + rsel * STAGE_ROW + c16 * 16;
             const float invA = lA > 0.f ? 1.f / lA : 0.f, invB = lB > 0.f ? 1.f / lB : 0.f;
-            if (p.o_lp) {
+            if (p.o_lp && !cur.tail) {
                 const auto rO = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.O) + (long)b * (orow / 2), 0, (int)(orow / 2), 0x00020000);
                 const unsigned swrite = stg + i * STAGE_ROW + hh * 8;
                 unsigned o[8];
@@ -173,13 +183,13 @@ __global__ __launch_bounds__(256, 1) void attn_q64_kernel(const AttnDirectP p, c
                 Q64_EPI(Q64_ASM_EPI_LP_A, invA, q64 * 64, 512, 256)
                 Q64_EPI(Q64_ASM_EPI_LP_B, invB, q64 * 64 + 32, 512, 256)
             } else {
-                const auto rO = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.O + (long)sp * p.o_sstride) + (long)b * orow, 0, (int)orow, 0x00020000);
+                const auto rO = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.O + (long)oslot * p.o_sstride) + (long)b * orow, 0, (int)orow, 0x00020000);
                 const unsigned swrite = stg + i * STAGE_ROW + hh * 16;
                 unsigned o[8];
                 Q64_EPI(Q64_ASM_EPI_F32_A, invA, q64 * 64, 1024, 512)
                 Q64_EPI(Q64_ASM_EPI_F32_B, invB, q64 * 64 + 32, 1024, 512)
             }
-            if (p.ml) {
+            if (p.ml && (ks > 1 || cur.tail)) {
                 const auto rM = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.ml + ((((long)sp * p.B + b) * 2 + h) * N) * 2), 0, N * 8, 0x00020000);
 #pragma unroll
                 for (int which = 0; which < 2; ++which) {
@@ -221,6 +231,38 @@ int attention_q64_ksplit(int N, int B, int max_split) {
     return best;
 }
 
+// The unit plan: a uniform key split (above), or - at batch size, where a uniform split costs the consumer a merge of every row - whole
+// units for the query groups below tail_g and a tail_ks-way split for the rest.  Makespan of the persistent grid (workgroup w runs
+// units w, w + 256, ...; whole units first) + the consumer's merge of the tail rows; tail_ks = 1: no tail split.
+void attention_q64_plan(int N, int B, int max_split, int* ks_out, int* tail_g_out, int* tail_ks_out) {
+    const int nt32 = (N + 31) / 32, nT = (nt32 + 1) / 2, ng = (nt32 + 7) / 8;
+    const double tile_us = 1.35, unit_us = 5.0;
+    const double merge_us = (double)B * N * 256 * 4 / 4.0e6 + 1.0;
+    const int ks = attention_q64_ksplit(N, B, max_split);
+    *ks_out = ks; *tail_g_out = ng; *tail_ks_out = 1;
+    if (ks > 1 || max_split < 2) return;
+    auto makespan = [&](int tg, int tk) {
+        const long nwhole = 2L * B * tg, ntail = 2L * B * (ng - tg) * tk;
+        const double cw = nT * tile_us + unit_us, ct = ((nT + tk - 1) / tk) * tile_us + unit_us;
+        // static deal: workgroup w of min(units, 256) gets units w, w + G, ...
+        const long G = std::min<long>(nwhole + ntail, 256);
+        double worst = 0;
+        for (long w = 0; w < G; ++w) {
+            double t = 0;
+            for (long u = w; u < nwhole + ntail; u += G) t += u < nwhole ? cw : ct;
+            worst = std::max(worst, t);
+        }
+        return worst;
+    };
+    double best = makespan(ng, 1);
+    for (int tk = 2; tk <= std::min(max_split - 1, 4) && tk <= nT; ++tk)
+        for (int tg = 1; tg < ng; ++tg) {
+            const double rows_tail = std::min(1.0, std::max(0.0, (double)(N - tg * 256) / N));
+            const double cost = makespan(tg, tk) + merge_us * tk * rows_tail;
+            if (cost < best - 0.5) { best = cost; *tail_g_out = tg; *tail_ks_out = tk; }
+        }
+}
+
 void launch_attention_q64(const AttnDirectP& p, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
@@ -229,7 +271,8 @@ void launch_attention_q64(const AttnDirectP& p, hipStream_t st) {
     }
     const int nt32 = (p.N + 31) / 32, ng = (nt32 + 7) / 8, ks = p.ksplit > 1 ? p.ksplit : 1;
     const int xcd_mode = ((2 * p.B) % 8 == 0) ? 1 : 0;
-    const int nunits = 2 * p.B * ng * ks;
+    const int tks = p.tail_ks > 1 && ks == 1 ? p.tail_ks : 1, tg = tks > 1 ? p.tail_g : ng;
+    const int nunits = 2 * p.B * (tg * ks + (ng - tg) * tks);
     const int grid = nunits < 256 ? nunits : 256;
     hipLaunchKernelGGL(attn_q64_kernel, dim3(grid), dim3(256), LDS_BYTES, st, p, ng, nunits, xcd_mode);
 }

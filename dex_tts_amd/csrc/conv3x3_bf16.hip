@@ -397,16 +397,36 @@ static void launch_c3(const Conv3P& p, hipStream_t st) {
     hipLaunchKernelGGL((conv3x3_lp_kernel<CC, COUT, NSL, TH, PRO2, RES, XB, NW>), grid, dim3(64 * NW), lds, st, p);
 }
 
-bool conv3x3_bf16_tail_supported(int C) { return C == 64 || C == 128; }
-bool conv3x3_bf16_xb_supported(int Cin, int Cout) { return Cin == Cout && (Cin == 64 || Cin == 128); }   // bf16 INPUT (needs pro_stats)
-bool conv3x3_bf16_res_supported(int Cin, int Cout) { return (Cout == 128 && Cin == 64) || (Cout == 64 && (Cin == 128 || Cin == 256)); }
+bool conv3x3_bf16_tail_supported(int C) {
+#if defined(DEX_LP_WSPLIT) && !defined(DEX_WS_HAVE_CONV3)
+    return false;            // no split-weight form yet (lp_config.h)
+#endif
+    return C == 64 || C == 128; }
+bool conv3x3_bf16_xb_supported(int Cin, int Cout) {
+#if defined(DEX_LP_WSPLIT) && !defined(DEX_WS_HAVE_CONV3)
+    return false;            // no split-weight form yet (lp_config.h)
+#endif
+    return Cin == Cout && (Cin == 64 || Cin == 128); }   // bf16 INPUT (needs pro_stats)
+bool conv3x3_bf16_res_supported(int Cin, int Cout) {
+#if defined(DEX_LP_WSPLIT) && !defined(DEX_WS_HAVE_CONV3_RES)
+    return false;            // no split-weight form yet (lp_config.h)
+#endif
+    return (Cout == 128 && Cin == 64) || (Cout == 64 && (Cin == 128 || Cin == 256)); }
 bool conv3x3_bf16_supported(int Cin, int Cout) {
+#if defined(DEX_LP_WSPLIT) && !defined(DEX_WS_HAVE_CONV3)
+    return false;            // no split-weight form yet (lp_config.h)
+#endif
+   
     return (Cin == 64 || Cin == 128 || Cin == 256) && (Cout == 64 || Cout == 128);
 }
 
 // plain (no GroupNorm prologue) 16-bit INPUT: only the eight-wave 64 -> 128 form with the fused shortcut is instantiated for it
 // (the first conv after a Downsample at batch size; dex_api.hip lp_inter)
 bool conv3x3_plain_lp_in_supported(int H, int W, int B, int Cin, int Cout) {
+#if defined(DEX_LP_WSPLIT) && !defined(DEX_WS_HAVE_CONV3)
+    return false;            // no split-weight form yet (lp_config.h)
+#endif
+   
     static const int w8 = getenv("DEX_CONV_W8") ? atoi(getenv("DEX_CONV_W8")) : 1;
     const long tiles4 = (long)((W + 31) / 32) * ((H + 3) / 4) * B;
     return w8 && tiles4 >= 256 && Cin == 64 && Cout == 128;
@@ -415,6 +435,10 @@ bool conv3x3_plain_lp_in_supported(int H, int W, int B, int Cin, int Cout) {
 // the up path's first conv (2C -> C with the fused 1x1 shortcut, plain input) reads a 16-bit concatenation buffer only on the
 // eight-wave patch forms below (same conditions as launch_conv3x3_lp's branches for res_w, Cout == 64, Cin >= 128)
 bool conv3x3_cat_lp_in_supported(int H, int W, int B, int Cin, int Cout) {
+#if defined(DEX_LP_WSPLIT) && !defined(DEX_WS_HAVE_CONV3_RES)
+    return false;            // no split-weight form yet (lp_config.h)
+#endif
+   
     if (Cout != 64 || Cin < 128 || Cin % 128 != 0) return false;
     static const int w8 = getenv("DEX_CONV_W8") ? atoi(getenv("DEX_CONV_W8")) : 1;
     static const long small_max = getenv("DEX_CONV_SMALL_MAX") ? atol(getenv("DEX_CONV_SMALL_MAX")) : 256;

@@ -649,6 +649,10 @@ __global__ __launch_bounds__(256) void conv3x3_rw_res128_kernel(const Conv3P p, 
 
 // the batch regime of the 128-channel layers: enough strips x rows for one full round of workgroups with long strips
 bool conv3x3_regw_form(const Conv3P& p) {
+#if defined(DEX_LP_WSPLIT)
+    return false;            // no split-weight form (lp_config.h)
+#endif
+   
     static const bool off = [] { const char* e = getenv("DEX_CONV_REGW"); return e && e[0] == '0'; }();
     if (off || !p.Wfrag || p.res2_w) return false;
     static const long min_tiles_r = [] { const char* e = getenv("DEX_REGW_MIN_TILES"); return e ? atol(e) : 1024L; }();

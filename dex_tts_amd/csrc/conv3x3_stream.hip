@@ -747,12 +747,20 @@ static bool pp_plan(const Conv3P& p, int& seg, int& nseg_y);
 // Will a 64 -> 64 fused-tail convolution of this grid run on the ping-pong form?  Only that form implements Conv3P::res2_*
 // (the caller then skips storing the first ResnetBlock's shortcut).
 bool conv3x3_res2_form(int H, int W, int B) {
+#if defined(DEX_LP_WSPLIT)
+    return false;            // no split-weight form (lp_config.h)
+#endif
+   
     Conv3P q{}; q.H = H; q.W = W; q.B = B; q.Cin = SC; q.Cout = SC; q.ldx = SC; q.x_bf16 = 1;
     q.pro_stats = reinterpret_cast<const gnfix_t*>(&q);      // (non-null: the prologue forms)
     int a, b2;
     return conv3x3_stream_tiles(q) != 0 && pp_plan(q, a, b2);
 }
 int conv3x3_stream_tiles(const Conv3P& p) {
+#if defined(DEX_LP_WSPLIT)
+    return 0;                // no split-weight form (lp_config.h)
+#endif
+   
     if (p.Cin != SC || p.Cout != SC || p.res_w || p.ldx % 8 != 0 || p.x_coff % 8 != 0) return 0;
     if (p.x_bf16 && !p.pro_stats) { int a, b2; if (!pp_plan(p, a, b2)) return 0; }       // plain 16-bit input: the ping-pong form only
     const int mode = knob_or("DEX_CONV_STREAM", 1);      // 0: never, 2: whenever the shape allows (tests), default: by grid size

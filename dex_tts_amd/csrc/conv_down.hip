@@ -163,6 +163,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ALP ? 2 : 1
 }
 
 bool conv_down_supported(int C, int H, int W, int ldx, int ldy, int x_coff) {
+#if defined(DEX_LP_WSPLIT) && !defined(DEX_WS_HAVE_DOWN)
+    return false;            // no split-weight form yet (lp_config.h)
+#endif
+   
     return C == CD_C && (ldx % 8) == 0 && (ldy % 8) == 0 && (x_coff % 8) == 0 && (H % 2) == 0 && (W % 2) == 0 && H >= 2 && W >= 2;
 }
 

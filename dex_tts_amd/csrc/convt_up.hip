@@ -194,7 +194,11 @@ __global__ __launch_bounds__(256) void convt_up_kernel(const ConvTUpP p) {
     }
 }
 
-bool convt_up_supported(int C, int H, int W, int ldx, int ldy) { return C == CU_C && (ldx % 8) == 0 && (ldy % 8) == 0 && H >= 1 && W >= 1; }
+bool convt_up_supported(int C, int H, int W, int ldx, int ldy) {
+#if defined(DEX_LP_WSPLIT) && !defined(DEX_WS_HAVE_UP)
+    return false;            // no split-weight form yet (lp_config.h)
+#endif
+    return C == CU_C && (ldx % 8) == 0 && (ldy % 8) == 0 && H >= 1 && W >= 1; }
 
 template <int MT, bool ALP, bool CLP>
 static void cu_launch(ConvTUpP p, hipStream_t st) {

@@ -26,7 +26,7 @@ using namespace dex;
 namespace dex {
 namespace {
 const char* const KNOB_NAMES[] = {
-    "DEX_CONV_STREAM", "DEX_CONV_PP", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_ATTN_Q64", "DEX_ATTN_GENERIC", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN",
+    "DEX_CONV_STREAM", "DEX_CONV_PP", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_ATTN_Q64", "DEX_ATTN_Q64_TAIL", "DEX_ATTN_GENERIC", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN",
     "DEX_DIT_CLUSTER", "DEX_DIT_CLUSTER_LOCAL", "DEX_ATTN_X_LP", "DEX_RES_X_LP", "DEX_CAT_LP", "DEX_XCD_MAP", "DEX_DEBUG_DROP_HANDOFF", "DEX_PATCH_FUSED",
     "DEX_CONV_DOWN", "DEX_CONVT_UP", "DEX_DEBUG_PLAN"};
 constexpr int N_KNOBS = (int)(sizeof(KNOB_NAMES) / sizeof(KNOB_NAMES[0]));
@@ -35,6 +35,11 @@ struct KnobSnapshot {
     KnobSnapshot() { for (int i = 0; i < N_KNOBS; ++i) { const char* e = getenv(KNOB_NAMES[i]); v[i] = e ? atoi(e) : KNOB_UNSET; } }
 };
 thread_local const KnobSnapshot* t_knobs = nullptr;
+struct WsplitScope {          // the split-weight mode of the call being built on this thread (lp_dispatch.hip's predicates read it)
+    bool prev;
+    explicit WsplitScope(bool on) : prev(g_lp_wsplit) { g_lp_wsplit = on; }
+    ~WsplitScope() { g_lp_wsplit = prev; }
+};
 struct KnobScope {            // installs a snapshot for the calls below it on this thread
     const KnobSnapshot* prev;
     explicit KnobScope(const KnobSnapshot* k) : prev(t_knobs) { t_knobs = k; }
@@ -51,7 +56,7 @@ int knob(const char* name) {
     return e ? atoi(e) : KNOB_UNSET;
 }
 }  // namespace dex
-static_assert(PREC_FP32 == DEX_PREC_FP32 && PREC_BF16 == DEX_PREC_BF16 && PREC_FP16 == DEX_PREC_FP16, "kernels.h mirrors DexPrecision");
+static_assert(PREC_FP32 == DEX_PREC_FP32 && PREC_BF16 == DEX_PREC_BF16 && PREC_FP16 == DEX_PREC_FP16 && PREC_FP16X2 == DEX_PREC_FP16X2, "kernels.h mirrors DexPrecision");
 
 namespace {
 void xcd_map_probe();       // (defined with the cluster launch plan below)
@@ -71,7 +76,7 @@ static bool attention_q64_regime(int N, int B) {
     const int nt32 = (N + 31) / 32, ng = (nt32 + 7) / 8;
     return 2L * B * ng * ks >= 128;
 }
-struct LinW { const float *wqkv, *wqkv_raw, *wout_raw, *bias_eff, *g; const void *wq_lp[2], *wkv_lp[2], *wq_frag[2]; int C; };   // [0] bf16, [1] fp16
+struct LinW { const float *wqkv, *wqkv_raw, *wout_raw, *bias_eff, *g; const void *wq_lp[3], *wkv_lp[3], *wq_frag[3]; int C; };   // [0] bf16, [1] fp16, [2] fp16 hi + lo
 struct DitBlockW { const float *wqkv, *bqkv, *wproj, *bproj, *wfc1, *bfc1, *wfc2, *bfc2, *ada_w, *ada_b; };
 
 struct Prof { std::string name; hipEvent_t a, b; double flops, bytes; };
@@ -100,10 +105,14 @@ struct DexCtx {
     std::vector<void*> owned;                              // hipMalloc'ed packed weights
     // low-precision twins of the fp32 [K][N] packs, one set per operand type: [0] bf16, [1] fp16 (both are packed at
     // finalize: the precision mode may change afterwards)
-    std::map<const float*, const void*> lp_of_[2];         // -> [N][K] twin
-    std::map<const float*, const void*> frag_of_[2];       // -> MFMA-fragment-order twin (DiT row chain)
-    int lpi() const { return precision == DEX_PREC_FP16 ? 1 : 0; }
-    int lp_kind() const { return precision == DEX_PREC_FP16 ? 2 : 1; }      // the element-wise kernels' runtime code
+    // [2] = the split-weight mode (DEX_PREC_FP16X2): fp16 twins whose lo pack (fp16 of what the hi rounding lost, same layout) follows
+    // the hi pack; lo_off_ maps a twin pointer to the distance in elements from a hi element to its lo element
+    std::map<const float*, const void*> lp_of_[3];         // -> [N][K] twin
+    std::map<const float*, const void*> frag_of_[3];       // -> MFMA-fragment-order twin (DiT row chain)
+    std::map<const void*, long> lo_off_;
+    long lo_off(const void* twin) const { auto it = lo_off_.find(twin); return it == lo_off_.end() ? 0 : it->second; }
+    int lpi() const { return precision == DEX_PREC_FP16X2 ? 2 : precision == DEX_PREC_FP16 ? 1 : 0; }
+    int lp_kind() const { return precision == DEX_PREC_BF16 ? 1 : 2; }      // the element-wise kernels' runtime code (fp16 for both fp16 modes)
     bool lp() const { return precision != DEX_PREC_FP32; }
     const std::map<const float*, const void*>& lp_of() const { return lp_of_[lpi()]; }
     const std::map<const float*, const void*>& frag_of() const { return frag_of_[lpi()]; }
@@ -118,7 +127,7 @@ struct DexCtx {
     const float *fc_w3 = nullptr, *fc_w1 = nullptr;        // first conv packs
     const float *fin_w = nullptr, *fin_b = nullptr, *fin_g = nullptr, *fin_be = nullptr, *fconv_w = nullptr, *fconv_b = nullptr;
     const float *pe_dw = nullptr, *pe_db = nullptr, *pe_pw = nullptr, *pe_pb = nullptr, *pos_w = nullptr, *pos_b = nullptr, *freq_pos = nullptr;
-    const void* pos_wfrag[2] = {nullptr, nullptr};          // pos-conv weights in MFMA fragment order (pos_conv.hip), bf16 / fp16
+    const void* pos_wfrag[3] = {nullptr, nullptr, nullptr}; // pos-conv weights in MFMA fragment order (pos_conv.hip), bf16 / fp16 / fp16 hi + lo
     std::vector<DitBlockW> blocks;
     const float *fl_w = nullptr, *fl_b = nullptr, *fl_ada_w = nullptr, *fl_ada_b = nullptr;
     const float *tv_wq_raw = nullptr, *tv_wk = nullptr, *tv_wv = nullptr, *tv_wl = nullptr;
@@ -351,7 +360,7 @@ int dex_ctx_load_weight_async(DexCtx* x, const char* key, const float* w_dev, co
 }
 
 int dex_ctx_set_precision(DexCtx* x, int precision) {
-    if (!x || (precision != DEX_PREC_FP32 && precision != DEX_PREC_BF16 && precision != DEX_PREC_FP16)) return DEX_ERR_ARG;
+    if (!x || (precision != DEX_PREC_FP32 && precision != DEX_PREC_BF16 && precision != DEX_PREC_FP16 && precision != DEX_PREC_FP16X2)) return DEX_ERR_ARG;
     // Geometries the tuned reduced-precision kernels do not cover (DEX-LibriTTS: dim 128 -> 128 / 256-channel stages, DiT hidden 384 =
     // 2 x 192, 48-channel pos-conv groups, 256-channel TVAdaptor; DexCtx::tuned == false) run the same modes PER OPERATION: every
     // convolution / linear layer with a packed 16-bit weight twin goes through the generic reduced-precision implicit GEMM (or the
@@ -376,25 +385,48 @@ struct Packer {
         x->owned.push_back(p);
         return p;
     }
-    // bf16 [N][K] twins of `count` consecutive fp32 [K][N] matrices starting at p
+    // twin set t: 0 bf16, 1 fp16, 2 fp16 hi + lo.  pack3 runs `pack(src, dst, precision)` for the set: once, or (t == 2) on the weight
+    // and on what its fp16 rounding lost (src - float(fp16(src)), through a scratch fp32 copy - packs are permutations, so the lo pack
+    // has the hi pack's layout), the lo pack `n_dst` elements behind the hi pack.
+    float* tmp = nullptr; long tmp_n = 0;
+    float* scratch(long n) {
+        if (n > tmp_n) { tmp = alloc(n); tmp_n = tmp ? n : 0; }     // (stream-ordered reuse: every pack of this Packer runs on `st`)
+        return tmp;
+    }
+    static constexpr int NSETS = 3;
+    static long set_elems(int t, long n) { return t == 2 ? 2 * n : n; }
+    template <class F> void pack3(int t, const float* src, long n_src, unsigned short* dst, long n_dst, F pack) {
+        if (t < 2) { pack(src, dst, t ? PREC_FP16 : PREC_BF16); return; }
+        pack(src, dst, PREC_FP16);
+        float* lo = scratch(n_src);
+        if (!lo) return;
+        launch_f32_residual_lp(src, lo, n_src, PREC_FP16, st);
+        pack(lo, dst + n_dst, PREC_FP16);
+    }
+    // 16-bit [N][K] twins of `count` consecutive fp32 [K][N] matrices starting at p
     void twin(const float* p, int count, int K, int N) {
         if (!p) return;
-        for (int t = 0; t < 2; ++t) {
-            unsigned short* d = (unsigned short*)alloc(((long)count * K * N + 1) / 2);
+        for (int t = 0; t < NSETS; ++t) {
+            const long n = (long)count * K * N;
+            unsigned short* d = (unsigned short*)alloc((set_elems(t, n) + 1) / 2);
             if (!d) return;
             for (int c = 0; c < count; ++c) {
-                launch_pack_lp_nk(p + (long)c * K * N, d + (long)c * K * N, K, N, t ? PREC_FP16 : PREC_BF16, st);
-                x->lp_of_[t][p + (long)c * K * N] = d + (long)c * K * N;
+                unsigned short* dc = d + (long)c * K * N;
+                pack3(t, p + (long)c * K * N, (long)K * N, dc, n, [&](const float* s, unsigned short* o, int prec) { launch_pack_lp_nk(s, o, K, N, prec, st); });
+                x->lp_of_[t][p + (long)c * K * N] = dc;
+                if (t == 2) x->lo_off_[dc] = n;
             }
         }
     }
     void frag(const float* p, int K, int N) {
         if (!p) return;
-        for (int t = 0; t < 2; ++t) {
-            void* d = alloc(((long)K * N + 1) / 2);
+        for (int t = 0; t < NSETS; ++t) {
+            const long n = (long)K * N;
+            unsigned short* d = (unsigned short*)alloc((set_elems(t, n) + 1) / 2);
             if (!d) return;
-            launch_pack_lp_frag(p, d, K, N, t ? PREC_FP16 : PREC_BF16, st);
+            pack3(t, p, n, d, n, [&](const float* s, unsigned short* o, int prec) { launch_pack_lp_frag(s, o, K, N, prec, st); });
             x->frag_of_[t][p] = d;
+            if (t == 2) x->lo_off_[d] = n;
         }
     }
     const RawW& R(const std::string& k) { return x->raw.at(k); }
@@ -440,14 +472,13 @@ struct Packer {
         l.wqkv_raw = raw(p + ".fn.fn.to_qkv.weight");                 // [384][C]: rows q | k | v
         l.wout_raw = raw(p + ".fn.fn.to_out.weight");
         {   // bf16 copy of the q | k | v rows in their native [N][K] layout (MFMA operands of the fused kernels)
-            for (int t = 0; t < 2; ++t) {
-                const int prec = t ? PREC_FP16 : PREC_BF16;
-                unsigned short* qb = (unsigned short*)alloc((384L * c + 1) / 2);
-                if (qb) launch_f32_to_lp(l.wqkv_raw, qb, 384L * c, prec, st);
-                l.wq_lp[t] = qb; l.wkv_lp[t] = qb ? qb + 128L * c : nullptr;
+            for (int t = 0; t < NSETS; ++t) {
+                unsigned short* qb = (unsigned short*)alloc((set_elems(t, 384L * c) + 1) / 2);
+                if (qb) pack3(t, l.wqkv_raw, 384L * c, qb, 384L * c, [&](const float* s, unsigned short* o, int prec) { launch_f32_to_lp(s, o, 384L * c, prec, st); });
+                l.wq_lp[t] = qb; l.wkv_lp[t] = qb ? qb + 128L * c : nullptr;        // (t == 2: the lo rows 384 c elements behind)
                 // the q rows again in MFMA fragment order (A operand of the tail's first GEMM: 1 KB contiguous per wave load)
-                void* qf = alloc((128L * c + 1) / 2);
-                if (qf) launch_pack_lp_frag_nk(l.wqkv_raw, qf, c, 128, prec, st);
+                unsigned short* qf = (unsigned short*)alloc((set_elems(t, 128L * c) + 1) / 2);
+                if (qf) pack3(t, l.wqkv_raw, 128L * c, qf, 128L * c, [&](const float* s, unsigned short* o, int prec) { launch_pack_lp_frag_nk(s, o, c, 128, prec, st); });
                 l.wq_frag[t] = qf;
             }
         }
@@ -498,7 +529,8 @@ extern "C" int dex_ctx_finalize(DexCtx* x, dex_stream_t stream) {
         if (!x->raw.at(k).loaded) return x->fail(DEX_ERR_STATE, "weight '%s' was never loaded", k.c_str());
     for (void* p : x->owned) hipFree(p);
     x->owned.clear();
-    for (int t = 0; t < 2; ++t) { x->lp_of_[t].clear(); x->frag_of_[t].clear(); }
+    for (int t = 0; t < 3; ++t) { x->lp_of_[t].clear(); x->frag_of_[t].clear(); }
+    x->lo_off_.clear();
     x->drop_graphs();
     const DexConfig& c = x->cfg;
     hipStream_t st = (hipStream_t)stream;
@@ -549,12 +581,13 @@ extern "C" int dex_ctx_finalize(DexCtx* x, dex_stream_t stream) {
         x->pos_w = wp;
     } else
     P.twin(x->pos_w, G, kp * kp * (hid / G), hid / G);
-    x->pos_wfrag[0] = x->pos_wfrag[1] = nullptr;
+    x->pos_wfrag[0] = x->pos_wfrag[1] = x->pos_wfrag[2] = nullptr;
     if (pos_conv_direct_supported(hid, G, kp, token_rows(c))) {
         const long kn_ = (long)kp * kp * (hid / G) * (hid / G);
-        for (int t = 0; t < 2; ++t) {
-            unsigned short* wf = (unsigned short*)P.alloc((G * kn_ + 1) / 2);
-            if (wf) for (int g = 0; g < G; ++g) launch_pack_lp_frag(x->pos_w + g * kn_, wf + g * kn_, kp * kp * (hid / G), hid / G, t ? PREC_FP16 : PREC_BF16, st);
+        for (int t = 0; t < Packer::NSETS; ++t) {
+            unsigned short* wf = (unsigned short*)P.alloc((Packer::set_elems(t, G * kn_) + 1) / 2);
+            if (wf) for (int g = 0; g < G; ++g)
+                P.pack3(t, x->pos_w + g * kn_, kn_, wf + g * kn_, G * kn_, [&](const float* s, unsigned short* o, int prec) { launch_pack_lp_frag(s, o, kp * kp * (hid / G), hid / G, prec, st); });
             x->pos_wfrag[t] = wf;
         }
     }
@@ -854,7 +887,9 @@ struct Runner {
         g.step = sp; g.unpatch_s = 0; g.unpatch_C = 0; g.B = P.d.B;
         return g;
     }
-    void gemm(const char* name, const IGemmP& g) {
+    void gemm(const char* name, const IGemmP& g_in) {
+        IGemmP g = g_in;
+        g.w_lo_off = g.Wbf ? x->lo_off(g.Wbf) : 0;        // split-weight mode: where the lo pack of this twin sits (0: a plain 16-bit operand)
         const double M = (double)g.Ho * g.Wo * g.B;
         const double fl = 2.0 * M * g.N * g.groups * g.K;
         const double by = 4.0 * (M * g.Cin * g.groups + M * g.N * g.groups * g.ksplit + (double)g.K * g.N * g.groups);
@@ -1026,7 +1061,7 @@ struct Runner {
         fl.outmask = mask; fl.outmask_ws = mask_ws;
         return fl;
     }
-    bool linattn_fused(int C) const { return x->lp() && (C == 64 || C == 128); }
+    bool linattn_fused(int C) const { return x->lp() && (C == 64 || C == 128) && linattn_fused_supported(C); }
     void linattn(const LinW& w, const StageBuf& s, const TD& X, float* out, int ldo, int ocoff, const LinKvCtxP* tail = nullptr, bool out_lp = false,
                  void* out2_lp = nullptr, int ldo2 = 0, int ocoff2 = 0) {
         const long npix = s.npix; const int B = P.d.B;
@@ -1171,7 +1206,7 @@ struct Runner {
                 const bool q64_ok = q64_env != KNOB_UNSET ? q64_env != 0 : attention_q64_regime(N, B);
                 const bool separate = sep_env != KNOB_UNSET ? sep_env != 0 : ((batch_regime && N >= 1024) || q64_ok);
                 const bool q64 = separate && q64_ok;
-                int ks = 1;
+                int ks = 1, tail_row0 = 0, tail_ks = 0;
                 bool o_lp = false;
                 if (separate) {
                     const long blocks = (long)((N + 31) / 32) * 2 * B;
@@ -1185,10 +1220,18 @@ struct Runner {
                     // (DEX_LP_INTER=0 keeps fp32)
                     o_lp = (batch_regime || q64) && ks == 1 && lp_inter_cur && dit_rowchain64_form(N, B, 0);
                     ad.o_lp = o_lp ? 1 : 0;
+                    // tail split of the 64-query form (attention_q64.hip): whole units for the first query groups, a key split for the
+                    // last ones, so that a chip-filling round of long units is followed by a round of short ones; the 64-row chain merges
+                    // the tail rows' partials (O slots 1.., fp32) and reads the other rows as before.  DEX_ATTN_Q64_TAIL=0 switches it off.
+                    if (q64 && ks == 1 && dit_rowchain64_form(N, B, 0) && knob_or("DEX_ATTN_Q64_TAIL", 1) != 0) {
+                        int pks = 1, tg = 0, tk = 1;
+                        attention_q64_plan(N, B, att_split_cap((long)B * N), &pks, &tg, &tk);
+                        if (pks == 1 && tk > 1) { ad.tail_g = tg; ad.tail_ks = tk; ad.ml = P.att_ml; tail_row0 = tg * 256; tail_ks = tk; }
+                    }
                     run("dit_attention", 4.0 * B * (double)N * N * hid, 2.0 * 3 * B * N * hid + (o_lp ? 2.0 : 4.0) * B * N * hid * ks,
                         [&] { if (q64) launch_attention_q64(ad, x->precision, st); else launch_attention_direct(ad, x->precision, st); });
                 }
-                ch.attn_inline = separate ? 0 : 1; ch.o_lp = o_lp ? 1 : 0;
+                ch.attn_inline = separate ? 0 : 1; ch.o_lp = o_lp ? 1 : 0; ch.tail_row0 = tail_row0; ch.tail_ks = tail_ks;
                 const bool last = k + 1 == c.dit_depth;
                 ch.O = P.ao; ch.ksplit = ks; ch.o_sstride = (long)B * N * hid; ch.ml = P.att_ml;
                 ch.Wp = x->frag_of().at(w.wproj); ch.W1 = x->frag_of().at(w.wfc1); ch.W2 = x->frag_of().at(w.wfc2);
@@ -1612,6 +1655,7 @@ int dex_denoise_once(DexCtx* x, const DexDenoiseArgs* da, dex_stream_t stream) {
     if (!da->x_dev) return x->fail(DEX_ERR_ARG, "x_dev is null");
     const KnobSnapshot knobs;
     const KnobScope knob_scope(&knobs);
+    const WsplitScope wsplit_scope(x->precision == DEX_PREC_FP16X2);
     xcd_map_probe();
     x->last_xerr = nullptr;
     hipStream_t st = (hipStream_t)stream;
@@ -1635,6 +1679,7 @@ int dex_sample(DexCtx* x, const DexSampleArgs* a, dex_stream_t stream) {
     if (a->solver != DEX_SOLVER_EULER && a->solver != DEX_SOLVER_HEUN) return x->fail(DEX_ERR_ARG, "solver must be DEX_SOLVER_EULER or DEX_SOLVER_HEUN (edm.py:107)");
     const KnobSnapshot knobs;            // one reading of every knob for this call (graph-cache key below)
     const KnobScope knob_scope(&knobs);
+    const WsplitScope wsplit_scope(x->precision == DEX_PREC_FP16X2);
     xcd_map_probe();                    // (once per device, before any capture; normally already done by dex_ctx_create)
     x->last_xerr = nullptr;             // set again by this call if it uses in-launch hand-offs (dex_call_status)
     hipStream_t st = (hipStream_t)stream;

@@ -253,13 +253,13 @@ __device__ __forceinline__ void store_qkv_tile_d(const DitChainP& p, const f32x1
 // maxima).  Up to RC_MAX_SPLITS splits, four at a time (16 loads in flight per round; one round = the <= 4 splits of the 32-query
 // attention forms, same operation order as before; the 64-query form takes up to 8 at long-form shapes).
 constexpr int RC_MAX_SPLITS = 8;
-__device__ __forceinline__ void rc_merge_splits(const DitChainP& p, const float* src, int b, int n, float4 (&v)[4]) {
+__device__ __forceinline__ void rc_merge_splits(const DitChainP& p, const float* src, int b, int n, float4 (&v)[4], int ksplit) {
     float w[2][RC_MAX_SPLITS], inv[2];
     {
         float2 st[RC_MAX_SPLITS][2];
 #pragma unroll
         for (int s_ = 0; s_ < RC_MAX_SPLITS; ++s_)
-            if (s_ < p.ksplit) {
+            if (s_ < ksplit) {
 #pragma unroll
                 for (int hd = 0; hd < 2; ++hd)
                     st[s_][hd] = *reinterpret_cast<const float2*>(p.ml + ((((long)s_ * p.B + b) * p.heads + hd) * p.rows_per_batch + n) * 2);
@@ -268,12 +268,12 @@ __device__ __forceinline__ void rc_merge_splits(const DitChainP& p, const float*
         for (int hd = 0; hd < 2; ++hd) {
             float mx = -INFINITY;
 #pragma unroll
-            for (int s_ = 0; s_ < RC_MAX_SPLITS; ++s_) if (s_ < p.ksplit) mx = fmaxf(mx, st[s_][hd].x);
+            for (int s_ = 0; s_ < RC_MAX_SPLITS; ++s_) if (s_ < ksplit) mx = fmaxf(mx, st[s_][hd].x);
             float wsum = 0.f;
 #pragma unroll
             for (int s_ = 0; s_ < RC_MAX_SPLITS; ++s_) {
                 w[hd][s_] = 0.f;
-                if (s_ < p.ksplit) { w[hd][s_] = st[s_][hd].y * exp2f(st[s_][hd].x - mx); wsum += w[hd][s_]; }
+                if (s_ < ksplit) { w[hd][s_] = st[s_][hd].y * exp2f(st[s_][hd].x - mx); wsum += w[hd][s_]; }
             }
             inv[hd] = 1.f / wsum;
         }
@@ -282,11 +282,11 @@ __device__ __forceinline__ void rc_merge_splits(const DitChainP& p, const float*
     for (int q = 0; q < 4; ++q) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int r0 = 0; r0 < RC_MAX_SPLITS; r0 += 4) {
-        if (r0 < p.ksplit) {                                  // (uniform)
+        if (r0 < ksplit) {                                  // (uniform)
             float4 pv[4][4];
 #pragma unroll
             for (int s_ = 0; s_ < 4; ++s_)
-                if (r0 + s_ < p.ksplit) {
+                if (r0 + s_ < ksplit) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) pv[s_][q] = *reinterpret_cast<const float4*>(src + (long)(r0 + s_) * p.o_sstride + q * 64);
                 }
@@ -294,7 +294,7 @@ __device__ __forceinline__ void rc_merge_splits(const DitChainP& p, const float*
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int s_ = 0; s_ < 4; ++s_)
-                    if (r0 + s_ < p.ksplit) {
+                    if (r0 + s_ < ksplit) {
                         const float ws = w[q >> 1][r0 + s_];
                         v[q].x = fmaf(ws, pv[s_][q].x, v[q].x); v[q].y = fmaf(ws, pv[s_][q].y, v[q].y);
                         v[q].z = fmaf(ws, pv[s_][q].z, v[q].z); v[q].w = fmaf(ws, pv[s_][q].w, v[q].w);
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(src + q * 64);
         } else {
-            rc_merge_splits(p, src, b, n, v);
+            rc_merge_splits(p, src, b, n, v, p.ksplit);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -678,7 +678,8 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain64_kernel(const DitCha
             const int n = min(n0 + row, N - 1);
             const float* src = p.O + (mb + n) * RC_H + seg * 4;
             float4 v[4];
-            if (p.o_lp) {              // (uniform) already in the operand type: straight into the A tile
+            const bool tail = p.tail_ks > 1 && n0 >= p.tail_row0;        // (uniform) rows of the attention's tail-split query groups
+            if (p.o_lp && !tail) {     // (uniform) already in the operand type: straight into the A tile
                 const u16* sh_ = reinterpret_cast<const u16*>(p.O) + (mb + n) * RC_H + seg * 4;
                 uint2 o4[4];
 #pragma unroll
@@ -687,11 +688,13 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain64_kernel(const DitCha
                 for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(As + row * A_LD + q * 64 + seg * 4) = o4[q];
                 continue;
             }
-            if (p.ksplit <= 1) {
+            if (tail) {
+                rc_merge_splits(p, src + p.o_sstride, b, n, v, p.tail_ks);        // partial slots 1 .. tail_ks
+            } else if (p.ksplit <= 1) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(src + q * 64);
             } else {
-                rc_merge_splits(p, src, b, n, v);
+                rc_merge_splits(p, src, b, n, v, p.ksplit);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1331,6 +1334,10 @@ constexpr size_t RC_LDS_CLUSTER = RC_LDS_CLUSTER_CHAIN > RC_LDS_ATTN ? RC_LDS_CL
 
 // the cluster form needs every workgroup of the launch resident at once (<= one per CU, 256 CUs): B x tiles x 4 <= 256
 bool dit_rowchain_cluster_form(int rows_per_batch, int B) {
+#if defined(DEX_LP_WSPLIT) && !defined(DEX_WS_HAVE_RCC)
+    return false;            // no split-weight form yet (lp_config.h)
+#endif
+   
     const int on = knob_or("DEX_DIT_CLUSTER", 1);       // (A/B tests flip it)
     return on && (long)B * ((rows_per_batch + RC_ROWS - 1) / RC_ROWS) * DIT_CLUSTER <= 256;
 }
@@ -1342,8 +1349,16 @@ bool dit_rowchain_cluster_local_fits(int rows_per_batch, int B) {
     return on && dit_rowchain_cluster_form(rows_per_batch, B) && (tiles + 7) / 8 * 8 * DIT_CLUSTER <= 256;
 }
 
-bool dit_rowchain_supported(int hidden, int mlp_hidden) { return hidden == RC_H && mlp_hidden == RC_MLP; }
+bool dit_rowchain_supported(int hidden, int mlp_hidden) {
+#if defined(DEX_LP_WSPLIT) && !defined(DEX_WS_HAVE_RC)
+    return false;            // no split-weight form yet (lp_config.h)
+#endif
+    return hidden == RC_H && mlp_hidden == RC_MLP; }
 bool dit_rowchain64_form(int rows_per_batch, int B, int attn_inline) {
+#if defined(DEX_LP_WSPLIT) && !defined(DEX_WS_HAVE_RC64)
+    return false;            // no split-weight form yet (lp_config.h)
+#endif
+   
     static const int m64 = getenv("DEX_ROWCHAIN64") ? atoi(getenv("DEX_ROWCHAIN64")) : 1;
     const long wg32 = (long)B * ((rows_per_batch + RC_ROWS - 1) / RC_ROWS);
     return m64 && !attn_inline && (m64 == 2 || wg32 >= 768);

@@ -17,7 +17,11 @@ typedef unsigned short u16;
 // one K tile of global loads into a register slot: raw fp32 activations (addresses clamped, validity folded into
 // the mask factor) and bf16 weights; nothing here waits on memory
 template <int BN, int BK, bool PT, int AP, int RPP, int BP, bool ALP = false>
-__device__ __forceinline__ void igemm_load_tile(const IGemmP& p, float4 (&fa)[AP][2], float (&fm)[AP], float (&fo)[AP], uint4& rb0, uint4& rb1, int k0, bool live, int tk8, int trow,
+__device__ __forceinline__ void igemm_load_tile(const IGemmP& p, float4 (&fa)[AP][2], float (&fm)[AP], float (&fo)[AP], uint4& rb0, uint4& rb1,
+#ifdef DEX_LP_WSPLIT
+                                                uint4& rl0, uint4& rl1,      // the lo halves of the same weights (p.w_lo_off elements behind)
+#endif
+                                                int k0, bool live, int tk8, int trow,
                                                 const int (&bh)[AP], const int (&bw)[AP], unsigned mvbits,
                                                 const float* Ab, const float* mrow, int mws, const u16* Wb, int n0) {
     const int kthr = PT ? k0 + tk8 : k0;                     // tap resolution per thread or per tile
@@ -39,6 +43,10 @@ __device__ __forceinline__ void igemm_load_tile(const IGemmP& p, float4 (&fa)[AP
     }
     if (BN >= RPP || trow < BN) rb0 = *reinterpret_cast<const uint4*>(Wb + (long)(n0 + trow) * p.K + k0 + tk8);
     if constexpr (BP > 1) rb1 = *reinterpret_cast<const uint4*>(Wb + (long)(n0 + trow + RPP) * p.K + k0 + tk8);
+#ifdef DEX_LP_WSPLIT
+    if (BN >= RPP || trow < BN) rl0 = *reinterpret_cast<const uint4*>(Wb + p.w_lo_off + (long)(n0 + trow) * p.K + k0 + tk8);
+    if constexpr (BP > 1) rl1 = *reinterpret_cast<const uint4*>(Wb + p.w_lo_off + (long)(n0 + trow + RPP) * p.K + k0 + tk8);
+#endif
 }
 
 // PT: the 8-element chunk of every thread resolves its own tap (k -> (kh,kw,c)); needed when Cin < BK, e.g. the
@@ -63,6 +71,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     static_assert(MT >= 1 && AP >= 1, "tile");
     __shared__ __attribute__((aligned(16))) u16 As[BM * LDS_LD];
     __shared__ __attribute__((aligned(16))) u16 Bs[BN * LDS_LD];
+#ifdef DEX_LP_WSPLIT
+    __shared__ __attribute__((aligned(16))) u16 Bl[BN * LDS_LD];       // lo halves of the weight tile: a second MFMA per product
+    const bool has_lo = p.w_lo_off != 0;                               // (a 16-bit operand built at run time has none: one MFMA)
+#define WS_RL(d) , rl0[d], rl1[d]
+#else
+#define WS_RL(d)
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
@@ -109,6 +124,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     uint4 rb0[D], rb1[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) { rb0[d] = make_uint4(0, 0, 0, 0); rb1[d] = rb0[d]; }
+#ifdef DEX_LP_WSPLIT
+    uint4 rl0[D], rl1[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { rl0[d] = make_uint4(0, 0, 0, 0); rl1[d] = rl0[d]; }
+#endif
     static_assert(BP <= 2, "B passes");
     f32x16 acc[MT];
 #pragma unroll
@@ -122,7 +142,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     const int nkt_pad = (nkt + D - 1) / D * D;
 #pragma unroll
     for (int d = 0; d < D; ++d)
-        igemm_load_tile<BN, BK, PT, AP, RPP, BP, ALP>(p, fa[d], fm[d], fo[d], rb0[d], rb1[d], kbeg + min(d, nkt - 1) * BK, d < nkt, tk8, trow, bh, bw, mvbits, Ab, mrow, mws, Wb, n0);
+        igemm_load_tile<BN, BK, PT, AP, RPP, BP, ALP>(p, fa[d], fm[d], fo[d], rb0[d], rb1[d] WS_RL(d), kbeg + min(d, nkt - 1) * BK, d < nkt, tk8, trow, bh, bw, mvbits, Ab, mrow, mws, Wb, n0);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll(NKT ? (NKT + D - 1) / D : 1)
     for (int kt0 = 0; kt0 < nkt_pad; kt0 += D) {
@@ -152,22 +172,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             }
             if (BN >= RPP || trow < BN) *reinterpret_cast<uint4*>(Bs + trow * LDS_LD + tk8) = rb0[d];
             if constexpr (BP > 1) *reinterpret_cast<uint4*>(Bs + (trow + RPP) * LDS_LD + tk8) = rb1[d];
+#ifdef DEX_LP_WSPLIT
+            if (BN >= RPP || trow < BN) *reinterpret_cast<uint4*>(Bl + trow * LDS_LD + tk8) = rl0[d];
+            if constexpr (BP > 1) *reinterpret_cast<uint4*>(Bl + (trow + RPP) * LDS_LD + tk8) = rl1[d];
+#endif
             lds_barrier();
-            igemm_load_tile<BN, BK, PT, AP, RPP, BP, ALP>(p, fa[d], fm[d], fo[d], rb0[d], rb1[d], kbeg + min(kt + D, nkt - 1) * BK, kt + D < nkt, tk8, trow, bh, bw, mvbits, Ab, mrow, mws, Wb, n0);
+            igemm_load_tile<BN, BK, PT, AP, RPP, BP, ALP>(p, fa[d], fm[d], fo[d], rb0[d], rb1[d] WS_RL(d), kbeg + min(kt + D, nkt - 1) * BK, kt + D < nkt, tk8, trow, bh, bw, mvbits, Ab, mrow, mws, Wb, n0);
             __builtin_amdgcn_sched_barrier(0);     // the scheduler otherwise sinks these loads down to their first use
             const u16* ap = As + (wm * (MT * 32) + i) * LDS_LD + hh * 8;
             const u16* bp = Bs + (wn * 32 + i) * LDS_LD + hh * 8;
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
                 const lp8 bf = *reinterpret_cast<const lp8*>(bp + ks * 16);
+#ifdef DEX_LP_WSPLIT
+                const lp8 bl = *reinterpret_cast<const lp8*>(bp + (Bl - Bs) + ks * 16);
+#endif
 #pragma unroll
                 for (int t = 0; t < MT; ++t) {
                     const lp8 af = *reinterpret_cast<const lp8*>(ap + t * 32 * LDS_LD + ks * 16);
                     acc[t] = DEX_MFMA_LP(af, bf, acc[t], 0, 0, 0);
+#ifdef DEX_LP_WSPLIT
+                    if (has_lo) acc[t] = DEX_MFMA_LP(af, bl, acc[t], 0, 0, 0);
+#endif
                 }
             }
         }
     }
+#undef WS_RL
     igemm_epilogue<MT, CLP>(p, acc, m0, n0, wm * (MT * 32), wn * 32, lane, b, g, s, M, oh0, ow0);
 }
 
@@ -186,6 +217,10 @@ __global__ __launch_bounds__(256) void igemm_lp_ss_kernel(const IGemmP p) {
     extern __shared__ __attribute__((aligned(16))) u16 smem_ss[];
     u16* As = smem_ss;
     u16* Bs = smem_ss + BM * LDS_LD;
+#ifdef DEX_LP_WSPLIT
+    u16* Bl = Bs + BN * LDS_LD;                              // lo halves of the weight tile (launcher: + BN rows of LDS)
+    const bool has_lo = p.w_lo_off != 0;
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
@@ -210,6 +245,15 @@ __global__ __launch_bounds__(256) void igemm_lp_ss_kernel(const IGemmP p) {
         const int n = it / KC, c8 = (it % KC) * 8;
         br[j] = *reinterpret_cast<const uint4*>(Wb + (long)(n0 + n) * K + c8);
     }
+#ifdef DEX_LP_WSPLIT
+    uint4 bl_[BIT];
+#pragma unroll
+    for (int j = 0; j < BIT; ++j) {
+        const int it = tid + 256 * j;
+        const int n = it / KC, c8 = (it % KC) * 8;
+        bl_[j] = *reinterpret_cast<const uint4*>(Wb + p.w_lo_off + (long)(n0 + n) * K + c8);
+    }
+#endif
 #pragma unroll
     for (int a0 = 0; a0 < AIT; a0 += ABATCH) {
         float4 f0[ABATCH], f1[ABATCH];
@@ -244,6 +288,9 @@ __global__ __launch_bounds__(256) void igemm_lp_ss_kernel(const IGemmP p) {
                 const int it = tid + 256 * j;
                 const int n = it / KC, c8 = (it % KC) * 8;
                 *reinterpret_cast<uint4*>(Bs + n * LDS_LD + c8) = br[j];
+#ifdef DEX_LP_WSPLIT
+                *reinterpret_cast<uint4*>(Bl + n * LDS_LD + c8) = bl_[j];
+#endif
             }
         }
 #pragma unroll
@@ -291,10 +338,16 @@ __global__ __launch_bounds__(256) void igemm_lp_ss_kernel(const IGemmP p) {
 #pragma unroll
     for (int ks = 0; ks < K / 16; ++ks) {
         const lp8 bf = *reinterpret_cast<const lp8*>(bp + ks * 16);
+#ifdef DEX_LP_WSPLIT
+        const lp8 bl = *reinterpret_cast<const lp8*>(bp + BN * LDS_LD + ks * 16);
+#endif
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             const lp8 af = *reinterpret_cast<const lp8*>(ap + t * 32 * LDS_LD + ks * 16);
             acc[t] = DEX_MFMA_LP(af, bf, acc[t], 0, 0, 0);
+#ifdef DEX_LP_WSPLIT
+            if (has_lo) acc[t] = DEX_MFMA_LP(af, bl, acc[t], 0, 0, 0);
+#endif
         }
     }
     igemm_epilogue<MT>(p, acc, m0, n0, wm * (MT * 32), wn * 32, lane, b, 0, 0, M, oh0, ow0);
@@ -496,7 +549,11 @@ static bool nwalk_eligible(const IGemmP& p) {
     const long wgs = (long)((p.Ho * p.Wo + 63) / 64) * p.B;
     return p.N / 64 >= 8 && (mode == 2 || wgs >= 256);
 }
-bool igemm_nwalk_form(const IGemmP& p) { return nwalk_eligible(p); }
+bool igemm_nwalk_form(const IGemmP& p) {
+#if defined(DEX_LP_WSPLIT) && !defined(DEX_WS_HAVE_NWALK)
+    return false;            // no split-weight form yet (lp_config.h)
+#endif
+    return nwalk_eligible(p); }
 static void launch_nwalk(const IGemmP& p, hipStream_t st) {
     constexpr int K = 256;
     const size_t lds = (size_t)(64 + 64) * (K + 8) * sizeof(u16);
@@ -519,7 +576,11 @@ static void launch_nwalk(const IGemmP& p, hipStream_t st) {
 
 template <int K>
 static void launch_ss(const IGemmP& p, hipStream_t st) {
+#ifdef DEX_LP_WSPLIT
+    const size_t lds = (size_t)(64 + 2 * 64) * (K + 8) * sizeof(u16);        // + the lo halves of the weight tile
+#else
     const size_t lds = (size_t)(64 + 64) * (K + 8) * sizeof(u16);
+#endif
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_lp_ss_kernel<64, 64, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -536,6 +597,9 @@ static bool ss_eligible(const IGemmP& p) {
     if (p.a_lp && (p.ln_shift || p.KH != 1 || p.KW != 1 || (p.Cin % 8) != 0)) return false;      // 16-bit A: plain 1x1 rows only
     if (p.ksplit != 1 || p.groups != 1 || (p.N % 64) != 0) return false;
     if (p.K != 64 && p.K != 128 && p.K != 256 && p.K != 512) return false;
+#ifdef DEX_LP_WSPLIT
+    if (p.K == 512) return false;             // A + hi + lo tiles of 520 columns do not fit the LDS
+#endif
     const long blocks = (long)((p.Ho * p.Wo + 63) / 64) * (p.N / 64) * p.B;
     // (K <= 128 - the DEX TV adaptor's 1x1 convs at batch size: one round trip instead of a two-tile loop, 124 -> 114 us for the pair)
     return blocks <= (p.K <= 128 ? 16384 : 4096) || p.ln_shift != nullptr;
@@ -545,7 +609,7 @@ bool igemm_lp_io_supported(int Cin, int K, int N, int ksplit) { return Cin % 64 
 
 void launch_igemm_lp(const IGemmP& p, hipStream_t st) {
     const int M = p.Ho * p.Wo;
-    if (nwalk_eligible(p)) { launch_nwalk(p, st); return; }
+    if (DEX_LP_NS::igemm_nwalk_form(p)) { launch_nwalk(p, st); return; }
     if (ss_eligible(p)) {
         if (p.K == 64) launch_ss<64>(p, st);
         else if (p.K == 128) launch_ss<128>(p, st);

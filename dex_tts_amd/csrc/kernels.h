@@ -35,7 +35,10 @@ extern thread_local const char* g_last_symbol;
 // Precision modes (== DexPrecision of include/dex_amd.h).  The reduced-precision kernels exist twice — namespace dex::bf16
 // and dex::f16, the same sources compiled for either operand type (lp_config.h) — and the launch functions below that
 // take a `precision` pick the namespace (lp_dispatch.hip).
-constexpr int PREC_FP32 = 0, PREC_BF16 = 1, PREC_FP16 = 2;
+constexpr int PREC_FP32 = 0, PREC_BF16 = 1, PREC_FP16 = 2, PREC_FP16X2 = 3;      // FP16X2: fp16 operands, weights as hi + lo (lp_config.h)
+inline bool prec_wsplit(int precision) { return precision == PREC_FP16X2; }
+// the mode of the C-ABI call being built on this thread (set by dex_api.hip): the shape predicates of lp_dispatch.hip answer for it
+extern thread_local bool g_lp_wsplit;
 inline bool prec_is_lp(int precision) { return precision != PREC_FP32; }
 
 // ------------------------------------------------------------------------------------------------
@@ -50,6 +53,7 @@ struct IGemmP {
     int Ho, Wo;
     const float* W; long w_bstride; long w_gstride;   // packed [K][N] (per group), optional per-batch
     const void* Wbf;                                   // bf16 copy, packed [N][K] (K contiguous), or null
+    long w_lo_off = 0;                                 // split-weight mode (PREC_FP16X2): elements from a weight of Wbf to its lo half, 0 = none
     int N, K, ksplit, groups;
     const float* bias; long bias_bstride;              // [groups*N] or null; optional per-batch stride
     float* C; int ldc; long c_bstride; long c_sstride; int c_coff;
@@ -233,6 +237,7 @@ struct LinOut2P { const float* X; int ldx; int x_coff; long xb; int npix; int C;
                   int x_lp; };      // 1: X is stored in the mode's 16-bit type [npix][C] (throughput form only; written by LinKvCtxP::xout_lp)
 void launch_linattn_out2(const LinOut2P& p, int precision, hipStream_t st);
 bool linattn_out2_lp_out_supported(int npix, int B);
+bool linattn_fused_supported(int C);          // the fused linear attention exists for this mode (lp_dispatch.hip: false in a build without a split-weight form)
 
 // Depthwise patch-embed conv + SiLU (dit.py:57-58), channels-last, zero padding incl. right pad to patch multiple.
 struct DwConvP { const float* X; int ldx; long xb; int Hi, Wi, C; int k, s, pad; const float* Wd; const float* bd;
@@ -282,7 +287,8 @@ struct DitChainP { const float* O; int ksplit; long o_sstride; const float* ml; 
                    int o_lp;                                // O is stored in the mode's 16-bit type [M][hidden] (ksplit == 1, 64-row form; AttnDirectP::o_lp)
                    int xcd_map;                             // set by the launcher: row tiles of batch element b run on XCD b % 8 (in-kernel attention, B % 8 == 0)
                    int xlocal;                              // 1: the members of a cluster share an XCD (hand-offs through its L2; grid padded to rounds of 8 clusters)
-                   int xdrop; };                            // tests only (DEX_DEBUG_DROP_HANDOFF): 1 member 3 never raises its flags -> the peers' waits time out; 2 L2-scope hand-offs across XCDs
+                   int xdrop;
+                   int tail_row0 = 0, tail_ks = 0; };      // 64-row form: rows from tail_row0 on are merged from tail_ks fp32 partials in O slots 1.. (AttnDirectP::tail_g); 0 / 1 = off                            // tests only (DEX_DEBUG_DROP_HANDOFF): 1 member 3 never raises its flags -> the peers' waits time out; 2 L2-scope hand-offs across XCDs
 // cluster form of the row chain: workgroups per 32-row tile, bytes of exchange slab / flag words per tile, and whether a launch
 // of B x N rows takes it (all workgroups co-resident: <= one per CU)
 constexpr int DIT_CLUSTER = 4;
@@ -296,12 +302,14 @@ bool dit_rowchain_supported(int hidden, int mlp_hidden);
 // straight from global memory.  O: fp32 [ksplit][B][N][256] partials + ml (merged by the next row chain launch).
 struct AttnDirectP { const void *Qh, *Kh, *Vt; int N, Npad, B; float* O; long o_sstride; float* ml; int ksplit; long long* dbg;
                      int o_lp;              // O (ksplit == 1, shared-ring kernel) is written in the mode's 16-bit type: its reader, the 64-row chain, rounds it so anyway (DitChainP::o_lp)
-                     int xcd_map; };        // set by the launcher (shared-ring kernel): 1-D grid, the query groups of one (element, split, head) share an XCD
+                     int xcd_map;           // set by the launcher (shared-ring kernel): 1-D grid, the query groups of one (element, split, head) share an XCD
+                     int tail_g = 0, tail_ks = 0; };   // 64-query form, ksplit == 1: query groups (256 rows) from tail_g on are split tail_ks ways (fp32 slots 1.., ml); 0 / 1 = off
 void launch_attention_direct(const AttnDirectP& p, int precision, hipStream_t st);
 bool attention_direct_batch_regime(int N, int B);     // shared-ring kernel (many query tiles) vs key-splitting waves (few)
 int attention_direct_ksplit(int N, int B);             // key split the batch regime wants for an even load
 void launch_attention_q64(const AttnDirectP& p, int precision, hipStream_t st);     // attention_q64.hip: the batch / long-form form (64 queries per wave)
 int attention_q64_ksplit(int N, int B, int max_split);
+void attention_q64_plan(int N, int B, int max_split, int* ks, int* tail_g, int* tail_ks);
 void launch_dit_rowchain(const DitChainP& p, int precision, hipStream_t st);
 void launch_pack_lp_frag(const float* src, void* dst, int K, int N, int precision, hipStream_t st);
 void launch_pack_lp_frag_nk(const float* src, void* dst, int K, int N, int precision, hipStream_t st);   // source [N][K]
@@ -338,6 +346,7 @@ void launch_step_inc(int* step, hipStream_t st);
 void launch_iota(int* dst, int n, hipStream_t st);
 void launch_permute4(const float* src, float* dst, int d0, int d1, int d2, int d3, int p0, int p1, int p2, int p3,
                      hipStream_t st);   // dst = src.permute(p0..p3).contiguous()
+void launch_f32_residual_lp(const float* src, float* dst, long n, int precision, hipStream_t st);   // src - float(lp(src)): the lo half of a split weight
 void launch_f32_to_lp(const float* src, void* dst, long n, int precision, hipStream_t st);        // fp32 -> bf16 / fp16, round to nearest even
 void launch_pack_lp_nk(const float* src, void* dst, int K, int N, int precision, hipStream_t st);  // fp32 [K][N] -> low precision [N][K]
 void launch_spk_plane(const float* spk_out, float* plane, int B, int F, hipStream_t st);

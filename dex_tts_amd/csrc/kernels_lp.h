@@ -18,6 +18,7 @@ void launch_conv3x3_stream(const Conv3P& p, int tiles_per_wg, hipStream_t st);
 bool conv3x3_regw_form(const Conv3P& p);                 // weights-in-registers strip form (conv3x3_regw.hip) takes this launch
 void launch_conv3x3_regw(const Conv3P& p, hipStream_t st);
 bool linattn_out2_lp_out_supported(int npix, int B);
+bool linattn_fused_supported(int C);
 bool conv3x3_plain_lp_in_supported(int H, int W, int B, int Cin, int Cout);
 bool conv3x3_res2_form(int H, int W, int B);          // the ping-pong strip form (the only one that implements Conv3P::res2_*) takes this grid
 // implicit GEMM on the low-precision MFMA (igemm_bf16.hip)
@@ -39,6 +40,7 @@ int attention_direct_ksplit(int N, int B);
 // 64-queries-per-wave form (attention_q64.hip): 4 waves x 64 queries, persistent work units, up to max_split key splits
 void launch_attention_q64(const AttnDirectP& p, hipStream_t st);
 int attention_q64_ksplit(int N, int B, int max_split);
+void attention_q64_plan(int N, int B, int max_split, int* ks, int* tail_g, int* tail_ks);
 // DiT row chain (dit_rowchain.hip) and its weight packing
 bool dit_rowchain_supported(int hidden, int mlp_hidden);
 bool dit_rowchain64_form(int rows_per_batch, int B, int attn_inline);

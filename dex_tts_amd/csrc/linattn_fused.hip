@@ -620,6 +620,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, C == 64 
         }
     }
 }
+bool linattn_fused_supported(int C) {
+#if defined(DEX_LP_WSPLIT) && !defined(DEX_WS_HAVE_LINATTN)
+    return false;            // no split-weight form yet (lp_config.h)
+#endif
+    return C == 64 || C == 128;
+}
 bool linattn_out2_lp_out_supported(int npix, int B) { return (long)((npix + 127) / 128) * B >= 2048; }       // == the throughput form below
 void launch_linattn_out2(const LinOut2P& p, hipStream_t st) {
     dim3 grid((p.npix + 127) / 128, p.B);

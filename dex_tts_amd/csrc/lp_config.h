@@ -9,6 +9,12 @@
 // (bench tools that compile a kernel file of their own next to the library's copy: a namespace - and so a kernel symbol - of their own;
 // two modules registering one kernel name resolve to whichever the runtime saw first)
 #define DEX_LP_NS DEX_LP_NS_OVERRIDE
+#elif defined(DEX_LP_WSPLIT)
+// third build: fp16 operands with every WEIGHT as hi + lo (w = fp16(w) + fp16(w - fp16(w)), two MFMAs per product, activations rounded
+// once) - the "fp16x2" mode: the weight rounding is what separates the fp16 mode from the fp32 reference over a 50-step sampler
+// (oracle/lowp_emulate.py).  Compiled with -DDEX_LP_F16 -DDEX_LP_WSPLIT; a packed weight twin is the hi pack followed by the lo pack
+// in the same layout.  Kernels without a split form answer false from their shape predicates in this namespace.
+#define DEX_LP_NS f16w
 #elif defined(DEX_LP_F16)
 #define DEX_LP_NS f16
 #else

@@ -106,6 +106,10 @@ __global__ __launch_bounds__(256) void patch_embed_fused_kernel(const DwConvP p,
 }
 
 bool patch_embed_fused_supported(int k, int C, int hid, long ntok) {
+#if defined(DEX_LP_WSPLIT) && !defined(DEX_WS_HAVE_PE)
+    return false;            // no split-weight form yet (lp_config.h)
+#endif
+   
     return (k == 3 || k == 7) && (C == 64 || C == 128) && hid % 128 == 0 && (ntok * (C / 4) + 255) / 256 < 1024;      // the small-grid regime of launch_dwconv_silu
 }
 

@@ -175,6 +175,10 @@ __global__ __launch_bounds__(256) void pos_conv_direct_kernel(const PosConvP p) 
 }
 
 bool pos_conv_direct_supported(int hid, int groups, int kernel, int Hf) {
+#if defined(DEX_LP_WSPLIT) && !defined(DEX_WS_HAVE_POS)
+    return false;            // no split-weight form yet (lp_config.h)
+#endif
+   
     return groups > 0 && hid / groups == CG && kernel == KP && Hf >= 1;
 }
 

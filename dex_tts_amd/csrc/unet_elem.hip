@@ -751,6 +751,18 @@ void launch_f32_to_lp(const float* src, void* dst, long n, int precision, hipStr
     long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(f32_to_lp_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, (unsigned short*)dst, n, precision);
 }
+// what rounding to the 16-bit type loses: dst = src - float(lp(src)) (the "lo" half of a split weight, packed like the weight itself)
+__global__ void f32_residual_lp_kernel(const float* src, float* dst, long n, int kind) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const unsigned h = pack2_kind(src[i], 0.f, kind) & 0xffffu;
+        const float hf = kind == 2 ? (float)__builtin_bit_cast(_Float16, (unsigned short)h) : __uint_as_float(h << 16);
+        dst[i] = src[i] - hf;
+    }
+}
+void launch_f32_residual_lp(const float* src, float* dst, long n, int precision, hipStream_t st) {
+    long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(f32_residual_lp_kernel, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, n, precision);
+}
 // fp32 [K][N] -> low precision [N][K] (the MFMA GEMMs' weight operand: K contiguous)
 __global__ void pack_lp_nk_kernel(const float* src, unsigned short* dst, int K, int N, int kind) {
     const long total = (long)K * N;

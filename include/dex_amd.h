@@ -42,7 +42,10 @@ typedef enum {
 typedef enum { DEX_VARIANT_GEDEX = 0, DEX_VARIANT_DEX = 1 } DexVariant;
 /* Arithmetic of the contractions: fp32 = exact-fp32 MFMA (the reference's arithmetic, the parity mode); bf16 / fp16 = operands
  * rounded to that type on the MFMA, fp32 accumulation, fp32 norms / softmax state / residual streams. */
-typedef enum { DEX_PREC_FP32 = 0, DEX_PREC_BF16 = 1, DEX_PREC_FP16 = 2 } DexPrecision;
+typedef enum { DEX_PREC_FP32 = 0, DEX_PREC_BF16 = 1, DEX_PREC_FP16 = 2,
+               DEX_PREC_FP16X2 = 3    /* fp16 operands with every weight as hi + lo (two MFMAs per product): the fast mode inside the
+                                       * fp32-grade sampler bound */
+} DexPrecision;
 /* ablation_sampler's solver argument (edm.py:107). */
 typedef enum { DEX_SOLVER_EULER = 0, DEX_SOLVER_HEUN = 1 } DexSolver;
 

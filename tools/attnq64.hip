@@ -136,6 +136,51 @@ int main(int argc, char** argv) {
             hipFree(dbg);
 #endif
         }
+        // ---- tail split: whole units (slot 0) for the query groups below tail_g, a tail_ks-way key split (slots 1.., ml) for the rest
+        {
+            const int ng = (nt32 + 7) / 8;
+            int pks = 1, ptg = ng, ptk = 1;
+            dex::q64tool::attention_q64_plan(c.N, c.B, KSMAX, &pks, &ptg, &ptk);
+            struct TP { int tg, tk, planned; };
+            std::vector<TP> tps;
+            if (pks == 1 && ptk > 1) tps.push_back({ptg, ptk, 1});
+            if (ng >= 2 && nT >= 3) { tps.push_back({ng - 1, 2, 0}); tps.push_back({std::max(1, ng / 2), 3, 0}); }
+            for (const TP& tp : tps) {
+                AttnDirectP a2 = a; a2.O = O2; a2.ksplit = 1; a2.ml = ml; a2.o_sstride = (long)on; a2.tail_g = tp.tg; a2.tail_ks = tp.tk;
+                hipMemset(O2, 0, on * 4 * KSMAX);
+                char label[96]; snprintf(label, sizeof label, "q64 tail split g>=%d x%d%s", tp.tg, tp.tk, tp.planned ? " (plan)" : "");
+                if (c.bench) timeit(label, 20, fl, [&] { dex::q64tool::launch_attention_q64(a2, 0); });
+                else dex::q64tool::launch_attention_q64(a2, 0);
+                if (hipDeviceSynchronize() != hipSuccess) { printf("      %s: LAUNCH FAILED\n", label); return 1; }
+                std::vector<float> g(on * (tp.tk + 1)), hml((size_t)tp.tk * c.B * 2 * c.N * 2);
+                hipMemcpy(g.data(), O2, g.size() * 4, hipMemcpyDeviceToHost);
+                hipMemcpy(hml.data(), ml, hml.size() * 4, hipMemcpyDeviceToHost);
+                double mx = 0, ref = 0; size_t bad = 0;
+                for (int b = 0; b < c.B; ++b)
+                    for (int n = 0; n < c.N; ++n)
+                        for (int h = 0; h < 2; ++h) {
+                            const bool tail = n >= tp.tg * 256;
+                            double M = -1e300, W = 0;
+                            if (tail) {
+                                for (int s = 0; s < tp.tk; ++s) M = std::max(M, (double)hml[((((size_t)s * c.B + b) * 2 + h) * c.N + n) * 2]);
+                                for (int s = 0; s < tp.tk; ++s) { const float* e = &hml[((((size_t)s * c.B + b) * 2 + h) * c.N + n) * 2]; W += e[1] * exp2((double)e[0] - M); }
+                            }
+                            for (int d = 0; d < 128; ++d) {
+                                const size_t idx = ((size_t)b * c.N + n) * 256 + h * 128 + d;
+                                double val = 0;
+                                if (!tail) val = g[idx];
+                                else {
+                                    for (int s = 0; s < tp.tk; ++s) { const float* e = &hml[((((size_t)s * c.B + b) * 2 + h) * c.N + n) * 2]; val += g[(size_t)(1 + s) * on + idx] * e[1] * exp2((double)e[0] - M); }
+                                    val /= W;
+                                }
+                                const double dlt = fabs(val - r[idx]);
+                                if (!(dlt <= 1e30)) ++bad;
+                                mx = std::max(mx, dlt); ref = std::max(ref, (double)fabsf(r[idx]));
+                            }
+                        }
+                printf("      %s vs shipped: max|d| = %.3e (|O|max %.3f)%s\n", label, mx, ref, bad ? "  NON-FINITE VALUES" : (mx > 2e-2 * std::max(ref, 1e-3) ? "  MISMATCH" : ""));
+            }
+        }
         hipFree(q); hipFree(k); hipFree(v); hipFree(O); hipFree(O2); hipFree(ml);
     }
     return 0;
