@@ -133,6 +133,13 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_lp_kernel(const Conv3P p) {
     constexpr int RING = CC == 128 ? (PRO2 ? 1 : 2) : 3;  // taps of weights in flight ahead of the MFMAs
     constexpr int NPASS = CC == 128 ? (TH == 8 ? (PRO2 ? 8 : 4) : (PRO2 ? 5 : 2)) : (PRO2 ? 3 : 1);   // patch staging passes: 128-channel chunks (or two source tensors) would need >256 registers in one
     constexpr int NIP = (NI + NPASS - 1) / NPASS;        // (1 workgroup per CU instead of 2: measured 16 -> 22 us at 40x256)
+#ifdef DEX_LP_WSPLIT
+    // split weights: the nine taps run twice over the same patch - taps 9..17 are the lo halves of the weights, p.w_lo_off elements
+    // behind their hi halves (same [COUT][9*Cin] layout); the 1x1 shortcut's lo half replaces its hi half in rbuf after the centre tap
+    constexpr int NTAP = 18;
+#else
+    constexpr int NTAP = 9;
+#endif
     static_assert(NT >= 1 && WPT >= 1, "tile");
     extern __shared__ __attribute__((aligned(16))) u16 smem[];
     u16* patch = smem;                                // [PH*PW][LDP]
@@ -195,6 +202,12 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_lp_kernel(const Conv3P p) {
         // ---- every global load of the chunk's first round goes out back to back: the patch FIRST (loads return in order and
         // the conversion, the long phase, needs only the patch), then the weights of taps 0..RING, which land under it
         u32x4 w0r[WPT], wr[RING][WPT], rwr[RES ? WPT : 1];
+#ifdef DEX_LP_WSPLIT
+        u32x4 rwl[RES ? WPT : 1];
+#define WS_TAPOFS(t) ((long)((t) % 9) * p.Cin + ((t) >= 9 ? p.w_lo_off : 0L))
+#else
+#define WS_TAPOFS(t) ((long)(t) * p.Cin)
+#endif
         float4 sc0, sc1, sh0, sh1, t0, t1;                // this thread's 8 channels of the coefficient table (read after the barrier)
 #pragma unroll
         for (int ps = 0; ps < NPASS; ++ps) {
@@ -232,6 +245,9 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_lp_kernel(const Conv3P p) {
                     for (int j = 0; j < WPT; ++j) {
                         const int it = tid + NTHR * j;
                         rwr[j] = *reinterpret_cast<const u32x4*>(Rg + (long)(it / (CC / 8)) * p.Cin + cbase + (it % (CC / 8)) * 8);
+#ifdef DEX_LP_WSPLIT
+                        rwl[j] = *reinterpret_cast<const u32x4*>(Rg + p.res_lo_off + (long)(it / (CC / 8)) * p.Cin + cbase + (it % (CC / 8)) * 8);
+#endif
                     }
                 }
 #pragma unroll
@@ -239,7 +255,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_lp_kernel(const Conv3P p) {
 #pragma unroll
                 for (int s = 0; s < RING; ++s)
 #pragma unroll
-                    for (int j = 0; j < WPT; ++j) wr[s][j] = *reinterpret_cast<const u32x4*>(Wg + wofs[j] + (long)(s + 1) * p.Cin + cbase);
+                    for (int j = 0; j < WPT; ++j) wr[s][j] = *reinterpret_cast<const u32x4*>(Wg + wofs[j] + WS_TAPOFS(s + 1) + cbase);
                 CSTAMP(0);
                 if (pro && ch == 0) cv_gn_finish<COEF_N>(p, gnl, tid, coef);
                 __builtin_amdgcn_sched_barrier(0);
@@ -305,20 +321,29 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_lp_kernel(const Conv3P p) {
         CSTAMP(2);
         // ---- nine taps; tap t's weights sit in wbuf[t & 1], taps t+1 .. t+RING are in registers / in flight
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            lds_barrier();                            // wbuf[tap & 1] (and the patch) visible; wbuf[(tap+1) & 1] is free
-            if (tap + 1 < 9) {
-                u16* wn = wbuf + ((tap + 1) & 1) * NSL * LDP;
+        for (int tt = 0; tt < NTAP; ++tt) {
+            const int tap = tt % 9;                   // (the loop is unrolled: a constant)
+            lds_barrier();                            // wbuf[tt & 1] (and the patch) visible; wbuf[(tt+1) & 1] is free
+            if (tt + 1 < NTAP) {
+                u16* wn = wbuf + ((tt + 1) & 1) * NSL * LDP;
 #pragma unroll
-                for (int j = 0; j < WPT; ++j) *reinterpret_cast<u32x4*>(wn + wlds[j]) = wr[tap % RING][j];
-                if (tap + 1 + RING < 9) {
+                for (int j = 0; j < WPT; ++j) *reinterpret_cast<u32x4*>(wn + wlds[j]) = wr[tt % RING][j];
+                if (tt + 1 + RING < NTAP) {
 #pragma unroll
                     for (int j = 0; j < WPT; ++j)
-                        wr[tap % RING][j] = *reinterpret_cast<const u32x4*>(Wg + wofs[j] + (long)(tap + 1 + RING) * p.Cin + cbase);
+                        wr[tt % RING][j] = *reinterpret_cast<const u32x4*>(Wg + wofs[j] + WS_TAPOFS(tt + 1 + RING) + cbase);
                 }
                 __builtin_amdgcn_sched_barrier(0);    // the refill loads issue before the MFMAs, not dripped between them
             }
-            const u16* wb = wbuf + (tap & 1) * NSL * LDP;
+#ifdef DEX_LP_WSPLIT
+            if constexpr (RES) {
+                if (tt == 5) {                        // every wave is past the centre tap (barrier above): the shortcut's lo half for tap 13
+#pragma unroll
+                    for (int j = 0; j < WPT; ++j) *reinterpret_cast<u32x4*>(rbuf + wlds[j]) = rwl[j];
+                }
+            }
+#endif
+            const u16* wb = wbuf + (tt & 1) * NSL * LDP;
             const int kh = tap / 3, kw = tap - kh * 3;
             const u16* ap = patch + ((wrow + kh) * PW + i + kw) * LDP + hh * 8;
             const u16* bp = wb + (wcol * NT * 32 + i) * LDP + hh * 8;

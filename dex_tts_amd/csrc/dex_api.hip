@@ -914,7 +914,7 @@ struct Runner {
             Conv3P c{};
             c.x_bf16 = (xb || X.lp) ? 1 : 0; c.y_bf16 = yb ? 1 : 0;
             c.X = X.p; c.ldx = X.ld; c.x_coff = X.coff; c.H = H; c.W = W; c.Cin = X.C; c.Cout = Cout;
-            c.Wbf = it->second; c.bias = bias; c.Y = out; c.mask = mask; c.mask_ws = mask_ws; c.mask_bstride = P.d.T;
+            c.Wbf = it->second; c.w_lo_off = x->lo_off(c.Wbf); c.bias = bias; c.Y = out; c.mask = mask; c.mask_ws = mask_ws; c.mask_bstride = P.d.T;
             if (pro) { c.pro_stats = pro->stats; c.pro_gamma = pro->gamma; c.pro_beta = pro->beta; c.pro_tadd = pro->tadd; c.pro_res = pro->res; c.pro_xout = pro->xout;
                 if (pro->res2) {
                     const FirstConvP& f = pro->res2f;
@@ -925,7 +925,7 @@ struct Runner {
             { auto itf = x->frag_of().find(Wt); c.Wfrag = itf != x->frag_of().end() ? itf->second : nullptr; }   // conv3x3_regw.hip
             const bool want_xout_lp = pro && pro->xout && pro->xout_lp_ok;
             if (shortcut) {       // the block's 1x1 res_conv rides on the centre tap of this conv
-                c.res_w = x->lp_of().at(shortcut->wr); c.res_b = shortcut->br; c.res_y = shortcut_out;
+                c.res_w = x->lp_of().at(shortcut->wr); c.res_lo_off = x->lo_off(c.res_w); c.res_b = shortcut->br; c.res_y = shortcut_out;
                 { auto itf = x->frag_of().find(shortcut->wr); c.res_wfrag = itf != x->frag_of().end() ? itf->second : nullptr; }
             }
             if (want_xout_lp && (c.pro_res || c.res2_w) && conv3x3_strip_form(c)) { c.xout_lp = 1; pro->xout_lp = true; }
@@ -1065,7 +1065,7 @@ struct Runner {
     void linattn(const LinW& w, const StageBuf& s, const TD& X, float* out, int ldo, int ocoff, const LinKvCtxP* tail = nullptr, bool out_lp = false,
                  void* out2_lp = nullptr, int ldo2 = 0, int ocoff2 = 0) {
         const long npix = s.npix; const int B = P.d.B;
-        if (x->lp() && (X.C == 64 || X.C == 128)) {
+        if (linattn_fused(X.C)) {
             // fused: y = x + W2 (Wq x) + g*b  with  W2 = g Wout blockdiag(ctx^T)   (linattn_fused.hip)
             int nsub = 1;
             // measured at 80x512, B=1: 320 / 160 / 80 workgroups -> context 19.9 / 13.7 / 19.4 us, merge 8.7 / 6.1 / 4.7 us
@@ -1074,6 +1074,7 @@ struct Runner {
             LinKvCtxP k{};
             if (tail) k = *tail;
             k.X = X.p; k.ldx = X.ld; k.x_coff = X.coff; k.xb = npix * X.ld; k.npix = (int)npix; k.C = X.C; k.Wkv = w.wkv_lp[x->lpi()];
+            k.wkv_lo_off = x->lpi() == 2 ? 384L * X.C : 0;          // (the q | k | v rows were converted as one array: Packer::linattn)
             k.nsub = nsub; k.nblk = nblk; k.part_m = s.pm; k.part_s = s.ps; k.part_c = s.pc; k.B = B;
             // x = the ResnetBlock output the context pass materialises has ONE reader, the tail kernel below, which rounds it to the
             // operand type for its q GEMM anyway and adds it back as the residual term: at batch size it is stored in that type
@@ -1086,6 +1087,7 @@ struct Runner {
             run("linattn_merge", 2.0 * 128 * 32 * X.C * B, 4.0 * nblk * 4 * 1088 * B, [&] { launch_linattn_merge(mg, x->precision, st); });
             LinOut2P o{X.p, X.ld, X.coff, npix * X.ld, (int)npix, X.C, w.wq_frag[x->lpi()], s.mbf, w.bias_eff, out, ldo, ocoff, npix * ldo, B, out_lp ? 1 : 0,
                        out2_lp, ldo2, ocoff2, npix * ldo2, xlp ? 1 : 0};
+            o.wq_lo_off = x->lpi() == 2 ? 128L * X.C : 0;
             run("linattn_out", 4.0 * npix * B * 128.0 * X.C, ((out_lp ? 6.0 : 8.0) - (xlp ? 2.0 : 0.0) + (out2_lp ? 2.0 : 0.0)) * npix * X.C * B, [&] { launch_linattn_out2(o, x->precision, st); });
             return;
         }

@@ -46,11 +46,27 @@ __device__ __forceinline__ float gelu_erf_rc(float x) {
     return 0.5f * x * (1.0f + copysignf(er, x));
 }
 
+// Split-weight build (DEX_LP_WSPLIT, lp_config.h): every weight matrix in fragment order is followed by its lo half (what the fp16
+// rounding of the weight lost, same layout), K * N elements behind; a product is two MFMAs, hi then lo, into one accumulator.
+// WT16: the hi fragments ride in registers one stage ahead as before, the lo fragments are fetched inside the MFMA chain (eight at
+// a time, under the eight hi MFMAs of their half): two more register tiles do not fit next to wa / wb.  WT8 (cluster form): both halves
+// ride ahead.  LO_* = the distance to the lo half in 16-byte units.
+constexpr long LO_WP = (long)RC_H * RC_H / 8, LO_W1 = (long)RC_H * RC_MLP / 8, LO_W2 = (long)RC_MLP * RC_H / 8, LO_WQ = (long)RC_H * 3 * RC_H / 8;
+#ifdef DEX_LP_WSPLIT
+struct WT16 { uint4 h[16]; const uint4* lo; };
+struct WT8 { uint4 h[8]; uint4 l[8]; };
+#else
+struct WT16 { uint4 h[16]; };
+struct WT8 { uint4 h[8]; };
+#endif
 // one weight tile = 32 output columns x 256 K = 16 K-steps x (64 lanes x 16 B)
-__device__ __forceinline__ void wload(uint4 (&w)[16], const void* W, int ksteps_total, int nt, int ks0, int lane) {
+__device__ __forceinline__ void wload(WT16& w, const void* W, long lo_u4, int ksteps_total, int nt, int ks0, int lane) {
     const uint4* src = reinterpret_cast<const uint4*>(W) + ((long)nt * ksteps_total + ks0) * 64 + lane;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) w[j] = src[j * 64];
+    for (int j = 0; j < 16; ++j) w.h[j] = src[j * 64];
+#ifdef DEX_LP_WSPLIT
+    w.lo = src + lo_u4;
+#endif
     __builtin_amdgcn_sched_barrier(0);     // all 16 loads issue HERE (the scheduler otherwise drips them into the MFMA chain below)
 }
 __device__ __forceinline__ f32x16 zero16() {
@@ -64,32 +80,52 @@ __device__ __forceinline__ f32x16 zero16() {
 // batches of 8 (all ds_read_b128 of a batch in flight together, 32 VGPRs) instead of one right before each MFMA,
 // which exposed an LDS latency per link of the dependent MFMA chain.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void mma16(f32x16& acc, const uint4 (&w)[16], const u16* a_lane) {
+__device__ __forceinline__ void mma16(f32x16& acc, const WT16& w, const u16* a_lane) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         u32x4 a[8];
+#ifdef DEX_LP_WSPLIT
+        uint4 l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) l[j] = w.lo[(h * 8 + j) * 64];
+#endif
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[j] = *reinterpret_cast<const u32x4*>(a_lane + (h * 8 + j) * 16);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            acc = DEX_MFMA_LP(__builtin_bit_cast(lp8, a[j]), __builtin_bit_cast(lp8, w[h * 8 + j]), acc, 0, 0, 0);
+            acc = DEX_MFMA_LP(__builtin_bit_cast(lp8, a[j]), __builtin_bit_cast(lp8, w.h[h * 8 + j]), acc, 0, 0, 0);
+#ifdef DEX_LP_WSPLIT
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            acc = DEX_MFMA_LP(__builtin_bit_cast(lp8, a[j]), __builtin_bit_cast(lp8, l[j]), acc, 0, 0, 0);
+#endif
     }
 }
 
 // The same product TRANSPOSED (weights as the A operand, activations as B): acc[r] = C[feature (r&3) + 8 (r>>2) + 4 hh][token lane&31].
 // Same products, same K order per output element: the values are those of mma16, only their placement over lanes / registers differs
 // - it is the placement from which the q / k fragment layouts can be written without a transpose (store_qkv_tile_d).
-__device__ __forceinline__ void mma16t(f32x16& acc, const uint4 (&w)[16], const u16* a_lane) {
+__device__ __forceinline__ void mma16t(f32x16& acc, const WT16& w, const u16* a_lane) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         u32x4 a[8];
+#ifdef DEX_LP_WSPLIT
+        uint4 l[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) l[j] = w.lo[(h * 8 + j) * 64];
+#endif
 #pragma unroll
         for (int j = 0; j < 8; ++j) a[j] = *reinterpret_cast<const u32x4*>(a_lane + (h * 8 + j) * 16);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            acc = DEX_MFMA_LP(__builtin_bit_cast(lp8, w[h * 8 + j]), __builtin_bit_cast(lp8, a[j]), acc, 0, 0, 0);
+            acc = DEX_MFMA_LP(__builtin_bit_cast(lp8, w.h[h * 8 + j]), __builtin_bit_cast(lp8, a[j]), acc, 0, 0, 0);
+#ifdef DEX_LP_WSPLIT
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            acc = DEX_MFMA_LP(__builtin_bit_cast(lp8, l[j]), __builtin_bit_cast(lp8, a[j]), acc, 0, 0, 0);
+#endif
     }
 }
 
@@ -340,14 +376,14 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
         lnv = *reinterpret_cast<const float2*>(src + c2);
         if (!ATTN || p.qkv_only) *reinterpret_cast<float2*>(LNp + which * RC_H + c2) = lnv;     // ATTN: the LDS is attention scratch first
     }
-    uint4 wa[16], wb[16];
+    WT16 wa, wb;
     const int col = wave * 32 + i;
     const u16* a_lane = As + i * A_LD + hh * 8;
     const u16* h_lane = Hs + i * H_LD + hh * 8;
     f32x16 acc;
     if (p.qkv_only) {
         // first block: just LN + modulate + qkv of the incoming token rows
-        wload(wb, p.Wq, 16, wave, 0, lane);
+        wload(wb, p.Wq, LO_WQ, 16, wave, 0, lane);
         const int row = tid >> 4, seg = tid & 15;
         const float* src = p.X + (mb + min(n0 + row, N - 1)) * RC_H + seg * 4;
 #pragma unroll
@@ -448,7 +484,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
                     make_float4(ao[t][rq * 4 + 0], ao[t][rq * 4 + 1], ao[t][rq * 4 + 2], ao[t][rq * 4 + 3]);
         if (hh == 0) { scr[RC_NW * 32 * AT_LD + (wave * 2 + 0) * 32 + i] = am; scr[RC_NW * 32 * AT_LD + (wave * 2 + 1) * 32 + i] = al; }
     }
-    wload(wa, p.Wp, 16, wave, 0, lane);
+    wload(wa, p.Wp, LO_WP, 16, wave, 0, lane);
     // residual rows of this lane's output column + the attention output tile
     float xres[16];
 #pragma unroll
@@ -519,7 +555,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
 #endif
 
     // ---- x1 = x + gate_msa * (O Wproj + b)
-    wload(wb, p.W1, 16, wave, 0, lane);
+    wload(wb, p.W1, LO_W1, 16, wave, 0, lane);
     acc = zero16();
     mma16(acc, wa, a_lane);
 #pragma unroll
@@ -539,7 +575,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
 
 
     // ---- h = GELU(A W1 + b1): column tiles `wave` and `wave + 8`
-    wload(wa, p.W1, 16, wave + 8, 0, lane);
+    wload(wa, p.W1, LO_W1, 16, wave + 8, 0, lane);
     acc = zero16();
     mma16(acc, wb, a_lane);
 #pragma unroll
@@ -547,7 +583,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
         const int row = (r & 3) + 8 * (r >> 2) + 4 * hh;
         Hs[row * H_LD + col] = (u16)(pack2_lp(gelu_erf_rc(acc[r] + b_1a), 0.f) & 0xffffu);
     }
-    wload(wb, p.W2, 32, wave, 0, lane);
+    wload(wb, p.W2, LO_W2, 32, wave, 0, lane);
     acc = zero16();
     mma16(acc, wa, a_lane);
 #pragma unroll
@@ -561,10 +597,10 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
 #endif
 
     // ---- x2 = x1 + gate_mlp * (h W2 + b2)
-    wload(wa, p.W2, 32, wave, 16, lane);
+    wload(wa, p.W2, LO_W2, 32, wave, 16, lane);
     acc = zero16();
     mma16(acc, wb, h_lane);
-    if (has_q) wload(wb, p.Wq, 16, wave, 0, lane);
+    if (has_q) wload(wb, p.Wq, LO_WQ, 16, wave, 0, lane);
     mma16(acc, wa, h_lane + 256);
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -589,7 +625,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
 #endif
     // ---- qkv of the next block: column tiles wave (q), wave+8 (k), wave+16 (v)
     const float bq0 = p.bq[col], bq1 = p.bq[col + 256], bq2 = p.bq[col + 512];
-    wload(wa, p.Wq, 16, wave + 8, 0, lane);
+    wload(wa, p.Wq, LO_WQ, 16, wave + 8, 0, lane);
 #ifdef DEX_TIMING
     long long u0 = wall_clock64();
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");       // wb (this tile's weights) landed; wa still in flight
@@ -606,7 +642,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_kernel(const DitChain
     long long u3 = wall_clock64();
     if (p.dbg && tid == 0) { p.dbg[256 + blockIdx.x * 4 + 0] = u1 - u0; p.dbg[256 + blockIdx.x * 4 + 1] = u2 - u1; p.dbg[256 + blockIdx.x * 4 + 2] = u3 - u2; }
 #endif
-    wload(wb, p.Wq, 16, wave + 16, 0, lane);
+    wload(wb, p.Wq, LO_WQ, 16, wave + 16, 0, lane);
     acc = zero16();
     qb = qkv_bias<1>(p, wave + 8, lane);
     mma16t(acc, wa, a_lane);
@@ -656,13 +692,13 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain64_kernel(const DitCha
                                       : (has_q ? p.next_scale + (long)step * p.next_step_stride : ada);
         *reinterpret_cast<float2*>(LNp + which * RC_H + c2) = *reinterpret_cast<const float2*>(src + c2);
     }
-    uint4 wa[16], wb[16];
+    WT16 wa, wb;
     const int col = wave * 32 + i;
     const u16* a_lane = As + i * A_LD + hh * 8;
     const u16* h_lane = Hs + i * A_LD + hh * 8;
     f32x16 acc;
     if (p.qkv_only) {
-        wload(wb, p.Wq, 16, wave, 0, lane);
+        wload(wb, p.Wq, LO_WQ, 16, wave, 0, lane);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             const int row = (tid >> 4) + 32 * m, seg = tid & 15;
@@ -703,13 +739,13 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain64_kernel(const DitCha
                 *reinterpret_cast<uint2*>(As + row * A_LD + q * 64 + seg * 4) = o;
             }
         }
-        wload(wa, p.Wp, 16, wave, 0, lane);                  // (after the merge: its 64 partial registers and this tile do not fit together)
+        wload(wa, p.Wp, LO_WP, 16, wave, 0, lane);                  // (after the merge: its 64 partial registers and this tile do not fit together)
         const float b_p = p.bp[col], g_msa = ada[2 * RC_H + col];
         const float b_1a = p.b1[col], b_1b = p.b1[col + 256];
         const float b_2 = p.b2[col], g_mlp = ada[5 * RC_H + col];
         lds_barrier();
         // ---- x1 = x + gate_msa * (O Wproj + b)
-        wload(wb, p.W1, 16, wave, 0, lane);
+        wload(wb, p.W1, LO_W1, 16, wave, 0, lane);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             float xres[16];                                   // residual rows of this lane's column (one half at a time: registers)
@@ -731,7 +767,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain64_kernel(const DitCha
         ln_to_A(X1 + 32 * X_LD, As + 32 * A_LD, LNp, LNp + RC_H, tid);
         lds_barrier();
         // ---- MLP, hidden columns 0..255: h = GELU(A W1[:, :256] + b1), partial x2 += h W2[:256, :]
-        wload(wa, p.W2, 32, wave, 0, lane);
+        wload(wa, p.W2, LO_W2, 32, wave, 0, lane);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             acc = zero16();
@@ -743,13 +779,13 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain64_kernel(const DitCha
             }
         }
         lds_barrier();
-        wload(wb, p.W1, 16, wave + 8, 0, lane);
+        wload(wb, p.W1, LO_W1, 16, wave + 8, 0, lane);
         f32x16 acc2[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m) { acc2[m] = zero16(); mma16(acc2[m], wa, h_lane + m * 32 * A_LD); }
         lds_barrier();                                        // every wave is done with this half of h
         // ---- hidden columns 256..511
-        wload(wa, p.W2, 32, wave, 16, lane);
+        wload(wa, p.W2, LO_W2, 32, wave, 16, lane);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             acc = zero16();
@@ -761,7 +797,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain64_kernel(const DitCha
             }
         }
         lds_barrier();
-        if (has_q) wload(wb, p.Wq, 16, wave, 0, lane);
+        if (has_q) wload(wb, p.Wq, LO_WQ, 16, wave, 0, lane);
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
             mma16(acc2[m], wa, h_lane + m * 32 * A_LD);
@@ -781,12 +817,12 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain64_kernel(const DitCha
     lds_barrier();
     // ---- qkv of the next block: column tiles wave (q), wave+8 (k), wave+16 (v), two row halves each; q and k are computed transposed
     // so that their fragment layouts leave the accumulators without an LDS transpose (store_qkv_tile_d)
-    wload(wa, p.Wq, 16, wave + 8, 0, lane);
+    wload(wa, p.Wq, LO_WQ, 16, wave + 8, 0, lane);
     QkvBias qb = qkv_bias<0>(p, wave, lane);
 #pragma unroll
     // (the operand buffers hold ceil(N / 32) row tiles per (utterance, head): a second half that lies wholly past them is skipped)
     for (int m = 0; m < 2; ++m) { if (n0 + 32 * m >= p.Npad) break; acc = zero16(); mma16t(acc, wb, a_lane + m * 32 * A_LD); store_qkv_tile_d<0>(p, acc, qb, wave, b, n0 + 32 * m, lane); }
-    wload(wb, p.Wq, 16, wave + 16, 0, lane);
+    wload(wb, p.Wq, LO_WQ, 16, wave + 16, 0, lane);
     qb = qkv_bias<1>(p, wave + 8, lane);
 #pragma unroll
     for (int m = 0; m < 2; ++m) { if (n0 + 32 * m >= p.Npad) break; acc = zero16(); mma16t(acc, wa, a_lane + m * 32 * A_LD); store_qkv_tile_d<1>(p, acc, qb, wave + 8, b, n0 + 32 * m, lane); }
@@ -820,19 +856,27 @@ constexpr int CL_AH_LD = 128 + 8;     // attention-output / GELU tile row stride
 constexpr int CL_RED_LD = 33;
 typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ void wload8(uint4 (&w)[8], const void* W, int ksteps_total, int nt, int ks0, int lane) {
+__device__ __forceinline__ void wload8(WT8& w, const void* W, long lo_u4, int ksteps_total, int nt, int ks0, int lane) {
     const uint4* src = reinterpret_cast<const uint4*>(W) + ((long)nt * ksteps_total + ks0) * 64 + lane;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) w[j] = src[j * 64];
+    for (int j = 0; j < 8; ++j) w.h[j] = src[j * 64];
+#ifdef DEX_LP_WSPLIT
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w.l[j] = src[lo_u4 + j * 64];
+#endif
     __builtin_amdgcn_sched_barrier(0);
 }
-__device__ __forceinline__ void mma8(f32x16& acc, const uint4 (&w)[8], const u16* a_lane) {
+__device__ __forceinline__ void mma8(f32x16& acc, const WT8& w, const u16* a_lane) {
     u32x4 a[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) a[j] = *reinterpret_cast<const u32x4*>(a_lane + j * 16);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc = DEX_MFMA_LP(__builtin_bit_cast(lp8, a[j]), __builtin_bit_cast(lp8, w[j]), acc, 0, 0, 0);
+    for (int j = 0; j < 8; ++j) acc = DEX_MFMA_LP(__builtin_bit_cast(lp8, a[j]), __builtin_bit_cast(lp8, w.h[j]), acc, 0, 0, 0);
+#ifdef DEX_LP_WSPLIT
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = DEX_MFMA_LP(__builtin_bit_cast(lp8, a[j]), __builtin_bit_cast(lp8, w.l[j]), acc, 0, 0, 0);
+#endif
 }
 // LayerNorm + modulate of a row held in registers (16 threads per row, four float4 each at columns q*64 + seg*4) -> bf16 A tile:
 // ln_to_A without the LDS round trip and its barrier (the row sums run over the 16 lanes of the row)
@@ -980,7 +1024,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const 
 #pragma unroll
     for (int q = 0; q < 4; ++q) xr[q] = *reinterpret_cast<const float4*>(p.X + (mb + nrow) * RC_H + q * 64 + seg * 4);
 
-    uint4 w8[8];
+    WT8 w8;
     f32x16 acc;
     if constexpr (!QKV_ONLY) {
         const int head = member >> 1, half = member & 1;
@@ -1071,7 +1115,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const 
 #ifdef DEX_TIMING
     cts[1] = wall_clock64();
 #endif
-        wload8(w8, p.Wp, 16, wave, 8 * head, lane);               // proj weights: output tile `wave`, the head's K half
+        wload8(w8, p.Wp, LO_WP, 16, wave, 8 * head, lane);               // proj weights: output tile `wave`, the head's K half
         // partial (m, l, O[query][d]) of this wave -> LDS scratch
         float* scr = reinterpret_cast<float*>(smem_rc);
         {
@@ -1125,7 +1169,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const 
         // ---- proj partial: P_c = O_c Wp[head rows, :]  (raw: bias, gate and residual are applied after the exchange)
         acc = zero16();
         mma8(acc, w8, Ah + i * CL_AH_LD + hh * 8);
-        wload8(w8, p.W1, 16, 4 * member + (wave & 3), 8 * (wave >> 2), lane);      // fc1: column tile wave & 3 of this member's four, K half wave >> 2
+        wload8(w8, p.W1, LO_W1, 16, 4 * member + (wave & 3), 8 * (wave >> 2), lane);      // fc1: column tile wave & 3 of this member's four, K half wave >> 2
         const int col = wave * 32 + i;
 #pragma unroll
         for (int r = 0; r < 16; ++r) X1[((r & 3) + 8 * (r >> 2) + 4 * hh) * X_LD + col] = acc[r];
@@ -1214,7 +1258,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const 
             const int ct = wave & 3, kh = wave >> 2;
             acc = zero16();
             mma8(acc, w8, As + i * A_LD + hh * 8 + kh * 128);
-            wload8(w8, p.W2, 32, wave, 8 * member, lane);                 // fc2: output tile `wave`, K = this member's hidden slice
+            wload8(w8, p.W2, LO_W2, 32, wave, 8 * member, lane);                 // fc2: output tile `wave`, K = this member's hidden slice
             if (kh == 1) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) RED[(ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * CL_RED_LD + i] = acc[r];
@@ -1302,9 +1346,9 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const 
         lds_barrier();                                   // the parameter table is complete
     }
     // ---- next block's qkv: column tiles 6 member .. 6 member + 5 on waves 0-5 (full K)
-    uint4 wq[16];
+    WT16 wq;
     const int nt = 6 * member + wave;
-    if (wave < 6) wload(wq, p.Wq, 16, nt, 0, lane);
+    if (wave < 6) wload(wq, p.Wq, LO_WQ, 16, nt, 0, lane);
     ln_regs_to_A(xr, As, PRM + 2 * RC_H, PRM + 3 * RC_H, row, seg);      // xr = x2 (or the incoming rows of the first block)
     lds_barrier();
 

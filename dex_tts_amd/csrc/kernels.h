@@ -131,6 +131,7 @@ struct Conv3P {
     // raw conv outputs that only a GroupNorm prologue reads next (h1, h2 of a ResnetBlock) may live in HBM as bf16:
     // x_bf16: X is bf16 [.. ldx] (PRO / PRO2 forms only); y_bf16: Y is written as bf16.  Statistics stay fp32.
     int x_bf16, y_bf16;
+    long w_lo_off = 0, res_lo_off = 0;                       // split-weight mode (PREC_FP16X2): elements from a weight of Wbf / res_w to its lo half
 };
 bool conv3x3_bf16_supported(int Cin, int Cout);
 bool conv3x3_bf16_tail_supported(int C);     // pro_res form (Cin == Cout == C)
@@ -225,7 +226,8 @@ struct LinKvCtxP { const float* X; int ldx; int x_coff; long xb; int npix; int C
                    const float* mask; int mask_ws; long mask_bstride; int W; float* Xout;
                    int h2_bf16;                             // H2 is bf16 [npix][C]
                    int res_lp;                              // res is stored in the mode's 16-bit type [npix][C] (written by Conv3P::xout_lp)
-                   int xout_lp; };                          // Xout is written in the mode's 16-bit type (its one reader, the tail kernel, takes LinOut2P::x_lp)
+                   int xout_lp;     long wkv_lo_off = 0;        // split-weight mode: elements from a weight of Wkv to its lo half
+};                          // Xout is written in the mode's 16-bit type (its one reader, the tail kernel, takes LinOut2P::x_lp)
 void launch_linattn_kvctx(const LinKvCtxP& p, int precision, hipStream_t st);
 struct LinMergeP { const float* part_m; const float* part_s; const float* part_c; int nblk;
                    const float* Wout; const float* g; int C; void* W2; int B; };       // Wout fp32 [C][128]
@@ -234,7 +236,8 @@ struct LinOut2P { const float* X; int ldx; int x_coff; long xb; int npix; int C;
                   const float* bias; float* Y; int ldy; int y_coff; long yb; int B; // Wq bf16 in MFMA fragment order (launch_pack_lp_frag_nk)
                   int y_lp;         // 1: Y is stored in the mode's 16-bit type (throughput form only: linattn_out2_lp_out_supported)
                   void* Y2; int ldy2; int y2_coff; long y2b;   // optional second copy of Y in the mode's 16-bit type (throughput form only): the skip half of the up path's concatenation buffer
-                  int x_lp; };      // 1: X is stored in the mode's 16-bit type [npix][C] (throughput form only; written by LinKvCtxP::xout_lp)
+                  int x_lp;     long wq_lo_off = 0;         // split-weight mode: elements from a weight of Wq to its lo half
+                  };      // 1: X is stored in the mode's 16-bit type [npix][C] (throughput form only; written by LinKvCtxP::xout_lp)
 void launch_linattn_out2(const LinOut2P& p, int precision, hipStream_t st);
 bool linattn_out2_lp_out_supported(int npix, int B);
 bool linattn_fused_supported(int C);          // the fused linear attention exists for this mode (lp_dispatch.hip: false in a build without a split-weight form)

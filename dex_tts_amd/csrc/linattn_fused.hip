@@ -46,6 +46,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 ? 2
             const int it = tid + 256 * j;
             *reinterpret_cast<uint4*>(Ws + (it / (C / 8)) * LDW + (it % (C / 8)) * 8) = wr[j];
         }
+#ifdef DEX_LP_WSPLIT
+        // the lo halves of the same rows (p.wkv_lo_off elements behind), a second LDS image behind the first
+#pragma unroll
+        for (int j = 0; j < C / 8; ++j) {
+            const int it = tid + 256 * j;
+            wr[j] = *reinterpret_cast<const uint4*>(Wg + p.wkv_lo_off + (long)(it / (C / 8)) * C + (it % (C / 8)) * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < C / 8; ++j) {
+            const int it = tid + 256 * j;
+            *reinterpret_cast<uint4*>(Ws + 256 * LDW + (it / (C / 8)) * LDW + (it % (C / 8)) * 8) = wr[j];
+        }
+#endif
     }
     const float* X = PRO ? p.H2 + (long)b * p.npix * C : p.X + (long)b * p.xb + p.x_coff;
     const int ldx = PRO ? C : p.ldx;
@@ -219,6 +232,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 ? 2
                 LFrag fk, fv; fk.u = *reinterpret_cast<const uint4*>(bk + ks * 16); fv.u = *reinterpret_cast<const uint4*>(bv + ks * 16);
                 kh = DEX_MFMA_LP(af[ks].v, fk.v, kh, 0, 0, 0);
                 vh = DEX_MFMA_LP(af[ks].v, fv.v, vh, 0, 0, 0);
+#ifdef DEX_LP_WSPLIT
+                LFrag lk, lv; lk.u = *reinterpret_cast<const uint4*>(bk + 256 * LDW + ks * 16); lv.u = *reinterpret_cast<const uint4*>(bv + 256 * LDW + ks * 16);
+                kh = DEX_MFMA_LP(af[ks].v, lk.v, kh, 0, 0, 0);
+                vh = DEX_MFMA_LP(af[ks].v, lv.v, vh, 0, 0, 0);
+#endif
             }
             // column (channel d = lane&31) max over the 32 pixels of the sub-tile
             float mx = -INFINITY;
@@ -290,15 +308,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 ? 2
 }
 
 void launch_linattn_kvctx(const LinKvCtxP& p, hipStream_t st) {
+#ifdef DEX_LP_WSPLIT
+    const size_t lds_w = (size_t)2 * 256 * (p.C + 8) * sizeof(u16);          // hi + lo images of the k | v rows
+    constexpr int LDS_MAX = 144 * 1024;
+#else
     const size_t lds_w = (size_t)256 * (p.C + 8) * sizeof(u16);
+    constexpr int LDS_MAX = 96 * 1024;
+#endif
     const size_t lds_m = (size_t)(4 * 4 * 32 * 33 + 2 * 4 * 4 * 32) * sizeof(float);
     const size_t lds = lds_w > lds_m ? lds_w : lds_m;
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_kvctx_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_kvctx_kernel<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_kvctx_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_kvctx_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_kvctx_kernel<64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_kvctx_kernel<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_kvctx_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_kvctx_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
         attr = true;
     }
     dim3 grid(p.nblk, p.B);
@@ -447,6 +471,10 @@ __global__ __launch_bounds__(256) void linattn_out2_direct_kernel(const LinOut2P
         for (int ks = 0; ks < KS1; ++ks) {
             LFrag af; af.u = wq[(t * KS1 + ks) * 64];
             q = DEX_MFMA_LP(af.v, xf[ks].v, q, 0, 0, 0);
+#ifdef DEX_LP_WSPLIT
+            LFrag al; al.u = wq[(t * KS1 + ks) * 64 + p.wq_lo_off / 8];       // the lo half of the same fragment
+            q = DEX_MFMA_LP(al.v, xf[ks].v, q, 0, 0, 0);
+#endif
         }
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {
@@ -571,6 +599,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, C == 64 
         for (int ks = 0; ks < KS1; ++ks) {
             LFrag af; af.u = wq[(t * KS1 + ks) * 64];
             q = DEX_MFMA_LP(af.v, xf[ks].v, q, 0, 0, 0);
+#ifdef DEX_LP_WSPLIT
+            LFrag al; al.u = wq[(t * KS1 + ks) * 64 + p.wq_lo_off / 8];       // the lo half of the same fragment
+            q = DEX_MFMA_LP(al.v, xf[ks].v, q, 0, 0, 0);
+#endif
         }
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2) {

@@ -15,6 +15,13 @@
 // (oracle/lowp_emulate.py).  Compiled with -DDEX_LP_F16 -DDEX_LP_WSPLIT; a packed weight twin is the hi pack followed by the lo pack
 // in the same layout.  Kernels without a split form answer false from their shape predicates in this namespace.
 #define DEX_LP_NS f16w
+// the fused kernels that have a split-weight form (their shape predicates answer as in the other builds)
+#define DEX_WS_HAVE_CONV3 1
+#define DEX_WS_HAVE_CONV3_RES 1
+#define DEX_WS_HAVE_LINATTN 1
+#define DEX_WS_HAVE_RC 1
+#define DEX_WS_HAVE_RC64 1
+#define DEX_WS_HAVE_RCC 1
 #elif defined(DEX_LP_F16)
 #define DEX_LP_NS f16
 #else
