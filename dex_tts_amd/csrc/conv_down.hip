@@ -35,7 +35,12 @@ template <> struct CdRow<false> { uint4 a[CD_NL]; uint4 c[CD_NL]; float m[CD_NL]
 
 // grid (nseg * nchunk, B); 256 threads
 template <bool ALP, bool CLP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ALP ? 2 : 1, ALP ? 2 : 1))) void conv_down_kernel(const ConvDownP p) {
+#ifdef DEX_LP_WSPLIT
+#define CD_WAVES_ATTR                // (twice the weight registers: one wave per SIMD)
+#else
+#define CD_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(ALP ? 2 : 1, ALP ? 2 : 1)))
+#endif
+__global__ __launch_bounds__(256) CD_WAVES_ATTR void conv_down_kernel(const ConvDownP p) {
     constexpr int SPB = CLP ? 144 : 272, STG = CD_MPX * SPB, OCH = CLP ? 8 : 16, NS = CD_MPX * OCH / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_cd[];
     unsigned char* ring = smem_cd;                                   // [3 slots][2 planes][CD_PL] pixels
@@ -104,6 +109,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ALP ? 2 : 1
 #pragma unroll
         for (int ks = 0; ks < 36; ++ks) wr[ks] = Wf[ks * 64];
     }
+#ifdef DEX_LP_WSPLIT
+    uint4 wl[36];                        // split weights: the lo halves (the whole [2 ct][36][64 lanes] pack behind the hi one)
+    {
+        const uint4* Wf = reinterpret_cast<const uint4*>(p.Wfrag) + 2L * 36 * 64 + (long)ct * 36 * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < 36; ++ks) wl[ks] = Wf[ks * 64];
+    }
+#endif
     if (tid < CD_C) bs[tid] = p.bias[tid];
     row_store(2 * r0 - 1, Ra);
     row_store(2 * r0, Rb);
@@ -126,8 +139,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ALP ? 2 : 1
                 // input column 2*(ow0 + pt*32 + i) - 1 + kw = patch column 2*(pt*32 + i) + kw
                 const unsigned char* xr = rowp + ((kw & 1) * CD_PL + pt * 32 + i + (kw >> 1)) * CD_PXB + hh * 16;
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    acc = DEX_MFMA_LP(__builtin_bit_cast(lp8, wr[(kh * 3 + kw) * 4 + ks]), *reinterpret_cast<const lp8*>(xr + ks * 32), acc, 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks) {
+                    const lp8 xv = *reinterpret_cast<const lp8*>(xr + ks * 32);
+                    acc = DEX_MFMA_LP(__builtin_bit_cast(lp8, wr[(kh * 3 + kw) * 4 + ks]), xv, acc, 0, 0, 0);
+#ifdef DEX_LP_WSPLIT
+                    acc = DEX_MFMA_LP(__builtin_bit_cast(lp8, wl[(kh * 3 + kw) * 4 + ks]), xv, acc, 0, 0, 0);
+#endif
+                }
             }
         }
         lds_barrier();              // every wave is past its reads of the ring and of the previous tile's output stage

@@ -112,6 +112,16 @@ __global__ __launch_bounds__(256) void convt_up_kernel(const ConvTUpP p) {
 #pragma unroll
             for (int ks = 0; ks < 16; ++ks) wr[ct][ks] = Wf[(ct * 16 + ks) * 64 + lane];
     }
+#ifdef DEX_LP_WSPLIT
+    uint4 wl[2][16];                     // split weights: the lo halves of this parity's matrix (its pack of 2 x 16 x 64 fragments behind the hi one)
+    {
+        const uint4* Wf = reinterpret_cast<const uint4*>(p.Wfrag[wave]) + 2L * 16 * 64;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) wl[ct][ks] = Wf[(ct * 16 + ks) * 64 + lane];
+    }
+#endif
     uint4 ra[G::NL], rb[ALP ? 1 : G::NL];
     float rm[G::NL];
     {
@@ -147,7 +157,12 @@ __global__ __launch_bounds__(256) void convt_up_kernel(const ConvTUpP p) {
             for (int pt = 0; pt < MT; ++pt) {
                 const lp8 xb = *reinterpret_cast<const lp8*>(xr + pt * 32 * CU_PXB);
 #pragma unroll
-                for (int ct = 0; ct < 2; ++ct) acc[ct][pt] = DEX_MFMA_LP(__builtin_bit_cast(lp8, wr[ct][ks]), xb, acc[ct][pt], 0, 0, 0);
+                for (int ct = 0; ct < 2; ++ct) {
+                    acc[ct][pt] = DEX_MFMA_LP(__builtin_bit_cast(lp8, wr[ct][ks]), xb, acc[ct][pt], 0, 0, 0);
+#ifdef DEX_LP_WSPLIT
+                    acc[ct][pt] = DEX_MFMA_LP(__builtin_bit_cast(lp8, wl[ct][ks]), xb, acc[ct][pt], 0, 0, 0);
+#endif
+                }
             }
         }
         lds_barrier();              // every wave is past the previous tile's reads of the output stage, and past this tile's reads of the ring

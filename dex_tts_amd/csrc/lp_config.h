@@ -22,6 +22,10 @@
 #define DEX_WS_HAVE_RC 1
 #define DEX_WS_HAVE_RC64 1
 #define DEX_WS_HAVE_RCC 1
+#define DEX_WS_HAVE_PE 1
+#define DEX_WS_HAVE_POS 1
+#define DEX_WS_HAVE_DOWN 1
+#define DEX_WS_HAVE_UP 1
 #elif defined(DEX_LP_F16)
 #define DEX_LP_NS f16
 #else

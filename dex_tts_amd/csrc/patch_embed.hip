@@ -35,10 +35,21 @@ __global__ __launch_bounds__(256) void patch_embed_fused_kernel(const DwConvP p,
     const int ntile = hid / 32, per_wave = ntile / 4;       // hid % 128 == 0
     union Fr { uint4 u; lp8 v; };
     Fr wf[2][KSTEPS];                                       // up to two column tiles in flight per pass (hidden 256: all of them)
+#ifdef DEX_LP_WSPLIT
+    Fr wl[2][KSTEPS];                                       // split weights: the lo halves, hid * C elements behind (the twin's second pack)
+#endif
     auto wload_tile = [&](int slot, int nt) __attribute__((always_inline)) {
         const u16* src = Wb + (long)(nt * 32 + i) * C + hh * 8;
 #pragma unroll
         for (int ks = 0; ks < KSTEPS; ++ks) wf[slot][ks].u = *reinterpret_cast<const uint4*>(src + ks * 16);
+    };
+    // (the lo halves are requested after the depthwise phase: next to its 49 taps in flight they would not fit the register file)
+    auto wload_lo = [&](int slot, int nt) __attribute__((always_inline)) {
+#ifdef DEX_LP_WSPLIT
+        const u16* src = Wb + (long)hid * C + (long)(nt * 32 + i) * C + hh * 8;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) wl[slot][ks].u = *reinterpret_cast<const uint4*>(src + ks * 16);
+#endif
     };
     wload_tile(0, wave * per_wave);
     if (per_wave > 1) wload_tile(1, wave * per_wave + 1);
@@ -74,6 +85,8 @@ __global__ __launch_bounds__(256) void patch_embed_fused_kernel(const DwConvP p,
         o.x = pack2_lp(silu_pe(acc.x), silu_pe(acc.y)); o.y = pack2_lp(silu_pe(acc.z), silu_pe(acc.w));
         *reinterpret_cast<uint2*>(As + tl * LD + cq * 4) = o;
     }
+    wload_lo(0, wave * per_wave);
+    if (per_wave > 1) wload_lo(1, wave * per_wave + 1);
     __syncthreads();
     // ---- pointwise GEMM: this wave's column tiles, K = C
     const u16* a_lane = As + i * LD + hh * 8;
@@ -89,6 +102,9 @@ __global__ __launch_bounds__(256) void patch_embed_fused_kernel(const DwConvP p,
             for (int ks = 0; ks < KSTEPS; ++ks) {
                 const lp8 af = *reinterpret_cast<const lp8*>(a_lane + ks * 16);
                 acc = DEX_MFMA_LP(af, wf[s_][ks].v, acc, 0, 0, 0);
+#ifdef DEX_LP_WSPLIT
+                acc = DEX_MFMA_LP(af, wl[s_][ks].v, acc, 0, 0, 0);
+#endif
             }
             const float bv = bias ? bias[nt * 32 + i] : 0.f;
             // accumulator rows (r & 3) + 8 (r >> 2) + 4 hh: rows 0..7 are r = 0..3 of both lane halves
@@ -99,8 +115,8 @@ __global__ __launch_bounds__(256) void patch_embed_fused_kernel(const DwConvP p,
             }
         }
         if (t0 + 2 < per_wave) {                           // hidden > 256: next pair of column tiles
-            wload_tile(0, wave * per_wave + t0 + 2);
-            if (t0 + 3 < per_wave) wload_tile(1, wave * per_wave + t0 + 3);
+            wload_tile(0, wave * per_wave + t0 + 2); wload_lo(0, wave * per_wave + t0 + 2);
+            if (t0 + 3 < per_wave) { wload_tile(1, wave * per_wave + t0 + 3); wload_lo(1, wave * per_wave + t0 + 3); }
         }
     }
 }

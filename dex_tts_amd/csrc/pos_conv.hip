@@ -64,12 +64,20 @@ __device__ __forceinline__ void pos_conv_body(const PosConvP& p, int rest) {
     // ---- weight ring: taps wave, wave+4, wave+8, wave+12 in flight before the patch is staged
     const u32x4* Wf = reinterpret_cast<const u32x4*>(p.Wf) + (long)g * (KP * KP * 2 * 64) + lane;
     u32x4 wr[4][2];
+#ifdef DEX_LP_WSPLIT
+    u32x4 wl[4][2];                                         // split weights: the lo halves ride the same ring, one whole pack (G groups) behind
+    const long lo_u4 = (long)p.G * (KP * KP * 2 * 64);
+#define PC_LOAD_LO(d, tap) do { wl[d][0] = Wf[lo_u4 + ((tap) * 2 + 0) * 64]; wl[d][1] = Wf[lo_u4 + ((tap) * 2 + 1) * 64]; } while (0)
+#else
+#define PC_LOAD_LO(d, tap) do { } while (0)
+#endif
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
         const int t = wave + 4 * d;                         // < 16 <= ntaps
         const int tap = (kh_lo + t / tdiv) * KP + (t % tdiv);
         wr[d][0] = Wf[(tap * 2 + 0) * 64];
         wr[d][1] = Wf[(tap * 2 + 1) * 64];
+        PC_LOAD_LO(d, tap);
     }
     // ---- stage the patch: item = (row, patch column, 8-channel chunk); zero outside the token grid
     {
@@ -130,13 +138,19 @@ __device__ __forceinline__ void pos_conv_body(const PosConvP& p, int rest) {
                 const lp8 a1 = *reinterpret_cast<const lp8*>(ap + (((2 + hh) ^ sw) * 8));
                 acc[ct] = DEX_MFMA_LP(a0, b0, acc[ct], 0, 0, 0);
                 acc[ct] = DEX_MFMA_LP(a1, b1, acc[ct], 0, 0, 0);
+#ifdef DEX_LP_WSPLIT
+                acc[ct] = DEX_MFMA_LP(a0, __builtin_bit_cast(lp8, wl[d][0]), acc[ct], 0, 0, 0);
+                acc[ct] = DEX_MFMA_LP(a1, __builtin_bit_cast(lp8, wl[d][1]), acc[ct], 0, 0, 0);
+#endif
             }
             const int tn = min(t + 16, ntaps - 4 + wave);   // refill (clamped re-read at the tail, never consumed)
             const int tap = (kh_lo + tn / tdiv) * KP + (tn % tdiv);
             wr[d][0] = Wf[(tap * 2 + 0) * 64];
             wr[d][1] = Wf[(tap * 2 + 1) * 64];
+            PC_LOAD_LO(d, tap);
         }
     }
+#undef PC_LOAD_LO
     // ---- sum the four waves' accumulators through LDS (the patch is dead), store raw sums
     lds_barrier();
     float* red = reinterpret_cast<float*>(smem_pc);          // [4][CT][32 rows][33]
