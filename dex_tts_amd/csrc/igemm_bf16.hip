@@ -218,8 +218,7 @@ __global__ __launch_bounds__(256) void igemm_lp_ss_kernel(const IGemmP p) {
     u16* As = smem_ss;
     u16* Bs = smem_ss + BM * LDS_LD;
 #ifdef DEX_LP_WSPLIT
-    u16* Bl = Bs + BN * LDS_LD;                              // lo halves of the weight tile (launcher: + BN rows of LDS)
-    const bool has_lo = p.w_lo_off != 0;
+    const bool has_lo = p.w_lo_off != 0;                     // (a 16-bit operand built at run time has no lo half: one MFMA per product)
 #endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
@@ -246,12 +245,13 @@ __global__ __launch_bounds__(256) void igemm_lp_ss_kernel(const IGemmP p) {
         br[j] = *reinterpret_cast<const uint4*>(Wb + (long)(n0 + n) * K + c8);
     }
 #ifdef DEX_LP_WSPLIT
-    uint4 bl_[BIT];
+    // the lo halves of this wave's weight columns go straight into B-operand registers (lane = column i, K half hh: 16 contiguous
+    // bytes of a weight row per K-step) - a second LDS tile would halve the workgroups per CU (measured: 14 -> 32 us at B = 1)
+    uint4 bl_[K / 16];
+    {
+        const u16* wl = Wb + p.w_lo_off + (long)(n0 + wn * 32 + i) * K + hh * 8;
 #pragma unroll
-    for (int j = 0; j < BIT; ++j) {
-        const int it = tid + 256 * j;
-        const int n = it / KC, c8 = (it % KC) * 8;
-        bl_[j] = *reinterpret_cast<const uint4*>(Wb + p.w_lo_off + (long)(n0 + n) * K + c8);
+        for (int ks = 0; ks < K / 16; ++ks) bl_[ks] = has_lo ? *reinterpret_cast<const uint4*>(wl + ks * 16) : make_uint4(0, 0, 0, 0);
     }
 #endif
 #pragma unroll
@@ -288,9 +288,6 @@ __global__ __launch_bounds__(256) void igemm_lp_ss_kernel(const IGemmP p) {
                 const int it = tid + 256 * j;
                 const int n = it / KC, c8 = (it % KC) * 8;
                 *reinterpret_cast<uint4*>(Bs + n * LDS_LD + c8) = br[j];
-#ifdef DEX_LP_WSPLIT
-                *reinterpret_cast<uint4*>(Bl + n * LDS_LD + c8) = bl_[j];
-#endif
             }
         }
 #pragma unroll
@@ -338,15 +335,12 @@ __global__ __launch_bounds__(256) void igemm_lp_ss_kernel(const IGemmP p) {
 #pragma unroll
     for (int ks = 0; ks < K / 16; ++ks) {
         const lp8 bf = *reinterpret_cast<const lp8*>(bp + ks * 16);
-#ifdef DEX_LP_WSPLIT
-        const lp8 bl = *reinterpret_cast<const lp8*>(bp + BN * LDS_LD + ks * 16);
-#endif
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             const lp8 af = *reinterpret_cast<const lp8*>(ap + t * 32 * LDS_LD + ks * 16);
             acc[t] = DEX_MFMA_LP(af, bf, acc[t], 0, 0, 0);
 #ifdef DEX_LP_WSPLIT
-            if (has_lo) acc[t] = DEX_MFMA_LP(af, bl, acc[t], 0, 0, 0);
+            if (has_lo) acc[t] = DEX_MFMA_LP(af, __builtin_bit_cast(lp8, bl_[ks]), acc[t], 0, 0, 0);
 #endif
         }
     }
@@ -576,11 +570,7 @@ static void launch_nwalk(const IGemmP& p, hipStream_t st) {
 
 template <int K>
 static void launch_ss(const IGemmP& p, hipStream_t st) {
-#ifdef DEX_LP_WSPLIT
-    const size_t lds = (size_t)(64 + 2 * 64) * (K + 8) * sizeof(u16);        // + the lo halves of the weight tile
-#else
     const size_t lds = (size_t)(64 + 64) * (K + 8) * sizeof(u16);
-#endif
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_lp_ss_kernel<64, 64, K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -597,9 +587,6 @@ static bool ss_eligible(const IGemmP& p) {
     if (p.a_lp && (p.ln_shift || p.KH != 1 || p.KW != 1 || (p.Cin % 8) != 0)) return false;      // 16-bit A: plain 1x1 rows only
     if (p.ksplit != 1 || p.groups != 1 || (p.N % 64) != 0) return false;
     if (p.K != 64 && p.K != 128 && p.K != 256 && p.K != 512) return false;
-#ifdef DEX_LP_WSPLIT
-    if (p.K == 512) return false;             // A + hi + lo tiles of 520 columns do not fit the LDS
-#endif
     const long blocks = (long)((p.Ho * p.Wo + 63) / 64) * (p.N / 64) * p.B;
     // (K <= 128 - the DEX TV adaptor's 1x1 convs at batch size: one round trip instead of a two-tile loop, 124 -> 114 us for the pair)
     return blocks <= (p.K <= 128 ? 16384 : 4096) || p.ln_shift != nullptr;

@@ -1,0 +1,136 @@
+"""The split-weight mode (DEX_PREC_FP16X2, `precision = "fp16x2"`): fp16 MFMA operands with every weight as hi + lo
+(w = fp16(w) + fp16(w - fp16(w)), two MFMAs per product), activations rounded once.
+
+Why it exists (oracle/lowp_emulate.py): over a 50-step sampler the distance of the fp16 mode from the fp32 reference is the
+WEIGHT rounding - a fixed perturbation of the model applied coherently at every step (2.0e-4 mean with both operands rounded,
+1.97e-4 with only the weights, 7.6e-5 with only the activations).  Splitting the weights alone lands inside the fp32-grade
+sampler bound the round-3 verdict asked a fast mode for (max <= 1e-3 and mean <= 1e-4 against the oracle) at 0.8x the speed
+of the fp16 mode instead of 0.27x for the exact-fp32 mode.
+
+Checks: (1) the benchmarked job against the ORACLE inside that bound; (2) with weights that are exactly representable in
+fp16 (lo = 0 everywhere) the mode is BITWISE the fp16 mode - the hi path is the fp16 mode's and a zero lo adds exactly
+nothing - at the B = 1 shape, where both modes pick the same kernel forms; (3) graph replay == eager; (4) single calls,
+a ragged batch, DEX and the long-form shape against the oracle; (5) the mode is closer to the oracle than the fp16 mode on
+every one of them."""
+import numpy as np
+import pytest
+import torch
+
+from tests import gpu_util as U
+from tests.tolerances import lowp_bounds
+
+pytestmark = pytest.mark.gpu
+record = U.record
+
+
+def _need():
+    from dex_tts_amd import _lib
+    if "fp16x2" not in _lib.PRECISION:
+        pytest.skip("fp16x2 is not built")
+
+
+def _check(tag, kind, got, ref):
+    e = np.abs(got - ref)
+    record(f"{tag}:fp16x2:{kind}", max=e.max(), mean=e.mean(), ref_absmax=np.abs(ref).max())
+    mx, mn = lowp_bounds(tag, "fp16x2", kind)
+    assert np.isfinite(got).all()
+    assert e.max() <= mx and e.mean() <= mn, (tag, kind, float(e.max()), float(e.mean()), mx, mn)
+    return float(e.max()), float(e.mean())
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_cfg1_sampler_n50_inside_the_fp32_grade_bound(graph):
+    """BASELINE.json configs[1] (GeDEX-LJ, B=1, T=512, 50 Euler steps) against 50 oracle steps: max <= 1e-3 AND mean <= 1e-4
+    (tests/tolerances.py holds the tighter 8e-4 / 1e-4), and closer to the oracle than the fp16 mode."""
+    _need()
+    cfg, eng, w = U.engine_for("gedex_lj")
+    case = U.make_case(cfg, B=1, T=512)
+    try:
+        eng.set_precision("fp16x2")
+        got, ref = U.run_sampler("gedex_lj", case, 50, use_graph=graph)
+        eng.set_precision("fp16")
+        got16, _ = U.run_sampler("gedex_lj", case, 50, use_graph=graph)
+    finally:
+        eng.set_precision("fp32")
+    mx, mn = _check(f"cfg1_T512_n50_graph{int(graph)}", "sampler", got, ref)
+    assert mx <= 1e-3 and mn <= 1e-4
+    e16 = np.abs(got16 - ref)
+    assert mn < 0.6 * e16.mean(), (mn, float(e16.mean()))
+
+
+def test_cfg1_single_calls_vs_oracle():
+    _need()
+    cfg, eng, w = U.engine_for("gedex_lj")
+    case = U.make_case(cfg, B=1, T=512)
+    try:
+        eng.set_precision("fp16x2")
+        for sigma in (80.0, 1.0, 0.002):
+            got, ref, _ = U.run_precond("gedex_lj", case, sigma, with_taps=False)
+            _check(f"cfg1_T512_sigma{sigma}", "call", got, ref)
+    finally:
+        eng.set_precision("fp32")
+
+
+def test_weights_on_the_fp16_grid_give_the_fp16_mode_bitwise():
+    """lo = fp16(w - fp16(w)) is exactly zero for a weight that fp16 represents: the split mode then computes the fp16 mode's products
+    plus exact zeros.  (B = 1, T = 512: every launch takes the same kernel form in both modes.)"""
+    _need()
+    from dex_tts_amd import synth, config as C
+    from dex_tts_amd.engine import ScoreNetEngine
+    cfg = C.PRESETS["gedex_lj"]()
+    dev = torch.device("cuda:0")
+    weights = {k: torch.from_numpy(v).to(torch.float16).to(torch.float32) for k, v in synth.make_weights(C.param_shapes(cfg)).items()}
+    eng = ScoreNetEngine(cfg, dev)
+    eng.load_weights(weights)
+    mu, mask, z, _ = synth.make_inputs(1, 512, None, seed=1234)
+    mu, mask, z = (torch.from_numpy(a).to(dev) for a in (mu, mask, z))
+    eng.set_precision("fp16")
+    y16 = eng.sample(z, mask, mu, 6)
+    eng.set_precision("fp16x2")
+    y2 = eng.sample(z, mask, mu, 6)
+    assert torch.isfinite(y2).all()
+    assert torch.equal(y16, y2), float((y16 - y2).abs().max())
+
+
+@pytest.mark.parametrize("name,B,T,n", [("gedex_lj", 3, 132, 10), ("gedex_vctk", 2, 96, 6), ("dex_vctk", 2, 64, 6), ("gedex_lj", 1, 4000, 3)])
+def test_other_shapes_vs_oracle_and_vs_fp16(name, B, T, n):
+    """ragged batch, speaker plane, DEX adaptors (their per-utterance folded weights stay plain fp16 operands), long form: against the
+    oracle inside the mode's small-shape bounds, never further from it than the fp16 mode, and graph replay == eager bitwise."""
+    _need()
+    cfg, eng, w = U.engine_for(name)
+    lengths = None if B == 1 else [T - 7 * i for i in range(B)]
+    case = U.make_case(cfg, B=B, T=T, lengths=lengths)
+    try:
+        eng.set_precision("fp16x2")
+        got, ref = U.run_sampler(name, case, n)
+        got_g, _ = U.run_sampler(name, case, n, use_graph=True)
+        eng.set_precision("fp16")
+        got16, _ = U.run_sampler(name, case, n)
+    finally:
+        eng.set_precision("fp32")
+    assert np.array_equal(got, got_g)
+    mx, mn = _check(f"x2_{name}_B{B}_T{T}_n{n}", "sampler", got, ref)
+    e16 = np.abs(got16 - ref)
+    record(f"x2_{name}_B{B}_T{T}_n{n}:fp16:sampler", max=e16.max(), mean=e16.mean())
+    assert mn <= 1.05 * e16.mean(), (mn, float(e16.mean()))
+
+
+@pytest.mark.parametrize("name,B,T,n,kw", [("gedex_lj", 8, 512, 10, {}), ("dex_vctk", 32, 256, 4, dict(Tr=348, Ts=348))])
+def test_batch_forms_vs_oracle(name, B, T, n, kw):
+    """The batch forms of the split mode (patch convolution at every size - the strip kernels keep their weights in registers / LDS and
+    have no room for a second set -, 32- and 64-row DiT chains with the lo fragments fetched inside the MFMA chain, the 64-query
+    attention): GeDEX B = 8 at T = 512 and BASELINE.json configs[2] (DEX-VCTK B = 32, T = 256, 348 reference frames)."""
+    _need()
+    cfg, eng, w = U.engine_for(name)
+    case = U.make_case(cfg, B=B, T=T, **kw)
+    try:
+        eng.set_precision("fp16x2")
+        got, ref = U.run_sampler(name, case, n)
+        eng.set_precision("fp16")
+        got16, _ = U.run_sampler(name, case, n)
+    finally:
+        eng.set_precision("fp32")
+    mx, mn = _check(f"x2_batch_{name}_B{B}_T{T}_n{n}", "sampler", got, ref)
+    e16 = np.abs(got16 - ref)
+    record(f"x2_batch_{name}_B{B}_T{T}_n{n}:fp16:sampler", max=e16.max(), mean=e16.mean())
+    assert mn <= 1.05 * e16.mean(), (mn, float(e16.mean()))

@@ -30,6 +30,8 @@ LOWP = {
     "bf16": {"call": (5e-2, 6.5e-3), "sampler": (5e-2, 7.5e-3)},
     # (round 3: the 3-utterance ragged batch with a 77-frame utterance of tests/test_gpu_cluster.py reaches 4.6e-3 max in BOTH forms of the DiT block)
     "fp16": {"call": (6e-3, 7.5e-4), "sampler": (7e-3, 6e-4)},
+    # fp16x2 (fp16 operands, weights as hi + lo): what is left is the rounding of the activations (small fuzz shapes, few steps)
+    "fp16x2": {"call": (4e-3, 5e-4), "sampler": (4e-3, 4e-4)},
 }
 
 
@@ -43,6 +45,11 @@ LOWP_AT = {
     ("cfg1_T512_n50", "fp16", "sampler"): (1.8e-3, 3.3e-4),      # measured 8.66e-4 / 1.64e-4
     ("cfg1_T512_sigma", "bf16", "call"): (2.7e-2, 5.1e-3),       # worst of the three sigmas: 1.34e-2 / 2.53e-3
     ("cfg1_T512_sigma", "fp16", "call"): (3.6e-3, 6.2e-4),       # 1.80e-3 / 3.07e-4
+    # the split-weight mode at the benchmarked job: the fast mode inside the fp32-grade sampler bound the round-3 verdict set
+    # (max <= 1e-3 AND mean <= 1e-4 against the oracle); measured 3.9e-4 / 6.9e-5
+    ("cfg1_T512_n50", "fp16x2", "sampler"): (8.0e-4, 1.0e-4),
+    ("cfg1_T512_sigma", "fp16x2", "call"): (2.6e-3, 4.2e-4),     # single calls: the weights' share of a call's rounding is small; set from the first run
+    ("cfg1_b32_n50", "fp16x2", "sampler"): (1.4e-3, 1.4e-4),     # GeDEX B=32 T=512 (ragged): measured 7.1e-4 / 7.1e-5
     # configs[2]: DEX-VCTK B=32 T=256 Tr=Ts=348
     ("cfg2_dex_b32_n4", "bf16", "sampler"): (4.3e-2, 5.4e-3),    # 2.12e-2 / 2.68e-3
     ("cfg2_dex_b32_n4", "fp16", "sampler"): (6.0e-3, 6.8e-4),    # 2.96e-3 / 3.39e-4
