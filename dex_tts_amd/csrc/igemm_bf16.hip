@@ -391,6 +391,15 @@ __global__ __launch_bounds__(256) void igemm_lp_nwalk_kernel(const IGemmP p) {
         const int it = tid + 256 * j;                                                                               \
         *reinterpret_cast<u32x4*>(Bs + (it / KC) * LDS_LD + (it % KC) * 8) = br[j];                                 \
     }
+#ifdef DEX_LP_WSPLIT
+    // split weights: the lo fragments of this wave's 32 columns go straight into B-operand registers (as in the single-shot kernel),
+    // one column tile ahead like the hi tile
+    const bool has_lo = p.w_lo_off != 0;
+    u32x4 bl_[2][K / 16];
+    const u16* Wlo = Wb + p.w_lo_off + (long)(wn * 32 + i) * K + hh * 8;
+#define NW_LOAD_LO(slot, nt_) _Pragma("unroll") for (int ks_ = 0; ks_ < K / 16; ++ks_) bl_[slot][ks_] = *reinterpret_cast<const u32x4*>(Wlo + (long)(nt_) * BN * K + ks_ * 16);
+    NW_LOAD_LO(0, 0)
+#endif
     NW_LOAD_B(0)
 #pragma unroll
     for (int a0 = 0; a0 < AIT; a0 += ABATCH) {
@@ -461,8 +470,17 @@ __global__ __launch_bounds__(256) void igemm_lp_nwalk_kernel(const IGemmP p) {
     }
     const float* omask = p.outmask ? p.outmask + (long)b * p.mask_bstride : nullptr;
     float* Cb = p.C + (long)b * p.c_bstride + p.c_coff;
+#ifdef DEX_LP_WSPLIT
+    for (int nt2 = 0; nt2 < ntile; nt2 += 2)
+#pragma unroll
+    for (int par_ = 0; par_ < 2; ++par_) {                 // (two tiles per trip: the lo ring's slot index is a constant)
+        const int nt = nt2 + par_;
+        if (nt >= ntile) break;
+        if (nt + 1 < ntile) { NW_LOAD_B(nt + 1) NW_LOAD_LO((par_ ^ 1), nt + 1) }
+#else
     for (int nt = 0; nt < ntile; ++nt) {
         if (nt + 1 < ntile) { NW_LOAD_B(nt + 1) }
+#endif
         float u_mk[16];
         int u_p1 = 0, u_p2 = 0, u_c = 0;
         {
@@ -485,6 +503,9 @@ __global__ __launch_bounds__(256) void igemm_lp_nwalk_kernel(const IGemmP p) {
             for (int t = 0; t < MT; ++t) {
                 const lp8 af = *reinterpret_cast<const lp8*>(ap + t * 32 * LDS_LD + ks * 16);
                 acc[t] = DEX_MFMA_LP(af, bf, acc[t], 0, 0, 0);
+#ifdef DEX_LP_WSPLIT
+                if (has_lo) acc[t] = DEX_MFMA_LP(af, __builtin_bit_cast(lp8, bl_[par_][ks]), acc[t], 0, 0, 0);
+#endif
             }
         }
         {

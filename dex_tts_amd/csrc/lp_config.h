@@ -26,6 +26,7 @@
 #define DEX_WS_HAVE_POS 1
 #define DEX_WS_HAVE_DOWN 1
 #define DEX_WS_HAVE_UP 1
+#define DEX_WS_HAVE_NWALK 1
 #elif defined(DEX_LP_F16)
 #define DEX_LP_NS f16
 #else
