@@ -135,7 +135,11 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_lp_kernel(const Conv3P p) {
     constexpr int NIP = (NI + NPASS - 1) / NPASS;        // (1 workgroup per CU instead of 2: measured 16 -> 22 us at 40x256)
 #ifdef DEX_LP_WSPLIT
     // split weights: the nine taps run twice over the same patch - taps 9..17 are the lo halves of the weights, p.w_lo_off elements
-    // behind their hi halves (same [COUT][9*Cin] layout); the 1x1 shortcut's lo half replaces its hi half in rbuf after the centre tap
+    // behind their hi halves (same [COUT][9*Cin] layout); the 1x1 shortcut's lo half replaces its hi half in rbuf after the centre tap.
+    // Two other routes for the lo halves were built and measured SLOWER than this second pass through the LDS ring: per-wave register
+    // rings fed from the row-major twin (a lane's 16 bytes of a weight row = 64 separate lines per load instruction: B = 1 19.3 -> 16.5 k
+    // frames/s, B = 32 50.8 -> 36.8 k) and from a fragment-order twin (coalesced, but every wave of a workgroup fetches the same
+    // fragments from L2 again, where the LDS ring loads them once per workgroup: 19.3 -> 18.1 k, 54.5 -> 45.9 k).
     constexpr int NTAP = 18;
 #else
     constexpr int NTAP = 9;
