@@ -1224,8 +1224,11 @@ struct Runner {
                     ad.o_lp = o_lp ? 1 : 0;
                     // tail split of the 64-query form (attention_q64.hip): whole units for the first query groups, a key split for the
                     // last ones, so that a chip-filling round of long units is followed by a round of short ones; the 64-row chain merges
-                    // the tail rows' partials (O slots 1.., fp32) and reads the other rows as before.  DEX_ATTN_Q64_TAIL=0 switches it off.
-                    if (q64 && ks == 1 && dit_rowchain64_form(N, B, 0) && knob_or("DEX_ATTN_Q64_TAIL", 1) != 0) {
+                    // the tail rows' partials (O slots 1.., fp32) and reads the other rows as before.  OPT-IN (DEX_ATTN_Q64_TAIL=1): measured at
+                    // DEX B = 32, N = 1300 the attention launch gains 4.5 us (70.0 -> 65.5: fp32 partials + (m, l) instead of 16-bit rows eat most
+                    // of the 13 us the unit plan predicts and tools/attnq64 measures on fp32 outputs) and the 64-row chain loses 6.2 us merging
+                    // the tail rows (79.2 -> 85.4): -0.3 % end to end (profiles/round4_attention_tail_split_ab.txt).
+                    if (q64 && ks == 1 && dit_rowchain64_form(N, B, 0) && knob_or("DEX_ATTN_Q64_TAIL", 0) != 0) {
                         int pks = 1, tg = 0, tk = 1;
                         attention_q64_plan(N, B, att_split_cap((long)B * N), &pks, &tg, &tk);
                         if (pks == 1 && tk > 1) { ad.tail_g = tg; ad.tail_ks = tk; ad.ml = P.att_ml; tail_row0 = tg * 256; tail_ks = tk; }

@@ -310,3 +310,29 @@ def test_xcd_aware_block_order_is_bit_identical(name, kw):
         os.environ.pop("DEX_XCD_MAP", None)
         eng.set_precision("fp32")
     assert np.isfinite(ys[0]).all() and np.array_equal(ys[0], ys[1]), float(np.abs(ys[0] - ys[1]).max())
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_cfg2_attention_tail_split_vs_oracle_and_vs_whole_units(prec):
+    """The 64-query attention's opt-in tail split (DEX_ATTN_Q64_TAIL=1: whole units for the first query groups, a two-way key split for
+    the last ones, merged by the 64-row chain) at configs[2]'s shape: inside the mode's bound against the oracle, and within the
+    mode's rounding of the default plan (the tail rows are merged from fp32 partials instead of read as 16-bit rows: not bitwise)."""
+    cfg, eng, w = U.engine_for("dex_vctk")
+    case = _cfg2_case(cfg)
+    set_prec(eng, prec)
+    old = os.environ.get("DEX_ATTN_Q64_TAIL")
+    try:
+        base, ref = U.run_sampler("dex_vctk", case, 4)
+        os.environ["DEX_ATTN_Q64_TAIL"] = "1"
+        got, _ = U.run_sampler("dex_vctk", case, 4)
+    finally:
+        eng.set_precision("fp32")
+        if old is None:
+            os.environ.pop("DEX_ATTN_Q64_TAIL", None)
+        else:
+            os.environ["DEX_ATTN_Q64_TAIL"] = old
+    check_lowp("cfg2_dex_b32_n4_tail", prec, "sampler", got, ref)
+    d = np.abs(got - base)
+    record(f"cfg2_dex_b32_n4_tail_vs_default:{prec}:sampler", max=d.max(), mean=d.mean())
+    mx, mn = __import__("tests.tolerances", fromlist=["x"]).lowp_bounds("cfg2_dex_b32_n4", prec, "sampler")
+    assert d.max() <= mx and d.mean() <= mn and d.max() > 0.0
