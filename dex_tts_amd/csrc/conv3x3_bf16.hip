@@ -139,7 +139,9 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_lp_kernel(const Conv3P p) {
     // Two other routes for the lo halves were built and measured SLOWER than this second pass through the LDS ring: per-wave register
     // rings fed from the row-major twin (a lane's 16 bytes of a weight row = 64 separate lines per load instruction: B = 1 19.3 -> 16.5 k
     // frames/s, B = 32 50.8 -> 36.8 k) and from a fragment-order twin (coalesced, but every wave of a workgroup fetches the same
-    // fragments from L2 again, where the LDS ring loads them once per workgroup: 19.3 -> 18.1 k, 54.5 -> 45.9 k).
+    // fragments from L2 again, where the LDS ring loads them once per workgroup: 19.3 -> 18.1 k, 54.5 -> 45.9 k).  A third: hi and lo rows
+    // of a tap in ONE LDS tile for the 64-channel chunks (nine phases, each A fragment read once for both MFMAs): 19.3 -> 18.8 k,
+    // 54.5 -> 51.4 k - the doubled weight tile costs a resident workgroup per CU.
     constexpr int NTAP = 18;
 #else
     constexpr int NTAP = 9;

@@ -53,5 +53,15 @@ for k, c in agg.items():
     print(k, {a: round(b / 1e6, 2) for a, b in sorted(c.items())})
 PY
 done
+# the split-weight mode (fp16x2): kernel stats + one-step traces of the B = 1 and B = 32 jobs, MFMA utilisation of its kernels
+for w in gedex_b1 gedex_b32; do
+  rm -rf /tmp/px_$w
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/px_$w -o t -- python $R/bench.py --workload $w --precision fp16x2 --steps 2 --warmup 1 --graph off $B > $O/${w}_fp16x2_bench_under_rocprof.json 2>/dev/null
+  cp $(find /tmp/px_$w -name "*kernel_stats.csv" | head -1) $O/${w}_fp16x2_kernel_stats.csv
+  python $R/tools/trace_step.py $(find /tmp/px_$w -name "*kernel_trace.csv" | head -1) > $O/${w}_fp16x2_one_euler_step_trace.txt
+  rm -rf /tmp/pqx_$w
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d /tmp/pqx_$w -o pmc -- python $R/bench.py --workload $w --precision fp16x2 --steps 1 --warmup 0 --graph off $B > /dev/null 2>&1
+  python $R/tools/pmc_mfma.py ${w}_fp16x2 0 $(find /tmp/pqx_$w -name "*counter_collection.csv" | head -1) $O/mfma_util.json > $O/${w}_fp16x2_mfma_util.txt 2>&1
+done
 python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
 ls -la $O
