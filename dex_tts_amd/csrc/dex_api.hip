@@ -26,7 +26,7 @@ using namespace dex;
 namespace dex {
 namespace {
 const char* const KNOB_NAMES[] = {
-    "DEX_CONV_STREAM", "DEX_CONV_PP", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_ATTN_Q64", "DEX_ATTN_Q64_TAIL", "DEX_ATTN_GENERIC", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN",
+    "DEX_CONV_STREAM", "DEX_CONV_PP", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_ATTN_Q64", "DEX_ATTN_Q64_TAIL", "DEX_DIT_XCDS", "DEX_ATTN_GENERIC", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN",
     "DEX_DIT_CLUSTER", "DEX_DIT_CLUSTER_LOCAL", "DEX_ATTN_X_LP", "DEX_RES_X_LP", "DEX_CAT_LP", "DEX_XCD_MAP", "DEX_DEBUG_DROP_HANDOFF", "DEX_PATCH_FUSED",
     "DEX_CONV_DOWN", "DEX_CONVT_UP", "DEX_DEBUG_PLAN"};
 constexpr int N_KNOBS = (int)(sizeof(KNOB_NAMES) / sizeof(KNOB_NAMES[0]));
@@ -1168,6 +1168,7 @@ struct Runner {
                     x->last_xerr = ch.xerr;
                     ch.xdrop = knob_or("DEX_DEBUG_DROP_HANDOFF", 0);
                     ch.xlocal = (P.xlocal && ch.epoch < (1u << 24)) ? 1 : 0;
+                    ch.xcds = dit_rowchain_cluster_xcds(N, B);
                 }
             }
             if (chain && k == 0) {                                   // first block: LN + modulate + qkv only

@@ -990,7 +990,10 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain_cluster_kernel(const 
     const int N = p.rows_per_batch, tpb = (N + RC_ROWS - 1) / RC_ROWS;
     // p.xlocal: the four members of a cluster share blockIdx % 8, i.e. their XCD (clusters are dealt to the XCDs in rounds of 8;
     // the grid is padded to whole rounds and the clusters past the last tile leave here)
-    const int cluster = p.xlocal ? (int)(blockIdx.x & 7) + 8 * (int)(blockIdx.x / (8 * DIT_CLUSTER)) : (int)blockIdx.x / DIT_CLUSTER;
+    // p.xcds < 8: only the first xcds XCDs take clusters (every XCD's L2 that takes part fetches the block's 1.5 MB of weights and the
+    // K / V^T of its clusters from HBM once per launch: 8 L2s for 21 clusters was 27 MB of traffic for 4.4 MB of algorithmic bytes)
+    if (p.xlocal && (int)(blockIdx.x & 7) >= p.xcds) return;
+    const int cluster = p.xlocal ? (int)(blockIdx.x & 7) + p.xcds * (int)(blockIdx.x / (8 * DIT_CLUSTER)) : (int)blockIdx.x / DIT_CLUSTER;
     const int member = p.xlocal ? (int)(blockIdx.x >> 3) % DIT_CLUSTER : (int)blockIdx.x % DIT_CLUSTER;
     if (cluster >= p.B * tpb) return;
     const unsigned my_xcc = LOCAL ? xcc_id() : 0u;
@@ -1392,6 +1395,15 @@ bool dit_rowchain_cluster_local_fits(int rows_per_batch, int B) {
     const long tiles = (long)B * ((rows_per_batch + RC_ROWS - 1) / RC_ROWS);
     return on && dit_rowchain_cluster_form(rows_per_batch, B) && (tiles + 7) / 8 * 8 * DIT_CLUSTER <= 256;
 }
+// how many XCDs the XCD-local clusters of this launch are dealt to: the fewest that still give every workgroup a CU of its own
+// (32 CUs per XCD, one workgroup per CU), unless DEX_DIT_XCDS says otherwise
+int dit_rowchain_cluster_xcds(int rows_per_batch, int B) {
+    const long tiles = (long)B * ((rows_per_batch + RC_ROWS - 1) / RC_ROWS);
+    const int forced = knob_or("DEX_DIT_XCDS", 0);
+    int x = forced >= 1 && forced <= 8 ? forced : 8;
+    while (x < 8 && (tiles + x - 1) / x * DIT_CLUSTER > 32) ++x;          // (a forced value that does not fit is raised)
+    return x;
+}
 
 bool dit_rowchain_supported(int hidden, int mlp_hidden) {
 #if defined(DEX_LP_WSPLIT) && !defined(DEX_WS_HAVE_RC)
@@ -1418,7 +1430,8 @@ void launch_dit_rowchain(const DitChainP& p, hipStream_t st) {
             attrc = true;
         }
         const int tiles = p.B * ((p.rows_per_batch + RC_ROWS - 1) / RC_ROWS);
-        const dim3 gridc((p.xlocal ? (tiles + 7) / 8 * 8 : tiles) * DIT_CLUSTER);
+        const int xc = p.xlocal ? (p.xcds >= 1 && p.xcds <= 8 ? p.xcds : 8) : 8;
+        const dim3 gridc((p.xlocal ? (tiles + xc - 1) / xc * 8 : tiles) * DIT_CLUSTER);
         if (p.qkv_only) hipLaunchKernelGGL((dit_rowchain_cluster_kernel<true, false>), gridc, dim3(RC_NW * 64), RC_LDS_CLUSTER, st, p);
         else if (p.xdrop == 2) {        // tests only: L2-scope hand-offs between members dealt to DIFFERENT XCDs - must end as an error, never as a mel
             DitChainP q = p; q.xlocal = 0;

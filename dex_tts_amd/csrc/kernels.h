@@ -291,7 +291,8 @@ struct DitChainP { const float* O; int ksplit; long o_sstride; const float* ml; 
                    int xcd_map;                             // set by the launcher: row tiles of batch element b run on XCD b % 8 (in-kernel attention, B % 8 == 0)
                    int xlocal;                              // 1: the members of a cluster share an XCD (hand-offs through its L2; grid padded to rounds of 8 clusters)
                    int xdrop;
-                   int tail_row0 = 0, tail_ks = 0; };      // 64-row form: rows from tail_row0 on are merged from tail_ks fp32 partials in O slots 1.. (AttnDirectP::tail_g); 0 / 1 = off                            // tests only (DEX_DEBUG_DROP_HANDOFF): 1 member 3 never raises its flags -> the peers' waits time out; 2 L2-scope hand-offs across XCDs
+                   int tail_row0 = 0, tail_ks = 0;
+                   int xcds = 8; };            // xlocal: the clusters are dealt to the first `xcds` XCDs only (workgroups of the others leave at once): fewer L2s fetch the weights and K / V^T      // 64-row form: rows from tail_row0 on are merged from tail_ks fp32 partials in O slots 1.. (AttnDirectP::tail_g); 0 / 1 = off                            // tests only (DEX_DEBUG_DROP_HANDOFF): 1 member 3 never raises its flags -> the peers' waits time out; 2 L2-scope hand-offs across XCDs
 // cluster form of the row chain: workgroups per 32-row tile, bytes of exchange slab / flag words per tile, and whether a launch
 // of B x N rows takes it (all workgroups co-resident: <= one per CU)
 constexpr int DIT_CLUSTER = 4;
@@ -300,6 +301,7 @@ constexpr size_t DIT_CLUSTER_FLAG_WORDS = 2 * DIT_CLUSTER;
 bool dit_rowchain64_form(int rows_per_batch, int B, int attn_inline);     // the 64-row batch form takes this launch (the one that implements DitChainP::o_lp)
 bool dit_rowchain_cluster_form(int rows_per_batch, int B);
 bool dit_rowchain_cluster_local_fits(int rows_per_batch, int B);
+int dit_rowchain_cluster_xcds(int rows_per_batch, int B);          // XCDs the XCD-local clusters are dealt to (DitChainP::xcds)
 bool dit_rowchain_supported(int hidden, int mlp_hidden);
 // Softmax attention on the row chain's bf16 operands (2 heads x 128): no staging, K / V^T / Q fragments are read
 // straight from global memory.  O: fp32 [ksplit][B][N][256] partials + ml (merged by the next row chain launch).

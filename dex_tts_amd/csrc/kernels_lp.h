@@ -46,6 +46,7 @@ bool dit_rowchain_supported(int hidden, int mlp_hidden);
 bool dit_rowchain64_form(int rows_per_batch, int B, int attn_inline);
 bool dit_rowchain_cluster_form(int rows_per_batch, int B);
 bool dit_rowchain_cluster_local_fits(int rows_per_batch, int B);
+int dit_rowchain_cluster_xcds(int rows_per_batch, int B);
 void launch_dit_rowchain(const DitChainP& p, hipStream_t st);
 void launch_pack_lp_frag(const float* src, void* dst, int K, int N, hipStream_t st);
 void launch_pack_lp_frag_nk(const float* src, void* dst, int K, int N, hipStream_t st);   // source [N][K]

@@ -41,6 +41,7 @@ bool patch_embed_fused_supported(int k, int C, int hid, long ntok) { return (g_l
 bool dit_rowchain_supported(int hidden, int mlp_hidden) { return (g_lp_wsplit ? f16w::dit_rowchain_supported(hidden, mlp_hidden) : bf16::dit_rowchain_supported(hidden, mlp_hidden)); }
 bool dit_rowchain64_form(int rows_per_batch, int B, int attn_inline) { return (g_lp_wsplit ? f16w::dit_rowchain64_form(rows_per_batch, B, attn_inline) : bf16::dit_rowchain64_form(rows_per_batch, B, attn_inline)); }
 bool dit_rowchain_cluster_form(int rows_per_batch, int B) { return (g_lp_wsplit ? f16w::dit_rowchain_cluster_form(rows_per_batch, B) : bf16::dit_rowchain_cluster_form(rows_per_batch, B)); }
+int dit_rowchain_cluster_xcds(int rows_per_batch, int B) { return bf16::dit_rowchain_cluster_xcds(rows_per_batch, B); }
 bool dit_rowchain_cluster_local_fits(int rows_per_batch, int B) { return (g_lp_wsplit ? f16w::dit_rowchain_cluster_local_fits(rows_per_batch, B) : bf16::dit_rowchain_cluster_local_fits(rows_per_batch, B)); }
 
 #define DEX_LP_CALL(fn, ...) do { if (precision == PREC_FP16X2) f16w::fn(__VA_ARGS__); else if (precision == PREC_FP16) f16::fn(__VA_ARGS__); else bf16::fn(__VA_ARGS__); } while (0)
