@@ -39,6 +39,7 @@ WORKLOADS = {
     # name: (preset, B per GPU, T, n_timesteps, Tr/Ts, precision or None = --precision)
     "gedex_b1": ("gedex_lj", 1, 512, 50, 0, None),               # BASELINE.json configs[1]
     "gedex_b1_t800": ("gedex_lj", 1, 800, 50, 0, None),
+    "gedex_long_x2": ("gedex_lj", 1, 4000, 50, 0, "fp16x2"),     # configs[4]'s job in the split-weight mode (its parity leg)
     "gedex_b2": ("gedex_lj", 2, 512, 50, 0, None),               # small batches: the cluster form of the DiT block covers B x 21 <= 64 row tiles
     "gedex_b3": ("gedex_lj", 3, 512, 50, 0, None),
     "gedex_b32": ("gedex_lj", 32, 512, 50, 0, None),
@@ -54,7 +55,7 @@ CONFIG_TAG = {"gedex_b1": "BASELINE.json configs[1]", "dex_b32": "BASELINE.json 
               "gedex_b1_t800": "SURVEY 8(d) C2 at T=800", "gedex_b32": "BASELINE.json metric: batch = 32",
               "dex_esd_b32_n100": "BASELINE.json configs[3], per-GPU share (256 utterances / 8 GPUs)",
               "dex_esd_b256_n100": "BASELINE.json configs[3], all 256 utterances (strong scaling: / N ranks)",
-              "gedex_long": "BASELINE.json configs[4] shape"}
+              "gedex_long": "BASELINE.json configs[4] shape", "gedex_long_x2": "BASELINE.json configs[4] shape, fp16x2"}
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0, "f16": 2500.0}      # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
 # what the chip SUSTAINS on dense 16-bit MFMA with random operands on all CUs (tools/mfmaceil, profiles/round3_mfma_ceiling_random_operands.txt):
@@ -657,6 +658,7 @@ def main():
             if "fp16x2" in _lib.PRECISION:
                 res["configs"]["configs[2] parity mode"] = side_workload("dex_b32", "fp16x2", device, stream, "on", steps=3, profile=False)
                 res["configs"]["configs[3] parity mode"] = side_workload("dex_esd_b32_n100", "fp16x2", device, stream, "on", steps=2, profile=False)
+                res["configs"]["configs[4] parity mode"] = side_workload("gedex_long_x2", "fp16x2", device, stream, "on", steps=3, profile=False)
         if prof and args.workload == "gedex_b1" and not args.no_configs:
             res["vocoder"] = vocoder_block(device, stream)
             res["vocoder_bf16"] = vocoder_block(device, stream, precision="bf16")
