@@ -4,7 +4,7 @@ import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 from tests import gpu_util as U
 cfg, eng, w = U.engine_for("gedex_lj")
-eng.set_precision("bf16")
+eng.set_precision(os.environ.get("SOAK_PREC", "bf16"))
 print("xcd_local", eng.xcd_local())
 bad = 0; t0 = time.time()
 for name_kw in [dict(B=1, T=512), dict(B=3, T=512, lengths=[512, 300, 77]), dict(B=2, T=100, lengths=[100, 61])]:
