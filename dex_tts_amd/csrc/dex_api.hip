@@ -1634,6 +1634,7 @@ extern "C" {
 
 size_t dex_workspace_bytes(const DexCtx* x, int B, int T, int Tr, int Ts, int n_steps) {
     if (!x || B < 1 || T < 4) return 0;
+    const WsplitScope wsplit_scope(x->precision == DEX_PREC_FP16X2);      // (the plan asks the same shape predicates as the call will)
     Plan P; Dims d{B, T, Tr, Ts, n_steps < 1 ? 1 : n_steps};
     make_plan(x, d, nullptr, P);
     return P.bytes;
