@@ -134,3 +134,24 @@ def test_batch_forms_vs_oracle(name, B, T, n, kw):
     e16 = np.abs(got16 - ref)
     record(f"x2_batch_{name}_B{B}_T{T}_n{n}:fp16:sampler", max=e16.max(), mean=e16.mean())
     assert mn <= 1.05 * e16.mean(), (mn, float(e16.mean()))
+
+
+@pytest.mark.parametrize("name", ["gedex_lj", "dex_vctk"])
+def test_heun_and_churn_in_the_split_mode(name):
+    """The other branches of `ablation_sampler` (edm.py:194-214) run through the same split kernels: Heun (2n - 1 evaluations) against
+    the oracle inside the mode's small-shape bounds, graph replay == eager."""
+    _need()
+    cfg, eng, w = U.engine_for(name)
+    case = U.make_case(cfg, B=2, T=72, lengths=[72, 50])
+    try:
+        eng.set_precision("fp16x2")
+        got, ref = U.run_sampler(name, case, 7, solver="heun")
+        got_g, _ = U.run_sampler(name, case, 7, use_graph=True, solver="heun")
+    finally:
+        eng.set_precision("fp32")
+    assert np.array_equal(got, got_g)
+    from tests.tolerances import LOWP
+    e = np.abs(got - ref)
+    record(f"x2_heun_{name}_n7:fp16x2:sampler", max=e.max(), mean=e.mean())
+    mx, mn = LOWP["fp16x2_heun"]["sampler"]
+    assert np.isfinite(got).all() and e.max() <= mx and e.mean() <= mn, (float(e.max()), float(e.mean()))

@@ -45,7 +45,7 @@ def test_golden_precond_and_sampler(name, preset):
     _golden_precond_and_sampler(name, preset)
 
 
-@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "fp16x2"])
 def test_golden_libritts_reduced_precision(prec):
     """DEX-LibriTTS against the real reference's golden in the reduced-precision modes."""
     g = gold("dex_libritts")
@@ -346,7 +346,7 @@ def test_mel_frontend_golden():
     ("dex_vctk", dict(B=1, T=64, lengths=[57], Tr=40, Ts=40, sty_lengths=[33])),
     ("dex_libritts", dict(B=2, T=68, lengths=[68, 41], Tr=37, Ts=50, sty_lengths=[50, 13])),     # dim 128, hidden 384 = 2 x 192: per-operation reduced precision
 ])
-@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "fp16x2"])
 def test_bf16_mfma_mode_tolerance(name, kw, prec):
     """bf16-MFMA mode (bf16 operands, fp32 accumulate/norms/softmax) has no reference counterpart — the
     reference cannot run in bf16 — so it is held to the stated tolerance of tests/tolerances.py against the
