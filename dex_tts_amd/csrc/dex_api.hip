@@ -831,7 +831,7 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
         P.tv_keys = A.f((size_t)B * d.Ts * mid); P.tv_K = A.f((size_t)B * (d.Ts + 1) * mid); P.tv_V = A.f((size_t)B * (d.Ts + 1) * mid);
         P.tv_q = A.f(pm * mid); P.tv_ao = A.f(pm * mid); P.tv_out = A.f(pm * mid); P.tiv_out = A.f(pm * mid);
         P.tv_weff = A.f((size_t)B * mid * mid); P.tv_beff = A.f((size_t)B * mid);
-        P.tv_wbf = A.take((size_t)B * mid * mid * 2);
+        P.tv_wbf = A.take((size_t)B * mid * mid * 2 * 2);          // (x2: the lo halves of the split-weight mode behind the hi ones)
         P.tv_stats = (gnfix_t*)A.take((size_t)B * mid * IN_SLOTS * 2 * 2 * sizeof(gnfix_t));   // IN2d partials of the TV input and the TIV input
         P.tiv_stats = A.dry ? nullptr : P.tv_stats + (size_t)B * mid * IN_SLOTS * 2;
     }
@@ -889,7 +889,7 @@ struct Runner {
     }
     void gemm(const char* name, const IGemmP& g_in) {
         IGemmP g = g_in;
-        g.w_lo_off = g.Wbf ? x->lo_off(g.Wbf) : 0;        // split-weight mode: where the lo pack of this twin sits (0: a plain 16-bit operand)
+        if (!g.w_lo_off) g.w_lo_off = g.Wbf ? x->lo_off(g.Wbf) : 0;      // split-weight mode: where the lo pack of this twin sits (0: a plain 16-bit operand; set by the caller for operands built at run time)
         const double M = (double)g.Ho * g.Wo * g.B;
         const double fl = 2.0 * M * g.N * g.groups * g.K;
         const double by = 4.0 * (M * g.Cin * g.groups + M * g.N * g.groups * g.ksplit + (double)g.K * g.N * g.groups);
@@ -1310,10 +1310,11 @@ struct Runner {
         run("in2d_stats", 3.0 * npix * mid * B, 4.0 * npix * mid * B, [&] { launch_in_stats(is, st); });
         const bool qbf = x->lp();      // reduced-precision modes: the folded per-utterance weight is written as the MFMA GEMM operand
         InFoldP fo{P.tv_stats, (int)npix, 1e-5f, x->tv_wq_raw, mid, P.tv_weff, P.tv_beff, B, qbf ? P.tv_wbf : nullptr, x->lp_kind()};
+        fo.split = x->lpi() == 2 ? 1 : 0;                            // split-weight mode: the folded weight gets its lo half too
         run("tv_fold_in2d", 2.0 * mid * mid * B, 8.0 * mid * mid * B, [&] { launch_in_fold(fo, st); });
         IGemmP q = base_gemm(X.p, X.ld, X.coff, P.Hm, P.Wm, mid, P.tv_weff, mid, P.tv_beff, P.tv_q, mid, 0);
         q.w_bstride = (long)mid * mid; q.bias_bstride = mid; q.inmask = mask; q.inmask_ws = mask_ws;
-        if (qbf) q.Wbf = P.tv_wbf;
+        if (qbf) { q.Wbf = P.tv_wbf; q.w_lo_off = fo.split ? (long)B * mid * mid : 0; }
         gemm("tv_q", q);
         TvRow0P r0{P.tv_k0, P.tv_v0, sp, P.tv_K, P.tv_V, (long)(P.d.Ts + 1) * mid, mid, B, reinterpret_cast<float*>(P.tv_stats),
                    (long)B * mid * IN_SLOTS * 2 * 2 * (long)(sizeof(gnfix_t) / sizeof(float))};

@@ -141,16 +141,30 @@ __global__ __launch_bounds__(256) void in_fold_kernel(const InFoldP p) {
             __syncthreads();
             unsigned short* Wo = reinterpret_cast<unsigned short*>(p.Wbf) + (long)b * C * C;
             for (int n = tid; n < C; n += 256) {
-                uint4 o[2];
+                uint4 o[2], ol[2];
                 unsigned* ow = reinterpret_cast<unsigned*>(o);
+                unsigned* olw = reinterpret_cast<unsigned*>(ol);
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) {
                     const float4 w = *reinterpret_cast<const float4*>(p.Wq + (long)n * C + k0 + q4 * 4);
-                    ow[q4 * 2] = pack2_kind(w.x * srstd[q4 * 4], w.y * srstd[q4 * 4 + 1], p.lp);
-                    ow[q4 * 2 + 1] = pack2_kind(w.z * srstd[q4 * 4 + 2], w.w * srstd[q4 * 4 + 3], p.lp);
+                    const float v0 = w.x * srstd[q4 * 4], v1 = w.y * srstd[q4 * 4 + 1], v2 = w.z * srstd[q4 * 4 + 2], v3 = w.w * srstd[q4 * 4 + 3];
+                    ow[q4 * 2] = pack2_kind(v0, v1, p.lp);
+                    ow[q4 * 2 + 1] = pack2_kind(v2, v3, p.lp);
+                    if (p.split) {          // (fp16) what the rounding lost, rounded again: the lo half of the split weight
+                        const unsigned a = ow[q4 * 2], c = ow[q4 * 2 + 1];
+                        const float h0 = (float)__builtin_bit_cast(_Float16, (unsigned short)(a & 0xffffu)), h1 = (float)__builtin_bit_cast(_Float16, (unsigned short)(a >> 16));
+                        const float h2 = (float)__builtin_bit_cast(_Float16, (unsigned short)(c & 0xffffu)), h3 = (float)__builtin_bit_cast(_Float16, (unsigned short)(c >> 16));
+                        olw[q4 * 2] = pack2_kind(v0 - h0, v1 - h1, p.lp);
+                        olw[q4 * 2 + 1] = pack2_kind(v2 - h2, v3 - h3, p.lp);
+                    }
                 }
                 *reinterpret_cast<uint4*>(Wo + (long)n * C + k0) = o[0];
                 *reinterpret_cast<uint4*>(Wo + (long)n * C + k0 + 8) = o[1];
+                if (p.split) {
+                    unsigned short* Wl = reinterpret_cast<unsigned short*>(p.Wbf) + (long)p.B * C * C + (long)b * C * C;
+                    *reinterpret_cast<uint4*>(Wl + (long)n * C + k0) = ol[0];
+                    *reinterpret_cast<uint4*>(Wl + (long)n * C + k0 + 8) = ol[1];
+                }
             }
             return;
         }

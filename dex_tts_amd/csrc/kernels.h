@@ -372,7 +372,7 @@ struct SapP { const float* t_tok; int t_ld; int t_coff; int nsteps; const float*
 void launch_sap(const SapP& p, hipStream_t st);
 // TV: fold InstanceNorm2D into w_q:  Weff[b][k][n] = rstd[b,k]*Wq[n,k];  beff[b][n] = -sum_k mean*rstd*Wq[n,k]
 struct InFoldP { const gnfix_t* stats; int npix; float eps; const float* Wq; int C; float* Weff; float* beff; int B;
-                 void* Wbf; int lp; }; // reduced-precision modes: write rstd[k] * Wq[n][k] as bf16 (lp = 1) / fp16 (lp = 2) [B][n][k]
+                 void* Wbf; int lp; int split = 0; }; // split = 1 (lp = 2): also the lo halves, fp16(v - fp16(v)), B * C * C elements behind (PREC_FP16X2).  reduced-precision modes: write rstd[k] * Wq[n][k] as bf16 (lp = 1) / fp16 (lp = 2) [B][n][k]
                                        // (the MFMA GEMM's weight layout) instead of Weff
 void launch_in_fold(const InFoldP& p, hipStream_t st);
 // TIV: y = IN2d(x)*s + m  (ref_encoder.py:271); s,m indexed [step][b][C]
