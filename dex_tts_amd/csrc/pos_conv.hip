@@ -35,10 +35,7 @@ constexpr int KP = 16, PAD = 8, CG = 32, LDP = CG;         // LDS pixel = 64 B, 
                                                             // then cover all 64 banks for any fixed chunk (conflict-free b128)
 }
 
-// RT (row workgroups only): output rows per workgroup.  A weight tap (kh, kw) serves every output row, so with RT = 2 each weight
-// fragment - fetched once from L2 by one wave - feeds the MFMAs of two row tiles instead of one (the batch regime is bound by that
-// stream: ~400 KB of weights per workgroup); the patch grows by one input row.
-template <int CT, bool COL, int RT = 1>
+template <int CT, bool COL>
 __device__ __forceinline__ void pos_conv_body(const PosConvP& p, int rest) {
     constexpr int CW = 32 * CT, PW = CW + KP - 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_pc[];
@@ -55,18 +52,12 @@ __device__ __forceinline__ void pos_conv_body(const PosConvP& p, int rest) {
     constexpr bool col = COL;                                               // a column workgroup (see the header)
     constexpr int CPW = KP + 1, CKW = PAD + 1;                              // its patch row stride (positions) and live kw count
     int w0, ho, b;
-    if (col) { b = rest; ho = 0; w0 = Wt - 1; }                              // (column workgroups: `rest` is the batch element)
-    else { const int nrp = (Hf + RT - 1) / RT; w0 = (rest % nchunk) * CW; rest /= nchunk; ho = (rest % nrp) * RT; b = rest / nrp; }
-    const int hi_lo = col ? -PAD : max(0, ho - PAD), hi_hi = col ? Hf + PAD - 1 : min(Hf, ho + (RT - 1) + PAD);   // input rows [hi_lo, hi_hi)
+    if (col) { b = rest - nchunk * Hf * p.B; ho = 0; w0 = Wt - 1; }
+    else { w0 = (rest % nchunk) * CW; rest /= nchunk; ho = rest % Hf; b = rest / Hf; }
+    const int hi_lo = col ? -PAD : max(0, ho - PAD), hi_hi = col ? Hf + PAD - 1 : min(Hf, ho + PAD);   // input rows [hi_lo, hi_hi)
     const int nrows = hi_hi - hi_lo;
-    // weight rows kh that some output row of this workgroup uses: output row ho + r reads input row ho + r + kh - PAD = patch row
-    // (kh - kh_lo) + poff[r]
-    const int kh_lo = col ? 0 : max(0, hi_lo - ho - (RT - 1) + PAD);
-    const int kh_hi = col ? KP : min(KP, hi_hi - ho + PAD);
-    const int ntaps = col ? KP * CKW : (kh_hi - kh_lo) * KP;                // multiple of 16: every wave gets ntaps/4
-    int poff[RT];
-#pragma unroll
-    for (int r = 0; r < RT; ++r) poff[r] = kh_lo + ho + r - PAD - hi_lo;
+    const int kh_lo = col ? 0 : hi_lo - ho + PAD;                           // kh of input row hi: hi - ho + PAD
+    const int ntaps = col ? KP * CKW : nrows * KP;                          // multiple of 16: every wave gets ntaps/4
     constexpr int tdiv = col ? CKW : KP;                                    // tap t = (kh_lo + t / tdiv, t % tdiv)
     constexpr int pw = col ? CPW : PW;                                      // patch row stride
 
@@ -120,13 +111,11 @@ __device__ __forceinline__ void pos_conv_body(const PosConvP& p, int rest) {
             }
         }
     }
-    f32x16 acc[RT][CT];
+    f32x16 acc[CT];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[rt][ct][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
     lds_barrier();
 
     // ---- this wave's taps: t = wave + 4*n, n = 0 .. ntaps/4 - 1 (a multiple of 4: the ring slot index is static)
@@ -135,30 +124,24 @@ __device__ __forceinline__ void pos_conv_body(const PosConvP& p, int rest) {
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
             const int t = wave + 4 * (n0 + d);
-            const int pr0 = t / tdiv, kw = t % tdiv;
+            const int pr = t / tdiv, kw = t % tdiv;
+            // patch pixel of column tile 0 (tile ct: + 32*ct, same swizzle phase); column workgroup: lane = token row
+            const int px = col ? (i + pr) * CPW + kw : pr * PW + i + kw;
             const lp8 b0 = __builtin_bit_cast(lp8, wr[d][0]);
             const lp8 b1 = __builtin_bit_cast(lp8, wr[d][1]);
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) {
-                // patch row of this tap for output row ho + rt (row workgroups; workgroup-uniform validity); column workgroup: pr0 itself
-                const int pr = col ? pr0 : pr0 + poff[rt];
-                if (!col && ((unsigned)pr >= (unsigned)nrows || ho + rt >= Hf)) continue;
-                // patch pixel of column tile 0 (tile ct: + 32*ct, same swizzle phase); column workgroup: lane = token row
-                const int px = col ? (i + pr) * CPW + kw : pr * PW + i + kw;
-#pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    if (ct > 0 && col) break;                     // (one tile)
-                    const int sw = (px >> 2) & 3;                 // (px + 32*ct) >> 2 has the same low two bits
-                    const u16* ap = patch + (long)(px + 32 * ct) * LDP;
-                    const lp8 a0 = *reinterpret_cast<const lp8*>(ap + ((hh ^ sw) * 8));
-                    const lp8 a1 = *reinterpret_cast<const lp8*>(ap + (((2 + hh) ^ sw) * 8));
-                    acc[rt][ct] = DEX_MFMA_LP(a0, b0, acc[rt][ct], 0, 0, 0);
-                    acc[rt][ct] = DEX_MFMA_LP(a1, b1, acc[rt][ct], 0, 0, 0);
+            for (int ct = 0; ct < CT; ++ct) {
+                if (ct > 0 && col) break;                     // (one tile)
+                const int sw = (px >> 2) & 3;                 // (px + 32*ct) >> 2 has the same low two bits
+                const u16* ap = patch + (long)(px + 32 * ct) * LDP;
+                const lp8 a0 = *reinterpret_cast<const lp8*>(ap + ((hh ^ sw) * 8));
+                const lp8 a1 = *reinterpret_cast<const lp8*>(ap + (((2 + hh) ^ sw) * 8));
+                acc[ct] = DEX_MFMA_LP(a0, b0, acc[ct], 0, 0, 0);
+                acc[ct] = DEX_MFMA_LP(a1, b1, acc[ct], 0, 0, 0);
 #ifdef DEX_LP_WSPLIT
-                    acc[rt][ct] = DEX_MFMA_LP(a0, __builtin_bit_cast(lp8, wl[d][0]), acc[rt][ct], 0, 0, 0);
-                    acc[rt][ct] = DEX_MFMA_LP(a1, __builtin_bit_cast(lp8, wl[d][1]), acc[rt][ct], 0, 0, 0);
+                acc[ct] = DEX_MFMA_LP(a0, __builtin_bit_cast(lp8, wl[d][0]), acc[ct], 0, 0, 0);
+                acc[ct] = DEX_MFMA_LP(a1, __builtin_bit_cast(lp8, wl[d][1]), acc[ct], 0, 0, 0);
 #endif
-                }
             }
             const int tn = min(t + 16, ntaps - 4 + wave);   // refill (clamped re-read at the tail, never consumed)
             const int tap = (kh_lo + tn / tdiv) * KP + (tn % tdiv);
@@ -170,42 +153,39 @@ __device__ __forceinline__ void pos_conv_body(const PosConvP& p, int rest) {
 #undef PC_LOAD_LO
     // ---- sum the four waves' accumulators through LDS (the patch is dead), store raw sums
     lds_barrier();
-    constexpr int NTL = RT * CT;                             // accumulator tiles per wave
-    float* red = reinterpret_cast<float*>(smem_pc);          // [4][RT * CT][32 rows][33]
+    float* red = reinterpret_cast<float*>(smem_pc);          // [4][CT][32 rows][33]
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
+    for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) red[((wave * NTL + rt * CT + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + i] = acc[rt][ct][r];
+        for (int r = 0; r < 16; ++r) red[((wave * CT + ct) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh) * 33 + i] = acc[ct][r];
     lds_barrier();
     float* Y = p.Y + ((long)b * Hf * Wt + (long)ho * Wt) * p.hid + g * CG;
     if (col) {                                              // tile row = token row ho, one column
         for (int idx = tid; idx < 1024; idx += 256) {
             const int n = idx & 31, row = idx >> 5;
             if (row < Hf)
-                Y[((long)row * Wt + w0) * p.hid + n] = (red[((0 * NTL) * 32 + row) * 33 + n] + red[((1 * NTL) * 32 + row) * 33 + n]) +
-                                                        (red[((2 * NTL) * 32 + row) * 33 + n] + red[((3 * NTL) * 32 + row) * 33 + n]);
+                Y[((long)row * Wt + w0) * p.hid + n] = (red[((0 * CT) * 32 + row) * 33 + n] + red[((1 * CT) * 32 + row) * 33 + n]) +
+                                                        (red[((2 * CT) * 32 + row) * 33 + n] + red[((3 * CT) * 32 + row) * 33 + n]);
         }
         return;
     }
-    for (int idx = tid; idx < NTL * 1024; idx += 256) {
-        const int n = idx & 31, row = (idx >> 5) & 31, tl = idx >> 10, ct = tl % CT, rt = tl / CT;
+    for (int idx = tid; idx < CT * 1024; idx += 256) {
+        const int n = idx & 31, row = (idx >> 5) & 31, ct = idx >> 10;
         const int w = w0 + ct * 32 + row;
-        if (w < Wrow && ho + rt < Hf) {
-            const float v = (red[((0 * NTL + tl) * 32 + row) * 33 + n] + red[((1 * NTL + tl) * 32 + row) * 33 + n]) +
-                            (red[((2 * NTL + tl) * 32 + row) * 33 + n] + red[((3 * NTL + tl) * 32 + row) * 33 + n]);
-            Y[((long)rt * Wt + w) * p.hid + n] = v;
+        if (w < Wrow) {
+            const float v = (red[((0 * CT + ct) * 32 + row) * 33 + n] + red[((1 * CT + ct) * 32 + row) * 33 + n]) +
+                            (red[((2 * CT + ct) * 32 + row) * 33 + n] + red[((3 * CT + ct) * 32 + row) * 33 + n]);
+            Y[(long)w * p.hid + n] = v;
         }
     }
 }
 
-template <int CT, int RT = 1>
+template <int CT>
 __global__ __launch_bounds__(256) void pos_conv_direct_kernel(const PosConvP p) {
     const int rest = blockIdx.x / p.G;
-    const int nrow_wgs = ((p.Wt - p.ncol + 32 * CT - 1) / (32 * CT)) * ((p.Hf + RT - 1) / RT) * p.B;
-    if (rest >= nrow_wgs) pos_conv_body<CT, true, 1>(p, rest - nrow_wgs);  // (workgroup-uniform)
-    else pos_conv_body<CT, false, RT>(p, rest);
+    const int nrow_wgs = ((p.Wt - p.ncol + 32 * CT - 1) / (32 * CT)) * p.Hf * p.B;
+    if (rest >= nrow_wgs) pos_conv_body<CT, true>(p, rest);                // (workgroup-uniform)
+    else pos_conv_body<CT, false>(p, rest);
 }
 
 bool pos_conv_direct_supported(int hid, int groups, int kernel, int Hf) {
@@ -216,22 +196,22 @@ bool pos_conv_direct_supported(int hid, int groups, int kernel, int Hf) {
     return groups > 0 && hid / groups == CG && kernel == KP && Hf >= 1;
 }
 
-template <int CT, int RT = 1>
+template <int CT>
 static void launch_pc(const PosConvP& p, hipStream_t st) {
     constexpr int PW = 32 * CT + KP - 1;
-    const int nrows = p.Hf < 2 * PAD + RT - 1 ? p.Hf : 2 * PAD + RT - 1;
+    const int nrows = p.Hf < 2 * PAD ? p.Hf : 2 * PAD;
     size_t lds = (size_t)nrows * PW * LDP * sizeof(u16);
-    const size_t lds_red = (size_t)4 * RT * CT * 32 * 33 * sizeof(float);
+    const size_t lds_red = (size_t)4 * CT * 32 * 33 * sizeof(float);
     if (lds < lds_red) lds = lds_red;
     const size_t lds_col = p.ncol ? (size_t)(32 + 2 * PAD - 1) * (KP + 1) * LDP * sizeof(u16) : 0;     // (lanes past the last token row read, and discard, up to row 31 + 15)
     if (lds < lds_col) lds = lds_col;
     static bool attr = false;
     if (!attr) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&pos_conv_direct_kernel<CT, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&pos_conv_direct_kernel<CT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr = true;
     }
-    dim3 grid((unsigned)((((p.Wt - p.ncol + 32 * CT - 1) / (32 * CT)) * ((p.Hf + RT - 1) / RT) + (p.ncol ? 1 : 0)) * p.B * p.G));
-    hipLaunchKernelGGL((pos_conv_direct_kernel<CT, RT>), grid, dim3(256), lds, st, p);
+    dim3 grid((unsigned)((((p.Wt - p.ncol + 32 * CT - 1) / (32 * CT)) * p.Hf + (p.ncol ? 1 : 0)) * p.B * p.G));
+    hipLaunchKernelGGL(pos_conv_direct_kernel<CT>, grid, dim3(256), lds, st, p);
 }
 
 void launch_pos_conv_direct(const PosConvP& p0, hipStream_t st) {
@@ -257,16 +237,9 @@ void launch_pos_conv_direct(const PosConvP& p0, hipStream_t st) {
     while (ct > 1 && wgs_of(ct) < 192) --ct;
     static const int ct_env = [] { const char* e = getenv("DEX_POS_CT"); return e ? atoi(e) : 0; }();
     if (ct_env >= 1 && ct_env <= 3 && ct_env <= tiles) ct = ct_env;
-    // two output rows per workgroup where the grid stays large (the batch regime): every weight fragment feeds two row tiles.
-    // DEX_POS_RT=1 / 2 forces either (A/B)
-    static const int rt_env = [] { const char* e = getenv("DEX_POS_RT"); return e ? atoi(e) : 0; }();
-    // measured (us per launch, rows per workgroup 1 / 2 / 4): DEX B=32 (20 token rows) 243 / 206 / 184, GeDEX B=32 (10 rows) 92 / 65 / 88
-    const int rt = rt_env ? rt_env
-                 : (ct <= 2 && p.Hf >= 16 && p.Hf % 4 == 0 && wgs_of(ct) >= 4096) ? 4
-                 : (ct <= 2 && p.Hf >= 2 && wgs_of(ct) >= 2048) ? 2 : 1;
     if (ct == 3) launch_pc<3>(p, st);
-    else if (ct == 2) { if (rt == 4) launch_pc<2, 4>(p, st); else if (rt == 2) launch_pc<2, 2>(p, st); else launch_pc<2>(p, st); }
-    else { if (rt == 4) launch_pc<1, 4>(p, st); else if (rt == 2) launch_pc<1, 2>(p, st); else launch_pc<1>(p, st); }
+    else if (ct == 2) launch_pc<2>(p, st);
+    else launch_pc<1>(p, st);
 }
 
 }  // namespace DEX_LP_NS
