@@ -173,8 +173,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             if (BN >= RPP || trow < BN) *reinterpret_cast<uint4*>(Bs + trow * LDS_LD + tk8) = rb0[d];
             if constexpr (BP > 1) *reinterpret_cast<uint4*>(Bs + (trow + RPP) * LDS_LD + tk8) = rb1[d];
 #ifdef DEX_LP_WSPLIT
-            if (BN >= RPP || trow < BN) *reinterpret_cast<uint4*>(Bl + trow * LDS_LD + tk8) = rl0[d];
-            if constexpr (BP > 1) *reinterpret_cast<uint4*>(Bl + (trow + RPP) * LDS_LD + tk8) = rl1[d];
+            // (no branch inside the MFMA stream: an operand without a lo half gets a zero lo tile)
+            if (BN >= RPP || trow < BN) *reinterpret_cast<uint4*>(Bl + trow * LDS_LD + tk8) = has_lo ? rl0[d] : make_uint4(0, 0, 0, 0);
+            if constexpr (BP > 1) *reinterpret_cast<uint4*>(Bl + (trow + RPP) * LDS_LD + tk8) = has_lo ? rl1[d] : make_uint4(0, 0, 0, 0);
 #endif
             lds_barrier();
             igemm_load_tile<BN, BK, PT, AP, RPP, BP, ALP>(p, fa[d], fm[d], fo[d], rb0[d], rb1[d] WS_RL(d), kbeg + min(kt + D, nkt - 1) * BK, kt + D < nkt, tk8, trow, bh, bw, mvbits, Ab, mrow, mws, Wb, n0);
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                     const lp8 af = *reinterpret_cast<const lp8*>(ap + t * 32 * LDS_LD + ks * 16);
                     acc[t] = DEX_MFMA_LP(af, bf, acc[t], 0, 0, 0);
 #ifdef DEX_LP_WSPLIT
-                    if (has_lo) acc[t] = DEX_MFMA_LP(af, bl, acc[t], 0, 0, 0);
+                    acc[t] = DEX_MFMA_LP(af, bl, acc[t], 0, 0, 0);
 #endif
                 }
             }
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(256) void igemm_lp_ss_kernel(const IGemmP p) {
             const lp8 af = *reinterpret_cast<const lp8*>(ap + t * 32 * LDS_LD + ks * 16);
             acc[t] = DEX_MFMA_LP(af, bf, acc[t], 0, 0, 0);
 #ifdef DEX_LP_WSPLIT
-            if (has_lo) acc[t] = DEX_MFMA_LP(af, __builtin_bit_cast(lp8, bl_[ks]), acc[t], 0, 0, 0);
+            acc[t] = DEX_MFMA_LP(af, __builtin_bit_cast(lp8, bl_[ks]), acc[t], 0, 0, 0);      // (zero fragments when the operand has no lo half)
 #endif
         }
     }
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(256) void igemm_lp_nwalk_kernel(const IGemmP p) {
     const bool has_lo = p.w_lo_off != 0;
     u32x4 bl_[2][K / 16];
     const u16* Wlo = Wb + p.w_lo_off + (long)(wn * 32 + i) * K + hh * 8;
-#define NW_LOAD_LO(slot, nt_) _Pragma("unroll") for (int ks_ = 0; ks_ < K / 16; ++ks_) bl_[slot][ks_] = *reinterpret_cast<const u32x4*>(Wlo + (long)(nt_) * BN * K + ks_ * 16);
+#define NW_LOAD_LO(slot, nt_) _Pragma("unroll") for (int ks_ = 0; ks_ < K / 16; ++ks_) { const u32x4 v_ = *reinterpret_cast<const u32x4*>(Wlo + (long)(nt_) * BN * K + ks_ * 16); bl_[slot][ks_] = has_lo ? v_ : u32x4{0u, 0u, 0u, 0u}; }
     NW_LOAD_LO(0, 0)
 #endif
     NW_LOAD_B(0)
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(256) void igemm_lp_nwalk_kernel(const IGemmP p) {
                 const lp8 af = *reinterpret_cast<const lp8*>(ap + t * 32 * LDS_LD + ks * 16);
                 acc[t] = DEX_MFMA_LP(af, bf, acc[t], 0, 0, 0);
 #ifdef DEX_LP_WSPLIT
-                if (has_lo) acc[t] = DEX_MFMA_LP(af, __builtin_bit_cast(lp8, bl_[par_][ks]), acc[t], 0, 0, 0);
+                acc[t] = DEX_MFMA_LP(af, __builtin_bit_cast(lp8, bl_[par_][ks]), acc[t], 0, 0, 0);
 #endif
             }
         }
