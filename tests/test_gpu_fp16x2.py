@@ -137,8 +137,8 @@ def test_batch_forms_vs_oracle(name, B, T, n, kw):
 
 
 @pytest.mark.parametrize("name", ["gedex_lj", "dex_vctk"])
-def test_heun_and_churn_in_the_split_mode(name):
-    """The other branches of `ablation_sampler` (edm.py:194-214) run through the same split kernels: Heun (2n - 1 evaluations) against
+def test_heun_in_the_split_mode(name):
+    """The second-order branch of `ablation_sampler` (edm.py:207-214) runs through the same split kernels: Heun (2n - 1 evaluations) against
     the oracle inside the mode's small-shape bounds, graph replay == eager."""
     _need()
     cfg, eng, w = U.engine_for(name)
