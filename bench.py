@@ -70,6 +70,17 @@ SYMBOL_OF = {"dit_block": "dit_rowchain_kernel<true>", "dit_qkv": "dit_rowchain_
              "dit_final_unpatchify": "igemm_lp_ss_kernel", "tv_attention": "attn_lp", "patch_dwconv_silu": "dwconv_silu_kernel"}
 
 
+# whole-job errors against the CPU oracle, measured on MI355X by tests/test_gpu_full_jobs.py (profiles/round5_parity_measured.jsonl): [max, mean]
+MEASURED_ERR = {
+    "cfg2_dex_b32_n50": {"fp32": [4.5e-6, 5.6e-7], "bf16": [1.22e-2, 1.70e-3], "fp16": [1.54e-3, 1.96e-4], "fp16x2": [9.2e-4, 1.10e-4]},
+    "cfg3_dex_esd_b32_n100": {"fp32": [5.7e-6, 6.0e-7], "bf16": [1.20e-2, 1.62e-3], "fp16x2": [6.4e-4, 8.0e-5]},
+}
+
+
+def dtype_name(precision):
+    return precision
+
+
 def lengths_for(B, T, salt=0):
     return [T] * B if B == 1 else [int(T * (0.6 + 0.4 * ((7 * i + 3 * salt) % 11) / 10.0)) for i in range(B)]
 
@@ -402,6 +413,95 @@ def frontend_block(device, stream, steps=10, warmup=3):
     return out
 
 
+_ROOF_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launches", "avg_launch_us", "rocprof_avg_launch_us",
+              "frac_at_rocprof_duration", "algorithmic_MB_per_launch", "algorithmic_GFLOP_per_launch")
+COMPACT_LIMIT = 8192        # bytes: the driver reads the bench line out of an 8 KB tail of stdout (BENCH_r04.json: a 30.6 KB line came back parsed = null)
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _err2(e):
+    return None if not e else {"max": float(f"{e['max']:.3g}"), "mean": float(f"{e['mean']:.3g}")}
+
+
+def compact(res):
+    """The ONE stdout line: the contract's keys + roofline / roofline_attention / cpu_baseline / parity_mode / batch32 / per-config
+    values, <= COMPACT_LIMIT bytes whatever the full record holds (tests/test_bench_line.py).  The full record goes to
+    gpurun_out/bench_full.json and to stderr."""
+    out = _pick(res, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                      "dtype", "data", "config", "rtf", "ms_per_euler_step", "hip_event_median_ms", "gpu_over_cpu"))
+    if res.get("abs_err"):
+        out["abs_err"] = _err2(res["abs_err"])
+    for k in ("roofline", "roofline_attention"):
+        if k in res:
+            out[k] = _pick(res[k], _ROOF_KEYS)
+    if "cpu_baseline" in res:
+        cb = res["cpu_baseline"]
+        out["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample"))
+        h = cb.get("host") or {}
+        out["cpu_baseline"]["host"] = f"{h.get('model')}, {h.get('physical_cores')} physical cores, {h.get('logical_cpus')} logical CPUs"
+    if "parity_mode" in res:
+        pm = res["parity_mode"]
+        out["parity_mode"] = _pick(pm, ("dtype", "value", "unit", "ms_per_step", "value_batch32", "ms_per_step_batch32"))
+        out["parity_mode"]["abs_err"] = _err2(pm.get("abs_err"))
+        if "exact_fp32_mode" in pm:
+            e = pm["exact_fp32_mode"]
+            out["exact_fp32_mode"] = dict(_pick(e, ("value", "ms_per_step", "value_batch32")), abs_err=_err2(e.get("abs_err")))
+    if "fp16_mode" in res:
+        out["fp16_mode"] = dict(_pick(res["fp16_mode"], ("value", "ms_per_step")), abs_err=_err2(res["fp16_mode"].get("abs_err")))
+    if "batch32" in res:
+        out["batch32"] = _pick(res["batch32"], ("value", "unit", "ms_per_step", "dtype", "workload", "hipgraph"))
+        r32 = res.get("roofline_batch32", {}).get(res.get("_precision"), {})
+        if "dominant" in r32:
+            out["batch32"]["roofline"] = _pick(r32["dominant"], _ROOF_KEYS)
+        if "dit_attention" in r32:
+            out["batch32"]["roofline_attention"] = _pick(r32["dit_attention"], _ROOF_KEYS)
+    if "batch32_bucketed" in res:
+        out["batch32_bucketed"] = _pick(res["batch32_bucketed"], ("value", "ms_per_step", "bucket_width", "hipgraph"))
+    if "configs" in res:
+        out["configs"] = {}
+        for name, c in res["configs"].items():
+            ent = _pick(c, ("value", "dtype", "ms_per_step", "hipgraph"))
+            ent["workload"] = c.get("workload", "").split(":")[0]
+            for k, short in (("roofline", "dominant"), ("roofline_attention", "attention")):
+                if k in c:
+                    ent[short] = _pick(c[k], ("kernel", "bound", "frac", "avg_launch_us", "rocprof_avg_launch_us", "frac_at_rocprof_duration", "traffic"))
+            if "abs_err" in c:
+                ent["abs_err"] = c["abs_err"]
+            out["configs"][name] = ent
+    for k in ("vocoder", "vocoder_bf16", "vocoder_bigvgan"):
+        if k in res:
+            out[k] = _pick(res[k], ("value", "ms_per_call"))
+    if "frontend" in res:
+        out["frontend_ms"] = {k: v.get("ms_per_call") for k, v in res["frontend"].items()}
+    out["full_record"] = res.get("_full_path")
+    # belt and braces: drop the optional blocks, least important first, until the line fits
+    for k in ("frontend_ms", "vocoder_bigvgan", "vocoder_bf16", "vocoder", "batch32_bucketed", "fp16_mode", "exact_fp32_mode", "configs"):
+        if len(json.dumps(out)) < COMPACT_LIMIT - 256:
+            break
+        out.pop(k, None)
+    return out
+
+
+def emit(res):
+    """Full record -> gpurun_out/bench_full.json (+ stderr); compact record -> the last (and only) stdout line."""
+    full_dir = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(full_dir, exist_ok=True)
+        path = os.path.join(full_dir, f"bench_full_{res.get('_workload', 'run')}_n{res.get('n_gpus', 1)}.json")
+        res["_full_path"] = os.path.relpath(path, ROOT)
+        with open(path, "w") as f:
+            json.dump({k: v for k, v in res.items() if not k.startswith("_")}, f)
+    except OSError:
+        res["_full_path"] = None
+    print("[bench full record] " + json.dumps({k: v for k, v in res.items() if not k.startswith("_")}), file=sys.stderr, flush=True)
+    line = json.dumps(compact(res))
+    assert len(line) < COMPACT_LIMIT, len(line)
+    print(line, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -505,6 +605,7 @@ def main():
             "ms_per_euler_step": round(ms_per_step / n_steps, 4),
             "hip_event_median_ms": round(statistics.median(ev_ms), 3),
             "hip_event_min_ms": round(min(ev_ms), 3),
+            "_precision": precision, "_workload": args.workload,
         }
         prof = world == 1 and not args.no_profile
         call_eager = lambda: eng.sample(z, mask, mu, n_steps, use_graph=False, **kw)
@@ -622,11 +723,12 @@ def main():
             # opt-in length bucketing on the same 32 utterances (lengths 0.6 T .. T): valid frames / s with every bucket padded to its own maximum
             eng.set_precision(precision)
             with torch.cuda.stream(stream):
-                fnb = lambda zz, mm, uu, **k2: eng.sample(zz, mm, uu, n32, use_graph=False, **k2)
+                # (one cached hipGraph per bucket shape: the four buckets are four graph-cache entries of the engine, replayed back to back)
+                fnb = lambda zz, mm, uu, **k2: eng.sample(zz, mm, uu, n32, use_graph=use_graph, **k2)
                 cb = lambda: D.sample_bucketed(fnb, mu2, mask2, z2, l32, 64)
-                dtk, evk, yk = timed_calls(cb, 3, 1, device)
+                dtk, evk, yk = timed_calls(cb, 3, 2, device)
             res["batch32_bucketed"] = {"value": round(sum(l32) * 3 / dtk, 1), "unit": "mel-frames/s", "bucket_width": 64,
-                                       "buckets": [[Tb, len(ix)] for Tb, ix in D.buckets_of(l32, 64)], "steps": 3, "warmup": 1, "hipgraph": False,
+                                       "buckets": [[Tb, len(ix)] for Tb, ix in D.buckets_of(l32, 64)], "steps": 3, "warmup": 2, "hipgraph": use_graph,
                                        "ms_per_step": round(dtk / 3 * 1e3, 3),
                                        "note": "dex_tts_amd.dist.sample_bucketed: per bucket the result of the reference run on that bucket, NOT of the globally padded batch (opt-in)"}
             del mu2, mask2, z2, yk
@@ -653,19 +755,27 @@ def main():
                 "C3 (SURVEY 8d) T=512": side_workload("dex_b32_t512", precision, device, stream, "on", steps=3),
                 "C2 (SURVEY 8d) T=800": side_workload("gedex_b1_t800", precision, device, stream, "on", steps=5, warmup=2),
             }
-            # configs[2] / [3] name no reduced precision: their parity-mode (fp32) leg, driver-timed like the blocks above
+            # configs[2] / [3] name no reduced precision: their exact-fp32 leg and their split-weight (fp16x2) legs, driver-timed like the blocks
+            # above.  abs_err = the WHOLE job against the CPU oracle as measured on MI355X by tests/test_gpu_full_jobs.py (the bench does not
+            # re-run a 2-4 minute oracle job): at configs[2] the split mode's mean sits just outside the 1e-4 it holds at configs[1], so these
+            # legs are reported as a mode with its measured error, not as "parity mode".
             res["configs"]["configs[2] exact fp32 mode"] = side_workload("dex_b32", "fp32", device, stream, "on", steps=2, profile=False)
+            res["configs"]["configs[2] exact fp32 mode"]["abs_err"] = MEASURED_ERR["cfg2_dex_b32_n50"]["fp32"]
+            res["configs"]["configs[2]"]["abs_err"] = MEASURED_ERR["cfg2_dex_b32_n50"].get(dtype_name(precision))
+            res["configs"]["configs[3]"]["abs_err"] = MEASURED_ERR["cfg3_dex_esd_b32_n100"].get(dtype_name(precision))
             if "fp16x2" in _lib.PRECISION:
-                res["configs"]["configs[2] parity mode"] = side_workload("dex_b32", "fp16x2", device, stream, "on", steps=3, profile=False)
-                res["configs"]["configs[3] parity mode"] = side_workload("dex_esd_b32_n100", "fp16x2", device, stream, "on", steps=2, profile=False)
-                res["configs"]["configs[4] parity mode"] = side_workload("gedex_long_x2", "fp16x2", device, stream, "on", steps=3, profile=False)
+                res["configs"]["configs[2] fp16x2"] = side_workload("dex_b32", "fp16x2", device, stream, "on", steps=3, profile=False)
+                res["configs"]["configs[2] fp16x2"]["abs_err"] = MEASURED_ERR["cfg2_dex_b32_n50"]["fp16x2"]
+                res["configs"]["configs[3] fp16x2"] = side_workload("dex_esd_b32_n100", "fp16x2", device, stream, "on", steps=2, profile=False)
+                res["configs"]["configs[3] fp16x2"]["abs_err"] = MEASURED_ERR["cfg3_dex_esd_b32_n100"]["fp16x2"]
+                res["configs"]["configs[4] fp16x2"] = side_workload("gedex_long_x2", "fp16x2", device, stream, "on", steps=3, profile=False)
         if prof and args.workload == "gedex_b1" and not args.no_configs:
             res["vocoder"] = vocoder_block(device, stream)
             res["vocoder_bf16"] = vocoder_block(device, stream, precision="bf16")
             res["vocoder_fp16"] = vocoder_block(device, stream, precision="fp16")
             res["vocoder_bigvgan"] = vocoder_block(device, stream, big=True)
             res["frontend"] = frontend_block(device, stream)
-        print(json.dumps(res), flush=True)
+        emit(res)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

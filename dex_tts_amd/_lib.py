@@ -10,6 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DEX_AMD_LIB") or os.path.join(HERE, "lib", "libdexamd.so")
 
 DEX_OK = 0
+DEX_ERR_HANDOFF, DEX_ERR_HANDOFF_XCD = -5, -6        # include/dex_amd.h: dex_call_status
 VARIANT = {"gedex": 0, "dex": 1}
 PRECISION = {"fp32": 0, "bf16": 1, "fp16": 2, "fp16x2": 3}
 SOLVER = {"euler": 0, "heun": 1}

@@ -354,7 +354,7 @@ void launch_attention_lp(const AttnP& p, hipStream_t st) {
             hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_lp_shared_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr = true;
         }
-        static const int w8 = getenv("DEX_ATTN_SHARED_W8") ? atoi(getenv("DEX_ATTN_SHARED_W8")) : 1;
+        const int w8 = knob_or("DEX_ATTN_SHARED_W8", 1);
         if (w8 && (long)((p.Nq + 255) / 256) * p.heads * p.B >= 512) {
             hipLaunchKernelGGL(attn_lp_shared_kernel<8>, dim3((p.Nq + 255) / 256, p.heads, p.B), dim3(512), lds, st, p);
             return;

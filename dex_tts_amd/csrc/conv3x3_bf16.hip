@@ -458,7 +458,7 @@ bool conv3x3_plain_lp_in_supported(int H, int W, int B, int Cin, int Cout) {
     return false;            // no split-weight form yet (lp_config.h)
 #endif
    
-    static const int w8 = getenv("DEX_CONV_W8") ? atoi(getenv("DEX_CONV_W8")) : 1;
+    const int w8 = knob_or("DEX_CONV_W8", 1);
     const long tiles4 = (long)((W + 31) / 32) * ((H + 3) / 4) * B;
     return w8 && tiles4 >= 256 && Cin == 64 && Cout == 128;
 }
@@ -471,8 +471,8 @@ bool conv3x3_cat_lp_in_supported(int H, int W, int B, int Cin, int Cout) {
 #endif
    
     if (Cout != 64 || Cin < 128 || Cin % 128 != 0) return false;
-    static const int w8 = getenv("DEX_CONV_W8") ? atoi(getenv("DEX_CONV_W8")) : 1;
-    static const long small_max = getenv("DEX_CONV_SMALL_MAX") ? atol(getenv("DEX_CONV_SMALL_MAX")) : 256;
+    const int w8 = knob_or("DEX_CONV_W8", 1);
+    const long small_max = knob_or("DEX_CONV_SMALL_MAX", 256);
     const long tiles4 = (long)((W + 31) / 32) * ((H + 3) / 4) * B;
     return w8 && tiles4 >= small_max;
 }
@@ -484,16 +484,16 @@ void launch_conv3x3_lp(const Conv3P& p, hipStream_t st) {
     // workgroups on the chip (per-tap weight traffic per workgroup halves, two workgroups fit per CU)
     const bool tail_ = p.pro_res != nullptr;     // (Conv3P::res2_* is served by the ping-pong strip kernel only: conv3x3_res2_form)
     const long tiles4 = (long)((p.W + 31) / 32) * ((p.H + 3) / 4) * p.B;
-    static const long small_max = getenv("DEX_CONV_SMALL_MAX") ? atol(getenv("DEX_CONV_SMALL_MAX")) : 256;
+    const long small_max = knob_or("DEX_CONV_SMALL_MAX", 256);
     const bool small = tiles4 < small_max;       // (at B=32 the 4-row tiles win despite one workgroup per CU: 189 vs 218 us)
     // the 128-channel-wide forms at 4-row tiles fill the LDS with ONE workgroup per CU; as eight waves (4 rows x 2 halves
     // of the output channels) that workgroup keeps two waves per SIMD busy instead of one: +8.6 % end to end at B=32
     // (DEX_CONV_W8=0 restores the four-wave form)
-    static const int w8 = getenv("DEX_CONV_W8") ? atoi(getenv("DEX_CONV_W8")) : 1;
+    const int w8 = knob_or("DEX_CONV_W8", 1);
     // 8-row tiles for the 128 -> 128 convs at batch size: each wave owns one row x all 128 output channels, the per-tap weight
     // slices are staged once per 256 pixels instead of once per 128 and there is one barrier per 32 MFMAs of a wave instead of
     // per 16 (the patch + two weight taps fill the LDS to within 64 bytes).  DEX_CONV_TH8=0 keeps the 4-row form.
-    static const int th8 = getenv("DEX_CONV_TH8") ? atoi(getenv("DEX_CONV_TH8")) : 1;
+    const int th8 = knob_or("DEX_CONV_TH8", 1);
     // (measured at B=32: 156 -> 139 us; the fused-tail form needs eight staging passes at this size and loses, 207 -> 243: 4-row tiles)
     if (th8 && w8 && !small && !tail_ && p.Cin == 128 && p.Cout == 128 && !p.res_w && p.H % 8 == 0 && (long)((p.W + 31) / 32) * (p.H / 8) * p.B >= 512) {
         p.x_bf16 ? launch_c3<128, 128, 128, 8, false, false, true, 8>(p, st) : launch_c3<128, 128, 128, 8, false, false, false, 8>(p, st);

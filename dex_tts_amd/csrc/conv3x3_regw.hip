@@ -653,18 +653,18 @@ bool conv3x3_regw_form(const Conv3P& p) {
     return false;            // no split-weight form (lp_config.h)
 #endif
    
-    static const bool off = [] { const char* e = getenv("DEX_CONV_REGW"); return e && e[0] == '0'; }();
+    const bool off = knob_off("DEX_CONV_REGW");
     if (off || !p.Wfrag || p.res2_w) return false;
-    static const long min_tiles_r = [] { const char* e = getenv("DEX_REGW_MIN_TILES"); return e ? atol(e) : 1024L; }();
+    const long min_tiles_r = knob_or("DEX_REGW_MIN_TILES", 1024);
     if (p.res_w) {      // 64 -> 128 + 1x1 shortcut on the plain Downsample output (conv3x3_rw_res128_kernel)
-        static const bool res_off = [] { const char* e = getenv("DEX_CONV_REGW_RES"); return e && e[0] == '0'; }();
+        const bool res_off = knob_off("DEX_CONV_REGW_RES");
         return !res_off && p.res_wfrag && p.Cin == 64 && p.Cout == 128 && (p.ldx % 8) == 0 && (p.x_coff % 8) == 0 && !p.pro_stats && !p.pro_res && p.y_bf16 &&
                (long)p.H * ((p.W + 63) / 64) * p.B >= min_tiles_r;
     }
     if (!(p.Cin == 128 && p.Cout == 128 && p.ldx == 128 && p.x_coff == 0)) return false;
     if (!p.y_bf16) return false;
     if (p.pro_stats ? !p.x_bf16 : true) return false;         // instantiated: the two GroupNorm-prologue forms on 16-bit h
-    static const long min_tiles = [] { const char* e = getenv("DEX_REGW_MIN_TILES"); return e ? atol(e) : 1024L; }();
+    const long min_tiles = knob_or("DEX_REGW_MIN_TILES", 1024);
     return (long)p.H * ((p.W + 63) / 64) * p.B >= min_tiles;
 }
 
@@ -672,7 +672,7 @@ template <int CIN, int COUT, int PROF, bool XB, bool YB, bool XOL = false>
 static void rw_launch(const Conv3P& p, hipStream_t st) {
     using G = RwGeom<CIN, COUT, YB>;
     const int nseg = (p.W + G::MPX - 1) / G::MPX;
-    static const int target = [] { const char* e = getenv("DEX_REGW_WGS"); return e ? atoi(e) : 256; }();
+    const int target = knob_or("DEX_REGW_WGS", 256);
     int nchunk = (target + nseg * p.B - 1) / (nseg * p.B);
     if (nchunk < 1) nchunk = 1;
     if (nchunk > p.H) nchunk = p.H;

@@ -194,7 +194,7 @@ void launch_conv_down(const ConvDownP& p0, hipStream_t st) {
     const int Ho = p.H / 2, Wo = p.W / 2;
     p.nseg = (Wo + CD_MPX - 1) / CD_MPX;
     // ~2 workgroups per CU (a workgroup re-reads one halo row per row chunk)
-    static const int target = [] { const char* e = getenv("DEX_CONV_DOWN_WGS"); return e ? atoi(e) : 512; }();
+    const int target = knob_or("DEX_CONV_DOWN_WGS", 512);
     int nchunk = (target + p.nseg * p.B - 1) / (p.nseg * p.B);
     if (nchunk < 1) nchunk = 1;
     if (nchunk > Ho) nchunk = Ho;

@@ -222,7 +222,7 @@ static void cu_launch(ConvTUpP p, hipStream_t st) {
     p.nseg = (p.W + G::MPX - 1) / G::MPX;
     // ~2 workgroups per CU; a workgroup re-reads two halo rows per row chunk, so chunks stay as long as the grid allows
     const long tiles = (long)p.H * p.nseg * p.B;
-    static const int target = [] { const char* e = getenv("DEX_CONVT_WGS"); return e ? atoi(e) : 512; }();
+    const int target = knob_or("DEX_CONVT_WGS", 512);
     int R = (int)(tiles / target);
     if (R < 1) R = 1;
     if (R > p.H) R = p.H;
@@ -237,7 +237,7 @@ void launch_convt_up(const ConvTUpP& p, hipStream_t st) {
     g_last_symbol = "convt_up_kernel";
     // 32-column strips (two workgroups per CU, 222 registers) beat 64-column ones (one per CU, 292) at every grid measured:
     // 60.8 vs 72.4 us (GeDEX B = 32), 36.7 vs 40.2 us (DEX B = 32); DEX_CONVT_MT=2 keeps the wide form reachable
-    static const bool wide = [] { const char* e = getenv("DEX_CONVT_MT"); return e && atoi(e) == 2; }();
+    const bool wide = knob_or("DEX_CONVT_MT", 0) == 2;
 #define CU_GO(MT) do { if (p.a_lp && p.c_lp) cu_launch<MT, true, true>(p, st); else if (p.a_lp) cu_launch<MT, true, false>(p, st); \
                        else if (p.c_lp) cu_launch<MT, false, true>(p, st); else cu_launch<MT, false, false>(p, st); } while (0)
     if (wide) CU_GO(2); else CU_GO(1);

@@ -28,11 +28,28 @@ namespace {
 const char* const KNOB_NAMES[] = {
     "DEX_CONV_STREAM", "DEX_CONV_PP", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_ATTN_Q64", "DEX_ATTN_Q64_TAIL", "DEX_DIT_XCDS", "DEX_ATTN_GENERIC", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN",
     "DEX_DIT_CLUSTER", "DEX_DIT_CLUSTER_LOCAL", "DEX_ATTN_X_LP", "DEX_RES_X_LP", "DEX_CAT_LP", "DEX_XCD_MAP", "DEX_DEBUG_DROP_HANDOFF", "DEX_PATCH_FUSED",
-    "DEX_CONV_DOWN", "DEX_CONVT_UP", "DEX_DEBUG_PLAN"};
+    "DEX_CONV_DOWN", "DEX_CONVT_UP", "DEX_DEBUG_PLAN",
+    // launcher heuristics (workgroup caps, shape thresholds, form switches) - process-static getenv reads until round 4
+    "DEX_ATTN_SHARED_W8", "DEX_CONVT_MT", "DEX_CONVT_WGS", "DEX_CONV_DOWN_WGS", "DEX_CONV_REGW", "DEX_CONV_REGW_RES", "DEX_CONV_SMALL_MAX", "DEX_CONV_TH8",
+    "DEX_CONV_W8", "DEX_DWCONV_CAP", "DEX_FINAL_CAP", "DEX_FIRST_CAP", "DEX_FIRST_MFMA", "DEX_GEMM_NWALK", "DEX_NWALK_SPLIT", "DEX_POS_COL", "DEX_POS_COL_MIN",
+    "DEX_POS_CT", "DEX_REGW_MIN_TILES", "DEX_REGW_WGS", "DEX_ROWCHAIN64", "DEX_TIV_CAP"};
 constexpr int N_KNOBS = (int)(sizeof(KNOB_NAMES) / sizeof(KNOB_NAMES[0]));
+// value of one variable: a decimal integer; unset, empty or without digits ("true", "on") = KNOB_UNSET, so a typo leaves the default
+// form on instead of silently switching it off
+int knob_parse(const char* e) {
+    if (!e) return KNOB_UNSET;
+    char* end = nullptr;
+    const long v = strtol(e, &end, 10);
+    if (end == e) {
+        static bool warned = false;
+        if (!warned) { warned = true; fprintf(stderr, "libdexamd: ignoring a DEX_* knob whose value '%s' is not an integer\n", e); }
+        return KNOB_UNSET;
+    }
+    return (int)v;
+}
 struct KnobSnapshot {
     int v[N_KNOBS];
-    KnobSnapshot() { for (int i = 0; i < N_KNOBS; ++i) { const char* e = getenv(KNOB_NAMES[i]); v[i] = e ? atoi(e) : KNOB_UNSET; } }
+    KnobSnapshot() { for (int i = 0; i < N_KNOBS; ++i) v[i] = knob_parse(getenv(KNOB_NAMES[i])); }
 };
 thread_local const KnobSnapshot* t_knobs = nullptr;
 struct WsplitScope {          // the split-weight mode of the call being built on this thread (lp_dispatch.hip's predicates read it)
@@ -52,8 +69,7 @@ int knob(const char* name) {
             if (t_knobs) return t_knobs->v[i];
             break;
         }
-    const char* e = getenv(name);              // outside a call (tools that launch kernels directly), or a knob nobody registered
-    return e ? atoi(e) : KNOB_UNSET;
+    return knob_parse(getenv(name));           // outside a call (tools that launch kernels directly), or a knob nobody registered
 }
 }  // namespace dex
 static_assert(PREC_FP32 == DEX_PREC_FP32 && PREC_BF16 == DEX_PREC_BF16 && PREC_FP16 == DEX_PREC_FP16 && PREC_FP16X2 == DEX_PREC_FP16X2, "kernels.h mirrors DexPrecision");
@@ -143,7 +159,7 @@ struct DexCtx {
     std::vector<ProfAgg> prof_agg;
     // hipGraph cache: one captured graph per (shape, pointer set) holds a WHOLE sampler call (conditioning tables, every
     // network evaluation, the final copy) and is replayed with one hipGraphLaunch
-    struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec; uint64_t stamp; };
+    struct GraphEntry { std::vector<uint64_t> key; hipGraphExec_t exec; uint64_t stamp; const int* xerr; };   // xerr: the hand-off word the captured launches write (null: no in-launch hand-offs)
     std::vector<GraphEntry> graphs;
     uint64_t graph_clock = 0;
     void drop_graphs() { for (auto& g : graphs) hipGraphExecDestroy(g.exec); graphs.clear(); }
@@ -1742,9 +1758,10 @@ int dex_sample(DexCtx* x, const DexSampleArgs* a, dex_stream_t stream) {
         ec = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         hipGraphDestroy(graph);
         if (ec != hipSuccess) return x->fail(DEX_ERR_HIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ec));
-        x->graphs.push_back({key, exec, 0});
+        x->graphs.push_back({key, exec, 0, x->last_xerr});        // (the Runner set last_xerr while its launches were captured)
         hit = &x->graphs.back();
     }
+    x->last_xerr = hit->xerr;           // a replay enqueues nothing on the host: dex_call_status reads the word the CAPTURED launches write
     hit->stamp = ++x->graph_clock;
     HIPCHK(x, hipGraphLaunch(hit->exec, st));
     HIPCHK(x, hipGetLastError());
@@ -1813,8 +1830,8 @@ int dex_call_status(DexCtx* x, dex_stream_t stream) {
         return x->fail(DEX_ERR_HIP, "dex_call_status: could not read the hand-off word");
     if (v == 0) return DEX_OK;
     if (v == 2 && !knob_set("DEX_DEBUG_DROP_HANDOFF")) { g_xcd_map.store(0); x->drop_graphs(); }
-    return x->fail(DEX_ERR_HANDOFF, v == 2 ? "a cluster hand-off met its peer on another XCD (outputs poisoned); the XCD-local form is now off for this device - repeat the call"
-                                           : "a cluster hand-off timed out (outputs poisoned)");
+    if (v == 2) return x->fail(DEX_ERR_HANDOFF_XCD, "a cluster hand-off met its peer on another XCD (outputs poisoned); the XCD-local form is now off for this device - repeat the call");
+    return x->fail(DEX_ERR_HANDOFF, "a cluster hand-off timed out (outputs poisoned)");
 }
 
 int dex_debug_handoff_timeouts(DexCtx* x, dex_stream_t stream) {

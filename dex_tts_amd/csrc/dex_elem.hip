@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void tiv_apply_kernel(const TivApplyP p) {
 void launch_tiv_apply(const TivApplyP& p, hipStream_t st) {
     const long total = (long)p.npix * (p.C / 4);
     long blocks = (total + 1023) / 1024; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
-    static const long cap = [] { const char* e = getenv("DEX_TIV_CAP"); return e ? atol(e) : 512L; }();    // workgroups in total: each recomputes the per-channel coefficients from the slot partials (measured at DEX B=32: 5120 workgroups 60.6 us, 2048 45.1, 1024 37.9, 512 34.3)
+    const long cap = knob_or("DEX_TIV_CAP", 512);    // workgroups in total: each recomputes the per-channel coefficients from the slot partials (measured at DEX B=32: 5120 workgroups 60.6 us, 2048 45.1, 1024 37.9, 512 34.3)
     if (cap > 0 && blocks * p.B > cap) { blocks = cap / p.B; if (blocks < 1) blocks = 1; }
     hipLaunchKernelGGL(tiv_apply_kernel, dim3((unsigned)blocks, p.B), dim3(256), 0, st, p);
 }

@@ -99,7 +99,7 @@ void launch_dwconv_silu(const DwConvP& p, hipStream_t st) {
         else if (p.k == 15) hipLaunchKernelGGL(dwconv_silu_direct_kernel<15>, g1, dim3(256), 0, st, p);
         return;
     }
-    static const long cap = getenv("DEX_DWCONV_CAP") ? atol(getenv("DEX_DWCONV_CAP")) : 1024;     // workgroups (each stages the weights once)
+    const long cap = knob_or("DEX_DWCONV_CAP", 1024);     // workgroups (each stages the weights once)
     if (blocks > cap) blocks = cap;
     const dim3 grid((unsigned)blocks);
     const size_t lds = (size_t)p.k * p.k * p.C * sizeof(float);

@@ -560,7 +560,7 @@ static bool nwalk_eligible(const IGemmP& p) {
     if (p.sh != 1 || p.sw != 1 || p.off_h != 0 || p.off_w != 0 || p.Ho != p.Hi || p.Wo != p.Wi || p.gn_stats) return false;
     // the kernel's epilogue is the unpatchify scatter and nothing else: bias, output mask, crop
     if (p.unpatch_s <= 0 || (p.unpatch_C % 32) != 0 || p.gate || p.res || p.act != 0 || p.stats_final) return false;
-    static const int mode = getenv("DEX_GEMM_NWALK") ? atoi(getenv("DEX_GEMM_NWALK")) : 1;       // 0: never, 2: whenever the shape allows (tests)
+    const int mode = knob_or("DEX_GEMM_NWALK", 1);       // 0: never, 2: whenever the shape allows (tests)
     if (mode == 0) return false;
     const long wgs = (long)((p.Ho * p.Wo + 63) / 64) * p.B;
     // small grids too (round 4): with one column tile per workgroup (nsplit = N / 64 below) the walker is the single-shot kernel with
@@ -586,7 +586,7 @@ static void launch_nwalk(const IGemmP& p, hipStream_t st) {
     // run back to back behind each other's store drain, more of them in flight hide it (measured at B=32: 115 -> ? us)
     const long wgs = (long)((p.Ho * p.Wo + 63) / 64) * p.B;
     int nsplit = 1;
-    static const int fs = getenv("DEX_NWALK_SPLIT") ? atoi(getenv("DEX_NWALK_SPLIT")) : 0;
+    const int fs = knob_or("DEX_NWALK_SPLIT", 0);
     while (nsplit < 4 && wgs * nsplit < 1280 && (p.N / 64) % (nsplit * 2) == 0) nsplit *= 2;
     if (wgs <= 16) nsplit = p.N / 64;              // small grid: one column tile per workgroup
     if (fs > 0 && (p.N / 64) % fs == 0) nsplit = fs;

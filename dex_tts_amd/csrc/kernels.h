@@ -301,7 +301,7 @@ constexpr size_t DIT_CLUSTER_FLAG_WORDS = 2 * DIT_CLUSTER;
 bool dit_rowchain64_form(int rows_per_batch, int B, int attn_inline);     // the 64-row batch form takes this launch (the one that implements DitChainP::o_lp)
 bool dit_rowchain_cluster_form(int rows_per_batch, int B);
 bool dit_rowchain_cluster_local_fits(int rows_per_batch, int B);
-int dit_rowchain_cluster_xcds(int rows_per_batch, int B);          // XCDs the XCD-local clusters are dealt to (DitChainP::xcds)
+int dit_rowchain_cluster_xcds(int rows_per_batch, int B);          // XCDs the XCD-local clusters are dealt to (DitChainP::xcds): 8 unless DEX_DIT_XCDS packs them
 bool dit_rowchain_supported(int hidden, int mlp_hidden);
 // Softmax attention on the row chain's bf16 operands (2 heads x 128): no staging, K / V^T / Q fragments are read
 // straight from global memory.  O: fp32 [ksplit][B][N][256] partials + ml (merged by the next row chain launch).

@@ -218,8 +218,8 @@ void launch_pos_conv_direct(const PosConvP& p0, hipStream_t st) {
     PosConvP p = p0;
     // one live column in the last 32-column tile (Wt = 65 in every shipped config at the BASELINE shapes) and enough row
     // workgroups that the extra column workgroups are noise: the column form (see the header).  DEX_POS_COL=0 disables it.
-    static const bool col_off = [] { const char* e = getenv("DEX_POS_COL"); return e && e[0] == '0'; }();
-    static const long col_min = [] { const char* e = getenv("DEX_POS_COL_MIN"); return e ? atol(e) : 512L; }();
+    const bool col_off = knob_off("DEX_POS_COL");
+    const long col_min = knob_or("DEX_POS_COL_MIN", 512);
     p.ncol = (!col_off && p.Wt > 32 && p.Wt % 32 == 1 && p.Hf <= 32 && (long)p.Hf * p.B * p.G >= col_min) ? 1 : 0;
     // widest chunk (fewest halo columns) whose patch still lets two workgroups share a CU (three when the grid is
     // large), but never so wide that a small batch leaves CUs idle.  Measured (us, CT = 3 / 2 / 1):
@@ -235,7 +235,7 @@ void launch_pos_conv_direct(const PosConvP& p0, hipStream_t st) {
     // then allows two, not three, workgroups per CU: DEX B=32 166 vs 210 us, GeDEX B=32 66 vs 85)
     if (wgs_of(ct) >= 2048 && !(p.ncol && tiles == 2)) while (ct > 1 && lds_of(ct) > 53 * 1024) --ct;
     while (ct > 1 && wgs_of(ct) < 192) --ct;
-    static const int ct_env = [] { const char* e = getenv("DEX_POS_CT"); return e ? atoi(e) : 0; }();
+    const int ct_env = knob_or("DEX_POS_CT", 0);
     if (ct_env >= 1 && ct_env <= 3 && ct_env <= tiles) ct = ct_env;
     if (ct == 3) launch_pc<3>(p, st);
     else if (ct == 2) launch_pc<2>(p, st);

@@ -353,13 +353,13 @@ void launch_first_conv(const FirstConvP& p, hipStream_t st) {
     const long npu = (long)p.H * p.T;
     const int ppb = p.C == 128 ? 32 : 64;
     long blocks = (npu + ppb - 1) / ppb;                          // one group per block at small batch ...
-    static const long capt = getenv("DEX_FIRST_CAP") ? atol(getenv("DEX_FIRST_CAP")) : 4096;
+    const long capt = knob_or("DEX_FIRST_CAP", 4096);
     const long cap = capt / p.B > 32 ? capt / p.B : 32;           // ... about two rounds of resident blocks at large batch
     if (blocks > cap) blocks = cap;
-    static const int mfma = getenv("DEX_FIRST_MFMA") ? atoi(getenv("DEX_FIRST_MFMA")) : 1;       // 0: the VALU form
+    const int mfma = knob_or("DEX_FIRST_MFMA", 1);       // 0: the VALU form
     if (mfma) {
         long nb = (npu + 127) / 128;                               // 4 waves x 32 pixels per block pass
-        static const long capm = getenv("DEX_FIRST_CAP") ? atol(getenv("DEX_FIRST_CAP")) : 1024;   // measured at B=32: 8192 blocks 122 us, 4096 112, 2048 103, 1024 99
+        const long capm = knob_or("DEX_FIRST_CAP", 1024);   // measured at B=32: 8192 blocks 122 us, 4096 112, 2048 103, 1024 99
         const long cm = capm / p.B > 16 ? capm / p.B : 16;
         if (nb > cm) nb = cm;
         const dim3 g2((unsigned)nb, p.B);
@@ -627,7 +627,7 @@ void launch_final(const FinalP& p, hipStream_t st) {
     // ... several passes at large batch: every block pays the GroupNorm-coefficient prologue (fp64 divide + sqrt behind a barrier,
     // 72 coefficient loads), so about one round of resident blocks is best (measured at B=32: 16384 blocks 87 us, 8192 85, 4096 74,
     // 2048 68)
-    static const long capt = getenv("DEX_FINAL_CAP") ? atol(getenv("DEX_FINAL_CAP")) : 2048;
+    const long capt = knob_or("DEX_FINAL_CAP", 2048);
     const long cap = capt / p.B > 32 ? capt / p.B : 32;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(final_kernel, dim3((unsigned)blocks, p.B), dim3(256), 0, st, p);

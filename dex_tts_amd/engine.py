@@ -189,6 +189,8 @@ class ScoreNetEngine:
         """ablation_sampler(solver, edm, linear, none) for latent z — edm.py:109-216.  ``solver`` is 'euler' (what
         Diffusion wires, diffusion.py:216) or 'heun' (edm.py:207-214; 2n-1 network evaluations).  Asynchronous.
         ``use_graph``: the whole call (conditioning tables + every network evaluation) is one cached hipGraph.
+        Small grids (B x row tiles <= 64: the cluster form of the DiT block) BLOCK the host until the call has finished when
+        ``check_handoffs`` is on (the default): the hand-off word is read before the mel is handed out.
         ``S_churn > 0`` turns on the stochastic sampler (edm.py:194-196); ``noise`` [n_steps,B,80,T] then holds step i's
         ``randn_like(x_cur)`` draw (the caller owns the RNG, as with ablation_sampler's ``randn_like`` argument)."""
         with torch.cuda.device(self.device):
@@ -249,9 +251,9 @@ class ScoreNetEngine:
                     rc = self.lib.dex_call_status(self.h, self._stream()) if self.check_handoffs else 0
                     if rc == 0:
                         break
-                    msg = self.lib.dex_last_error(self.h) or b""
-                    if attempt == 0 and b"another XCD" in msg:
+                    if attempt == 0 and rc == _lib.DEX_ERR_HANDOFF_XCD:
                         continue                   # the XCD-local form was just switched off for this device: the repeat is placement-independent
+                    msg = self.lib.dex_last_error(self.h) or b""
                     raise RuntimeError(f"libdexamd error {rc}: {msg.decode()}")
                 self._keep = keep + [z]           # keep inputs alive until the stream work is enqueued & consumed
                 if use_graph:

@@ -36,7 +36,9 @@ typedef enum {
     DEX_ERR_STATE = -2,    /* call order (weights missing, not finalized) */
     DEX_ERR_HIP = -3,      /* a HIP runtime call failed */
     DEX_ERR_WORKSPACE = -4,/* workspace too small */
-    DEX_ERR_HANDOFF = -5   /* dex_call_status: an in-launch hand-off of the small-batch DiT block failed; the call's outputs are NaN */
+    DEX_ERR_HANDOFF = -5,  /* dex_call_status: an in-launch hand-off of the small-batch DiT block timed out; the call's outputs are NaN */
+    DEX_ERR_HANDOFF_XCD = -6 /* dex_call_status: a hand-off met its peer on another XCD (outputs NaN); the XCD-local form is now off for the
+                              * device, so REPEATING the call succeeds */
 } DexStatus;
 
 typedef enum { DEX_VARIANT_GEDEX = 0, DEX_VARIANT_DEX = 1 } DexVariant;
@@ -148,9 +150,10 @@ int  dex_profile_get(const DexCtx* ctx, int i, const char** name, int* calls, do
 
 /* Status of the LAST dex_sample / dex_denoise_once call of this context on `stream`.  Small-grid DiT blocks run as clusters of
  * co-operating workgroups whose in-launch hand-offs are bounded waits: a lost hand-off cannot hang the GPU, it turns every output of
- * the call into NaN and sets a device word.  This call waits for the stream and reads that word: DEX_OK, or DEX_ERR_HANDOFF (the
- * outputs are NaN).  When the cause was a peer on another XCD the XCD-local form is switched off for the device - for every
- * context - so repeating the call succeeds.  Calls that used no hand-offs return DEX_OK without waiting.  The Python mirror
+ * the call into NaN and sets a device word.  This call waits for the stream and reads that word: DEX_OK, DEX_ERR_HANDOFF (a
+ * time-out) or DEX_ERR_HANDOFF_XCD (a peer on another XCD) - the outputs are NaN in both.  In the second case the XCD-local form is
+ * switched off for the device - for every context - so repeating the call succeeds.  A hipGraph replay is checked like an eager call
+ * (the graph entry remembers the word its captured launches write).  Calls that used no hand-offs return DEX_OK without waiting.  The Python mirror
  * (ScoreNetEngine.sample) checks every call that could use hand-offs and raises. */
 int  dex_call_status(DexCtx* ctx, dex_stream_t stream);
 /* Debug: 1 if a workgroup hand-off of the LAST dex_sample / dex_denoise_once call on this context timed out (small-grid DiT

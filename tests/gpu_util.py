@@ -15,6 +15,9 @@ from oracle import dex_oracle as O  # noqa: E402
 
 _ENG = {}
 _LOG = os.path.join(ROOT, "gpurun_out")
+# the CPU oracle's small-tensor torch ops run SLOWER on all 256 logical CPUs of the GPU box's host than on 16 threads (bench.py's
+# cpu_baseline measured both: 16 wins); the whole-job tests (tests/test_gpu_full_jobs.py) run the oracle for minutes
+torch.set_num_threads(min(16, torch.get_num_threads()))
 
 
 def record(tag, **vals):

@@ -290,7 +290,7 @@ def test_residual_stream_16bit_stores_error(name, kw, prec):
 
 @pytest.mark.parametrize("name,kw", [
     ("gedex_lj", dict(B=32, T=512, lengths=[512 - 9 * i for i in range(32)])),      # fused DiT block with the in-kernel attention: element b's row tiles on XCD b % 8
-    ("dex_vctk", dict(B=32, T=512, lengths=[512 - 9 * i for i in range(32)], Tr=60, Ts=60)),   # N = 1300: the attention as its own launch (shared-ring kernel, 1-D grid)
+    ("dex_vctk", dict(B=32, T=512, lengths=[512 - 9 * i for i in range(32)], Tr=60, Ts=60)),   # N = 2580: the attention as its own launch (64-query kernel, 41-tile units; oracle check: tests/test_gpu_full_jobs.py)
     ("gedex_lj", dict(B=8, T=512, lengths=[512 - 30 * i for i in range(8)])),       # one element per XCD
     ("dex_vctk", dict(B=16, T=256, lengths=[256 - 9 * i for i in range(16)], Tr=60, Ts=60)),   # shared-ring kernel with TWO key splits per (element, head)
 ])

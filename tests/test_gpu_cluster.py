@@ -136,6 +136,52 @@ def test_xcd_local_clusters_equal_cross_xcd_clusters_bitwise(name, kw, n, prec):
         eng.set_precision("fp32")
 
 
+def test_lost_handoff_is_loud_on_graph_replays_too():
+    """a hipGraph REPLAY enqueues nothing on the host, so the status check must read the word the captured launches write
+    (kept in the graph entry).  With the drop knob set, the first graph call captures (and fails), the second is a cache hit under an
+    unchanged key - both must raise, and handoff_timeouts() must see the word after each."""
+    cfg, eng, w = U.engine_for("gedex_lj")
+    case = U.make_case(cfg, B=1, T=64)
+    eng.set_precision("bf16")
+    try:
+        good = _run(eng, case, 2, graph=True)
+        assert np.array_equal(good, _run(eng, case, 2, graph=True)) and eng.handoff_timeouts() == 0     # clean capture, clean replay
+        os.environ["DEX_DEBUG_DROP_HANDOFF"] = "1"
+        try:
+            for _ in range(3):                                                   # capture, then two replay hits
+                with pytest.raises(RuntimeError, match="hand-off timed out"):
+                    _run(eng, case, 2, graph=True)
+                assert eng.handoff_timeouts() == 1
+        finally:
+            del os.environ["DEX_DEBUG_DROP_HANDOFF"]
+        assert np.array_equal(good, _run(eng, case, 2, graph=True)) and eng.handoff_timeouts() == 0     # the clean graph is still cached and clean
+    finally:
+        eng.set_precision("fp32")
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_clusters_packed_onto_three_xcds_are_bit_identical(prec):
+    """DEX_DIT_XCDS=3: the 21 clusters of the headline shape dealt to 3 XCDs (7 x 4 workgroups each) instead of 8 - same arithmetic, same
+    bits; keeps the packed blockIdx -> (cluster, member) mapping covered while the default stays 8."""
+    cfg, eng, w = U.engine_for("gedex_lj")
+    if eng.xcd_local() != 1:
+        pytest.skip("XCD-local form off on this device")
+    case = U.make_case(cfg, B=1, T=512)
+    eng.set_precision(prec)
+    try:
+        a = _run(eng, case, 3)
+        os.environ["DEX_DIT_XCDS"] = "3"
+        try:
+            b = _run(eng, case, 3)
+            g = _run(eng, case, 3, graph=True)
+            assert eng.handoff_timeouts() == 0
+        finally:
+            del os.environ["DEX_DIT_XCDS"]
+        assert np.isfinite(a).all() and np.array_equal(a, b) and np.array_equal(a, g)
+    finally:
+        eng.set_precision("fp32")
+
+
 def test_l2_scope_handoff_across_xcds_is_loud():
     """DEX_DEBUG_DROP_HANDOFF=2 runs the XCD-local protocol on clusters whose members sit on DIFFERENT XCDs (what a device with
     another workgroup placement rule would do to it): the peers' plain stores never reach this XCD's L2 in time (time-out, 1) or
