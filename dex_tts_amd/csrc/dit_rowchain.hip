@@ -1046,6 +1046,8 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain64p_kernel(const DitCh
     {   // parameter rows -> LDS (float2 per thread and round)
         for (int e = tid; e < P_FLOATS / 2; e += RC_NW * 64) {
             const int f = 2 * e, row = f >> 8, c = f & 255;
+            // (uniform per row) the last block has no qkv stage (bq, next_* are null) and the first launch nothing but it (ada, bp, b1, b2 unused)
+            if (f >= P_BQ ? !has_q : p.qkv_only ? (f >= P_B1 || (row != P_SHN && row != P_SCN)) : false) continue;
             const float* src = f >= P_BQ ? p.bq + (f - P_BQ) : f >= P_B1 ? p.b1 + (f - P_B1)
                              : row == P_SHM ? ada + 3 * RC_H + c : row == P_SCM ? ada + 4 * RC_H + c
                              : row == P_SHN ? (has_q ? p.next_shift + (long)step * p.next_step_stride + c : ada + c)
@@ -1219,6 +1221,7 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain64p_kernel(const DitCh
     auto qkv_fill = [&](auto kind, const f32x16& a_, int nt, int mt) __attribute__((always_inline)) {
         return [&, nt, mt](int j) __attribute__((always_inline)) {
             constexpr int KIND = decltype(kind)::value;
+            if (n0 + 32 * mt >= p.Npad) return;          // (uniform) the operand buffers hold ceil(N / 32) row tiles per (utterance, head)
             if (j == 3) qkv_half<KIND>(p, a_, PRM, nt, b, n0 + 32 * mt, lane, 0);
             if (j == 10) qkv_half<KIND>(p, a_, PRM, nt, b, n0 + 32 * mt, lane, 1);
         };
@@ -1236,8 +1239,10 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain64p_kernel(const DitCh
     rc_tile<false, false, true, true>(acc, w, nullptr, ar, a_lane, a_lane + 32 * A_LD, qkv_fill(K1{}, accp, wave + 8, 1));
     accp = acc; acc = zero16();
     rc_tile<false, false, true, false>(acc, w, nullptr, ar, a_lane + 32 * A_LD, nullptr, qkv_fill(K2{}, accp, wave + 16, 0));
-    qkv_half<2>(p, acc, PRM, wave + 16, b, n0 + 32, lane, 0);
-    qkv_half<2>(p, acc, PRM, wave + 16, b, n0 + 32, lane, 1);
+    if (n0 + 32 < p.Npad) {
+        qkv_half<2>(p, acc, PRM, wave + 16, b, n0 + 32, lane, 0);
+        qkv_half<2>(p, acc, PRM, wave + 16, b, n0 + 32, lane, 1);
+    }
 #ifdef DEX_TIMING
     if (p.dbg && tid == 0) { tst[8] = wall_clock64(); tst[9] = tst[8]; for (int q_ = 0; q_ < 10; ++q_) p.dbg[(long)blockIdx.x * 16 + q_] = tst[q_]; }
 #endif
@@ -1873,7 +1878,7 @@ void launch_dit_rowchain(const DitChainP& p, hipStream_t st) {
                 attr64 = true;
             }
 #ifndef DEX_LP_WSPLIT
-            if (knob_or("DEX_ROWCHAIN64P", 1)) {          // the software-pipelined form (0: the round-3 kernel)
+            if (knob_or("DEX_ROWCHAIN64P", 0)) {          // 1: the software-pipelined C++ form (measured slower than the round-3 kernel: 108 vs 106 us in tools/rc64bench; opt-in)
                 static bool attr64p = false;
                 if (!attr64p) {
                     hipFuncSetAttribute(reinterpret_cast<const void*>(&dit_rowchain64p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC64P_LDS);

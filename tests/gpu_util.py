@@ -156,5 +156,29 @@ def run_sampler(name, case, n_steps, use_graph=False, solver="euler"):
     got = eng.sample(z, mask, mu, n_steps, use_graph=use_graph, solver=solver, **engine_kwargs(case)).cpu().numpy()
     okey = (name, "sampler", int(n_steps), solver, _case_key(case))
     if okey not in _ORACLE:
-        _ORACLE[okey] = O.diffusion_infer(W, cfg, mask, mu, n_steps, z, solver=solver, **oracle_kwargs(case)).numpy()
+        _ORACLE[okey] = oracle_sampler_stored(name, case, n_steps, solver)
     return got, _ORACLE[okey]
+
+
+ORACLE_JOBS = os.path.join(ROOT, "tests", "golden", "oracle_jobs")
+
+
+def oracle_job_path(name, case, n_steps, solver="euler"):
+    import hashlib
+    h = hashlib.sha1(repr((name, int(n_steps), solver, _case_key(case))).encode()).hexdigest()[:16]
+    return os.path.join(ORACLE_JOBS, f"{name}_n{int(n_steps)}_{solver}_{h}.npy")
+
+
+def oracle_sampler_stored(name, case, n_steps, solver="euler"):
+    """The CPU oracle's result of a whole sampler job.  The long batch jobs (B = 32, 50 / 100 Euler steps: 5 - 11 minutes of host time
+    each) are committed under tests/golden/oracle_jobs/ - the oracle's OUTPUT on the portable synthetic inputs, keyed by a hash of the
+    inputs, written by oracle/make_oracle_jobs.py on the CPU - so the GPU suite does not spend a quarter of an hour of box time on them;
+    any job without a stored file is computed here."""
+    path = oracle_job_path(name, case, n_steps, solver)
+    if os.path.exists(path):
+        return np.load(path)
+    cfg = C.PRESETS[name]()
+    w = synth.make_weights(C.param_shapes(cfg))
+    W = O.as_torch(w, torch.float32)
+    mu, mask, z = (torch.from_numpy(case[k]) for k in ("mu", "mask", "z"))
+    return O.diffusion_infer(W, cfg, mask, mu, n_steps, z, solver=solver, **oracle_kwargs(case)).numpy()

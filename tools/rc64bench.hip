@@ -24,14 +24,15 @@ static void* dfill(size_t bytes, bool half, unsigned seed) {
 
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 1300, B = argc > 2 ? atoi(argv[2]) : 32, o_lp = argc > 3 ? atoi(argv[3]) : 1;
-    const int Npad = (N + 31) / 32 * 32 + 32;
+    const int Npad = (N + 31) / 32 * 32;        // the product's padding (dex_api.hip); the buffers carry a guard tile behind the last head
     const size_t xb = (size_t)B * N * 256 * 4;
     float* X0 = (float*)dfill(xb, false, 1);
     float* X; hipMalloc(&X, xb);
     void* O = dfill((size_t)B * N * 256 * (o_lp ? 2 : 4), o_lp != 0, 7);
     void *Wp = dfill(256 * 256 * 2, true, 2), *W1 = dfill(256 * 512 * 2, true, 3), *W2 = dfill(512 * 256 * 2, true, 4), *Wq = dfill(256 * 768 * 2, true, 5);
     void* qkv[3];
-    for (int k = 0; k < 3; ++k) { hipMalloc(&qkv[k], (size_t)B * 2 * Npad * 128 * 2); hipMemset(qkv[k], 0, (size_t)B * 2 * Npad * 128 * 2); }
+    const size_t qbytes = (size_t)B * 2 * Npad * 128 * 2, qguard = 64 * 128 * 2;
+    for (int k = 0; k < 3; ++k) { hipMalloc(&qkv[k], qbytes + qguard); hipMemset(qkv[k], 0, qbytes + qguard); }
     float* bias = (float*)dfill(768 * 4, false, 6); float* ada = (float*)dfill(6 * 256 * 4, false, 8);
     DitChainP c{}; c.heads = 2; c.rows_per_batch = N; c.X = X; c.Wp = Wp; c.W1 = W1; c.W2 = W2; c.Wq = Wq; c.bp = bias; c.b1 = bias; c.b2 = bias; c.bq = bias;
     c.ada = ada; c.next_shift = ada; c.next_scale = ada + 256; c.next_step_stride = 0; c.Npad = Npad; c.qscale = 0.088f * 1.4427f; c.M = B * N; c.B = B;
@@ -60,6 +61,7 @@ int main(int argc, char** argv) {
         for (int k = 0; k < 3; ++k) { std::vector<unsigned short> hq((size_t)B * 2 * Npad * 128); hipMemcpy(hq.data(), qkv[k], hq.size() * 2, hipMemcpyDeviceToHost);
             unsigned long long t = 0; const long tiles = (N + 31) / 32;
             for (int bh = 0; bh < B * 2; ++bh) for (long e = 0; e < tiles * 4096; ++e) t = t * 1000003ull + hq[(size_t)bh * Npad * 128 + e];
+            { std::vector<unsigned short> g(qguard / 2); hipMemcpy(g.data(), (char*)qkv[k] + qbytes, qguard, hipMemcpyDeviceToHost); for (auto u : g) if (u) { printf("  !! write behind the operand buffer %d\n", k); break; } }
             sq[k] = t; }
         float* fx = (float*)hx.data(); double m = 0; for (size_t i = 0; i < hx.size(); ++i) m = std::max(m, (double)fabsf(fx[i]));
         printf("  checksum X %016llx q %016llx k %016llx vT %016llx  |X|max %.4f\n", s, sq[0], sq[1], sq[2], m);
