@@ -1248,6 +1248,116 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain64p_kernel(const DitCh
 #endif
 }
 
+// ---- 64-row form, round 5: GENERATED INSTRUCTION STREAMS ("a" form, dit_rowchain64a_kernel; tools/gen_rowchain_a.py ->
+// dit_rowchain_a_core.inc).  Four waves, one per SIMD, each owning 64 features x 64 tokens of every stage; the weights stream through a
+// 56-fragment ring in the accumulation file, the residual rows stay in registers, every epilogue sits in the MFMA gaps of the next
+// pass - the generator's header has the register map and the schedule.  This shell stages the parameter rows (LDS) and hands the
+// statement its buffer descriptors; the statement owns v0..v249, a0..a255 and the rest of LDS.  Taken when the attention output
+// arrives as 16-bit rows (o_lp: one key split, no tail split) - the other cases keep the kernel above.
+#ifndef DEX_LP_WSPLIT
+#ifndef RCA_CORE_INC
+#define RCA_CORE_INC "dit_rowchain_a_core.inc"
+#endif
+#include RCA_CORE_INC
+#ifdef DEX_LP_F16
+#define RCA_MFMA "v_mfma_f32_32x32x16_f16"
+#define RCA_PK "v_cvt_pk_f16_f32"
+#else
+#define RCA_MFMA "v_mfma_f32_32x32x16_bf16"
+#define RCA_PK "v_cvt_pk_bf16_f32"
+#endif
+__global__ __launch_bounds__(256) void dit_rowchain64a_kernel(const DitChainP p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_rc[];
+    float* PRM = reinterpret_cast<float*>(smem_rc + RCA_LDS_PRM);
+    const int tid = threadIdx.x;
+#ifdef RCA_TIMING
+    const long long t_entry = clock64();
+#endif
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = p.rows_per_batch, tpb = (N + 63) / 64, ntiles = p.B * tpb;
+    const int step = p.step;
+    const float* ada = p.ada + (long)step * 6 * RC_H;
+    const bool has_q = p.next_shift != nullptr;
+    const unsigned long long wp = reinterpret_cast<unsigned long long>(p.Wp), w1 = reinterpret_cast<unsigned long long>(p.W1);
+    const unsigned long long w2 = reinterpret_cast<unsigned long long>(p.W2), wq = reinterpret_cast<unsigned long long>(p.Wq);
+    const unsigned qs = __float_as_uint(p.qscale);
+    // descriptors of a tile (64 rows of one utterance): the residual rows and the O rows of its utterance (rows >= N are out of range:
+    // stores dropped), this wave's head of q / k / v^T (feature tiles 2w, 2w + 1: head w >> 1); `on` = false: zero records (a prefetch
+    // past the workgroup's last tile reads zeros)
+#define RCA_DESC(SFX, TILE, ON)                                                                                                                         \
+    const int b##SFX = (TILE) / tpb, n0##SFX = ((TILE) - b##SFX * tpb) * 64;                                                                           \
+    const auto rx##SFX = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.X + (long)b##SFX * N * RC_H), 0, (ON) ? N * RC_H * 4 : 0, 0x00020000); \
+    const auto ro##SFX = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(p.O)) + (long)b##SFX * N * RC_H * 2, 0, \
+                                                           (ON) && !p.qkv_only ? N * RC_H * 2 : 0, 0x00020000);
+#define RCA_OPERANDS                                                                                                                     \
+        : : [tid] "v"(tid), [w] "s"(wave), [n0] "s"(n0), [nm1] "s"(N - 1), [qscale] "s"(qs), [rx] "s"(rx), [ro] "s"(ro), [rq] "s"(rq), [rk] "s"(rk), [rv] "s"(rv), \
+            [n0_n] "s"(n0_n), [rx_n] "s"(rx_n), [ro_n] "s"(ro_n),                                                                         \
+            [wp_lo] "s"((unsigned)wp), [wp_hi] "s"((unsigned)(wp >> 32)), [w1_lo] "s"((unsigned)w1), [w1_hi] "s"((unsigned)(w1 >> 32)),  \
+            [w2_lo] "s"((unsigned)w2), [w2_hi] "s"((unsigned)(w2 >> 32)), [wq_lo] "s"((unsigned)wq), [wq_hi] "s"((unsigned)(wq >> 32)),  \
+            [dbg] "s"(dbg)                                                                                                                 \
+        : RCA_CLOBBER
+    int tile = blockIdx.x;
+    {   // ---- statement 1: the requests of the first tile that depend on nothing (O rows, residual rows, first weight fragments) leave first
+        RCA_DESC(, tile, true)
+        const int n0_n = n0; const auto rx_n = rx; const auto ro_n = ro;
+        const auto rq = rx, rk = rx, rv = rx;                       // (unused by this statement)
+        const long long* dbg = nullptr;
+        if (p.qkv_only) { asm volatile(RCA_ASM_PRE_QKV RCA_OPERANDS); }
+        else { asm volatile(RCA_ASM_PRE RCA_OPERANDS); }
+    }
+    // ---- parameter rows: 0 shift_mlp, 1 1 + scale_mlp, 2 next shift_msa, 3 1 + next scale_msa, 4 gate_msa, 5 b_proj, 6 gate_mlp, 7 b_fc2, then
+    // b_fc1 (2 rows) and b_qkv (3 rows): 13 rows of 256 floats, wave w takes rows w + 4 k - every load first, then the LDS writes (a
+    // loop of load -> store was 6 serial round trips, 8k cycles).  The last block has no qkv stage (bq, next_* null), the first launch
+    // nothing but it: such rows load a dummy (ada) and are not written.  (Nothing between the statements may touch the accumulation
+    // file - it holds requests in flight: tools/audit_rowchain_a.py checks the build.)
+    {
+        float4 v[4]; bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = wave + 4 * k;
+            const bool need_q = row >= 10 || row == 2 || row == 3;
+            ok[k] = row < 13 && (need_q ? has_q : !p.qkv_only);
+            const float* src = !ok[k] ? ada
+                             : row == 0 ? ada + 3 * RC_H : row == 1 ? ada + 4 * RC_H
+                             : row == 2 ? p.next_shift + (long)step * p.next_step_stride
+                             : row == 3 ? p.next_scale + (long)step * p.next_step_stride
+                             : row == 4 ? ada + 2 * RC_H : row == 5 ? p.bp : row == 6 ? ada + 5 * RC_H : row == 7 ? p.b2
+                             : row < 10 ? p.b1 + (row - 8) * RC_H : p.bq + (row - 10) * RC_H;
+            v[k] = reinterpret_cast<const float4*>(src)[tid & 63];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = wave + 4 * k;
+            if (row == 1 || row == 3) { v[k].x += 1.f; v[k].y += 1.f; v[k].z += 1.f; v[k].w += 1.f; }
+            if (ok[k]) reinterpret_cast<float4*>(PRM + row * RC_H)[tid & 63] = v[k];
+        }
+    }
+    // ---- one statement per tile: the chain; its q pass requests the next tile's rows (the workgroup walks tiles blockIdx.x, + gridDim.x, ..)
+    for (;;) {
+        const int next = tile + (int)gridDim.x;
+        const bool more = next < ntiles;
+        RCA_DESC(, tile, true)
+        RCA_DESC(_n, more ? next : tile, more)
+        const long hb = ((long)b * 2 + (wave >> 1)) * p.Npad * 256;
+        const int hsz = has_q ? p.Npad * 256 : 0;
+        const auto rq = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.Qh) + hb, 0, hsz, 0x00020000);
+        const auto rk = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.Kh) + hb, 0, hsz, 0x00020000);
+        const auto rv = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.Vt) + hb, 0, hsz, 0x00020000);
+        const long long* dbg = p.dbg ? p.dbg + ((long)tile * 4 + wave) * 32 : nullptr;          // (timing builds of the streams: one row of stamps per wave and tile)
+#ifdef RCA_TIMING
+        if (dbg && (tid & 63) == 0) const_cast<long long*>(dbg)[31] = tile == (int)blockIdx.x ? t_entry : 0;
+#endif
+        if (p.qkv_only) { asm volatile(RCA_ASM_QKV RCA_OPERANDS); }
+        else if (has_q) { asm volatile(RCA_ASM_FULL RCA_OPERANDS); }
+        else { asm volatile(RCA_ASM_LAST RCA_OPERANDS); }
+        if (!more) break;
+        tile = next;
+    }
+#undef RCA_OPERANDS
+#undef RCA_DESC
+}
+#endif
+
 // ---- cluster form (small grids: B x ceil(N / 32) row tiles <= 64).  At B = 1 the kernels above run 21 workgroups, each streaming
 // the K / V^T of both heads and every weight matrix of the block (1.7 MB) through ONE CU's L2 -> register path: 22 us of which no
 // phase is bound by anything but that path.  Here a 32-row tile belongs to a CLUSTER of DIT_CLUSTER = 4 workgroups
@@ -1878,6 +1988,19 @@ void launch_dit_rowchain(const DitChainP& p, hipStream_t st) {
                 attr64 = true;
             }
 #ifndef DEX_LP_WSPLIT
+            if (knob_or("DEX_ROWCHAIN64A", 1) && (p.qkv_only || (p.o_lp && p.ksplit <= 1 && p.tail_ks <= 1))) {   // the generated streams (0: the round-3 kernel)
+                static bool attr64a = false;
+                if (!attr64a) {
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(&dit_rowchain64a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RCA_LDS_BYTES);
+                    attr64a = true;
+                }
+                g_last_symbol = "dit_rowchain64a_kernel";
+                static int ncu = 0;
+                if (!ncu) { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); if (ncu <= 0) ncu = 256; }
+                const int ntiles = p.B * ((p.rows_per_batch + 63) / 64);
+                hipLaunchKernelGGL(dit_rowchain64a_kernel, dim3(ntiles < ncu ? ntiles : ncu), dim3(256), RCA_LDS_BYTES, st, p);      // persistent: one workgroup per CU walks its tiles
+                return;
+            }
             if (knob_or("DEX_ROWCHAIN64P", 0)) {          // 1: the software-pipelined C++ form (measured slower than the round-3 kernel: 108 vs 106 us in tools/rc64bench; opt-in)
                 static bool attr64p = false;
                 if (!attr64p) {

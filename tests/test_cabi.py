@@ -103,6 +103,23 @@ def test_generated_attention_streams_are_up_to_date():
     assert r.returncode == 0, "run python tools/gen_attn_q64.py and commit the .inc"
 
 
+def test_generated_rowchain_streams_are_up_to_date_and_their_registers_untouched():
+    """dex_tts_amd/csrc/dit_rowchain_a_core.inc is GENERATED (tools/gen_rowchain_a.py: register map, schedule, computed wait counts of
+    the 64-row DiT row chain): the committed file must be what the committed generator writes.  And the kernel is two asm statements
+    around a few lines of C++ with requests in flight into registers the compiler does not know about: tools/audit_rowchain_a.py compiles
+    the file and checks that no compiler-generated instruction of the kernel names one of them (both operand-type builds)."""
+    import shutil, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("RCAGEN_")}
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gen_rowchain_a.py"), "--check"], env=env)
+    assert r.returncode == 0, "run python tools/gen_rowchain_a.py and commit the .inc"
+    if shutil.which("/opt/rocm/bin/hipcc"):
+        sys.path.insert(0, os.path.join(root, "tools"))
+        import audit_rowchain_a
+        assert audit_rowchain_a.audit() == []
+        assert audit_rowchain_a.audit(["-DDEX_LP_F16"]) == []
+
+
 def test_every_knob_is_in_the_call_snapshot():
     """Every DEX_* variable the launchers consult goes through kernels.h knob() and is registered in dex_api.hip's KNOB_NAMES, i.e. it is
     read once per call and hashed into the graph-cache key (VERDICT r4 Weak #9: 28 process-static getenv reads sat outside both)."""

@@ -39,49 +39,73 @@ int main(int argc, char** argv) {
     c.O = (const float*)O; c.ksplit = 1; c.o_sstride = 0; c.o_lp = o_lp; c.Qh = qkv[0]; c.Kh = qkv[1]; c.Vt = qkv[2];
     setenv("DEX_ROWCHAIN64", "2", 1);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+#ifdef RCA_TIMING
+    long long* dbgbuf; hipMalloc(&dbgbuf, (size_t)B * ((N + 63) / 64) * 4 * 32 * 8); hipMemset(dbgbuf, 0, (size_t)B * ((N + 63) / 64) * 4 * 32 * 8);
+    c.dbg = dbgbuf;
+#endif
+    const char* mode_name[3] = {"block + next qkv", "last block (no qkv)", "qkv only (first launch)"};
+    for (int mode = 0; mode < 3; ++mode) {
+    DitChainP m = c;
+    if (mode == 1) { m.next_shift = m.next_scale = nullptr; m.Wq = nullptr; m.bq = nullptr; }
+    if (mode == 2) m.qkv_only = 1;
     std::vector<float> keepX; std::vector<unsigned short> keepQ[3];
+    printf("-- %s\n", mode_name[mode]);
     for (int form = 0; form < 2; ++form) {
-    setenv("DEX_ROWCHAIN64P", form ? "1" : "0", 1);
-    for (int i = 0; i < 3; ++i) launch_dit_rowchain(c, 0);
+    setenv("DEX_ROWCHAIN64A", form ? "1" : "0", 1);
+    for (int i = 0; i < 3; ++i) launch_dit_rowchain(m, 0);
     hipDeviceSynchronize();
     const int iters = 50;
     hipEventRecord(a, 0);
-    for (int i = 0; i < iters; ++i) launch_dit_rowchain(c, 0);
+    for (int i = 0; i < iters; ++i) launch_dit_rowchain(m, 0);
     hipEventRecord(b, 0); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
-    const double fl = 2.0 * B * N * (256.0 * 256 + 2 * 256.0 * 512 + 256.0 * 768);
+    const double fl = 2.0 * B * N * ((mode == 2 ? 0.0 : 256.0 * 256 + 2 * 256.0 * 512) + (mode == 1 ? 0.0 : 256.0 * 768));
     printf("%s N=%d B=%d o_lp=%d: %.2f us per launch (back to back), %.1f TFLOP/s\n", g_last_symbol, N, B, o_lp, ms * 1e3 / iters, fl / (ms * 1e-3 / iters) / 1e12);
-    // checksum of one launch from a fixed input (A/B of kernel versions: must be bitwise equal)
+    // one launch from a fixed input; the two forms against each other (not bitwise: the LayerNorm statistics are summed in another order)
     hipMemcpy(X, X0, xb, hipMemcpyDeviceToDevice);
-    launch_dit_rowchain(c, 0); hipDeviceSynchronize();
+    for (int k = 0; k < 3; ++k) hipMemset(qkv[k], 0, qbytes + qguard);
+    launch_dit_rowchain(m, 0); hipDeviceSynchronize();
     {
-        std::vector<unsigned> hx(xb / 4); hipMemcpy(hx.data(), X, xb, hipMemcpyDeviceToHost);
-        unsigned long long s = 0; for (size_t i = 0; i < hx.size(); ++i) s = s * 1000003ull + hx[i];
-        unsigned long long sq[3];
-        for (int k = 0; k < 3; ++k) { std::vector<unsigned short> hq((size_t)B * 2 * Npad * 128); hipMemcpy(hq.data(), qkv[k], hq.size() * 2, hipMemcpyDeviceToHost);
-            unsigned long long t = 0; const long tiles = (N + 31) / 32;
-            for (int bh = 0; bh < B * 2; ++bh) for (long e = 0; e < tiles * 4096; ++e) t = t * 1000003ull + hq[(size_t)bh * Npad * 128 + e];
-            { std::vector<unsigned short> g(qguard / 2); hipMemcpy(g.data(), (char*)qkv[k] + qbytes, qguard, hipMemcpyDeviceToHost); for (auto u : g) if (u) { printf("  !! write behind the operand buffer %d\n", k); break; } }
-            sq[k] = t; }
-        float* fx = (float*)hx.data(); double m = 0; for (size_t i = 0; i < hx.size(); ++i) m = std::max(m, (double)fabsf(fx[i]));
-        printf("  checksum X %016llx q %016llx k %016llx vT %016llx  |X|max %.4f\n", s, sq[0], sq[1], sq[2], m);
-        // the two forms against each other (not bitwise: the LayerNorm statistics are summed in another order)
+        std::vector<float> hx(xb / 4); hipMemcpy(hx.data(), X, xb, hipMemcpyDeviceToHost);
         std::vector<unsigned short> hq[3];
-        for (int k = 0; k < 3; ++k) { hq[k].resize((size_t)B * 2 * Npad * 128); hipMemcpy(hq[k].data(), qkv[k], hq[k].size() * 2, hipMemcpyDeviceToHost); }
-        if (form == 0) { keepX.assign(fx, fx + hx.size()); for (int k = 0; k < 3; ++k) keepQ[k] = hq[k]; }
+        for (int k = 0; k < 3; ++k) { hq[k].resize((qbytes + qguard) / 2); hipMemcpy(hq[k].data(), qkv[k], qbytes + qguard, hipMemcpyDeviceToHost);
+            for (size_t e = qbytes / 2; e < hq[k].size(); ++e) if (hq[k][e]) { printf("  !! write behind the operand buffer %d\n", k); break; } }
+        double mx = 0; for (float v : hx) mx = std::max(mx, (double)fabsf(v));
+        if (form == 0) { keepX = hx; for (int k = 0; k < 3; ++k) keepQ[k] = hq[k]; printf("  |X|max %.4f\n", mx); }
         else {
-            double dx = 0; size_t nbad = 0;
-            for (size_t i = 0; i < hx.size(); ++i) { const double d = fabs((double)fx[i] - keepX[i]); if (!(d <= 1e30)) ++nbad; else dx = std::max(dx, d); }
-            printf("  p form vs round-3 form: X max|d| %.3e (%zu non-finite)", dx, nbad);
+            double dx = 0; size_t nbad = 0, nd = 0;
+            for (size_t i = 0; i < hx.size(); ++i) { const double d = fabs((double)hx[i] - keepX[i]); if (!(d <= 1e30)) ++nbad; else { dx = std::max(dx, d); if (d > 1e-3) ++nd; } }
+            printf("  a form vs round-3 form: X max|d| %.3e (%zu non-finite, %zu above 1e-3)", dx, nbad, nd);
             auto bf = [](unsigned short u) { unsigned v = (unsigned)u << 16; float f; memcpy(&f, &v, 4); return (double)f; };
-            const long tiles = (N + 31) / 32;
-            for (int k = 0; k < 3; ++k) { double dq = 0, mq = 0; size_t nd = 0, tot = 0;
-                for (int bh = 0; bh < B * 2; ++bh) for (long e = 0; e < tiles * 4096; ++e) { const size_t ix = (size_t)bh * Npad * 128 + e; ++tot;
-                    const double u = bf(hq[k][ix]), v = bf(keepQ[k][ix]); if (hq[k][ix] != keepQ[k][ix]) ++nd; dq = std::max(dq, fabs(u - v)); mq = std::max(mq, fabs(v)); }
-                printf("  %s: %zu of %zu differ, max|d| %.3e (|v|max %.3f)", k == 0 ? "q" : k == 1 ? "k" : "vT", nd, tot, dq, mq); }
+            for (int k = 0; k < 3; ++k) { double dq = 0, mq = 0; size_t ndq = 0, big = 0;
+                for (size_t ix = 0; ix < qbytes / 2; ++ix) { const double u = bf(hq[k][ix]), v = bf(keepQ[k][ix]); if (hq[k][ix] != keepQ[k][ix]) ++ndq;
+                    const double d = fabs(u - v); if (!(d <= 1e30)) { ++big; continue; } dq = std::max(dq, d); mq = std::max(mq, fabs(v)); if (d > 0.02 * std::max(1.0, fabs(v))) ++big; }
+                printf("  %s: %zu of %zu differ (%zu by more than 2 %%), max|d| %.3e (|v|max %.3f)", k == 0 ? "q" : k == 1 ? "k" : "vT", ndq, qbytes / 2, big, dq, mq); }
             printf("\n");
         }
     }
+#ifdef RCA_TIMING
+    if (form == 1 && mode == 0) {
+        m.dbg = dbgbuf; launch_dit_rowchain(m, 0); hipDeviceSynchronize();
+        const int nb = B * ((N + 63) / 64);
+        std::vector<long long> h((size_t)nb * 4 * 32); hipMemcpy(h.data(), dbgbuf, h.size() * 8, hipMemcpyDeviceToHost);
+        const char* nm[] = {RCA_ASM_FULL_STAMPS};
+        const int ns = (int)(sizeof(nm) / sizeof(nm[0]));
+        std::vector<double> ph(ns, 0.0); long long t0 = h[0], t1 = 0;
+        for (int r = 0; r < nb * 4; ++r) { t0 = std::min(t0, h[(size_t)r * 32]); t1 = std::max(t1, h[(size_t)r * 32 + ns - 1]); for (int k = 1; k < ns; ++k) ph[k] += (double)(h[(size_t)r * 32 + k] - h[(size_t)r * 32 + k - 1]); }
+        { double r1 = 0, r2 = 0; int n1 = 0, n2 = 0; for (int r = 0; r < nb * 4; ++r) { const double d = (double)(h[(size_t)r * 32 + ns - 1] - h[(size_t)r * 32]); if (r < 256 * 4) { r1 += d; ++n1; } else { r2 += d; ++n2; } }
+          printf("  start -> end per wave: workgroups 0..255 %.0f, the later ones %.0f cycles\n", r1 / std::max(n1, 1), r2 / std::max(n2, 1)); }
+        { double pr = 0; for (int r = 0; r < nb * 4; ++r) pr += (double)(h[(size_t)r * 32] - h[(size_t)r * 32 + 31]); printf("  kernel entry -> first stamp of the streams (parameter staging in C++): %.0f cycles\n", pr / (nb * 4)); }
+        double tot = 0; printf("  s_memtime per wave (mean over %d waves, cycles of its clock):\n   ", nb * 4);
+        for (int k = 1; k < ns; ++k) { printf("  %s=%.0f", nm[k], ph[k] / (nb * 4)); tot += ph[k] / (nb * 4); }
+        printf("\n    total=%.0f  (first start -> last end %lld)\n", tot, t1 - t0);
+    }
+#endif
+    }
+    }
+    return 0;
+}
+#if 0
 #ifdef DEX_TIMING
     long long* dbg; const int nb = B * ((N + 63) / 64); hipMalloc(&dbg, (size_t)nb * 16 * 8); hipMemset(dbg, 0, (size_t)nb * 16 * 8);
     c.dbg = dbg; launch_dit_rowchain(c, 0); hipDeviceSynchronize(); c.dbg = nullptr;
@@ -98,3 +122,4 @@ int main(int argc, char** argv) {
     }
     return 0;
 }
+#endif
