@@ -38,7 +38,8 @@ import struct
 import sys
 
 OUT = os.environ.get("RCAGEN_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dex_tts_amd", "csrc", "dit_rowchain_a_core.inc")
-GELU_TERMS = int(os.environ.get("RCAGEN_GELU", "5"))       # 5: Abramowitz-Stegun 7.1.26 (|err| 1.5e-7, the C++ kernels' formula); 3: 7.1.25 (2.5e-5)
+GELU_TERMS = int(os.environ.get("RCAGEN_GELU", "3"))       # erf by Abramowitz-Stegun: 3 = 7.1.25 (|err| 2.5e-5: a twentieth of the fp16 rounding the value gets next,
+                                                            # 2 VALU instructions per value less), 5 = 7.1.26 (1.5e-7, the C++ kernels' formula; A/B builds)
 DROP = set(filter(None, os.environ.get("RCAGEN_DROP", "").split(",")))   # anatomy builds (results wrong): gelu, mfma, wload
 TIMING = os.environ.get("RCAGEN_TIMING", "0") == "1"        # s_memtime stamps after every pass / at every barrier -> %[dbg] (tools/rc64bench -DRCA_TIMING)
 
@@ -54,7 +55,9 @@ PRM_BYTES = P_BQ + 3072
 ST = PRM + PRM_BYTES
 LDS_BYTES = ST + 64 * 4 * 8
 
-NRING = 32                           # weight ring: a[0:127]
+NRING = 32                           # weight ring a[0:127].  The ring position of a fragment is (index in the tile's stream) % NRING and the stream wraps
+                                     # into the next tile, so NRING must divide every variant's fragment count (256 / 160 / 96): 40 was tried and read the
+                                     # previous tile's slots
 AG_O, AG_X = 128, 160                # the NEXT tile's O rows (8 quads) and residual rows (16 quads) wait in a[128:159], a[160:223]
 
 # ---- register map
@@ -109,8 +112,15 @@ class Prog:
 
     # ---- counted waits
     def vmem(self, text):
+        # vmcnt is a 6-bit counter: the wave must never have more than 63 requests in flight (ring 40 + the next tile's 24 rows once did:
+        # silently wrong data).  What the generator KNOWS to be complete is a lower bound, so this wait is conservative.
+        if self.vm_issued - self.vm_done >= 60:
+            self.e("s_waitcnt vmcnt(56)")
+            self.vm_done = self.vm_issued - 56
+            self.forced_vm_waits = getattr(self, "forced_vm_waits", 0) + 1
         self.e(text)
         self.vm_issued += 1
+        self.max_vm = max(getattr(self, "max_vm", 0), self.vm_issued - self.vm_done)
         return self.vm_issued
 
     def lds(self, text):
@@ -209,6 +219,7 @@ class Weights:
                     self.index[(pi, ks, jj)] = len(self.frags)
                     self.frags.append((pi, ks, jj))
         self.passes = passes
+        assert len(self.frags) % NRING == 0
         self.tag = {}
         self.next = 0
 
@@ -865,7 +876,7 @@ def main():
         p = core(variant)
         body = p.text().replace("\n", " \\\n")
         parts.append(f"#define {name} \\\n    {body}\n")
-        info.append(f"{variant}: {p.stats}")
+        info.append(f"{variant}: {p.stats} max VMEM in flight (upper bound) {getattr(p, 'max_vm', 0)}, forced waits {getattr(p, 'forced_vm_waits', 0)}")
         if TIMING:
             parts.append(f"#define {name}_STAMPS " + ", ".join(f'"{n}"' for n in p.names) + "\n")
     parts.append("#define RCA_CLOBBER \\\n    " + clobbers() + "\n")
