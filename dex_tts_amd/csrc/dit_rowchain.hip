@@ -16,7 +16,6 @@
 #include <hip/hip_runtime.h>
 #include "kernels.h"
 #include <cstdlib>
-#include <type_traits>
 #include "lp_util.h"
 #include "kernels_lp.h"
 
@@ -25,7 +24,6 @@ namespace DEX_LP_NS {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned short u16;
-typedef unsigned u32x2q __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -872,382 +870,6 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain64_kernel(const DitCha
 #endif
 }
 
-// ---- 64-row form, round 5: SOFTWARE-PIPELINED ("p" form, dit_rowchain64p_kernel).  The round-3 kernel above runs every stage as
-// "all MFMAs of a tile, then its whole epilogue": 3 058 VALU instructions per wave against 273 MFMAs, none of them under an MFMA
-// (profiles/round4_dex_b32_diag_counters.txt: matrix pipe 0.196 busy).  Here
-//   * every product is computed TRANSPOSED (weights as the A operand, activations as B): a lane owns ONE token and 16 features of a
-//     32-feature tile, four runs of four consecutive features - biases / gates / LayerNorm parameters are quads read by broadcast,
-//     the residual stream moves as float4, and a tile leaves for LDS as two ds_write_b128 (one v_permlane32_swap per dword pairs the
-//     two halves of a token into whole 8-feature chunks, as store_qkv_tile_d does for q / k) instead of 16 ds_write_b16 / b32;
-//   * the fp32 residual rows never touch LDS: a wave keeps the 32 features it produces (tile `wave` of proj and fc2) in 32
-//     registers; LayerNorm statistics are per-wave (mean, M2) partials over those 32 features, exchanged through a 4 KB LDS table
-//     and combined with Chan's formula (exact two-pass statistics per wave, no E[x^2] - mean^2 cancellation) - the X1 round trip
-//     and the row-wise ln_to_A pass with its 8 shuffles per row are gone, and with X1 out of LDS the whole 64 x 512 GELU tile fits,
-//     so the MLP runs as one fc1 phase and one fc2 phase (6 workgroup barriers per block instead of 10);
-//   * the instruction stream is written slot by slot: slot j = MFMA j of the current tile + the LDS read of an operand 8 slots ahead
-//     + the in-place refill of weight fragment j with the NEXT tile's (one 64-register weight tile instead of two) + a piece of the
-//     PREVIOUS tile's epilogue (GELU of a feature pair, a residual quad, half a q / k / v^T store), with a scheduling barrier between
-//     slots - the compiler allocates registers and inserts the waits, but cannot move an epilogue out from under its MFMAs.
-// Same operand layouts, same fragment-ordered weights and outputs as the kernels above; products and sums of a row are the same
-// numbers in a different order only in the LayerNorm statistics (Chan combine) - tests/test_gpu_parity.py holds both to the oracle.
-namespace {
-constexpr int HS_LD = RC_MLP + 8;                 // GELU(fc1) tile row stride (elements): 1040 B, b128 accesses of 8 rows hit 32 banks
-constexpr int P_SHM = 0, P_SCM = 1, P_SHN = 2, P_SCN = 3, P_GMSA = 4, P_BP = 5, P_GMLP = 6, P_B2 = 7;      // 256-float parameter rows in LDS
-constexpr int P_B1 = 8 * RC_H, P_BQ = P_B1 + RC_MLP, P_FLOATS = P_BQ + 3 * RC_H;
-constexpr size_t RC64P_LDS = (size_t)64 * (A_LD + HS_LD) * sizeof(u16) + (size_t)(P_FLOATS + 64 * 2 * RC_NW) * sizeof(float);
-typedef float f2v __attribute__((ext_vector_type(2)));
-
-// gelu_erf_rc on a pair (the compiler packs the fp32 multiply-adds: v_pk_fma_f32 / v_pk_mul_f32)
-__device__ __forceinline__ f2v gelu2_rc(f2v x) {
-    const f2v z = __builtin_elementwise_abs(x) * 0.70710678118654752440f;
-    f2v d = z * 0.3275911f + 1.0f;
-    f2v t; t.x = __builtin_amdgcn_rcpf(d.x); t.y = __builtin_amdgcn_rcpf(d.y);
-    f2v pl = t * 1.061405429f + -1.453152027f;
-    pl = pl * t + 1.421413741f; pl = pl * t + -0.284496736f; pl = pl * t + 0.254829592f;
-    const f2v a = z * z * -1.4426950408889634f;
-    f2v e; e.x = __builtin_amdgcn_exp2f(a.x); e.y = __builtin_amdgcn_exp2f(a.y);
-    const f2v er = 1.0f - pl * t * e;
-    f2v r;
-    r.x = 0.5f * x.x * (1.0f + copysignf(er.x, x.x));
-    r.y = 0.5f * x.y * (1.0f + copysignf(er.y, x.y));
-    return r;
-}
-__device__ __forceinline__ float xhalf_add(float v) {          // v + its value in the other 32-lane half
-    const u32x2q r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-struct ARing { u32x4 a[8]; };
-__device__ __forceinline__ u32x4 lds_frag(const u16* p) { return *reinterpret_cast<const u32x4*>(p); }
-// One tile = 16 slots.  TRANS: acc[r] = C[feature (r & 3) + 8 (r >> 2) + 4 hh][token lane & 31]; else the roles of the lane / register
-// index swap (v^T).  REFILL: fragment j is replaced by wnext[j * 64] right after its MFMA.  PRE: the ring already holds fragments
-// 0..7 of this tile; NEXT: slots 8..15 fetch fragments 0..7 of the tile at act_next.
-template <bool TRANS, bool REFILL, bool PRE, bool NEXT, class Fill>
-__device__ __forceinline__ void rc_tile(f32x16& acc, uint4 (&w)[16], const uint4* wnext, ARing& ar, const u16* act, const u16* act_next, Fill&& fill) {
-    if constexpr (!PRE) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ar.a[j] = lds_frag(act + j * 16);
-    }
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        if constexpr (TRANS) acc = DEX_MFMA_LP(__builtin_bit_cast(lp8, w[j]), __builtin_bit_cast(lp8, ar.a[j & 7]), acc, 0, 0, 0);
-        else acc = DEX_MFMA_LP(__builtin_bit_cast(lp8, ar.a[j & 7]), __builtin_bit_cast(lp8, w[j]), acc, 0, 0, 0);
-        if (j < 8) ar.a[j] = lds_frag(act + (j + 8) * 16);
-        else if constexpr (NEXT) ar.a[j - 8] = lds_frag(act_next + (j - 8) * 16);
-        if constexpr (REFILL) w[j] = wnext[j * 64];
-        fill(j);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-__device__ __forceinline__ const uint4* wtile(const void* W, int ksteps_total, int nt, int ks0, int lane) {
-    return reinterpret_cast<const uint4*>(W) + ((long)nt * ksteps_total + ks0) * 64 + lane;
-}
-// two packed quads of a token (features 8 (2 pr) + 4 hh .. and 8 (2 pr + 1) + 4 hh ..) -> the 8-feature chunk 2 pr + hh of the tile
-__device__ __forceinline__ uint4 pair_chunk(const unsigned (&d0)[2], const unsigned (&d1)[2]) {
-    const u32x2q s0 = __builtin_amdgcn_permlane32_swap(d0[0], d1[0], false, false);
-    const u32x2q s1 = __builtin_amdgcn_permlane32_swap(d0[1], d1[1], false, false);
-    return make_uint4(s0[0], s1[0], s0[1], s1[1]);
-}
-// residual + gated GEMM output of one feature quad: x += g * (acc + b)
-__device__ __forceinline__ void res_quad(float4& x, const f32x16& acc, int q, const float4& g, const float4& b) {
-    x.x = fmaf(g.x, acc[4 * q + 0] + b.x, x.x); x.y = fmaf(g.y, acc[4 * q + 1] + b.y, x.y);
-    x.z = fmaf(g.z, acc[4 * q + 2] + b.z, x.z); x.w = fmaf(g.w, acc[4 * q + 3] + b.w, x.w);
-}
-// (mean, M2) of this wave's 32 features of one token (both halves of the wave hold the result)
-__device__ __forceinline__ float2 wave_stats(const float4 (&x)[4]) {
-    float s = 0.f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) s += (x[q].x + x[q].y) + (x[q].z + x[q].w);
-    const float mean = xhalf_add(s) * (1.f / 32.f);
-    float m2 = 0.f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float a = x[q].x - mean, b = x[q].y - mean, c = x[q].z - mean, d = x[q].w - mean;
-        m2 = fmaf(a, a, m2); m2 = fmaf(b, b, m2); m2 = fmaf(c, c, m2); m2 = fmaf(d, d, m2);
-    }
-    return make_float2(mean, xhalf_add(m2));
-}
-// LayerNorm (eps 1e-6) + modulate of this wave's 32 features of token `tok` from the 8 per-wave partials -> two 8-feature chunks of As
-__device__ __forceinline__ void ln_write(const float4 (&x)[4], const float* ST, const float* PRM, int p_shift, int p_scale, u16* As, int tok, int wave, int hh) {
-    float4 st[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) st[k] = *reinterpret_cast<const float4*>(ST + tok * (2 * RC_NW) + 4 * k);     // (mean, M2) of waves 2k, 2k + 1
-    float mean = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) mean += st[k].x + st[k].z;
-    mean *= (1.f / RC_NW);
-    float m2 = 0.f, dv = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float d0 = st[k].x - mean, d1 = st[k].z - mean;
-        m2 += st[k].y + st[k].w; dv = fmaf(d0, d0, dv); dv = fmaf(d1, d1, dv);
-    }
-    const float rstd = rsqrtf(fmaf(32.f, dv, m2) * (1.f / RC_H) + 1e-6f);
-    unsigned D[4][2];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float4 sc = *reinterpret_cast<const float4*>(PRM + p_scale * RC_H + wave * 32 + 8 * q + 4 * hh);
-        const float4 sh = *reinterpret_cast<const float4*>(PRM + p_shift * RC_H + wave * 32 + 8 * q + 4 * hh);
-        D[q][0] = pack2_lp((x[q].x - mean) * rstd * (1.f + sc.x) + sh.x, (x[q].y - mean) * rstd * (1.f + sc.y) + sh.y);
-        D[q][1] = pack2_lp((x[q].z - mean) * rstd * (1.f + sc.z) + sh.z, (x[q].w - mean) * rstd * (1.f + sc.w) + sh.w);
-    }
-#pragma unroll
-    for (int pr = 0; pr < 2; ++pr)
-        *reinterpret_cast<uint4*>(As + tok * A_LD + wave * 32 + 16 * pr + 8 * hh) = pair_chunk(D[2 * pr], D[2 * pr + 1]);
-}
-// half of store_qkv_tile_d (pr = 0 / 1): the same values and addresses, cut in two so that each half fits an MFMA slot
-template <int KIND>
-__device__ __forceinline__ void qkv_half(const DitChainP& p, const f32x16& acc, const float* PRM, int nt, int b, int n0, int lane, int pr) {
-    const int i = lane & 31, hh = lane >> 5;
-    const int head = (nt >> 2) & 1, d0 = (nt & 3) * 32;
-    u16* base = (KIND == 0 ? reinterpret_cast<u16*>(p.Qh) : KIND == 1 ? reinterpret_cast<u16*>(p.Kh) : reinterpret_cast<u16*>(p.Vt))
-                + ((long)b * 2 + head) * p.Npad * 128 + (long)(n0 >> 5) * 4096;
-    if constexpr (KIND < 2) {
-        const float sc = KIND == 0 ? p.qscale : 1.f;
-        unsigned D[2][2];
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-            const int j = 2 * pr + jj;
-            const float4 bj = *reinterpret_cast<const float4*>(PRM + P_BQ + nt * 32 + 8 * j + 4 * hh);
-            D[jj][0] = pack2_lp((acc[4 * j + 0] + bj.x) * sc, (acc[4 * j + 1] + bj.y) * sc);
-            D[jj][1] = pack2_lp((acc[4 * j + 2] + bj.z) * sc, (acc[4 * j + 3] + bj.w) * sc);
-        }
-        const int ks = (d0 >> 4) + pr;
-        *reinterpret_cast<uint4*>(base + ((ks * 64 + lane) << 3)) = pair_chunk(D[0], D[1]);
-    } else {
-        const float bias = PRM[P_BQ + nt * 32 + i];
-        const int t = d0 >> 5, half = pr;
-        unsigned w[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) w[j] = pack2_lp(acc[8 * half + 2 * j] + bias, acc[8 * half + 2 * j + 1] + bias);
-        *reinterpret_cast<uint4*>(base + (((t * 2 + half) * 64 + lane) << 3)) = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-}
-}  // namespace
-
-__global__ __launch_bounds__(RC_NW * 64) void dit_rowchain64p_kernel(const DitChainP p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_rc[];
-    u16* As = reinterpret_cast<u16*>(smem_rc);                 // [64][A_LD]   16-bit operand rows: O, then the LayerNorm outputs
-    u16* Hs = As + 64 * A_LD;                                  // [64][HS_LD]  GELU(fc1), all 512 hidden columns
-    float* PRM = reinterpret_cast<float*>(Hs + 64 * HS_LD);    // parameter rows (P_*)
-    float* ST = PRM + P_FLOATS;                                // [64 tokens][8 waves] (mean, M2)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int i = lane & 31, hh = lane >> 5;
-    const int N = p.rows_per_batch, tpb = (N + 63) / 64;
-    const int b = blockIdx.x / tpb, n0 = (blockIdx.x - b * tpb) * 64;
-    const long mb = (long)b * N;
-    const int step = p.step;
-    const float* ada = p.ada + (long)step * 6 * RC_H;
-    const bool has_q = p.next_shift != nullptr;
-#ifdef DEX_TIMING
-    long long tst[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};
-    tst[0] = wall_clock64();
-#endif
-    {   // parameter rows -> LDS (float2 per thread and round)
-        for (int e = tid; e < P_FLOATS / 2; e += RC_NW * 64) {
-            const int f = 2 * e, row = f >> 8, c = f & 255;
-            // (uniform per row) the last block has no qkv stage (bq, next_* are null) and the first launch nothing but it (ada, bp, b1, b2 unused)
-            if (f >= P_BQ ? !has_q : p.qkv_only ? (f >= P_B1 || (row != P_SHN && row != P_SCN)) : false) continue;
-            const float* src = f >= P_BQ ? p.bq + (f - P_BQ) : f >= P_B1 ? p.b1 + (f - P_B1)
-                             : row == P_SHM ? ada + 3 * RC_H + c : row == P_SCM ? ada + 4 * RC_H + c
-                             : row == P_SHN ? (has_q ? p.next_shift + (long)step * p.next_step_stride + c : ada + c)
-                             : row == P_SCN ? (has_q ? p.next_scale + (long)step * p.next_step_stride + c : ada + c)
-                             : row == P_GMSA ? ada + 2 * RC_H + c : row == P_BP ? p.bp + c : row == P_GMLP ? ada + 5 * RC_H + c : p.b2 + c;
-            *reinterpret_cast<float2*>(PRM + f) = *reinterpret_cast<const float2*>(src);
-        }
-    }
-    uint4 w[16];
-    ARing ar;
-    f32x16 acc, accp;
-    float4 x[2][4];                                            // residual stream: features 32 wave + 8 q + 4 hh .. + 3 of token 32 mt + i
-    const u16* a_lane = As + i * A_LD + hh * 8;
-    const u16* h_lane = Hs + i * HS_LD + hh * 8;
-    auto nofill = [](int) __attribute__((always_inline)) {};
-    auto load_w = [&](const uint4* src) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) w[j] = src[j * 64];
-    };
-    const uint4* wq0 = wtile(p.Wq, 16, wave, 0, lane);
-    // the incoming residual rows of this wave's features
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const float* xr = p.X + (mb + min(n0 + 32 * mt + i, N - 1)) * RC_H + wave * 32 + 4 * hh;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) x[mt][q] = *reinterpret_cast<const float4*>(xr + 8 * q);
-    }
-    if (p.qkv_only) {
-        load_w(wq0);
-    } else {
-        load_w(wtile(p.Wp, 16, wave, 0, lane));
-        __builtin_amdgcn_sched_barrier(0);
-        // the attention output rows (merged from the key-split partials when there are several) -> 16-bit operand tile
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-            const int row = (tid >> 4) + 32 * m, seg = tid & 15;
-            const int n = min(n0 + row, N - 1);
-            const float* src = p.O + (mb + n) * RC_H + seg * 4;
-            float4 v[4];
-            const bool tail = p.tail_ks > 1 && n0 >= p.tail_row0;        // (uniform) rows of the attention's tail-split query groups
-            if (p.o_lp && !tail) {     // (uniform) already in the operand type: straight into the tile
-                const u16* sh_ = reinterpret_cast<const u16*>(p.O) + (mb + n) * RC_H + seg * 4;
-                uint2 o4[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) o4[q] = *reinterpret_cast<const uint2*>(sh_ + q * 64);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(As + row * A_LD + q * 64 + seg * 4) = o4[q];
-                continue;
-            }
-            if (tail) {
-                rc_merge_splits(p, src + p.o_sstride, b, n, v, p.tail_ks);
-            } else if (p.ksplit <= 1) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const float4*>(src + q * 64);
-            } else {
-                rc_merge_splits(p, src, b, n, v, p.ksplit);
-            }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                uint2 o;
-                o.x = pack2_lp(v[q].x, v[q].y); o.y = pack2_lp(v[q].z, v[q].w);
-                *reinterpret_cast<uint2*>(As + row * A_LD + q * 64 + seg * 4) = o;
-            }
-        }
-        lds_barrier();
-#ifdef DEX_TIMING
-        tst[1] = wall_clock64();
-#endif
-        // ---- x1 = x + gate_msa * (O Wproj + b): tile `wave`, token halves m0 / m1; m0's epilogue runs under m1's MFMAs
-        float4 g4[2], b4[2];
-        auto res_fill = [&](const f32x16& a_, float4 (&xx)[4], int pg, int pb, bool store, int mt) __attribute__((always_inline)) {
-            return [&, pg, pb, store, mt](int j) __attribute__((always_inline)) {
-                const int q = j >> 2;
-                if ((j & 3) == 0) {
-                    g4[q & 1] = *reinterpret_cast<const float4*>(PRM + pg * RC_H + wave * 32 + 8 * q + 4 * hh);
-                    b4[q & 1] = *reinterpret_cast<const float4*>(PRM + pb * RC_H + wave * 32 + 8 * q + 4 * hh);
-                }
-                if ((j & 3) == 2) {
-                    res_quad(xx[q], a_, q, g4[q & 1], b4[q & 1]);
-                    if (store && n0 + 32 * mt + i < N) *reinterpret_cast<float4*>(p.X + (mb + n0 + 32 * mt + i) * RC_H + wave * 32 + 8 * q + 4 * hh) = xx[q];
-                }
-            };
-        };
-        auto res_all = [&](const f32x16& a_, float4 (&xx)[4], int pg, int pb, bool store, int mt) __attribute__((always_inline)) {
-            auto f = res_fill(a_, xx, pg, pb, store, mt);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) f(j);
-        };
-        acc = zero16();
-        rc_tile<true, false, false, true>(acc, w, nullptr, ar, a_lane, a_lane + 32 * A_LD, nofill);
-        accp = acc; acc = zero16();
-        rc_tile<true, true, true, false>(acc, w, wtile(p.W1, 16, wave, 0, lane), ar, a_lane + 32 * A_LD, nullptr, res_fill(accp, x[0], P_GMSA, P_BP, false, 0));
-        res_all(acc, x[1], P_GMSA, P_BP, false, 1);
-        // LayerNorm statistics of x1: per-wave partials -> ST, then every wave normalises its own 32 features of every token
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const float2 s_ = wave_stats(x[mt]);
-            if (hh == 0) *reinterpret_cast<float2*>(ST + (32 * mt + i) * (2 * RC_NW) + 2 * wave) = s_;
-        }
-        lds_barrier();
-#ifdef DEX_TIMING
-        tst[2] = wall_clock64();
-#endif
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) ln_write(x[mt], ST, PRM, P_SHM, P_SCM, As, 32 * mt + i, wave, hh);
-        lds_barrier();
-#ifdef DEX_TIMING
-        tst[3] = wall_clock64();
-#endif
-        // ---- h = GELU(A W1 + b1): tiles (m0, wave), (m1, wave), (m0, wave + 8), (m1, wave + 8); the GELU of a tile runs under the next one
-        unsigned D[4][2];
-        float4 bb;
-        auto gelu_fill = [&](const f32x16& a_, int nt, int mt) __attribute__((always_inline)) {
-            return [&, nt, mt](int j) __attribute__((always_inline)) {
-                const int q = j >> 2, e = j & 3;
-                if (e == 0) bb = *reinterpret_cast<const float4*>(PRM + P_B1 + nt * 32 + 8 * q + 4 * hh);
-                if (e == 1) { const f2v h = gelu2_rc(f2v{a_[4 * q + 0] + bb.x, a_[4 * q + 1] + bb.y}); D[q][0] = pack2_lp(h.x, h.y); }
-                if (e == 2) { const f2v h = gelu2_rc(f2v{a_[4 * q + 2] + bb.z, a_[4 * q + 3] + bb.w}); D[q][1] = pack2_lp(h.x, h.y); }
-                if (e == 3 && (q & 1))
-                    *reinterpret_cast<uint4*>(Hs + (32 * mt + i) * HS_LD + nt * 32 + 16 * (q >> 1) + 8 * hh) = pair_chunk(D[q - 1], D[q]);
-            };
-        };
-        acc = zero16();
-        rc_tile<true, false, false, true>(acc, w, nullptr, ar, a_lane, a_lane + 32 * A_LD, nofill);
-        accp = acc; acc = zero16();
-        rc_tile<true, true, true, true>(acc, w, wtile(p.W1, 16, wave + 8, 0, lane), ar, a_lane + 32 * A_LD, a_lane, gelu_fill(accp, wave, 0));
-        accp = acc; acc = zero16();
-        rc_tile<true, false, true, true>(acc, w, nullptr, ar, a_lane, a_lane + 32 * A_LD, gelu_fill(accp, wave, 1));
-        accp = acc; acc = zero16();
-        rc_tile<true, true, true, false>(acc, w, wtile(p.W2, 32, wave, 0, lane), ar, a_lane + 32 * A_LD, nullptr, gelu_fill(accp, wave + 8, 0));
-        {
-            auto f = gelu_fill(acc, wave + 8, 1);
-#pragma unroll
-            for (int j = 0; j < 16; ++j) f(j);
-        }
-        lds_barrier();
-#ifdef DEX_TIMING
-        tst[4] = wall_clock64();
-#endif
-        // ---- x2 = x1 + gate_mlp * (h W2 + b2): K halves a / b, token halves m0 / m1
-        f32x16 acc2[2];
-        acc2[0] = zero16(); acc2[1] = zero16();
-        rc_tile<true, false, false, true>(acc2[0], w, nullptr, ar, h_lane, h_lane + 32 * HS_LD, nofill);
-        rc_tile<true, true, true, true>(acc2[1], w, wtile(p.W2, 32, wave, 16, lane), ar, h_lane + 32 * HS_LD, h_lane + 256, nofill);
-        rc_tile<true, false, true, true>(acc2[0], w, nullptr, ar, h_lane + 256, h_lane + 32 * HS_LD + 256, nofill);
-        if (has_q) rc_tile<true, true, true, false>(acc2[1], w, wq0, ar, h_lane + 32 * HS_LD + 256, nullptr, res_fill(acc2[0], x[0], P_GMLP, P_B2, true, 0));
-        else rc_tile<true, false, true, false>(acc2[1], w, nullptr, ar, h_lane + 32 * HS_LD + 256, nullptr, res_fill(acc2[0], x[0], P_GMLP, P_B2, true, 0));
-        res_all(acc2[1], x[1], P_GMLP, P_B2, true, 1);
-        if (!has_q) return;
-#ifdef DEX_TIMING
-        tst[5] = wall_clock64();
-#endif
-    }
-    // ---- LayerNorm + modulate with the next block's parameters
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const float2 s_ = wave_stats(x[mt]);
-        if (hh == 0) *reinterpret_cast<float2*>(ST + (32 * mt + i) * (2 * RC_NW) + 2 * wave) = s_;
-    }
-    lds_barrier();           // (qkv_only: also publishes the parameter rows)
-#ifdef DEX_TIMING
-    tst[6] = wall_clock64();
-#endif
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) ln_write(x[mt], ST, PRM, P_SHN, P_SCN, As, 32 * mt + i, wave, hh);
-    lds_barrier();
-#ifdef DEX_TIMING
-    tst[7] = wall_clock64();
-#endif
-    // ---- qkv of the next block: q (tile wave) and k (wave + 8) transposed, v^T (wave + 16) plain; the stores of a tile run under the next
-    auto qkv_fill = [&](auto kind, const f32x16& a_, int nt, int mt) __attribute__((always_inline)) {
-        return [&, nt, mt](int j) __attribute__((always_inline)) {
-            constexpr int KIND = decltype(kind)::value;
-            if (n0 + 32 * mt >= p.Npad) return;          // (uniform) the operand buffers hold ceil(N / 32) row tiles per (utterance, head)
-            if (j == 3) qkv_half<KIND>(p, a_, PRM, nt, b, n0 + 32 * mt, lane, 0);
-            if (j == 10) qkv_half<KIND>(p, a_, PRM, nt, b, n0 + 32 * mt, lane, 1);
-        };
-    };
-    using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>; using K2 = std::integral_constant<int, 2>;
-    acc = zero16();
-    rc_tile<true, false, false, true>(acc, w, nullptr, ar, a_lane, a_lane + 32 * A_LD, nofill);
-    accp = acc; acc = zero16();
-    rc_tile<true, true, true, true>(acc, w, wtile(p.Wq, 16, wave + 8, 0, lane), ar, a_lane + 32 * A_LD, a_lane, qkv_fill(K0{}, accp, wave, 0));
-    accp = acc; acc = zero16();
-    rc_tile<true, false, true, true>(acc, w, nullptr, ar, a_lane, a_lane + 32 * A_LD, qkv_fill(K0{}, accp, wave, 1));
-    accp = acc; acc = zero16();
-    rc_tile<true, true, true, true>(acc, w, wtile(p.Wq, 16, wave + 16, 0, lane), ar, a_lane + 32 * A_LD, a_lane, qkv_fill(K1{}, accp, wave + 8, 0));
-    accp = acc; acc = zero16();
-    rc_tile<false, false, true, true>(acc, w, nullptr, ar, a_lane, a_lane + 32 * A_LD, qkv_fill(K1{}, accp, wave + 8, 1));
-    accp = acc; acc = zero16();
-    rc_tile<false, false, true, false>(acc, w, nullptr, ar, a_lane + 32 * A_LD, nullptr, qkv_fill(K2{}, accp, wave + 16, 0));
-    if (n0 + 32 < p.Npad) {
-        qkv_half<2>(p, acc, PRM, wave + 16, b, n0 + 32, lane, 0);
-        qkv_half<2>(p, acc, PRM, wave + 16, b, n0 + 32, lane, 1);
-    }
-#ifdef DEX_TIMING
-    if (p.dbg && tid == 0) { tst[8] = wall_clock64(); tst[9] = tst[8]; for (int q_ = 0; q_ < 10; ++q_) p.dbg[(long)blockIdx.x * 16 + q_] = tst[q_]; }
-#endif
-}
-
 // ---- 64-row form, round 5: GENERATED INSTRUCTION STREAMS ("a" form, dit_rowchain64a_kernel; tools/gen_rowchain_a.py ->
 // dit_rowchain_a_core.inc).  Four waves, one per SIMD, each owning 64 features x 64 tokens of every stage; the weights stream through a
 // 56-fragment ring in the accumulation file, the residual rows stay in registers, every epilogue sits in the MFMA gaps of the next
@@ -1999,16 +1621,6 @@ void launch_dit_rowchain(const DitChainP& p, hipStream_t st) {
                 if (!ncu) { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); if (ncu <= 0) ncu = 256; }
                 const int ntiles = p.B * ((p.rows_per_batch + 63) / 64);
                 hipLaunchKernelGGL(dit_rowchain64a_kernel, dim3(ntiles < ncu ? ntiles : ncu), dim3(256), RCA_LDS_BYTES, st, p);      // persistent: one workgroup per CU walks its tiles
-                return;
-            }
-            if (knob_or("DEX_ROWCHAIN64P", 0)) {          // 1: the software-pipelined C++ form (measured slower than the round-3 kernel: 108 vs 106 us in tools/rc64bench; opt-in)
-                static bool attr64p = false;
-                if (!attr64p) {
-                    hipFuncSetAttribute(reinterpret_cast<const void*>(&dit_rowchain64p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC64P_LDS);
-                    attr64p = true;
-                }
-                g_last_symbol = "dit_rowchain64p_kernel";
-                hipLaunchKernelGGL(dit_rowchain64p_kernel, dim3(p.B * ((p.rows_per_batch + 63) / 64)), dim3(RC_NW * 64), RC64P_LDS, st, p);
                 return;
             }
 #endif

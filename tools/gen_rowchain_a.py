@@ -40,7 +40,8 @@ import sys
 OUT = os.environ.get("RCAGEN_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "dex_tts_amd", "csrc", "dit_rowchain_a_core.inc")
 GELU_TERMS = int(os.environ.get("RCAGEN_GELU", "3"))       # erf by Abramowitz-Stegun: 3 = 7.1.25 (|err| 2.5e-5: a twentieth of the fp16 rounding the value gets next,
                                                             # 2 VALU instructions per value less), 5 = 7.1.26 (1.5e-7, the C++ kernels' formula; A/B builds)
-DROP = set(filter(None, os.environ.get("RCAGEN_DROP", "").split(",")))   # anatomy builds (results wrong): gelu, mfma, wload
+DROP = set(filter(None, os.environ.get("RCAGEN_DROP", "").split(",")))   # anatomy builds (results wrong): gelu, mfma, wload, xstore, qkvstore
+STORE_MOD = os.environ.get("RCAGEN_STORE", "")              # cache-policy bits on the output stores (A/B: nt, sc1, "sc0 sc1")
 TIMING = os.environ.get("RCAGEN_TIMING", "0") == "1"        # s_memtime stamps after every pass / at every barrier -> %[dbg] (tools/rc64bench -DRCA_TIMING)
 
 # ---- LDS map (bytes) - mirrored by dit_rowchain.hip (RCA_*)
@@ -350,7 +351,8 @@ def qk_atoms(ps_prev, rsrc, scale):
                 if scale:
                     ops += [f"v_mul_f32 {vr(base + 8 * pr + k)}, %[qscale], {vr(base + 8 * pr + k)}" for k in range(8)]
                 ops += chunk_ops(base, pr)
-                ops.append(f"buffer_store_dwordx4 {vr(base + 8 * pr, 4)}, {vr(V_QK1 if Tt else V_QK0)}, %[{rsrc}], 0 offen offset:{2048 * jj + 1024 * pr}")
+                if "qkvstore" not in DROP:
+                    ops.append(f"buffer_store_dwordx4 {vr(base + 8 * pr, 4)}, {vr(V_QK1 if Tt else V_QK0)}, %[{rsrc}], 0 offen offset:{2048 * jj + 1024 * pr} {STORE_MOD}".rstrip())
                 atoms.append(emit_strs(ops))
     return atoms
 
@@ -374,14 +376,7 @@ def run_pass(p, W, pi, ps, atoms, first_act_tags, acc_tag, next_ps=None):
                     p.wait_lg(acc_tag)
                 base = ps.accs[(jj, Tt)]
                 slot = RING((2 * ks + Tt) % 8)
-                wreg = ar(4 * (g % NRING), 4)
-                if "mfma" in DROP:
-                    pass
-                elif ps.trans:
-                    p.e(f"MFMA {vr(base, 16)}, {wreg}, {vr(slot, 4)}, {vr(base, 16)}")
-                else:
-                    p.e(f"MFMA {vr(base, 16)}, {vr(slot, 4)}, {wreg}, {vr(base, 16)}")
-                p.mfma_at[base] = p.n
+                mfma(p, ps, base, g, slot)
                 if Tt == 1 and "wload" not in DROP:
                     W.issue(min(g + NRING + 1, W.next + 2))  # fragment g is dead: its slot may take fragment g + NRING (at most two requests per
                                                              # death: the ring fills up over the first passes instead of in one burst at the start)
@@ -401,6 +396,17 @@ def run_pass(p, W, pi, ps, atoms, first_act_tags, acc_tag, next_ps=None):
         atoms.pop(0)(p)
     p.stamp(ps.name)
     return next_tags
+
+
+def mfma(p, ps, base, g, slot):
+    wreg = ar(4 * (g % NRING), 4)
+    if "mfma" in DROP:
+        pass
+    elif ps.trans:
+        p.e(f"MFMA {vr(base, 16)}, {wreg}, {vr(slot, 4)}, {vr(base, 16)}")
+    else:
+        p.e(f"MFMA {vr(base, 16)}, {vr(slot, 4)}, {wreg}, {vr(base, 16)}")
+    p.mfma_at[base] = p.n
 
 
 def first_act_reads(p, ps):
@@ -459,13 +465,16 @@ def x_stage_writes(p):
         p.lds(f"ds_write_b128 {vr(T(13))}, {ar(AG_X + 4 * k, 4)} offset:{k * X_ROW}")
 
 
+def x_store_write_atoms(addr):
+    """X registers -> XS in the accumulator layout (the caller has made sure every wave is done with the bytes); `addr` = x_lds_addr"""
+    return [emit_strs([f"ds_write_b128 {vr(addr)}, {vr(X(j, Tt) + 4 * q, 4)} offset:{Tt * 32 * X_ROW + j * 128 + q * 32}" for Tt in range(2)])
+            for j in range(2) for q in range(4)]
+
+
 def x_store_write(p):
-    """X registers -> XS in the accumulator layout (the caller has made sure every wave is done with the bytes)"""
     x_lds_addr(p, T(15))
-    for j in range(2):
-        for Tt in range(2):
-            for q in range(4):
-                p.lds(f"ds_write_b128 {vr(T(15))}, {vr(X(j, Tt) + 4 * q, 4)} offset:{Tt * 32 * X_ROW + j * 128 + q * 32}")
+    for a in x_store_write_atoms(T(15)):
+        a(p)
 
 
 def x_store_atoms():
@@ -487,13 +496,14 @@ def x_store_atoms():
                 p.e(f"s_add_u32 {sr(S_TMP2)}, {sr(S_N0W)}, {r}")
                 p.e(f"s_lshl_b32 {sr(S_TMP2)}, {sr(S_TMP2)}, 10")
                 p.wait_lg(tg[r])
-                p.vmem(f"buffer_store_dwordx4 {vr(T(4 * (r % 2)), 4)}, {vr(T(12))}, %[rx], {sr(S_TMP2)} offen")
+                if "xstore" not in DROP:
+                    p.vmem(f"buffer_store_dwordx4 {vr(T(4 * (r % 2)), 4)}, {vr(T(12))}, %[rx], {sr(S_TMP2)} offen {STORE_MOD}".rstrip())
         atoms.append(one)
     return atoms
 
 
-def residual(p, acc_base, gate_row):
-    """X += gate * acc (the bias is already in acc)"""
+def residual(p, acc_base, gate_row, tiles=(0, 1)):
+    """X += gate * acc (the bias is already in acc) for the token tiles `tiles`"""
     G = [T(0), T(4)]                     # two gate quads alternate
     gt = {}
     seq = [(j, q) for j in range(2) for q in range(4)]
@@ -501,7 +511,7 @@ def residual(p, acc_base, gate_row):
         gt[(j, q)] = p.lds(f"ds_read_b128 {vr(G[n & 1], 4)}, {vr(V_PRM)} offset:{gate_row * 1024 + j * 128 + q * 32}")
     for n, (j, q) in enumerate(seq):
         p.wait_lg(gt[(j, q)])
-        for Tt in range(2):
+        for Tt in tiles:
             a = acc_base + 32 * j + 16 * Tt
             p.acc_read(a)
             for e in range(4):
@@ -512,33 +522,39 @@ def residual(p, acc_base, gate_row):
             gt[(j2, q2)] = p.lds(f"ds_read_b128 {vr(G[n & 1], 4)}, {vr(V_PRM)} offset:{gate_row * 1024 + j2 * 128 + q2 * 32}")
 
 
-def layernorm(p, SCR, ln_shift_row, ln_scale_row, between=None):
-    """LayerNorm statistics of the wave's 64 features -> ST; barrier; combine the 4 waves (Chan); [between(p)]; LayerNorm + modulate ->
-    As (16-bit chunks); barrier.  SCR: 64 scratch registers (a consumed accumulator set)."""
+def wave_stats(p, Tt):
+    """per-wave LayerNorm statistics of token tile Tt: mean over the wave's 64 features, M2 = sum of squared deviations from it -> ST"""
     p.e(f"v_add_u32 {vr(T(15))}, {sr(S_W8)}, {vr(V_ST)}")
-    for Tt in range(2):
-        s0, s1, tmp = T(0), T(1), T(2)
-        regs = [X(j, Tt) + r for j in range(2) for r in range(16)]
-        p.e(f"v_add_f32 {vr(s0)}, {vr(regs[0])}, {vr(regs[1])}")
-        p.e(f"v_add_f32 {vr(s1)}, {vr(regs[2])}, {vr(regs[3])}")
-        for k in range(4, 32, 2):
-            p.e(f"v_add_f32 {vr(s0)}, {vr(s0)}, {vr(regs[k])}")
-            p.e(f"v_add_f32 {vr(s1)}, {vr(s1)}, {vr(regs[k + 1])}")
-        p.e(f"v_add_f32 {vr(s0)}, {vr(s0)}, {vr(s1)}")
-        xhalf_sum(p, s0, tmp)
-        mean, m2a, m2b, d0, d1 = T(4), T(5), T(3), T(6), T(7)      # (mean, M2) = T(4), T(5): consecutive for the ds_write_b64
-        p.e(f"v_mul_f32 {vr(mean)}, {f32(1.0 / 64)}, {vr(s0)}")
-        p.e(f"v_mov_b32 {vr(m2a)}, 0")
-        p.e(f"v_mov_b32 {vr(m2b)}, 0")
-        for k in range(0, 32, 2):
-            p.e(f"v_sub_f32 {vr(d0)}, {vr(regs[k])}, {vr(mean)}")
-            p.e(f"v_sub_f32 {vr(d1)}, {vr(regs[k + 1])}, {vr(mean)}")
-            p.e(f"v_fmac_f32 {vr(m2a)}, {vr(d0)}, {vr(d0)}")
-            p.e(f"v_fmac_f32 {vr(m2b)}, {vr(d1)}, {vr(d1)}")
-        p.e(f"v_add_f32 {vr(m2a)}, {vr(m2a)}, {vr(m2b)}")
-        xhalf_sum(p, m2a, tmp)
-        p.lds(f"ds_write_b64 {vr(T(15))}, {vr(mean, 2)} offset:{Tt * 1024}")
-        p.e("s_nop 1")
+    s0, s1, tmp = T(0), T(1), T(2)
+    regs = [X(j, Tt) + r for j in range(2) for r in range(16)]
+    p.e(f"v_add_f32 {vr(s0)}, {vr(regs[0])}, {vr(regs[1])}")
+    p.e(f"v_add_f32 {vr(s1)}, {vr(regs[2])}, {vr(regs[3])}")
+    for k in range(4, 32, 2):
+        p.e(f"v_add_f32 {vr(s0)}, {vr(s0)}, {vr(regs[k])}")
+        p.e(f"v_add_f32 {vr(s1)}, {vr(s1)}, {vr(regs[k + 1])}")
+    p.e(f"v_add_f32 {vr(s0)}, {vr(s0)}, {vr(s1)}")
+    xhalf_sum(p, s0, tmp)
+    mean, m2a, m2b, d0, d1 = T(4), T(5), T(3), T(6), T(7)      # (mean, M2) = T(4), T(5): consecutive for the ds_write_b64
+    p.e(f"v_mul_f32 {vr(mean)}, {f32(1.0 / 64)}, {vr(s0)}")
+    p.e(f"v_mov_b32 {vr(m2a)}, 0")
+    p.e(f"v_mov_b32 {vr(m2b)}, 0")
+    for k in range(0, 32, 2):
+        p.e(f"v_sub_f32 {vr(d0)}, {vr(regs[k])}, {vr(mean)}")
+        p.e(f"v_sub_f32 {vr(d1)}, {vr(regs[k + 1])}, {vr(mean)}")
+        p.e(f"v_fmac_f32 {vr(m2a)}, {vr(d0)}, {vr(d0)}")
+        p.e(f"v_fmac_f32 {vr(m2b)}, {vr(d1)}, {vr(d1)}")
+    p.e(f"v_add_f32 {vr(m2a)}, {vr(m2a)}, {vr(m2b)}")
+    xhalf_sum(p, m2a, tmp)
+    p.lds(f"ds_write_b64 {vr(T(15))}, {vr(mean, 2)} offset:{Tt * 1024}")
+    p.e("s_nop 1")
+
+
+def layernorm(p, SCR, ln_shift_row, ln_scale_row, between=None, stats_tiles=(0, 1)):
+    """LayerNorm statistics of the wave's 64 features -> ST (token tiles `stats_tiles`: the others' are there already); barrier; combine
+    the 4 waves (Chan); LayerNorm + modulate -> As (16-bit chunks) [the finished residual rows go to XS between its steps]; barrier.
+    SCR: 64 scratch registers (a consumed accumulator set)."""
+    for Tt in stats_tiles:
+        wave_stats(p, Tt)
     p.barrier("stats")
     # ---- all four waves' partials of the lane's token -> mean, rstd (Chan's combination, equal counts)
     RS, CC = [T(8), T(10)], [T(9), T(11)]
@@ -567,8 +583,10 @@ def layernorm(p, SCR, ln_shift_row, ln_scale_row, between=None):
         p.e(f"v_rsq_f32 {vr(RS[Tt])}, {vr(dv)}")
         p.e("s_nop 0")
         p.e(f"v_mul_f32_e64 {vr(CC[Tt])}, -{vr(mean)}, {vr(RS[Tt])}")
+    extra = []
     if between:
-        between(p)
+        x_lds_addr(p, T(14))
+        extra = x_store_write_atoms(T(14))       # one per step of the loop below: the writes' LDS time hides under the arithmetic
     # ---- y = ((x - mean) rstd) (1 + scale) + shift -> 16-bit, chunks of 8 features -> As
     p.e(f"v_add_u32 {vr(T(15))}, {sr(S_W128)}, {vr(V_AS)}")
     PQ = [SCR + 16, SCR + 24]               # (1 + scale | shift) quads of a feature quad, two sets alternate
@@ -592,6 +610,8 @@ def layernorm(p, SCR, ln_shift_row, ln_scale_row, between=None):
                 p.e(f"v_fma_f32 {vr(y)}, {vr(y)}, {vr(PQ[n & 1] + e)}, {vr(PQ[n & 1] + 4 + e)}")
         if n + 2 < len(seq):
             prm_reads(n + 2)
+        if extra:
+            extra.pop(0)(p)
         if q & 1:
             pr = q >> 1
             for Tt in range(2):
@@ -751,16 +771,16 @@ def core(variant):
         p.e(f"v_lshl_add_u32 {vr(ow)}, {vr(och)}, 4, {vr(ow)}")
         for m in range(8):
             p.lds(f"ds_write_b128 {vr(ow)}, {ar(AG_O + 4 * m, 4)} offset:{m * 8 * A_ROW}")
+        x_stage_writes(p)                    # the residual rows (a[160:223], requested by the first statement / the previous tile) -> XS
         acc1 = acc_init_reads(p, passes[0])
         p.barrier("stage O")
-        # ---- proj (set 0); its first slots push the residual rows on into XS, a barrier half way, then they come back in the accumulator layout
+        # ---- proj (set 0); the residual rows come back from XS in the accumulator layout meanwhile
         tags = first_act_reads(p, passes[0])
-        def x_ready(p):
-            p.barrier("x staged")
-            x_lds_addr(p, T(13))
-        atoms = [x_stage_writes] + [lambda p: None] * 5 + [x_ready] + x_read_atoms(T(13)) + [lambda p: None] * 3
+        atoms = [lambda p: x_lds_addr(p, T(13))] + x_read_atoms(T(13)) + [lambda p: None] * 3
         run_pass(p, W, 0, passes[0], atoms, tags, acc1)
         p.wait_lg(p.lg_issued)
+        # (token-tile-major order - all of T0's MFMAs, then T1's with T0's residual + statistics in their gaps - was built and measured for
+        # this pass and for fc2.3: the epilogues shrank by 0.6k / 0.8k cycles, the passes grew by 1.5k / 0.8k; dropped)
         residual(p, A0, P_GMSA)
         layernorm(p, A0, P_SHM, P_SC1M)
         # ---- fc1 quarters 0..3 (set 0 halves), GELU of quarter q - 1 under quarter q; fc2's accumulators (set 1) take b2 meanwhile
@@ -789,17 +809,17 @@ def core(variant):
         third = (len(g3) + 2) // 3
         for c in range(4):
             pi = idx[f"fc2.{c}"]
-            tags = first_act_reads(p, passes[pi])
             atoms = g3[c * third:(c + 1) * third] if c < 3 else []
             if c == 3 and variant == "FULL":
                 atoms = [lambda p: init.__setitem__("q", acc_init_reads(p, passes[idx["q"]]))]
+            tags = first_act_reads(p, passes[pi])
             run_pass(p, W, pi, passes[pi], atoms, tags, init["fc2"] if c == 0 else None)
             if c == 2:
                 p.barrier("B4")              # Hs[:, 384:512] complete
         p.wait_lg(p.lg_issued)
         residual(p, A1, P_GMLP)
         if variant == "FULL":
-            layernorm(p, A1, P_SHN, P_SC1N, between=x_store_write)
+            layernorm(p, A1, P_SHN, P_SC1N, between=True)
         else:
             p.barrier("all done with Hs")
             x_store_write(p)
@@ -843,7 +863,7 @@ def core(variant):
                 for half in range(2):
                     for k in range(4):
                         p.e(f"PK {vr(base + 8 * half + k)}, {vr(base + 8 * half + 2 * k)}, {vr(base + 8 * half + 2 * k + 1)}")
-                    p.vmem(f"buffer_store_dwordx4 {vr(base + 8 * half, 4)}, {vr(V_QK1 if Tt else V_QK0)}, %[rv], 0 offen offset:{2048 * j + 1024 * half}")
+                    p.vmem(f"buffer_store_dwordx4 {vr(base + 8 * half, 4)}, {vr(V_QK1 if Tt else V_QK0)}, %[rv], 0 offen offset:{2048 * j + 1024 * half} {STORE_MOD}".rstrip())
     assert W.next == len(W.frags) + NRING, (W.next, len(W.frags))      # the next tile finds its first NRING fragments requested
     p.e("s_nop 1")
     p.stamp("end")
