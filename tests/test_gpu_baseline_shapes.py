@@ -317,6 +317,36 @@ def test_xcd_aware_block_order_is_bit_identical(name, kw):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("name,kw", [
+    ("dex_vctk", dict(B=32, T=256, lengths=[256 - 3 * i for i in range(32)], Tr=60, Ts=60)),      # N = 1300: 20 full tiles + 20 rows per utterance
+    ("dex_vctk", dict(B=10, T=512, lengths=[512 - 33 * i for i in range(10)], Tr=60, Ts=60)),     # 410 tiles on 256 workgroups: one or two tiles each
+])
+def test_generated_row_chain_streams_vs_round3_kernel(name, kw, prec):
+    """dit_rowchain64a_kernel (tools/gen_rowchain_a.py: generated instruction streams, persistent workgroups) against the compiler-
+    scheduled round-3 kernel it replaces (DEX_ROWCHAIN64A=0) on one EDMPrecond call: the same products in the same K order, sums that
+    differ only in the LayerNorm statistics' order, the place of the bias in the sum and the GELU's erf polynomial - the two results
+    differ by about half of either's distance from the oracle (independent roundings of the same size), and both are held to the oracle elsewhere (test_cfg2_*, test_gpu_full_jobs)."""
+    cfg, eng, w = U.engine_for(name)
+    case = U.make_case(cfg, **kw)
+    mu, mask, eps = (torch.from_numpy(case[k]) for k in ("mu", "mask", "eps"))
+    x = mu + 80.0 * eps
+    set_prec(eng, prec)
+    try:
+        ys = []
+        for flag in ("0", "1"):
+            os.environ["DEX_ROWCHAIN64A"] = flag
+            ys.append(eng.denoise_once(x, 80.0, mask, mu, **U.engine_kwargs(case)).cpu().numpy())
+    finally:
+        os.environ.pop("DEX_ROWCHAIN64A", None)
+        eng.set_precision("fp32")
+    d = np.abs(ys[0] - ys[1])
+    U.record(f"rowchain64a_vs_round3_{name}_B{kw['B']}:{prec}:call", max=d.max(), mean=d.mean(), ref_absmax=np.abs(ys[0]).max())
+    mx, mn = LOWP[prec]["call"]
+    assert np.isfinite(ys[1]).all() and d.max() > 0.0            # (two different kernels ran)
+    assert d.max() <= 0.5 * mx and d.mean() <= 0.5 * mn, (float(d.max()), float(d.mean()))      # measured: 0.27 / 0.25 of the bounds (fp16), 0.3 / 0.25 (bf16)
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
 def test_cfg2_attention_tail_split_vs_oracle_and_vs_whole_units(prec):
     """The 64-query attention's opt-in tail split (DEX_ATTN_Q64_TAIL=1: whole units for the first query groups, a two-way key split for
     the last ones, merged by the 64-row chain) at configs[2]'s shape: inside the mode's bound against the oracle, and within the
