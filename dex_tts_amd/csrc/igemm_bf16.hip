@@ -456,21 +456,29 @@ __global__ __launch_bounds__(256) void igemm_lp_nwalk_kernel(const IGemmP p) {
     // and a 64-bit address per element and column tile: the launch was bound by that integer work and by 16 dependent mask
     // loads per tile, not by its 170 MB of output)
     static_assert(MT == 1, "one 32-row tile per wave");
-    int u_pix[16], u_f[16], u_w[16];
-    {
+    // Round 5: the product is computed TRANSPOSED (weight fragment = A operand): a lane owns ONE token row (lane & 31) and 16 of the
+    // tile's 32 channels, four runs of four (8 q + 4 hh ..).  The scatter then writes 16 bytes per lane - two stores of a tile in the
+    // 16-bit form (one v_permlane32_swap per dword pairs the two halves of a token into 8-channel chunks), four in fp32 - where the
+    // plain product wrote one 2- / 4-byte element per lane and register: 16 store instructions of 128 / 256 bytes per tile, and the
+    // launch was bound by their number (5.4k store instructions per CU at DEX B = 32: 66 us for a 9 us GEMM with a 20 us output).
+    // Same products in the same K order, same (acc + bias) * mask: the values are bit-identical, only their placement changes.
+    // the wave's 32 token rows stay in registers for the whole walk (16 fragments: they were re-read from LDS for every column tile -
+    // two LDS fragment reads per MFMA)
+    lp8 afr[K / 16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            const bool v = m < M;
-            const int mm = v ? m : 0;
-            const int f = mm / p.Wo, w = mm - f * p.Wo;
-            u_f[r] = v ? f * p.unpatch_s : 0x40000000;                    // an invalid row fails the height test below
-            u_w[r] = w * p.unpatch_s;
-            u_pix[r] = f * p.unpatch_s * p.OWf + w * p.unpatch_s;
-        }
+    for (int ks = 0; ks < K / 16; ++ks) afr[ks] = *reinterpret_cast<const lp8*>(ap + ks * 16);
+    int u_pix, u_f, u_w;
+    {
+        const int m = m0 + wm * 32 + i;
+        const bool v = m < M;
+        const int mm = v ? m : 0;
+        const int f = mm / p.Wo, w = mm - f * p.Wo;
+        u_f = v ? f * p.unpatch_s : 0x40000000;                    // an invalid row fails the height test below
+        u_w = w * p.unpatch_s;
+        u_pix = f * p.unpatch_s * p.OWf + w * p.unpatch_s;
     }
     const float* omask = p.outmask ? p.outmask + (long)b * p.mask_bstride : nullptr;
-    float* Cb = p.C + (long)b * p.c_bstride + p.c_coff;
+    const float* biasb = p.bias ? p.bias + (long)b * p.bias_bstride : nullptr;
 #ifdef DEX_LP_WSPLIT
     for (int nt2 = 0; nt2 < ntile; nt2 += 2)
 #pragma unroll
@@ -482,15 +490,13 @@ __global__ __launch_bounds__(256) void igemm_lp_nwalk_kernel(const IGemmP p) {
     for (int nt = 0; nt < ntile; ++nt) {
         if (nt + 1 < ntile) { NW_LOAD_B(nt + 1) }
 #endif
-        float u_mk[16];
-        int u_p1 = 0, u_p2 = 0, u_c = 0;
-        {
-            const int ng0 = (nt_first + nt) * BN + wn * 32, pp = ng0 / p.unpatch_C;
-            u_c = ng0 - pp * p.unpatch_C + i;
-            u_p1 = pp / p.unpatch_s; u_p2 = pp - u_p1 * p.unpatch_s;
+        const int ng0 = (nt_first + nt) * BN + wn * 32, pp = ng0 / p.unpatch_C;
+        const int u_c0 = ng0 - pp * p.unpatch_C;                // first channel of this wave's 32 (a multiple of 32)
+        const int u_p1 = pp / p.unpatch_s, u_p2 = pp - u_p1 * p.unpatch_s;
+        const float u_mk = omask ? omask[min(u_w + u_p2, p.OWf - 1) * p.outmask_ws] : 1.f;
+        float4 b4[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) u_mk[r] = omask ? omask[min(u_w[r] + u_p2, p.OWf - 1) * p.outmask_ws] : 1.f;
-        }
+        for (int q = 0; q < 4; ++q) b4[q] = biasb ? *reinterpret_cast<const float4*>(biasb + ng0 + 8 * q + 4 * hh) : make_float4(0.f, 0.f, 0.f, 0.f);
         __builtin_amdgcn_sched_barrier(0);
         f32x16 acc[MT];
 #pragma unroll
@@ -500,49 +506,53 @@ __global__ __launch_bounds__(256) void igemm_lp_nwalk_kernel(const IGemmP p) {
 #pragma unroll
         for (int ks = 0; ks < K / 16; ++ks) {
             const lp8 bf = *reinterpret_cast<const lp8*>(bp + ks * 16);
-#pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                const lp8 af = *reinterpret_cast<const lp8*>(ap + t * 32 * LDS_LD + ks * 16);
-                acc[t] = DEX_MFMA_LP(af, bf, acc[t], 0, 0, 0);
+            acc[0] = DEX_MFMA_LP(bf, afr[ks], acc[0], 0, 0, 0);
 #ifdef DEX_LP_WSPLIT
-                acc[t] = DEX_MFMA_LP(af, __builtin_bit_cast(lp8, bl_[par_][ks]), acc[t], 0, 0, 0);
+            acc[0] = DEX_MFMA_LP(__builtin_bit_cast(lp8, bl_[par_][ks]), afr[ks], acc[0], 0, 0, 0);
 #endif
-            }
         }
         {
-            const float bias = p.bias ? p.bias[(long)b * p.bias_bstride + (nt_first + nt) * BN + wn * 32 + i] : 0.f;
-            float* cp = Cb + (long)(u_p1 * p.OWf + u_p2) * p.ldc + u_c;
-            // values first (the mask loads are consumed here, once), then the stores: a store under a per-lane branch that still
-            // depends on a load gets an s_waitcnt vmcnt(0) of its own, which also drains every earlier STORE - the first version
-            // of this loop completed its 16 stores one at a time (4.9 us per column tile)
+            // values first (the mask / bias loads are consumed here, once), then the stores: a store under a per-lane branch that still
+            // depends on a load gets an s_waitcnt vmcnt(0) of its own, which also drains every earlier STORE
             float val[16];
-            bool all_ok = true;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                val[r] = (acc[0][r] + bias) * u_mk[r];
-                all_ok = all_ok && (u_f[r] + u_p1 < p.OHf && u_w[r] + u_p2 < p.OWf);
+            for (int q = 0; q < 4; ++q) {
+                val[4 * q + 0] = (acc[0][4 * q + 0] + b4[q].x) * u_mk; val[4 * q + 1] = (acc[0][4 * q + 1] + b4[q].y) * u_mk;
+                val[4 * q + 2] = (acc[0][4 * q + 2] + b4[q].z) * u_mk; val[4 * q + 3] = (acc[0][4 * q + 3] + b4[q].w) * u_mk;
             }
+            const bool ok = u_f + u_p1 < p.OHf && u_w + u_p2 < p.OWf;
+            const long e0 = (long)b * p.c_bstride + p.c_coff + (long)(u_p1 * p.OWf + u_p2 + u_pix) * p.ldc + u_c0;     // element offset of (token, channel u_c0)
             __builtin_amdgcn_sched_barrier(0);
             if (p.c_lp) {             // (uniform) C in the mode's 16-bit type: its reader rounds it so anyway (the up path's 3x3 conv)
-                u16* cph = reinterpret_cast<u16*>(p.C) + (long)b * p.c_bstride + p.c_coff + (long)(u_p1 * p.OWf + u_p2) * p.ldc + u_c;
-                if (__builtin_amdgcn_ballot_w64(!all_ok) == 0) {
+                typedef unsigned u32x2n __attribute__((ext_vector_type(2)));
+                unsigned D[4][2];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) cph[(long)u_pix[r] * p.ldc] = lp_bits(val[r]);
-                } else {
+                for (int q = 0; q < 4; ++q) { D[q][0] = pack2_lp(val[4 * q], val[4 * q + 1]); D[q][1] = pack2_lp(val[4 * q + 2], val[4 * q + 3]); }
+                uint4 ch[2];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const bool ok = u_f[r] + u_p1 < p.OHf && u_w[r] + u_p2 < p.OWf;
-                        if (ok) cph[(long)u_pix[r] * p.ldc] = lp_bits(val[r]);
-                    }
+                for (int pr = 0; pr < 2; ++pr) {
+                    const u32x2n s0 = __builtin_amdgcn_permlane32_swap(D[2 * pr][0], D[2 * pr + 1][0], false, false);
+                    const u32x2n s1 = __builtin_amdgcn_permlane32_swap(D[2 * pr][1], D[2 * pr + 1][1], false, false);
+                    ch[pr] = make_uint4(s0[0], s1[0], s0[1], s1[1]);                 // channels u_c0 + 16 pr + 8 hh .. + 7 of this lane's token
                 }
-            } else if (__builtin_amdgcn_ballot_w64(!all_ok) == 0) {          // the common case: nothing of this tile is cropped
-#pragma unroll
-                for (int r = 0; r < 16; ++r) cp[(long)u_pix[r] * p.ldc] = val[r];
+                // (passing the workgroup's 64 x 64 outputs through an LDS tile so that a request writes 8 tokens x 128 contiguous bytes was
+                // measured too: 55.4 vs 54.3 us at DEX B = 32, 77.4 vs 74.1 at GeDEX B = 32 - the stores no longer bound the launch)
+                u16* cph = reinterpret_cast<u16*>(p.C) + e0 + 8 * hh;
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0) {                        // the common case: nothing of this tile is cropped
+                    *reinterpret_cast<uint4*>(cph) = ch[0];
+                    *reinterpret_cast<uint4*>(cph + 16) = ch[1];
+                } else if (ok) {
+                    *reinterpret_cast<uint4*>(cph) = ch[0];
+                    *reinterpret_cast<uint4*>(cph + 16) = ch[1];
+                }
             } else {
+                float* cp = p.C + e0 + 4 * hh;
+                if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const bool ok = u_f[r] + u_p1 < p.OHf && u_w[r] + u_p2 < p.OWf;
-                    if (ok) cp[(long)u_pix[r] * p.ldc] = val[r];
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(cp + 8 * q) = make_float4(val[4 * q], val[4 * q + 1], val[4 * q + 2], val[4 * q + 3]);
+                } else if (ok) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(cp + 8 * q) = make_float4(val[4 * q], val[4 * q + 1], val[4 * q + 2], val[4 * q + 3]);
                 }
             }
         }
@@ -560,6 +570,7 @@ static bool nwalk_eligible(const IGemmP& p) {
     if (p.sh != 1 || p.sw != 1 || p.off_h != 0 || p.off_w != 0 || p.Ho != p.Hi || p.Wo != p.Wi || p.gn_stats) return false;
     // the kernel's epilogue is the unpatchify scatter and nothing else: bias, output mask, crop
     if (p.unpatch_s <= 0 || (p.unpatch_C % 32) != 0 || p.gate || p.res || p.act != 0 || p.stats_final) return false;
+    if ((p.ldc % 8) != 0 || (p.c_coff % 8) != 0 || (p.c_bstride % 8) != 0) return false;          // 16-byte scatter stores (8 x 16 bit / 4 x fp32 per lane)
     const int mode = knob_or("DEX_GEMM_NWALK", 1);       // 0: never, 2: whenever the shape allows (tests)
     if (mode == 0) return false;
     const long wgs = (long)((p.Ho * p.Wo + 63) / 64) * p.B;

@@ -42,6 +42,7 @@ GELU_TERMS = int(os.environ.get("RCAGEN_GELU", "3"))       # erf by Abramowitz-S
                                                             # 2 VALU instructions per value less), 5 = 7.1.26 (1.5e-7, the C++ kernels' formula; A/B builds)
 DROP = set(filter(None, os.environ.get("RCAGEN_DROP", "").split(",")))   # anatomy builds (results wrong): gelu, mfma, wload, xstore, qkvstore
 STORE_MOD = os.environ.get("RCAGEN_STORE", "")              # cache-policy bits on the output stores (A/B: nt, sc1, "sc0 sc1")
+XS_SPLIT = tuple(int(v) for v in os.environ.get("RCAGEN_XSPLIT", "10,8,0").split(","))   # x2 row-store atoms (18) in the q / k / v passes
 TIMING = os.environ.get("RCAGEN_TIMING", "0") == "1"        # s_memtime stamps after every pass / at every barrier -> %[dbg] (tools/rc64bench -DRCA_TIMING)
 
 # ---- LDS map (bytes) - mirrored by dit_rowchain.hip (RCA_*)
@@ -836,7 +837,7 @@ def core(variant):
         xs_atoms = x_store_atoms() if variant == "FULL" else []
         if variant == "QKV":
             atoms += prefetch_atoms(variant)
-        atoms += xs_atoms[:10]
+        atoms += xs_atoms[:XS_SPLIT[0]]
         nt = run_pass(p, W, pq, passes[pq], atoms, tags, tq, passes[pk])
         # v^T bias: the lane's feature (32 (16 + 2 w + j) + i) for all 16 registers of a tile; set 0 is free once its q tile has left
         def vbias(p):
@@ -853,9 +854,9 @@ def core(variant):
                     for r in range(16):
                         p.e(f"v_mov_b32 {vr(passes[pv].accs[(j, Tt)] + r)}, {vr(T(10 + j))}")
         qa = qk_atoms(passes[pq], "rq", True)
-        atoms = [vbias] + interleave(qa, xs_atoms[10:]) + [vinit]
+        atoms = [vbias] + interleave(qa, xs_atoms[XS_SPLIT[0]:XS_SPLIT[0] + XS_SPLIT[1]]) + [vinit]
         nt2 = run_pass(p, W, pk, passes[pk], atoms, nt, init_k["t"], passes[pv])
-        run_pass(p, W, pv, passes[pv], qk_atoms(passes[pk], "rk", False), nt2, None)
+        run_pass(p, W, pv, passes[pv], interleave(qk_atoms(passes[pk], "rk", False), xs_atoms[XS_SPLIT[0] + XS_SPLIT[1]:]), nt2, None)
         for j in range(2):
             for Tt in range(2):
                 base = passes[pv].accs[(j, Tt)]
