@@ -25,7 +25,11 @@ union LFrag { uint4 u; lp8 v; };
 
 // grid (nblk, B); 256 threads; each wave owns `nsub` consecutive 32-pixel sub-tiles.
 // part_m/part_s: [B][4][nblk][32], part_c: [B][4][nblk][32 d][32 e]   (same layout linattn_combine reads)
-template <int C, bool PRO>
+// FL >= 0 (round 5): the flags of the PRO form as COMPILE-TIME constants - bit 0 h2_bf16, bit 1 res_lp, bit 2 xout_lp, bit 3 res_under_mask.  As
+// run-time (uniform) flags they became ~180 v_cndmask + both sides of every select per 32-pixel sub-tile of a VALU-bound loop; the
+// launcher instantiates every combination with 16-bit h2 (the default of the reduced-precision modes) and keeps FL = -1 for the rest
+// (DEX_H_BF16=0).
+template <int C, bool PRO, int FL = -1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 ? 2 : 1, C == 64 ? 2 : 8))) void linattn_kvctx_kernel(const LinKvCtxP p) {
     constexpr int LDW = C + 8, KS = C / 16;
     extern __shared__ __attribute__((aligned(16))) u16 smem_la[];
@@ -80,8 +84,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 ? 2
     float mkv = 1.f;
     float ga_pre = 0.f, be_pre = 0.f;                       // GroupNorm affine of channel tid, requested with the first loads
     if constexpr (PRO) { if (tid < C) { ga_pre = p.gamma[tid]; be_pre = p.beta[tid]; } }
-    const bool hb = PRO && p.h2_bf16 != 0;                 // H2 stored as bf16: xa holds the 8 raw values until they are used
-    const bool rlp = PRO && p.res_lp != 0;                 // the residual rows likewise (ra holds 8 raw 16-bit values)
+    const bool hb = FL >= 0 ? (FL & 1) != 0 : (PRO && p.h2_bf16 != 0);      // H2 stored as bf16: xa holds the 8 raw values until they are used
+    const bool rlp = FL >= 0 ? (FL & 2) != 0 : (PRO && p.res_lp != 0);      // the residual rows likewise (ra holds 8 raw 16-bit values)
+    const bool xlp = FL >= 0 ? (FL & 4) != 0 : (p.xout_lp != 0);            // x leaves in the mode's 16-bit type
     const unsigned short* Rh = (PRO && p.res) ? reinterpret_cast<const unsigned short*>(p.res) + (long)b * p.resb : nullptr;
     const unsigned short* Xh = PRO ? reinterpret_cast<const unsigned short*>(p.H2) + (long)b * p.npix * C : nullptr;
     {
@@ -139,7 +144,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 ? 2
         if (px0 >= p.npix) break;
         if constexpr (PRO) {
             // x = mask * (Mish(GN(h2)) + r)   (identity shortcut)   or   mask * Mish(GN(h2)) + r   (res_conv shortcut)
-            const bool under = p.res_under_mask != 0;
+            const bool under = FL >= 0 ? (FL & 8) != 0 : (p.res_under_mask != 0);
             const bool live = px0 + i < p.npix;
             float* xo = p.Xout + ((long)b * p.npix + min(px0 + i, p.npix - 1)) * C + hh * 8;
 #pragma unroll
@@ -171,7 +176,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 ? 2
                 }
                 xa[ks] = make_float4(v[0], v[1], v[2], v[3]); xc[ks] = make_float4(v[4], v[5], v[6], v[7]);
                 if (live) {
-                    if (p.xout_lp) {       // 16-bit x for the tail kernel: its q operand rounds x the same way, its residual term reads the rounded value
+                    if (xlp) {       // 16-bit x for the tail kernel: its q operand rounds x the same way, its residual term reads the rounded value
                         u16* xh = reinterpret_cast<u16*>(p.Xout) + ((long)b * p.npix + min(px0 + i, p.npix - 1)) * C + hh * 8 + ks * 16;
                         *reinterpret_cast<uint4*>(xh) = make_uint4(pack2_lp(v[0], v[1]), pack2_lp(v[2], v[3]), pack2_lp(v[4], v[5]), pack2_lp(v[6], v[7]));
                     } else {
@@ -323,17 +328,26 @@ void launch_linattn_kvctx(const LinKvCtxP& p, hipStream_t st) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_kvctx_kernel<128, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_kvctx_kernel<64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_kvctx_kernel<128, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+#define KVCTX_ATTR(CC, F) hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_kvctx_kernel<CC, true, F>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+        KVCTX_ATTR(64, 1) KVCTX_ATTR(64, 3) KVCTX_ATTR(64, 5) KVCTX_ATTR(64, 7) KVCTX_ATTR(64, 9) KVCTX_ATTR(64, 11) KVCTX_ATTR(64, 13) KVCTX_ATTR(64, 15)
+        KVCTX_ATTR(128, 1) KVCTX_ATTR(128, 3) KVCTX_ATTR(128, 5) KVCTX_ATTR(128, 7) KVCTX_ATTR(128, 9) KVCTX_ATTR(128, 11) KVCTX_ATTR(128, 13) KVCTX_ATTR(128, 15)
+#undef KVCTX_ATTR
         attr = true;
     }
     dim3 grid(p.nblk, p.B);
     const bool pro = p.H2 != nullptr;
-    if (p.C == 64) {
-        if (pro) hipLaunchKernelGGL((linattn_kvctx_kernel<64, true>), grid, dim3(256), lds, st, p);
-        else hipLaunchKernelGGL((linattn_kvctx_kernel<64, false>), grid, dim3(256), lds, st, p);
-    } else {
-        if (pro) hipLaunchKernelGGL((linattn_kvctx_kernel<128, true>), grid, dim3(256), lds, st, p);
-        else hipLaunchKernelGGL((linattn_kvctx_kernel<128, false>), grid, dim3(256), lds, st, p);
+    const int fl = pro ? (p.h2_bf16 != 0 ? 1 : 0) | (p.res_lp != 0 ? 2 : 0) | (p.xout_lp != 0 ? 4 : 0) | (p.res_under_mask != 0 ? 8 : 0) : -1;
+#define KVCTX_CASE(CC, F) case F: hipLaunchKernelGGL((linattn_kvctx_kernel<CC, true, F>), grid, dim3(256), lds, st, p); break;
+#define KVCTX_LAUNCH(CC)                                                                                                              \
+    switch (fl) {                                                                                                                      \
+        KVCTX_CASE(CC, 1) KVCTX_CASE(CC, 3) KVCTX_CASE(CC, 5) KVCTX_CASE(CC, 7) KVCTX_CASE(CC, 9) KVCTX_CASE(CC, 11) KVCTX_CASE(CC, 13) KVCTX_CASE(CC, 15)   \
+        default:                                                                                                                       \
+            if (pro) hipLaunchKernelGGL((linattn_kvctx_kernel<CC, true>), grid, dim3(256), lds, st, p);                                \
+            else hipLaunchKernelGGL((linattn_kvctx_kernel<CC, false>), grid, dim3(256), lds, st, p);                                   \
     }
+    if (p.C == 64) { KVCTX_LAUNCH(64) } else { KVCTX_LAUNCH(128) }
+#undef KVCTX_LAUNCH
+#undef KVCTX_CASE
 }
 
 // grid (4 heads, B, 32 rows d): merge the workgroup partials of ONE context row -> normalised ctx[b][h][d][:], then
