@@ -373,5 +373,329 @@ void launch_attention_lp(const AttnP& p, hipStream_t st) {
     else launch_split<2>(p, st);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// The DEX TV adaptor as ONE launch (batch regime; ref_encoder.py:154-179, kernels.h TvChainP).  As separate launches the adaptor is
+// a 1x1 GEMM (q, 84 MB written at B = 32), the shared-K/V attention above (q read back, every workgroup converting and transposing
+// the same <= 349 fp32 keys / values of its utterance, 88 us) and a second 1x1 GEMM (output projection + residual, 4-byte stores
+// per lane): 206 us of a 2.4 ms Euler step for 40 GFLOP and 168 MB of tensors that HAVE to move (x in, the result out).  Here a
+// workgroup of four waves owns 128 pixels from x to the result:
+//   * x rows arrive as coalesced 512-byte rows, are masked, rounded once and staged in LDS next to this utterance's folded W_eff;
+//     q^T = W_eff x^T comes out of the MFMA with lane = pixel and the channels of a 16-group in accumulator order, which IS the
+//     B-operand order of the score MFMA once the keys' channels are stored in the same order (launch_tv_kv_prep) - as P^T needs
+//     no shuffle in front of V^T (attn_tile), q needs none in front of K;
+//   * the K / V^T tiles are 16-byte copies of operands prepared once per step (no conversion, no transposed LDS writes);
+//   * O^T (lane = pixel) is normalised, rounded and fed to out^T = W_l O^T the same way (W_l staged with permuted columns);
+//   * the result leaves through an LDS stage as whole 256-byte row segments, where the residual is added, the mask applied and the
+//     per-channel statistics of the TIV adaptor's InstanceNorm accumulate with lane = channel (fixed order inside a wave,
+//     fixed-point integer adds across waves and workgroups: deterministic, kernels.h GN_SLOTS).
+// Roundings are the ones of the separate launches (x, q / sqrt(C), P, O in the operand type; fp32 everywhere else).
+constexpr int TVC_KT = 64, TVC_VLD = TVC_KT + 8;
+constexpr int TVC_KBUF = TVC_KT * K_LD, TVC_VBUF = AHD * TVC_VLD;
+constexpr int TVC_U16 = 2 * TVC_KBUF + 2 * TVC_VBUF;            // 35840 u16 = 71680 B: the K / V rings; W_eff + x tile and W_l + output stage alias them
+constexpr int TVC_SLD = 68;                                     // floats per pixel of the output stage (64 channels + 4: conflict-free 16 B accesses)
+static_assert(2 * 128 * K_LD <= TVC_U16 && 128 * K_LD * 2 + 128 * TVC_SLD * 4 <= TVC_U16 * 2, "aliases fit the rings");
+
+__global__ __launch_bounds__(256) void tv_kv_prep_kernel(const TvKvPrepP p) {
+    const long nk = (long)p.B * p.NkPad * (AHD / 8);             // K chunks: 8 positions of one key
+    const long nv = (long)p.B * (p.NkPad / 8) * AHD;             // V chunks: 8 key positions of one channel (channel fastest: coalesced reads)
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    u16* Kp = reinterpret_cast<u16*>(p.Kp);
+    u16* VTp = reinterpret_cast<u16*>(p.VTp);
+    if (idx < nk) {
+        const int c = (int)(idx % (AHD / 8)), key = (int)((idx / (AHD / 8)) % p.NkPad), b = (int)(idx / ((long)(AHD / 8) * p.NkPad));
+        const int d0 = 16 * (c >> 1) + 4 * (c & 1);              // positions 8c .. 8c + 7 hold channels d0 .. d0 + 3, d0 + 8 .. d0 + 11
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), e = a;
+        if (key < p.Nk) {
+            const float* src = p.K + (long)b * p.kvb + (long)key * AHD + d0;
+            a = *reinterpret_cast<const float4*>(src); e = *reinterpret_cast<const float4*>(src + 8);
+        }
+        *reinterpret_cast<uint4*>(Kp + ((long)b * p.NkPad + key) * AHD + 8 * c) =
+            make_uint4(pack2_lp(a.x, a.y), pack2_lp(a.z, a.w), pack2_lp(e.x, e.y), pack2_lp(e.z, e.w));
+    } else if (idx < nk + nv) {
+        const long j = idx - nk;
+        const int d = (int)(j % AHD), c = (int)((j / AHD) % (p.NkPad / 8)), b = (int)(j / ((long)AHD * (p.NkPad / 8)));
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int key = key_pos(8 * c + q);
+            v[q] = key < p.Nk ? p.V[(long)b * p.kvb + (long)key * AHD + d] : 0.f;
+        }
+        *reinterpret_cast<uint4*>(VTp + ((long)b * AHD + d) * p.NkPad + 8 * c) =
+            make_uint4(pack2_lp(v[0], v[1]), pack2_lp(v[2], v[3]), pack2_lp(v[4], v[5]), pack2_lp(v[6], v[7]));
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void tv_chain_kernel(const TvChainP p) {
+    extern __shared__ __attribute__((aligned(16))) u16 smem_b[];
+    __shared__ long long red[2 * AHD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.y, row0 = blockIdx.x * 128;
+    int Nk = p.Nk;
+    if (p.kv_len) Nk = min(p.Nk, p.kv_len[b] + p.kv_len_add);
+    const int ntiles = (Nk + TVC_KT - 1) / TVC_KT;
+    const float* Xb = p.X + (long)b * p.x_bstride + p.x_coff;
+    const float* mrow = p.mask + (long)b * p.mask_bstride;
+    const u16* Wg = reinterpret_cast<const u16*>(p.Weff) + (long)b * AHD * AHD;
+    const u16* Kg = reinterpret_cast<const u16*>(p.Kp) + (long)b * p.NkPad * AHD;
+    const u16* Vg = reinterpret_cast<const u16*>(p.VTp) + (long)b * AHD * p.NkPad;
+    red[tid] = 0;
+
+    // ---- K / V^T tile kt: 16 KB + 16 KB of ready operands, four + four 16-byte chunks per thread
+    uint4 kr[4], vr[4];
+    auto kv_load = [&](int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int id = tid + 256 * j;
+            kr[j] = *reinterpret_cast<const uint4*>(Kg + ((long)kt * TVC_KT + (id >> 4)) * AHD + (id & 15) * 8);
+            vr[j] = *reinterpret_cast<const uint4*>(Vg + (long)(id >> 3) * p.NkPad + kt * TVC_KT + (id & 7) * 8);
+        }
+    };
+    auto kv_store = [&](int buf) __attribute__((always_inline)) {
+        u16* kS = smem_b + buf * TVC_KBUF;
+        u16* vT = smem_b + 2 * TVC_KBUF + buf * TVC_VBUF;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int id = tid + 256 * j;
+            *reinterpret_cast<uint4*>(kS + (id >> 4) * K_LD + (id & 15) * 8) = kr[j];
+            *reinterpret_cast<uint4*>(vT + (id >> 3) * TVC_VLD + (id & 7) * 8) = vr[j];
+        }
+    };
+
+    // ---- prologue: W_eff and the 128 x rows (masked, rounded once) into LDS
+    u16* Ws = smem_b;                        // [128 n][K_LD]
+    u16* Xs = smem_b + 128 * K_LD;           // [128 pixels][K_LD]
+    {
+        uint4 wr[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int id = tid + 256 * j; wr[j] = *reinterpret_cast<const uint4*>(Wg + (id >> 4) * AHD + (id & 15) * 8); }
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            float4 xa[8];
+            float mk[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int id = tid + 256 * (jb * 8 + j);
+                const int pix = row0 + (id >> 5);
+                const bool ok = pix < p.npix;
+                const int pc = ok ? pix : p.npix - 1;
+                xa[j] = *reinterpret_cast<const float4*>(Xb + (long)pc * p.ldx + (id & 31) * 4);
+                const float mv = mrow[(pc % p.Wm) * p.mask_ws];
+                mk[j] = ok ? mv : 0.f;
+            }
+            if (jb == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const int id = tid + 256 * j; *reinterpret_cast<uint4*>(Ws + (id >> 4) * K_LD + (id & 15) * 8) = wr[j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int id = tid + 256 * (jb * 8 + j);
+                *reinterpret_cast<uint2*>(Xs + (id >> 5) * K_LD + (id & 31) * 4) =
+                    make_uint2(pack2_lp(xa[j].x * mk[j], xa[j].y * mk[j]), pack2_lp(xa[j].z * mk[j], xa[j].w * mk[j]));
+            }
+        }
+    }
+    if (ntiles > 0) kv_load(0);              // first K / V tile in flight under the q projection
+    __syncthreads();
+
+    // ---- q^T = W_eff x^T (+ b_eff), scaled, rounded: the B operand of the score MFMAs
+    Frag qf[8];
+    {
+        Frag xf[8];
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) xf[ks].u = *reinterpret_cast<const uint4*>(Xs + (wave * 32 + i) * K_LD + ks * 16 + hh * 8);
+        const float* be = p.beff + (long)b * AHD;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                Frag a; a.u = *reinterpret_cast<const uint4*>(Ws + (t * 32 + i) * K_LD + ks * 16 + hh * 8);
+                acc = DEX_MFMA_LP(a.v, xf[ks].v, acc, 0, 0, 0);
+            }
+#ifdef DEX_LP_WSPLIT
+            if (p.weff_lo_off) {             // (uniform) lo halves straight from global: 32 KB per utterance, cache resident
+                const u16* wl = Wg + p.weff_lo_off + (long)(t * 32 + i) * AHD + hh * 8;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    Frag a; a.u = *reinterpret_cast<const uint4*>(wl + ks * 16);
+                    acc = DEX_MFMA_LP(a.v, xf[ks].v, acc, 0, 0, 0);
+                }
+            }
+#endif
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const float4 b0 = *reinterpret_cast<const float4*>(be + t * 32 + 16 * k2 + 4 * hh);
+                const float4 b1 = *reinterpret_cast<const float4*>(be + t * 32 + 16 * k2 + 8 + 4 * hh);
+                const float sc = p.scale;
+                Frag& q = qf[2 * t + k2];
+                q.u.x = pack2_lp((acc[8 * k2 + 0] + b0.x) * sc, (acc[8 * k2 + 1] + b0.y) * sc);
+                q.u.y = pack2_lp((acc[8 * k2 + 2] + b0.z) * sc, (acc[8 * k2 + 3] + b0.w) * sc);
+                q.u.z = pack2_lp((acc[8 * k2 + 4] + b1.x) * sc, (acc[8 * k2 + 5] + b1.y) * sc);
+                q.u.w = pack2_lp((acc[8 * k2 + 6] + b1.z) * sc, (acc[8 * k2 + 7] + b1.w) * sc);
+            }
+        }
+    }
+    __syncthreads();                         // W_eff / x tile read by every wave: the rings may overwrite them
+
+    // ---- attention over the style keys
+    f32x16 o[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    if (ntiles > 0) kv_store(0);
+    for (int kt = 0; kt < ntiles; ++kt) {
+        __syncthreads();                     // tile kt visible; buffer (kt + 1) & 1 free
+        const int cur = kt & 1;
+        if (kt + 1 < ntiles) kv_load(kt + 1);
+        attn_tile<TVC_KT>(smem_b + cur * TVC_KBUF, smem_b + 2 * TVC_KBUF + cur * TVC_VBUF, qf, o, m_run, l_run, kt * TVC_KT, Nk, lane);
+        if (kt + 1 < ntiles) kv_store(cur ^ 1);
+    }
+    l_run += __shfl_xor(l_run, 32);
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    __syncthreads();                         // rings free
+
+    // ---- out^T = W_l O^T: W_l with the columns of every 16-group in accumulator order
+    u16* Ls = smem_b;                        // [128 n][K_LD]
+    float* stage = reinterpret_cast<float*>(smem_b + 128 * K_LD);          // [128 pixels][TVC_SLD]
+    const u16* Wl = reinterpret_cast<const u16*>(p.Wl);
+    {
+        uint2 la[8], lb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int id = tid + 256 * j;
+            const int n = id >> 4, c = id & 15, d0 = 16 * (c >> 1) + 4 * (c & 1);
+            la[j] = *reinterpret_cast<const uint2*>(Wl + n * AHD + d0);
+            lb[j] = *reinterpret_cast<const uint2*>(Wl + n * AHD + d0 + 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int id = tid + 256 * j;
+            *reinterpret_cast<uint4*>(Ls + (id >> 4) * K_LD + (id & 15) * 8) = make_uint4(la[j].x, la[j].y, lb[j].x, lb[j].y);
+        }
+    }
+    Frag of[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            Frag& f = of[2 * t + k2];
+            f.u.x = pack2_lp(o[t][8 * k2 + 0] * inv, o[t][8 * k2 + 1] * inv); f.u.y = pack2_lp(o[t][8 * k2 + 2] * inv, o[t][8 * k2 + 3] * inv);
+            f.u.z = pack2_lp(o[t][8 * k2 + 4] * inv, o[t][8 * k2 + 5] * inv); f.u.w = pack2_lp(o[t][8 * k2 + 6] * inv, o[t][8 * k2 + 7] * inv);
+        }
+    __syncthreads();
+    float gs[2][4], gq[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gs[h][e] = 0.f; gq[h][e] = 0.f; }
+    float* myst = stage + wave * 32 * TVC_SLD;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = 2 * h + u;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                Frag a; a.u = *reinterpret_cast<const uint4*>(Ls + (t * 32 + i) * K_LD + ks * 16 + hh * 8);
+                acc = DEX_MFMA_LP(a.v, of[ks].v, acc, 0, 0, 0);
+            }
+#ifdef DEX_LP_WSPLIT
+            if (p.wl_lo_off) {
+                const u16* wl = Wl + p.wl_lo_off + (long)(t * 32 + i) * AHD;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const int d0 = 16 * ks + 4 * hh;
+                    const uint2 x0 = *reinterpret_cast<const uint2*>(wl + d0), x1 = *reinterpret_cast<const uint2*>(wl + d0 + 8);
+                    Frag a; a.u = make_uint4(x0.x, x0.y, x1.x, x1.y);
+                    acc = DEX_MFMA_LP(a.v, of[ks].v, acc, 0, 0, 0);
+                }
+            }
+#endif
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(myst + i * TVC_SLD + u * 32 + 8 * g + 4 * hh) = make_float4(acc[4 * g + 0], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): this wave's stage rows written
+        __builtin_amdgcn_wave_barrier();
+        float4 sv[8], rv[8];
+        float mk[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int id = j * 64 + lane;
+            const int px = id >> 4, c4 = (id & 15) * 4;
+            const int pix = row0 + wave * 32 + px;
+            const bool ok = pix < p.npix;
+            const int pc = ok ? pix : p.npix - 1;
+            rv[j] = *reinterpret_cast<const float4*>(Xb + (long)pc * p.ldx + h * 64 + c4);
+            const float mv = mrow[(pc % p.Wm) * p.mask_ws];
+            mk[j] = ok ? mv : 0.f;
+            sv[j] = *reinterpret_cast<const float4*>(myst + px * TVC_SLD + c4);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int id = j * 64 + lane;
+            const int px = id >> 4, c4 = (id & 15) * 4;
+            const int pix = row0 + wave * 32 + px;
+            float4 v;
+            v.x = (sv[j].x + rv[j].x) * mk[j]; v.y = (sv[j].y + rv[j].y) * mk[j];
+            v.z = (sv[j].z + rv[j].z) * mk[j]; v.w = (sv[j].w + rv[j].w) * mk[j];
+            if (pix < p.npix) {
+                *reinterpret_cast<float4*>(p.out + ((long)b * p.npix + pix) * AHD + h * 64 + c4) = v;
+                gs[h][0] += v.x; gs[h][1] += v.y; gs[h][2] += v.z; gs[h][3] += v.w;
+                gq[h][0] = fmaf(v.x, v.x, gq[h][0]); gq[h][1] = fmaf(v.y, v.y, gq[h][1]);
+                gq[h][2] = fmaf(v.z, v.z, gq[h][2]); gq[h][3] = fmaf(v.w, v.w, gq[h][3]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();               // the stage rows are rewritten by the next half
+    }
+    if (p.stats) {
+        const double inv_n = 1.0 / (double)p.npix;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = gs[h][e], q = gq[h][e];
+                a += __shfl_xor(a, 16); q += __shfl_xor(q, 16);
+                a += __shfl_xor(a, 32); q += __shfl_xor(q, 32);
+                if (lane < 16) {
+                    const int ch = h * 64 + lane * 4 + e;
+                    gn_add(&red[ch * 2], gn_fix(a, inv_n)); gn_add(&red[ch * 2 + 1], gn_fix(q, inv_n));
+                }
+            }
+        __syncthreads();
+        const long long v = red[tid];
+        if (v != 0) gn_add(p.stats + (((long)b * AHD + (tid >> 1)) * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * 2 + (tid & 1), v);
+    }
+}
+
+// batch regime of the one-launch TV adaptor: enough 128-pixel workgroups for two rounds of the chip
+bool tv_chain_form(int npix, int C, int B) {
+    const int k = knob_or("DEX_TV_CHAIN", 1);            // 0: the three separate launches, 2: this form at any size (tests)
+    return C == AHD && k != 0 && (k == 2 || (long)((npix + 127) / 128) * B >= 512);
+}
+void launch_tv_kv_prep(const TvKvPrepP& p, hipStream_t st) {
+    const long n = (long)p.B * p.NkPad * (AHD / 8) + (long)p.B * (p.NkPad / 8) * AHD;
+    hipLaunchKernelGGL(tv_kv_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+}
+void launch_tv_chain(const TvChainP& p, hipStream_t st) {
+    const size_t lds = (size_t)TVC_U16 * sizeof(u16);
+    static bool attr = false;
+    if (!attr) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&tv_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    g_last_symbol = "tv_chain_kernel";
+    hipLaunchKernelGGL(tv_chain_kernel, dim3((p.npix + 127) / 128, p.B), dim3(256), lds, st, p);
+}
+
 }  // namespace DEX_LP_NS
 }  // namespace dex

@@ -32,7 +32,7 @@ const char* const KNOB_NAMES[] = {
     // launcher heuristics (workgroup caps, shape thresholds, form switches) - process-static getenv reads until round 4
     "DEX_ATTN_SHARED_W8", "DEX_CONVT_MT", "DEX_CONVT_WGS", "DEX_CONV_DOWN_WGS", "DEX_CONV_REGW", "DEX_CONV_REGW_RES", "DEX_CONV_SMALL_MAX", "DEX_CONV_TH8",
     "DEX_CONV_W8", "DEX_DWCONV_CAP", "DEX_FINAL_CAP", "DEX_FIRST_CAP", "DEX_FIRST_MFMA", "DEX_GEMM_NWALK", "DEX_NWALK_SPLIT", "DEX_POS_COL", "DEX_POS_COL_MIN",
-    "DEX_POS_CT", "DEX_REGW_MIN_TILES", "DEX_REGW_WGS", "DEX_ROWCHAIN64", "DEX_ROWCHAIN64A", "DEX_TIV_CAP"};
+    "DEX_POS_CT", "DEX_REGW_MIN_TILES", "DEX_REGW_WGS", "DEX_ROWCHAIN64", "DEX_ROWCHAIN64A", "DEX_TIV_CAP", "DEX_TV_CHAIN"};
 constexpr int N_KNOBS = (int)(sizeof(KNOB_NAMES) / sizeof(KNOB_NAMES[0]));
 // value of one variable: a decimal integer; unset, empty or without digits ("true", "on") = KNOB_UNSET, so a typo leaves the default
 // form on instead of silently switching it off
@@ -683,6 +683,7 @@ struct Plan {
     void *qh, *kh, *vt, *qh2, *kh2, *vt2; int Npad; size_t vt_bytes;   // bf16 attention operands of the row-chain path (two sets:
                                                                         // a fused block reads one while its workgroups write the other)
     float *tv_keys, *tv_K, *tv_V, *tv_q, *tv_ao, *tv_out, *tiv_out, *tv_weff, *tv_beff; gnfix_t *tv_stats, *tiv_stats; void* tv_wbf;
+    void *tv_kp, *tv_vtp; int tv_nkpad;        // the one-launch TV adaptor's 16-bit key / value operands (TvKvPrepP)
     size_t bytes;
 };
 
@@ -842,12 +843,15 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
     P.dbg_tok = A.f(tok * hid * (c.dit_depth + 1));
     P.tv_keys = P.tv_K = P.tv_V = P.tv_q = P.tv_ao = P.tv_out = P.tiv_out = P.tv_weff = P.tv_beff = nullptr; P.tv_wbf = nullptr;
     P.tv_stats = P.tiv_stats = nullptr;
+    P.tv_kp = P.tv_vtp = nullptr; P.tv_nkpad = 0;
     if (c.variant == DEX_VARIANT_DEX) {
         const size_t pm = (size_t)B * P.Hm * P.Wm;
         P.tv_keys = A.f((size_t)B * d.Ts * mid); P.tv_K = A.f((size_t)B * (d.Ts + 1) * mid); P.tv_V = A.f((size_t)B * (d.Ts + 1) * mid);
         P.tv_q = A.f(pm * mid); P.tv_ao = A.f(pm * mid); P.tv_out = A.f(pm * mid); P.tiv_out = A.f(pm * mid);
         P.tv_weff = A.f((size_t)B * mid * mid); P.tv_beff = A.f((size_t)B * mid);
         P.tv_wbf = A.take((size_t)B * mid * mid * 2 * 2);          // (x2: the lo halves of the split-weight mode behind the hi ones)
+        P.tv_nkpad = (d.Ts + 1 + 63) / 64 * 64;
+        P.tv_kp = A.take((size_t)B * P.tv_nkpad * mid * 2); P.tv_vtp = A.take((size_t)B * P.tv_nkpad * mid * 2);
         P.tv_stats = (gnfix_t*)A.take((size_t)B * mid * IN_SLOTS * 2 * 2 * sizeof(gnfix_t));   // IN2d partials of the TV input and the TIV input
         P.tiv_stats = A.dry ? nullptr : P.tv_stats + (size_t)B * mid * IN_SLOTS * 2;
     }
@@ -1331,10 +1335,30 @@ struct Runner {
         IGemmP q = base_gemm(X.p, X.ld, X.coff, P.Hm, P.Wm, mid, P.tv_weff, mid, P.tv_beff, P.tv_q, mid, 0);
         q.w_bstride = (long)mid * mid; q.bias_bstride = mid; q.inmask = mask; q.inmask_ws = mask_ws;
         if (qbf) { q.Wbf = P.tv_wbf; q.w_lo_off = fo.split ? (long)B * mid * mid : 0; }
-        gemm("tv_q", q);
+        const bool chain = qbf && x->lp_of().count(x->tv_wl) && P.tv_kp && tv_chain_form((int)npix, mid, B);
+        if (!chain) gemm("tv_q", q);
         TvRow0P r0{P.tv_k0, P.tv_v0, sp, P.tv_K, P.tv_V, (long)(P.d.Ts + 1) * mid, mid, B, reinterpret_cast<float*>(P.tv_stats),
                    (long)B * mid * IN_SLOTS * 2 * 2 * (long)(sizeof(gnfix_t) / sizeof(float))};
         run("tv_time_token", 0, 8.0 * mid * B, [&] { launch_tv_row0(r0, st); });
+        // Batch regime, reduced-precision modes: q projection, attention, output projection, residual, mask and the TIV statistics as
+        // ONE launch per 128 pixels (attention_bf16.hip tv_chain_kernel; DEX_TV_CHAIN=0: the three launches below).  q and the
+        // attention output never reach HBM; the keys / values become 16-bit operands once per step.
+        if (chain) {
+            TvKvPrepP kp{P.tv_K, P.tv_V, (long)(P.d.Ts + 1) * mid, P.d.Ts + 1, P.tv_nkpad, P.tv_kp, P.tv_vtp, B};
+            run("tv_kv_operands", 0, 12.0 * B * (P.d.Ts + 1) * mid, [&] { launch_tv_kv_prep(kp, x->precision, st); });
+            const void* wl = x->lp_of().at(x->tv_wl);
+            TvChainP tc{X.p, X.ld, X.coff, npix * X.ld, (int)npix, P.Wm, mask, mask_ws, (long)P.d.T,
+                        P.tv_wbf, fo.split ? (long)B * mid * mid : 0L, P.tv_beff, wl, x->lo_off(wl),
+                        P.tv_kp, P.tv_vtp, P.tv_nkpad, P.d.Ts + 1, args->sty_lengths_dev, 1, 1.0f / sqrtf((float)mid),
+                        P.tv_out, P.tiv_stats, B};
+            run("tv_chain", 4.0 * B * (double)npix * mid * mid + 4.0 * B * (double)npix * (P.d.Ts + 1) * mid, 8.0 * B * npix * mid,
+                [&] { launch_tv_chain(tc, x->precision, st); });
+            tap("tv", P.tv_out, B * npix, mid, mid);
+            TivApplyP ta{P.tv_out, mid, npix * mid, P.tiv_out, mid, npix * mid, (int)npix, mid, P.tiv_stats, 1e-5f, P.sap_s, P.sap_m, sp, B};
+            run("tiv_adain", 2.0 * npix * mid * B, 8.0 * npix * mid * B, [&] { launch_tiv_apply(ta, st); });
+            tap("tiv", P.tiv_out, B * npix, mid, mid);
+            return;
+        }
         AttnP a{};
         a.Q = P.tv_q; a.ldq = mid; a.qb = npix * mid; a.K = P.tv_K; a.ldk = mid; a.kb = (long)(P.d.Ts + 1) * mid;
         a.V = P.tv_V; a.ldv = mid; a.vb = a.kb; a.O = P.tv_ao; a.ldo = mid; a.ob = npix * mid;
@@ -1688,6 +1712,7 @@ int dex_denoise_once(DexCtx* x, const DexDenoiseArgs* da, dex_stream_t stream) {
     if (P.bytes > a->workspace_bytes) return x->fail(DEX_ERR_WORKSPACE, "workspace too small: need %zu bytes, got %zu", P.bytes, a->workspace_bytes);
     make_plan(x, d, a->workspace_dev, P);
     x->taps.clear();
+    if (x->prof_on) { for (auto& pr : x->prof) { hipEventDestroy(pr.a); hipEventDestroy(pr.b); } x->prof.clear(); x->prof_agg.clear(); }     // (rows describe the last call, as in dex_sample)
     Runner R{x, P, st, a->mask_dev, a->mu_dev, da->x_dev, a, true};
     R.sp = 0; R.stats_base = P.stats; R.stats_other = nullptr;
     hipLaunchKernelGGL(set_sigma_pair, dim3(1), dim3(1), 0, st, a->sigmas_dev, P.sig2);

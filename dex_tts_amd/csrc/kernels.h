@@ -383,6 +383,23 @@ void launch_tiv_apply(const TivApplyP& p, hipStream_t st);
 struct TvRow0P { const float* k0; const float* v0; int step; float* K; float* V; long kvb; int C; int B;
                  float* zero_ptr; long zero_n; };          // optional: clear the IN2d statistics for their next use
 void launch_tv_row0(const TvRow0P& p, hipStream_t st);
+// The TV adaptor as ONE launch in the batch regime (attention_bf16.hip, reduced-precision modes; ref_encoder.py:154-179):
+//   out = mask * (x + linear(softmax((IN2d(x) W_q^T / sqrt(C)) K^T) V))   with the InstanceNorm folded into a per-utterance W_eff, b_eff
+// (launch_in_fold) - q projection, attention over the Ts + 1 style keys, output projection, residual, mask and the TIV adaptor's
+// InstanceNorm statistics of the result per 128-pixel workgroup; q and the attention output never exist in HBM.
+// TvKvPrepP: K / V (fp32 [B][Nk][C]) -> 16-bit operands in the layouts the chain's LDS tiles take as they are: Kp [B][NkPad][C] with the
+// channels of every 16-group in accumulator order, VTp [B][C][NkPad] transposed with the keys of every 16-group in accumulator order;
+// keys >= Nk are zeros.  C = 128.
+struct TvKvPrepP { const float* K; const float* V; long kvb; int Nk; int NkPad; void* Kp; void* VTp; int B; };
+struct TvChainP { const float* X; int ldx; int x_coff; long x_bstride; int npix; int Wm;
+                  const float* mask; int mask_ws; long mask_bstride;
+                  const void* Weff; long weff_lo_off; const float* beff;      // 16-bit [B][C][C] ([n][k]; lo halves weff_lo_off elements behind, 0 = none), fp32 [B][C]
+                  const void* Wl; long wl_lo_off;                             // 16-bit [C][C] ([n][k])
+                  const void* Kp; const void* VTp; int NkPad; int Nk; const int* kv_len; int kv_len_add; float scale;
+                  float* out; gnfix_t* stats; int B; };
+bool tv_chain_form(int npix, int C, int B);
+void launch_tv_kv_prep(const TvKvPrepP& p, int precision, hipStream_t st);
+void launch_tv_chain(const TvChainP& p, int precision, hipStream_t st);
 // transpose [B,C,L] -> [B, L(+row_off), C]
 void launch_transpose_cl(const float* src, float* dst, int B, int C, int L, int row_off, long dst_bstride, hipStream_t st);
 

@@ -35,6 +35,10 @@ void launch_conv_down(const ConvDownP& p, hipStream_t st);
 // softmax attention (attention_bf16.hip: fp32 q/k/v in HBM; attention_direct.hip: fragment-ordered operands)
 void launch_attention_lp(const AttnP& p, hipStream_t st);
 void launch_attention_direct(const AttnDirectP& p, hipStream_t st);
+// the DEX TV adaptor as one launch (attention_bf16.hip)
+bool tv_chain_form(int npix, int C, int B);
+void launch_tv_kv_prep(const TvKvPrepP& p, hipStream_t st);
+void launch_tv_chain(const TvChainP& p, hipStream_t st);
 bool attention_direct_batch_regime(int N, int B);
 int attention_direct_ksplit(int N, int B);
 // 64-queries-per-wave form (attention_q64.hip): 4 waves x 64 queries, persistent work units, up to max_split key splits

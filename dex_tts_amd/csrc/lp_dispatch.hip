@@ -31,6 +31,7 @@ bool igemm_nwalk_form(const IGemmP& p) { return (g_lp_wsplit ? f16w::igemm_nwalk
 bool conv3x3_cat_lp_in_supported(int H, int W, int B, int Cin, int Cout) { return (g_lp_wsplit ? f16w::conv3x3_cat_lp_in_supported(H, W, B, Cin, Cout) : bf16::conv3x3_cat_lp_in_supported(H, W, B, Cin, Cout)); }
 bool conv3x3_strip_form(const Conv3P& p) { return (g_lp_wsplit ? f16w::conv3x3_stream_tiles(p) : bf16::conv3x3_stream_tiles(p)) != 0 || (g_lp_wsplit ? f16w::conv3x3_regw_form(p) : bf16::conv3x3_regw_form(p)); }
 bool pos_conv_direct_supported(int hid, int groups, int kernel, int Hf) { return (g_lp_wsplit ? f16w::pos_conv_direct_supported(hid, groups, kernel, Hf) : bf16::pos_conv_direct_supported(hid, groups, kernel, Hf)); }
+bool tv_chain_form(int npix, int C, int B) { return (g_lp_wsplit ? f16w::tv_chain_form(npix, C, B) : bf16::tv_chain_form(npix, C, B)); }
 bool attention_direct_batch_regime(int N, int B) { return (g_lp_wsplit ? f16w::attention_direct_batch_regime(N, B) : bf16::attention_direct_batch_regime(N, B)); }
 int attention_direct_ksplit(int N, int B) { return (g_lp_wsplit ? f16w::attention_direct_ksplit(N, B) : bf16::attention_direct_ksplit(N, B)); }
 int attention_q64_ksplit(int N, int B, int max_split) { return (g_lp_wsplit ? f16w::attention_q64_ksplit(N, B, max_split) : bf16::attention_q64_ksplit(N, B, max_split)); }
@@ -51,6 +52,8 @@ void launch_igemm_lp(const IGemmP& p, int precision, hipStream_t st) { DEX_LP_CA
 void launch_convt_up(const ConvTUpP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_convt_up, p, st); }
 void launch_conv_down(const ConvDownP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_conv_down, p, st); }
 void launch_attention_lp(const AttnP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_attention_lp, p, st); }
+void launch_tv_kv_prep(const TvKvPrepP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_tv_kv_prep, p, st); }
+void launch_tv_chain(const TvChainP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_tv_chain, p, st); }
 void launch_attention_direct(const AttnDirectP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_attention_direct, p, st); }
 void launch_attention_q64(const AttnDirectP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_attention_q64, p, st); }
 void launch_dit_rowchain(const DitChainP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_dit_rowchain, p, st); }

@@ -370,3 +370,45 @@ def test_cfg2_attention_tail_split_vs_oracle_and_vs_whole_units(prec):
     record(f"cfg2_dex_b32_n4_tail_vs_default:{prec}:sampler", max=d.max(), mean=d.mean())
     mx, mn = __import__("tests.tolerances", fromlist=["x"]).lowp_bounds("cfg2_dex_b32_n4", prec, "sampler")
     assert d.max() <= mx and d.mean() <= mn and d.max() > 0.0
+
+
+# measured |tap - oracle tap|max / |tap|max of the "tv" / "tiv" taps in the mode (profiles/round5_parity_measured.jsonl), x2
+TV_TAP_REL = {"bf16": {"tv": 2.1e-2, "tiv": 4.5e-2}, "fp16": {"tv": 2.5e-3, "tiv": 6.0e-3}, "fp16x2": {"tv": 2.5e-3, "tiv": 6.0e-3}}
+
+
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "fp16x2"])
+@pytest.mark.parametrize("name,kw", [
+    ("dex_vctk", dict(B=2, T=52, lengths=[52, 31], Tr=37, Ts=65, sty_lengths=[65, 9])),       # 1040 pixels: 8 full workgroups + 16 rows; two key tiles, ragged key counts
+    ("dex_vctk", dict(B=3, T=256, lengths=[256, 199, 64], Tr=60, Ts=348, sty_lengths=[348, 120, 63])),   # configs[2]'s key count: six key tiles, 349 / 121 / 64 keys
+])
+def test_tv_adaptor_one_launch_vs_oracle_taps_and_vs_three_launches(name, kw, prec):
+    """The TV adaptor as one launch (tv_chain_kernel: q projection -> attention over the style keys -> output projection + residual +
+    mask + the TIV adaptor's statistics, DEX_TV_CHAIN=2 forces it below the batch regime) against the oracle's "tv" / "tiv" taps and
+    the call's result, and against the three separate launches (DEX_TV_CHAIN=0): the same roundings (x, q / sqrt(C), P, O in the
+    operand type), different summation orders."""
+    cfg, eng, w = U.engine_for(name)
+    case = U.make_case(cfg, **kw)
+    set_prec(eng, prec)
+    res, ran = {}, {}
+    eng.profile(True)
+    try:
+        for flag in ("0", "2"):
+            os.environ["DEX_TV_CHAIN"] = flag
+            got, ref, terr = U.run_precond(name, case, 0.7)
+            ran[flag] = any("tv_chain" in r["name"] for r in eng.profile_rows())
+            res[flag] = (got, ref, terr, {k: v.cpu().numpy() for k, v in eng.taps().items() if k in ("tv", "tiv")})
+    finally:
+        eng.profile(False)
+        os.environ.pop("DEX_TV_CHAIN", None)
+        eng.set_precision("fp32")
+    assert ran == {"0": False, "2": True}, ran              # (the two forms did run: their results can agree to the bit)
+    tag = f"tv_chain_{name}_B{kw['B']}_T{kw['T']}"
+    for flag, (got, ref, terr, _) in res.items():
+        for k in ("tv", "tiv"):
+            err, mag = terr[k]
+            U.record(f"{tag}_chain{flag}:{prec}:tap_{k}", max=err, ref_absmax=mag)
+            assert err <= TV_TAP_REL[prec][k] * max(1.0, mag), (flag, k, err, mag)
+        check_lowp(f"{tag}_chain{flag}", prec, "call", got, ref)
+    d = {k: float(np.abs(res["0"][3][k] - res["2"][3][k]).max()) for k in ("tv", "tiv")}
+    U.record(f"{tag}_chain_vs_separate:{prec}", tv=d["tv"], tiv=d["tiv"])
+    assert d["tv"] <= 0.25 * TV_TAP_REL[prec]["tv"] * max(1.0, res["0"][2]["tv"][1])      # (measured: 0.02 of it)
