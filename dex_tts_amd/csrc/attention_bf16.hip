@@ -396,6 +396,80 @@ constexpr int TVC_U16 = 2 * TVC_KBUF + 2 * TVC_VBUF;            // 35840 u16 = 7
 constexpr int TVC_SLD = 68;                                     // floats per pixel of the output stage (64 channels + 4: conflict-free 16 B accesses)
 static_assert(2 * 128 * K_LD <= TVC_U16 && 128 * K_LD * 2 + 128 * TVC_SLD * 4 <= TVC_U16 * 2, "aliases fit the rings");
 
+// One tile of 64 style keys for a wave's 32 pixels: attn_tile's products in attn_tile's order with less VALU work around them - the
+// softmax is the instruction stream that bounds this kernel (32 MFMAs against ~340 VALU instructions per tile in attn_tile):
+//   * key masking (compare + select per score) only in the tile that holds keys >= Nk;
+//   * exp(s - m) as ONE fma into the exp2 domain + v_exp_f32 (m2 = m * log2 e per lane);
+//   * LAZY rescaling: the reference maximum m moves - and the 64 accumulator multiplies run - only when some pixel's tile maximum
+//     exceeds it by more than TVC_TAU; until then P = exp(s - m) is formed against the old m (<= e^TAU, no overflow in either operand
+//     type), which is the same softmax once O is divided by the l accumulated against the same m.
+constexpr float TVC_TAU = 6.f, TVC_LOG2E = 1.4426950408889634f;
+__device__ __forceinline__ void tvc_tile(const u16* kS, const u16* vT, const Frag (&qf)[8], f32x16 (&o)[4], float& m_run, float& l_run, int k0, int Nk, int lane) {
+    constexpr int KT = TVC_KT, V_LD = TVC_VLD, NS = KT / 32;
+    const int i = lane & 31, hh = lane >> 5;
+    f32x16 s[NS];
+#pragma unroll
+    for (int st = 0; st < NS; ++st) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[st][r] = 0.f;
+        const u16* ka = kS + (st * 32 + i) * K_LD + hh * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            Frag a; a.u = *reinterpret_cast<const uint4*>(ka + ks * 16);
+            s[st] = DEX_MFMA_LP(a.v, qf[ks].v, s[st], 0, 0, 0);
+        }
+    }
+    if (k0 + KT > Nk) {                                                     // (uniform) the tile that holds keys >= Nk
+#pragma unroll
+        for (int st = 0; st < NS; ++st)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (key >= Nk) s[st][r] = -INFINITY;
+            }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int st = 0; st < NS; ++st)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[st][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (__builtin_amdgcn_ballot_w64(mx > m_run + TVC_TAU) != 0) {          // (uniform) some pixel's maximum moved: new reference for every pixel
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        l_run *= alpha;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+    }
+    const float m2 = -m_run * TVC_LOG2E;
+    float psum = 0.f;
+#pragma unroll
+    for (int st = 0; st < NS; ++st)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[st][r] = __builtin_amdgcn_exp2f(fmaf(s[st][r], TVC_LOG2E, m2)); psum += s[st][r]; }
+    l_run += psum;
+    // (software-pipelining the fragment reads one MFMA chain ahead with sched_group_barrier pairs was measured and is slower:
+    // 108.5 against 99.9 us per launch at B = 32 - the tile is bound by LDS bandwidth and VALU issue at two waves per SIMD, not by
+    // exposed read latency)
+#pragma unroll
+    for (int st = 0; st < NS; ++st)
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            Frag pb;
+            pb.u.x = pack2_lp_asm(s[st][8 * k2 + 0], s[st][8 * k2 + 1]); pb.u.y = pack2_lp_asm(s[st][8 * k2 + 2], s[st][8 * k2 + 3]);
+            pb.u.z = pack2_lp_asm(s[st][8 * k2 + 4], s[st][8 * k2 + 5]); pb.u.w = pack2_lp_asm(s[st][8 * k2 + 6], s[st][8 * k2 + 7]);
+            const u16* va = vT + i * V_LD + (st * 2 + k2) * 16 + hh * 8;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                Frag a; a.u = *reinterpret_cast<const uint4*>(va + t * 32 * V_LD);
+                o[t] = DEX_MFMA_LP(a.v, pb.v, o[t], 0, 0, 0);
+            }
+        }
+}
+
 __global__ __launch_bounds__(256) void tv_kv_prep_kernel(const TvKvPrepP p) {
     const long nk = (long)p.B * p.NkPad * (AHD / 8);             // K chunks: 8 positions of one key
     const long nv = (long)p.B * (p.NkPad / 8) * AHD;             // V chunks: 8 key positions of one channel (channel fastest: coalesced reads)
@@ -426,6 +500,9 @@ __global__ __launch_bounds__(256) void tv_kv_prep_kernel(const TvKvPrepP p) {
     }
 }
 
+#ifndef TVC_SKIP
+#define TVC_SKIP 0             // tools/tvchainbench: phases left out (anatomy builds; results are wrong): 1 attention tiles, 2 result I/O, 4 x loads
+#endif
 __global__ __launch_bounds__(256, 2) void tv_chain_kernel(const TvChainP p) {
     extern __shared__ __attribute__((aligned(16))) u16 smem_b[];
     __shared__ long long red[2 * AHD];
@@ -434,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void tv_chain_kernel(const TvChainP p) {
     const int b = blockIdx.y, row0 = blockIdx.x * 128;
     int Nk = p.Nk;
     if (p.kv_len) Nk = min(p.Nk, p.kv_len[b] + p.kv_len_add);
-    const int ntiles = (Nk + TVC_KT - 1) / TVC_KT;
+    const int ntiles = (TVC_SKIP & 1) ? 0 : (Nk + TVC_KT - 1) / TVC_KT;
     const float* Xb = p.X + (long)b * p.x_bstride + p.x_coff;
     const float* mrow = p.mask + (long)b * p.mask_bstride;
     const u16* Wg = reinterpret_cast<const u16*>(p.Weff) + (long)b * AHD * AHD;
@@ -480,7 +557,7 @@ __global__ __launch_bounds__(256, 2) void tv_chain_kernel(const TvChainP p) {
                 const int pix = row0 + (id >> 5);
                 const bool ok = pix < p.npix;
                 const int pc = ok ? pix : p.npix - 1;
-                xa[j] = *reinterpret_cast<const float4*>(Xb + (long)pc * p.ldx + (id & 31) * 4);
+                xa[j] = (TVC_SKIP & 4) ? make_float4(1.f, 2.f, 3.f, 4.f) : *reinterpret_cast<const float4*>(Xb + (long)pc * p.ldx + (id & 31) * 4);
                 const float mv = mrow[(pc % p.Wm) * p.mask_ws];
                 mk[j] = ok ? mv : 0.f;
             }
@@ -497,6 +574,17 @@ __global__ __launch_bounds__(256, 2) void tv_chain_kernel(const TvChainP p) {
         }
     }
     if (ntiles > 0) kv_load(0);              // first K / V tile in flight under the q projection
+    float4 bq[4][2][2];                      // b_eff of this lane's accumulator rows: requested before the barrier, back by the end of the first MFMA chain
+    {
+        const float* be = p.beff + (long)b * AHD;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                bq[t][k2][0] = *reinterpret_cast<const float4*>(be + t * 32 + 16 * k2 + 4 * hh);
+                bq[t][k2][1] = *reinterpret_cast<const float4*>(be + t * 32 + 16 * k2 + 8 + 4 * hh);
+            }
+    }
     __syncthreads();
 
     // ---- q^T = W_eff x^T (+ b_eff), scaled, rounded: the B operand of the score MFMAs
@@ -505,7 +593,6 @@ __global__ __launch_bounds__(256, 2) void tv_chain_kernel(const TvChainP p) {
         Frag xf[8];
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) xf[ks].u = *reinterpret_cast<const uint4*>(Xs + (wave * 32 + i) * K_LD + ks * 16 + hh * 8);
-        const float* be = p.beff + (long)b * AHD;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             f32x16 acc;
@@ -528,8 +615,7 @@ __global__ __launch_bounds__(256, 2) void tv_chain_kernel(const TvChainP p) {
 #endif
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) {
-                const float4 b0 = *reinterpret_cast<const float4*>(be + t * 32 + 16 * k2 + 4 * hh);
-                const float4 b1 = *reinterpret_cast<const float4*>(be + t * 32 + 16 * k2 + 8 + 4 * hh);
+                const float4 b0 = bq[t][k2][0], b1 = bq[t][k2][1];
                 const float sc = p.scale;
                 Frag& q = qf[2 * t + k2];
                 q.u.x = pack2_lp((acc[8 * k2 + 0] + b0.x) * sc, (acc[8 * k2 + 1] + b0.y) * sc);
@@ -549,12 +635,30 @@ __global__ __launch_bounds__(256, 2) void tv_chain_kernel(const TvChainP p) {
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     if (ntiles > 0) kv_store(0);
-    for (int kt = 0; kt < ntiles; ++kt) {
+    // (W_l's 32 KB are requested under the last tile, in the registers the K / V prefetch no longer needs)
+    const u16* Wl = reinterpret_cast<const u16*>(p.Wl);
+    uint2 la[8], lb[8];
+    auto wl_load = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int id = tid + 256 * j;
+            const int n = id >> 4, c = id & 15, d0 = 16 * (c >> 1) + 4 * (c & 1);
+            la[j] = *reinterpret_cast<const uint2*>(Wl + n * AHD + d0);
+            lb[j] = *reinterpret_cast<const uint2*>(Wl + n * AHD + d0 + 8);
+        }
+    };
+    for (int kt = 0; kt + 1 < ntiles; ++kt) {
         __syncthreads();                     // tile kt visible; buffer (kt + 1) & 1 free
         const int cur = kt & 1;
-        if (kt + 1 < ntiles) kv_load(kt + 1);
-        attn_tile<TVC_KT>(smem_b + cur * TVC_KBUF, smem_b + 2 * TVC_KBUF + cur * TVC_VBUF, qf, o, m_run, l_run, kt * TVC_KT, Nk, lane);
-        if (kt + 1 < ntiles) kv_store(cur ^ 1);
+        kv_load(kt + 1);
+        tvc_tile(smem_b + cur * TVC_KBUF, smem_b + 2 * TVC_KBUF + cur * TVC_VBUF, qf, o, m_run, l_run, kt * TVC_KT, Nk, lane);
+        kv_store(cur ^ 1);
+    }
+    __syncthreads();
+    wl_load();
+    if (ntiles > 0) {
+        const int kt = ntiles - 1, cur = kt & 1;
+        tvc_tile(smem_b + cur * TVC_KBUF, smem_b + 2 * TVC_KBUF + cur * TVC_VBUF, qf, o, m_run, l_run, kt * TVC_KT, Nk, lane);
     }
     l_run += __shfl_xor(l_run, 32);
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
@@ -563,16 +667,7 @@ __global__ __launch_bounds__(256, 2) void tv_chain_kernel(const TvChainP p) {
     // ---- out^T = W_l O^T: W_l with the columns of every 16-group in accumulator order
     u16* Ls = smem_b;                        // [128 n][K_LD]
     float* stage = reinterpret_cast<float*>(smem_b + 128 * K_LD);          // [128 pixels][TVC_SLD]
-    const u16* Wl = reinterpret_cast<const u16*>(p.Wl);
     {
-        uint2 la[8], lb[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int id = tid + 256 * j;
-            const int n = id >> 4, c = id & 15, d0 = 16 * (c >> 1) + 4 * (c & 1);
-            la[j] = *reinterpret_cast<const uint2*>(Wl + n * AHD + d0);
-            lb[j] = *reinterpret_cast<const uint2*>(Wl + n * AHD + d0 + 8);
-        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int id = tid + 256 * j;
@@ -635,7 +730,7 @@ __global__ __launch_bounds__(256, 2) void tv_chain_kernel(const TvChainP p) {
             const int pix = row0 + wave * 32 + px;
             const bool ok = pix < p.npix;
             const int pc = ok ? pix : p.npix - 1;
-            rv[j] = *reinterpret_cast<const float4*>(Xb + (long)pc * p.ldx + h * 64 + c4);
+            rv[j] = (TVC_SKIP & 2) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(Xb + (long)pc * p.ldx + h * 64 + c4);
             const float mv = mrow[(pc % p.Wm) * p.mask_ws];
             mk[j] = ok ? mv : 0.f;
             sv[j] = *reinterpret_cast<const float4*>(myst + px * TVC_SLD + c4);
@@ -649,7 +744,7 @@ __global__ __launch_bounds__(256, 2) void tv_chain_kernel(const TvChainP p) {
             v.x = (sv[j].x + rv[j].x) * mk[j]; v.y = (sv[j].y + rv[j].y) * mk[j];
             v.z = (sv[j].z + rv[j].z) * mk[j]; v.w = (sv[j].w + rv[j].w) * mk[j];
             if (pix < p.npix) {
-                *reinterpret_cast<float4*>(p.out + ((long)b * p.npix + pix) * AHD + h * 64 + c4) = v;
+                if (!(TVC_SKIP & 2) || v.x == 12345.f) *reinterpret_cast<float4*>(p.out + ((long)b * p.npix + pix) * AHD + h * 64 + c4) = v;
                 gs[h][0] += v.x; gs[h][1] += v.y; gs[h][2] += v.z; gs[h][3] += v.w;
                 gq[h][0] = fmaf(v.x, v.x, gq[h][0]); gq[h][1] = fmaf(v.y, v.y, gq[h][1]);
                 gq[h][2] = fmaf(v.z, v.z, gq[h][2]); gq[h][3] = fmaf(v.w, v.w, gq[h][3]);

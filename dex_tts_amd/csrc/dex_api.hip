@@ -1319,6 +1319,10 @@ struct Runner {
         gemm("dit_final_unpatchify", fl);
     }
 
+    // the TV adaptor runs as one launch (attention_bf16.hip tv_chain_kernel)
+    bool tv_chain_on() const {
+        return x->lp() && x->lp_of().count(x->tv_wl) && P.tv_kp && tv_chain_form(P.Hm * P.Wm, mid_dim(x->cfg), P.d.B);
+    }
     // TVAdaptor + TIVAdaptor (ref_encoder.py:154-179,264-273); X is the (unmasked) bottleneck view.
     void dex_adaptors(const TD& X, int mask_ws) {
         const DexConfig& c = x->cfg;
@@ -1335,17 +1339,16 @@ struct Runner {
         IGemmP q = base_gemm(X.p, X.ld, X.coff, P.Hm, P.Wm, mid, P.tv_weff, mid, P.tv_beff, P.tv_q, mid, 0);
         q.w_bstride = (long)mid * mid; q.bias_bstride = mid; q.inmask = mask; q.inmask_ws = mask_ws;
         if (qbf) { q.Wbf = P.tv_wbf; q.w_lo_off = fo.split ? (long)B * mid * mid : 0; }
-        const bool chain = qbf && x->lp_of().count(x->tv_wl) && P.tv_kp && tv_chain_form((int)npix, mid, B);
+        const bool chain = tv_chain_on();
         if (!chain) gemm("tv_q", q);
         TvRow0P r0{P.tv_k0, P.tv_v0, sp, P.tv_K, P.tv_V, (long)(P.d.Ts + 1) * mid, mid, B, reinterpret_cast<float*>(P.tv_stats),
                    (long)B * mid * IN_SLOTS * 2 * 2 * (long)(sizeof(gnfix_t) / sizeof(float))};
+        if (chain) { r0.Kp = P.tv_kp; r0.VTp = P.tv_vtp; r0.NkPad = P.tv_nkpad; r0.lp_kind = x->lp_kind(); }
         run("tv_time_token", 0, 8.0 * mid * B, [&] { launch_tv_row0(r0, st); });
         // Batch regime, reduced-precision modes: q projection, attention, output projection, residual, mask and the TIV statistics as
         // ONE launch per 128 pixels (attention_bf16.hip tv_chain_kernel; DEX_TV_CHAIN=0: the three launches below).  q and the
-        // attention output never reach HBM; the keys / values become 16-bit operands once per step.
+        // attention output never reach HBM; the style keys / values become 16-bit operands once per call (prepare()), the time token's row per step.
         if (chain) {
-            TvKvPrepP kp{P.tv_K, P.tv_V, (long)(P.d.Ts + 1) * mid, P.d.Ts + 1, P.tv_nkpad, P.tv_kp, P.tv_vtp, B};
-            run("tv_kv_operands", 0, 12.0 * B * (P.d.Ts + 1) * mid, [&] { launch_tv_kv_prep(kp, x->precision, st); });
             const void* wl = x->lp_of().at(x->tv_wl);
             TvChainP tc{X.p, X.ld, X.coff, npix * X.ld, (int)npix, P.Wm, mask, mask_ws, (long)P.d.T,
                         P.tv_wbf, fo.split ? (long)B * mid * mid : 0L, P.tv_beff, wl, x->lo_off(wl),
@@ -1581,6 +1584,10 @@ struct Runner {
                 IGemmP g = base_gemm(P.tv_keys, mid, 0, 1, args->Ts, mid, which ? x->tv_wv : x->tv_wk, mid, nullptr, dst + mid, mid, 0);
                 g.c_bstride = (long)(args->Ts + 1) * mid;
                 gemm("tv_kv", g);
+            }
+            if (tv_chain_on()) {       // ... and their 16-bit operand forms (row 0, the time token, is rewritten every step: launch_tv_row0)
+                TvKvPrepP kp{P.tv_K, P.tv_V, (long)(args->Ts + 1) * mid, args->Ts + 1, P.tv_nkpad, P.tv_kp, P.tv_vtp, B};
+                run("tv_kv_operands", 0, 12.0 * B * (args->Ts + 1) * mid, [&] { launch_tv_kv_prep(kp, x->precision, st); });
             }
         }
     }

@@ -260,8 +260,14 @@ __global__ void tv_row0_kernel(const TvRow0P p) {
     const int step = p.step;
     if (p.zero_ptr) for (long i = (long)b * blockDim.x + c; i < p.zero_n; i += (long)gridDim.x * blockDim.x) p.zero_ptr[i] = 0.f;
     if (c < p.C) {
-        p.K[(long)b * p.kvb + c] = p.k0[(long)step * p.C + c];
-        p.V[(long)b * p.kvb + c] = p.v0[(long)step * p.C + c];
+        const float kv = p.k0[(long)step * p.C + c], vv = p.v0[(long)step * p.C + c];
+        p.K[(long)b * p.kvb + c] = kv;
+        p.V[(long)b * p.kvb + c] = vv;
+        if (p.Kp) {        // the time token's row of the 16-bit operands (the style rows are converted once per call: launch_tv_kv_prep)
+            const int pos = (c & ~12) | ((c & 4) << 1) | ((c & 8) >> 1);          // channel c sits at position pos of its 16-group (accumulator order)
+            reinterpret_cast<unsigned short*>(p.Kp)[(long)b * p.NkPad * p.C + pos] = (unsigned short)(pack2_kind(kv, 0.f, p.lp_kind) & 0xffffu);
+            reinterpret_cast<unsigned short*>(p.VTp)[((long)b * p.C + c) * p.NkPad] = (unsigned short)(pack2_kind(vv, 0.f, p.lp_kind) & 0xffffu);
+        }
     }
 }
 void launch_tv_row0(const TvRow0P& p, hipStream_t st) {

@@ -381,7 +381,8 @@ struct TivApplyP { const float* X; int ld; long xb; float* Y; int ldy; long yb; 
 void launch_tiv_apply(const TivApplyP& p, hipStream_t st);
 // write per-step time-token rows into K/V row 0 (ref_encoder.py:157)
 struct TvRow0P { const float* k0; const float* v0; int step; float* K; float* V; long kvb; int C; int B;
-                 float* zero_ptr; long zero_n; };          // optional: clear the IN2d statistics for their next use
+                 float* zero_ptr; long zero_n;             // optional: clear the IN2d statistics for their next use
+                 void* Kp = nullptr; void* VTp = nullptr; int NkPad = 0; int lp_kind = 0; };   // optional: row 0 of the one-launch adaptor's 16-bit operands too (TvKvPrepP layouts, C = 128)
 void launch_tv_row0(const TvRow0P& p, hipStream_t st);
 // The TV adaptor as ONE launch in the batch regime (attention_bf16.hip, reduced-precision modes; ref_encoder.py:154-179):
 //   out = mask * (x + linear(softmax((IN2d(x) W_q^T / sqrt(C)) K^T) V))   with the InstanceNorm folded into a per-utterance W_eff, b_eff
