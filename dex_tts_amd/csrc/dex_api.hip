@@ -32,7 +32,7 @@ const char* const KNOB_NAMES[] = {
     // launcher heuristics (workgroup caps, shape thresholds, form switches) - process-static getenv reads until round 4
     "DEX_ATTN_SHARED_W8", "DEX_CONVT_MT", "DEX_CONVT_WGS", "DEX_CONV_DOWN_WGS", "DEX_CONV_REGW", "DEX_CONV_REGW_RES", "DEX_CONV_SMALL_MAX", "DEX_CONV_TH8",
     "DEX_CONV_W8", "DEX_DWCONV_CAP", "DEX_FINAL_CAP", "DEX_FIRST_CAP", "DEX_FIRST_MFMA", "DEX_GEMM_NWALK", "DEX_NWALK_SPLIT", "DEX_POS_COL", "DEX_POS_COL_MIN",
-    "DEX_POS_CT", "DEX_REGW_MIN_TILES", "DEX_REGW_WGS", "DEX_ROWCHAIN64", "DEX_ROWCHAIN64A", "DEX_TIV_CAP", "DEX_TV_CHAIN"};
+    "DEX_POS_CT", "DEX_REGW_MIN_TILES", "DEX_REGW_WGS", "DEX_ROWCHAIN64", "DEX_ROWCHAIN64A", "DEX_TIV_CAP", "DEX_TV_CHAIN", "DEX_TIV_FOLD"};
 constexpr int N_KNOBS = (int)(sizeof(KNOB_NAMES) / sizeof(KNOB_NAMES[0]));
 // value of one variable: a decimal integer; unset, empty or without digits ("true", "on") = KNOB_UNSET, so a typo leaves the default
 // form on instead of silently switching it off
@@ -683,6 +683,7 @@ struct Plan {
     void *qh, *kh, *vt, *qh2, *kh2, *vt2; int Npad; size_t vt_bytes;   // bf16 attention operands of the row-chain path (two sets:
                                                                         // a fused block reads one while its workgroups write the other)
     float *tv_keys, *tv_K, *tv_V, *tv_q, *tv_ao, *tv_out, *tiv_out, *tv_weff, *tv_beff; gnfix_t *tv_stats, *tiv_stats; void* tv_wbf;
+    float* tiv_aff;                            // TIV adaptor folded into the patch embedding's load: [B][2][mid] coefficients (launch_tiv_coef)
     void *tv_kp, *tv_vtp; int tv_nkpad;        // the one-launch TV adaptor's 16-bit key / value operands (TvKvPrepP)
     size_t bytes;
 };
@@ -844,6 +845,7 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
     P.tv_keys = P.tv_K = P.tv_V = P.tv_q = P.tv_ao = P.tv_out = P.tiv_out = P.tv_weff = P.tv_beff = nullptr; P.tv_wbf = nullptr;
     P.tv_stats = P.tiv_stats = nullptr;
     P.tv_kp = P.tv_vtp = nullptr; P.tv_nkpad = 0;
+    P.tiv_aff = nullptr;
     if (c.variant == DEX_VARIANT_DEX) {
         const size_t pm = (size_t)B * P.Hm * P.Wm;
         P.tv_keys = A.f((size_t)B * d.Ts * mid); P.tv_K = A.f((size_t)B * (d.Ts + 1) * mid); P.tv_V = A.f((size_t)B * (d.Ts + 1) * mid);
@@ -851,6 +853,7 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
         P.tv_weff = A.f((size_t)B * mid * mid); P.tv_beff = A.f((size_t)B * mid);
         P.tv_wbf = A.take((size_t)B * mid * mid * 2 * 2);          // (x2: the lo halves of the split-weight mode behind the hi ones)
         P.tv_nkpad = (d.Ts + 1 + 63) / 64 * 64;
+        P.tiv_aff = A.f((size_t)B * 2 * mid);
         P.tv_kp = A.take((size_t)B * P.tv_nkpad * mid * 2); P.tv_vtp = A.take((size_t)B * P.tv_nkpad * mid * 2);
         P.tv_stats = (gnfix_t*)A.take((size_t)B * mid * IN_SLOTS * 2 * 2 * sizeof(gnfix_t));   // IN2d partials of the TV input and the TIV input
         P.tiv_stats = A.dry ? nullptr : P.tv_stats + (size_t)B * mid * IN_SLOTS * 2;
@@ -1124,16 +1127,16 @@ struct Runner {
     }
 
     // DiTMask.forward (dit.py:485-525): X = bottleneck input view; writes [B,Hm,Wm,mid] into (out, ldo, ocoff)
-    void dit(const TD& X, bool mask_input, int mask_ws, float* out, int ldo, int ocoff) {
+    void dit(const TD& X, bool mask_input, int mask_ws, float* out, int ldo, int ocoff, const float* in_aff = nullptr) {
         const DexConfig& c = x->cfg;
         const int B = P.d.B, hid = c.dit_hidden, mid = mid_dim(c), N = P.N, mh = mlp_hidden(c);
         DwConvP dw{};
         dw.X = X.p + X.coff; dw.ldx = X.ld; dw.xb = (long)P.Hm * P.Wm * X.ld; dw.Hi = P.Hm; dw.Wi = P.Wm; dw.C = mid;
         dw.k = c.dit_patch; dw.s = c.dit_stride; dw.pad = c.dit_patch / 2; dw.Wd = x->pe_dw; dw.bd = x->pe_db;
         dw.mask = mask_input ? mask : nullptr; dw.mask_ws = mask_ws; dw.mask_bstride = P.d.T;
-        dw.Y = P.pe0; dw.Hf = P.Hf; dw.Wt = P.Wt; dw.B = B;
+        dw.Y = P.pe0; dw.Hf = P.Hf; dw.Wt = P.Wt; dw.B = B; dw.aff = in_aff;
         auto pw_lp = x->lp_of().find(x->pe_pw);
-        if (x->lp() && !debug && !knob_off("DEX_PATCH_FUSED") && pw_lp != x->lp_of().end() && patch_embed_fused_supported(c.dit_patch, mid, hid, (long)B * N)) {
+        if (patch_fused()) {
             // small grids: depthwise conv + SiLU + pointwise GEMM in ONE launch (bit-identical to the two-kernel form below)
             run("patch_embed", 2.0 * B * N * mid * (c.dit_patch * c.dit_patch + hid), 4.0 * B * (P.Hm * P.Wm * mid + N * hid),
                 [&] { launch_patch_embed_fused(dw, pw_lp->second, x->pe_pb, P.emb, hid, x->precision, st); });
@@ -1319,6 +1322,16 @@ struct Runner {
         gemm("dit_final_unpatchify", fl);
     }
 
+    // PatchEmbed2D runs as one launch (patch_embed.hip; small grids)
+    bool patch_fused() const {
+        const DexConfig& c = x->cfg;
+        return x->lp() && !debug && !knob_off("DEX_PATCH_FUSED") && x->lp_of().count(x->pe_pw) &&
+               patch_embed_fused_supported(c.dit_patch, mid_dim(c), c.dit_hidden, (long)P.d.B * P.N);
+    }
+    // The TIV adaptor's y = IN2d(x) * s + m (ref_encoder.py:271) has ONE consumer, the patch embedding's depthwise convolution: outside
+    // debug calls (the "tiv" tap) it is applied there on load from per-channel coefficients (launch_tiv_coef: the same fmaf, the same
+    // bits) and the adaptor's output never goes to HBM and back (168 MB per step at B = 32).  DEX_TIV_FOLD=0: the separate launch.
+    bool tiv_fold() const { return !debug && P.tiv_aff && !patch_fused() && knob_or("DEX_TIV_FOLD", 1) != 0; }
     // the TV adaptor runs as one launch (attention_bf16.hip tv_chain_kernel)
     bool tv_chain_on() const {
         return x->lp() && x->lp_of().count(x->tv_wl) && P.tv_kp && tv_chain_form(P.Hm * P.Wm, mid_dim(x->cfg), P.d.B);
@@ -1357,9 +1370,7 @@ struct Runner {
             run("tv_chain", 4.0 * B * (double)npix * mid * mid + 4.0 * B * (double)npix * (P.d.Ts + 1) * mid, 8.0 * B * npix * mid,
                 [&] { launch_tv_chain(tc, x->precision, st); });
             tap("tv", P.tv_out, B * npix, mid, mid);
-            TivApplyP ta{P.tv_out, mid, npix * mid, P.tiv_out, mid, npix * mid, (int)npix, mid, P.tiv_stats, 1e-5f, P.sap_s, P.sap_m, sp, B};
-            run("tiv_adain", 2.0 * npix * mid * B, 8.0 * npix * mid * B, [&] { launch_tiv_apply(ta, st); });
-            tap("tiv", P.tiv_out, B * npix, mid, mid);
+            tiv(npix);
             return;
         }
         AttnP a{};
@@ -1380,7 +1391,12 @@ struct Runner {
         o.gn_stats = P.tiv_stats; o.gn_groups = mid; o.gn_cpg = 1; o.stats_final = 1;
         gemm("tv_out", o);
         tap("tv", P.tv_out, B * npix, mid, mid);
+        tiv(npix);
+    }
+    void tiv(long npix) {
+        const int B = P.d.B, mid = mid_dim(x->cfg);
         TivApplyP ta{P.tv_out, mid, npix * mid, P.tiv_out, mid, npix * mid, (int)npix, mid, P.tiv_stats, 1e-5f, P.sap_s, P.sap_m, sp, B};
+        if (tiv_fold()) { run("tiv_coefficients", 0, 16.0 * mid * B, [&] { launch_tiv_coef(ta, P.tiv_aff, st); }); return; }
         run("tiv_adain", 2.0 * npix * mid * B, 8.0 * npix * mid * B, [&] { launch_tiv_apply(ta, st); });
         tap("tiv", P.tiv_out, B * npix, mid, mid);
     }
@@ -1463,8 +1479,8 @@ struct Runner {
         const int dit_ld = 2 * sm.C;
         if (c.variant == DEX_VARIANT_DEX) {
             dex_adaptors(mid_in, sm.mask_ws);
-            TD t{P.tiv_out, sm.C, 0, sm.C};
-            dit(t, false, sm.mask_ws, dit_dst, dit_ld, 0);
+            TD t{tiv_fold() ? P.tv_out : P.tiv_out, sm.C, 0, sm.C};
+            dit(t, false, sm.mask_ws, dit_dst, dit_ld, 0, tiv_fold() ? P.tiv_aff : nullptr);
         } else {
             dit(mid_in, true, sm.mask_ws, dit_dst, dit_ld, 0);
         }

@@ -2,6 +2,7 @@
 // around the shared attention / GEMM kernels: instance-norm statistics, SAP pooling tables, IN2d folded
 // into w_q, AdaIN apply, time-token rows, layout transposes.
 #include "kernels.h"
+#include <algorithm>
 #include "bf16_util.h"
 
 namespace dex {
@@ -247,6 +248,20 @@ __global__ __launch_bounds__(256) void tiv_apply_kernel(const TivApplyP p) {
         *reinterpret_cast<float4*>(Y + px * p.ldy + c) = y;
     }
 }
+__global__ void tiv_coef_kernel(const TivApplyP p, float* aff) {
+    const int tid = threadIdx.x, b = blockIdx.x;
+    if (tid < p.C) {          // (the arithmetic of tiv_apply_kernel's prologue: the consumer's fmaf(x, a, c) gives tiv_apply's bits)
+        float mean, rstd;
+        in_mean_rstd(p.stats, (long)b * p.C + tid, p.npix, p.eps, mean, rstd);
+        const float s = p.s_tab[((long)p.step * p.B + b) * p.C + tid];
+        const float m = p.m_tab[((long)p.step * p.B + b) * p.C + tid];
+        aff[((long)b * 2 + 0) * p.C + tid] = rstd * s;
+        aff[((long)b * 2 + 1) * p.C + tid] = m - mean * rstd * s;
+    }
+}
+void launch_tiv_coef(const TivApplyP& p, float* aff, hipStream_t st) {
+    hipLaunchKernelGGL(tiv_coef_kernel, dim3(p.B), dim3(256), 0, st, p, aff);
+}
 void launch_tiv_apply(const TivApplyP& p, hipStream_t st) {
     const long total = (long)p.npix * (p.C / 4);
     long blocks = (total + 1023) / 1024; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
@@ -259,7 +274,7 @@ __global__ void tv_row0_kernel(const TvRow0P p) {
     const int b = blockIdx.x, c = threadIdx.x;
     const int step = p.step;
     if (p.zero_ptr) for (long i = (long)b * blockDim.x + c; i < p.zero_n; i += (long)gridDim.x * blockDim.x) p.zero_ptr[i] = 0.f;
-    if (c < p.C) {
+    if (b < p.B && c < p.C) {
         const float kv = p.k0[(long)step * p.C + c], vv = p.v0[(long)step * p.C + c];
         p.K[(long)b * p.kvb + c] = kv;
         p.V[(long)b * p.kvb + c] = vv;
@@ -271,7 +286,9 @@ __global__ void tv_row0_kernel(const TvRow0P p) {
     }
 }
 void launch_tv_row0(const TvRow0P& p, hipStream_t st) {
-    hipLaunchKernelGGL(tv_row0_kernel, dim3(p.B), dim3(256), 0, st, p);
+    // (the statistics it clears for their next use are 4 MB at B = 32: B workgroups took 7 us over them)
+    const long zb = p.zero_ptr ? (p.zero_n + 4095) / 4096 : 0;
+    hipLaunchKernelGGL(tv_row0_kernel, dim3((unsigned)std::max<long>(p.B, std::min<long>(zb, 1024))), dim3(256), 0, st, p);
 }
 
 __global__ void transpose_cl_kernel(const float* src, float* dst, int B, int C, int L, int row_off, long dst_bstride) {

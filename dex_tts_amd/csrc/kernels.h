@@ -245,7 +245,9 @@ bool linattn_fused_supported(int C);          // the fused linear attention exis
 // Depthwise patch-embed conv + SiLU (dit.py:57-58), channels-last, zero padding incl. right pad to patch multiple.
 struct DwConvP { const float* X; int ldx; long xb; int Hi, Wi, C; int k, s, pad; const float* Wd; const float* bd;
                  const float* mask; int mask_ws; long mask_bstride;
-                 float* Y; int Hf, Wt; int B; };
+                 float* Y; int Hf, Wt; int B;
+                 const float* aff = nullptr; };        // optional per-(utterance, channel) affine on the input, [B][2][C] (scale row, shift row): the DEX TIV
+                                                       // adaptor's y = IN2d(x) * s + m folded into the load (launch_tiv_coef) - zero padding applies to y
 void launch_dwconv_silu(const DwConvP& p, hipStream_t st);
 // the depthwise conv + SiLU + pointwise GEMM of PatchEmbed2D as ONE launch (reduced-precision modes, small grids: patch_embed.hip);
 // Wb = the pointwise weight's 16-bit [hidden][C] twin
@@ -379,6 +381,8 @@ void launch_in_fold(const InFoldP& p, hipStream_t st);
 struct TivApplyP { const float* X; int ld; long xb; float* Y; int ldy; long yb; int npix; int C; const gnfix_t* stats;
                    float eps; const float* s_tab; const float* m_tab; int step; int B; };
 void launch_tiv_apply(const TivApplyP& p, hipStream_t st);
+// the same transform as per-channel coefficients for a consumer that applies it on load: aff [B][2][C] (y = x * aff[b][0][c] + aff[b][1][c]; p.X / p.Y unused)
+void launch_tiv_coef(const TivApplyP& p, float* aff, hipStream_t st);
 // write per-step time-token rows into K/V row 0 (ref_encoder.py:157)
 struct TvRow0P { const float* k0; const float* v0; int step; float* K; float* V; long kvb; int C; int B;
                  float* zero_ptr; long zero_n;             // optional: clear the IN2d statistics for their next use

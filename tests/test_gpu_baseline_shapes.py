@@ -412,3 +412,26 @@ def test_tv_adaptor_one_launch_vs_oracle_taps_and_vs_three_launches(name, kw, pr
     d = {k: float(np.abs(res["0"][3][k] - res["2"][3][k]).max()) for k in ("tv", "tiv")}
     U.record(f"{tag}_chain_vs_separate:{prec}", tv=d["tv"], tiv=d["tiv"])
     assert d["tv"] <= 0.25 * TV_TAP_REL[prec]["tv"] * max(1.0, res["0"][2]["tv"][1])      # (measured: 0.02 of it)
+
+
+@pytest.mark.parametrize("prec,kw", [
+    ("fp32", dict(B=2, T=52, lengths=[52, 31], Tr=37, Ts=65, sty_lengths=[65, 9])),
+    ("bf16", dict(B=32, T=256, lengths=[256 - 3 * i for i in range(32)], Tr=60, Ts=60)),
+    ("fp16x2", dict(B=32, T=256, lengths=[256 - 3 * i for i in range(32)], Tr=60, Ts=60)),
+])
+def test_tiv_adaptor_folded_into_patch_embedding_is_bit_identical(prec, kw):
+    """The TIV adaptor's y = IN2d(x) * s + m applied by its one consumer on load (per-channel coefficients, launch_tiv_coef) against the
+    separate launch that writes y to HBM (DEX_TIV_FOLD=0): the same fmaf on the same values - a 4-step sampler agrees to the bit."""
+    cfg, eng, w = U.engine_for("dex_vctk")
+    case = U.make_case(cfg, **kw)
+    mu, mask, z = (torch.from_numpy(case[k]) for k in ("mu", "mask", "z"))
+    set_prec(eng, prec)
+    ys = {}
+    try:
+        for flag in ("0", "1"):
+            os.environ["DEX_TIV_FOLD"] = flag
+            ys[flag] = eng.sample(z, mask, mu, 4, **U.engine_kwargs(case)).cpu().numpy()
+    finally:
+        os.environ.pop("DEX_TIV_FOLD", None)
+        eng.set_precision("fp32")
+    assert np.isfinite(ys["1"]).all() and np.array_equal(ys["0"], ys["1"])
