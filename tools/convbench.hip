@@ -8,7 +8,10 @@
 #include "../dex_tts_amd/csrc/kernels_lp.h"      // reduced-precision launchers, bf16 build (namespace dex::bf16)
 using namespace dex;
 using namespace dex::bf16;
-namespace dex { thread_local const char* g_last_symbol = nullptr; }   // defined in lp_dispatch.hip in the library build
+namespace dex {
+thread_local const char* g_last_symbol = nullptr;                         // defined in lp_dispatch.hip in the library build
+int knob(const char* name) { const char* e = getenv(name); return e ? atoi(e) : KNOB_UNSET; }   // (dex_api.hip in the library build)
+}
 static float* dalloc(size_t n, int fill = 0) { float* p; hipMalloc(&p, n * 4); hipMemset(p, fill, n * 4); return p; }
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 32, H = 80, W = 512, C = 64;
