@@ -32,7 +32,7 @@ const char* const KNOB_NAMES[] = {
     // launcher heuristics (workgroup caps, shape thresholds, form switches) - process-static getenv reads until round 4
     "DEX_ATTN_SHARED_W8", "DEX_CONVT_MT", "DEX_CONVT_WGS", "DEX_CONV_DOWN_WGS", "DEX_CONV_REGW", "DEX_CONV_REGW_RES", "DEX_CONV_SMALL_MAX", "DEX_CONV_TH8",
     "DEX_CONV_W8", "DEX_DWCONV_CAP", "DEX_FINAL_CAP", "DEX_FIRST_CAP", "DEX_FIRST_MFMA", "DEX_GEMM_NWALK", "DEX_NWALK_SPLIT", "DEX_POS_COL", "DEX_POS_COL_MIN",
-    "DEX_POS_CT", "DEX_REGW_MIN_TILES", "DEX_REGW_WGS", "DEX_ROWCHAIN64", "DEX_ROWCHAIN64A", "DEX_TIV_CAP", "DEX_TV_CHAIN", "DEX_TIV_FOLD"};
+    "DEX_POS_CT", "DEX_REGW_MIN_TILES", "DEX_REGW_WGS", "DEX_ROWCHAIN64", "DEX_ROWCHAIN64A", "DEX_TIV_CAP", "DEX_TV_CHAIN", "DEX_TIV_FOLD", "DEX_LINATTN_NSUB"};
 constexpr int N_KNOBS = (int)(sizeof(KNOB_NAMES) / sizeof(KNOB_NAMES[0]));
 // value of one variable: a decimal integer; unset, empty or without digits ("true", "on") = KNOB_UNSET, so a typo leaves the default
 // form on instead of silently switching it off
@@ -1093,6 +1093,25 @@ struct Runner {
             int nsub = 1;
             // measured at 80x512, B=1: 320 / 160 / 80 workgroups -> context 19.9 / 13.7 / 19.4 us, merge 8.7 / 6.1 / 4.7 us
             while (nsub < 4 && (npix + 128 * nsub - 1) / (128 * nsub) * B > 192) nsub *= 2;
+            {
+                // Batch regime (round 5): the grid is several rounds of the chip's workgroup slots - two per CU at C = 64, ONE at C = 128
+                // (the context pass holds 256 + 73 registers there) - and powers of two land between rounds: DEX B = 32 ran 1 280 workgroups
+                // on 512 slots (2.5 rounds) at full resolution and 320 on 256 (1.25) at half.  Choose the sub-tile count that minimises
+                // rounds x sub-tiles; among equals the largest (fewer partials for the merge, fewer weight stagings).  DEX_LINATTN_NSUB forces one.
+                static int ncu = 0;
+                if (!ncu) { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); if (ncu <= 0) ncu = 256; }
+                const long slots = (long)(X.C == 64 ? 2 : 1) * ncu;
+                if ((npix + 127) / 128 * B >= 2 * slots) {
+                    long best = -1;
+                    for (int n = 1; n <= 8; ++n) {
+                        const long wgs = (npix + 128L * n - 1) / (128L * n) * B;
+                        const long cost = (wgs + slots - 1) / slots * n;
+                        if (best < 0 || cost <= best) { best = cost; nsub = n; }
+                    }
+                }
+                const int forced = knob_or("DEX_LINATTN_NSUB", 0);
+                if (forced > 0) nsub = forced;
+            }
             const int nblk = (int)((npix + 128L * nsub - 1) / (128L * nsub));
             LinKvCtxP k{};
             if (tail) k = *tail;
