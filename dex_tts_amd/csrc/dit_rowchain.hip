@@ -1567,7 +1567,11 @@ bool dit_rowchain64_form(int rows_per_batch, int B, int attn_inline) {
    
     const int m64 = knob_or("DEX_ROWCHAIN64", 1);
     const long wg32 = (long)B * ((rows_per_batch + RC_ROWS - 1) / RC_ROWS);
-    return m64 && !attn_inline && (m64 == 2 || wg32 >= 768);
+    bool small_n = false;
+#ifndef DEX_LP_WSPLIT
+    small_n = dit_sep64_small_n(rows_per_batch, B);       // (kernels.h: GeDEX B = 32)
+#endif
+    return m64 && !attn_inline && (m64 == 2 || wg32 >= 768 || small_n);
 }
 
 void launch_dit_rowchain(const DitChainP& p, hipStream_t st) {
