@@ -359,7 +359,7 @@ void launch_first_conv(const FirstConvP& p, hipStream_t st) {
     const int mfma = knob_or("DEX_FIRST_MFMA", 1);       // 0: the VALU form
     if (mfma) {
         long nb = (npu + 127) / 128;                               // 4 waves x 32 pixels per block pass
-        const long capm = knob_or("DEX_FIRST_CAP", 1024);   // measured at B=32: 8192 blocks 122 us, 4096 112, 2048 103, 1024 99
+        const long capm = knob_or("DEX_FIRST_CAP", p.B >= 8 ? 512 : 1024);   // measured at B=32: 8192 blocks 122 us, 4096 112, 2048 103, 1024 99; round 5: 1536 / 1024 / 512 = 97.5 / 91.7 / 89.1 (one round of the 512 slots)
         const long cm = capm / p.B > 16 ? capm / p.B : 16;
         if (nb > cm) nb = cm;
         const dim3 g2((unsigned)nb, p.B);
