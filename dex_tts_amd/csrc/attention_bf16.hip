@@ -772,10 +772,11 @@ __global__ __launch_bounds__(256, 2) void tv_chain_kernel(const TvChainP p) {
     }
 }
 
-// batch regime of the one-launch TV adaptor: enough 128-pixel workgroups for two rounds of the chip
+// The one-launch TV adaptor takes every grid: measured against the three launches (tools/tv_chain_small_batches.py, 10-step calls, bf16)
+// B = 1: +1.3 ... 3.5 % end to end (T = 128 ... 512), B = 2 ... 12: +2.4 ... 5.8 %, B = 32: +4.5 %.  DEX_TV_CHAIN=0: the three launches.
 bool tv_chain_form(int npix, int C, int B) {
-    const int k = knob_or("DEX_TV_CHAIN", 1);            // 0: the three separate launches, 2: this form at any size (tests)
-    return C == AHD && k != 0 && (k == 2 || (long)((npix + 127) / 128) * B >= 512);
+    (void)npix; (void)B;
+    return C == AHD && knob_or("DEX_TV_CHAIN", 1) != 0;
 }
 void launch_tv_kv_prep(const TvKvPrepP& p, hipStream_t st) {
     const long n = (long)p.B * p.NkPad * (AHD / 8) + (long)p.B * (p.NkPad / 8) * AHD;
