@@ -1348,9 +1348,9 @@ struct Runner {
                patch_embed_fused_supported(c.dit_patch, mid_dim(c), c.dit_hidden, (long)P.d.B * P.N);
     }
     // The TIV adaptor's y = IN2d(x) * s + m (ref_encoder.py:271) has ONE consumer, the patch embedding's depthwise convolution: outside
-    // debug calls (the "tiv" tap) it is applied there on load from per-channel coefficients (launch_tiv_coef: the same fmaf, the same
+    // debug calls (the "tiv" tap) it is applied there on load - in either form of the patch embedding - from per-channel coefficients (launch_tiv_coef: the same fmaf, the same
     // bits) and the adaptor's output never goes to HBM and back (168 MB per step at B = 32).  DEX_TIV_FOLD=0: the separate launch.
-    bool tiv_fold() const { return !debug && P.tiv_aff && !patch_fused() && knob_or("DEX_TIV_FOLD", 1) != 0; }
+    bool tiv_fold() const { return !debug && P.tiv_aff && knob_or("DEX_TIV_FOLD", 1) != 0; }
     // the TV adaptor runs as one launch (attention_bf16.hip tv_chain_kernel)
     bool tv_chain_on() const {
         return x->lp() && x->lp_of().count(x->tv_wl) && P.tv_kp && tv_chain_form(P.Hm * P.Wm, mid_dim(x->cfg), P.d.B);

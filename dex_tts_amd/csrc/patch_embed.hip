@@ -65,6 +65,9 @@ __global__ __launch_bounds__(256) void patch_embed_fused_kernel(const DwConvP p,
         const float* X = p.X + (long)b * p.xb;
         const float* mrow = p.mask ? p.mask + (long)b * p.mask_bstride : nullptr;
         float4 acc = *reinterpret_cast<const float4*>(p.bd + cq * 4);
+        // (DwConvP::aff: the DEX TIV adaptor's per-channel affine applied on load, as in dit_elem.hip)
+        const float4 a4 = p.aff ? *reinterpret_cast<const float4*>(p.aff + ((long)b * 2 + 0) * p.C + cq * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 c4 = p.aff ? *reinterpret_cast<const float4*>(p.aff + ((long)b * 2 + 1) * p.C + cq * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int kh = 0; kh < KS; ++kh) {
             const int hi = f * p.s + kh - p.pad;
@@ -73,7 +76,8 @@ __global__ __launch_bounds__(256) void patch_embed_fused_kernel(const DwConvP p,
                 const int wi = wt * p.s + kw - p.pad;
                 const bool inb = (unsigned)hi < (unsigned)p.Hi && (unsigned)wi < (unsigned)p.Wi;
                 const int hc = inb ? hi : 0, wc = inb ? wi : 0;              // clamped: loads are unconditional
-                const float4 v = *reinterpret_cast<const float4*>(X + ((long)hc * p.Wi + wc) * p.ldx + cq * 4);
+                float4 v = *reinterpret_cast<const float4*>(X + ((long)hc * p.Wi + wc) * p.ldx + cq * 4);
+                if (p.aff) { v.x = fmaf(v.x, a4.x, c4.x); v.y = fmaf(v.y, a4.y, c4.y); v.z = fmaf(v.z, a4.z, c4.z); v.w = fmaf(v.w, a4.w, c4.w); }
                 const float4 w = *reinterpret_cast<const float4*>(p.Wd + (kh * KS + kw) * p.C + cq * 4);
                 float mk = mrow ? mrow[wc * p.mask_ws] : 1.f;
                 mk = inb ? mk : 0.f;

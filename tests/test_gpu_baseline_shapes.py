@@ -416,6 +416,8 @@ def test_tv_adaptor_one_launch_vs_oracle_taps_and_vs_three_launches(name, kw, pr
 
 @pytest.mark.parametrize("prec,kw", [
     ("fp32", dict(B=2, T=52, lengths=[52, 31], Tr=37, Ts=65, sty_lengths=[65, 9])),
+    ("bf16", dict(B=2, T=52, lengths=[52, 31], Tr=37, Ts=65, sty_lengths=[65, 9])),          # small grid: the one-launch patch embedding applies it
+    ("fp16x2", dict(B=1, T=256, lengths=[256], Tr=60, Ts=60)),
     ("bf16", dict(B=32, T=256, lengths=[256 - 3 * i for i in range(32)], Tr=60, Ts=60)),
     ("fp16x2", dict(B=32, T=256, lengths=[256 - 3 * i for i in range(32)], Tr=60, Ts=60)),
 ])
