@@ -577,7 +577,9 @@ static bool nwalk_eligible(const IGemmP& p) {
     // small grids too (round 4): with one column tile per workgroup (nsplit = N / 64 below) the walker is the single-shot kernel with
     // the cheap unpatchify scatter - row-only terms once instead of two divisions and a 64-bit address per element: 14.3 -> 12 us at
     // B = 1, +0.4 % end to end
-    return p.N / 64 >= 8 && (mode == 2 || wgs >= 256 || wgs <= 16);
+    // (round 5: the grids in between as well - the long form's 79 row tiles ran the single-shot kernel at 73 us, the walker takes 31)
+    (void)wgs;
+    return p.N / 64 >= 8;
 }
 bool igemm_nwalk_form(const IGemmP& p) {
 #if defined(DEX_LP_WSPLIT) && !defined(DEX_WS_HAVE_NWALK)
