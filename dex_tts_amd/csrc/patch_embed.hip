@@ -130,7 +130,9 @@ bool patch_embed_fused_supported(int k, int C, int hid, long ntok) {
     return false;            // no split-weight form yet (lp_config.h)
 #endif
    
-    return (k == 3 || k == 7) && (C == 64 || C == 128) && hid % 128 == 0 && (ntok * (C / 4) + 255) / 256 < 1024;      // the small-grid regime of launch_dwconv_silu
+    // the small-grid regime: measured (fused vs depthwise kernel + GEMM, us) 1 015 tokens (T = 800) 14.1 vs 16.1, 5 010 tokens (T = 4000) 41.6 vs 35.0,
+    // 20 800 tokens (B = 32) 153 vs 94 - the one launch pays off up to a few thousand tokens
+    return (k == 3 || k == 7) && (C == 64 || C == 128) && hid % 128 == 0 && (ntok * (C / 4) + 255) / 256 < 320;
 }
 
 void launch_patch_embed_fused(const DwConvP& p, const void* Wb, const float* bias, float* emb, int hid, hipStream_t st) {
