@@ -789,11 +789,27 @@ static bool pp_plan(const Conv3P& p, int& seg, int& nseg_y) {
     if (mode == 0) return false;
     const int tiles = (p.H + PR - 1) / PR;
     const long cols = (long)((p.W + 31) / 32) * p.B;
-    int k = 1;
+    // Round 5: the split of a strip into segments by ROUNDS of the chip (one workgroup of two segments per CU).  The first rule cut
+    // strips until there were >= 512 segments; the long form (T = 4000: 125 strips of 20 tiles) got 5 x 4-tile segments = 313
+    // workgroups - two rounds, the second 22 % full, the 72 KB weight load amortised over four tiles - where 4 x 5-tile segments are
+    // 250 workgroups in ONE round: cost = rounds x (tiles per segment + ~2 tiles' worth of prologue), among splits that keep >= 95 %
+    // of the CUs busy and >= 3 tiles per segment.  The batch shapes (DEX / GeDEX B = 32: 256 workgroups) choose as before.
+    static int ncu = 0;
+    if (!ncu) { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); if (ncu <= 0) ncu = 256; }
+    long best = -1;
+    for (int k = 1; k == 1 || tiles / k >= 3; ++k) {
+        const int sg = (tiles + k - 1) / k, ny = (tiles + sg - 1) / sg;
+        const long wgs = (cols * ny + 1) / 2;
+        if (wgs * 20 < (long)ncu * 19) continue;          // (a 3/4 bound also took DEX B = 32's half-resolution convs from the 8-row strip walker: 35 vs 31 us)
+        const long cost = (wgs + ncu - 1) / ncu * (sg + 2);
+        if (best < 0 || cost < best) { best = cost; seg = sg; nseg_y = ny; }
+    }
+    if (best >= 0) return true;
+    int k = 1;                                     // (mode 2, tests: the first rule's split on grids below a round)
     while (cols * k < 512 && tiles / (k + 1) >= 3) ++k;
     seg = (tiles + k - 1) / k;
     nseg_y = (tiles + seg - 1) / seg;
-    return mode == 2 || cols * nseg_y >= 512;
+    return mode == 2;
 }
 
 void launch_conv3x3_stream(const Conv3P& p, int tiles_per_wg, hipStream_t st) {
