@@ -627,7 +627,8 @@ void launch_final(const FinalP& p, hipStream_t st) {
     // ... several passes at large batch: every block pays the GroupNorm-coefficient prologue (fp64 divide + sqrt behind a barrier,
     // 72 coefficient loads), so about one round of resident blocks is best (measured at B=32: 16384 blocks 87 us, 8192 85, 4096 74,
     // 2048 68)
-    const long capt = knob_or("DEX_FINAL_CAP", 2048);
+    // (round 5: three workgroups fit a CU - 768 slots; 768 / 1536 / 2048 / 3072 blocks = 79.5 / 69.5 / 69.8 / 72.6 us at GeDEX B = 32, 40.2 / 38.8 / 40.4 / 41.8 at DEX B = 32)
+    const long capt = knob_or("DEX_FINAL_CAP", 1536);
     const long cap = capt / p.B > 32 ? capt / p.B : 32;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(final_kernel, dim3((unsigned)blocks, p.B), dim3(256), 0, st, p);
