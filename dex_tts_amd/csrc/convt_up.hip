@@ -223,7 +223,7 @@ static void cu_launch(ConvTUpP p, hipStream_t st) {
     // ~2 workgroups per CU; a workgroup re-reads two halo rows per row chunk, so chunks stay as long as the grid allows
     const long tiles = (long)p.H * p.nseg * p.B;
     const int target = knob_or("DEX_CONVT_WGS", 512);
-    int R = (int)(tiles / target);
+    int R = (int)((tiles + target - 1) / target);      // (rounded UP: the long form's 2 520 row segments were 630 workgroups on 512 slots with R = 4; R = 5 is 504)
     if (R < 1) R = 1;
     if (R > p.H) R = p.H;
     const int nchunk = (p.H + R - 1) / R;
