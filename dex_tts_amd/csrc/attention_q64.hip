@@ -59,7 +59,7 @@ constexpr int LDS_BYTES = STAGE + 4 * STAGE_WAVE;
 #endif
 #include Q64_CORE_INC
 
-struct Q64Unit { int bh, g, sp, T_lo, nt, tail; };
+struct Q64Unit { int bh, g, sp, T_lo, nt, tail, half, blk0; };      // blk0: the unit's first 32-query block
 
 __device__ __forceinline__ float xhalf_sum(float x) {
     const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
@@ -95,21 +95,27 @@ __global__ __launch_bounds__(256, 1) void attn_q64_kernel(const AttnDirectP p, c
     long long tst[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
-    const int tks = p.tail_ks > 1 ? p.tail_ks : 1, tail_g = tks > 1 ? p.tail_g : ng;
-    const int nwhole = 2 * p.B * tail_g * ks;                 // units of the whole groups (all of them without a tail split)
+    const int tks = p.tail_ks > 1 ? p.tail_ks : 1;
+    const int half_n = p.half_n > 0 ? p.half_n : 0;          // half units (4 waves x ONE 32-query block) per (element, head) behind half_g whole groups
+    const int tail_g = half_n ? p.half_g : tks > 1 ? p.tail_g : ng;
+    const int nwhole = 2 * p.B * tail_g * ks;                 // units of the whole groups (all of them without a tail split / half units)
     auto decode = [&](int unit) __attribute__((always_inline)) -> Q64Unit {
         Q64Unit u;
-        u.tail = unit >= nwhole ? 1 : 0;
-        const int uks = u.tail ? tks : ks;
-        const int per = (u.tail ? ng - tail_g : tail_g) * uks;
-        int r = u.tail ? unit - nwhole : unit;
+        const int second = unit >= nwhole ? 1 : 0;            // the unit order's second class: tail-split groups, or half units
+        u.half = second && half_n ? 1 : 0;
+        u.tail = second && !half_n ? 1 : 0;
+        const int uks = u.tail ? tks : u.half ? 1 : ks;
+        const int per = u.half ? half_n : (u.tail ? ng - tail_g : tail_g) * uks;
+        int r = second ? unit - nwhole : unit;
         if (xcd_mode) { const int x = r & 7, s = r >> 3; u.bh = x + 8 * (s / per); r = s % per; }
         else { u.bh = r / per; r = r % per; }
         u.g = r / uks + (u.tail ? tail_g : 0); u.sp = r % uks;
+        u.blk0 = u.half ? 8 * tail_g + 4 * r : 8 * u.g;
         u.T_lo = (int)((long)nT * u.sp / uks);
         u.nt = (int)((long)nT * (u.sp + 1) / uks) - u.T_lo;
-        u.tail = __builtin_amdgcn_readfirstlane(u.tail);
+        u.tail = __builtin_amdgcn_readfirstlane(u.tail); u.half = __builtin_amdgcn_readfirstlane(u.half);
         u.bh = __builtin_amdgcn_readfirstlane(u.bh); u.g = __builtin_amdgcn_readfirstlane(u.g); u.sp = __builtin_amdgcn_readfirstlane(u.sp);
+        u.blk0 = __builtin_amdgcn_readfirstlane(u.blk0);
         u.T_lo = __builtin_amdgcn_readfirstlane(u.T_lo); u.nt = __builtin_amdgcn_readfirstlane(u.nt);
         return u;
     };
@@ -119,14 +125,14 @@ __global__ __launch_bounds__(256, 1) void attn_q64_kernel(const AttnDirectP p, c
     // a unit's first requests (generated stream): K(0), Q -> a[128:191], V(0), K(1), V(1), K(2), K(3)
     auto issue_prologue = [&](const Q64Unit& u) __attribute__((always_inline)) {
         const auto rK = rsrc_of(p.Kh, u.bh), rV = rsrc_of(p.Vt, u.bh);
-        const int q64 = u.g * 4 + wave;
-        const int qtA = min(q64 * 2, nt32 - 1), qtB = min(q64 * 2 + 1, nt32 - 1);
-        const unsigned qa = vlane + qtA * 8192, qb = vlane + qtB * 8192;
         const unsigned char* qbase = reinterpret_cast<const unsigned char*>(p.Qh) + u.bh * bh_bytes;
+        const int blkA = u.blk0 + (u.half ? wave : 2 * wave);       // one asm for both unit shapes (a half unit skips the block-B loads inside)
+        const int qtA = min(blkA, nt32 - 1), qtB = min(blkA + 1, nt32 - 1);
+        const unsigned qa = vlane + qtA * 8192, qb = vlane + qtB * 8192;
         asm volatile(Q64_ASM_PROLOGUE
                      :
                      : [rk] "s"(rK), [rv] "s"(rV), [tlo] "s"(u.T_lo), [nt] "s"(u.nt), [nt32] "s"(nt32), [wh] "s"(wh), [wq] "s"(wq), [dbase] "s"(dbase),
-                       [vlane] "v"(vlane), [qa] "v"(qa), [qb] "v"(qb), [qbase] "s"(qbase)
+                       [vlane] "v"(vlane), [qa] "v"(qa), [qb] "v"(qb), [qbase] "s"(qbase), [half] "s"(u.half)
                      : Q64_CLOBBER_PROLOGUE);
     };
 
@@ -136,15 +142,15 @@ __global__ __launch_bounds__(256, 1) void attn_q64_kernel(const AttnDirectP p, c
     for (int unit = blockIdx.x;;) {
         const int bh = cur.bh, sp = cur.sp, oslot = cur.tail ? 1 + cur.sp : cur.sp;
         const int b = bh >> 1, h = bh & 1;
-        const int q64 = cur.g * 4 + wave;                      // this wave's 64-query block
+        const int rowA = (cur.half ? cur.blk0 + wave : cur.blk0 + 2 * wave) * 32;      // this wave's first query row (block B: + 32)
         Q64_T(0); Q64_T(1); Q64_T(2);
         float lA, lB, mA, mB;
         {
             const auto rK = rsrc_of(p.Kh, bh), rV = rsrc_of(p.Vt, bh);
-            asm volatile(Q64_ASM_CORE
+            asm volatile(Q64_ASM_CORE               // both unit shapes: the statement dispatches on %[half] itself
                          : [o_la] "=&v"(lA), [o_lb] "=&v"(lB), [o_ma] "=&v"(mA), [o_mb] "=&v"(mB)
                          : [rk] "s"(rK), [rv] "s"(rV), [tlo] "s"(cur.T_lo), [nt] "s"(cur.nt), [nt32] "s"(nt32), [N] "s"(N), [wh] "s"(wh), [wq] "s"(wq),
-                           [dbase] "s"(dbase), [first] "s"(first_unit), [lane16] "v"(lane16), [vlane] "v"(vlane), [hh4] "v"(hh4)
+                           [dbase] "s"(dbase), [first] "s"(first_unit), [half] "s"(cur.half), [lane16] "v"(lane16), [vlane] "v"(vlane), [hh4] "v"(hh4)
                          : Q64_CLOBBER_CORE);
         }
         Q64_T(3); Q64_T(4);
@@ -177,23 +183,24 @@ __global__ __launch_bounds__(256, 1) void attn_q64_kernel(const AttnDirectP p, c
                         o[k] = row < N ? (unsigned)(row * (RB) + h * (HB) + c16 * 16) : 0x80000000u;                                             \
                     }                                                                                                                            \
                     asm volatile(STREAM : : [inv] "v"(INV), [sw] "v"(swrite), [sr] "v"(sread), [ro] "s"(rO), [o0] "v"(o[0]), [o1] "v"(o[1]),   \
-                                 [o2] "v"(o[2]), [o3] "v"(o[3]), [o4] "v"(o[4]), [o5] "v"(o[5]), [o6] "v"(o[6]), [o7] "v"(o[7])                  \
+                                 [o2] "v"(o[2]), [o3] "v"(o[3]), [o4] "v"(o[4]), [o5] "v"(o[5]), [o6] "v"(o[6]), [o7] "v"(o[7]),                 \
+                                 [half] "s"(cur.half)                                                                                           \
                                  : Q64_CLOBBER_EPI);                                                                                            \
                 }
-                Q64_EPI(Q64_ASM_EPI_LP_A, invA, q64 * 64, 512, 256)
-                Q64_EPI(Q64_ASM_EPI_LP_B, invB, q64 * 64 + 32, 512, 256)
+                Q64_EPI(Q64_ASM_EPI_LP_A, invA, rowA, 512, 256)
+                Q64_EPI(Q64_ASM_EPI_LP_B, invB, rowA + 32, 512, 256)
             } else {
                 const auto rO = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.O + (long)oslot * p.o_sstride) + (long)b * orow, 0, (int)orow, 0x00020000);
                 const unsigned swrite = stg + i * STAGE_ROW + hh * 16;
                 unsigned o[8];
-                Q64_EPI(Q64_ASM_EPI_F32_A, invA, q64 * 64, 1024, 512)
-                Q64_EPI(Q64_ASM_EPI_F32_B, invB, q64 * 64 + 32, 1024, 512)
+                Q64_EPI(Q64_ASM_EPI_F32_A, invA, rowA, 1024, 512)
+                Q64_EPI(Q64_ASM_EPI_F32_B, invB, rowA + 32, 1024, 512)
             }
             if (p.ml && (ks > 1 || cur.tail)) {
                 const auto rM = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.ml + ((((long)sp * p.B + b) * 2 + h) * N) * 2), 0, N * 8, 0x00020000);
 #pragma unroll
                 for (int which = 0; which < 2; ++which) {
-                    const int q = (q64 * 2 + which) * 32 + i;
+                    const int q = rowA + which * 32 + i;
                     const u32x2 v = {__float_as_uint(which ? mB : mA), __float_as_uint(which ? lB : lA)};
                     __builtin_amdgcn_raw_buffer_store_b64(v, rM, (hh == 0 && q < N) ? (unsigned)(q * 8) : 0x80000000u, 0, 0);
                 }
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(256, 1) void attn_q64_kernel(const AttnDirectP p, c
         if (p.dbg && lane == 0) {
             long long* d = p.dbg + ((long)unit * 4 + wave) * 8;
             for (int k = 0; k < 6; ++k) d[k] = tst[k];
-            d[6] = cur.nt; d[7] = __builtin_amdgcn_s_getreg(0x14 | (0 << 6) | (3 << 11));    // HW_REG_XCC_ID
+            d[6] = cur.nt | (cur.half << 16); d[7] = __builtin_amdgcn_s_getreg(0x14 | (0 << 6) | (3 << 11));    // HW_REG_XCC_ID
         }
 #endif
         if (!has_next) break;
@@ -263,16 +270,55 @@ void attention_q64_plan(int N, int B, int max_split, int* ks_out, int* tail_g_ou
         }
 }
 
-void launch_attention_q64(const AttnDirectP& p, hipStream_t st) {
+// Whole units + HALF units.  The 32-query blocks of an (element, head) are dealt as half_g whole units (8 blocks: 4 waves x 64 queries)
+// and half_n half units (4 blocks: 4 waves x 32 queries, the block-A-only streams) behind them in the unit order, when that shortens the
+// makespan of the persistent grid: DEX B = 32, N = 1300 has 41 blocks per (element, head) - as 6 whole units (the last one a single ragged
+// block) 384 units = two full-length rounds of 256 workgroups with the second half empty; as 4 whole + 3 half units the second round is
+// 192 half units at ~0.6 of the length.  Unlike a key split the half units write ordinary rows: the consumer sees no difference.
+// Cost model in key tiles of a whole unit (per-unit overhead ~4.5 tiles: first-tile wait, tile 0, last tile, output; half unit ~0.6 x).
+bool attention_q64_half_plan(int N, int B, int* half_g, int* half_n) {
+    const int nt32 = (N + 31) / 32, nT = (nt32 + 1) / 2, ng = (nt32 + 7) / 8;
+    const double cw = nT + 4.5, ch = 0.6 * nT + 3.5;
+    auto makespan = [&](long nw, long nh) {
+        const long G = std::min<long>(nw + nh, 256);
+        double worst = 0;
+        for (long w = 0; w < G; ++w) {
+            double t = 0;
+            for (long u = w; u < nw + nh; u += G) t += u < nw ? cw : ch;
+            worst = std::max(worst, t);
+        }
+        return worst;
+    };
+    double best = makespan(2L * B * ng, 0);
+    bool found = false;
+    for (int hg = nt32 / 8; hg >= 0; --hg) {                 // more whole units first: a tie keeps the fewer half units
+        const int hn = (nt32 - 8 * hg + 3) / 4;
+        if (hn <= 0) continue;
+        const double c = makespan(2L * B * hg, 2L * B * hn);
+        if (c < best * 0.95) { best = c; *half_g = hg; *half_n = hn; found = true; }
+    }
+    return found;
+}
+
+void launch_attention_q64(const AttnDirectP& p0, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_q64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr = true;
     }
+    AttnDirectP p = p0;
     const int nt32 = (p.N + 31) / 32, ng = (nt32 + 7) / 8, ks = p.ksplit > 1 ? p.ksplit : 1;
     const int xcd_mode = ((2 * p.B) % 8 == 0) ? 1 : 0;
     const int tks = p.tail_ks > 1 && ks == 1 ? p.tail_ks : 1, tg = tks > 1 ? p.tail_g : ng;
-    const int nunits = 2 * p.B * (tg * ks + (ng - tg) * tks);
+    int nunits = 2 * p.B * (tg * ks + (ng - tg) * tks);
+    p.half_g = p.half_n = 0;
+    if (ks == 1 && tks == 1) {
+        const int env = p0.half_n < 0 ? 0 : knob_or("DEX_ATTN_Q64_HALF", 1);      // 0: whole units only; half_n < 0: the caller forbids them (tools)
+        int hg = 0, hn = 0;
+        if (p0.half_n > 0) { hg = p0.half_g; hn = p0.half_n; }                      // forced plan (tools / tests)
+        else if (!(env && attention_q64_half_plan(p.N, p.B, &hg, &hn))) hn = 0;
+        if (hn > 0) { p.half_g = hg; p.half_n = hn; nunits = 2 * p.B * (hg + hn); }
+    }
     const int grid = nunits < 256 ? nunits : 256;
     hipLaunchKernelGGL(attn_q64_kernel, dim3(grid), dim3(256), LDS_BYTES, st, p, ng, nunits, xcd_mode);
 }

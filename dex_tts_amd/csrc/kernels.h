@@ -310,13 +310,15 @@ bool dit_rowchain_supported(int hidden, int mlp_hidden);
 struct AttnDirectP { const void *Qh, *Kh, *Vt; int N, Npad, B; float* O; long o_sstride; float* ml; int ksplit; long long* dbg;
                      int o_lp;              // O (ksplit == 1, shared-ring kernel) is written in the mode's 16-bit type: its reader, the 64-row chain, rounds it so anyway (DitChainP::o_lp)
                      int xcd_map;           // set by the launcher (shared-ring kernel): 1-D grid, the query groups of one (element, split, head) share an XCD
-                     int tail_g = 0, tail_ks = 0; };   // 64-query form, ksplit == 1: query groups (256 rows) from tail_g on are split tail_ks ways (fp32 slots 1.., ml); 0 / 1 = off
+                     int tail_g = 0, tail_ks = 0;      // 64-query form, ksplit == 1: query groups (256 rows) from tail_g on are split tail_ks ways (fp32 slots 1.., ml); 0 / 1 = off
+                     int half_g = 0, half_n = 0; };    // 64-query form, set by its launcher: half_g whole query groups per (element, head), then half_n HALF units (4 waves x one 32-query block); half_n == 0 = off
 void launch_attention_direct(const AttnDirectP& p, int precision, hipStream_t st);
 bool attention_direct_batch_regime(int N, int B);     // shared-ring kernel (many query tiles) vs key-splitting waves (few)
 int attention_direct_ksplit(int N, int B);             // key split the batch regime wants for an even load
 void launch_attention_q64(const AttnDirectP& p, int precision, hipStream_t st);     // attention_q64.hip: the batch / long-form form (64 queries per wave)
 int attention_q64_ksplit(int N, int B, int max_split);
 void attention_q64_plan(int N, int B, int max_split, int* ks, int* tail_g, int* tail_ks);
+bool attention_q64_half_plan(int N, int B, int* half_g, int* half_n);     // whole units + a shorter round of half units (no merge anywhere); false: whole units only
 void launch_dit_rowchain(const DitChainP& p, int precision, hipStream_t st);
 void launch_pack_lp_frag(const float* src, void* dst, int K, int N, int precision, hipStream_t st);
 void launch_pack_lp_frag_nk(const float* src, void* dst, int K, int N, int precision, hipStream_t st);   // source [N][K]

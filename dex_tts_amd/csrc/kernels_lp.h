@@ -45,6 +45,7 @@ int attention_direct_ksplit(int N, int B);
 void launch_attention_q64(const AttnDirectP& p, hipStream_t st);
 int attention_q64_ksplit(int N, int B, int max_split);
 void attention_q64_plan(int N, int B, int max_split, int* ks, int* tail_g, int* tail_ks);
+bool attention_q64_half_plan(int N, int B, int* half_g, int* half_n);
 // DiT row chain (dit_rowchain.hip) and its weight packing
 bool dit_rowchain_supported(int hidden, int mlp_hidden);
 bool dit_rowchain64_form(int rows_per_batch, int B, int attn_inline);

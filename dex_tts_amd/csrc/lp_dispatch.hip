@@ -55,6 +55,7 @@ void launch_attention_lp(const AttnP& p, int precision, hipStream_t st) { DEX_LP
 void launch_tv_kv_prep(const TvKvPrepP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_tv_kv_prep, p, st); }
 void launch_tv_chain(const TvChainP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_tv_chain, p, st); }
 void launch_attention_direct(const AttnDirectP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_attention_direct, p, st); }
+bool attention_q64_half_plan(int N, int B, int* half_g, int* half_n) { return bf16::attention_q64_half_plan(N, B, half_g, half_n); }
 void launch_attention_q64(const AttnDirectP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_attention_q64, p, st); }
 void launch_dit_rowchain(const DitChainP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_dit_rowchain, p, st); }
 void launch_pack_lp_frag(const float* src, void* dst, int K, int N, int precision, hipStream_t st) { DEX_LP_CALL(launch_pack_lp_frag, src, dst, K, N, st); }

@@ -372,6 +372,35 @@ def test_cfg2_attention_tail_split_vs_oracle_and_vs_whole_units(prec):
     assert d.max() <= mx and d.mean() <= mn and d.max() > 0.0
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+def test_cfg2_attention_half_units_vs_oracle_and_vs_whole_units(prec):
+    """The 64-query attention's unit plan at configs[2]'s shape (N = 1300: 4 whole units + 3 HALF units per (element, head) - 4 waves x
+    one 32-query block, the block-A-only streams - instead of 6 whole units; default ON, DEX_ATTN_Q64_HALF=0 = whole units only):
+    inside the mode's bound against the oracle, and within the mode's rounding of the whole-unit plan (a block's arithmetic is the same
+    instruction sequence in either unit shape; only the rare lazy move of the softmax reference, decided per wave, can differ)."""
+    cfg, eng, w = U.engine_for("dex_vctk")
+    case = _cfg2_case(cfg)
+    set_prec(eng, prec)
+    old = os.environ.get("DEX_ATTN_Q64_HALF")
+    try:
+        os.environ["DEX_ATTN_Q64_HALF"] = "0"
+        base, ref = U.run_sampler("dex_vctk", case, 4)
+        os.environ["DEX_ATTN_Q64_HALF"] = "1"
+        got, _ = U.run_sampler("dex_vctk", case, 4)
+    finally:
+        eng.set_precision("fp32")
+        if old is None:
+            os.environ.pop("DEX_ATTN_Q64_HALF", None)
+        else:
+            os.environ["DEX_ATTN_Q64_HALF"] = old
+    check_lowp("cfg2_dex_b32_n4_half", prec, "sampler", got, ref)
+    check_lowp("cfg2_dex_b32_n4_whole", prec, "sampler", base, ref)
+    d = np.abs(got - base)
+    record(f"cfg2_dex_b32_n4_half_vs_whole:{prec}:sampler", max=d.max(), mean=d.mean())
+    mx, mn = __import__("tests.tolerances", fromlist=["x"]).lowp_bounds("cfg2_dex_b32_n4", prec, "sampler")
+    assert d.max() <= mx and d.mean() <= mn
+
+
 # measured |tap - oracle tap|max / |tap|max of the "tv" / "tiv" taps in the mode (profiles/round5_parity_measured.jsonl), x2
 TV_TAP_REL = {"bf16": {"tv": 2.1e-2, "tiv": 4.5e-2}, "fp16": {"tv": 2.5e-3, "tiv": 6.0e-3}, "fp16x2": {"tv": 2.5e-3, "tiv": 6.0e-3}}
 

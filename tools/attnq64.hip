@@ -74,15 +74,32 @@ int main(int argc, char** argv) {
         if (nT >= 2) splits.push_back(2);
         if (nT >= 3) splits.push_back(3);
         if (auto_ks > 3) splits.push_back(auto_ks);
-        for (int ks : splits) {
+        // (key split, half plan): half_g = -1: whole units only; -2: the launcher's own plan; >= 0: that many whole groups, the rest as half units
+        struct Var { int ks, hg; };
+        std::vector<Var> vars;
+        for (int ks : splits) vars.push_back({ks, -1});
+        {
+            int phg = 0, phn = 0;
+            if (dex::q64tool::attention_q64_half_plan(c.N, c.B, &phg, &phn)) vars.push_back({1, -2});
+            vars.push_back({1, 0});                                      // half units only
+            if (nt32 > 8) vars.push_back({1, 1});
+            if (nt32 > 16) vars.push_back({1, nt32 / 8 - 1});
+        }
+        for (const Var& var : vars) {
+            const int ks = var.ks;
             AttnDirectP a2 = a; a2.O = O2; a2.ksplit = ks; a2.ml = ks > 1 ? ml : nullptr; a2.o_sstride = (long)on;
+            if (var.hg == -1) a2.half_n = -1;
+            else if (var.hg >= 0) { a2.half_g = var.hg; a2.half_n = (nt32 - 8 * var.hg + 3) / 4; if (a2.half_n <= 0) continue; }
 #ifdef Q64_STAMP
-            const int ng = (nt32 + 7) / 8, nunits = 2 * c.B * ng * ks;
+            const int ng = (nt32 + 7) / 8, nunits = 2 * c.B * std::max(ng * ks, var.hg >= 0 ? var.hg + a2.half_n : 0) + (var.hg == -2 ? 2 * c.B * 8 : 0);
             hipMalloc(&dbg, (size_t)nunits * 4 * 8 * 8); hipMemset(dbg, 0, (size_t)nunits * 4 * 8 * 8);
             a2.dbg = dbg;
 #endif
             hipMemset(O2, 0, on * 4 * ks);
-            char label[96]; snprintf(label, sizeof label, "q64 ksplit=%d%s", ks, ks == auto_ks ? " (auto)" : "");
+            char label[96];
+            if (var.hg == -1) snprintf(label, sizeof label, "q64 ksplit=%d%s", ks, ks == auto_ks ? " (auto)" : "");
+            else if (var.hg == -2) snprintf(label, sizeof label, "q64 half plan (launcher)");
+            else snprintf(label, sizeof label, "q64 %d whole + %d half units", var.hg, a2.half_n);
             if (c.bench) timeit(label, 20, fl, [&] { dex::q64tool::launch_attention_q64(a2, 0); });
             else dex::q64tool::launch_attention_q64(a2, 0);
             if (hipDeviceSynchronize() != hipSuccess) { printf("      %s: LAUNCH FAILED: %s\n", label, hipGetErrorString(hipGetLastError())); return 1; }
@@ -123,15 +140,18 @@ int main(int argc, char** argv) {
 #ifdef Q64_STAMP
             if (c.bench) {
                 std::vector<long long> hd((size_t)nunits * 4 * 8); hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost);
-                double ph[5] = {0, 0, 0, 0, 0}; double tiles = 0; long long t0 = 1LL << 62, t1 = 0;
-                for (int u = 0; u < nunits * 4; ++u) {
-                    const long long* d = &hd[(size_t)u * 8];
-                    for (int k2 = 0; k2 < 5; ++k2) ph[k2] += (double)(d[k2 + 1] - d[k2]);
-                    tiles += d[6]; t0 = std::min(t0, d[0]); t1 = std::max(t1, d[5]);
+                for (int cls = 0; cls < 2; ++cls) {                       // whole units, half units
+                    double ph[5] = {0, 0, 0, 0, 0}; double tiles = 0, nw = 0; long long t0 = 1LL << 62, t1 = 0;
+                    for (int u = 0; u < nunits * 4; ++u) {
+                        const long long* d = &hd[(size_t)u * 8];
+                        if (d[5] == 0 || (int)(d[6] >> 16) != cls) continue;
+                        for (int k2 = 0; k2 < 5; ++k2) ph[k2] += (double)(d[k2 + 1] - d[k2]);
+                        tiles += d[6] & 0xffff; nw += 1; t0 = std::min(t0, d[0]); t1 = std::max(t1, d[5]);
+                    }
+                    if (nw == 0) continue;
+                    printf("      stamps %s (shader cycles, mean per wave-unit, %.0f wave-units): core %.0f (%.1f per tile, %.1f tiles) | seam + output %.0f ; first start to last end %lld\n",
+                           cls ? "HALF " : "whole", nw, ph[2] / nw, ph[2] / std::max(1.0, tiles), tiles / nw, ph[4] / nw, t1 - t0);
                 }
-                const double nw = nunits * 4.0;
-                printf("      stamps (cycles of the 100 MHz s_memtime clock x?, mean per wave-unit): prologue %.0f | tile 0 %.0f | loop %.0f (%.1f per tile, %.1f tiles) | tail %.0f | epilogue %.0f ; span %lld\n",
-                       ph[0] / nw, ph[1] / nw, ph[2] / nw, ph[2] / std::max(1.0, tiles - nw), tiles / nw, ph[3] / nw, ph[4] / nw, t1 - t0);
             }
             hipFree(dbg);
 #endif
@@ -146,7 +166,7 @@ int main(int argc, char** argv) {
             if (pks == 1 && ptk > 1) tps.push_back({ptg, ptk, 1});
             if (ng >= 2 && nT >= 3) { tps.push_back({ng - 1, 2, 0}); tps.push_back({std::max(1, ng / 2), 3, 0}); }
             for (const TP& tp : tps) {
-                AttnDirectP a2 = a; a2.O = O2; a2.ksplit = 1; a2.ml = ml; a2.o_sstride = (long)on; a2.tail_g = tp.tg; a2.tail_ks = tp.tk;
+                AttnDirectP a2 = a; a2.O = O2; a2.ksplit = 1; a2.ml = ml; a2.o_sstride = (long)on; a2.tail_g = tp.tg; a2.tail_ks = tp.tk; a2.half_n = -1;
                 hipMemset(O2, 0, on * 4 * KSMAX);
                 char label[96]; snprintf(label, sizeof label, "q64 tail split g>=%d x%d%s", tp.tg, tp.tk, tp.planned ? " (plan)" : "");
                 if (c.bench) timeit(label, 20, fl, [&] { dex::q64tool::launch_attention_q64(a2, 0); });

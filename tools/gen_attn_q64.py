@@ -459,7 +459,11 @@ def tail(p, cb):
 
 
 def core():
+    """whole unit (blocks A and B).  The statement is ONE asm for both unit shapes (a C++ branch around two statements made hipcc
+    duplicate them): it starts with the dispatch to the half-unit stream (core_h, appended behind this one's cold blocks)"""
     p = Prog()
+    p.e("s_cmp_lg_u32 %[half], 0")
+    p.br("s_cbranch_scc1", "HCORE")
     p.e(f"v_mov_b32 {vr(V_L16)}, %[lane16]")
     p.e(f"v_mov_b32 {vr(V_VOFF)}, %[vlane]")
     p.e(f"v_mov_b32 {vr(V_HH4)}, %[hh4]")
@@ -561,12 +565,413 @@ def core():
     p.e(f"v_mov_b32 %[o_mb], {vr(V_MB)}")
     p.br("s_branch", "EXIT")
     p.finish()
+    return p
+
+
+
+# ------------------------------------------------------------------------------------------------------------------ half units
+# A HALF unit = 4 waves x ONE 32-query block (block A only): the unit shape of the second, shorter round when the whole units of a
+# launch fill the persistent grid once and a bit (DEX B = 32, N = 1300: 41 query blocks per (element, head) = 4 whole units + 9 blocks;
+# as whole units the 9 blocks were a second full-length round for half of the chip).  Its rows leave in the ordinary output format -
+# unlike a key split, nobody merges anything.  Same rings, same DMA, same lazy reference move; 16 + 16 MFMAs per tile, so every K / V^T
+# fragment feeds ONE MFMA: fragment staging is four sets deep (a[192:255]) and requested TWO groups ahead.
+def FRH(st, q): return 192 + 16 * st + 4 * q
+
+
+class LdsQ:
+    """LDS reads return in order: the wait count for a group = the number of reads issued after its last one"""
+    def __init__(self, p, outstanding=()):
+        self.p, self.q = p, list(outstanding)
+
+    def read(self, tag, text):
+        self.p.e(text)
+        self.q.append(tag)
+
+    def need(self, tag):
+        idx = max(i for i, t in enumerate(self.q) if t == tag)
+        self.p.e(f"s_waitcnt lgkmcnt({len(self.q) - 1 - idx})")
+        self.q = self.q[idx + 1:]
+
+
+def k_read_h(lds, grp, q, vaddr):
+    lds.read(("K", grp), f"ds_read_b128 {ar(FRH(grp, q), 4)}, {vr(vaddr)} offset:{(4 * grp + q) * 1024}")
+
+
+def v_read_h(lds, grp, q, vaddr):
+    lds.read(("V", grp), f"ds_read_b128 {ar(FRH(grp, q), 4)}, {vr(vaddr)} offset:{VOFF(grp, q)}")
+
+
+def qk_phase_h(p, lds, dst, first, fill, ahead):
+    """16 S^T MFMAs of block A into score buffer dst; K groups 0 and 1 already requested; ahead(grp, q) issues the read two groups on"""
+    for n in range(16):
+        kb, s = n >> 3, n & 7
+        grp, q = n >> 2, n & 3
+        if q == 0:
+            lds.need(("K", grp))
+        acc = vr(S(dst, kb), 16)
+        c = ("0" if first else vr(NEGM[0], 16)) if s == 0 else acc
+        p.e(f"MFMA {acc}, {ar(FRH(grp, q), 4)}, {ar(QA(s), 4)}, {c}")
+        ahead(grp, q)
+        fill(p, n)
+
+
+def pv_phase_h(p, lds, pbuf, fill, ahead):
+    """16 O^T MFMAs of block A; V^T groups 0 and 1 already requested"""
+    for n in range(16):
+        kk, td = n >> 2, n & 3
+        if td == 0:
+            lds.need(("V", kk))
+        acc = ar(OA(td), 16)
+        pb = vr(S(pbuf, kk >> 1) + 8 * (kk & 1), 4)
+        p.e(f"MFMA {acc}, {ar(FRH(kk, td), 4)}, {pb}, {acc}")
+        ahead(kk, td)
+        fill(p, n)
+
+
+def max_step_h(p, buf, kb, k):
+    c, b = V_C[kb], S(buf, kb)
+    if k == 0:
+        p.e(f"v_max3_f32 {vr(c)}, {vr(b)}, {vr(b + 1)}, {vr(b + 2)}")
+    else:
+        p.e(f"v_max3_f32 {vr(c)}, {vr(c)}, {vr(b + 2 * k + 1)}, {vr(b + 2 * k + 2)}")
+
+
+def max_last_h(p, buf, d):
+    p.e(f"v_max3_f32 {vr(d)}, {vr(V_C[0])}, {vr(V_C[1])}, {vr(S(buf, 0) + 15)}")
+    p.e(f"v_max_f32 {vr(d)}, {vr(d)}, {vr(S(buf, 1) + 15)}")
+
+
+def late_h(p, cb, n):
+    """gap n = 0..15 of phase A: the late exponentials of tile T (array 0 registers 14, 15, all of array 1) + pack n, in place"""
+    a0, a1 = S(cb, 0), S(cb, 1)
+    ev = [a0 + 14, a0 + 15] if n == 0 else [a1, a1 + 1] if n == 1 else [a1 + 2, a1 + 3] if n == 2 else [a1 + n + 1] if n <= 14 else []
+    arr, pi = (a0, n) if n < 8 else (a1, n - 8)
+    lo, dst = arr + 2 * pi, arr + 8 * (pi >> 2) + (pi & 3)
+    for r in ev:
+        p.e(f"v_exp_f32 {vr(r)}, {vr(r)}")
+    p.e(f"PK {vr(dst)}, {vr(lo)}, {vr(lo + 1)}")
+    for r in ev:
+        p.e(f"v_add_f32 {vr(V_LA)}, {vr(V_LA)}, {vr(r)}")
+
+
+def early_h(p, buf, e):
+    """early exponentials, pair e = 0..6: registers 2 e, 2 e + 1 of array 0"""
+    r = S(buf, 0) + 2 * e
+    p.e(f"v_exp_f32 {vr(r)}, {vr(r)}")
+    p.e(f"v_exp_f32 {vr(r + 1)}, {vr(r + 1)}")
+    p.e(f"v_add_f32 {vr(V_LA)}, {vr(V_LA)}, {vr(r)}")
+    p.e(f"v_add_f32 {vr(V_LA)}, {vr(V_LA)}, {vr(r + 1)}")
+
+
+def mask_tile_h(p, buf, s_tile64):
+    p.e(f"v_mov_b32 {vr(V_NINF)}, 0xff800000")
+    p.e(f"s_sub_i32 {sr(S_X1)}, %[N], {sr(s_tile64)}")
+    for kb in range(2):
+        for r in range(16):
+            const = kb * 32 + (r & 3) + 8 * (r >> 2)
+            p.e(f"s_sub_i32 {sr(S_X2)}, {sr(S_X1)}, {const}")
+            p.e(f"v_cmp_ge_i32 vcc, {vr(V_HH4)}, {sr(S_X2)}")
+            reg = S(buf, kb) + r
+            p.e(f"v_cndmask_b32 {vr(reg)}, {vr(reg)}, {vr(V_NINF)}, vcc")
+
+
+H_K_GAPS = (8, 9, 14, 15)       # gaps of phase A that issue the four K(T+4) pieces
+H_V_GAPS = (0, 1, 2, 3)         # gaps of phase B that issue the four V(T+2) pieces
+
+
+def iteration_h(p, cb, nb, steady, tag):
+    """half unit: tile T (scores in buffer cb) is current, T + 1 (buffer nb) is next; LDS state at entry: K(T+1) groups 0, 1 requested"""
+    lds = LdsQ(p, [("K", 0)] * 4 + [("K", 1)] * 4)
+    p.e(f"v_mov_b32 {vr(V_KA)}, {vr(V_KA2)}")
+    if not steady:
+        p.e(f"s_sub_i32 {sr(S_X0)}, %[nt], {sr(S_IT)}")
+        p.e(f"s_cmp_gt_i32 {sr(S_X0)}, 4")
+        p.e(f"s_cselect_b32 {sr(S_HK)}, 1, 0")
+        p.e(f"s_cmp_gt_i32 {sr(S_X0)}, 2")
+        p.e(f"s_cselect_b32 {sr(S_HV)}, 1, 0")
+
+    def dma_guarded(rs, soff, j, flag, name):
+        if steady:
+            dma_piece(p, rs, soff, j)
+        else:
+            p.e(f"s_cmp_eq_u32 {sr(flag)}, 0")
+            p.br("s_cbranch_scc1", name)
+            dma_piece(p, rs, soff, j)
+            p.label(name)
+
+    def setup_a(n):
+        if n == 1:
+            p.e(f"s_add_i32 {sr(S_SOFFK)}, {sr(S_T)}, 4")
+            p.e(f"s_lshl_b32 {sr(S_SOFFK)}, {sr(S_SOFFK)}, 1")
+            p.e(f"s_add_i32 {sr(S_SOFFK)}, {sr(S_SOFFK)}, %[wh]")
+        if n == 2:
+            p.e(f"s_min_i32 {sr(S_SOFFK)}, {sr(S_SOFFK)}, {sr(S_NT32M1)}")
+            p.e(f"s_lshl_b32 {sr(S_SOFFK)}, {sr(S_SOFFK)}, 13")
+            p.e(f"s_add_i32 {sr(S_SOFFK)}, {sr(S_SOFFK)}, %[wq]")
+        if n == 3:
+            p.e(f"s_and_b32 {sr(S_KDST)}, {sr(S_T)}, 3")
+            p.e(f"s_lshl_b32 {sr(S_KDST)}, {sr(S_KDST)}, 14")
+            p.e(f"s_add_i32 {sr(S_KDST)}, {sr(S_KDST)}, %[dbase]")
+        if n == 4:
+            p.e(f"s_mov_b32 m0, {sr(S_KDST)}")
+            p.e(f"v_add_u32_e32 {vr(V_VA)}, {sr(S_VS0)}, {vr(V_L16)}")      # V(T) read address (first use: gap 8)
+        if n == 6:          # look-ahead address: K(T+2) (first use: gap 8 of phase B)
+            p.e(f"s_add_i32 {sr(S_X0)}, {sr(S_T)}, 2")
+            p.e(f"s_and_b32 {sr(S_X0)}, {sr(S_X0)}, 3")
+            p.e(f"s_lshl_b32 {sr(S_X0)}, {sr(S_X0)}, 14")
+            p.e(f"v_add_u32_e32 {vr(V_KA2)}, {sr(S_X0)}, {vr(V_L16)}")
+        if n == 12:
+            p.e(f"s_add_i32 {sr(S_SOFFV)}, {sr(S_T)}, 2")
+            p.e(f"s_lshl_b32 {sr(S_SOFFV)}, {sr(S_SOFFV)}, 1")
+            p.e(f"s_add_i32 {sr(S_SOFFV)}, {sr(S_SOFFV)}, %[wh]")
+        if n == 13:
+            p.e(f"s_min_i32 {sr(S_SOFFV)}, {sr(S_SOFFV)}, {sr(S_NT32M1)}")
+            p.e(f"s_lshl_b32 {sr(S_SOFFV)}, {sr(S_SOFFV)}, 13")
+            p.e(f"s_add_i32 {sr(S_SOFFV)}, {sr(S_SOFFV)}, %[wq]")
+            p.e(f"s_add_i32 {sr(S_VDST)}, {sr(S_VS2)}, %[dbase]")
+
+    def fa(p_, n):
+        late_h(p, cb, n)
+        if 10 <= n <= 15:
+            max_step_h(p, nb, 0, n - 10)
+        if n == 15:
+            max_step_h(p, nb, 0, 6)
+        setup_a(n)
+        for j, g in enumerate(H_K_GAPS):
+            if g == n:
+                dma_guarded("%[rk]", S_SOFFK, j, S_HK, f"HKK{tag}{j}")
+
+    def ahead_a(grp, q):
+        if grp < 2:
+            k_read_h(lds, grp + 2, q, V_KA)
+        else:
+            v_read_h(lds, grp - 2, q, V_VA)
+
+    qk_phase_h(p, lds, nb, False, fa, ahead_a)
+
+    def fb(p_, n):
+        for j, g in enumerate(H_V_GAPS):
+            if g == n:
+                if j == 0:
+                    p.e(f"s_mov_b32 m0, {sr(S_VDST)}")
+                    p.e("s_nop 0")
+                dma_guarded("%[rv]", S_SOFFV, j, S_HV, f"HKV{tag}{j}")
+        if n == 2:
+            p.e(f"s_add_i32 {sr(S_X0)}, {sr(S_T)}, 1")
+            p.e(f"s_lshl_b32 {sr(S_X0)}, {sr(S_X0)}, 6")
+            p.e(f"s_add_i32 {sr(S_X1)}, {sr(S_X0)}, 64")
+            p.e(f"s_cmp_gt_i32 {sr(S_X1)}, %[N]")
+            p.br("s_cbranch_scc1", f"HMASK{tag}")
+            p.label(f"HNOMASK{tag}")
+            p.begin_cold(f"HMASK{tag}", f"HNOMASK{tag}")
+            p.e("s_nop 7")
+            mask_tile_h(p, nb, S_X0)
+            p.end_cold()
+        if 2 <= n <= 4:
+            max_step_h(p, nb, 1, 2 * (n - 2))
+            max_step_h(p, nb, 1, 2 * (n - 2) + 1)
+        if n == 5:
+            max_step_h(p, nb, 1, 6)
+            max_last_h(p, nb, V_MXA)
+        if n == 6:
+            xhalf_max(p, V_MXA, V_T0)
+        if n == 7:
+            p.e(f"v_cmp_lt_f32 vcc, 0x41000000, {vr(V_MXA)}")          # 8.0 < max
+            p.br("s_cbranch_vccnz", f"HMOVE{tag}")
+            p.label(f"HNOMOVE{tag}")
+            p.begin_cold(f"HMOVE{tag}", f"HNOMOVE{tag}")
+            p.e(f"v_max_f32 {vr(V_T0)}, 0, {vr(V_MXA)}")
+            p.e(f"v_add_f32 {vr(V_MA)}, {vr(V_MA)}, {vr(V_T0)}")
+            p.e(f"v_exp_f32 {vr(V_ALA)}, -{vr(V_T0)}")
+            p.e("s_nop 0")
+            p.e(f"v_mul_f32 {vr(V_LA)}, {vr(V_LA)}, {vr(V_ALA)}")
+            for a in range(2):
+                for r in range(16):
+                    reg = S(nb, a) + r
+                    p.e(f"v_sub_f32 {vr(reg)}, {vr(reg)}, {vr(V_T0)}")
+            for r in range(16):
+                p.e(f"v_sub_f32 {vr(NEGM[0] + r)}, 0, {vr(V_MA)}")
+            p.e(f"s_mov_b32 {sr(S_PEND)}, 1")
+            p.end_cold()
+        if 8 <= n <= 14:
+            early_h(p, nb, n - 8)
+
+    def ahead_b(kk, td):
+        if kk < 2:
+            v_read_h(lds, kk + 2, td, V_VA)
+        else:
+            k_read_h(lds, kk - 2, td, V_KA2)
+
+    pv_phase_h(p, lds, cb, fb, ahead_b)
+    assert lds.q == [("K", 0)] * 4 + [("K", 1)] * 4
+    p.e(f"s_cmp_lg_u32 {sr(S_PEND)}, 0")
+    p.br("s_cbranch_scc1", f"HPEND{tag}")
+    p.label(f"HNOPEND{tag}")
+    p.begin_cold(f"HPEND{tag}", f"HNOPEND{tag}")
+    p.e("s_nop 15")
+    p.e("s_nop 7")
+    for k in range(64):
+        p.e(f"v_accvgpr_read_b32 {vr(V_T0)}, {ar(k)}")
+        p.e(f"v_mul_f32 {vr(V_T0)}, {vr(V_T0)}, {vr(V_ALA)}")
+        p.e(f"v_accvgpr_write_b32 {ar(k)}, {vr(V_T0)}")
+    p.e("s_nop 3")
+    p.e(f"s_mov_b32 {sr(S_PEND)}, 0")
+    p.end_cold()
+    if steady:
+        p.e("s_waitcnt vmcnt(8)")
+    else:
+        p.e(f"s_cmp_eq_u32 {sr(S_HK)}, 0")
+        p.br("s_cbranch_scc1", f"HW4{tag}")
+        p.e("s_waitcnt vmcnt(8)")
+        p.br("s_branch", f"HWD{tag}")
+        p.label(f"HW4{tag}")
+        p.e(f"s_cmp_eq_u32 {sr(S_HV)}, 0")
+        p.br("s_cbranch_scc1", f"HW0{tag}")
+        p.e("s_waitcnt vmcnt(4)")
+        p.br("s_branch", f"HWD{tag}")
+        p.label(f"HW0{tag}")
+        p.e("s_waitcnt vmcnt(0)")
+        p.label(f"HWD{tag}")
+    p.e("s_barrier")
+    p.e(f"s_mov_b32 {sr(S_X0)}, {sr(S_VS0)}")
+    p.e(f"s_mov_b32 {sr(S_VS0)}, {sr(S_VS1)}")
+    p.e(f"s_mov_b32 {sr(S_VS1)}, {sr(S_VS2)}")
+    p.e(f"s_mov_b32 {sr(S_VS2)}, {sr(S_X0)}")
+    p.e(f"s_add_i32 {sr(S_IT)}, {sr(S_IT)}, 1")
+    p.e(f"s_add_i32 {sr(S_T)}, {sr(S_T)}, 1")
+
+
+def tail_h(p, cb):
+    """the sequence's last tile: late exponentials + packs, then its O^T MFMAs (older reads may still be in flight: counts are relative)"""
+    for n in range(16):
+        late_h(p, cb, n)
+    p.e(f"v_add_u32_e32 {vr(V_VA)}, {sr(S_VS0)}, {vr(V_L16)}")
+    lds = LdsQ(p, ["old"] * 8)
+    for g in range(2):
+        for q in range(4):
+            v_read_h(lds, g, q, V_VA)
+
+    def ahead(kk, td):
+        if kk < 2:
+            v_read_h(lds, kk + 2, td, V_VA)
+
+    pv_phase_h(p, lds, cb, lambda p_, n: None, ahead)
+
+
+def core_h():
+    p = Prog()
+    p.label("HCORE")
+    p.e(f"v_mov_b32 {vr(V_L16)}, %[lane16]")
+    p.e(f"v_mov_b32 {vr(V_VOFF)}, %[vlane]")
+    p.e(f"v_mov_b32 {vr(V_HH4)}, %[hh4]")
+    p.e(f"v_mov_b32 {vr(V_LA)}, 0")
+    p.e(f"s_mov_b32 {sr(S_IT)}, 0")
+    p.e(f"s_mov_b32 {sr(S_T)}, %[tlo]")
+    p.e(f"s_mov_b32 {sr(S_PEND)}, 0")
+    p.e(f"s_sub_i32 {sr(S_NT32M1)}, %[nt32], 1")
+    p.e(f"s_mov_b32 {sr(S_VS0)}, {V_RING}")
+    p.e(f"s_mov_b32 {sr(S_VS1)}, {V_RING + TILE}")
+    p.e(f"s_mov_b32 {sr(S_VS2)}, {V_RING + 2 * TILE}")
+    # the unit's first requests but K(3) have landed; a finished unit's stores (>= 8: a half unit's one block in 16-bit rows) may fly on
+    p.e("s_cmp_eq_u32 %[first], 0")
+    p.br("s_cbranch_scc1", "HWNF")
+    p.e("s_cmp_gt_i32 %[nt], 3")
+    p.br("s_cbranch_scc1", "HWF4")
+    p.e("s_waitcnt vmcnt(0)")
+    p.br("s_branch", "HWDONE")
+    p.label("HWF4")
+    p.e("s_waitcnt vmcnt(4)")
+    p.br("s_branch", "HWDONE")
+    p.label("HWNF")
+    p.e("s_cmp_gt_i32 %[nt], 3")
+    p.br("s_cbranch_scc1", "HWN4")
+    p.e("s_waitcnt vmcnt(8)")
+    p.br("s_branch", "HWDONE")
+    p.label("HWN4")
+    p.e("s_waitcnt vmcnt(12)")
+    p.label("HWDONE")
+    p.e("s_barrier")
+    # ---- tile 0
+    kslot_addr(p, V_KA, 0)
+    lds = LdsQ(p)
+    for g in range(2):
+        for q in range(4):
+            k_read_h(lds, g, q, V_KA)
+
+    def f0(p_, n):
+        for k in range(4):
+            p.e(f"v_accvgpr_write_b32 {ar(4 * n + k)}, 0")
+
+    def ahead0(grp, q):
+        if grp < 2:
+            k_read_h(lds, grp + 2, q, V_KA)
+
+    qk_phase_h(p, lds, 0, True, f0, ahead0)
+    p.e("s_nop 15")
+    p.e("s_nop 7")
+    p.e(f"s_lshl_b32 {sr(S_X0)}, {sr(S_T)}, 6")
+    p.e(f"s_add_i32 {sr(S_X1)}, {sr(S_X0)}, 64")
+    p.e(f"s_cmp_gt_i32 {sr(S_X1)}, %[N]")
+    p.br("s_cbranch_scc1", "HMASK0")
+    p.label("HNOMASK0")
+    p.begin_cold("HMASK0", "HNOMASK0")
+    mask_tile_h(p, 0, S_X0)
+    p.end_cold()
+    for k in range(7):
+        max_step_h(p, 0, 0, k)
+        max_step_h(p, 0, 1, k)
+    max_last_h(p, 0, V_MA)
+    xhalf_max(p, V_MA, V_T0)
+    for a in range(2):
+        for r in range(16):
+            reg = S(0, a) + r
+            p.e(f"v_sub_f32 {vr(reg)}, {vr(reg)}, {vr(V_MA)}")
+    for r in range(16):
+        p.e(f"v_sub_f32 {vr(NEGM[0] + r)}, 0, {vr(V_MA)}")
+    for e in range(7):
+        early_h(p, 0, e)
+    p.e("s_barrier")                                                       # every wave has read K(0): its slot may take K(4)
+    p.e("s_cmp_lt_i32 %[nt], 2")
+    p.br("s_cbranch_scc1", "HTAIL_E")
+    kslot_addr(p, V_KA2, 1)
+    for g in range(2):
+        for q in range(4):
+            p.e(f"ds_read_b128 {ar(FRH(g, q), 4)}, {vr(V_KA2)} offset:{(4 * g + q) * 1024}")
+    for par, (cb, nb) in enumerate(((0, 1), (1, 0))):
+        me, other = "EO"[par], "OE"[par]
+        p.label(f"HLOOP_{me}")
+        p.e(f"s_add_i32 {sr(S_X0)}, {sr(S_IT)}, 1")
+        p.e(f"s_cmp_ge_i32 {sr(S_X0)}, %[nt]")
+        p.br("s_cbranch_scc1", f"HTAIL_{me}")
+        p.e(f"s_add_i32 {sr(S_X0)}, {sr(S_IT)}, 4")
+        p.e(f"s_cmp_ge_i32 {sr(S_X0)}, %[nt]")
+        p.br("s_cbranch_scc1", f"HDRAIN_{me}")
+        iteration_h(p, cb, nb, True, f"S{me}")
+        p.br("s_branch", f"HLOOP_{other}")
+        p.label(f"HDRAIN_{me}")
+        iteration_h(p, cb, nb, False, f"D{me}")
+        p.br("s_branch", f"HLOOP_{other}")
+    p.label("HTAIL_E")
+    tail_h(p, 0)
+    p.br("s_branch", "HEND")
+    p.label("HTAIL_O")
+    tail_h(p, 1)
+    p.label("HEND")
+    p.e("s_barrier")
+    p.e("s_nop 15")
+    p.e("s_nop 7")
+    p.e(f"v_mov_b32 %[o_la], {vr(V_LA)}")
+    p.e(f"v_mov_b32 %[o_ma], {vr(V_MA)}")
+    p.e("v_mov_b32 %[o_lb], 0")
+    p.e("v_mov_b32 %[o_mb], 0")
+    p.br("s_branch", "EXIT")
+    p.finish()
     p.label("EXIT")
     return p
 
 
 def prologue():
-    """a unit's first requests: K(0), Q (straight into a[128:191]), V(0), K(1), V(1), K(2), K(3)"""
+    """a unit's first requests: K(0), Q (straight into a[128:191]; a half unit - %[half] - block A only), V(0), K(1), V(1), K(2), K(3)"""
     p = Prog()
     X0, X1, X2 = 40, 41, 42
 
@@ -597,10 +1002,12 @@ def prologue():
     p.e("v_add_u32_e32 v0, 0x1000, %[qa]")
     p.e("v_add_u32_e32 v1, 0x1000, %[qb]")
     for s in range(8):
-        va = "%[qa]" if s < 4 else "v0"
-        vb = "%[qb]" if s < 4 else "v1"
-        p.e(f"global_load_dwordx4 {ar(QA(s), 4)}, {va}, %[qbase] offset:{(s & 3) * 1024}")
-        p.e(f"global_load_dwordx4 {ar(QB(s), 4)}, {vb}, %[qbase] offset:{(s & 3) * 1024}")
+        p.e(f"global_load_dwordx4 {ar(QA(s), 4)}, {'%[qa]' if s < 4 else 'v0'}, %[qbase] offset:{(s & 3) * 1024}")
+    p.e("s_cmp_lg_u32 %[half], 0")
+    p.br("s_cbranch_scc1", "NOQB")
+    for s in range(8):
+        p.e(f"global_load_dwordx4 {ar(QB(s), 4)}, {'%[qb]' if s < 4 else 'v1'}, %[qbase] offset:{(s & 3) * 1024}")
+    p.label("NOQB")
     vdst(0); tile("%[rv]", 0, X1)
     p.e("s_cmp_lt_i32 %[nt], 2")
     p.br("s_cbranch_scc1", "PDONE")
@@ -618,9 +1025,12 @@ def prologue():
 
 def epilogue(which, lp):
     """block `which` of the finished unit: a[64 which ..] * inv -> this wave's LDS rows -> 256-byte row segments to memory.
-    fp32: two passes (64 d each); 16-bit: one pass.  Temps v0..v63."""
+    fp32: two passes (64 d each); 16-bit: one pass.  Temps v0..v63.  Block B: skipped by a half unit (%[half])."""
     p = Prog()
     base = 64 * which
+    if which:
+        p.e("s_cmp_lg_u32 %[half], 0")
+        p.br("s_cbranch_scc1", "NOEPI")
     if lp:
         # 16 ds_write_b64: (t, rq) -> row i, bytes (t*32 + 8*rq + 4*hh)*2 ; the per-lane part (i, hh) is in %[sw]
         for t in range(4):
@@ -660,6 +1070,8 @@ def epilogue(which, lp):
             for k in range(8):
                 p.e(f"buffer_store_dwordx4 {vr(4 * k, 4)}, %[o{k}], %[ro], 0 offen offset:{half * 256}")
             p.e("s_nop 1")
+    if which:
+        p.label("NOEPI")
     return p
 
 
@@ -685,14 +1097,16 @@ def main():
         body = prog.text().replace("\n", " \\\n")
         parts.append(f"#define {name} \\\n    {body}\n")
 
-    macro("Q64_ASM_CORE", core())
+    both = core()
+    both.hot.extend(core_h().hot)
+    macro("Q64_ASM_CORE", both)
     macro("Q64_ASM_PROLOGUE", prologue())
     for which in (0, 1):
         macro(f"Q64_ASM_EPI_F32_{'AB'[which]}", epilogue(which, False))
         macro(f"Q64_ASM_EPI_LP_{'AB'[which]}", epilogue(which, True))
     parts.append("#define Q64_CLOBBER_CORE \\\n    " + clobbers(V_TOP, S_TOP, range(256), ("vcc", "scc", "memory")) + "\n")
     parts.append("#define Q64_CLOBBER_PROLOGUE \\\n    " + clobbers(1, 42, range(128, 192), ("scc", "memory")) + "\n")
-    parts.append("#define Q64_CLOBBER_EPI \\\n    " + clobbers(63, 39, (), ("memory",)) + "\n")
+    parts.append("#define Q64_CLOBBER_EPI \\\n    " + clobbers(63, 39, (), ("scc", "memory")) + "\n")
     text = "\n".join(parts)
     if "--check" in sys.argv:
         cur = open(OUT).read() if os.path.exists(OUT) else ""
