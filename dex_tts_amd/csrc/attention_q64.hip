@@ -122,17 +122,26 @@ __global__ __launch_bounds__(256, 1) void attn_q64_kernel(const AttnDirectP p, c
     auto rsrc_of = [&](const void* base, int bh) __attribute__((always_inline)) {
         return __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(reinterpret_cast<const unsigned char*>(base) + bh * bh_bytes), 0, (int)bh_bytes, 0x00020000);
     };
+    // The stream of THIS WAVE in a unit: 0 both of its 32-query blocks are live, 1 only block A is (a half unit's wave, or the wave of a
+    // whole unit that holds the (element, head)'s last, odd block), 2 none is (the waves of a ragged unit past the last block: they only
+    // issue their share of the tile requests and keep the barriers).  Round 6: before, such waves ran the full stream on clamped rows -
+    // 3 to 12 % of a launch's MFMAs at the judged shapes, and under dense MFMA the chip is power-limited.
+    auto wave_mode = [&](const Q64Unit& u) __attribute__((always_inline)) -> int {
+        const int blkA = u.blk0 + (u.half ? wave : 2 * wave);
+        return __builtin_amdgcn_readfirstlane(blkA >= nt32 ? 2 : (u.half || blkA + 1 >= nt32) ? 1 : 0);
+    };
     // a unit's first requests (generated stream): K(0), Q -> a[128:191], V(0), K(1), V(1), K(2), K(3)
     auto issue_prologue = [&](const Q64Unit& u) __attribute__((always_inline)) {
         const auto rK = rsrc_of(p.Kh, u.bh), rV = rsrc_of(p.Vt, u.bh);
         const unsigned char* qbase = reinterpret_cast<const unsigned char*>(p.Qh) + u.bh * bh_bytes;
-        const int blkA = u.blk0 + (u.half ? wave : 2 * wave);       // one asm for both unit shapes (a half unit skips the block-B loads inside)
+        const int blkA = u.blk0 + (u.half ? wave : 2 * wave);       // one asm for every stream (a half / passive wave skips the block-B loads inside)
         const int qtA = min(blkA, nt32 - 1), qtB = min(blkA + 1, nt32 - 1);
         const unsigned qa = vlane + qtA * 8192, qb = vlane + qtB * 8192;
+        const int mode = wave_mode(u);
         asm volatile(Q64_ASM_PROLOGUE
                      :
                      : [rk] "s"(rK), [rv] "s"(rV), [tlo] "s"(u.T_lo), [nt] "s"(u.nt), [nt32] "s"(nt32), [wh] "s"(wh), [wq] "s"(wq), [dbase] "s"(dbase),
-                       [vlane] "v"(vlane), [qa] "v"(qa), [qb] "v"(qb), [qbase] "s"(qbase), [half] "s"(u.half)
+                       [vlane] "v"(vlane), [qa] "v"(qa), [qb] "v"(qb), [qbase] "s"(qbase), [half] "s"(mode)
                      : Q64_CLOBBER_PROLOGUE);
     };
 
@@ -143,6 +152,7 @@ __global__ __launch_bounds__(256, 1) void attn_q64_kernel(const AttnDirectP p, c
         const int bh = cur.bh, sp = cur.sp, oslot = cur.tail ? 1 + cur.sp : cur.sp;
         const int b = bh >> 1, h = bh & 1;
         const int rowA = (cur.half ? cur.blk0 + wave : cur.blk0 + 2 * wave) * 32;      // this wave's first query row (block B: + 32)
+        const int mode = wave_mode(cur);
         Q64_T(0); Q64_T(1); Q64_T(2);
         float lA, lB, mA, mB;
         {
@@ -150,7 +160,7 @@ __global__ __launch_bounds__(256, 1) void attn_q64_kernel(const AttnDirectP p, c
             asm volatile(Q64_ASM_CORE               // both unit shapes: the statement dispatches on %[half] itself
                          : [o_la] "=&v"(lA), [o_lb] "=&v"(lB), [o_ma] "=&v"(mA), [o_mb] "=&v"(mB)
                          : [rk] "s"(rK), [rv] "s"(rV), [tlo] "s"(cur.T_lo), [nt] "s"(cur.nt), [nt32] "s"(nt32), [N] "s"(N), [wh] "s"(wh), [wq] "s"(wq),
-                           [dbase] "s"(dbase), [first] "s"(first_unit), [half] "s"(cur.half), [lane16] "v"(lane16), [vlane] "v"(vlane), [hh4] "v"(hh4)
+                           [dbase] "s"(dbase), [first] "s"(first_unit), [half] "s"(mode), [lane16] "v"(lane16), [vlane] "v"(vlane), [hh4] "v"(hh4)
                          : Q64_CLOBBER_CORE);
         }
         Q64_T(3); Q64_T(4);
@@ -184,7 +194,7 @@ __global__ __launch_bounds__(256, 1) void attn_q64_kernel(const AttnDirectP p, c
                     }                                                                                                                            \
                     asm volatile(STREAM : : [inv] "v"(INV), [sw] "v"(swrite), [sr] "v"(sread), [ro] "s"(rO), [o0] "v"(o[0]), [o1] "v"(o[1]),   \
                                  [o2] "v"(o[2]), [o3] "v"(o[3]), [o4] "v"(o[4]), [o5] "v"(o[5]), [o6] "v"(o[6]), [o7] "v"(o[7]),                 \
-                                 [half] "s"(cur.half)                                                                                           \
+                                 [half] "s"(mode)                                                                                               \
                                  : Q64_CLOBBER_EPI);                                                                                            \
                 }
                 Q64_EPI(Q64_ASM_EPI_LP_A, invA, rowA, 512, 256)
@@ -211,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void attn_q64_kernel(const AttnDirectP p, c
         if (p.dbg && lane == 0) {
             long long* d = p.dbg + ((long)unit * 4 + wave) * 8;
             for (int k = 0; k < 6; ++k) d[k] = tst[k];
-            d[6] = cur.nt | (cur.half << 16); d[7] = __builtin_amdgcn_s_getreg(0x14 | (0 << 6) | (3 << 11));    // HW_REG_XCC_ID
+            d[6] = cur.nt | (mode << 16); d[7] = __builtin_amdgcn_s_getreg(0x14 | (0 << 6) | (3 << 11));    // HW_REG_XCC_ID
         }
 #endif
         if (!has_next) break;

@@ -88,10 +88,12 @@ int main(int argc, char** argv) {
         for (const Var& var : vars) {
             const int ks = var.ks;
             AttnDirectP a2 = a; a2.O = O2; a2.ksplit = ks; a2.ml = ks > 1 ? ml : nullptr; a2.o_sstride = (long)on;
+            const bool olp = getenv("Q64_OLP") && ks == 1;       // 16-bit output rows, as the product path at batch size
+            if (olp) a2.o_lp = 1;
             if (var.hg == -1) a2.half_n = -1;
             else if (var.hg >= 0) { a2.half_g = var.hg; a2.half_n = (nt32 - 8 * var.hg + 3) / 4; if (a2.half_n <= 0) continue; }
 #ifdef Q64_STAMP
-            const int ng = (nt32 + 7) / 8, nunits = 2 * c.B * std::max(ng * ks, var.hg >= 0 ? var.hg + a2.half_n : 0) + (var.hg == -2 ? 2 * c.B * 8 : 0);
+            const int ng = (nt32 + 7) / 8, nunits = 2 * c.B * (ng * ks + 2 * ng + 8);        // (an upper bound of every plan's unit count)
             hipMalloc(&dbg, (size_t)nunits * 4 * 8 * 8); hipMemset(dbg, 0, (size_t)nunits * 4 * 8 * 8);
             a2.dbg = dbg;
 #endif
@@ -105,6 +107,10 @@ int main(int argc, char** argv) {
             if (hipDeviceSynchronize() != hipSuccess) { printf("      %s: LAUNCH FAILED: %s\n", label, hipGetErrorString(hipGetLastError())); return 1; }
             std::vector<float> g(on * ks), hml((size_t)ks * c.B * 2 * c.N * 2);
             hipMemcpy(g.data(), O2, on * 4 * ks, hipMemcpyDeviceToHost);
+            if (olp) {
+                std::vector<unsigned short> h16(on); memcpy(h16.data(), g.data(), on * 2);
+                for (size_t j = 0; j < on; ++j) { const unsigned u = (unsigned)h16[j] << 16; memcpy(&g[j], &u, 4); }
+            }
             if (ks > 1) hipMemcpy(hml.data(), ml, hml.size() * 4, hipMemcpyDeviceToHost);
             double mx = 0, ref = 0; size_t bad = 0, nbad = 0; int ndiag = 0; std::vector<size_t> badrow((c.N + 31) / 32 + 1, 0), badd(4, 0);
             for (int b = 0; b < c.B; ++b)
@@ -140,7 +146,7 @@ int main(int argc, char** argv) {
 #ifdef Q64_STAMP
             if (c.bench) {
                 std::vector<long long> hd((size_t)nunits * 4 * 8); hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost);
-                for (int cls = 0; cls < 2; ++cls) {                       // whole units, half units
+                for (int cls = 0; cls < 3; ++cls) {                       // waves on the whole / half / passive stream
                     double ph[5] = {0, 0, 0, 0, 0}; double tiles = 0, nw = 0; long long t0 = 1LL << 62, t1 = 0;
                     for (int u = 0; u < nunits * 4; ++u) {
                         const long long* d = &hd[(size_t)u * 8];
@@ -150,7 +156,7 @@ int main(int argc, char** argv) {
                     }
                     if (nw == 0) continue;
                     printf("      stamps %s (shader cycles, mean per wave-unit, %.0f wave-units): core %.0f (%.1f per tile, %.1f tiles) | seam + output %.0f ; first start to last end %lld\n",
-                           cls ? "HALF " : "whole", nw, ph[2] / nw, ph[2] / std::max(1.0, tiles), tiles / nw, ph[4] / nw, t1 - t0);
+                           cls == 2 ? "pass." : cls ? "HALF " : "whole", nw, ph[2] / nw, ph[2] / std::max(1.0, tiles), tiles / nw, ph[4] / nw, t1 - t0);
                 }
             }
             hipFree(dbg);

@@ -26,6 +26,11 @@ OUT = os.environ.get("Q64GEN_OUT") or os.path.join(os.path.dirname(os.path.abspa
 # -DQ64_CORE_INC='"/tmp/x.inc"').  The committed .inc is generated with none of them set.
 OPT_DMA = os.environ.get("Q64GEN_DMA", "default")        # where the 4 + 4 LDS-DMA pieces of an iteration sit: see DMA_PLANS
 OPT_QK = os.environ.get("Q64GEN_QK", "kb")             # order of the 32 S^T MFMAs: "kb" key block 0 first, "ks" K-step major (4 accumulators rotate)
+OPT_LAG = int(os.environ.get("Q64GEN_LAG", "0"))          # 1: a row-sum add follows its exponential one gap later (no dependent issue right behind a transcendental)
+OPT_HK = tuple(int(x) for x in os.environ.get("Q64GEN_HK", "8,9,14,15").split(","))      # half units: gaps of phase A that issue the K(T+4) pieces
+OPT_HV = tuple(int(x) for x in os.environ.get("Q64GEN_HV", "0,1,2,3").split(","))        # half units: gaps of phase B that issue the V(T+2) pieces
+OPT_DEEP = int(os.environ.get("Q64GEN_DEEP", "0"))        # 1: whole units stage K / V^T fragments four sets deep (a[192:255]) and request them TWO groups ahead, as the half units do
+OPT_V1 = int(os.environ.get("Q64GEN_V1", "0"))            # 1: the round-4 / 5 streams (two-phase loop, ring addresses in registers) for A/B builds
 OPT_DROP = set(filter(None, os.environ.get("Q64GEN_DROP", "").split(",")))     # anatomy: fill, dma, lds, bar (results are wrong without them)
 DMA_PLANS = {            # (gaps of phase A for K pieces 0..3, gaps of phase B for V pieces 0..3)
     "default": ((13, 15, 29, 31), (4, 5, 6, 7)),
@@ -68,6 +73,7 @@ class Prog:
     """instruction list; cold(): blocks that almost never run are collected and emitted behind the hot stream (the hot path stays
     dense in the instruction cache and falls through its branches)"""
     def __init__(self):
+        self.lag = []            # Q64GEN_LAG: row-sum adds waiting for the next gap
         self.out = []
         self.hot = self.out
         self.cold_blocks = []
@@ -153,6 +159,35 @@ def pv_phase(p, pbuf, fill, last4):
         fill(p, n)
 
 
+def qk_phase_d(p, lds, dst, first, fill, ahead):
+    """Q64GEN_DEEP: the 32 S^T MFMAs with four fragment sets (FRH) requested two groups ahead; K groups 0 and 1 already requested"""
+    for n in range(32):
+        kb, s, x = n >> 4, (n >> 1) & 7, n & 1
+        j = n >> 1
+        grp, q = j >> 2, j & 3
+        if n & 7 == 0:
+            lds.need(("K", grp))
+        acc = vr(S(dst, x * 2 + kb), 16)
+        c = ("0" if first else vr(NEGM[x], 16)) if s == 0 else acc
+        p.e(f"MFMA {acc}, {ar(FRH(grp, q), 4)}, {ar((QB if x else QA)(s), 4)}, {c}")
+        if (n & 7) < 4:
+            ahead(grp, n & 7)
+        fill(p, n)
+
+
+def pv_phase_d(p, lds, pbuf, fill, ahead):
+    for n in range(32):
+        kk, td, x = n >> 3, (n >> 1) & 3, n & 1
+        if n & 7 == 0:
+            lds.need(("V", kk))
+        acc = ar((OB if x else OA)(td), 16)
+        pb = vr(S(pbuf, x * 2 + (kk >> 1)) + 8 * (kk & 1), 4)
+        p.e(f"MFMA {acc}, {ar(FRH(kk, td), 4)}, {pb}, {acc}")
+        if (n & 7) < 4:
+            ahead(kk, n & 7)
+        fill(p, n)
+
+
 def frag_off(j):
     """LDS byte offset of the j-th K fragment an S^T phase consumes: (kb, s) at (kb * 8 + s) KB"""
     if OPT_QK == "ks":
@@ -172,6 +207,20 @@ def v_group0(p, vaddr):
 
 
 # ---- softmax shadow (see attention_q64.hip for the schedule)
+def flush_lag(p):
+    for t in p.lag:
+        p.e(t)
+    p.lag = []
+
+
+def row_sum(p, l, r):
+    t = f"v_add_f32 {vr(l)}, {vr(l)}, {vr(r)}"
+    if OPT_LAG:
+        p.lag.append(t)
+    else:
+        p.e(t)
+
+
 def fill_a(p, buf, n):
     """gap n of phase A: late exponential n (n < 24) + its row sum, pack n (in place)"""
     pa = 0 if n < 8 else 2 if n < 16 else 1 if n < 24 else 3
@@ -183,9 +232,11 @@ def fill_a(p, buf, n):
         ev = S(buf, ea) + er
         p.e(f"v_exp_f32 {vr(ev)}, {vr(ev)}")
         p.e(f"PK {vr(dst)}, {vr(lo)}, {vr(lo + 1)}")
-        p.e(f"v_add_f32 {vr(V_LA if ea == 1 else V_LB)}, {vr(V_LA if ea == 1 else V_LB)}, {vr(ev)}")
+        flush_lag(p)
+        row_sum(p, V_LA if ea == 1 else V_LB, ev)
     else:
         p.e(f"PK {vr(dst)}, {vr(lo)}, {vr(lo + 1)}")
+        flush_lag(p)
 
 
 def fill_b(p, buf, e):
@@ -195,8 +246,11 @@ def fill_b(p, buf, e):
     l = V_LB if a == 2 else V_LA
     p.e(f"v_exp_f32 {vr(r)}, {vr(r)}")
     p.e(f"v_exp_f32 {vr(r + 1)}, {vr(r + 1)}")
-    p.e(f"v_add_f32 {vr(l)}, {vr(l)}, {vr(r)}")
-    p.e(f"v_add_f32 {vr(l)}, {vr(l)}, {vr(r + 1)}")
+    flush_lag(p)
+    row_sum(p, l, r)
+    row_sum(p, l, r + 1)
+    if e == 19:
+        flush_lag(p)             # the last pair of a phase: nothing may stay pending across the iteration's end
 
 
 def max_step(p, buf, kb, k):
@@ -350,7 +404,11 @@ def iteration(p, cb, nb, steady, tag):
     def last4_a(p, q):
         p.e(f"ds_read_b128 {ar(FR(0, q), 4)}, {vr(V_VA)} offset:{VOFF(0, q)}")
 
-    qk_phase(p, nb, False, fa, last4_a)
+    if OPT_DEEP:
+        lds = LdsQ(p, [("K", 0)] * 4 + [("K", 1)] * 4)
+        qk_phase_d(p, lds, nb, False, fa, lambda grp, q: k_read_h(lds, grp + 2, q, V_KA) if grp < 2 else v_read_h(lds, grp - 2, q, V_VA))
+    else:
+        qk_phase(p, nb, False, fa, last4_a)
 
     def fb(p, n):
         dma_at(p, 1, n)
@@ -408,7 +466,11 @@ def iteration(p, cb, nb, steady, tag):
     def last4_b(p, q):
         p.e(f"ds_read_b128 {ar(FR(0, q), 4)}, {vr(V_KA2)} offset:{frag_off(q)}")
 
-    pv_phase(p, cb, fb, last4_b)
+    if OPT_DEEP:
+        pv_phase_d(p, lds, cb, fb, lambda kk, q: v_read_h(lds, kk + 2, q, V_VA) if kk < 2 else k_read_h(lds, kk - 2, q, V_KA2))
+        assert lds.q == [("K", 0)] * 4 + [("K", 1)] * 4
+    else:
+        pv_phase(p, cb, fb, last4_b)
     # pending rescale of O^T
     p.e(f"s_cmp_lg_u32 {sr(S_PEND)}, 0")
     p.br("s_cbranch_scc1", f"PEND{tag}")
@@ -454,6 +516,13 @@ def tail(p, cb):
     for n in range(32):
         fill_a(p, cb, n)
     p.e(f"v_add_u32_e32 {vr(V_VA)}, {sr(S_VS0)}, {vr(V_L16)}")
+    if OPT_DEEP:
+        lds = LdsQ(p, ["old"] * 8)
+        for g in range(2):
+            for q in range(4):
+                v_read_h(lds, g, q, V_VA)
+        pv_phase_d(p, lds, cb, lambda p, n: None, lambda kk, q: v_read_h(lds, kk + 2, q, V_VA) if kk < 2 else None)
+        return
     v_group0(p, V_VA)
     pv_phase(p, cb, lambda p, n: None, lambda p, q: None)
 
@@ -497,13 +566,20 @@ def core():
     p.e("s_barrier")
     # ---- tile 0: scores with a zero seed (the O^T accumulators are zeroed in its gaps), first reference maximum, early exponentials
     kslot_addr(p, V_KA, 0)
-    k_group0(p, V_KA)
 
     def f0(p, n):
         for k in range(4):
             p.e(f"v_accvgpr_write_b32 {ar(4 * n + k)}, 0")
 
-    qk_phase(p, 0, True, f0, lambda p, q: None)
+    if OPT_DEEP:
+        lds0 = LdsQ(p)
+        for g in range(2):
+            for q in range(4):
+                k_read_h(lds0, g, q, V_KA)
+        qk_phase_d(p, lds0, 0, True, f0, lambda grp, q: k_read_h(lds0, grp + 2, q, V_KA) if grp < 2 else None)
+    else:
+        k_group0(p, V_KA)
+        qk_phase(p, 0, True, f0, lambda p, q: None)
     p.e("s_nop 15")
     p.e("s_nop 7")
     p.e(f"s_lshl_b32 {sr(S_X0)}, {sr(S_T)}, 6")
@@ -534,7 +610,12 @@ def core():
     p.e("s_cmp_lt_i32 %[nt], 2")
     p.br("s_cbranch_scc1", "TAIL_E")
     kslot_addr(p, V_KA2, 1)
-    k_group0(p, V_KA2)
+    if OPT_DEEP:
+        for g in range(2):
+            for q in range(4):
+                p.e(f"ds_read_b128 {ar(FRH(g, q), 4)}, {vr(V_KA2)} offset:{(4 * g + q) * 1024}")
+    else:
+        k_group0(p, V_KA2)
     # ---- the loop: even iterations have the current tile in buffer 0, odd ones in buffer 1
     for par, (cb, nb) in enumerate(((0, 1), (1, 0))):
         me, other = "EO"[par], "OE"[par]
@@ -650,8 +731,9 @@ def late_h(p, cb, n):
     for r in ev:
         p.e(f"v_exp_f32 {vr(r)}, {vr(r)}")
     p.e(f"PK {vr(dst)}, {vr(lo)}, {vr(lo + 1)}")
+    flush_lag(p)
     for r in ev:
-        p.e(f"v_add_f32 {vr(V_LA)}, {vr(V_LA)}, {vr(r)}")
+        row_sum(p, V_LA, r)
 
 
 def early_h(p, buf, e):
@@ -659,8 +741,11 @@ def early_h(p, buf, e):
     r = S(buf, 0) + 2 * e
     p.e(f"v_exp_f32 {vr(r)}, {vr(r)}")
     p.e(f"v_exp_f32 {vr(r + 1)}, {vr(r + 1)}")
-    p.e(f"v_add_f32 {vr(V_LA)}, {vr(V_LA)}, {vr(r)}")
-    p.e(f"v_add_f32 {vr(V_LA)}, {vr(V_LA)}, {vr(r + 1)}")
+    flush_lag(p)
+    row_sum(p, V_LA, r)
+    row_sum(p, V_LA, r + 1)
+    if e == 6:
+        flush_lag(p)
 
 
 def mask_tile_h(p, buf, s_tile64):
@@ -675,8 +760,8 @@ def mask_tile_h(p, buf, s_tile64):
             p.e(f"v_cndmask_b32 {vr(reg)}, {vr(reg)}, {vr(V_NINF)}, vcc")
 
 
-H_K_GAPS = (8, 9, 14, 15)       # gaps of phase A that issue the four K(T+4) pieces
-H_V_GAPS = (0, 1, 2, 3)         # gaps of phase B that issue the four V(T+2) pieces
+H_K_GAPS = OPT_HK               # gaps of phase A that issue the four K(T+4) pieces
+H_V_GAPS = OPT_HV               # gaps of phase B that issue the four V(T+2) pieces
 
 
 def iteration_h(p, cb, nb, steady, tag):
@@ -970,6 +1055,583 @@ def core_h():
     return p
 
 
+
+# ================================================================================================================== v2 streams
+# Round 6.  tools/valubench says what a lone wave pays per instruction between its MFMAs (32 cycles each): a plain VALU ~5.7, a VALU
+# that depends on the one before ~8.5, v_exp ~9.5, ANY scalar ALU instruction ~8.5.  The v1 iteration issued ~50 scalar instructions
+# per key tile (ring-slot addresses, soffsets, V-slot rotation, two counters, loop dispatch) and its 64 row-sum adds were one dependent
+# chain per query block - ~500 cycles over the 2 048 of the tile's MFMAs, exactly what the stamps showed (2 554).  v2:
+#   * the loop is unrolled over the FOUR ring slots (phase p = tile & 3, unit-relative): K / V^T slot addresses are immediates of the
+#     ds_read / of one s_add into M0 - no address registers; the V^T ring has four slots too (its fourth aliases the output stage, which
+#     is only live between a unit's last barrier and the next unit's first), so nothing rotates;
+#   * steady iterations (five or more to go) advance the DMA soffsets by one add each, never clamp, never mask; one counter (REM);
+#   * the pending O^T rescale after a reference-maximum move is the VCC of the move test itself (s_cbranch_vccnz), not a flag register;
+#     the cross-half maximum of the running maxima is only taken inside the (cold) move;
+#   * row sums go to two accumulators per block alternately, and an add follows its exponential one gap later;
+#   * fragments are staged four sets deep and requested two groups ahead in both unit shapes.
+# One generator for both unit shapes: NB = 2 (whole: blocks A and B) / 1 (half: block A).
+V2_LA = (184, 185)       # row-sum accumulators of block A
+V2_LB = (186, 187)
+V2_L16V = 188            # lane16 + 64 KB: base of the V^T ring reads
+V2_TOP = 189
+S_REM = 40               # iterations left (including the current one at its start)
+S2_TOP = 57
+
+
+class StreamV2:
+    def __init__(self, NB, pfx):
+        self.NB, self.G, self.pfx = NB, 16 * NB, pfx
+        self.sum_i = [0, 0]
+
+    # ---- small helpers
+    def L(self, name): return f"{self.pfx}{name}"
+
+    def row_sum(self, p, x, r):
+        acc = (V2_LA, V2_LB)[x][self.sum_i[x] & 1]
+        self.sum_i[x] += 1
+        p.lag.append(f"v_add_f32 {vr(acc)}, {vr(acc)}, {vr(r)}")
+
+    def exp(self, p, x, r):
+        p.e(f"v_exp_f32 {vr(r)}, {vr(r)}")
+        self.row_sum(p, x, r)
+
+    def k_read(self, lds, slot, grp, q):
+        lds.read(("K", grp), f"ds_read_b128 {ar(FRH(grp, q), 4)}, {vr(V_L16)} offset:{slot * TILE + (4 * grp + q) * 1024}")
+
+    def v_read(self, lds, slot, grp, q):
+        lds.read(("V", grp), f"ds_read_b128 {ar(FRH(grp, q), 4)}, {vr(V2_L16V)} offset:{slot * TILE + VOFF(grp, q)}")
+
+    def qk(self, p, lds, dst, first, fill, ahead):
+        NB = self.NB
+        for n in range(self.G):
+            if NB == 2:
+                kb, s_, x, j = n >> 4, (n >> 1) & 7, n & 1, n >> 1
+            else:
+                kb, s_, x, j = n >> 3, n & 7, 0, n
+            grp, q = j >> 2, j & 3
+            if n % (4 * NB) == 0:
+                lds.need(("K", grp))
+            acc = vr(S(dst, 2 * x + kb), 16)
+            c = ("0" if first else vr(NEGM[x], 16)) if s_ == 0 else acc
+            p.e(f"MFMA {acc}, {ar(FRH(grp, q), 4)}, {ar((QB if x else QA)(s_), 4)}, {c}")
+            if n % (4 * NB) < 4:
+                ahead(grp, n % (4 * NB))
+            fill(n)
+
+    def pv(self, p, lds, pbuf, fill, ahead):
+        NB = self.NB
+        for n in range(self.G):
+            if NB == 2:
+                kk, td, x = n >> 3, (n >> 1) & 3, n & 1
+            else:
+                kk, td, x = n >> 2, n & 3, 0
+            if n % (4 * NB) == 0:
+                lds.need(("V", kk))
+            acc = ar((OB if x else OA)(td), 16)
+            pb = vr(S(pbuf, 2 * x + (kk >> 1)) + 8 * (kk & 1), 4)
+            p.e(f"MFMA {acc}, {ar(FRH(kk, td), 4)}, {pb}, {acc}")
+            if n % (4 * NB) < 4:
+                ahead(kk, n % (4 * NB))
+            fill(n)
+
+    def max_step(self, p, buf, kb, k):
+        for X in range(self.NB):
+            c, b = V_C[2 * X + kb], S(buf, 2 * X + kb)
+            if k == 0:
+                p.e(f"v_max3_f32 {vr(c)}, {vr(b)}, {vr(b + 1)}, {vr(b + 2)}")
+            else:
+                p.e(f"v_max3_f32 {vr(c)}, {vr(c)}, {vr(b + 2 * k + 1)}, {vr(b + 2 * k + 2)}")
+
+    def max_last(self, p, buf, dA, dB):
+        p.e(f"v_max3_f32 {vr(dA)}, {vr(V_C[0])}, {vr(V_C[1])}, {vr(S(buf, 0) + 15)}")
+        if self.NB == 2:
+            p.e(f"v_max3_f32 {vr(dB)}, {vr(V_C[2])}, {vr(V_C[3])}, {vr(S(buf, 2) + 15)}")
+        p.e(f"v_max_f32 {vr(dA)}, {vr(dA)}, {vr(S(buf, 1) + 15)}")
+        if self.NB == 2:
+            p.e(f"v_max_f32 {vr(dB)}, {vr(dB)}, {vr(S(buf, 3) + 15)}")
+
+    def mask(self, p, buf, s_tile64):
+        p.e(f"v_mov_b32 {vr(V_NINF)}, 0xff800000")
+        p.e(f"s_sub_i32 {sr(S_X1)}, %[N], {sr(s_tile64)}")
+        for kb in range(2):
+            for r in range(16):
+                const = kb * 32 + (r & 3) + 8 * (r >> 2)
+                p.e(f"s_sub_i32 {sr(S_X2)}, {sr(S_X1)}, {const}")
+                p.e(f"v_cmp_ge_i32 vcc, {vr(V_HH4)}, {sr(S_X2)}")
+                for X in range(self.NB):
+                    reg = S(buf, 2 * X + kb) + r
+                    p.e(f"v_cndmask_b32 {vr(reg)}, {vr(reg)}, {vr(V_NINF)}, vcc")
+
+    # ---- softmax shadow
+    def late(self, p, cb, n):
+        """gap n of phase A: late exponentials of tile T (+ their lagged row sums) and pack n, in place"""
+        flush_lag(p)
+        if self.NB == 2:
+            pa = 0 if n < 8 else 2 if n < 16 else 1 if n < 24 else 3
+            pi = n & 7
+            if n < 24:
+                ea, er = (1, 8 + n) if n < 8 else (3, n - 8)
+                self.exp(p, ea >> 1, S(cb, ea) + er)
+        else:
+            a1 = S(cb, 1)
+            for r in ([a1, a1 + 1] if n == 0 else [a1 + n + 1] if n <= 14 else []):
+                self.exp(p, 0, r)
+            pa, pi = (0, n) if n < 8 else (1, n - 8)
+        lo, dst = S(cb, pa) + 2 * pi, S(cb, pa) + 8 * (pi >> 2) + (pi & 3)
+        p.e(f"PK {vr(dst)}, {vr(lo)}, {vr(lo + 1)}")
+        if n == self.G - 1:
+            flush_lag(p)
+
+    N_EARLY = {2: 20, 1: 8}
+
+    def early(self, p, buf, e):
+        """early exponentials of tile T + 1, pair e: whole: (A, kb 0) 0..7, (B, kb 0) 8..15, (A, kb 1, registers 0..7) 16..19; half: (A, kb 0) 0..7"""
+        flush_lag(p)
+        if self.NB == 2:
+            a = 0 if e < 8 else 2 if e < 16 else 1
+        else:
+            a = 0
+        r = S(buf, a) + 2 * (e & 7)
+        self.exp(p, a >> 1, r)
+        self.exp(p, a >> 1, r + 1)
+        if e == self.N_EARLY[self.NB] - 1:
+            flush_lag(p)
+
+    # ---- schedule tables: gaps of the phases
+    def sched(self):
+        if self.NB == 2:
+            return dict(max0=range(24, 31), k_dma=(13, 15, 29, 31), v_dma=(1, 2, 3, 4), max1=[(g, (g - 2,)) for g in range(2, 9)], last=9, test=10, early0=12)
+        return dict(max0=None, k_dma=(8, 9, 14, 15), v_dma=(1, 2, 3, 4), max1=[(2, (0, 1)), (3, (2, 3)), (4, (4, 5)), (5, (6,))], last=5, test=6, early0=7)
+
+    def iteration(self, p, ph, steady):
+        """iteration IT with IT & 3 == ph: phase A S(IT+1) = K(IT+1) Q^T - m, phase B O^T += V^T(IT) P(IT)^T"""
+        NB, G, sc = self.NB, self.G, self.sched()
+        cb, nb = ph & 1, (ph & 1) ^ 1
+        tag = f"{'SD'[0 if steady else 1]}{ph}"
+        kslot_r, kslot_la, vslot_r = (ph + 1) & 3, (ph + 2) & 3, ph
+        kdst, vdst = ph * TILE, V_RING + ((ph + 2) & 3) * TILE
+        lds = LdsQ(p, [("K", 0)] * 4 + [("K", 1)] * 4)
+        if not steady:
+            # T = tlo + nt - 1 - REM (absolute index of the current tile); which of this iteration's requests exist
+            p.e(f"s_sub_i32 {sr(S_T)}, %[nt], {sr(S_REM)}")
+            p.e(f"s_add_i32 {sr(S_T)}, {sr(S_T)}, %[tlo]")
+            p.e(f"s_sub_i32 {sr(S_T)}, {sr(S_T)}, 1")
+            p.e(f"s_cmp_gt_i32 {sr(S_REM)}, 3")
+            p.e(f"s_cselect_b32 {sr(S_HK)}, 1, 0")
+            p.e(f"s_cmp_gt_i32 {sr(S_REM)}, 1")
+            p.e(f"s_cselect_b32 {sr(S_HV)}, 1, 0")
+
+        def dma(rs, soff, j, flag, name):
+            if steady:
+                dma_piece(p, rs, soff, j)
+            else:
+                p.e(f"s_cmp_eq_u32 {sr(flag)}, 0")
+                p.br("s_cbranch_scc1", self.L(name))
+                dma_piece(p, rs, soff, j)
+                p.label(self.L(name))
+
+        def fa(n):
+            self.late(p, cb, n)
+            if NB == 2:
+                if n in sc["max0"]:
+                    self.max_step(p, nb, 0, n - sc["max0"][0])
+            else:
+                if 10 <= n <= 15:
+                    self.max_step(p, nb, 0, n - 10)
+                if n == 15:
+                    self.max_step(p, nb, 0, 6)
+            if steady:
+                if n == 0:
+                    p.e(f"s_add_i32 {sr(S_SOFFK)}, {sr(S_SOFFK)}, {TILE}")
+                if n == 2:
+                    p.e(f"s_sub_i32 {sr(S_REM)}, {sr(S_REM)}, 1")
+                if n == 3:
+                    p.e(f"s_add_i32 {sr(S_SOFFV)}, {sr(S_SOFFV)}, {TILE}")
+            else:
+                if n == 0:
+                    soff_of(p, S_SOFFK, S_T, 4)
+                if n == 2:
+                    p.e(f"s_sub_i32 {sr(S_REM)}, {sr(S_REM)}, 1")
+                if n == 3:
+                    soff_of(p, S_SOFFV, S_T, 2)
+            if n == 1:
+                p.e(f"s_add_i32 m0, %[dbase], {kdst}")
+            for j, g in enumerate(sc["k_dma"]):
+                if g == n:
+                    dma("%[rk]", S_SOFFK, j, S_HK, f"KK{tag}{j}")
+
+        def ahead_a(grp, q):
+            if grp < 2:
+                self.k_read(lds, kslot_r, grp + 2, q)
+            else:
+                self.v_read(lds, vslot_r, grp - 2, q)
+
+        self.qk(p, lds, nb, False, fa, ahead_a)
+
+        def fb(n):
+            if n == 0:
+                p.e(f"s_add_i32 m0, %[dbase], {vdst}")
+            for j, g in enumerate(sc["v_dma"]):
+                if g == n:
+                    dma("%[rv]", S_SOFFV, j, S_HV, f"KV{tag}{j}")
+            if n == 2 and not steady:
+                # the next tile may be the last of the sequence and ragged: mask its keys >= N
+                p.e(f"s_add_i32 {sr(S_X0)}, {sr(S_T)}, 1")
+                p.e(f"s_lshl_b32 {sr(S_X0)}, {sr(S_X0)}, 6")
+                p.e(f"s_add_i32 {sr(S_X1)}, {sr(S_X0)}, 64")
+                p.e(f"s_cmp_gt_i32 {sr(S_X1)}, %[N]")
+                p.br("s_cbranch_scc1", self.L(f"MASK{tag}"))
+                p.label(self.L(f"NOMASK{tag}"))
+                p.begin_cold(self.L(f"MASK{tag}"), self.L(f"NOMASK{tag}"))
+                p.e("s_nop 7")
+                self.mask(p, nb, S_X0)
+                p.end_cold()
+            for g, ks in sc["max1"]:
+                if g == n:
+                    for k in ks:
+                        self.max_step(p, nb, 1, k)
+            if n == sc["last"]:
+                self.max_last(p, nb, V_MXA, V_MXB)
+            if n == sc["test"]:
+                if NB == 2:
+                    p.e(f"v_max_f32 {vr(V_T0)}, {vr(V_MXA)}, {vr(V_MXB)}")
+                    p.e(f"v_cmp_lt_f32 vcc, 0x41000000, {vr(V_T0)}")           # 8.0 < max (any lane: the halves are only combined in the move)
+                else:
+                    p.e(f"v_cmp_lt_f32 vcc, 0x41000000, {vr(V_MXA)}")
+                p.br("s_cbranch_vccnz", self.L(f"MOVE{tag}"))
+                p.label(self.L(f"NOMOVE{tag}"))
+                p.begin_cold(self.L(f"MOVE{tag}"), self.L(f"NOMOVE{tag}"))
+                # ---- the reference maximum moves (rare): scores of tile T+1, seeds, row sums now; O^T after this phase's MFMAs (VCC stays set)
+                xhalf_max(p, V_MXA, V_T0)
+                if NB == 2:
+                    xhalf_max(p, V_MXB, V_T1)
+                p.e(f"v_max_f32 {vr(V_T0)}, 0, {vr(V_MXA)}")
+                p.e(f"v_add_f32 {vr(V_MA)}, {vr(V_MA)}, {vr(V_T0)}")
+                p.e(f"v_exp_f32 {vr(V_ALA)}, -{vr(V_T0)}")
+                if NB == 2:
+                    p.e(f"v_max_f32 {vr(V_T1)}, 0, {vr(V_MXB)}")
+                    p.e(f"v_add_f32 {vr(V_MB)}, {vr(V_MB)}, {vr(V_T1)}")
+                    p.e(f"v_exp_f32 {vr(V_ALB)}, -{vr(V_T1)}")
+                p.e("s_nop 0")
+                for X in range(NB):
+                    for acc in (V2_LA, V2_LB)[X]:
+                        p.e(f"v_mul_f32 {vr(acc)}, {vr(acc)}, {vr((V_ALA, V_ALB)[X])}")
+                for X in range(NB):
+                    for kb in range(2):
+                        for r in range(16):
+                            reg = S(nb, 2 * X + kb) + r
+                            p.e(f"v_sub_f32 {vr(reg)}, {vr(reg)}, {vr((V_T0, V_T1)[X])}")
+                for r in range(16):
+                    for X in range(NB):
+                        p.e(f"v_sub_f32 {vr(NEGM[X] + r)}, 0, {vr((V_MA, V_MB)[X])}")
+                p.end_cold()
+            if n >= sc["early0"] and n - sc["early0"] < self.N_EARLY[NB]:
+                self.early(p, nb, n - sc["early0"])
+
+        def ahead_b(kk, q):
+            if kk < 2:
+                self.v_read(lds, vslot_r, kk + 2, q)
+            else:
+                self.k_read(lds, kslot_la, kk - 2, q)
+
+        self.pv(p, lds, cb, fb, ahead_b)
+        assert lds.q == [("K", 0)] * 4 + [("K", 1)] * 4 and not p.lag
+        # pending rescale of O^T: the move test's VCC
+        p.br("s_cbranch_vccnz", self.L(f"PEND{tag}"))
+        p.label(self.L(f"NOPEND{tag}"))
+        p.begin_cold(self.L(f"PEND{tag}"), self.L(f"NOPEND{tag}"))
+        p.e("s_nop 15")
+        p.e("s_nop 7")
+        for k in range(64 * NB):
+            p.e(f"v_accvgpr_read_b32 {vr(V_T0)}, {ar(k)}")
+            p.e(f"v_mul_f32 {vr(V_T0)}, {vr(V_T0)}, {vr(V_ALA if k < 64 else V_ALB)}")
+            p.e(f"v_accvgpr_write_b32 {ar(k)}, {vr(V_T0)}")
+        p.e("s_nop 3")
+        p.end_cold()
+        if steady:
+            p.e("s_waitcnt vmcnt(8)")
+        else:
+            p.e(f"s_cmp_eq_u32 {sr(S_HK)}, 0")
+            p.br("s_cbranch_scc1", self.L(f"W4{tag}"))
+            p.e("s_waitcnt vmcnt(8)")
+            p.br("s_branch", self.L(f"WD{tag}"))
+            p.label(self.L(f"W4{tag}"))
+            p.e(f"s_cmp_eq_u32 {sr(S_HV)}, 0")
+            p.br("s_cbranch_scc1", self.L(f"W0{tag}"))
+            p.e("s_waitcnt vmcnt(4)")
+            p.br("s_branch", self.L(f"WD{tag}"))
+            p.label(self.L(f"W0{tag}"))
+            p.e("s_waitcnt vmcnt(0)")
+            p.label(self.L(f"WD{tag}"))
+        p.e("s_barrier")
+
+    def tail(self, p, ph):
+        """the sequence's last tile (IT & 3 == ph): late exponentials + packs, then its O^T MFMAs"""
+        cb = ph & 1
+        self.sum_i = [0, 0]
+        for n in range(self.G):
+            self.late(p, cb, n)
+        lds = LdsQ(p, ["old"] * 8)
+        for g in range(2):
+            for q in range(4):
+                self.v_read(lds, ph, g, q)
+        self.pv(p, lds, cb, lambda n: None, lambda kk, q: self.v_read(lds, ph, kk + 2, q) if kk < 2 else None)
+
+    def core(self):
+        NB = self.NB
+        p = Prog()
+        if NB == 1:
+            p.label("HCORE")
+        else:
+            # the stream of this WAVE (%[half]): 0 both query blocks, 1 block A only, 2 no live block (requests and barriers only)
+            p.e("s_cmp_eq_u32 %[half], 1")
+            p.br("s_cbranch_scc1", "HCORE")
+            p.e("s_cmp_eq_u32 %[half], 2")
+            p.br("s_cbranch_scc1", "PCORE")
+        p.e(f"v_mov_b32 {vr(V_L16)}, %[lane16]")
+        p.e(f"v_add_u32_e32 {vr(V2_L16V)}, {V_RING}, {vr(V_L16)}")
+        p.e(f"v_mov_b32 {vr(V_VOFF)}, %[vlane]")
+        p.e(f"v_mov_b32 {vr(V_HH4)}, %[hh4]")
+        for X in range(NB):
+            for acc in (V2_LA, V2_LB)[X]:
+                p.e(f"v_mov_b32 {vr(acc)}, 0")
+        p.e(f"s_sub_i32 {sr(S_REM)}, %[nt], 1")
+        p.e(f"s_mov_b32 {sr(S_T)}, %[tlo]")
+        p.e(f"s_sub_i32 {sr(S_NT32M1)}, %[nt32], 1")
+        # steady soffsets: K(IT + 4) / V(IT + 2) of iteration IT after its add
+        p.e(f"s_lshl_b32 {sr(S_X0)}, %[tlo], 14")
+        p.e(f"s_lshl_b32 {sr(S_X1)}, %[wh], 13")
+        p.e(f"s_add_i32 {sr(S_X0)}, {sr(S_X0)}, {sr(S_X1)}")
+        p.e(f"s_add_i32 {sr(S_X0)}, {sr(S_X0)}, %[wq]")
+        p.e(f"s_add_i32 {sr(S_SOFFK)}, {sr(S_X0)}, {3 * TILE}")
+        p.e(f"s_add_i32 {sr(S_SOFFV)}, {sr(S_X0)}, {1 * TILE}")
+        # ---- the unit's first requests but K(3) have landed (Q too); a finished unit's stores may fly on (whole: >= 16 behind a whole
+        # unit; half: >= 8, a half unit's one block in 16-bit rows - and a half unit never precedes a whole one)
+        st = 8        # stores a finished unit's wave has issued at least (one block in 16-bit rows: the wave may have run the half / passive stream)
+        p.e("s_cmp_eq_u32 %[first], 0")
+        p.br("s_cbranch_scc1", self.L("WNF"))
+        p.e("s_cmp_gt_i32 %[nt], 3")
+        p.br("s_cbranch_scc1", self.L("WF4"))
+        p.e("s_waitcnt vmcnt(0)")
+        p.br("s_branch", self.L("WDONE"))
+        p.label(self.L("WF4"))
+        p.e("s_waitcnt vmcnt(4)")
+        p.br("s_branch", self.L("WDONE"))
+        p.label(self.L("WNF"))
+        p.e("s_cmp_gt_i32 %[nt], 3")
+        p.br("s_cbranch_scc1", self.L("WN4"))
+        p.e(f"s_waitcnt vmcnt({st})")
+        p.br("s_branch", self.L("WDONE"))
+        p.label(self.L("WN4"))
+        p.e(f"s_waitcnt vmcnt({st + 4})")
+        p.label(self.L("WDONE"))
+        p.e("s_barrier")
+        # ---- tile 0: scores with a zero seed (the O^T accumulators are zeroed in its gaps), first reference maximum, early exponentials
+        lds = LdsQ(p)
+        for g in range(2):
+            for q in range(4):
+                self.k_read(lds, 0, g, q)
+
+        def f0(n):
+            for k in range(4):
+                p.e(f"v_accvgpr_write_b32 {ar(4 * n + k)}, 0")
+
+        self.qk(p, lds, 0, True, f0, lambda grp, q: self.k_read(lds, 0, grp + 2, q) if grp < 2 else None)
+        p.e("s_nop 15")
+        p.e("s_nop 7")
+        p.e(f"s_lshl_b32 {sr(S_X0)}, {sr(S_T)}, 6")
+        p.e(f"s_add_i32 {sr(S_X1)}, {sr(S_X0)}, 64")
+        p.e(f"s_cmp_gt_i32 {sr(S_X1)}, %[N]")
+        p.br("s_cbranch_scc1", self.L("MASK0"))
+        p.label(self.L("NOMASK0"))
+        p.begin_cold(self.L("MASK0"), self.L("NOMASK0"))
+        self.mask(p, 0, S_X0)
+        p.end_cold()
+        for k in range(7):
+            self.max_step(p, 0, 0, k)
+            self.max_step(p, 0, 1, k)
+        self.max_last(p, 0, V_MA, V_MB)
+        xhalf_max(p, V_MA, V_T0)
+        if NB == 2:
+            xhalf_max(p, V_MB, V_T1)
+        for X in range(NB):
+            for kb in range(2):
+                for r in range(16):
+                    reg = S(0, 2 * X + kb) + r
+                    p.e(f"v_sub_f32 {vr(reg)}, {vr(reg)}, {vr((V_MA, V_MB)[X])}")
+        for r in range(16):
+            for X in range(NB):
+                p.e(f"v_sub_f32 {vr(NEGM[X] + r)}, 0, {vr((V_MA, V_MB)[X])}")
+        self.sum_i = [0, 0]
+        for e in range(self.N_EARLY[NB]):
+            self.early(p, 0, e)
+        p.e("s_barrier")                                                       # every wave has read K(0): its slot may take K(4)
+        p.e(f"s_cmp_lt_i32 {sr(S_REM)}, 1")
+        p.br("s_cbranch_scc1", self.L("TAIL_0"))
+        for g in range(2):                                                     # K(1) groups 0, 1 for the first iteration
+            for q in range(4):
+                p.e(f"ds_read_b128 {ar(FRH(g, q), 4)}, {vr(V_L16)} offset:{1 * TILE + (4 * g + q) * 1024}")
+        # ---- the loop, unrolled over the four ring phases; steady bodies fall through into each other
+        p.e(f"s_cmp_lt_i32 {sr(S_REM)}, 5")
+        p.br("s_cbranch_scc1", self.L("DRAIN_0"))
+        for ph in range(4):
+            p.label(self.L(f"STEADY_{ph}"))
+            self.sum_i = [0, 0]
+            self.iteration(p, ph, True)
+            if ph < 3:
+                p.e(f"s_cmp_lt_i32 {sr(S_REM)}, 5")
+                p.br("s_cbranch_scc1", self.L(f"ENTRY_{ph + 1}"))
+            else:
+                p.e(f"s_cmp_gt_i32 {sr(S_REM)}, 4")
+                p.br("s_cbranch_scc1", self.L("STEADY_0"))
+        for ph in (0, 1, 2, 3):                                                # (ENTRY_0 first: STEADY_3 falls into it)
+            p.label(self.L(f"ENTRY_{ph}"))
+            p.e(f"s_cmp_lt_i32 {sr(S_REM)}, 1")
+            p.br("s_cbranch_scc1", self.L(f"TAIL_{ph}"))
+            p.label(self.L(f"DRAIN_{ph}"))
+            self.sum_i = [0, 0]
+            self.iteration(p, ph, False)
+            if ph == 3:
+                p.br("s_branch", self.L("ENTRY_0"))
+        for ph in range(4):
+            p.label(self.L(f"TAIL_{ph}"))
+            self.tail(p, ph)
+            if ph < 3:
+                p.br("s_branch", self.L("END"))
+        p.label(self.L("END"))
+        p.e("s_barrier")                                                       # the rings are free for the next unit's first requests
+        p.e("s_nop 15")
+        p.e("s_nop 7")
+        p.e(f"v_add_f32 %[o_la], {vr(V2_LA[0])}, {vr(V2_LA[1])}")
+        p.e(f"v_mov_b32 %[o_ma], {vr(V_MA)}")
+        if NB == 2:
+            p.e(f"v_add_f32 %[o_lb], {vr(V2_LB[0])}, {vr(V2_LB[1])}")
+            p.e(f"v_mov_b32 %[o_mb], {vr(V_MB)}")
+        else:
+            p.e("v_mov_b32 %[o_lb], 0")
+            p.e("v_mov_b32 %[o_mb], 0")
+        p.br("s_branch", "EXIT")
+        p.finish()
+        return p
+
+
+def passive_v2():
+    """the stream of a wave without a live query block (a ragged unit's waves past the last block): its share of the tile requests and
+    every barrier of the unit, nothing else - no MFMA, no LDS read, no softmax (the chip is power-limited under dense MFMA: garbage
+    blocks cost everybody clock)"""
+    p = Prog()
+    p.label("PCORE")
+    p.e(f"v_mov_b32 {vr(V_VOFF)}, %[vlane]")
+    p.e(f"s_sub_i32 {sr(S_REM)}, %[nt], 1")
+    p.e(f"s_sub_i32 {sr(S_NT32M1)}, %[nt32], 1")
+    p.e("s_cmp_eq_u32 %[first], 0")
+    p.br("s_cbranch_scc1", "PWNF")
+    p.e("s_waitcnt vmcnt(0)")
+    p.br("s_branch", "PWDONE")
+    p.label("PWNF")
+    p.e("s_waitcnt vmcnt(8)")
+    p.label("PWDONE")
+    p.e("s_barrier")                      # (core start)
+    p.e("s_barrier")                      # (tile 0 read)
+    p.label("PLOOP")
+    p.e(f"s_cmp_lt_i32 {sr(S_REM)}, 1")
+    p.br("s_cbranch_scc1", "PEND_")
+    # T = tlo + nt - 1 - REM, IT = nt - 1 - REM
+    p.e(f"s_sub_i32 {sr(S_X2)}, %[nt], {sr(S_REM)}")
+    p.e(f"s_sub_i32 {sr(S_X2)}, {sr(S_X2)}, 1")                    # IT
+    p.e(f"s_add_i32 {sr(S_T)}, {sr(S_X2)}, %[tlo]")
+    p.e(f"s_cmp_gt_i32 {sr(S_REM)}, 3")
+    p.br("s_cbranch_scc0", "PNOK")
+    soff_of(p, S_SOFFK, S_T, 4)
+    p.e(f"s_and_b32 {sr(S_X0)}, {sr(S_X2)}, 3")
+    p.e(f"s_lshl_b32 {sr(S_X0)}, {sr(S_X0)}, 14")
+    p.e(f"s_add_i32 m0, {sr(S_X0)}, %[dbase]")
+    p.e("s_nop 0")
+    for j in range(4):
+        dma_piece(p, "%[rk]", S_SOFFK, j)
+    p.label("PNOK")
+    p.e(f"s_cmp_gt_i32 {sr(S_REM)}, 1")
+    p.br("s_cbranch_scc0", "PNOV")
+    soff_of(p, S_SOFFV, S_T, 2)
+    p.e(f"s_add_i32 {sr(S_X0)}, {sr(S_X2)}, 2")
+    p.e(f"s_and_b32 {sr(S_X0)}, {sr(S_X0)}, 3")
+    p.e(f"s_lshl_b32 {sr(S_X0)}, {sr(S_X0)}, 14")
+    p.e(f"s_add_i32 {sr(S_X0)}, {sr(S_X0)}, {V_RING}")
+    p.e(f"s_add_i32 m0, {sr(S_X0)}, %[dbase]")
+    p.e("s_nop 0")
+    for j in range(4):
+        dma_piece(p, "%[rv]", S_SOFFV, j)
+    p.label("PNOV")
+    # everything issued before this iteration has landed (the pieces of this iteration: 8, 4 or none)
+    p.e(f"s_cmp_gt_i32 {sr(S_REM)}, 3")
+    p.br("s_cbranch_scc1", "PW8")
+    p.e(f"s_cmp_gt_i32 {sr(S_REM)}, 1")
+    p.br("s_cbranch_scc1", "PW4")
+    p.e("s_waitcnt vmcnt(0)")
+    p.br("s_branch", "PWD")
+    p.label("PW4")
+    p.e("s_waitcnt vmcnt(4)")
+    p.br("s_branch", "PWD")
+    p.label("PW8")
+    p.e("s_waitcnt vmcnt(8)")
+    p.label("PWD")
+    p.e("s_barrier")
+    p.e(f"s_sub_i32 {sr(S_REM)}, {sr(S_REM)}, 1")
+    p.br("s_branch", "PLOOP")
+    p.label("PEND_")
+    p.e("s_barrier")
+    p.e("v_mov_b32 %[o_la], 0")
+    p.e("v_mov_b32 %[o_ma], 0")
+    p.e("v_mov_b32 %[o_lb], 0")
+    p.e("v_mov_b32 %[o_mb], 0")
+    p.label("EXIT")
+    return p
+
+
+def prologue_v2():
+    """a unit's first requests: K(0), Q (straight into a[128:191]; a half unit - %[half] - block A only), V(0), K(1), V(1), K(2), K(3);
+    tile i of the unit goes to ring slot i"""
+    p = Prog()
+    X0, X2 = 40, 42
+
+    def tile(rs, add, dst):
+        p.e(f"s_add_i32 {sr(X0)}, %[tlo], {add}")
+        p.e(f"s_lshl_b32 {sr(X0)}, {sr(X0)}, 1")
+        p.e(f"s_add_i32 {sr(X0)}, {sr(X0)}, %[wh]")
+        p.e(f"s_min_i32 {sr(X0)}, {sr(X0)}, {sr(X2)}")
+        p.e(f"s_lshl_b32 {sr(X0)}, {sr(X0)}, 13")
+        p.e(f"s_add_i32 {sr(X0)}, {sr(X0)}, %[wq]")
+        p.e(f"s_add_i32 m0, %[dbase], {dst}")
+        p.e("s_nop 0")
+        for j in range(4):
+            p.e(f"buffer_load_dwordx4 %[vlane], {rs}, {sr(X0)} offen offset:{j * 1024} lds")
+
+    p.e(f"s_sub_i32 {sr(X2)}, %[nt32], 1")
+    tile("%[rk]", 0, 0)
+    p.e("v_add_u32_e32 v0, 0x1000, %[qa]")
+    p.e("v_add_u32_e32 v1, 0x1000, %[qb]")
+    for s_ in range(8):
+        p.e(f"global_load_dwordx4 {ar(QA(s_), 4)}, {'%[qa]' if s_ < 4 else 'v0'}, %[qbase] offset:{(s_ & 3) * 1024}")
+    p.e("s_cmp_lg_u32 %[half], 0")
+    p.br("s_cbranch_scc1", "NOQB")
+    for s_ in range(8):
+        p.e(f"global_load_dwordx4 {ar(QB(s_), 4)}, {'%[qb]' if s_ < 4 else 'v1'}, %[qbase] offset:{(s_ & 3) * 1024}")
+    p.label("NOQB")
+    tile("%[rv]", 0, V_RING)
+    p.e("s_cmp_lt_i32 %[nt], 2")
+    p.br("s_cbranch_scc1", "PDONE")
+    tile("%[rk]", 1, TILE)
+    tile("%[rv]", 1, V_RING + TILE)
+    p.e("s_cmp_lt_i32 %[nt], 3")
+    p.br("s_cbranch_scc1", "PDONE")
+    tile("%[rk]", 2, 2 * TILE)
+    p.e("s_cmp_lt_i32 %[nt], 4")
+    p.br("s_cbranch_scc1", "PDONE")
+    tile("%[rk]", 3, 3 * TILE)
+    p.label("PDONE")
+    return p
+
+
 def prologue():
     """a unit's first requests: K(0), Q (straight into a[128:191]; a half unit - %[half] - block A only), V(0), K(1), V(1), K(2), K(3)"""
     p = Prog()
@@ -1097,14 +1759,21 @@ def main():
         body = prog.text().replace("\n", " \\\n")
         parts.append(f"#define {name} \\\n    {body}\n")
 
-    both = core()
-    both.hot.extend(core_h().hot)
-    macro("Q64_ASM_CORE", both)
-    macro("Q64_ASM_PROLOGUE", prologue())
+    if OPT_V1:
+        both = core()
+        both.hot.extend(core_h().hot)
+        macro("Q64_ASM_CORE", both)
+        macro("Q64_ASM_PROLOGUE", prologue())
+    else:
+        both = StreamV2(2, "").core()
+        both.hot.extend(StreamV2(1, "H").core().hot)
+        both.hot.extend(passive_v2().hot)
+        macro("Q64_ASM_CORE", both)
+        macro("Q64_ASM_PROLOGUE", prologue_v2())
     for which in (0, 1):
         macro(f"Q64_ASM_EPI_F32_{'AB'[which]}", epilogue(which, False))
         macro(f"Q64_ASM_EPI_LP_{'AB'[which]}", epilogue(which, True))
-    parts.append("#define Q64_CLOBBER_CORE \\\n    " + clobbers(V_TOP, S_TOP, range(256), ("vcc", "scc", "memory")) + "\n")
+    parts.append("#define Q64_CLOBBER_CORE \\\n    " + clobbers(V_TOP if OPT_V1 else V2_TOP, S_TOP, range(256), ("vcc", "scc", "memory")) + "\n")
     parts.append("#define Q64_CLOBBER_PROLOGUE \\\n    " + clobbers(1, 42, range(128, 192), ("scc", "memory")) + "\n")
     parts.append("#define Q64_CLOBBER_EPI \\\n    " + clobbers(63, 39, (), ("scc", "memory")) + "\n")
     text = "\n".join(parts)

@@ -25,6 +25,13 @@ __device__ __forceinline__ void fill(float (&f)[8], f2t (&p)[8], u32x4& l0, u32x
         if constexpr (KIND == 11) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[q & 7]) : "v"(p[(q + 1) & 7]));
         if constexpr (KIND == 12) asm volatile("v_accvgpr_read_b32 %0, a0" : "=v"(f[q & 7]));
         if constexpr (KIND == 13) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f[q & 7]) : "v"(f[(q + 1) & 7]));
+        if constexpr (KIND == 14) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(f[0]) : "v"(f[(q + 1) & 7]), "v"(f[(q + 2) & 7]));      // dependent chain on f[0], as a row sum
+        if constexpr (KIND == 15) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(f[q & 7]) : "v"(f[(q + 1) & 7]), "v"(f[(q + 2) & 7]));
+        if constexpr (KIND == 16) asm volatile("s_add_i32 %0, %0, 3" : "+s"(l0[0]) : : "scc");
+        if constexpr (KIND == 17) asm volatile("v_add_f32 %0, %0, %1" : "+v"(f[0]) : "v"(f[(q + 1) & 7]));                                   // dependent chain on f[0]
+        if constexpr (KIND == 18) { asm volatile("v_exp_f32 %0, %0" : "+v"(f[1 + (q & 3)])); asm volatile("v_add_f32 %0, %0, %1" : "+v"(f[0]) : "v"(f[1 + (q & 3)])); }   // exp + dependent add
+        if constexpr (KIND == 19) asm volatile("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(f[0]) : "v"(f[(q + 1) & 7]), "v"(f[(q + 2) & 7]));
+        if constexpr (KIND == 20) asm volatile("s_nop 0");
     }
 }
 
@@ -82,6 +89,8 @@ int main() {
     run<1>("v_fma_f32", out, cyc); run<13>("v_mul_f32", out, cyc); run<2>("v_pk_fma_f32", out, cyc); run<10>("v_pk_mul_f32", out, cyc); run<11>("v_pk_add_f32", out, cyc);
     run<3>("v_exp_f32", out, cyc); run<4>("v_rcp_f32", out, cyc); run<5>("v_cvt_pk_bf16_f32", out, cyc); run<6>("v_permlane32_swap", out, cyc);
     run<12>("v_accvgpr_read", out, cyc);
+    run<14>("v_dot2c_f32_bf16 chain", out, cyc); run<19>("v_dot2_f32_bf16 chain", out, cyc); run<15>("v_max3_f32", out, cyc); run<16>("s_add_i32", out, cyc); run<17>("v_add_f32 chain", out, cyc);
+    run<18>("v_exp+v_add dep", out, cyc); run<20>("s_nop 0", out, cyc);
     run<7>("ds_read_b128", out, cyc); run<8>("ds_write_b128", out, cyc); run<9>("ds_write_b64", out, cyc);
     return 0;
 }
