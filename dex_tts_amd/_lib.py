@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("DEX_AMD_LIB") or os.path.join(HERE, "lib", "libdexamd
 
 DEX_OK = 0
 DEX_ERR_HANDOFF, DEX_ERR_HANDOFF_XCD = -5, -6        # include/dex_amd.h: dex_call_status
+DEX_PENDING = 1                                   # dex_call_status_poll(wait = 0)
 VARIANT = {"gedex": 0, "dex": 1}
 PRECISION = {"fp32": 0, "bf16": 1, "fp16": 2, "fp16x2": 3}
 SOLVER = {"euler": 0, "heun": 1}
@@ -135,6 +136,8 @@ SYMBOLS = [
     ("dex_text_encode", C.c_int, [C.c_void_p, C.POINTER(DexTextArgs), C.c_void_p]),
     ("dex_text_align", C.c_int, [C.c_void_p, C.POINTER(DexAlignArgs), C.c_void_p]),
     ("dex_call_status", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("dex_call_status_begin", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("dex_call_status_poll", C.c_int, [C.c_void_p, C.c_int]),
     ("dex_debug_handoff_timeouts", C.c_int, [C.c_void_p, C.c_void_p]),
     ("dex_debug_xcd_local", C.c_int, []),
     ("dex_mel_frames", C.c_int, [C.c_int]),

@@ -79,12 +79,40 @@ def _compile(job, force):
     return obj
 
 
+# Kernels whose asm statements (generated instruction streams) keep state in registers ACROSS statement boundaries - loads in flight
+# into v64.. / the accumulation file (dit_rowchain64a_kernel), O^T and Q in the accumulation file (attn_q64_kernel) - which hipcc only
+# knows as clobbers: nothing the compiler emits between the statements may touch them.  ADVICE r5: the check (tools/audit_rowchain_a.py)
+# ran from the test-suite only, and not with the build's flags; it is part of the build now - every compilation of these files, with
+# exactly its flags, and a hit fails the build.  (source, kernel, also-forbid-v64-up, object suffixes it exists in)
+AUDITS = (("dit_rowchain.hip", "dit_rowchain64a_kernel", True, ("", ".f16")),
+          ("attention_q64.hip", "attn_q64_kernel", False, ("", ".f16", ".f16w")))
+
+
+def _audit(job):
+    src, extra, suffix = job
+    for a_src, kernel, vgprs, suffixes in AUDITS:
+        if src != a_src or suffix not in suffixes:
+            continue
+        obj = os.path.join(OBJ, src[:-4] + suffix + ".o")
+        stamp = obj + ".audit_ok"
+        if os.path.exists(stamp) and os.path.getmtime(stamp) >= os.path.getmtime(obj):
+            continue
+        sys.path.insert(0, os.path.join(HERE, "..", "tools"))
+        import audit_rowchain_a
+        problems = audit_rowchain_a.audit(list(extra), src, kernel, vgprs)
+        if problems:
+            raise RuntimeError(f"register audit of {kernel} ({src} {extra}) FAILED - the compiler touches registers the generated streams own:\n  "
+                               + "\n  ".join(problems[:20]))
+        open(stamp, "w").write("clean\n")
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     srcs = sources()
     with cf.ThreadPoolExecutor(max_workers=min(12, len(srcs))) as ex:
         objs = list(ex.map(lambda s: _compile(s, force), srcs))
+        list(ex.map(_audit, srcs))
     if force or _stale(LIB, objs):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -794,8 +794,7 @@ static bool pp_plan(const Conv3P& p, int& seg, int& nseg_y) {
     // workgroups - two rounds, the second 22 % full, the 72 KB weight load amortised over four tiles - where 4 x 5-tile segments are
     // 250 workgroups in ONE round: cost = rounds x (tiles per segment + ~2 tiles' worth of prologue), among splits that keep >= 95 %
     // of the CUs busy and >= 3 tiles per segment.  The batch shapes (DEX / GeDEX B = 32: 256 workgroups) choose as before.
-    static int ncu = 0;
-    if (!ncu) { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); if (ncu <= 0) ncu = 256; }
+    const int ncu = device_cus();
     long best = -1;
     for (int k = 1; k == 1 || tiles / k >= 3; ++k) {
         const int sg = (tiles + k - 1) / k, ny = (tiles + sg - 1) / sg;

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <map>
 #include <unordered_map>
+#include <string_view>
 #include <string>
 #include <vector>
 
@@ -31,7 +32,7 @@ const char* const KNOB_NAMES[] = {
     "DEX_CONV_DOWN", "DEX_CONVT_UP", "DEX_DEBUG_PLAN",
     // launcher heuristics (workgroup caps, shape thresholds, form switches) - process-static getenv reads until round 4
     "DEX_ATTN_SHARED_W8", "DEX_CONVT_MT", "DEX_CONVT_WGS", "DEX_CONV_DOWN_WGS", "DEX_CONV_REGW", "DEX_CONV_REGW_RES", "DEX_CONV_SMALL_MAX", "DEX_CONV_TH8",
-    "DEX_CONV_W8", "DEX_DWCONV_CAP", "DEX_FINAL_CAP", "DEX_FIRST_CAP", "DEX_FIRST_MFMA", "DEX_GEMM_NWALK", "DEX_NWALK_SPLIT", "DEX_POS_COL", "DEX_POS_COL_MIN",
+    "DEX_CONV_W8", "DEX_DWCONV_CAP", "DEX_FINAL_CAP", "DEX_FIRST_CAP", "DEX_FIRST_MFMA", "DEX_GEMM_NWALK", "DEX_NWALK_SPLIT", "DEX_NWALK_BM", "DEX_POS_COL", "DEX_POS_COL_MIN",
     "DEX_POS_CT", "DEX_REGW_MIN_TILES", "DEX_REGW_WGS", "DEX_ROWCHAIN64", "DEX_ROWCHAIN64A", "DEX_TIV_CAP", "DEX_TV_CHAIN", "DEX_TIV_FOLD", "DEX_LINATTN_NSUB"};
 constexpr int N_KNOBS = (int)(sizeof(KNOB_NAMES) / sizeof(KNOB_NAMES[0]));
 // value of one variable: a decimal integer; unset, empty or without digits ("true", "on") = KNOB_UNSET, so a typo leaves the default
@@ -63,12 +64,22 @@ struct KnobScope {            // installs a snapshot for the calls below it on t
     ~KnobScope() { t_knobs = prev; }
 };
 }  // namespace
+// name -> registry index through one hash lookup (the launchers consult several knobs per launch, hundreds of launches per
+// eager step, and a lookup was a linear strcmp scan over the registry)
+static int knob_index(const char* name) {
+    static const std::unordered_map<std::string_view, int> idx = [] {
+        std::unordered_map<std::string_view, int> m;
+        for (int i = 0; i < N_KNOBS; ++i) m.emplace(KNOB_NAMES[i], i);
+        return m;
+    }();
+    const auto it = idx.find(std::string_view(name));
+    return it == idx.end() ? -1 : it->second;
+}
 int knob(const char* name) {
-    for (int i = 0; i < N_KNOBS; ++i)
-        if (!strcmp(KNOB_NAMES[i], name)) {
-            if (t_knobs) return t_knobs->v[i];
-            break;
-        }
+    if (t_knobs) {
+        const int i = knob_index(name);
+        if (i >= 0) return t_knobs->v[i];
+    }
     return knob_parse(getenv(name));           // outside a call (tools that launch kernels directly), or a knob nobody registered
 }
 }  // namespace dex
@@ -150,6 +161,8 @@ struct DexCtx {
     // mel front-end constants
     float *mel_basis = nullptr, *mel_filt = nullptr; void* mel_ws = nullptr; size_t mel_ws_bytes = 0;
     const int* last_xerr = nullptr;     // time-out word of the last call's cluster row chain (inside that call's workspace)
+    // asynchronous status (dex_call_status_begin / _poll): a pinned host word the stream copies the call's hand-off word into + the event behind it
+    int* st_host = nullptr; hipEvent_t st_ev = nullptr; bool st_pending = false;
     // taps of the last call
     struct Tap { std::string name; const float* p; std::vector<int64_t> shape; };
     std::vector<Tap> taps;
@@ -334,6 +347,8 @@ void dex_ctx_destroy(DexCtx* x) {
     if (x->mel_ws) hipFree(x->mel_ws);
     x->drop_graphs();
     for (auto& pr : x->prof) { hipEventDestroy(pr.a); hipEventDestroy(pr.b); }
+    if (x->st_ev) hipEventDestroy(x->st_ev);
+    if (x->st_host) hipHostFree(x->st_host);
     delete x;
 }
 
@@ -1098,8 +1113,7 @@ struct Runner {
                 // (the context pass holds 256 + 73 registers there) - and powers of two land between rounds: DEX B = 32 ran 1 280 workgroups
                 // on 512 slots (2.5 rounds) at full resolution and 320 on 256 (1.25) at half.  Choose the sub-tile count that minimises
                 // rounds x sub-tiles; among equals the largest (fewer partials for the merge, fewer weight stagings).  DEX_LINATTN_NSUB forces one.
-                static int ncu = 0;
-                if (!ncu) { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); if (ncu <= 0) ncu = 256; }
+                const int ncu = device_cus();
                 const long slots = (long)(X.C == 64 ? 2 : 1) * ncu;
                 if ((npix + 127) / 128 * B >= 2 * slots) {
                     long best = -1;
@@ -1889,16 +1903,47 @@ int dex_mel_frames(int n_samples) { return n_samples / 256 + 1; }
 // word.  DEX_OK, or DEX_ERR_HANDOFF when an in-launch hand-off of the cluster row chain timed out (1) or met a peer on another XCD
 // (2) - the call's outputs are NaN in that case.  An XCC mismatch switches the XCD-local form off for the device (all contexts:
 // the graph-cache generation moves), so simply repeating the call takes the placement-independent form.
+static int handoff_verdict(DexCtx* x, int v) {
+    if (v == 0) return DEX_OK;
+    if (v == 2 && !knob_set("DEX_DEBUG_DROP_HANDOFF")) { g_xcd_map.store(0); x->drop_graphs(); }
+    if (v == 2) return x->fail(DEX_ERR_HANDOFF_XCD, "a cluster hand-off met its peer on another XCD (outputs poisoned); the XCD-local form is now off for this device - repeat the call");
+    return x->fail(DEX_ERR_HANDOFF, "a cluster hand-off timed out (outputs poisoned)");
+}
 int dex_call_status(DexCtx* x, dex_stream_t stream) {
     if (!x) return DEX_ERR_ARG;
     if (!x->last_xerr) return DEX_OK;
     int v = 0;
     if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess || hipMemcpy(&v, x->last_xerr, sizeof v, hipMemcpyDeviceToHost) != hipSuccess)
         return x->fail(DEX_ERR_HIP, "dex_call_status: could not read the hand-off word");
-    if (v == 0) return DEX_OK;
-    if (v == 2 && !knob_set("DEX_DEBUG_DROP_HANDOFF")) { g_xcd_map.store(0); x->drop_graphs(); }
-    if (v == 2) return x->fail(DEX_ERR_HANDOFF_XCD, "a cluster hand-off met its peer on another XCD (outputs poisoned); the XCD-local form is now off for this device - repeat the call");
-    return x->fail(DEX_ERR_HANDOFF, "a cluster hand-off timed out (outputs poisoned)");
+    return handoff_verdict(x, v);
+}
+// The same check without blocking the host (the call is asynchronous): _begin enqueues, behind the call on its
+// stream, a copy of the hand-off word into a pinned host word of the context and records an event; _poll reads the verdict once that
+// event has passed (wait = 0: DEX_PENDING while it has not; wait != 0: waits for THAT event only, not for the stream).
+int dex_call_status_begin(DexCtx* x, dex_stream_t stream) {
+    if (!x) return DEX_ERR_ARG;
+    if (x->st_pending) { const int rc = dex_call_status_poll(x, 1); if (rc != DEX_OK) return rc; }      // (one check in flight per context)
+    if (!x->last_xerr) return DEX_OK;
+    if (!x->st_host) {
+        if (hipHostMalloc(reinterpret_cast<void**>(&x->st_host), sizeof(int), hipHostMallocDefault) != hipSuccess) return x->fail(DEX_ERR_HIP, "dex_call_status_begin: hipHostMalloc failed");
+        if (hipEventCreateWithFlags(&x->st_ev, hipEventDisableTiming) != hipSuccess) return x->fail(DEX_ERR_HIP, "dex_call_status_begin: hipEventCreate failed");
+    }
+    HIPCHK(x, hipMemcpyAsync(x->st_host, x->last_xerr, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(x, hipEventRecord(x->st_ev, (hipStream_t)stream));
+    x->st_pending = true;
+    return DEX_OK;
+}
+int dex_call_status_poll(DexCtx* x, int wait) {
+    if (!x) return DEX_ERR_ARG;
+    if (!x->st_pending) return DEX_OK;
+    if (wait) { if (hipEventSynchronize(x->st_ev) != hipSuccess) return x->fail(DEX_ERR_HIP, "dex_call_status_poll: event wait failed"); }
+    else {
+        const hipError_t q = hipEventQuery(x->st_ev);
+        if (q == hipErrorNotReady) return DEX_PENDING;
+        if (q != hipSuccess) return x->fail(DEX_ERR_HIP, "dex_call_status_poll: event query failed");
+    }
+    x->st_pending = false;
+    return handoff_verdict(x, *static_cast<volatile int*>(x->st_host));
 }
 
 int dex_debug_handoff_timeouts(DexCtx* x, dex_stream_t stream) {

@@ -44,9 +44,14 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const InStatsP p, const i
     const int cq = tid % C4, prow = tid / C4, rpp = 256 / C4;
     const int pbeg = blockIdx.x * pix_per_wg, pend = min(p.npix, pbeg + pix_per_wg);
     const float* X = p.X + (long)b * p.bstride;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = make_float4(0.f, 0.f, 0.f, 0.f);
-    // rounds of 16 unconditional (clamped) loads in flight together (a plain loop serialised 32 round trips: 14-17 us)
+    // rounds of 16 unconditional (clamped) loads in flight together (a plain loop serialised 32 round trips: 14-17 us).  A round's 16
+    // values are summed in fp32 in a fixed order and converted to fixed point ONCE PER ROUND; the rounds of a thread add up as integers.
+    // Rounds sit at absolute pixel positions (pixels per workgroup is a multiple of a round's span), so the bits of the statistics do not
+    // depend on how many pixels a workgroup takes - i.e. not on the batch size (the per-thread fp32 run was 32 values at
+    // B = 1 and up to 512 at batch, and an utterance's fp32-mode result was not batch-invariant).
     constexpr int RN = 16;
+    const double inv_n = 1.0 / (double)p.npix;
+    gnfix_t as[4] = {0, 0, 0, 0}, aq[4] = {0, 0, 0, 0};
     for (int px0 = pbeg + prow; px0 < pend; px0 += RN * rpp) {
         float4 v[RN]; float mk[RN];
 #pragma unroll
@@ -55,6 +60,7 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const InStatsP p, const i
             v[k] = *reinterpret_cast<const float4*>(X + (long)px * p.ld + cq * 4);
             mk[k] = p.mask ? p.mask[(long)b * p.mask_bstride + (px % p.W) * p.mask_ws] : 1.f;
         }
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f), q = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int k = 0; k < RN; ++k) {
             const float m = (px0 + k * rpp < pend) ? mk[k] : 0.f;
@@ -62,13 +68,12 @@ __global__ __launch_bounds__(256) void in_stats_kernel(const InStatsP p, const i
             s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
             q.x = fmaf(t.x, t.x, q.x); q.y = fmaf(t.y, t.y, q.y); q.z = fmaf(t.z, t.z, q.z); q.w = fmaf(t.w, t.w, q.w);
         }
+        as[0] += gn_fix(s.x, inv_n); as[1] += gn_fix(s.y, inv_n); as[2] += gn_fix(s.z, inv_n); as[3] += gn_fix(s.w, inv_n);
+        aq[0] += gn_fix(q.x, inv_n); aq[1] += gn_fix(q.y, inv_n); aq[2] += gn_fix(q.z, inv_n); aq[3] += gn_fix(q.w, inv_n);
     }
     const int c = cq * 4;
-    const double inv_n = 1.0 / (double)p.npix;          // per-thread sums run in a fixed order; the integer adds commute
-    gn_add(&red[c + 0][0], gn_fix(s.x, inv_n)); gn_add(&red[c + 0][1], gn_fix(q.x, inv_n));
-    gn_add(&red[c + 1][0], gn_fix(s.y, inv_n)); gn_add(&red[c + 1][1], gn_fix(q.y, inv_n));
-    gn_add(&red[c + 2][0], gn_fix(s.z, inv_n)); gn_add(&red[c + 2][1], gn_fix(q.z, inv_n));
-    gn_add(&red[c + 3][0], gn_fix(s.w, inv_n)); gn_add(&red[c + 3][1], gn_fix(q.w, inv_n));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { gn_add(&red[c + e][0], as[e]); gn_add(&red[c + e][1], aq[e]); }
     __syncthreads();
     if (tid < p.C) {
         gnfix_t* dst = p.stats + (((long)b * p.C + tid) * IN_SLOTS + (blockIdx.x % IN_SLOTS)) * 2;

@@ -1621,8 +1621,7 @@ void launch_dit_rowchain(const DitChainP& p, hipStream_t st) {
                     attr64a = true;
                 }
                 g_last_symbol = "dit_rowchain64a_kernel";
-                static int ncu = 0;
-                if (!ncu) { int dev = 0; hipGetDevice(&dev); hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); if (ncu <= 0) ncu = 256; }
+                const int ncu = device_cus();
                 const int ntiles = p.B * ((p.rows_per_batch + 63) / 64);
                 hipLaunchKernelGGL(dit_rowchain64a_kernel, dim3(ntiles < ncu ? ntiles : ncu), dim3(256), RCA_LDS_BYTES, st, p);      // persistent: one workgroup per CU walks its tiles
                 return;

@@ -356,12 +356,15 @@ __global__ __launch_bounds__(256) void igemm_lp_ss_kernel(const IGemmP p) {
 // Its epilogue is the unpatchify scatter only (bias, output mask, crop): everything that depends on the token row is computed
 // once for the whole walk.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-template <int K>
-__global__ __launch_bounds__(256) void igemm_lp_nwalk_kernel(const IGemmP p) {
-    constexpr int BM = 64, BN = 64;
-    constexpr int WN = BN / 32, WM = 4 / WN, MT = BM / (WM * 32);
+// BM rows per workgroup, BM / 16 waves (a wave = 32 rows x 32 of the tile's 64 columns).  BM = 128 (round 6): every 64-column weight
+// tile a workgroup stages serves 128 rows instead of 64 (650 -> 360 MB of L2 -> LDS weight traffic per launch at DEX B = 32) - measured
+// no faster, so it is opt-in (launch_nwalk).
+template <int K, int BM = 64>
+__global__ __launch_bounds__(BM * 4) void igemm_lp_nwalk_kernel(const IGemmP p) {
+    constexpr int BN = 64, NTHR = BM * 4;
+    constexpr int WN = BN / 32, WM = BM / 32, MT = 1;
     constexpr int LDS_LD = K + 8, KC = K / 8;
-    constexpr int AIT = BM * KC / 256, BIT = BN * KC / 256;
+    constexpr int AIT = BM * KC / NTHR, BIT = BN * KC / NTHR;
     constexpr int ABATCH = AIT > 8 ? 8 : AIT;
     extern __shared__ __attribute__((aligned(16))) u16 smem_ss[];
     u16* As = smem_ss;
@@ -384,12 +387,12 @@ __global__ __launch_bounds__(256) void igemm_lp_nwalk_kernel(const IGemmP p) {
     u32x4 br[BIT];                          // (native vectors + macros, not lambdas over an array: those ended up in scratch)
 #define NW_LOAD_B(nt_)                                                                                              \
     _Pragma("unroll") for (int j = 0; j < BIT; ++j) {                                                              \
-        const int it = tid + 256 * j;                                                                               \
+        const int it = tid + NTHR * j;                                                                              \
         br[j] = *reinterpret_cast<const u32x4*>(Wb + (long)((nt_) * BN + it / KC) * K + (it % KC) * 8);            \
     }
 #define NW_STORE_B()                                                                                                \
     _Pragma("unroll") for (int j = 0; j < BIT; ++j) {                                                              \
-        const int it = tid + 256 * j;                                                                               \
+        const int it = tid + NTHR * j;                                                                              \
         *reinterpret_cast<u32x4*>(Bs + (it / KC) * LDS_LD + (it % KC) * 8) = br[j];                                 \
     }
 #ifdef DEX_LP_WSPLIT
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(256) void igemm_lp_nwalk_kernel(const IGemmP p) {
         float mk[ABATCH];
 #pragma unroll
         for (int j = 0; j < ABATCH; ++j) {
-            const int it = tid + 256 * (a0 + j);
+            const int it = tid + NTHR * (a0 + j);
             const int row = it / KC, k8 = (it % KC) * 8;
             const int m = m0 + row;
             const int mm = m < M ? m : 0;                    // (1 x 1 taps only: row m of the A matrix)
@@ -421,7 +424,7 @@ __global__ __launch_bounds__(256) void igemm_lp_nwalk_kernel(const IGemmP p) {
         if (a0 == 0) { NW_STORE_B() }
 #pragma unroll
         for (int j = 0; j < ABATCH; ++j) {
-            const int it = tid + 256 * (a0 + j);
+            const int it = tid + NTHR * (a0 + j);
             const int row = it / KC, k8 = (it % KC) * 8;
             float4 a = f0[j], c = f1[j];
             if (lsh) {
@@ -588,11 +591,30 @@ bool igemm_nwalk_form(const IGemmP& p) {
     return nwalk_eligible(p); }
 static void launch_nwalk(const IGemmP& p, hipStream_t st) {
     constexpr int K = 256;
-    const size_t lds = (size_t)(64 + 64) * (K + 8) * sizeof(u16);
+    const size_t lds = (size_t)(64 + 64) * (K + 8) * sizeof(u16), lds128 = (size_t)(128 + 64) * (K + 8) * sizeof(u16);
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_lp_nwalk_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_lp_nwalk_kernel<K, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
         attr = true;
+    }
+    // 128-row workgroups (eight waves, one workgroup per CU): half the weight stream per row.  Built, bit-identical, and measured NO faster
+    // (profiles/round6_unpatchify_gemm_128_row_workgroups_negative.txt: 53.8 vs 56.4 us at DEX B = 32, 73.3 vs 74.7 at GeDEX B = 32) - the
+    // L2 -> LDS weight stream the round-5 notes blamed is not what bounds the launch; what is left is the scatter itself (256- / 512-byte
+    // runs at 2.3 - 3.1 TB/s of writes).  OPT-IN: DEX_NWALK_BM=128 (tests keep the form alive).
+    {
+        const long wgs128 = (long)((p.Ho * p.Wo + 127) / 128) * p.B;
+        const int bm_env = knob_or("DEX_NWALK_BM", 0);
+        int ns = 1;
+        while (ns < 4 && wgs128 * ns < 640 && (p.N / 64) % (ns * 2) == 0) ns *= 2;
+        const bool big = bm_env == 128;
+        if (big) {
+            const int fs = knob_or("DEX_NWALK_SPLIT", 0);
+            if (fs > 0 && (p.N / 64) % fs == 0) ns = fs;
+            g_last_symbol = "igemm_lp_nwalk_kernel<256, 128>";
+            hipLaunchKernelGGL((igemm_lp_nwalk_kernel<K, 128>), dim3((p.Ho * p.Wo + 127) / 128, ns, p.B), dim3(512), lds128, st, p);
+            return;
+        }
     }
     g_last_symbol = "igemm_lp_nwalk_kernel<256>";
     // split the walk over 1 / 2 / 4 workgroups so that the grid is at least ~2.5 rounds of the chip's 512 slots: a workgroup's tiles

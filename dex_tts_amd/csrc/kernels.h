@@ -19,6 +19,12 @@ int knob(const char* name);                                  // atoi of the valu
 inline int knob_or(const char* name, int dflt) { const int v = knob(name); return v == KNOB_UNSET ? dflt : v; }
 inline bool knob_off(const char* name) { return knob(name) == 0; }          // set to 0: the optional form is switched off
 inline bool knob_set(const char* name) { return knob(name) != KNOB_UNSET; }
+// compute units of the current device (256 on MI355X); function-local static of an inline function: initialised once, thread-safely
+// (three launchers kept their own unsynchronised `static int ncu`)
+inline int device_cus() {
+    static const int n = [] { int dev = 0, v = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev); return v > 0 ? v : 256; }();
+    return n;
+}
 
 // GroupNorm / InstanceNorm statistics: [B][groups][GN_SLOTS][2] partial (mean, mean-of-squares) contributions as 64-bit
 // FIXED-POINT integers (2^-36 resolution, see bf16_util.h gn_fix): integer addition is associative, so the native L2

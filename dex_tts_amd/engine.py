@@ -54,7 +54,24 @@ class ScoreNetEngine:
         self.loaded_version = None
 
     # ---------------------------------------------------------------------------------------
-    check_handoffs = True        # sample(): verify the in-launch hand-offs of a call before returning its result (see dex_call_status)
+    # sample(): how the in-launch hand-offs of a call (small grids: the cluster form of the DiT block) are verified.
+    #   "deferred" (default): asynchronous - a copy of the call's hand-off word into pinned host memory + an event are enqueued behind the
+    #       call (dex_call_status_begin); the verdict is read at the NEXT call into this engine or at .status() and raises there.  sample()
+    #       returns at once, so a caller can put the vocoder of this utterance behind it and go on to the next one.  A lost
+    #       hand-off also poisons every output of its call with NaN, so nothing wrong can look right in the meantime.
+    #   True / "sync": the host waits for the call and raises before the mel is handed out (rounds 3-5; repeats the call by itself when
+    #       the XCD-local form had to be switched off).   False: no check.
+    check_handoffs = "deferred"
+
+    def status(self, wait: bool = True) -> bool:
+        """Verdict of the deferred hand-off check of the last call (check_handoffs = "deferred"): raises RuntimeError if a hand-off was
+        lost; returns False while the stream has not reached the check yet (wait=False), True once it is known to be clean."""
+        with torch.cuda.device(self.device):
+            rc = self.lib.dex_call_status_poll(self.h, 1 if wait else 0)
+        if rc == _lib.DEX_PENDING:
+            return False
+        self._check(rc)
+        return True
 
     def _check(self, rc: int):
         if rc != 0:
@@ -189,8 +206,9 @@ class ScoreNetEngine:
         """ablation_sampler(solver, edm, linear, none) for latent z — edm.py:109-216.  ``solver`` is 'euler' (what
         Diffusion wires, diffusion.py:216) or 'heun' (edm.py:207-214; 2n-1 network evaluations).  Asynchronous.
         ``use_graph``: the whole call (conditioning tables + every network evaluation) is one cached hipGraph.
-        Small grids (B x row tiles <= 64: the cluster form of the DiT block) BLOCK the host until the call has finished when
-        ``check_handoffs`` is on (the default): the hand-off word is read before the mel is handed out.
+        Small grids (B x row tiles <= 64: the cluster form of the DiT block) have their in-launch hand-offs checked: asynchronously by
+        default (``check_handoffs = "deferred"``: the verdict surfaces at the next call or at ``status()``), or before the mel is handed out
+        (``check_handoffs = True``: blocks the host until the call has finished).
         ``S_churn > 0`` turns on the stochastic sampler (edm.py:194-196); ``noise`` [n_steps,B,80,T] then holds step i's
         ``randn_like(x_cur)`` draw (the caller owns the RNG, as with ablation_sampler's ``randn_like`` argument)."""
         with torch.cuda.device(self.device):
@@ -243,11 +261,17 @@ class ScoreNetEngine:
                 a = _lib.DexSampleArgs()
                 keep = self._fill_args(a, mu, mask, sig, out, n_steps, spk, ref, sty, sty_lengths, use_graph, solver, noise, churn)
                 a.z_dev = z.data_ptr()
+                deferred = self.check_handoffs == "deferred"
+                if deferred:
+                    self.status(wait=True)         # the previous call's verdict (its event has long passed; raises if that call lost a hand-off)
                 for attempt in (0, 1):
                     self._check(self.lib.dex_sample(self.h, C.byref(a), self._stream()))
-                    # calls that used in-launch hand-offs (small grids: the cluster form of the DiT block) are checked before their
-                    # result is handed out: a lost hand-off poisons the outputs with NaN, and a NaN mel must not leave silently
-                    # (ADVICE r3).  dex_call_status returns at once, without waiting, for calls that used none.
+                    # calls that used in-launch hand-offs (small grids: the cluster form of the DiT block) are checked: a lost hand-off
+                    # poisons the outputs with NaN, and a NaN mel must not leave silently.  Deferred: the check rides the
+                    # stream behind the call; sync: dex_call_status waits (it returns at once for calls that used no hand-offs).
+                    if deferred:
+                        self._check(self.lib.dex_call_status_begin(self.h, self._stream()))
+                        break
                     rc = self.lib.dex_call_status(self.h, self._stream()) if self.check_handoffs else 0
                     if rc == 0:
                         break

@@ -208,3 +208,77 @@ def make_text_inputs(B: int, L: int, lengths=None, n_vocab: int = 149, seed: int
     for b in range(B):
         tok[b, lengths[b]:] = 0
     return tok, lengths
+
+
+# ---- pinned whole-job cases: the inputs of the long sampler jobs whose CPU-oracle outputs are committed under tests/golden/oracle_jobs/
+# (written by oracle/make_oracle_jobs.py; data, not code).  The GPU tests compare against them (tests/gpu_util.py) and bench.py measures
+# the `abs_err` fields of its configs blocks against them in the run itself.  Nothing here touches oracle/.
+ORACLE_VERSION = 1          # bump when oracle/dex_oracle.py changes what it computes: every stored job is then recomputed
+_WKEY = {}
+
+
+def make_case(cfg, B, T, lengths=None, Tr=40, Ts=40, sty_lengths=None, seed=1234):
+    mu, mask, z, lengths = make_inputs(B, T, lengths, seed=seed)
+    case = {"mu": mu, "mask": mask, "z": z, "eps": normalish("eps", (B, 80, T), seed + 5)}
+    if cfg.variant == "dex":
+        ref, rl, sty, sl = make_dex_style(B, Tr, Ts, cfg.mid_dim, sty_lengths=sty_lengths)
+        case.update(ref=np.stack(ref), ref_lengths=rl, sty=sty, sty_lengths=sl)
+    if cfg.n_spks > 1:
+        case["spk"] = normalish("spk", (B, cfg.spk_emb_dim), 9)
+    return case
+
+
+def case_key(case):
+    import zlib
+    parts = []
+    for k in sorted(case):
+        a = np.ascontiguousarray(case[k])
+        parts.append((k, a.shape, zlib.crc32(a.tobytes())))
+    return tuple(parts)
+
+
+def weights_key(name):
+    """crc of the packed synthetic weights + the preset's config: a changed make_weights / PRESETS entry misses the store"""
+    if name not in _WKEY:
+        import zlib
+        from . import config as C
+        cfg = C.PRESETS[name]()
+        w = make_weights(C.param_shapes(cfg))
+        crc = 0
+        for k in sorted(w):
+            crc = zlib.crc32(np.ascontiguousarray(w[k]).tobytes(), zlib.crc32(k.encode(), crc))
+        _WKEY[name] = (crc, repr(cfg))
+    return _WKEY[name]
+
+
+def stored_job_path(root, name, case, n_steps, solver="euler"):
+    import hashlib
+    import os
+    h = hashlib.sha1(repr((name, int(n_steps), solver, case_key(case), weights_key(name), ORACLE_VERSION)).encode()).hexdigest()[:16]
+    return os.path.join(root, "tests", "golden", "oracle_jobs", f"{name}_n{int(n_steps)}_{solver}_{h}.npy")
+
+
+def pinned_job_case(name):
+    """(case, n_steps) of the whole job bench.py / tests/test_gpu_full_jobs.py pin for a preset: BASELINE.json configs[2] (dex_vctk),
+    the per-GPU share of configs[3] (dex_esd), configs[4] (gedex_lj: long form)"""
+    from . import config as C
+    cfg = C.PRESETS[name]()
+    if name == "gedex_lj":
+        return make_case(cfg, B=1, T=4000), 50
+    case = make_case(cfg, B=32, T=256, lengths=[256 - 3 * i for i in range(32)], Tr=348, Ts=348, sty_lengths=[348 - 5 * i for i in range(32)])
+    return case, (100 if name == "dex_esd" else 50)
+
+
+def kernel_sources_sha(root):
+    """sha1 over the kernel sources (dex_tts_amd/csrc: .hip / .h / .inc, sorted by name): what a committed rocprof summary was measured on
+    (tools/collect_profiles.py writes it to profiles/profiles_head.json, bench.py compares it with the tree it runs from)"""
+    import hashlib
+    import os
+    d = os.path.join(root, "dex_tts_amd", "csrc")
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".inc")):
+            h.update(f.encode())
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]

@@ -31,6 +31,7 @@ typedef struct DexCtx DexCtx;
 typedef void* dex_stream_t; /* hipStream_t */
 
 typedef enum {
+    DEX_PENDING = 1,       /* dex_call_status_poll(wait = 0): the stream has not reached the call's status copy yet */
     DEX_OK = 0,
     DEX_ERR_ARG = -1,      /* bad argument / shape (e.g. T % 4 != 0, unknown key, wrong weight shape) */
     DEX_ERR_STATE = -2,    /* call order (weights missing, not finalized) */
@@ -156,6 +157,15 @@ int  dex_profile_get(const DexCtx* ctx, int i, const char** name, int* calls, do
  * (the graph entry remembers the word its captured launches write).  Calls that used no hand-offs return DEX_OK without waiting.  The Python mirror
  * (ScoreNetEngine.sample) checks every call that could use hand-offs and raises. */
 int  dex_call_status(DexCtx* ctx, dex_stream_t stream);
+/* The same verdict WITHOUT blocking the host (the sampler call is asynchronous: a caller overlaps the vocoder of utterance i with the
+ * sampler of utterance i + 1).  _begin enqueues, behind the last dex_sample / dex_denoise_once on `stream`, a copy of the call's
+ * hand-off word into a pinned host word of the context and an event; it returns at once (calls without hand-offs: nothing is enqueued).
+ * _poll returns the verdict of that call - DEX_OK / DEX_ERR_HANDOFF / DEX_ERR_HANDOFF_XCD - once the event has passed; before that
+ * DEX_PENDING (wait = 0), or it waits for that event alone (wait != 0; never for later work on the stream).  One check is in flight per
+ * context: a second _begin first resolves the pending one (and returns its error if it failed).  The Python mirror's default
+ * (ScoreNetEngine.check_handoffs = "deferred") begins a check after every call and reads it at the next call or at .status(). */
+int  dex_call_status_begin(DexCtx* ctx, dex_stream_t stream);
+int  dex_call_status_poll(DexCtx* ctx, int wait);
 /* Debug: 1 if a workgroup hand-off of the LAST dex_sample / dex_denoise_once call on this context timed out (small-grid DiT
  * blocks run as clusters of co-operating workgroups; a wait is bounded so a lost hand-off cannot hang the GPU), 0 if none did or
  * the call used no hand-offs, < 0 on a HIP error.  Synchronises the stream; the call's workspace must still be alive. */

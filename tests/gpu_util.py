@@ -59,13 +59,7 @@ def fp32_taps_ok(tag, terr):
 _ORACLE = {}          # oracle outputs are mode-independent: computed once per (case, sigma / n) and reused across precisions
 
 
-def _case_key(case):
-    import zlib
-    parts = []
-    for k in sorted(case):
-        a = np.ascontiguousarray(case[k])
-        parts.append((k, a.shape, zlib.crc32(a.tobytes())))
-    return tuple(parts)
+_case_key = synth.case_key
 
 
 def engine_for(name):
@@ -80,15 +74,7 @@ def engine_for(name):
     return _ENG[name]
 
 
-def make_case(cfg, B, T, lengths=None, Tr=40, Ts=40, sty_lengths=None, seed=1234):
-    mu, mask, z, lengths = synth.make_inputs(B, T, lengths, seed=seed)
-    case = {"mu": mu, "mask": mask, "z": z, "eps": synth.normalish("eps", (B, 80, T), seed + 5)}
-    if cfg.variant == "dex":
-        ref, rl, sty, sl = synth.make_dex_style(B, Tr, Ts, cfg.mid_dim, sty_lengths=sty_lengths)
-        case.update(ref=np.stack(ref), ref_lengths=rl, sty=sty, sty_lengths=sl)
-    if cfg.n_spks > 1:
-        case["spk"] = synth.normalish("spk", (B, cfg.spk_emb_dim), 9)
-    return case
+make_case = synth.make_case
 
 
 def oracle_kwargs(case, dtype=torch.float32):
@@ -164,9 +150,7 @@ ORACLE_JOBS = os.path.join(ROOT, "tests", "golden", "oracle_jobs")
 
 
 def oracle_job_path(name, case, n_steps, solver="euler"):
-    import hashlib
-    h = hashlib.sha1(repr((name, int(n_steps), solver, _case_key(case))).encode()).hexdigest()[:16]
-    return os.path.join(ORACLE_JOBS, f"{name}_n{int(n_steps)}_{solver}_{h}.npy")
+    return synth.stored_job_path(ROOT, name, case, n_steps, solver)
 
 
 def oracle_sampler_stored(name, case, n_steps, solver="euler"):

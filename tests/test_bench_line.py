@@ -50,3 +50,27 @@ def test_compact_line_survives_a_bloated_record():
     assert len(line) < b.COMPACT_LIMIT
     back = json.loads(line)
     assert "roofline" in back and "cpu_baseline" in back and back["value"] == full["value"]
+
+
+def test_bench_has_no_unresolved_global_names():
+    """bench.py's GPU-only branches never run in the CPU suite: a name that resolves nowhere (round 6: `np` in job_abs_err) would only
+    surface in the driver's run.  Every implicitly-global name referenced inside any function of bench.py must be defined at module
+    level or be a builtin."""
+    import builtins
+    import os
+    import symtable
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "bench.py")).read()
+    top = symtable.symtable(src, "bench.py", "exec")
+    defined = {s.get_name() for s in top.get_symbols() if s.is_assigned() or s.is_imported() or s.is_namespace()} | set(dir(builtins))
+    missing = []
+
+    def walk(tab):
+        for ch in tab.get_children():
+            for s in ch.get_symbols():
+                if s.is_referenced() and s.is_global() and s.get_name() not in defined:
+                    missing.append((ch.get_name(), s.get_name()))
+            walk(ch)
+
+    walk(top)
+    assert not missing, missing

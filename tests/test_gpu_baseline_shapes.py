@@ -316,6 +316,29 @@ def test_xcd_aware_block_order_is_bit_identical(name, kw):
     assert np.isfinite(ys[0]).all() and np.array_equal(ys[0], ys[1]), float(np.abs(ys[0] - ys[1]).max())
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16x2"])
+@pytest.mark.parametrize("name,kw", [
+    ("dex_vctk", dict(B=32, T=256, lengths=[256 - 3 * i for i in range(32)], Tr=60, Ts=60)),      # 1280 token rows per utterance: ten full 128-row tiles
+    ("gedex_lj", dict(B=32, T=508, lengths=[508 - 9 * i for i in range(32)])),                    # 635 token rows: the last 128-row tile is ragged
+])
+def test_unpatchify_gemm_128_row_workgroups_are_bit_identical(name, kw, prec):
+    """igemm_lp_nwalk_kernel<256, 128> (round 6: 128-row workgroups at batch size - every staged weight tile serves twice the rows)
+    against the 64-row form (DEX_NWALK_BM=64): same products in the same K order per token row, only the tiling changes."""
+    cfg, eng, w = U.engine_for(name)
+    case = U.make_case(cfg, **kw)
+    mu, mask, z = (torch.from_numpy(case[k]).cuda() for k in ("mu", "mask", "z"))
+    set_prec(eng, prec)
+    try:
+        ys = []
+        for flag in ("64", "128"):
+            os.environ["DEX_NWALK_BM"] = flag
+            ys.append(eng.sample(z, mask, mu, 2, **U.engine_kwargs(case)).cpu().numpy())
+    finally:
+        os.environ.pop("DEX_NWALK_BM", None)
+        eng.set_precision("fp32")
+    assert np.isfinite(ys[0]).all() and np.array_equal(ys[0], ys[1]), float(np.abs(ys[0] - ys[1]).max())
+
+
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 @pytest.mark.parametrize("name,kw", [
     ("dex_vctk", dict(B=32, T=256, lengths=[256 - 3 * i for i in range(32)], Tr=60, Ts=60)),      # N = 1300: 20 full tiles + 20 rows per utterance

@@ -84,14 +84,25 @@ def test_lost_handoff_is_loud():
         assert np.isfinite(good).all() and eng.handoff_timeouts() == 0
         os.environ["DEX_DEBUG_DROP_HANDOFF"] = "1"
         try:
-            with pytest.raises(RuntimeError, match="hand-off timed out"):       # the host mirror checks every call that uses hand-offs
-                _run(eng, case, 2)
-            eng.check_handoffs = False                                           # ... unless told not to: the poisoned result itself
+            eng.check_handoffs = True
             try:
+                with pytest.raises(RuntimeError, match="hand-off timed out"):   # the synchronous check: raises before the mel is handed out
+                    _run(eng, case, 2)
+                eng.check_handoffs = False                                       # ... unless told not to: the poisoned result itself
                 bad = _run(eng, case, 2)
             finally:
-                eng.check_handoffs = True
+                eng.check_handoffs = "deferred"
             assert eng.handoff_timeouts() == 1
+            # the default, asynchronous check: the call returns (poisoned), the verdict surfaces at status() - or at the next call
+            bad2 = _run(eng, case, 2)
+            assert np.isnan(bad2).all()
+            with pytest.raises(RuntimeError, match="hand-off timed out"):
+                eng.status()
+            assert eng.status() is True                                          # (one verdict per call)
+            _run(eng, case, 2)
+            with pytest.raises(RuntimeError, match="hand-off timed out"):
+                _run(eng, case, 2)                                               # the previous call's verdict, before anything new is enqueued
+            assert eng.status() is True
         finally:
             del os.environ["DEX_DEBUG_DROP_HANDOFF"]
         assert np.isnan(bad).all()
@@ -148,11 +159,15 @@ def test_lost_handoff_is_loud_on_graph_replays_too():
         assert np.array_equal(good, _run(eng, case, 2, graph=True)) and eng.handoff_timeouts() == 0     # clean capture, clean replay
         os.environ["DEX_DEBUG_DROP_HANDOFF"] = "1"
         try:
-            for _ in range(3):                                                   # capture, then two replay hits
-                with pytest.raises(RuntimeError, match="hand-off timed out"):
-                    _run(eng, case, 2, graph=True)
-                assert eng.handoff_timeouts() == 1
+            for mode in (True, "deferred"):                                      # the synchronous and the asynchronous check
+                eng.check_handoffs = mode
+                for _ in range(3):                                               # capture, then two replay hits
+                    with pytest.raises(RuntimeError, match="hand-off timed out"):
+                        _run(eng, case, 2, graph=True)
+                        eng.status()
+                    assert eng.handoff_timeouts() == 1
         finally:
+            eng.check_handoffs = "deferred"
             del os.environ["DEX_DEBUG_DROP_HANDOFF"]
         assert np.array_equal(good, _run(eng, case, 2, graph=True)) and eng.handoff_timeouts() == 0     # the clean graph is still cached and clean
     finally:
@@ -198,11 +213,12 @@ def test_l2_scope_handoff_across_xcds_is_loud():
         try:
             with pytest.raises(RuntimeError, match="hand-off"):
                 _run(eng, case, 2)
+                eng.status()
             eng.check_handoffs = False
             try:
                 bad = _run(eng, case, 2)
             finally:
-                eng.check_handoffs = True
+                eng.check_handoffs = "deferred"
             assert eng.handoff_timeouts() in (1, 2)
         finally:
             del os.environ["DEX_DEBUG_DROP_HANDOFF"]

@@ -1,6 +1,7 @@
 """The WHOLE jobs bench.py times at batch, against the CPU oracle (VERDICT r4 Missing #4): BASELINE.json configs[2] (DEX-VCTK, B = 32,
-T = 256, 348 reference frames, 50 Euler steps) and the per-GPU share of configs[3] (DEX-ESD, B = 32, 100 steps), in every mode the bench
-reports for them, plus one single-call check at DEX B = 32, T = 512 (N = 2580 tokens: the 64-query attention's 41-tile plan).
+T = 256, 348 reference frames, 50 Euler steps), the per-GPU share of configs[3] (DEX-ESD, B = 32, 100 steps) and - round 6 - configs[4]
+(GeDEX long form, T = 4000, 50 steps), in every mode the bench reports for them, plus one single-call check at DEX B = 32, T = 512
+(N = 2580 tokens: the 64-query attention's 41-tile plan).
 
 The oracle runs each job once on the host cores (about 2 and 4 minutes) and the result is reused across the modes (gpu_util._ORACLE).
 Bounds: tests/tolerances.py LOWP_AT, <= 2x what was measured on MI355X (profiles/round5_parity_measured.jsonl)."""
@@ -35,6 +36,25 @@ def test_cfg2_whole_job_n50_vs_oracle(prec):
 @pytest.mark.parametrize("prec", ["fp32", "bf16", "fp16x2"])
 def test_cfg3_per_gpu_job_n100_vs_oracle(prec):
     _job("dex_esd", 100, prec, "cfg3_dex_esd_b32_n100")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "fp16", "fp16x2"])
+def test_cfg4_long_form_whole_job_n50_vs_oracle(prec):
+    """BASELINE configs[4] (VERDICT r5 Missing #4): GeDEX long form, B = 1, T = 4000 (N = 5010 tokens), all 50 Euler steps as ONE
+    whole-call hipGraph, in the mode configs[4] names (fp16), in the split-weight mode and in exact fp32, against the oracle's stored
+    output of the same job (tests/golden/oracle_jobs/gedex_lj_n50_*.npy, oracle/make_oracle_jobs.py: 203 s of host time)."""
+    from dex_tts_amd import synth
+    cfg, eng, w = U.engine_for("gedex_lj")
+    case, n = synth.pinned_job_case("gedex_lj")
+    set_prec(eng, prec)
+    try:
+        got, ref = U.run_sampler("gedex_lj", case, n, use_graph=True)
+    finally:
+        eng.set_precision("fp32")
+    if prec == "fp32":
+        U.fp32_sampler_ok("cfg4_T4000_n50", got, ref)
+    else:
+        check_lowp("cfg4_T4000_n50", prec, "sampler", got, ref)
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])

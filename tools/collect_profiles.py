@@ -9,6 +9,14 @@ import sys
 src, prefix = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(root, "profiles")
+sys.path.insert(0, root)
+from dex_tts_amd import synth  # noqa: E402
+import json  # noqa: E402
+import subprocess  # noqa: E402
+head = subprocess.run(["git", "-C", root, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+with open(os.path.join(dst, "profiles_head.json"), "w") as fh:      # what the spliced rocprof / PMC numbers of the bench line were measured on
+    json.dump({"round_prefix": prefix, "commit_at_collection": head, "kernel_sources_sha": synth.kernel_sources_sha(root),
+               "note": "kernel_sources_sha = sha1 of dex_tts_amd/csrc at collection time; bench.py reports profiles_stale when the tree differs"}, fh, indent=1)
 for f in sorted(os.listdir(src)):
     if f.endswith(".err"):
         continue
