@@ -84,7 +84,7 @@ def _compile(job, force):
 # knows as clobbers: nothing the compiler emits between the statements may touch them.  ADVICE r5: the check (tools/audit_rowchain_a.py)
 # ran from the test-suite only, and not with the build's flags; it is part of the build now - every compilation of these files, with
 # exactly its flags, and a hit fails the build.  (source, kernel, also-forbid-v64-up, object suffixes it exists in)
-AUDITS = (("dit_rowchain.hip", "dit_rowchain64a_kernel", True, ("", ".f16")),
+AUDITS = (("dit_rowchain.hip", "dit_rowchain64a_kernel", True, ("", ".f16", ".f16w")),
           ("attention_q64.hip", "attn_q64_kernel", False, ("", ".f16", ".f16w")))
 
 

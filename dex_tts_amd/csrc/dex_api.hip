@@ -98,7 +98,7 @@ constexpr int ATT_KSPLIT_MAX = 4;     // key-split attention partials kept per t
 static int att_split_cap(long tokens) { return tokens <= 20480 ? 8 : ATT_KSPLIT_MAX; }
 // ... and takes the attention of a launch when it can fill the chip: >= 1024 tokens per element and >= 128 work units at its best split
 static bool attention_q64_regime(int N, int B) {
-    if (N < 1024) return !g_lp_wsplit && dit_sep64_small_n(N, B) && dit_rowchain64_form(N, B, 0);
+    if (N < 1024) return dit_sep64_small_n(N, B) && dit_rowchain64_form(N, B, 0);
     const int ks = attention_q64_ksplit(N, B, att_split_cap((long)B * N));
     const int nt32 = (N + 31) / 32, ng = (nt32 + 7) / 8;
     return 2L * B * ng * ks >= 128;

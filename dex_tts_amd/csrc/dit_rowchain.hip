@@ -876,7 +876,8 @@ __global__ __launch_bounds__(RC_NW * 64) void dit_rowchain64_kernel(const DitCha
 // pass - the generator's header has the register map and the schedule.  This shell stages the parameter rows (LDS) and hands the
 // statement its buffer descriptors; the statement owns v0..v249, a0..a255 and the rest of LDS.  Taken when the attention output
 // arrives as 16-bit rows (o_lp: one key split, no tail split) - the other cases keep the kernel above.
-#ifndef DEX_LP_WSPLIT
+// Round 6: the split-weight build (dex::f16w) has streams of its own (tools/gen_rowchain_a.py WS: every weight fragment is followed by
+// its lo fragment in the same ring, hi then lo MFMA into one accumulator) - the round-3 kernel it ran before took 173 us at DEX B = 32.
 #ifndef RCA_CORE_INC
 #define RCA_CORE_INC "dit_rowchain_a_core.inc"
 #endif
@@ -978,7 +979,6 @@ __global__ __launch_bounds__(256) void dit_rowchain64a_kernel(const DitChainP p)
 #undef RCA_OPERANDS
 #undef RCA_DESC
 }
-#endif
 
 // ---- cluster form (small grids: B x ceil(N / 32) row tiles <= 64).  At B = 1 the kernels above run 21 workgroups, each streaming
 // the K / V^T of both heads and every weight matrix of the block (1.7 MB) through ONE CU's L2 -> register path: 22 us of which no
@@ -1567,10 +1567,7 @@ bool dit_rowchain64_form(int rows_per_batch, int B, int attn_inline) {
    
     const int m64 = knob_or("DEX_ROWCHAIN64", 1);
     const long wg32 = (long)B * ((rows_per_batch + RC_ROWS - 1) / RC_ROWS);
-    bool small_n = false;
-#ifndef DEX_LP_WSPLIT
-    small_n = dit_sep64_small_n(rows_per_batch, B);       // (kernels.h: GeDEX B = 32)
-#endif
+    const bool small_n = dit_sep64_small_n(rows_per_batch, B);       // (kernels.h: GeDEX B = 32)
     return m64 && !attn_inline && (m64 == 2 || wg32 >= 768 || small_n);
 }
 
@@ -1613,7 +1610,6 @@ void launch_dit_rowchain(const DitChainP& p, hipStream_t st) {
                 hipFuncSetAttribute(reinterpret_cast<const void*>(&dit_rowchain64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)RC64_LDS);
                 attr64 = true;
             }
-#ifndef DEX_LP_WSPLIT
             if (knob_or("DEX_ROWCHAIN64A", 1) && (p.qkv_only || (p.o_lp && p.ksplit <= 1 && p.tail_ks <= 1))) {   // the generated streams (0: the round-3 kernel)
                 static bool attr64a = false;
                 if (!attr64a) {
@@ -1626,7 +1622,6 @@ void launch_dit_rowchain(const DitChainP& p, hipStream_t st) {
                 hipLaunchKernelGGL(dit_rowchain64a_kernel, dim3(ntiles < ncu ? ntiles : ncu), dim3(256), RCA_LDS_BYTES, st, p);      // persistent: one workgroup per CU walks its tiles
                 return;
             }
-#endif
             g_last_symbol = "dit_rowchain64_kernel";
             hipLaunchKernelGGL(dit_rowchain64_kernel, dim3(p.B * ((p.rows_per_batch + 63) / 64)), dim3(RC_NW * 64), RC64_LDS, st, p);
             return;

@@ -343,7 +343,7 @@ struct AttnP { const float* Q; int ldq; long qb; const float* K; int ldk; long k
 // DiT blocks with 512 <= N < 1024 tokens at batch size (GeDEX B = 32: N = 650): the 64-query attention as its own launch + the 64-row
 // generated streams take the block when the B x ceil(N / 64) row tiles fill at least 65 % of their rounds of 256 persistent workgroups -
 // measured at 352 tiles (69 %): +0.9 % end to end over attention fused into the 32-row chain (profiles/round5_gedex_b32_separate_attention_ab.txt),
-// and the gap grows with the fill.  Not in the split-weight build (no generated streams there: the round-3 64-row kernel loses 2 %).
+// and the gap grows with the fill.  (Round 6: the split-weight build has generated streams too and takes the same route.)
 inline bool dit_sep64_small_n(int N, int B) {
     if (N < 512 || N >= 1024) return false;
     const long t = (long)B * ((N + 63) / 64), r = (t + 255) / 256;

@@ -339,7 +339,7 @@ def test_unpatchify_gemm_128_row_workgroups_are_bit_identical(name, kw, prec):
     assert np.isfinite(ys[0]).all() and np.array_equal(ys[0], ys[1]), float(np.abs(ys[0] - ys[1]).max())
 
 
-@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "fp16x2"])       # (fp16x2, round 6: the split-weight streams - hi then lo fragment through one ring)
 @pytest.mark.parametrize("name,kw", [
     ("dex_vctk", dict(B=32, T=256, lengths=[256 - 3 * i for i in range(32)], Tr=60, Ts=60)),      # N = 1300: 20 full tiles + 20 rows per utterance
     ("dex_vctk", dict(B=10, T=512, lengths=[512 - 33 * i for i in range(10)], Tr=60, Ts=60)),     # 410 tiles on 256 workgroups: one or two tiles each
@@ -351,14 +351,17 @@ def test_generated_row_chain_streams_vs_round3_kernel(name, kw, prec):
     differ by about half of either's distance from the oracle (independent roundings of the same size), and both are held to the oracle elsewhere (test_cfg2_*, test_gpu_full_jobs)."""
     cfg, eng, w = U.engine_for(name)
     case = U.make_case(cfg, **kw)
-    mu, mask, eps = (torch.from_numpy(case[k]) for k in ("mu", "mask", "eps"))
+    mu, mask, eps, z = (torch.from_numpy(case[k]) for k in ("mu", "mask", "eps", "z"))
     x = mu + 80.0 * eps
     set_prec(eng, prec)
     try:
-        ys = []
+        ys, ss = [], []
         for flag in ("0", "1"):
             os.environ["DEX_ROWCHAIN64A"] = flag
             ys.append(eng.denoise_once(x, 80.0, mask, mu, **U.engine_kwargs(case)).cpu().numpy())
+            # (round 6) a debug-tap call keeps fp32 intermediates: only the sampler path hands the chain 16-bit attention rows, i.e. runs
+            # the generated streams of the FULL / LAST blocks too (the split-weight streams' first version passed the call and was wrong there)
+            ss.append(eng.sample(z.cuda(), mask.cuda(), mu.cuda(), 2, **U.engine_kwargs(case)).cpu().numpy())
     finally:
         os.environ.pop("DEX_ROWCHAIN64A", None)
         eng.set_precision("fp32")
@@ -367,6 +370,11 @@ def test_generated_row_chain_streams_vs_round3_kernel(name, kw, prec):
     mx, mn = LOWP[prec]["call"]
     assert np.isfinite(ys[1]).all() and d.max() > 0.0            # (two different kernels ran)
     assert d.max() <= 0.5 * mx and d.mean() <= 0.5 * mn, (float(d.max()), float(d.mean()))      # measured: 0.27 / 0.25 of the bounds (fp16), 0.3 / 0.25 (bf16)
+    d2 = np.abs(ss[0] - ss[1])
+    U.record(f"rowchain64a_vs_round3_{name}_B{kw['B']}:{prec}:sampler_n2", max=d2.max(), mean=d2.mean(), ref_absmax=np.abs(ss[0]).max())
+    mx2, mn2 = LOWP[prec]["sampler"]
+    assert np.isfinite(ss[1]).all() and d2.max() > 0.0
+    assert d2.max() <= 0.5 * mx2 and d2.mean() <= 0.5 * mn2, (float(d2.max()), float(d2.mean()))
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])

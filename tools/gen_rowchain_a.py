@@ -57,6 +57,10 @@ PRM_BYTES = P_BQ + 3072
 ST = PRM + PRM_BYTES
 LDS_BYTES = ST + 64 * 4 * 8
 
+WS = False                           # split-weight build of the streams (set per generation in main()): every weight fragment is followed in the
+                                     # stream by its lo fragment (what the fp16 rounding of the weight lost; the lo pack sits LO_BYTES behind the
+                                     # hi pack, dit_rowchain.hip LO_*), a product is hi then lo into the same accumulator - both ride the same ring
+LO_BYTES = {"wp": 256 * 256 * 2, "w1": 256 * 512 * 2, "w2": 512 * 256 * 2, "wq": 256 * 768 * 2}      # bytes of a matrix's hi pack (RC_H = 256, RC_MLP = 512)
 NRING = 32                           # weight ring a[0:127].  The ring position of a fragment is (index in the tile's stream) % NRING and the stream wraps
                                      # into the next tile, so NRING must divide every variant's fragment count (256 / 160 / 96): 40 was tried and read the
                                      # previous tile's slots
@@ -74,7 +78,8 @@ S_WA, S_WB = 60, 62           # pairs
 S_C1, S_P, S_A1, S_A2, S_A3, S_A4 = 64, 65, 66, 67, 68, 69
 S_TMP, S_W8, S_W64, S_W128, S_W256, S_C64, S_EPS, S_XSB, S_N0W, S_TMP2 = 70, 71, 72, 73, 74, 75, 76, 77, 78, 79
 S_TS = 80                      # timing build: s_memtime lands in s[80:81], leaves through v[252:253] (v251 = 0) to %[dbg] + 8 k
-S_TOP = 81
+S_WAL, S_WBL = 82, 84          # pairs: the lo halves' bases (split-weight streams)
+S_TOP = 85
 
 
 def vr(i, n=1): return f"v{i}" if n == 1 else f"v[{i}:{i + n - 1}]"
@@ -187,7 +192,7 @@ class Pass:
         self.act, self.act_ks0, self.accs, self.bias, self.trans = act, act_ks0, accs, bias, trans
         self.ntile = len(tiles)
         self.voff = {(2, 16): V_OFF16, (2, 32): V_OFF32, (1, 16): V_OFFQ}[(wmul, kt)]
-        self.nmfma = self.ntile * 2 * nks
+        self.nmfma = self.ntile * 2 * nks * (2 if WS else 1)
 
 
 def set_accs(base, ntile=2):
@@ -213,13 +218,14 @@ class Weights:
     """the fragment stream in consumption order -> ring slot g % NRING; loads are issued in stream order"""
     def __init__(self, p, passes):
         self.p = p
-        self.frags = []                 # (pass index, ks, jj)
+        self.frags = []                 # (pass index, ks, jj, part): part 0 = the (hi) fragment, 1 = its lo fragment (split-weight streams)
         self.index = {}
         for pi, ps in enumerate(passes):
             for ks in range(ps.nks):
                 for jj in range(ps.ntile):
-                    self.index[(pi, ks, jj)] = len(self.frags)
-                    self.frags.append((pi, ks, jj))
+                    for part in range(2 if WS else 1):
+                        self.index[(pi, ks, jj, part)] = len(self.frags)
+                        self.frags.append((pi, ks, jj, part))
         self.passes = passes
         assert len(self.frags) % NRING == 0
         self.tag = {}
@@ -231,15 +237,17 @@ class Weights:
         p = self.p
         while self.next < upto:
             g = self.next
-            pi, ks, jj = self.frags[g % len(self.frags)]
+            pi, ks, jj, part = self.frags[g % len(self.frags)]
             ps = self.passes[pi]
-            if ks % 4 == 0 and jj == 0:
+            if ks % 4 == 0 and jj == 0 and part == 0:
                 for j2 in range(ps.ntile):
                     c = (ps.tiles[j2] * ps.kt + ps.ks0 + ks) * 1024
-                    pair = S_WB if j2 else S_WA
-                    p.e(f"s_add_u32 {sr(pair)}, %[{ps.mat}_lo], {c}")
-                    p.e(f"s_addc_u32 {sr(pair + 1)}, %[{ps.mat}_hi], 0")
-            self.tag[g] = p.vmem(f"global_load_dwordx4 {ar(4 * (g % NRING), 4)}, {vr(ps.voff)}, {sr(S_WB if jj else S_WA, 2)} offset:{(ks % 4) * 1024}")
+                    for lo in range(2 if WS else 1):
+                        pair = ((S_WBL if j2 else S_WAL) if lo else (S_WB if j2 else S_WA))
+                        p.e(f"s_add_u32 {sr(pair)}, %[{ps.mat}_lo], {c + (LO_BYTES[ps.mat] if lo else 0)}")
+                        p.e(f"s_addc_u32 {sr(pair + 1)}, %[{ps.mat}_hi], 0")
+            pair = ((S_WBL if jj else S_WAL) if part else (S_WB if jj else S_WA))
+            self.tag[g] = p.vmem(f"global_load_dwordx4 {ar(4 * (g % NRING), 4)}, {vr(ps.voff)}, {sr(pair, 2)} offset:{(ks % 4) * 1024}")
             self.next += 1
 
 
@@ -367,10 +375,12 @@ def run_pass(p, W, pi, ps, atoms, first_act_tags, acc_tag, next_ps=None):
     nslot = ps.nmfma
     done = 0
     slot_i = 0
+    nparts = 2 if WS else 1
     for ks in range(ps.nks):
-        for jj in range(ps.ntile):
+      for jj in range(ps.ntile):
+        for part in range(nparts):
             for Tt in range(2):
-                g = W.index[(pi, ks, jj)]
+                g = W.index[(pi, ks, jj, part)]
                 p.wait_vm(W.tag.get(g))
                 p.wait_lg(act_tag[(ks, Tt)])
                 if ks == 0:
@@ -381,7 +391,7 @@ def run_pass(p, W, pi, ps, atoms, first_act_tags, acc_tag, next_ps=None):
                 if Tt == 1 and "wload" not in DROP:
                     W.issue(min(g + NRING + 1, W.next + 2))  # fragment g is dead: its slot may take fragment g + NRING (at most two requests per
                                                              # death: the ring fills up over the first passes instead of in one burst at the start)
-                if jj == ps.ntile - 1:                       # activation fragment (ks, T) is dead: its slot takes (ks + 4, T)
+                if jj == ps.ntile - 1 and part == nparts - 1:   # activation fragment (ks, T) is dead: its slot takes (ks + 4, T)
                     if ks + 4 < ps.nks:
                         va, off = act_addr(ps, ks + 4, Tt)
                         act_tag[(ks + 4, Tt)] = p.lds(f"ds_read_b128 {vr(slot, 4)}, {vr(va)} offset:{off}")
@@ -884,22 +894,34 @@ def clobbers():
 
 
 def main():
+    global WS, GELU_TERMS
     parts = ["// GENERATED by tools/gen_rowchain_a.py - do not edit (the generator holds the register map, the schedule and the wait counts).\n"
              "// Instruction streams of the 64-row DiT row chain (dit_rowchain64a_kernel, dit_rowchain.hip); RCA_MFMA / RCA_PK are the\n"
              "// mnemonics of the operand type (bf16 / fp16 build).\n",
              f"#define RCA_LDS_BYTES {LDS_BYTES}\n#define RCA_LDS_AS {AS}\n#define RCA_LDS_HS {HS}\n#define RCA_LDS_PRM {PRM}\n#define RCA_LDS_ST {ST}\n"
              f"#define RCA_A_ROW {A_ROW}\n#define RCA_GELU_TERMS {GELU_TERMS}\n"]
     info = []
-    for name, variant in (("RCA_ASM_PRE", "FULL"), ("RCA_ASM_PRE_QKV", "QKV")):
-        body = prologue(variant).text().replace("\n", " \\\n")
-        parts.append(f"#define {name} \\\n    {body}\n")
-    for name, variant in (("RCA_ASM_FULL", "FULL"), ("RCA_ASM_LAST", "LAST"), ("RCA_ASM_QKV", "QKV")):
-        p = core(variant)
-        body = p.text().replace("\n", " \\\n")
-        parts.append(f"#define {name} \\\n    {body}\n")
-        info.append(f"{variant}: {p.stats} max VMEM in flight (upper bound) {getattr(p, 'max_vm', 0)}, forced waits {getattr(p, 'forced_vm_waits', 0)}")
-        if TIMING:
-            parts.append(f"#define {name}_STAMPS " + ", ".join(f'"{n}"' for n in p.names) + "\n")
+    gelu_default = GELU_TERMS
+    for ws in (False, True):
+        # the split-weight build (namespace dex::f16w: -DDEX_LP_WSPLIT) gets streams of its own under the same macro names.  Its GELU is the
+        # five-term erf (7.1.26, |err| 1.5e-7 - the formula of the C++ kernels): the mode exists to sit at the fp32 reference's 1e-4, the
+        # three-term form's 2.5e-5 is a quarter of that budget, and with twice the MFMA slots the two extra instructions per value hide
+        WS = ws
+        GELU_TERMS = int(os.environ.get("RCAGEN_GELU_WS", "5")) if ws else gelu_default
+        parts.append("#ifdef DEX_LP_WSPLIT\n" if ws else "#ifndef DEX_LP_WSPLIT\n")
+        for name, variant in (("RCA_ASM_PRE", "FULL"), ("RCA_ASM_PRE_QKV", "QKV")):
+            body = prologue(variant).text().replace("\n", " \\\n")
+            parts.append(f"#define {name} \\\n    {body}\n")
+        for name, variant in (("RCA_ASM_FULL", "FULL"), ("RCA_ASM_LAST", "LAST"), ("RCA_ASM_QKV", "QKV")):
+            p = core(variant)
+            body = p.text().replace("\n", " \\\n")
+            parts.append(f"#define {name} \\\n    {body}\n")
+            info.append(f"{'split-weight ' if ws else ''}{variant}: {p.stats} max VMEM in flight (upper bound) {getattr(p, 'max_vm', 0)}, forced waits {getattr(p, 'forced_vm_waits', 0)}")
+            if TIMING:
+                parts.append(f"#define {name}_STAMPS " + ", ".join(f'"{n}"' for n in p.names) + "\n")
+        parts.append("#endif\n")
+    WS = False
+    GELU_TERMS = gelu_default
     parts.append("#define RCA_CLOBBER \\\n    " + clobbers() + "\n")
     text = "\n".join(parts)
     if "--check" in sys.argv:
