@@ -396,13 +396,25 @@ __global__ __launch_bounds__(BM * 4) void igemm_lp_nwalk_kernel(const IGemmP p) 
         *reinterpret_cast<u32x4*>(Bs + (it / KC) * LDS_LD + (it % KC) * 8) = br[j];                                 \
     }
 #ifdef DEX_LP_WSPLIT
-    // split weights: the lo fragments of this wave's 32 columns go straight into B-operand registers (as in the single-shot kernel),
-    // one column tile ahead like the hi tile
+    // split weights (round 6): the lo tile travels like the hi tile - coalesced 16-byte loads one column tile ahead, then LDS - into the
+    // bytes of the A tile, which is dead once every wave holds its token rows as fragments (afr below).  Before, the lo fragments of a
+    // wave's 32 columns were loaded straight into B-operand registers: 16 bytes per lane from 32 weight rows per request, the pattern
+    // that costs the CU's address path 4x a contiguous one, and 128 registers of ring - 124.5 us against the plain build's 52.6 at DEX B = 32.
     const bool has_lo = p.w_lo_off != 0;
-    u32x4 bl_[2][K / 16];
-    const u16* Wlo = Wb + p.w_lo_off + (long)(wn * 32 + i) * K + hh * 8;
-#define NW_LOAD_LO(slot, nt_) _Pragma("unroll") for (int ks_ = 0; ks_ < K / 16; ++ks_) { const u32x4 v_ = *reinterpret_cast<const u32x4*>(Wlo + (long)(nt_) * BN * K + ks_ * 16); bl_[slot][ks_] = has_lo ? v_ : u32x4{0u, 0u, 0u, 0u}; }
-    NW_LOAD_LO(0, 0)
+    u16* Bl = As;
+    u32x4 brl[BIT];
+#define NW_LOAD_LO(nt_)                                                                                             \
+    _Pragma("unroll") for (int j = 0; j < BIT; ++j) {                                                              \
+        const int it = tid + NTHR * j;                                                                              \
+        const u32x4 v_ = *reinterpret_cast<const u32x4*>(Wb + (has_lo ? p.w_lo_off : 0) + (long)((nt_) * BN + it / KC) * K + (it % KC) * 8); \
+        brl[j] = has_lo ? v_ : u32x4{0u, 0u, 0u, 0u};                                                               \
+    }
+#define NW_STORE_LO()                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < BIT; ++j) {                                                              \
+        const int it = tid + NTHR * j;                                                                              \
+        *reinterpret_cast<u32x4*>(Bl + (it / KC) * LDS_LD + (it % KC) * 8) = brl[j];                                \
+    }
+    NW_LOAD_LO(0)
 #endif
     NW_LOAD_B(0)
 #pragma unroll
@@ -470,6 +482,12 @@ __global__ __launch_bounds__(BM * 4) void igemm_lp_nwalk_kernel(const IGemmP p) 
     lp8 afr[K / 16];
 #pragma unroll
     for (int ks = 0; ks < K / 16; ++ks) afr[ks] = *reinterpret_cast<const lp8*>(ap + ks * 16);
+#ifdef DEX_LP_WSPLIT
+    __syncthreads();                                      // every wave holds its rows: the A tile's bytes take the lo weight tiles from here on
+    NW_STORE_LO()
+    __syncthreads();
+    const u16* blp = Bl + (wn * 32 + i) * LDS_LD + hh * 8;
+#endif
     int u_pix, u_f, u_w;
     {
         const int m = m0 + wm * 32 + i;
@@ -482,16 +500,10 @@ __global__ __launch_bounds__(BM * 4) void igemm_lp_nwalk_kernel(const IGemmP p) 
     }
     const float* omask = p.outmask ? p.outmask + (long)b * p.mask_bstride : nullptr;
     const float* biasb = p.bias ? p.bias + (long)b * p.bias_bstride : nullptr;
-#ifdef DEX_LP_WSPLIT
-    for (int nt2 = 0; nt2 < ntile; nt2 += 2)
-#pragma unroll
-    for (int par_ = 0; par_ < 2; ++par_) {                 // (two tiles per trip: the lo ring's slot index is a constant)
-        const int nt = nt2 + par_;
-        if (nt >= ntile) break;
-        if (nt + 1 < ntile) { NW_LOAD_B(nt + 1) NW_LOAD_LO((par_ ^ 1), nt + 1) }
-#else
     for (int nt = 0; nt < ntile; ++nt) {
         if (nt + 1 < ntile) { NW_LOAD_B(nt + 1) }
+#ifdef DEX_LP_WSPLIT
+        if (nt + 1 < ntile) { NW_LOAD_LO(nt + 1) }
 #endif
         const int ng0 = (nt_first + nt) * BN + wn * 32, pp = ng0 / p.unpatch_C;
         const int u_c0 = ng0 - pp * p.unpatch_C;                // first channel of this wave's 32 (a multiple of 32)
@@ -511,7 +523,7 @@ __global__ __launch_bounds__(BM * 4) void igemm_lp_nwalk_kernel(const IGemmP p) 
             const lp8 bf = *reinterpret_cast<const lp8*>(bp + ks * 16);
             acc[0] = DEX_MFMA_LP(bf, afr[ks], acc[0], 0, 0, 0);
 #ifdef DEX_LP_WSPLIT
-            acc[0] = DEX_MFMA_LP(__builtin_bit_cast(lp8, bl_[par_][ks]), afr[ks], acc[0], 0, 0, 0);
+            acc[0] = DEX_MFMA_LP(*reinterpret_cast<const lp8*>(blp + ks * 16), afr[ks], acc[0], 0, 0, 0);
 #endif
         }
         {
@@ -562,6 +574,9 @@ __global__ __launch_bounds__(BM * 4) void igemm_lp_nwalk_kernel(const IGemmP p) 
         if (nt + 1 < ntile) {
             __syncthreads();                              // every wave is done with this weight tile
             NW_STORE_B()
+#ifdef DEX_LP_WSPLIT
+            NW_STORE_LO()
+#endif
             __syncthreads();
         }
     }
