@@ -183,7 +183,8 @@ __global__ __launch_bounds__(256, 1) void attn_q64_kernel(const AttnDirectP p, c
             const unsigned sread = stg + rsel * STAGE_ROW + c16 * 16;
             const float invA = lA > 0.f ? 1.f / lA : 0.f, invB = lB > 0.f ? 1.f / lB : 0.f;
             if (p.o_lp && !cur.tail) {
-                const auto rO = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.O) + (long)b * (orow / 2), 0, (int)(orow / 2), 0x00020000);
+                // (key splits, round 6: slot sp of the 16-bit partials sits o_sstride ELEMENTS behind slot sp - 1, as in the fp32 layout)
+                const auto rO = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<unsigned char*>(p.O) + (long)oslot * p.o_sstride * 2 + (long)b * (orow / 2), 0, (int)(orow / 2), 0x00020000);
                 const unsigned swrite = stg + i * STAGE_ROW + hh * 8;
                 unsigned o[8];
 #define Q64_EPI(STREAM, INV, Q0, RB, HB)                                                                                                        \
