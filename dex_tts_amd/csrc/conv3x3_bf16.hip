@@ -166,7 +166,11 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_lp_kernel(const Conv3P p) {
 #else
 #define CSTAMP(k) do {} while (0)
 #endif
-    const int w0 = blockIdx.x * 32, h0 = blockIdx.y * TH;
+    // (skip_dead: the strip index is rotated by the row-tile and batch indices.  Workgroup L runs on XCD L % 8 and the grid's x extent is
+    // a multiple of 8 at the batch shapes, so unrotated a strip - and with it the padding, which sits in the high strips of every short
+    // utterance - always lands on the same XCD: with 79 % of the tiles skipped three XCDs did all the work and the launch got 9 % shorter)
+    const int xs = p.skip_dead ? (int)((blockIdx.x + blockIdx.y + blockIdx.z) % gridDim.x) : (int)blockIdx.x;
+    const int w0 = xs * 32, h0 = blockIdx.y * TH;
     const int b = blockIdx.z / NSLICE, slice = blockIdx.z % NSLICE;
     const int step = p.step;
     const float* X = p.X + (long)b * p.H * p.W * p.ldx + p.x_coff;
@@ -175,6 +179,19 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_lp_kernel(const Conv3P p) {
     const int K = 9 * p.Cin;
     const u16* Wg = reinterpret_cast<const u16*>(p.Wbf) + (long)slice * NSL * K;     // [COUT][9*Cin], rows of this slice
     const bool pro = p.pro_stats != nullptr;
+    // Round 6: DEAD tiles.  The batched jobs are ragged (an utterance shorter than the batch's T is padded, mask 0) and the reference
+    // computes the padding: the conv sees x * mask = 0 there, so a tile whose 34 patch columns are all masked produces exactly
+    // conv(0) + bias - zero accumulators into the ordinary epilogue (stores, statistics).  Such a tile skips its loads, the GroupNorm /
+    // Mish prologue and every MFMA: bit-identical, 10 - 16 % of the tiles of the benchmarked batches.  (Not the fused-tail form: it also
+    // writes x = mask * Mish(GN(h2)) + res for later consumers, which is not zero in the padding.)
+    bool dead = false;
+    if constexpr (!PRO2) {
+        if (p.skip_dead) {
+            const int wi = w0 - 1 + (lane < 34 ? lane : 33);
+            const float mv = (unsigned)wi < (unsigned)p.W ? mrow[wi * p.mask_ws] : 0.f;
+            dead = __builtin_amdgcn_ballot_w64(mv != 0.f) == 0;          // (every wave of the workgroup computes the same answer)
+        }
+    }
 
     f32x16 acc[NT];
 #pragma unroll
@@ -201,8 +218,8 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_lp_kernel(const Conv3P p) {
     const int pc8 = (tid % (CC / 8)) * 8;             // 256 % (CC/8) == 0: a thread's patch items share one channel chunk
 
     CvGnLoads gnl{};
-    if (pro) gnl = cv_gn_issue(p, b, tid, step);
-    const int nchunk = p.Cin / CC;
+    if (pro && !dead) gnl = cv_gn_issue(p, b, tid, step);
+    const int nchunk = dead ? 0 : p.Cin / CC;
     for (int ch = 0; ch < nchunk; ++ch) {
         const int cbase = ch * CC;
         // ---- every global load of the chunk's first round goes out back to back: the patch FIRST (loads return in order and
@@ -422,10 +439,12 @@ static void launch_c3(const Conv3P& p, hipStream_t st) {
         attr = true;
     }
     dim3 grid((p.W + 31) / 32, (p.H + TH - 1) / TH, p.B * (COUT / NSL));
+    Conv3P q = p;
+    q.skip_dead = knob_or("DEX_CONV_SKIP_DEAD", 1) != 0 ? 1 : 0;
     static char sym[96];
     if (!sym[0]) snprintf(sym, sizeof sym, "conv3x3_lp_kernel<%d,%d,%d,%d,%d,%d,%d,%d>", CC, COUT, NSL, TH, (int)PRO2, (int)RES, (int)XB, NW);
     g_last_symbol = sym;
-    hipLaunchKernelGGL((conv3x3_lp_kernel<CC, COUT, NSL, TH, PRO2, RES, XB, NW>), grid, dim3(64 * NW), lds, st, p);
+    hipLaunchKernelGGL((conv3x3_lp_kernel<CC, COUT, NSL, TH, PRO2, RES, XB, NW>), grid, dim3(64 * NW), lds, st, q);
 }
 
 bool conv3x3_bf16_tail_supported(int C) {

@@ -27,7 +27,7 @@ using namespace dex;
 namespace dex {
 namespace {
 const char* const KNOB_NAMES[] = {
-    "DEX_CONV_STREAM", "DEX_CONV_PP", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_ATTN_Q64", "DEX_ATTN_Q64_TAIL", "DEX_ATTN_Q64_HALF", "DEX_ATTN_PART_LP", "DEX_DIT_XCDS", "DEX_ATTN_GENERIC", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN",
+    "DEX_CONV_STREAM", "DEX_CONV_PP", "DEX_CONV_SKIP_DEAD", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_ATTN_Q64", "DEX_ATTN_Q64_TAIL", "DEX_ATTN_Q64_HALF", "DEX_ATTN_PART_LP", "DEX_DIT_XCDS", "DEX_ATTN_GENERIC", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN",
     "DEX_DIT_CLUSTER", "DEX_DIT_CLUSTER_LOCAL", "DEX_ATTN_X_LP", "DEX_RES_X_LP", "DEX_CAT_LP", "DEX_XCD_MAP", "DEX_DEBUG_DROP_HANDOFF", "DEX_PATCH_FUSED",
     "DEX_CONV_DOWN", "DEX_CONVT_UP", "DEX_DEBUG_PLAN",
     // launcher heuristics (workgroup caps, shape thresholds, form switches) - process-static getenv reads until round 4

@@ -138,6 +138,8 @@ struct Conv3P {
     // x_bf16: X is bf16 [.. ldx] (PRO / PRO2 forms only); y_bf16: Y is written as bf16.  Statistics stay fp32.
     int x_bf16, y_bf16;
     long w_lo_off = 0, res_lo_off = 0;                       // split-weight mode (PREC_FP16X2): elements from a weight of Wbf / res_w to its lo half
+    int skip_dead = 0;                                       // set by the launchers (DEX_CONV_SKIP_DEAD): tiles whose whole input patch lies in an utterance's padding
+                                                             // (mask 0 in every column) skip loads, prologue and MFMAs - conv(0) + bias is what they would compute
 };
 bool conv3x3_bf16_supported(int Cin, int Cout);
 bool conv3x3_bf16_tail_supported(int C);     // pro_res form (Cin == Cout == C)

@@ -316,6 +316,31 @@ def test_xcd_aware_block_order_is_bit_identical(name, kw):
     assert np.isfinite(ys[0]).all() and np.array_equal(ys[0], ys[1]), float(np.abs(ys[0] - ys[1]).max())
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16", "fp16x2"])
+@pytest.mark.parametrize("name,kw", [
+    ("dex_vctk", dict(B=32, T=256, lengths=[256 - 6 * i for i in range(32)], Tr=60, Ts=60)),      # lengths 256 .. 70: up to five of eight 32-column strips in the padding
+    ("gedex_lj", dict(B=32, T=512, lengths=[int(512 * (0.6 + 0.4 * ((7 * i) % 11) / 10.0)) for i in range(32)])),   # the bench's ragged batch
+    ("gedex_lj", dict(B=3, T=132, lengths=[132, 73, 20])),                                        # small grid: the 2-row tile forms
+    ("dex_vctk", dict(B=2, T=64, lengths=[64, 1], Tr=40, Ts=40, sty_lengths=[40, 7])),            # a one-frame utterance
+])
+def test_padding_only_conv_tiles_skip_their_work_bit_identically(name, kw, prec):
+    """Round 6 (conv3x3_lp_kernel): a tile whose whole 34-column input patch lies in an utterance's padding computes conv(0) + bias -
+    it skips loads, prologue and MFMAs and runs the ordinary epilogue on zero accumulators.  DEX_CONV_SKIP_DEAD=0 computes them."""
+    cfg, eng, w = U.engine_for(name)
+    case = U.make_case(cfg, **kw)
+    mu, mask, z = (torch.from_numpy(case[k]).cuda() for k in ("mu", "mask", "z"))
+    set_prec(eng, prec)
+    try:
+        ys = []
+        for flag in ("0", "1"):
+            os.environ["DEX_CONV_SKIP_DEAD"] = flag
+            ys.append(eng.sample(z, mask, mu, 3, **U.engine_kwargs(case)).cpu().numpy())
+    finally:
+        os.environ.pop("DEX_CONV_SKIP_DEAD", None)
+        eng.set_precision("fp32")
+    assert np.isfinite(ys[0]).all() and np.array_equal(ys[0], ys[1]), float(np.abs(ys[0] - ys[1]).max())
+
+
 @pytest.mark.parametrize("prec", ["bf16", "fp16x2"])
 @pytest.mark.parametrize("name,kw", [
     ("dex_vctk", dict(B=32, T=256, lengths=[256 - 3 * i for i in range(32)], Tr=60, Ts=60)),      # 1280 token rows per utterance: ten full 128-row tiles
