@@ -29,6 +29,16 @@
 //   XCD u % 8 and all units of one (element, head) share an XCD (its K and V^T cross the fabric once).  At a unit seam the next
 //   unit's first tiles and its Q are requested BEFORE the finished unit's output leaves, and the output goes through a
 //   wave-private LDS stage so that every store instruction writes whole 256-byte row segments.
+//
+//   ROUND 6 (what differs from the description above; DESIGN.md section 4 "Round 6"):
+//   * unit shapes: a WHOLE unit is the one above; a HALF unit is 4 waves x ONE 32-query block on a block-A-only stream (16 + 16 MFMAs
+//     per tile) - the second, shorter round of the persistent grid when the whole units alone fill it once and a bit (N = 1300: 4 whole
+//     + 3 half units per (element, head) instead of 6 whole ones); its rows leave in the ordinary format, nobody merges anything;
+//   * a stream per WAVE: whole / half / passive - a wave whose blocks lie past the sequence end only requests its share of the tiles
+//     and keeps the barriers (all three streams have the same barrier count and DMA share per tile, so they mix inside a workgroup);
+//   * the v2 streams: the loop is unrolled over the four ring slots (every LDS address an immediate; the V^T ring has four slots, the
+//     fourth aliases the output stage), soffsets advance by one add, the pending-rescale flag is the VCC of the move test, fragments are
+//     staged four sets deep and requested two groups ahead, row sums go to two accumulators per block.
 // Output: normalised O per key split (+ (m, l) for the consumer's merge), the format attn_direct_ring_kernel writes.
 #include <hip/hip_runtime.h>
 #include <algorithm>

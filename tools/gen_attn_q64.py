@@ -10,7 +10,11 @@ plain C++ fillers out of their gaps; as one statement with a fixed register map 
 
     python tools/gen_attn_q64.py            # rewrites the .inc (committed; tests/test_cabi.py checks it is up to date)
 
-Register map (core):
+Round 6: the shipped streams are the v2 ones (class StreamV2 below: one generator for whole units - 64 queries per wave - and half
+units - 32 -, plus passive_v2 for waves without a live query block; the loop is unrolled over the four ring slots, see the comment
+there).  The v1 functions (core / iteration / core_h ...) are kept for A/B builds: Q64GEN_V1=1.
+
+Register map (core; v2 adds v[184:187] row-sum accumulators, v188 the V^T ring's read base, fragment sets a[192:255]):
   a[0:127]   O^T accumulators: block A d-tile td = a[16 td ..], block B = a[64 + 16 td ..]
   a[128:191] Q fragments: QA[s] = a[128 + 4 s ..], QB[s] = a[160 + 4 s ..]
   a[192:223] K / V^T fragment staging: fr[set][q] = a[192 + 16 set + 4 q ..]
