@@ -117,6 +117,35 @@ __device__ __forceinline__ void cv_epilogue(const Conv3P& p, f32x16 (&acc)[NT], 
     }
 }
 
+// the fused 1x1 shortcut's output tile of one wave: + bias, no statistics, same tile addressing as the main output
+template <int NT, int COUT>
+__device__ __forceinline__ void cv_res_store(const Conv3P& p, const f32x16 (&accr)[NT], int b, int ho, int w0, int nb, int lane) {
+    const int i = lane & 31, hh = lane >> 5;
+    float* yl = p.res_y + ((long)b * p.H * p.W + (long)ho * p.W + w0 + 4 * hh) * COUT + nb + i;
+    const bool rfull = ho < p.H && w0 + 32 <= p.W;
+    const bool odd = (lane & 1) != 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float bias = p.res_b[nb + t * 32 + i];
+        if (rfull) {           // channel pairs of 8 rows per lane (DPP swap with the neighbouring lane): 8-byte stores
+            float* yp = yl + (odd ? 16 * COUT - 1 : 0) + t * 32;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float lo_r = accr[t][j] + bias, hi_r = accr[t][8 + j] + bias;
+                const float recv = lane_xor1(odd ? lo_r : hi_r);
+                const float mine = odd ? hi_r : lo_r;
+                *reinterpret_cast<float2*>(yp + ((j & 3) + 8 * (j >> 2)) * COUT) = odd ? make_float2(recv, mine) : make_float2(mine, recv);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int wo = w0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (ho < p.H && wo < p.W) yl[((r & 3) + 8 * (r >> 2)) * COUT + t * 32] = accr[t][r] + bias;
+            }
+        }
+    }
+}
+
 // CC channels per chunk, output-channel slice [slice*NSL, +NSL) of COUT, TH rows (waves: TH x (4/TH)).
 // grid.z = b * (COUT/NSL) + slice.
 template <int CC, int COUT, int NSL, int TH, bool PRO2 = false, bool RES = false, bool XB = false, int NW = 4>
@@ -184,12 +213,22 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_lp_kernel(const Conv3P p) {
     // conv(0) + bias - zero accumulators into the ordinary epilogue (stores, statistics).  Such a tile skips its loads, the GroupNorm /
     // Mish prologue and every MFMA: bit-identical, 10 - 16 % of the tiles of the benchmarked batches.  (Not the fused-tail form: it also
     // writes x = mask * Mish(GN(h2)) + res for later consumers, which is not zero in the padding.)
-    bool dead = false;
+    // (a branch of its own that ENDS the kernel: folded into the main path - a `dead` flag around the chunk loop - it changed the main
+    // path's register allocation: 181 -> 240 VGPRs for the 64-channel form, one resident workgroup per SIMD pair less, +40 % launch time)
     if constexpr (!PRO2) {
         if (p.skip_dead) {
             const int wi = w0 - 1 + (lane < 34 ? lane : 33);
             const float mv = (unsigned)wi < (unsigned)p.W ? mrow[wi * p.mask_ws] : 0.f;
-            dead = __builtin_amdgcn_ballot_w64(mv != 0.f) == 0;          // (every wave of the workgroup computes the same answer)
+            if (__builtin_amdgcn_ballot_w64(mv != 0.f) == 0) {          // (every wave of the workgroup computes the same answer)
+                f32x16 zacc[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) zacc[t][r] = 0.f;
+                if constexpr (RES) cv_res_store<NT, COUT>(p, zacc, b, h0 + wrow, w0, slice * NSL + wcol * NT * 32, lane);
+                cv_epilogue<NT, COUT>(p, zacc, b, h0 + wrow, w0, slice * NSL + wcol * NT * 32, lane, tid, gnred);
+                return;
+            }
         }
     }
 
@@ -218,8 +257,8 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_lp_kernel(const Conv3P p) {
     const int pc8 = (tid % (CC / 8)) * 8;             // 256 % (CC/8) == 0: a thread's patch items share one channel chunk
 
     CvGnLoads gnl{};
-    if (pro && !dead) gnl = cv_gn_issue(p, b, tid, step);
-    const int nchunk = dead ? 0 : p.Cin / CC;
+    if (pro) gnl = cv_gn_issue(p, b, tid, step);
+    const int nchunk = p.Cin / CC;
     for (int ch = 0; ch < nchunk; ++ch) {
         const int cbase = ch * CC;
         // ---- every global load of the chunk's first round goes out back to back: the patch FIRST (loads return in order and
@@ -390,33 +429,7 @@ __global__ __launch_bounds__(64 * NW) void conv3x3_lp_kernel(const Conv3P p) {
             }
         }
     }
-    if constexpr (RES) {
-        // shortcut output: + bias, no statistics, same tile addressing as the main output
-        const int ho = h0 + wrow, nb = slice * NSL + wcol * NT * 32;
-        float* yl = p.res_y + ((long)b * p.H * p.W + (long)ho * p.W + w0 + 4 * hh) * COUT + nb + i;
-        const bool rfull = ho < p.H && w0 + 32 <= p.W;
-        const bool odd = (lane & 1) != 0;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float bias = p.res_b[nb + t * 32 + i];
-            if (rfull) {           // channel pairs of 8 rows per lane (DPP swap with the neighbouring lane): 8-byte stores
-                float* yp = yl + (odd ? 16 * COUT - 1 : 0) + t * 32;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float lo_r = accr[t][j] + bias, hi_r = accr[t][8 + j] + bias;
-                    const float recv = lane_xor1(odd ? lo_r : hi_r);
-                    const float mine = odd ? hi_r : lo_r;
-                    *reinterpret_cast<float2*>(yp + ((j & 3) + 8 * (j >> 2)) * COUT) = odd ? make_float2(recv, mine) : make_float2(mine, recv);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int wo = w0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    if (ho < p.H && wo < p.W) yl[((r & 3) + 8 * (r >> 2)) * COUT + t * 32] = accr[t][r] + bias;
-                }
-            }
-        }
-    }
+    if constexpr (RES) cv_res_store<NT, COUT>(p, accr, b, h0 + wrow, w0, slice * NSL + wcol * NT * 32, lane);
     CSTAMP(3);
     cv_epilogue<NT, COUT>(p, acc, b, h0 + wrow, w0, slice * NSL + wcol * NT * 32, lane, tid, gnred);
 #ifdef DEX_TIMING
@@ -440,7 +453,9 @@ static void launch_c3(const Conv3P& p, hipStream_t st) {
     }
     dim3 grid((p.W + 31) / 32, (p.H + TH - 1) / TH, p.B * (COUT / NSL));
     Conv3P q = p;
-    q.skip_dead = knob_or("DEX_CONV_SKIP_DEAD", 1) != 0 ? 1 : 0;
+    // padding-only tiles are looked for at batch size only: the test is one more dependent load at the head of a launch, and the small
+    // grids are latency chains (B = 1, where nothing is padded anyway: 25.5 -> 25.1 k frames/s with the test on; B = 32 fp16x2: +0.5 ... 2 %)
+    q.skip_dead = (p.B >= 4 && (long)grid.x * grid.y * grid.z >= 1024 && knob_or("DEX_CONV_SKIP_DEAD", 1) != 0) ? 1 : 0;
     static char sym[96];
     if (!sym[0]) snprintf(sym, sizeof sym, "conv3x3_lp_kernel<%d,%d,%d,%d,%d,%d,%d,%d>", CC, COUT, NSL, TH, (int)PRO2, (int)RES, (int)XB, NW);
     g_last_symbol = sym;
