@@ -27,7 +27,7 @@ using namespace dex;
 namespace dex {
 namespace {
 const char* const KNOB_NAMES[] = {
-    "DEX_CONV_STREAM", "DEX_CONV_PP", "DEX_CONV_SKIP_DEAD", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_ATTN_Q64", "DEX_ATTN_Q64_TAIL", "DEX_ATTN_Q64_HALF", "DEX_ATTN_PART_LP", "DEX_DIT_XCDS", "DEX_ATTN_GENERIC", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN",
+    "DEX_CONV_STREAM", "DEX_CONV_PP", "DEX_CONV_SKIP_DEAD", "DEX_H_BF16", "DEX_ATTN_SEPARATE", "DEX_ATTN_Q64", "DEX_ATTN_Q64_TAIL", "DEX_ATTN_Q64_HALF", "DEX_DIT_XCDS", "DEX_ATTN_GENERIC", "DEX_RES2", "DEX_LP_INTER", "DEX_DIT_CHAIN",
     "DEX_DIT_CLUSTER", "DEX_DIT_CLUSTER_LOCAL", "DEX_ATTN_X_LP", "DEX_RES_X_LP", "DEX_CAT_LP", "DEX_XCD_MAP", "DEX_DEBUG_DROP_HANDOFF", "DEX_PATCH_FUSED",
     "DEX_CONV_DOWN", "DEX_CONVT_UP", "DEX_DEBUG_PLAN",
     // launcher heuristics (workgroup caps, shape thresholds, form switches) - process-static getenv reads until round 4
@@ -1266,7 +1266,7 @@ struct Runner {
                 const bool separate = sep_env != KNOB_UNSET ? sep_env != 0 : ((batch_regime && N >= 1024) || q64_ok);
                 const bool q64 = separate && q64_ok;
                 int ks = 1, tail_row0 = 0, tail_ks = 0;
-                bool o_lp = false, part_lp = false;
+                bool o_lp = false;
                 if (separate) {
                     const long blocks = (long)((N + 31) / 32) * 2 * B;
                     const int ntiles = (N + 31) / 32;
@@ -1278,14 +1278,9 @@ struct Runner {
                     // batch forms (shared-ring / 64-query attention -> 64-row chain) it is stored in that type - same bits, half the bytes
                     // (DEX_LP_INTER=0 keeps fp32)
                     o_lp = (batch_regime || q64) && ks == 1 && lp_inter_cur && dit_rowchain64_form(N, B, 0);
-                    // key splits of the 64-query form (long form: six): the partial O slots in the 16-bit type too - each is a normalised
-                    // attention output that the merge weights and the row chain then rounds to the operand type anyway; (m, l) stay fp32.
-                    // Halves the bytes the attention writes and the row chain merges - built, inside every long-form bound, and measured a net LOSS
-                    // (profiles/round6_attention_16bit_partials_negative.txt: attention 30.4 -> 29.6 us, but the 32-row chain's merge 23.3 ->
-                    // 25.9 us - 8-byte loads + unpacking in a loop that was bound by its load count, not its bytes; -1.0 % end to end at
-                    // configs[4]).  OPT-IN: DEX_ATTN_PART_LP=1.
-                    part_lp = q64 && ks > 1 && lp_inter_cur && knob_or("DEX_ATTN_PART_LP", 0) != 0;
-                    ad.o_lp = (o_lp || part_lp) ? 1 : 0;
+                    // (round 6 also built 16-bit PARTIAL slots for the long form's six key splits; a net loss - the 32-row chain's merge is
+                    // bound by its load count, not its bytes: profiles/round6_attention_16bit_partials_negative.txt - and removed again)
+                    ad.o_lp = o_lp ? 1 : 0;
                     // tail split of the 64-query form (attention_q64.hip): whole units for the first query groups, a key split for the
                     // last ones, so that a chip-filling round of long units is followed by a round of short ones; the 64-row chain merges
                     // the tail rows' partials (O slots 1.., fp32) and reads the other rows as before.  OPT-IN (DEX_ATTN_Q64_TAIL=1): measured at
@@ -1297,10 +1292,10 @@ struct Runner {
                         attention_q64_plan(N, B, att_split_cap((long)B * N), &pks, &tg, &tk);
                         if (pks == 1 && tk > 1) { ad.tail_g = tg; ad.tail_ks = tk; ad.ml = P.att_ml; tail_row0 = tg * 256; tail_ks = tk; }
                     }
-                    run("dit_attention", 4.0 * B * (double)N * N * hid, 2.0 * 3 * B * N * hid + ((o_lp || part_lp) ? 2.0 : 4.0) * B * N * hid * ks,
+                    run("dit_attention", 4.0 * B * (double)N * N * hid, 2.0 * 3 * B * N * hid + (o_lp ? 2.0 : 4.0) * B * N * hid * ks,
                         [&] { if (q64) launch_attention_q64(ad, x->precision, st); else launch_attention_direct(ad, x->precision, st); });
                 }
-                ch.attn_inline = separate ? 0 : 1; ch.o_lp = o_lp ? 1 : 0; ch.o_part_lp = part_lp ? 1 : 0; ch.tail_row0 = tail_row0; ch.tail_ks = tail_ks;
+                ch.attn_inline = separate ? 0 : 1; ch.o_lp = o_lp ? 1 : 0; ch.tail_row0 = tail_row0; ch.tail_ks = tail_ks;
                 const bool last = k + 1 == c.dit_depth;
                 ch.O = P.ao; ch.ksplit = ks; ch.o_sstride = (long)B * N * hid; ch.ml = P.att_ml;
                 ch.Wp = x->frag_of().at(w.wproj); ch.W1 = x->frag_of().at(w.wfc1); ch.W2 = x->frag_of().at(w.wfc2);

@@ -324,12 +324,7 @@ __device__ __forceinline__ void rc_merge_splits(const DitChainP& p, const float*
             for (int s_ = 0; s_ < 4; ++s_)
                 if (r0 + s_ < ksplit) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        if (p.o_part_lp) {      // (uniform) 16-bit partials (round 6: the long form's six key splits - half the bytes written and merged)
-                            const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const u16*>(p.O) + (src - p.O) + (long)(r0 + s_) * p.o_sstride + q * 64);
-                            pv[s_][q] = make_float4(lp_lo(u.x), lp_hi(u.x), lp_lo(u.y), lp_hi(u.y));
-                        } else pv[s_][q] = *reinterpret_cast<const float4*>(src + (long)(r0 + s_) * p.o_sstride + q * 64);
-                    }
+                    for (int q = 0; q < 4; ++q) pv[s_][q] = *reinterpret_cast<const float4*>(src + (long)(r0 + s_) * p.o_sstride + q * 64);
                 }
 #pragma unroll
             for (int q = 0; q < 4; ++q)

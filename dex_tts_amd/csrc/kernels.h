@@ -302,7 +302,6 @@ struct DitChainP { const float* O; int ksplit; long o_sstride; const float* ml; 
                    int xlocal;                              // 1: the members of a cluster share an XCD (hand-offs through its L2; grid padded to rounds of 8 clusters)
                    int xdrop;
                    int tail_row0 = 0, tail_ks = 0;
-                   int o_part_lp = 0;                       // ksplit > 1 (64-query attention, long form): the partial slots hold the mode's 16-bit type (same element offsets), (m, l) stay fp32
                    int xcds = 8; };            // xlocal: the clusters are dealt to the first `xcds` XCDs only (workgroups of the others leave at once): fewer L2s fetch the weights and K / V^T      // 64-row form: rows from tail_row0 on are merged from tail_ks fp32 partials in O slots 1.. (AttnDirectP::tail_g); 0 / 1 = off                            // tests only (DEX_DEBUG_DROP_HANDOFF): 1 member 3 never raises its flags -> the peers' waits time out; 2 L2-scope hand-offs across XCDs
 // cluster form of the row chain: workgroups per 32-row tile, bytes of exchange slab / flag words per tile, and whether a launch
 // of B x N rows takes it (all workgroups co-resident: <= one per CU)
