@@ -21,6 +21,7 @@ namespace DEX_LP_NS {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned short u16;
 union LFrag { uint4 u; lp8 v; };
+constexpr float LOG2E_F = 1.4426950408889634f;
 
 
 // grid (nblk, B); 256 threads; each wave owns `nsub` consecutive 32-pixel sub-tiles.
@@ -225,11 +226,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 ? 2
         }
         // head by head: k_h and v_h tiles (2 x 16 accumulator registers live instead of the 128 of all eight tiles at once -
         // the kernel sat at one wave per SIMD), softmax statistics, then ctx_h += v_h^T p_h from those registers
+        // (round 6) SEED forms: the ragged last sub-tile's pixels >= npix enter as -inf seeds of the k accumulators, once per sub-tile,
+        // instead of a compare + select per element and head (124 of the 537 vector instructions of this block); the 16 seed registers
+        // fit beside a 16-bit residual prefetch (the batch forms), with an fp32 one the 64-channel form would spill (12 registers).
+        constexpr bool SEED = C == 128 || (FL >= 0 && (FL & 2) != 0);
+        f32x16 kseed;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) kseed[r] = (SEED && px0 + (r & 3) + 8 * (r >> 2) + 4 * hh >= p.npix) ? -INFINITY : 0.f;
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             f32x16 kh, vh;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { kh[r] = 0.f; vh[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { kh[r] = SEED ? kseed[r] : 0.f; vh[r] = 0.f; }
             const u16* bk = Ws + (h * 32 + i) * LDW + hh * 8;
             const u16* bv = Ws + ((4 + h) * 32 + i) * LDW + hh * 8;
 #pragma unroll
@@ -247,8 +255,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 ? 2
             float mx = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int px = px0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (px >= p.npix) kh[r] = -INFINITY;
+                if constexpr (!SEED) { if (px0 + (r & 3) + 8 * (r >> 2) + 4 * hh >= p.npix) kh[r] = -INFINITY; }
                 mx = fmaxf(mx, kh[r]);
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
@@ -260,9 +267,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(C == 64 ? 2
             const float mn = fmaxf(m_run[h], mx - KSHIFT);
             const float alpha = __expf(m_run[h] - mn);
             m_run[h] = mn;
+            const float nmn2 = -mn * LOG2E_F;
             float ps = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { kh[r] = __expf(kh[r] - mn); ps += kh[r]; }
+            for (int r = 0; r < 16; ++r) { kh[r] = __builtin_amdgcn_exp2f(fmaf(kh[r], LOG2E_F, nmn2)); ps += kh[r]; }
             s_run[h] = s_run[h] * alpha + ps;
 #pragma unroll
             for (int r = 0; r < 16; ++r) ctxT[h][r] *= alpha;

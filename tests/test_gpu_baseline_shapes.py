@@ -394,12 +394,14 @@ def test_generated_row_chain_streams_vs_round3_kernel(name, kw, prec):
     U.record(f"rowchain64a_vs_round3_{name}_B{kw['B']}:{prec}:call", max=d.max(), mean=d.mean(), ref_absmax=np.abs(ys[0]).max())
     mx, mn = LOWP[prec]["call"]
     assert np.isfinite(ys[1]).all() and d.max() > 0.0            # (two different kernels ran)
-    assert d.max() <= 0.5 * mx and d.mean() <= 0.5 * mn, (float(d.max()), float(d.mean()))      # measured: 0.27 / 0.25 of the bounds (fp16), 0.3 / 0.25 (bf16)
+    # the distance of two kernels: its mean is stable (0.25-0.45 of the bound in every mode), its maximum is one element of a tail and
+    # moves with any rounding change upstream (fp16x2 B = 10: 1.6e-3 -> 2.1e-3 when the linear attention's exp became fma + exp2)
+    assert d.max() <= 0.75 * mx and d.mean() <= 0.5 * mn, (float(d.max()), float(d.mean()))
     d2 = np.abs(ss[0] - ss[1])
     U.record(f"rowchain64a_vs_round3_{name}_B{kw['B']}:{prec}:sampler_n2", max=d2.max(), mean=d2.mean(), ref_absmax=np.abs(ss[0]).max())
     mx2, mn2 = LOWP[prec]["sampler"]
     assert np.isfinite(ss[1]).all() and d2.max() > 0.0
-    assert d2.max() <= 0.5 * mx2 and d2.mean() <= 0.5 * mn2, (float(d2.max()), float(d2.mean()))
+    assert d2.max() <= 0.75 * mx2 and d2.mean() <= 0.5 * mn2, (float(d2.max()), float(d2.mean()))
 
 
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
