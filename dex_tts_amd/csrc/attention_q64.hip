@@ -109,20 +109,43 @@ __global__ __launch_bounds__(256, 1) void attn_q64_kernel(const AttnDirectP p, c
     const int half_n = p.half_n > 0 ? p.half_n : 0;          // half units (4 waves x ONE 32-query block) per (element, head) behind half_g whole groups
     const int tail_g = half_n ? p.half_g : tks > 1 ? p.tail_g : ng;
     const int nwhole = 2 * p.B * tail_g * ks;                 // units of the whole groups (all of them without a tail split / half units)
+    // Unit decode without integer division (round 6): hipcc's signed 32-bit / 64-bit divisions by run-time values were ~400 SCALAR instructions
+    // per decode - ~3.4k cycles for a lone wave (tools/valubench: ~8.5 cycles per scalar instruction) at the start of the launch and at every
+    // unit seam, 7 % of a workgroup's time at N = 1300.  Quotients of small unsigned values through a float reciprocal + one correction step
+    // (a < 2^22, b < 2^12: the truncated product is off by at most one either way).
+    auto divmod = [](unsigned a, unsigned b, float rb, unsigned& q, unsigned& r) __attribute__((always_inline)) {
+        q = (unsigned)((float)a * rb);
+        int rem = (int)(a - q * b);
+        if (rem < 0) { --q; rem += (int)b; }
+        else if (rem >= (int)b) { ++q; rem -= (int)b; }
+        r = (unsigned)rem;
+    };
+    // the two unit classes: whole groups (key split ks), then tail-split groups or half units
+    const unsigned per_w = (unsigned)(tail_g * ks), per_s = (unsigned)(half_n ? half_n : (ng - tail_g) * tks);
+    const float rcp_per_w = 1.f / (float)(per_w ? per_w : 1u), rcp_per_s = 1.f / (float)(per_s ? per_s : 1u);
+    const float rcp_ks = 1.f / (float)ks, rcp_tks = 1.f / (float)tks;
     auto decode = [&](int unit) __attribute__((always_inline)) -> Q64Unit {
         Q64Unit u;
         const int second = unit >= nwhole ? 1 : 0;            // the unit order's second class: tail-split groups, or half units
         u.half = second && half_n ? 1 : 0;
         u.tail = second && !half_n ? 1 : 0;
-        const int uks = u.tail ? tks : u.half ? 1 : ks;
-        const int per = u.half ? half_n : (u.tail ? ng - tail_g : tail_g) * uks;
-        int r = second ? unit - nwhole : unit;
-        if (xcd_mode) { const int x = r & 7, s = r >> 3; u.bh = x + 8 * (s / per); r = s % per; }
-        else { u.bh = r / per; r = r % per; }
-        u.g = r / uks + (u.tail ? tail_g : 0); u.sp = r % uks;
-        u.blk0 = u.half ? 8 * tail_g + 4 * r : 8 * u.g;
-        u.T_lo = (int)((long)nT * u.sp / uks);
-        u.nt = (int)((long)nT * (u.sp + 1) / uks) - u.T_lo;
+        const unsigned uks = u.tail ? (unsigned)tks : u.half ? 1u : (unsigned)ks;
+        const float rcp_uks = u.tail ? rcp_tks : u.half ? 1.f : rcp_ks;
+        const unsigned per = second ? per_s : per_w;
+        const float rcp_per = second ? rcp_per_s : rcp_per_w;
+        unsigned r = (unsigned)(second ? unit - nwhole : unit), q;
+        if (xcd_mode) { const unsigned x = r & 7u; divmod(r >> 3, per, rcp_per, q, r); u.bh = (int)(x + 8u * q); }
+        else { divmod(r, per, rcp_per, q, r); u.bh = (int)q; }
+        unsigned g = r, sp = 0;
+        if (uks > 1) divmod(r, uks, rcp_uks, g, sp);           // (uniform)
+        u.g = (int)g + (u.tail ? tail_g : 0); u.sp = (int)sp;
+        u.blk0 = u.half ? 8 * tail_g + 4 * (int)r : 8 * u.g;
+        if (uks > 1) {
+            unsigned t0, t1, rem;
+            divmod((unsigned)nT * sp, uks, rcp_uks, t0, rem);
+            divmod((unsigned)nT * (sp + 1), uks, rcp_uks, t1, rem);
+            u.T_lo = (int)t0; u.nt = (int)(t1 - t0);
+        } else { u.T_lo = 0; u.nt = nT; }
         u.tail = __builtin_amdgcn_readfirstlane(u.tail); u.half = __builtin_amdgcn_readfirstlane(u.half);
         u.bh = __builtin_amdgcn_readfirstlane(u.bh); u.g = __builtin_amdgcn_readfirstlane(u.g); u.sp = __builtin_amdgcn_readfirstlane(u.sp);
         u.blk0 = __builtin_amdgcn_readfirstlane(u.blk0);
@@ -158,6 +181,8 @@ __global__ __launch_bounds__(256, 1) void attn_q64_kernel(const AttnDirectP p, c
     Q64Unit cur = decode(blockIdx.x);
     issue_prologue(cur);
     int first_unit = 1;
+    // (no peeling: a peeled first iteration is a second copy of the 13k-instruction core statement)
+#pragma clang loop unroll(disable)
     for (int unit = blockIdx.x;;) {
         const int bh = cur.bh, sp = cur.sp, oslot = cur.tail ? 1 + cur.sp : cur.sp;
         const int b = bh >> 1, h = bh & 1;
