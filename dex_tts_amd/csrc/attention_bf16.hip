@@ -404,6 +404,10 @@ static_assert(2 * 128 * K_LD <= TVC_U16 && 128 * K_LD * 2 + 128 * TVC_SLD * 4 <=
 //     exceeds it by more than TVC_TAU; until then P = exp(s - m) is formed against the old m (<= e^TAU, no overflow in either operand
 //     type), which is the same softmax once O is divided by the l accumulated against the same m.
 constexpr float TVC_TAU = 6.f, TVC_LOG2E = 1.4426950408889634f;
+// FRAG (the folded form below): the tiles lie in LDS in MFMA fragment order - piece (st, ks) of K', piece (t, st * 2 + k2) of V'^T, 1 KB
+// each, lane l's 16 bytes at l * 16 - as the LDS-DMA ring delivers them from operands their producers write in that order (linear,
+// unpadded, conflict-free); otherwise padded row-major tiles (K_LD / TVC_VLD).
+template <bool FRAG = false>
 __device__ __forceinline__ void tvc_tile(const u16* kS, const u16* vT, const Frag (&qf)[8], f32x16 (&o)[4], float& m_run, float& l_run, int k0, int Nk, int lane) {
     constexpr int KT = TVC_KT, V_LD = TVC_VLD, NS = KT / 32;
     const int i = lane & 31, hh = lane >> 5;
@@ -412,10 +416,10 @@ __device__ __forceinline__ void tvc_tile(const u16* kS, const u16* vT, const Fra
     for (int st = 0; st < NS; ++st) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[st][r] = 0.f;
-        const u16* ka = kS + (st * 32 + i) * K_LD + hh * 8;
+        const u16* ka = FRAG ? kS + (st * 8 * 64 + lane) * 8 : kS + (st * 32 + i) * K_LD + hh * 8;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            Frag a; a.u = *reinterpret_cast<const uint4*>(ka + ks * 16);
+            Frag a; a.u = *reinterpret_cast<const uint4*>(ka + ks * (FRAG ? 512 : 16));
             s[st] = DEX_MFMA_LP(a.v, qf[ks].v, s[st], 0, 0, 0);
         }
     }
@@ -461,10 +465,10 @@ __device__ __forceinline__ void tvc_tile(const u16* kS, const u16* vT, const Fra
             Frag pb;
             pb.u.x = pack2_lp_asm(s[st][8 * k2 + 0], s[st][8 * k2 + 1]); pb.u.y = pack2_lp_asm(s[st][8 * k2 + 2], s[st][8 * k2 + 3]);
             pb.u.z = pack2_lp_asm(s[st][8 * k2 + 4], s[st][8 * k2 + 5]); pb.u.w = pack2_lp_asm(s[st][8 * k2 + 6], s[st][8 * k2 + 7]);
-            const u16* va = vT + i * V_LD + (st * 2 + k2) * 16 + hh * 8;
+            const u16* va = FRAG ? vT + ((st * 2 + k2) * 64 + lane) * 8 : vT + i * V_LD + (st * 2 + k2) * 16 + hh * 8;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                Frag a; a.u = *reinterpret_cast<const uint4*>(va + t * 32 * V_LD);
+                Frag a; a.u = *reinterpret_cast<const uint4*>(va + t * (FRAG ? 4 * 512 : 32 * V_LD));
                 o[t] = DEX_MFMA_LP(a.v, pb.v, o[t], 0, 0, 0);
             }
         }
@@ -772,6 +776,206 @@ __global__ __launch_bounds__(256, 2) void tv_chain_kernel(const TvChainP p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// FOLDED form (round 6; bf16 / fp16 modes): w_q and `linear` live inside the style operands (dex_elem.hip tv_fold2_kernel per step,
+// tv_vfrag_prep_kernel below per call; dex_api.hip prepare()):
+//   scores = (x * mask - mean) . K'^T,   K'[key][k] = rstd[k] / sqrt(C) * sum_n K[key][n] W_q[n][k]      (IN2d and w_q inside the keys)
+//   result = mask * (x + softmax(scores) V'),   V'[key][c] = sum_d V[key][d] W_l[c][d]                      (`linear` inside the values)
+// so a workgroup runs NO projection: the centred x tile is the score MFMAs' B operand as it lies in LDS, the normalised O^T accumulators
+// go straight to the output stage - per wave 64 of 256 MFMAs, both weight stagings (2 x 32 KB per workgroup from L2) and three
+// workgroup barriers less.  And the K' / V'^T operands are written by their producers in MFMA FRAGMENT order (a 64-key tile = sixteen
+// 1-KB pieces each), so the ring is filled by LDS-DMA (global_load_lds_dwordx4, four + four pieces per wave and tile): no staging
+// registers (the register-staged ring above keeps its 8 x 16 bytes per thread in SCRATCH across every tile - 16 + 10 scratch
+// instructions in the loop), no ds_write pass, unpadded conflict-free fragment reads.
+// LDS: [K'0 | V'^T0 | K'1 | V'^T1], 4 x 16 KB; the x tile and the output stage alias the second half (+ 2.8 KB), so tile 0 lands under
+// the x rows.  The residual rows of the first output half are requested under the last tile, the second half's before the first is
+// processed (the registers the projection form spends on W_l's prefetch).
+constexpr int TVC_FBUF = TVC_KT * AHD;                          // u16 per fragment-ordered K' or V'^T tile (16 KB: sixteen 1-KB pieces)
+static_assert(2 * TVC_FBUF + 128 * K_LD <= TVC_U16 && 2 * TVC_FBUF * 2 + 128 * TVC_SLD * 4 <= TVC_U16 * 2, "x tile / output stage fit behind ring half 0");
+__global__ __launch_bounds__(256, 2) void tv_chain_fold_kernel(const TvChainP p) {
+    extern __shared__ __attribute__((aligned(16))) u16 smem_b[];
+    __shared__ long long red[2 * AHD];
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.y, row0 = blockIdx.x * 128;
+    int Nk = p.Nk;
+    if (p.kv_len) Nk = min(p.Nk, p.kv_len[b] + p.kv_len_add);
+    const int ntiles = (TVC_SKIP & 1) ? 0 : (Nk + TVC_KT - 1) / TVC_KT;
+    const float* Xb = p.X + (long)b * p.x_bstride + p.x_coff;
+    const float* mrow = p.mask + (long)b * p.mask_bstride;
+    const u16* Kg = reinterpret_cast<const u16*>(p.Kp) + (long)b * p.NkPad * AHD;
+    const u16* Vg = reinterpret_cast<const u16*>(p.VTp) + (long)b * AHD * p.NkPad;
+    red[tid] = 0;
+    auto kv_dma = [&](int kt) __attribute__((always_inline)) {       // tile kt of the fragment-ordered operands -> ring half kt & 1
+        u16* dst = smem_b + (kt & 1) * 2 * TVC_FBUF;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int piece = 4 * wave + j;
+            __builtin_amdgcn_global_load_lds(Kg + (long)kt * TVC_FBUF + piece * 512 + lane * 8, (lds_ptr)(dst + piece * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(Vg + (long)kt * TVC_FBUF + piece * 512 + lane * 8, (lds_ptr)(dst + TVC_FBUF + piece * 512), 16, 0, 0);
+        }
+    };
+    if (ntiles > 0) kv_dma(0);               // first K' / V'^T tile in flight under the x rows
+
+    // ---- prologue: the 128 x rows, masked and centred (x * mask - mean: what IN2d subtracts; its 1 / std lives in K'), rounded once
+    u16* Xs = smem_b + 2 * TVC_FBUF;         // [128 pixels][K_LD]
+    Frag qf[8];
+    {
+        const float4 mu = *reinterpret_cast<const float4*>(p.xmean + (long)b * AHD + (tid & 31) * 4);
+        if (p.zero_ptr) {                    // the TV input statistics' next use is the next step: cleared here, after their last reader (launch_tv_fold2)
+            const long zstep = (long)gridDim.x * gridDim.y * 512;
+            for (long zi = ((long)(blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid) * 2; zi < p.zero_n; zi += zstep)       // (zero_n even, 8-byte aligned)
+                *reinterpret_cast<float2*>(p.zero_ptr + zi) = make_float2(0.f, 0.f);
+        }
+        // all sixteen row chunks of a thread in flight together: one round trip
+        float4 xa[16];
+        float mk[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int id = tid + 256 * j;
+            const int pix = row0 + (id >> 5);
+            const bool ok = pix < p.npix;
+            const int pc = ok ? pix : p.npix - 1;
+            xa[j] = (TVC_SKIP & 4) ? make_float4(1.f, 2.f, 3.f, 4.f) : *reinterpret_cast<const float4*>(Xb + (long)pc * p.ldx + (id & 31) * 4);
+            const float mv = mrow[(pc % p.Wm) * p.mask_ws];
+            mk[j] = ok ? mv : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int id = tid + 256 * j;
+            *reinterpret_cast<uint2*>(Xs + (id >> 5) * K_LD + (id & 31) * 4) =
+                make_uint2(pack2_lp(fmaf(xa[j].x, mk[j], -mu.x), fmaf(xa[j].y, mk[j], -mu.y)), pack2_lp(fmaf(xa[j].z, mk[j], -mu.z), fmaf(xa[j].w, mk[j], -mu.w)));
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) qf[ks].u = *reinterpret_cast<const uint4*>(Xs + (wave * 32 + i) * K_LD + ks * 16 + hh * 8);
+    // (the loop's first barrier - or the one in front of the last tile - separates these reads from tile 1's DMA into the same bytes)
+
+    // ---- attention over the style keys
+    f32x16 o[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    float4 rpre[2][8];
+    float mkp[8];
+    auto res_load = [&](int h) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int id = j * 64 + lane;
+            const int px = id >> 4, c4 = (id & 15) * 4;
+            const int pix = row0 + wave * 32 + px;
+            const int pc = pix < p.npix ? pix : p.npix - 1;
+            rpre[h][j] = (TVC_SKIP & 2) ? make_float4(0.f, 0.f, 0.f, 0.f) : *reinterpret_cast<const float4*>(Xb + (long)pc * p.ldx + h * 64 + c4);
+            if (h == 0) { const float mv = mrow[(pc % p.Wm) * p.mask_ws]; mkp[j] = pix < p.npix ? mv : 0.f; }
+        }
+    };
+    for (int kt = 0; kt + 1 < ntiles; ++kt) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces of tile kt have landed
+        __syncthreads();                     // ... everybody's: tile kt visible; ring half (kt + 1) & 1 (and the x tile in it) free
+        kv_dma(kt + 1);
+        tvc_tile<true>(smem_b + (kt & 1) * 2 * TVC_FBUF, smem_b + (kt & 1) * 2 * TVC_FBUF + TVC_FBUF, qf, o, m_run, l_run, kt * TVC_KT, Nk, lane);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+    res_load(0);
+    if (ntiles > 0) {
+        const int kt = ntiles - 1;
+        tvc_tile<true>(smem_b + (kt & 1) * 2 * TVC_FBUF, smem_b + (kt & 1) * 2 * TVC_FBUF + TVC_FBUF, qf, o, m_run, l_run, kt * TVC_KT, Nk, lane);
+    }
+    l_run += __shfl_xor(l_run, 32);
+    const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+    __syncthreads();                         // rings free
+
+    // ---- result: O^T / l through the LDS stage as 256-byte row segments, + residual, * mask, the TIV statistics (as the projection form)
+    float* stage = reinterpret_cast<float*>(smem_b + 2 * TVC_FBUF);          // [128 pixels][TVC_SLD]
+    float gs[2][4], gq[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gs[h][e] = 0.f; gq[h][e] = 0.f; }
+    float* myst = stage + wave * 32 * TVC_SLD;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int t = 2 * h + u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(myst + i * TVC_SLD + u * 32 + 8 * g + 4 * hh) =
+                    make_float4(o[t][4 * g + 0] * inv, o[t][4 * g + 1] * inv, o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): this wave's stage rows written
+        __builtin_amdgcn_wave_barrier();
+        if (h == 0) res_load(1);
+        float4 sv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int id = j * 64 + lane;
+            const int px = id >> 4, c4 = (id & 15) * 4;
+            sv[j] = *reinterpret_cast<const float4*>(myst + px * TVC_SLD + c4);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int id = j * 64 + lane;
+            const int px = id >> 4, c4 = (id & 15) * 4;
+            const int pix = row0 + wave * 32 + px;
+            const float4 rv = rpre[h][j];
+            float4 v;
+            v.x = (sv[j].x + rv.x) * mkp[j]; v.y = (sv[j].y + rv.y) * mkp[j];
+            v.z = (sv[j].z + rv.z) * mkp[j]; v.w = (sv[j].w + rv.w) * mkp[j];
+            if (pix < p.npix) {
+                if (!(TVC_SKIP & 2) || v.x == 12345.f) *reinterpret_cast<float4*>(p.out + ((long)b * p.npix + pix) * AHD + h * 64 + c4) = v;
+                gs[h][0] += v.x; gs[h][1] += v.y; gs[h][2] += v.z; gs[h][3] += v.w;
+                gq[h][0] = fmaf(v.x, v.x, gq[h][0]); gq[h][1] = fmaf(v.y, v.y, gq[h][1]);
+                gq[h][2] = fmaf(v.z, v.z, gq[h][2]); gq[h][3] = fmaf(v.w, v.w, gq[h][3]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();               // the stage rows are rewritten by the next half
+    }
+    if (p.stats) {
+        const double inv_n = 1.0 / (double)p.npix;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = gs[h][e], q = gq[h][e];
+                a += __shfl_xor(a, 16); q += __shfl_xor(q, 16);
+                a += __shfl_xor(a, 32); q += __shfl_xor(q, 32);
+                if (lane < 16) {
+                    const int ch = h * 64 + lane * 4 + e;
+                    gn_add(&red[ch * 2], gn_fix(a, inv_n)); gn_add(&red[ch * 2 + 1], gn_fix(q, inv_n));
+                }
+            }
+        __syncthreads();
+        const long long v = red[tid];
+        if (v != 0) gn_add(p.stats + (((long)b * AHD + (tid >> 1)) * GN_SLOTS + (blockIdx.x % GN_SLOTS)) * 2 + (tid & 1), v);
+    }
+}
+
+// V' (fp32 [B][Nk][C], row 0 = the time token: rewritten per step by tv_fold2_kernel) -> the 16-bit V'^T operand in fragment order:
+// VTp[b][tile][t][q][lane (i, hh)][e] = V'[b][key = tile * 64 + (q >> 1) * 32 + (q & 1) * 16 + key_pos(hh * 8 + e)][ch = t * 32 + i], 0 for keys >= Nk
+__global__ __launch_bounds__(256) void tv_vfrag_prep_kernel(const TvKvPrepP p) {
+    const long n = (long)p.B * (p.NkPad / 64) * 16 * 64;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int lane = (int)(idx & 63), q = (int)((idx >> 6) & 3), t = (int)((idx >> 8) & 3);
+    const long bt = idx >> 10;
+    const int tile = (int)(bt % (p.NkPad / 64)), b = (int)(bt / (p.NkPad / 64));
+    const int i = lane & 31, hh = lane >> 5, ch = t * 32 + i;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int key = tile * 64 + (q >> 1) * 32 + (q & 1) * 16 + key_pos(hh * 8 + e);
+        v[e] = key < p.Nk ? p.V[(long)b * p.kvb + (long)key * AHD + ch] : 0.f;
+    }
+    reinterpret_cast<uint4*>(p.VTp)[idx] = make_uint4(pack2_lp(v[0], v[1]), pack2_lp(v[2], v[3]), pack2_lp(v[4], v[5]), pack2_lp(v[6], v[7]));
+}
+
 // The one-launch TV adaptor takes every grid: measured against the three launches (tools/tv_chain_small_batches.py, 10-step calls, bf16)
 // B = 1: +1.3 ... 3.5 % end to end (T = 128 ... 512), B = 2 ... 12: +2.4 ... 5.8 %, B = 32: +4.5 %.  DEX_TV_CHAIN=0: the three launches.
 bool tv_chain_form(int npix, int C, int B) {
@@ -782,15 +986,26 @@ void launch_tv_kv_prep(const TvKvPrepP& p, hipStream_t st) {
     const long n = (long)p.B * p.NkPad * (AHD / 8) + (long)p.B * (p.NkPad / 8) * AHD;
     hipLaunchKernelGGL(tv_kv_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
 }
+void launch_tv_vfrag_prep(const TvKvPrepP& p, hipStream_t st) {
+    const long n = (long)p.B * (p.NkPad / 64) * 16 * 64;
+    hipLaunchKernelGGL(tv_vfrag_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+}
 void launch_tv_chain(const TvChainP& p, hipStream_t st) {
     const size_t lds = (size_t)TVC_U16 * sizeof(u16);
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&tv_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&tv_chain_fold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
+    const dim3 grid((p.npix + 127) / 128, p.B);
+    if (p.xmean) {                     // the folded form (kernels.h TvChainP)
+        g_last_symbol = "tv_chain_fold_kernel";
+        hipLaunchKernelGGL(tv_chain_fold_kernel, grid, dim3(256), lds, st, p);
+        return;
+    }
     g_last_symbol = "tv_chain_kernel";
-    hipLaunchKernelGGL(tv_chain_kernel, dim3((p.npix + 127) / 128, p.B), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(tv_chain_kernel, grid, dim3(256), lds, st, p);
 }
 
 }  // namespace DEX_LP_NS

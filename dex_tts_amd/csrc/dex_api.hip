@@ -33,7 +33,7 @@ const char* const KNOB_NAMES[] = {
     // launcher heuristics (workgroup caps, shape thresholds, form switches) - process-static getenv reads until round 4
     "DEX_ATTN_SHARED_W8", "DEX_CONVT_MT", "DEX_CONVT_WGS", "DEX_CONV_DOWN_WGS", "DEX_CONV_REGW", "DEX_CONV_REGW_RES", "DEX_CONV_SMALL_MAX", "DEX_CONV_TH8",
     "DEX_CONV_W8", "DEX_DWCONV_CAP", "DEX_FINAL_CAP", "DEX_FIRST_CAP", "DEX_FIRST_MFMA", "DEX_GEMM_NWALK", "DEX_NWALK_SPLIT", "DEX_NWALK_BM", "DEX_POS_COL", "DEX_POS_COL_MIN",
-    "DEX_POS_CT", "DEX_REGW_MIN_TILES", "DEX_REGW_WGS", "DEX_ROWCHAIN64", "DEX_ROWCHAIN64A", "DEX_TIV_CAP", "DEX_TV_CHAIN", "DEX_TIV_FOLD", "DEX_LINATTN_NSUB"};
+    "DEX_POS_CT", "DEX_REGW_MIN_TILES", "DEX_REGW_WGS", "DEX_ROWCHAIN64", "DEX_ROWCHAIN64A", "DEX_TIV_CAP", "DEX_TV_CHAIN", "DEX_TIV_FOLD", "DEX_LINATTN_NSUB", "DEX_TV_FOLD"};
 constexpr int N_KNOBS = (int)(sizeof(KNOB_NAMES) / sizeof(KNOB_NAMES[0]));
 // value of one variable: a decimal integer; unset, empty or without digits ("true", "on") = KNOB_UNSET, so a typo leaves the default
 // form on instead of silently switching it off
@@ -700,6 +700,7 @@ struct Plan {
     float *tv_keys, *tv_K, *tv_V, *tv_q, *tv_ao, *tv_out, *tiv_out, *tv_weff, *tv_beff; gnfix_t *tv_stats, *tiv_stats; void* tv_wbf;
     float* tiv_aff;                            // TIV adaptor folded into the patch embedding's load: [B][2][mid] coefficients (launch_tiv_coef)
     void *tv_kp, *tv_vtp; int tv_nkpad;        // the one-launch TV adaptor's 16-bit key / value operands (TvKvPrepP)
+    float *tv_G, *tv_Vp, *tv_g0, *tv_v0p, *tv_xmean;   // its folded form (TvFold2P): G = K W_q, V' = V W_l^T ([B][Ts + 1][mid], row 0 unused), the time token's rows per step, the IN2d means
     size_t bytes;
 };
 
@@ -860,6 +861,7 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
     P.tv_keys = P.tv_K = P.tv_V = P.tv_q = P.tv_ao = P.tv_out = P.tiv_out = P.tv_weff = P.tv_beff = nullptr; P.tv_wbf = nullptr;
     P.tv_stats = P.tiv_stats = nullptr;
     P.tv_kp = P.tv_vtp = nullptr; P.tv_nkpad = 0;
+    P.tv_G = P.tv_Vp = P.tv_g0 = P.tv_v0p = P.tv_xmean = nullptr;
     P.tiv_aff = nullptr;
     if (c.variant == DEX_VARIANT_DEX) {
         const size_t pm = (size_t)B * P.Hm * P.Wm;
@@ -872,6 +874,8 @@ void make_plan(const DexCtx* x, const Dims& d, void* ws, Plan& P) {
         P.tv_kp = A.take((size_t)B * P.tv_nkpad * mid * 2); P.tv_vtp = A.take((size_t)B * P.tv_nkpad * mid * 2);
         P.tv_stats = (gnfix_t*)A.take((size_t)B * mid * IN_SLOTS * 2 * 2 * sizeof(gnfix_t));   // IN2d partials of the TV input and the TIV input
         P.tiv_stats = A.dry ? nullptr : P.tv_stats + (size_t)B * mid * IN_SLOTS * 2;
+        P.tv_G = A.f((size_t)B * (d.Ts + 1) * mid); P.tv_Vp = A.f((size_t)B * (d.Ts + 1) * mid);
+        P.tv_g0 = A.f((size_t)n * mid); P.tv_v0p = A.f((size_t)n * mid); P.tv_xmean = A.f((size_t)B * mid);
     }
     P.bytes = (A.off + 255) & ~size_t(255);
 }
@@ -1371,6 +1375,9 @@ struct Runner {
     bool tv_chain_on() const {
         return x->lp() && x->lp_of().count(x->tv_wl) && P.tv_kp && tv_chain_form(P.Hm * P.Wm, mid_dim(x->cfg), P.d.B);
     }
+    // ... in its folded form (w_q and `linear` inside the style operands: kernels.h TvFold2P).  bf16 / fp16 modes: the split-weight mode would need K' and
+    // V' as hi + lo pairs, i.e. twice the MFMAs of the key tiles that bound the kernel - it keeps the projections (DEX_TV_FOLD=0: every mode does)
+    bool tv_fold_on() const { return tv_chain_on() && x->lpi() != 2 && P.tv_G && knob_or("DEX_TV_FOLD", 1) != 0; }
     // TVAdaptor + TIVAdaptor (ref_encoder.py:154-179,264-273); X is the (unmasked) bottleneck view.
     void dex_adaptors(const TD& X, int mask_ws) {
         const DexConfig& c = x->cfg;
@@ -1380,6 +1387,21 @@ struct Runner {
         // time-token kernel, which runs after their last reader)
         InStatsP is{X.p + X.coff, X.ld, npix * X.ld, (int)npix, mid, P.tv_stats, B, mask, mask_ws, (long)P.d.T, P.Wm};
         run("in2d_stats", 3.0 * npix * mid * B, 4.0 * npix * mid * B, [&] { launch_in_stats(is, st); });
+        const long stats_floats = (long)B * mid * IN_SLOTS * 2 * (long)(sizeof(gnfix_t) / sizeof(float));      // of ONE of the two statistics arrays
+        if (tv_fold_on()) {
+            // folded form: one element-wise launch turns the statistics into this step's K' (and the time token's rows), then the chain
+            TvFold2P f2{P.tv_stats, (int)npix, 1e-5f, P.tv_G, (long)(P.d.Ts + 1) * mid, P.tv_g0, P.tv_v0p, sp, P.d.Ts + 1, P.tv_nkpad, mid,
+                        1.0f / sqrtf((float)mid), P.tv_kp, P.tv_vtp, P.tv_xmean, reinterpret_cast<float*>(P.tiv_stats), stats_floats, x->lp_kind(), B};
+            run("tv_fold_keys", 2.0 * B * (P.d.Ts + 1) * mid, 6.0 * B * (P.d.Ts + 1) * mid, [&] { launch_tv_fold2(f2, st); });
+            TvChainP tc{X.p, X.ld, X.coff, npix * X.ld, (int)npix, P.Wm, mask, mask_ws, (long)P.d.T,
+                        nullptr, 0L, nullptr, nullptr, 0L,
+                        P.tv_kp, P.tv_vtp, P.tv_nkpad, P.d.Ts + 1, args->sty_lengths_dev, 1, 1.0f,
+                        P.tv_out, P.tiv_stats, B, P.tv_xmean, reinterpret_cast<float*>(P.tv_stats), stats_floats};
+            run("tv_chain", 4.0 * B * (double)npix * (P.d.Ts + 1) * mid, 8.0 * B * npix * mid, [&] { launch_tv_chain(tc, x->precision, st); });
+            tap("tv", P.tv_out, B * npix, mid, mid);
+            tiv(npix);
+            return;
+        }
         const bool qbf = x->lp();      // reduced-precision modes: the folded per-utterance weight is written as the MFMA GEMM operand
         InFoldP fo{P.tv_stats, (int)npix, 1e-5f, x->tv_wq_raw, mid, P.tv_weff, P.tv_beff, B, qbf ? P.tv_wbf : nullptr, x->lp_kind()};
         fo.split = x->lpi() == 2 ? 1 : 0;                            // split-weight mode: the folded weight gets its lo half too
@@ -1639,6 +1661,20 @@ struct Runner {
             if (tv_chain_on()) {       // ... and their 16-bit operand forms (row 0, the time token, is rewritten every step: launch_tv_row0)
                 TvKvPrepP kp{P.tv_K, P.tv_V, (long)(args->Ts + 1) * mid, args->Ts + 1, P.tv_nkpad, P.tv_kp, P.tv_vtp, B};
                 run("tv_kv_operands", 0, 12.0 * B * (args->Ts + 1) * mid, [&] { launch_tv_kv_prep(kp, x->precision, st); });
+            }
+            if (tv_fold_on()) {        // folded form: G = K W_q and V' = V W_l^T in fp32 (style rows once per call, the time token's rows of every step), V'^T as the 16-bit operand
+                const long kvb = (long)(args->Ts + 1) * mid;
+                for (int which = 0; which < 2; ++which) {
+                    IGemmP g = base_gemm((which ? P.tv_V : P.tv_K) + mid, mid, 0, 1, args->Ts, mid, which ? x->tv_wl : x->tv_wq_raw, mid, nullptr,
+                                         (which ? P.tv_Vp : P.tv_G) + mid, mid, 0);       // w_q raw [n][k] IS the packed [K = n][N = k] matrix of K W_q
+                    g.a_bstride = kvb; g.c_bstride = kvb; g.Wbf = nullptr;
+                    gemm("tv_fold_kv", g);
+                    IGemmP t = base_gemm(which ? P.tv_v0 : P.tv_k0, mid, 0, 1, n, mid, which ? x->tv_wl : x->tv_wq_raw, mid, nullptr, which ? P.tv_v0p : P.tv_g0, mid, 0);
+                    t.B = 1; t.Wbf = nullptr;
+                    gemm("tv_fold_time_rows", t);
+                }
+                TvKvPrepP kp{P.tv_G, P.tv_Vp, kvb, args->Ts + 1, P.tv_nkpad, P.tv_kp, P.tv_vtp, B};      // (K' is written by every step's launch_tv_fold2)
+                run("tv_fold_operands", 0, 6.0 * B * (args->Ts + 1) * mid, [&] { launch_tv_vfrag_prep(kp, x->precision, st); });
             }
         }
     }

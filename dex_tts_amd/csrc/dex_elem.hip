@@ -301,6 +301,53 @@ void launch_tv_row0(const TvRow0P& p, hipStream_t st) {
     hipLaunchKernelGGL(tv_row0_kernel, dim3((unsigned)std::max<long>(p.B, std::min<long>(zb, 1024))), dim3(256), 0, st, p);
 }
 
+// Folded TV adaptor, per step (kernels.h TvFold2P): grid (NkPad / 64, B), 256 threads.  Every workgroup reduces the utterance's 128 x IN_SLOTS
+// statistics itself (64 KB from L2, all loads in flight), then scales its 64 keys of G into the 16-bit K' operand: 4 x 16 B per thread, in the
+// MFMA fragment order tv_chain_fold_kernel's LDS-DMA ring takes as it is (attention_bf16.hip).
+__global__ __launch_bounds__(256) void tv_fold2_kernel(const TvFold2P p) {
+    __shared__ float srstd[128];
+    const int tid = threadIdx.x, b = blockIdx.y, C = p.C;
+    if (p.zero_ptr) {
+        const long nthr = (long)gridDim.x * gridDim.y * 256;
+        for (long i = ((long)blockIdx.y * gridDim.x + blockIdx.x) * 256 + tid; i < p.zero_n; i += nthr) p.zero_ptr[i] = 0.f;
+    }
+    if (tid < C) {
+        float mean, rstd;
+        in_mean_rstd(p.stats, (long)b * C + tid, p.npix, p.eps, mean, rstd);
+        srstd[tid] = rstd * p.scale;
+        if (blockIdx.x == 0) {
+            p.xmean[(long)b * C + tid] = mean;
+            // key 0 of V'^T in fragment order: tile 0, piece (t = ch / 32, q = 0), lane ch % 32 (hh = 0), element 0
+            reinterpret_cast<unsigned short*>(p.VTp)[(long)b * C * p.NkPad + (((tid >> 5) * 4) * 64 + (tid & 31)) * 8] =
+                (unsigned short)(pack2_kind(p.v0p[(long)p.step * C + tid], 0.f, p.lp_kind) & 0xffffu);
+        }
+    }
+    __syncthreads();
+    unsigned short* Kp = reinterpret_cast<unsigned short*>(p.Kp) + (long)b * p.NkPad * C;
+    const int c8 = (tid & 15) * 8;
+    const float4 r0 = *reinterpret_cast<const float4*>(srstd + c8), r1 = *reinterpret_cast<const float4*>(srstd + c8 + 4);
+    float4 ga[4], gc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int key = blockIdx.x * 64 + (tid >> 4) + 16 * j;
+        const float* src = key == 0 ? p.g0 + (long)p.step * C + c8 : p.G + (long)b * p.gb + (long)min(key, p.Nk - 1) * C + c8;
+        ga[j] = *reinterpret_cast<const float4*>(src); gc[j] = *reinterpret_cast<const float4*>(src + 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int key = blockIdx.x * 64 + (tid >> 4) + 16 * j;
+        uint4 o = make_uint4(pack2_kind(ga[j].x * r0.x, ga[j].y * r0.y, p.lp_kind), pack2_kind(ga[j].z * r0.z, ga[j].w * r0.w, p.lp_kind),
+                             pack2_kind(gc[j].x * r1.x, gc[j].y * r1.y, p.lp_kind), pack2_kind(gc[j].z * r1.z, gc[j].w * r1.w, p.lp_kind));
+        if (key >= p.Nk) o = make_uint4(0u, 0u, 0u, 0u);
+        // fragment order: tile key / 64, piece (st = (key / 32) % 2, ks = chunk / 2), lane (i = key % 32, hh = chunk % 2)
+        const int c = tid & 15;
+        *reinterpret_cast<uint4*>(Kp + ((long)((key >> 6) * 16 + ((key >> 5) & 1) * 8 + (c >> 1)) * 64 + (c & 1) * 32 + (key & 31)) * 8) = o;
+    }
+}
+void launch_tv_fold2(const TvFold2P& p, hipStream_t st) {
+    hipLaunchKernelGGL(tv_fold2_kernel, dim3(p.NkPad / 64, p.B), dim3(256), 0, st, p);
+}
+
 __global__ void transpose_cl_kernel(const float* src, float* dst, int B, int C, int L, int row_off, long dst_bstride) {
     const long total = (long)B * C * L;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {

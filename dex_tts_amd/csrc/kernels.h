@@ -420,9 +420,24 @@ struct TvChainP { const float* X; int ldx; int x_coff; long x_bstride; int npix;
                   const void* Weff; long weff_lo_off; const float* beff;      // 16-bit [B][C][C] ([n][k]; lo halves weff_lo_off elements behind, 0 = none), fp32 [B][C]
                   const void* Wl; long wl_lo_off;                             // 16-bit [C][C] ([n][k])
                   const void* Kp; const void* VTp; int NkPad; int Nk; const int* kv_len; int kv_len_add; float scale;
-                  float* out; gnfix_t* stats; int B; };
+                  float* out; gnfix_t* stats; int B;
+                  // folded form (tv_chain_fold_kernel; TvFold2P): xmean != null -> Kp holds K' and VTp holds V'^T, both in MFMA FRAGMENT order (per
+                  // utterance and 64-key tile sixteen 1-KB pieces: K' piece (st, ks) lane (i, hh) = K'[tile * 64 + st * 32 + i][ks * 16 + hh * 8 .. + 8];
+                  // V'^T piece (t, q) lane (i, hh) element e = V'[key tile * 64 + (q / 2) * 32 + (q % 2) * 16 + key_pos(hh * 8 + e)][t * 32 + i]), x is
+                  // centred with xmean [B][C] on load, Weff / beff / Wl are not read; zero_ptr: zero_n floats (even) cleared by the launch
+                  const float* xmean = nullptr; float* zero_ptr = nullptr; long zero_n = 0; };
+// Per-step operands of the folded one-launch TV adaptor (dex_elem.hip tv_fold2_kernel; replaces launch_in_fold + launch_tv_row0 there):
+//   Kp[b][key][k]  = rstd[b,k] * scale * G[b][key][k]   (key 0: g0[step][k]; keys >= Nk: 0)   G = K W_q   (fp32 [B][Nk][C], row 0 unused)
+//   VTp: key 0     = v0p[step][c]                        (the time token's column of V'^T = (V W_l^T)^T; the style columns are written once per
+//                                                         call by launch_tv_vfrag_prep on V'); both operands in fragment order (TvChainP)
+//   xmean[b][k]    = mean[b,k]
+// and clears zero_n floats at zero_ptr (the TIV statistics: their last reader was the previous step's launch_tiv_coef).  C = 128.
+struct TvFold2P { const gnfix_t* stats; int npix; float eps; const float* G; long gb; const float* g0; const float* v0p; int step;
+                  int Nk; int NkPad; int C; float scale; void* Kp; void* VTp; float* xmean; float* zero_ptr; long zero_n; int lp_kind; int B; };
+void launch_tv_fold2(const TvFold2P& p, hipStream_t st);
 bool tv_chain_form(int npix, int C, int B);
 void launch_tv_kv_prep(const TvKvPrepP& p, int precision, hipStream_t st);
+void launch_tv_vfrag_prep(const TvKvPrepP& p, int precision, hipStream_t st);     // the folded form's V'^T operand (p.V = V'; p.K / p.Kp unused)
 void launch_tv_chain(const TvChainP& p, int precision, hipStream_t st);
 // transpose [B,C,L] -> [B, L(+row_off), C]
 void launch_transpose_cl(const float* src, float* dst, int B, int C, int L, int row_off, long dst_bstride, hipStream_t st);

@@ -38,6 +38,7 @@ void launch_attention_direct(const AttnDirectP& p, hipStream_t st);
 // the DEX TV adaptor as one launch (attention_bf16.hip)
 bool tv_chain_form(int npix, int C, int B);
 void launch_tv_kv_prep(const TvKvPrepP& p, hipStream_t st);
+void launch_tv_vfrag_prep(const TvKvPrepP& p, hipStream_t st);
 void launch_tv_chain(const TvChainP& p, hipStream_t st);
 bool attention_direct_batch_regime(int N, int B);
 int attention_direct_ksplit(int N, int B);

@@ -53,6 +53,7 @@ void launch_convt_up(const ConvTUpP& p, int precision, hipStream_t st) { DEX_LP_
 void launch_conv_down(const ConvDownP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_conv_down, p, st); }
 void launch_attention_lp(const AttnP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_attention_lp, p, st); }
 void launch_tv_kv_prep(const TvKvPrepP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_tv_kv_prep, p, st); }
+void launch_tv_vfrag_prep(const TvKvPrepP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_tv_vfrag_prep, p, st); }
 void launch_tv_chain(const TvChainP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_tv_chain, p, st); }
 void launch_attention_direct(const AttnDirectP& p, int precision, hipStream_t st) { DEX_LP_CALL(launch_attention_direct, p, st); }
 bool attention_q64_half_plan(int N, int B, int* half_g, int* half_n) { return bf16::attention_q64_half_plan(N, B, half_g, half_n); }

@@ -472,33 +472,45 @@ def test_tv_adaptor_one_launch_vs_oracle_taps_and_vs_three_launches(name, kw, pr
     """The TV adaptor as one launch (tv_chain_kernel: q projection -> attention over the style keys -> output projection + residual +
     mask + the TIV adaptor's statistics, DEX_TV_CHAIN=2 forces it below the batch regime) against the oracle's "tv" / "tiv" taps and
     the call's result, and against the three separate launches (DEX_TV_CHAIN=0): the same roundings (x, q / sqrt(C), P, O in the
-    operand type), different summation orders."""
+    operand type), different summation orders.  Round 6: the FOLDED one-launch form (w_q and `linear` inside the style operands K' =
+    rstd * (K W_q) / sqrt(C), V' = V W_l^T; the centred x tile is the score operand, no projection in the launch; DEX_TV_FOLD, the
+    default of the bf16 / fp16 modes) against the same taps and bounds - its roundings differ (x - mean, K', V' in the operand type
+    instead of x, W_eff, q, O, W_l), its distance from the oracle must not."""
     cfg, eng, w = U.engine_for(name)
     case = U.make_case(cfg, **kw)
     set_prec(eng, prec)
     res, ran = {}, {}
     eng.profile(True)
     try:
-        for flag in ("0", "2"):
+        for flag, fold in (("0", "0"), ("2", "0"), ("2", "1")):
             os.environ["DEX_TV_CHAIN"] = flag
+            os.environ["DEX_TV_FOLD"] = fold
             got, ref, terr = U.run_precond(name, case, 0.7)
-            ran[flag] = any("tv_chain" in r["name"] for r in eng.profile_rows())
-            res[flag] = (got, ref, terr, {k: v.cpu().numpy() for k, v in eng.taps().items() if k in ("tv", "tiv")})
+            rows = [r["name"] for r in eng.profile_rows()]
+            ran[flag + fold] = (any("tv_chain" in r for r in rows), any("tv_fold_keys" in r for r in rows))
+            res[flag + fold] = (got, ref, terr, {k: v.cpu().numpy() for k, v in eng.taps().items() if k in ("tv", "tiv")})
     finally:
         eng.profile(False)
         os.environ.pop("DEX_TV_CHAIN", None)
+        os.environ.pop("DEX_TV_FOLD", None)
         eng.set_precision("fp32")
-    assert ran == {"0": False, "2": True}, ran              # (the two forms did run: their results can agree to the bit)
+    folded = prec != "fp16x2"                               # (the split-weight mode keeps the projections: K' / V' would need lo halves)
+    assert ran == {"00": (False, False), "20": (True, False), "21": (True, folded)}, ran      # (the forms did run: their results can agree to the bit)
     tag = f"tv_chain_{name}_B{kw['B']}_T{kw['T']}"
-    for flag, (got, ref, terr, _) in res.items():
+    for key, (got, ref, terr, _) in res.items():
+        flag = key[0] if key[1] == "0" else "2f"
         for k in ("tv", "tiv"):
             err, mag = terr[k]
             U.record(f"{tag}_chain{flag}:{prec}:tap_{k}", max=err, ref_absmax=mag)
-            assert err <= TV_TAP_REL[prec][k] * max(1.0, mag), (flag, k, err, mag)
+            assert err <= TV_TAP_REL[prec][k] * max(1.0, mag), (key, k, err, mag)
         check_lowp(f"{tag}_chain{flag}", prec, "call", got, ref)
-    d = {k: float(np.abs(res["0"][3][k] - res["2"][3][k]).max()) for k in ("tv", "tiv")}
+    d = {k: float(np.abs(res["00"][3][k] - res["20"][3][k]).max()) for k in ("tv", "tiv")}
     U.record(f"{tag}_chain_vs_separate:{prec}", tv=d["tv"], tiv=d["tiv"])
-    assert d["tv"] <= 0.25 * TV_TAP_REL[prec]["tv"] * max(1.0, res["0"][2]["tv"][1])      # (measured: 0.02 of it)
+    assert d["tv"] <= 0.25 * TV_TAP_REL[prec]["tv"] * max(1.0, res["00"][2]["tv"][1])      # (measured: 0.02 of it)
+    df = {k: float(np.abs(res["20"][3][k] - res["21"][3][k]).max()) for k in ("tv", "tiv")}
+    U.record(f"{tag}_folded_vs_chain:{prec}", tv=df["tv"], tiv=df["tiv"])
+    assert df["tv"] <= TV_TAP_REL[prec]["tv"] * max(1.0, res["00"][2]["tv"][1])
+    if not folded: assert df["tv"] == 0.0 and df["tiv"] == 0.0
 
 
 @pytest.mark.parametrize("prec,kw", [
