@@ -407,7 +407,10 @@ constexpr float TVC_TAU = 6.f, TVC_LOG2E = 1.4426950408889634f;
 // FRAG (the folded form below): the tiles lie in LDS in MFMA fragment order - piece (st, ks) of K', piece (t, st * 2 + k2) of V'^T, 1 KB
 // each, lane l's 16 bytes at l * 16 - as the LDS-DMA ring delivers them from operands their producers write in that order (linear,
 // unpadded, conflict-free); otherwise padded row-major tiles (K_LD / TVC_VLD).
-template <bool FRAG = false>
+// LAST: only the last tile of an utterance can hold keys >= Nk, and only it carries the masking code - as a (uniform) branch inside one
+// tile function hipcc if-converted it into 30 compare + select pairs (+ their index arithmetic and hazard nops: ~110 of a tile's ~390
+// instructions) in EVERY tile.
+template <bool FRAG = false, bool LAST = true>
 __device__ __forceinline__ void tvc_tile(const u16* kS, const u16* vT, const Frag (&qf)[8], f32x16 (&o)[4], float& m_run, float& l_run, int k0, int Nk, int lane) {
     constexpr int KT = TVC_KT, V_LD = TVC_VLD, NS = KT / 32;
     const int i = lane & 31, hh = lane >> 5;
@@ -423,14 +426,16 @@ __device__ __forceinline__ void tvc_tile(const u16* kS, const u16* vT, const Fra
             s[st] = DEX_MFMA_LP(a.v, qf[ks].v, s[st], 0, 0, 0);
         }
     }
-    if (k0 + KT > Nk) {                                                     // (uniform) the tile that holds keys >= Nk
+    if constexpr (LAST) {
+        if (k0 + KT > Nk) {                                                 // (uniform) the tile that holds keys >= Nk
 #pragma unroll
-        for (int st = 0; st < NS; ++st)
+            for (int st = 0; st < NS; ++st)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (key >= Nk) s[st][r] = -INFINITY;
-            }
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + st * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (key >= Nk) s[st][r] = -INFINITY;
+                }
+        }
     }
     float mx = -INFINITY;
 #pragma unroll
@@ -655,7 +660,7 @@ __global__ __launch_bounds__(256, 2) void tv_chain_kernel(const TvChainP p) {
         __syncthreads();                     // tile kt visible; buffer (kt + 1) & 1 free
         const int cur = kt & 1;
         kv_load(kt + 1);
-        tvc_tile(smem_b + cur * TVC_KBUF, smem_b + 2 * TVC_KBUF + cur * TVC_VBUF, qf, o, m_run, l_run, kt * TVC_KT, Nk, lane);
+        tvc_tile<false, false>(smem_b + cur * TVC_KBUF, smem_b + 2 * TVC_KBUF + cur * TVC_VBUF, qf, o, m_run, l_run, kt * TVC_KT, Nk, lane);
         kv_store(cur ^ 1);
     }
     __syncthreads();
@@ -878,7 +883,7 @@ __global__ __launch_bounds__(256, 2) void tv_chain_fold_kernel(const TvChainP p)
         __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces of tile kt have landed
         __syncthreads();                     // ... everybody's: tile kt visible; ring half (kt + 1) & 1 (and the x tile in it) free
         kv_dma(kt + 1);
-        tvc_tile<true>(smem_b + (kt & 1) * 2 * TVC_FBUF, smem_b + (kt & 1) * 2 * TVC_FBUF + TVC_FBUF, qf, o, m_run, l_run, kt * TVC_KT, Nk, lane);
+        tvc_tile<true, false>(smem_b + (kt & 1) * 2 * TVC_FBUF, smem_b + (kt & 1) * 2 * TVC_FBUF + TVC_FBUF, qf, o, m_run, l_run, kt * TVC_KT, Nk, lane);
     }
     __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();

@@ -33,7 +33,7 @@ const char* const KNOB_NAMES[] = {
     // launcher heuristics (workgroup caps, shape thresholds, form switches) - process-static getenv reads until round 4
     "DEX_ATTN_SHARED_W8", "DEX_CONVT_MT", "DEX_CONVT_WGS", "DEX_CONV_DOWN_WGS", "DEX_CONV_REGW", "DEX_CONV_REGW_RES", "DEX_CONV_SMALL_MAX", "DEX_CONV_TH8",
     "DEX_CONV_W8", "DEX_DWCONV_CAP", "DEX_FINAL_CAP", "DEX_FIRST_CAP", "DEX_FIRST_MFMA", "DEX_GEMM_NWALK", "DEX_NWALK_SPLIT", "DEX_NWALK_BM", "DEX_POS_COL", "DEX_POS_COL_MIN",
-    "DEX_POS_CT", "DEX_REGW_MIN_TILES", "DEX_REGW_WGS", "DEX_ROWCHAIN64", "DEX_ROWCHAIN64A", "DEX_TIV_CAP", "DEX_TV_CHAIN", "DEX_TIV_FOLD", "DEX_LINATTN_NSUB", "DEX_TV_FOLD"};
+    "DEX_POS_CT", "DEX_REGW_MIN_TILES", "DEX_REGW_WGS", "DEX_ROWCHAIN64", "DEX_ROWCHAIN64A", "DEX_TIV_CAP", "DEX_TV_CHAIN", "DEX_TIV_FOLD", "DEX_LINATTN_NSUB", "DEX_TV_FOLD", "DEX_OUT2_MIN"};
 constexpr int N_KNOBS = (int)(sizeof(KNOB_NAMES) / sizeof(KNOB_NAMES[0]));
 // value of one variable: a decimal integer; unset, empty or without digits ("true", "on") = KNOB_UNSET, so a typo leaves the default
 // form on instead of silently switching it off

@@ -680,7 +680,9 @@ bool linattn_fused_supported(int C) {
 #endif
     return C == 64 || C == 128;
 }
-bool linattn_out2_lp_out_supported(int npix, int B) { return (long)((npix + 127) / 128) * B >= 2048; }       // == the throughput form below
+// the throughput form below takes grids of at least this many workgroups (DEX_OUT2_MIN)
+static long out2_min_wgs() { return knob_or("DEX_OUT2_MIN", 256); }
+bool linattn_out2_lp_out_supported(int npix, int B) { return (long)((npix + 127) / 128) * B >= out2_min_wgs(); }       // == the throughput form below
 void launch_linattn_out2(const LinOut2P& p, hipStream_t st) {
     dim3 grid((p.npix + 127) / 128, p.B);
     const size_t lds = (size_t)4 * 32 * (p.C + 4) * sizeof(float);
@@ -689,7 +691,7 @@ void launch_linattn_out2(const LinOut2P& p, hipStream_t st) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&linattn_out2_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)4 * 32 * 132 * sizeof(float)));
         attr = true;
     }
-    if ((long)grid.x * p.B < 2048) {        // latency regime: the direct form
+    if ((long)grid.x * p.B < out2_min_wgs()) {        // latency regime: the direct form
         if (p.C == 64) hipLaunchKernelGGL(linattn_out2_direct_kernel<64>, grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL(linattn_out2_direct_kernel<128>, grid, dim3(256), 0, st, p);
         return;
