@@ -33,7 +33,7 @@ const char* const KNOB_NAMES[] = {
     // launcher heuristics (workgroup caps, shape thresholds, form switches) - process-static getenv reads until round 4
     "DEX_ATTN_SHARED_W8", "DEX_CONVT_MT", "DEX_CONVT_WGS", "DEX_CONV_DOWN_WGS", "DEX_CONV_REGW", "DEX_CONV_REGW_RES", "DEX_CONV_SMALL_MAX", "DEX_CONV_TH8",
     "DEX_CONV_W8", "DEX_DWCONV_CAP", "DEX_FINAL_CAP", "DEX_FIRST_CAP", "DEX_FIRST_MFMA", "DEX_GEMM_NWALK", "DEX_NWALK_SPLIT", "DEX_NWALK_BM", "DEX_POS_COL", "DEX_POS_COL_MIN",
-    "DEX_POS_CT", "DEX_REGW_MIN_TILES", "DEX_REGW_WGS", "DEX_ROWCHAIN64", "DEX_ROWCHAIN64A", "DEX_TIV_CAP", "DEX_TV_CHAIN", "DEX_TIV_FOLD", "DEX_LINATTN_NSUB", "DEX_TV_FOLD", "DEX_OUT2_MIN"};
+    "DEX_POS_CT", "DEX_REGW_MIN_TILES", "DEX_REGW_WGS", "DEX_ROWCHAIN64", "DEX_ROWCHAIN64A", "DEX_TIV_CAP", "DEX_TV_CHAIN", "DEX_TIV_FOLD", "DEX_LINATTN_NSUB", "DEX_TV_FOLD", "DEX_OUT2_MIN", "DEX_NWALK_DMA"};
 constexpr int N_KNOBS = (int)(sizeof(KNOB_NAMES) / sizeof(KNOB_NAMES[0]));
 // value of one variable: a decimal integer; unset, empty or without digits ("true", "on") = KNOB_UNSET, so a typo leaves the default
 // form on instead of silently switching it off
@@ -639,6 +639,7 @@ extern "C" int dex_ctx_finalize(DexCtx* x, dex_stream_t stream) {
         x->blocks.push_back(b);
     }
     x->fl_w = P.kn("vit.final_layer.linear.weight"); x->fl_b = P.raw("vit.final_layer.linear.bias");
+    if (hid == 256) P.frag(x->fl_w, hid, c.dit_stride * c.dit_stride * mid_dim(c));      // the column walker's LDS-DMA ring takes fragment-ordered tiles (igemm_lp_nwalk_kernel)
     x->fl_ada_w = P.raw("vit.final_layer.adaLN_modulation.1.weight"); x->fl_ada_b = P.raw("vit.final_layer.adaLN_modulation.1.bias");
     if (c.variant == DEX_VARIANT_DEX) {
         x->tv_wq_raw = P.raw("tv_adaptor.w_q.weight");
@@ -1098,6 +1099,7 @@ struct Runner {
         const int s2c = c.dit_stride * c.dit_stride * mid;
         IGemmP fl = base_gemm(fuse_lnf ? P.tok : P.xn, hid, 0, P.Hf, P.Wt, hid, x->fl_w, s2c, x->fl_b, out, ldo, ocoff);
         if (fuse_lnf) { fl.ln_shift = P.fin_mod; fl.ln_scale = P.fin_mod + hid; fl.ln_step_stride = 2L * hid; }
+        { auto it = x->frag_of().find(x->fl_w); fl.Wfrag = (it != x->frag_of().end()) ? it->second : nullptr; }
         fl.unpatch_s = c.dit_stride; fl.unpatch_C = mid; fl.OHf = P.Hm; fl.OWf = P.Wm;
         fl.c_bstride = (long)P.Hm * P.Wm * ldo;
         fl.outmask = mask; fl.outmask_ws = mask_ws;

@@ -359,16 +359,25 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // BM rows per workgroup, BM / 16 waves (a wave = 32 rows x 32 of the tile's 64 columns).  BM = 128 (round 6): every 64-column weight
 // tile a workgroup stages serves 128 rows instead of 64 (650 -> 360 MB of L2 -> LDS weight traffic per launch at DEX B = 32) - measured
 // no faster, so it is opt-in (launch_nwalk).
-template <int K, int BM = 64>
+// DMA (round 6; 64-row workgroups, not the split-weight build): the weight tiles come from the FRAGMENT-ordered twin (IGemmP::Wfrag: a
+// 64-column tile = 32 contiguous 1-KB pieces, piece (wn, ks) = the A fragment of columns wn * 32 .. + 32, K-step ks) through a two-slot
+// LDS-DMA ring (global_load_lds_dwordx4, eight pieces per wave and tile): no staging registers, no ds_write pass, ONE barrier per tile
+// instead of two, unpadded conflict-free fragment reads.  The A tile (LayerNorm staging, dead once every wave holds its rows as
+// fragments) aliases slot 1, so tile 0 lands under the staging.  A wave waits for its own pieces with vmcnt(number of scatter stores
+// it issued behind them) - loads and stores leave the counter in issue order on this target - so the stores of a tile stay in flight.
+template <int K, int BM = 64, bool DMA = false>
 __global__ __launch_bounds__(BM * 4) void igemm_lp_nwalk_kernel(const IGemmP p) {
     constexpr int BN = 64, NTHR = BM * 4;
     constexpr int WN = BN / 32, WM = BM / 32, MT = 1;
     constexpr int LDS_LD = K + 8, KC = K / 8;
     constexpr int AIT = BM * KC / NTHR, BIT = BN * KC / NTHR;
     constexpr int ABATCH = AIT > 8 ? 8 : AIT;
+    constexpr int TILE = BN * K;                      // u16 per fragment-ordered weight tile (32 KB)
+    static_assert(!DMA || BM == 64, "DMA form: 64-row workgroups");
     extern __shared__ __attribute__((aligned(16))) u16 smem_ss[];
-    u16* As = smem_ss;
+    u16* As = DMA ? smem_ss + TILE : smem_ss;         // DMA: [slot 0 | slot 1 = A tile (+ its padding past the slot)]
     u16* Bs = smem_ss + BM * LDS_LD;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, hh = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
@@ -384,6 +393,29 @@ __global__ __launch_bounds__(BM * 4) void igemm_lp_nwalk_kernel(const IGemmP p) 
     const float* lsh = p.ln_shift ? p.ln_shift + (long)step * p.ln_step_stride : nullptr;
     const float* lsc = p.ln_scale ? p.ln_scale + (long)step * p.ln_step_stride : nullptr;
 
+    const u16* Wf = DMA ? reinterpret_cast<const u16*>(p.Wfrag) + (long)b * p.w_bstride + (long)nt_first * TILE : nullptr;
+#define NW_DMA(nt_)                                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                                \
+        const int piece = 8 * wave + j;                                                                             \
+        __builtin_amdgcn_global_load_lds(Wf + (long)(nt_) * TILE + piece * 512 + lane * 8,                          \
+                                         (lds_ptr_t)(smem_ss + ((nt_) & 1) * TILE + piece * 512), 16, 0, 0);        \
+    }
+    // DMA: bias (N floats) and this workgroup's output-mask values (64 token rows x unpatch_s column offsets) go to LDS once - with
+    // LDS-DMA pieces in flight hipcc turns the wait of ANY ordinary global load into vmcnt(0), so the walk must not issue one
+    float* sbias = reinterpret_cast<float*>(smem_ss + TILE + BM * LDS_LD);        // [N]
+    float* smk = sbias + p.N;                                                      // [64 rows][8]
+    if constexpr (DMA) {
+        NW_DMA(0)
+        const float* biasg = p.bias ? p.bias + (long)b * p.bias_bstride : nullptr;
+        for (int idx = tid; idx < p.N; idx += NTHR) sbias[idx] = biasg ? biasg[idx] : 0.f;
+        const float* omg = p.outmask ? p.outmask + (long)b * p.mask_bstride : nullptr;
+        const int row = tid >> 2, mrow_ = m0 + row, mm_ = mrow_ < M ? mrow_ : 0, uw_ = (mm_ % p.Wo) * p.unpatch_s;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int sft = (tid & 3) + 4 * e;
+            smk[row * 8 + sft] = omg ? omg[min(uw_ + sft, p.OWf - 1) * p.outmask_ws] : 1.f;
+        }
+    }
     u32x4 br[BIT];                          // (native vectors + macros, not lambdas over an array: those ended up in scratch)
 #define NW_LOAD_B(nt_)                                                                                              \
     _Pragma("unroll") for (int j = 0; j < BIT; ++j) {                                                              \
@@ -416,7 +448,7 @@ __global__ __launch_bounds__(BM * 4) void igemm_lp_nwalk_kernel(const IGemmP p) 
     }
     NW_LOAD_LO(0)
 #endif
-    NW_LOAD_B(0)
+    if constexpr (!DMA) { NW_LOAD_B(0) }
 #pragma unroll
     for (int a0 = 0; a0 < AIT; a0 += ABATCH) {
         float4 f0[ABATCH], f1[ABATCH];
@@ -433,7 +465,7 @@ __global__ __launch_bounds__(BM * 4) void igemm_lp_nwalk_kernel(const IGemmP p) 
             const float mv = mrow ? mrow[(mm % p.Wi) * p.inmask_ws] : 1.f;
             mk[j] = m < M ? mv : 0.f;
         }
-        if (a0 == 0) { NW_STORE_B() }
+        if constexpr (!DMA) { if (a0 == 0) { NW_STORE_B() } }
 #pragma unroll
         for (int j = 0; j < ABATCH; ++j) {
             const int it = tid + NTHR * (a0 + j);
@@ -465,7 +497,7 @@ __global__ __launch_bounds__(BM * 4) void igemm_lp_nwalk_kernel(const IGemmP p) 
     }
     __syncthreads();
     const u16* ap = As + (wm * (MT * 32) + i) * LDS_LD + hh * 8;
-    const u16* bp = Bs + (wn * 32 + i) * LDS_LD + hh * 8;
+    const u16* bp = Bs + (wn * 32 + i) * LDS_LD + hh * 8;            // (DMA: the ring slot's piece (wn, 0), set per tile)
     // unpatchify scatter without activation / gate / residual (the FinalLayer): everything that depends on the ROW only - token
     // (f, w), its pixel base, validity - is computed once for the whole column walk (the shared epilogue redoes two divisions
     // and a 64-bit address per element and column tile: the launch was bound by that integer work and by 16 dependent mask
@@ -500,18 +532,49 @@ __global__ __launch_bounds__(BM * 4) void igemm_lp_nwalk_kernel(const IGemmP p) 
     }
     const float* omask = p.outmask ? p.outmask + (long)b * p.mask_bstride : nullptr;
     const float* biasb = p.bias ? p.bias + (long)b * p.bias_bstride : nullptr;
+    // DMA: the scatter of a tile is DEFERRED to the head of the next iteration, behind the next DMA group and in front of the MFMA chain:
+    // waiting for a wave's pieces is vmcnt(0) (hipcc drains the counter in front of any LDS read that may alias a piece in flight), and a
+    // tile's stores issued at its end would be waited for a few instructions later; issued here they have a whole MFMA chain to drain
+    float4 dst4[4]; char* d_ptr = nullptr; bool d_ok = false, d_all = false, d_have = false;
+#define NW_FLUSH()                                                                                                  \
+    if (d_have) {                                                                                                   \
+        if (p.c_lp) {                                                                                               \
+            u16* c_ = reinterpret_cast<u16*>(d_ptr);                                                                \
+            if (d_all) { *reinterpret_cast<float4*>(c_) = dst4[0]; *reinterpret_cast<float4*>(c_ + 16) = dst4[1]; } \
+            else if (d_ok) { *reinterpret_cast<float4*>(c_) = dst4[0]; *reinterpret_cast<float4*>(c_ + 16) = dst4[1]; } \
+        } else {                                                                                                    \
+            float* c_ = reinterpret_cast<float*>(d_ptr);                                                            \
+            if (d_all) { _Pragma("unroll") for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(c_ + 8 * q) = dst4[q]; } \
+            else if (d_ok) { _Pragma("unroll") for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(c_ + 8 * q) = dst4[q]; } \
+        }                                                                                                           \
+    }
     for (int nt = 0; nt < ntile; ++nt) {
-        if (nt + 1 < ntile) { NW_LOAD_B(nt + 1) }
+        if constexpr (DMA) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);       // vmcnt(0): this wave's pieces of tile nt have landed ...
+            __syncthreads();                          // ... everybody's: tile nt visible, slot (nt + 1) & 1 (tile nt - 1 / the A tile) free
+            bp = smem_ss + (nt & 1) * TILE + (wn * 16 * 64 + lane) * 8;
+        } else {
+            if (nt + 1 < ntile) { NW_LOAD_B(nt + 1) }
+        }
 #ifdef DEX_LP_WSPLIT
         if (nt + 1 < ntile) { NW_LOAD_LO(nt + 1) }
 #endif
         const int ng0 = (nt_first + nt) * BN + wn * 32, pp = ng0 / p.unpatch_C;
         const int u_c0 = ng0 - pp * p.unpatch_C;                // first channel of this wave's 32 (a multiple of 32)
         const int u_p1 = pp / p.unpatch_s, u_p2 = pp - u_p1 * p.unpatch_s;
-        const float u_mk = omask ? omask[min(u_w + u_p2, p.OWf - 1) * p.outmask_ws] : 1.f;
+        float u_mk;
         float4 b4[4];
+        if constexpr (DMA) {
+            u_mk = smk[(wm * 32 + i) * 8 + u_p2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) b4[q] = biasb ? *reinterpret_cast<const float4*>(biasb + ng0 + 8 * q + 4 * hh) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < 4; ++q) b4[q] = *reinterpret_cast<const float4*>(sbias + ng0 + 8 * q + 4 * hh);
+            if (nt + 1 < ntile) { NW_DMA(nt + 1) }
+            NW_FLUSH()
+        } else {
+            u_mk = omask ? omask[min(u_w + u_p2, p.OWf - 1) * p.outmask_ws] : 1.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b4[q] = biasb ? *reinterpret_cast<const float4*>(biasb + ng0 + 8 * q + 4 * hh) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         __builtin_amdgcn_sched_barrier(0);
         f32x16 acc[MT];
 #pragma unroll
@@ -520,7 +583,7 @@ __global__ __launch_bounds__(BM * 4) void igemm_lp_nwalk_kernel(const IGemmP p) 
             for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < K / 16; ++ks) {
-            const lp8 bf = *reinterpret_cast<const lp8*>(bp + ks * 16);
+            const lp8 bf = *reinterpret_cast<const lp8*>(bp + ks * (DMA ? 512 : 16));
             acc[0] = DEX_MFMA_LP(bf, afr[ks], acc[0], 0, 0, 0);
 #ifdef DEX_LP_WSPLIT
             acc[0] = DEX_MFMA_LP(*reinterpret_cast<const lp8*>(blp + ks * 16), afr[ks], acc[0], 0, 0, 0);
@@ -553,6 +616,10 @@ __global__ __launch_bounds__(BM * 4) void igemm_lp_nwalk_kernel(const IGemmP p) 
                 // (passing the workgroup's 64 x 64 outputs through an LDS tile so that a request writes 8 tokens x 128 contiguous bytes was
                 // measured too: 55.4 vs 54.3 us at DEX B = 32, 77.4 vs 74.1 at GeDEX B = 32 - the stores no longer bound the launch)
                 u16* cph = reinterpret_cast<u16*>(p.C) + e0 + 8 * hh;
+                if constexpr (DMA) {
+                    dst4[0] = __builtin_bit_cast(float4, ch[0]); dst4[1] = __builtin_bit_cast(float4, ch[1]);
+                    d_ptr = reinterpret_cast<char*>(cph); d_ok = ok; d_all = __builtin_amdgcn_ballot_w64(!ok) == 0; d_have = true;
+                } else
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0) {                        // the common case: nothing of this tile is cropped
                     *reinterpret_cast<uint4*>(cph) = ch[0];
                     *reinterpret_cast<uint4*>(cph + 16) = ch[1];
@@ -562,6 +629,11 @@ __global__ __launch_bounds__(BM * 4) void igemm_lp_nwalk_kernel(const IGemmP p) 
                 }
             } else {
                 float* cp = p.C + e0 + 4 * hh;
+                if constexpr (DMA) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) dst4[q] = make_float4(val[4 * q], val[4 * q + 1], val[4 * q + 2], val[4 * q + 3]);
+                    d_ptr = reinterpret_cast<char*>(cp); d_ok = ok; d_all = __builtin_amdgcn_ballot_w64(!ok) == 0; d_have = true;
+                } else
                 if (__builtin_amdgcn_ballot_w64(!ok) == 0) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) *reinterpret_cast<float4*>(cp + 8 * q) = make_float4(val[4 * q], val[4 * q + 1], val[4 * q + 2], val[4 * q + 3]);
@@ -571,7 +643,7 @@ __global__ __launch_bounds__(BM * 4) void igemm_lp_nwalk_kernel(const IGemmP p) 
                 }
             }
         }
-        if (nt + 1 < ntile) {
+        if (!DMA && nt + 1 < ntile) {
             __syncthreads();                              // every wave is done with this weight tile
             NW_STORE_B()
 #ifdef DEX_LP_WSPLIT
@@ -580,6 +652,7 @@ __global__ __launch_bounds__(BM * 4) void igemm_lp_nwalk_kernel(const IGemmP p) 
             __syncthreads();
         }
     }
+    if constexpr (DMA) { NW_FLUSH() }
 }
 
 static bool nwalk_eligible(const IGemmP& p) {
@@ -611,6 +684,9 @@ static void launch_nwalk(const IGemmP& p, hipStream_t st) {
     if (!attr) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_lp_nwalk_kernel<K>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_lp_nwalk_kernel<K, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds128);
+#ifndef DEX_LP_WSPLIT
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_lp_nwalk_kernel<K, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+#endif
         attr = true;
     }
     // 128-row workgroups (eight waves, one workgroup per CU): half the weight stream per row.  Built, bit-identical, and measured NO faster
@@ -631,6 +707,20 @@ static void launch_nwalk(const IGemmP& p, hipStream_t st) {
             return;
         }
     }
+#ifndef DEX_LP_WSPLIT
+    if (p.Wfrag && p.w_bstride == 0 && p.N <= 2048 && p.unpatch_s <= 8 && knob_or("DEX_NWALK_DMA", 0) != 0) {       // the LDS-DMA form (fragment-ordered twin of the weight): OPT-IN - built, bit-identical, measured no faster (see below)
+        const size_t lds_dma = (size_t)64 * K * 2 + (size_t)64 * (K + 8) * 2 + (size_t)p.N * 4 + 64 * 8 * 4;       // ring slot 0 | slot 1 = A tile | bias | mask table
+        const long wgs = (long)((p.Ho * p.Wo + 63) / 64) * p.B;
+        int nsplit = 1;
+        const int fs = knob_or("DEX_NWALK_SPLIT", 0);
+        while (nsplit < 4 && wgs * nsplit < 1280 && (p.N / 64) % (nsplit * 2) == 0) nsplit *= 2;
+        if (wgs <= 16) nsplit = p.N / 64;
+        if (fs > 0 && (p.N / 64) % fs == 0) nsplit = fs;
+        g_last_symbol = "igemm_lp_nwalk_kernel<256,64,1>";
+        hipLaunchKernelGGL((igemm_lp_nwalk_kernel<K, 64, true>), dim3((p.Ho * p.Wo + 63) / 64, nsplit, p.B), dim3(256), lds_dma, st, p);
+        return;
+    }
+#endif
     g_last_symbol = "igemm_lp_nwalk_kernel<256>";
     // split the walk over 1 / 2 / 4 workgroups so that the grid is at least ~2.5 rounds of the chip's 512 slots: a workgroup's tiles
     // run back to back behind each other's store drain, more of them in flight hide it (measured at B=32: 115 -> ? us)

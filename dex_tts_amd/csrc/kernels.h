@@ -59,6 +59,8 @@ struct IGemmP {
     int Ho, Wo;
     const float* W; long w_bstride; long w_gstride;   // packed [K][N] (per group), optional per-batch
     const void* Wbf;                                   // bf16 copy, packed [N][K] (K contiguous), or null
+    const void* Wfrag = nullptr;                       // the same 16-bit weights in MFMA fragment order (launch_pack_lp_frag of the [K][N] matrix), or null:
+                                                       // the column walker's LDS-DMA form (igemm_bf16.hip); its lo half sits lo_off(Wfrag) elements behind (unused there)
     long w_lo_off = 0;                                 // split-weight mode (PREC_FP16X2): elements from a weight of Wbf to its lo half, 0 = none
     int N, K, ksplit, groups;
     const float* bias; long bias_bstride;              // [groups*N] or null; optional per-batch stride

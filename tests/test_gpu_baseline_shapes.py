@@ -364,6 +364,32 @@ def test_unpatchify_gemm_128_row_workgroups_are_bit_identical(name, kw, prec):
     assert np.isfinite(ys[0]).all() and np.array_equal(ys[0], ys[1]), float(np.abs(ys[0] - ys[1]).max())
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp16"])
+@pytest.mark.parametrize("name,kw", [
+    ("dex_vctk", dict(B=32, T=256, lengths=[256 - 3 * i for i in range(32)], Tr=60, Ts=60)),      # batch: two-way split walk, 16-bit output into the concatenation buffer
+    ("gedex_lj", dict(B=32, T=508, lengths=[508 - 9 * i for i in range(32)])),                    # 635 token rows: ragged last row tile, cropped columns
+    ("gedex_lj", dict(B=1, T=512, lengths=[512])),                                                 # small grid: one column tile per workgroup, fp32 output
+    ("gedex_lj", dict(B=3, T=200, lengths=[200, 133, 64])),
+])
+def test_unpatchify_gemm_lds_dma_form_is_bit_identical(name, kw, prec):
+    """igemm_lp_nwalk_kernel<256, 64, true> (round 6: weight tiles from the fragment-ordered twin through an LDS-DMA ring, bias / output
+    mask from LDS tables, the scatter of a tile deferred behind the next DMA group) against the register-staged form (DEX_NWALK_DMA=0):
+    the same products in the same order, the same (acc + bias) * mask - bit-identical."""
+    cfg, eng, w = U.engine_for(name)
+    case = U.make_case(cfg, **kw)
+    mu, mask, z = (torch.from_numpy(case[k]).cuda() for k in ("mu", "mask", "z"))
+    set_prec(eng, prec)
+    try:
+        ys = []
+        for flag in ("0", "1"):
+            os.environ["DEX_NWALK_DMA"] = flag
+            ys.append(eng.sample(z, mask, mu, 2, **U.engine_kwargs(case)).cpu().numpy())
+    finally:
+        os.environ.pop("DEX_NWALK_DMA", None)
+        eng.set_precision("fp32")
+    assert np.isfinite(ys[0]).all() and np.array_equal(ys[0], ys[1]), float(np.abs(ys[0] - ys[1]).max())
+
+
 @pytest.mark.parametrize("prec", ["bf16", "fp16", "fp16x2"])       # (fp16x2, round 6: the split-weight streams - hi then lo fragment through one ring)
 @pytest.mark.parametrize("name,kw", [
     ("dex_vctk", dict(B=32, T=256, lengths=[256 - 3 * i for i in range(32)], Tr=60, Ts=60)),      # N = 1300: 20 full tiles + 20 rows per utterance
