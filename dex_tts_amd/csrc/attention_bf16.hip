@@ -393,6 +393,7 @@ void launch_attention_lp(const AttnP& p, hipStream_t st) {
 constexpr int TVC_KT = 64, TVC_VLD = TVC_KT + 8;
 constexpr int TVC_KBUF = TVC_KT * K_LD, TVC_VBUF = AHD * TVC_VLD;
 constexpr int TVC_U16 = 2 * TVC_KBUF + 2 * TVC_VBUF;            // 35840 u16 = 71680 B: the K / V rings; W_eff + x tile and W_l + output stage alias them
+constexpr int TVC_FBUF = TVC_KT * AHD;                          // u16 per fragment-ordered K or V^T tile (16 KB: sixteen 1-KB pieces)
 constexpr int TVC_SLD = 68;                                     // floats per pixel of the output stage (64 channels + 4: conflict-free 16 B accesses)
 static_assert(2 * 128 * K_LD <= TVC_U16 && 128 * K_LD * 2 + 128 * TVC_SLD * 4 <= TVC_U16 * 2, "aliases fit the rings");
 
@@ -479,12 +480,13 @@ __device__ __forceinline__ void tvc_tile(const u16* kS, const u16* vT, const Fra
         }
 }
 
+// K (fp32 [B][Nk][C]) -> the 16-bit K operand in MFMA fragment order, the channels of every 16-group in accumulator order (what q^T's
+// accumulators are as a B operand): piece (st, ks) of 64-key tile t, lane (i, hh), elements 0..3 = channels 16 ks + 4 hh .. + 3,
+// elements 4..7 = channels 16 ks + 4 hh + 8 .. + 11 of key t * 64 + st * 32 + i; keys >= Nk are zeros.  (V: tv_vfrag_prep_kernel below.)
 __global__ __launch_bounds__(256) void tv_kv_prep_kernel(const TvKvPrepP p) {
     const long nk = (long)p.B * p.NkPad * (AHD / 8);             // K chunks: 8 positions of one key
-    const long nv = (long)p.B * (p.NkPad / 8) * AHD;             // V chunks: 8 key positions of one channel (channel fastest: coalesced reads)
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     u16* Kp = reinterpret_cast<u16*>(p.Kp);
-    u16* VTp = reinterpret_cast<u16*>(p.VTp);
     if (idx < nk) {
         const int c = (int)(idx % (AHD / 8)), key = (int)((idx / (AHD / 8)) % p.NkPad), b = (int)(idx / ((long)(AHD / 8) * p.NkPad));
         const int d0 = 16 * (c >> 1) + 4 * (c & 1);              // positions 8c .. 8c + 7 hold channels d0 .. d0 + 3, d0 + 8 .. d0 + 11
@@ -493,19 +495,8 @@ __global__ __launch_bounds__(256) void tv_kv_prep_kernel(const TvKvPrepP p) {
             const float* src = p.K + (long)b * p.kvb + (long)key * AHD + d0;
             a = *reinterpret_cast<const float4*>(src); e = *reinterpret_cast<const float4*>(src + 8);
         }
-        *reinterpret_cast<uint4*>(Kp + ((long)b * p.NkPad + key) * AHD + 8 * c) =
+        *reinterpret_cast<uint4*>(Kp + (long)b * p.NkPad * AHD + ((long)((key >> 6) * 16 + ((key >> 5) & 1) * 8 + (c >> 1)) * 64 + (c & 1) * 32 + (key & 31)) * 8) =
             make_uint4(pack2_lp(a.x, a.y), pack2_lp(a.z, a.w), pack2_lp(e.x, e.y), pack2_lp(e.z, e.w));
-    } else if (idx < nk + nv) {
-        const long j = idx - nk;
-        const int d = (int)(j % AHD), c = (int)((j / AHD) % (p.NkPad / 8)), b = (int)(j / ((long)AHD * (p.NkPad / 8)));
-        float v[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int key = key_pos(8 * c + q);
-            v[q] = key < p.Nk ? p.V[(long)b * p.kvb + (long)key * AHD + d] : 0.f;
-        }
-        *reinterpret_cast<uint4*>(VTp + ((long)b * AHD + d) * p.NkPad + 8 * c) =
-            make_uint4(pack2_lp(v[0], v[1]), pack2_lp(v[2], v[3]), pack2_lp(v[4], v[5]), pack2_lp(v[6], v[7]));
     }
 }
 
@@ -528,24 +519,18 @@ __global__ __launch_bounds__(256, 2) void tv_chain_kernel(const TvChainP p) {
     const u16* Vg = reinterpret_cast<const u16*>(p.VTp) + (long)b * AHD * p.NkPad;
     red[tid] = 0;
 
-    // ---- K / V^T tile kt: 16 KB + 16 KB of ready operands, four + four 16-byte chunks per thread
-    uint4 kr[4], vr[4];
-    auto kv_load = [&](int kt) __attribute__((always_inline)) {
+    // ---- K / V^T tile kt: 16 KB + 16 KB of ready operands in MFMA fragment order, sixteen + sixteen 1-KB pieces by LDS-DMA into ring half
+    // kt & 1 ([K 0 | V^T 0 | K 1 | V^T 1]: four + four pieces per wave).  Round 6: the tiles travelled through 8 x 16 bytes of registers per
+    // thread and a ds_write pass into padded rows - registers the kernel does not have: hipcc kept them in SCRATCH across every tile
+    // (16 + 10 scratch instructions in the loop).  122 -> 75 us at configs[2] for the folded form below, which shares the ring.
+    typedef __attribute__((address_space(3))) void* lds_ptr;
+    auto kv_dma = [&](int kt) __attribute__((always_inline)) {
+        u16* dst = smem_b + (kt & 1) * 2 * TVC_FBUF;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int id = tid + 256 * j;
-            kr[j] = *reinterpret_cast<const uint4*>(Kg + ((long)kt * TVC_KT + (id >> 4)) * AHD + (id & 15) * 8);
-            vr[j] = *reinterpret_cast<const uint4*>(Vg + (long)(id >> 3) * p.NkPad + kt * TVC_KT + (id & 7) * 8);
-        }
-    };
-    auto kv_store = [&](int buf) __attribute__((always_inline)) {
-        u16* kS = smem_b + buf * TVC_KBUF;
-        u16* vT = smem_b + 2 * TVC_KBUF + buf * TVC_VBUF;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int id = tid + 256 * j;
-            *reinterpret_cast<uint4*>(kS + (id >> 4) * K_LD + (id & 15) * 8) = kr[j];
-            *reinterpret_cast<uint4*>(vT + (id >> 3) * TVC_VLD + (id & 7) * 8) = vr[j];
+            const int piece = 4 * wave + j;
+            __builtin_amdgcn_global_load_lds(Kg + (long)kt * TVC_FBUF + piece * 512 + lane * 8, (lds_ptr)(dst + piece * 512), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(Vg + (long)kt * TVC_FBUF + piece * 512 + lane * 8, (lds_ptr)(dst + TVC_FBUF + piece * 512), 16, 0, 0);
         }
     };
 
@@ -582,7 +567,6 @@ __global__ __launch_bounds__(256, 2) void tv_chain_kernel(const TvChainP p) {
             }
         }
     }
-    if (ntiles > 0) kv_load(0);              // first K / V tile in flight under the q projection
     float4 bq[4][2][2];                      // b_eff of this lane's accumulator rows: requested before the barrier, back by the end of the first MFMA chain
     {
         const float* be = p.beff + (long)b * AHD;
@@ -643,7 +627,7 @@ __global__ __launch_bounds__(256, 2) void tv_chain_kernel(const TvChainP p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
-    if (ntiles > 0) kv_store(0);
+    if (ntiles > 0) kv_dma(0);               // (the W_eff / x tiles filled the ring's bytes: the first tile cannot land earlier)
     // (W_l's 32 KB are requested under the last tile, in the registers the K / V prefetch no longer needs)
     const u16* Wl = reinterpret_cast<const u16*>(p.Wl);
     uint2 la[8], lb[8];
@@ -657,17 +641,17 @@ __global__ __launch_bounds__(256, 2) void tv_chain_kernel(const TvChainP p) {
         }
     };
     for (int kt = 0; kt + 1 < ntiles; ++kt) {
-        __syncthreads();                     // tile kt visible; buffer (kt + 1) & 1 free
-        const int cur = kt & 1;
-        kv_load(kt + 1);
-        tvc_tile<false, false>(smem_b + cur * TVC_KBUF, smem_b + 2 * TVC_KBUF + cur * TVC_VBUF, qf, o, m_run, l_run, kt * TVC_KT, Nk, lane);
-        kv_store(cur ^ 1);
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces of tile kt have landed
+        __syncthreads();                     // ... everybody's: tile kt visible; ring half (kt + 1) & 1 free
+        kv_dma(kt + 1);
+        tvc_tile<true, false>(smem_b + (kt & 1) * 2 * TVC_FBUF, smem_b + (kt & 1) * 2 * TVC_FBUF + TVC_FBUF, qf, o, m_run, l_run, kt * TVC_KT, Nk, lane);
     }
+    __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
     wl_load();
     if (ntiles > 0) {
-        const int kt = ntiles - 1, cur = kt & 1;
-        tvc_tile(smem_b + cur * TVC_KBUF, smem_b + 2 * TVC_KBUF + cur * TVC_VBUF, qf, o, m_run, l_run, kt * TVC_KT, Nk, lane);
+        const int kt = ntiles - 1;
+        tvc_tile<true>(smem_b + (kt & 1) * 2 * TVC_FBUF, smem_b + (kt & 1) * 2 * TVC_FBUF + TVC_FBUF, qf, o, m_run, l_run, kt * TVC_KT, Nk, lane);
     }
     l_run += __shfl_xor(l_run, 32);
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
@@ -796,7 +780,6 @@ __global__ __launch_bounds__(256, 2) void tv_chain_kernel(const TvChainP p) {
 // LDS: [K'0 | V'^T0 | K'1 | V'^T1], 4 x 16 KB; the x tile and the output stage alias the second half (+ 2.8 KB), so tile 0 lands under
 // the x rows.  The residual rows of the first output half are requested under the last tile, the second half's before the first is
 // processed (the registers the projection form spends on W_l's prefetch).
-constexpr int TVC_FBUF = TVC_KT * AHD;                          // u16 per fragment-ordered K' or V'^T tile (16 KB: sixteen 1-KB pieces)
 static_assert(2 * TVC_FBUF + 128 * K_LD <= TVC_U16 && 2 * TVC_FBUF * 2 + 128 * TVC_SLD * 4 <= TVC_U16 * 2, "x tile / output stage fit behind ring half 0");
 __global__ __launch_bounds__(256, 2) void tv_chain_fold_kernel(const TvChainP p) {
     extern __shared__ __attribute__((aligned(16))) u16 smem_b[];
@@ -987,9 +970,11 @@ bool tv_chain_form(int npix, int C, int B) {
     (void)npix; (void)B;
     return C == AHD && knob_or("DEX_TV_CHAIN", 1) != 0;
 }
+void launch_tv_vfrag_prep(const TvKvPrepP& p, hipStream_t st);
 void launch_tv_kv_prep(const TvKvPrepP& p, hipStream_t st) {
-    const long n = (long)p.B * p.NkPad * (AHD / 8) + (long)p.B * (p.NkPad / 8) * AHD;
+    const long n = (long)p.B * p.NkPad * (AHD / 8);
     hipLaunchKernelGGL(tv_kv_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p);
+    launch_tv_vfrag_prep(p, st);
 }
 void launch_tv_vfrag_prep(const TvKvPrepP& p, hipStream_t st) {
     const long n = (long)p.B * (p.NkPad / 64) * 16 * 64;

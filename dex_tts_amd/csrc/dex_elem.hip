@@ -289,9 +289,11 @@ __global__ void tv_row0_kernel(const TvRow0P p) {
         p.K[(long)b * p.kvb + c] = kv;
         p.V[(long)b * p.kvb + c] = vv;
         if (p.Kp) {        // the time token's row of the 16-bit operands (the style rows are converted once per call: launch_tv_kv_prep)
-            const int pos = (c & ~12) | ((c & 4) << 1) | ((c & 8) >> 1);          // channel c sits at position pos of its 16-group (accumulator order)
-            reinterpret_cast<unsigned short*>(p.Kp)[(long)b * p.NkPad * p.C + pos] = (unsigned short)(pack2_kind(kv, 0.f, p.lp_kind) & 0xffffu);
-            reinterpret_cast<unsigned short*>(p.VTp)[((long)b * p.C + c) * p.NkPad] = (unsigned short)(pack2_kind(vv, 0.f, p.lp_kind) & 0xffffu);
+            // (fragment order, TvKvPrepP: key 0 = tile 0, st 0, lane i = 0)
+            const int pos = (c & ~12) | ((c & 4) << 1) | ((c & 8) >> 1);          // channel c sits at position pos of its key row (accumulator order inside every 16-group)
+            reinterpret_cast<unsigned short*>(p.Kp)[(long)b * p.NkPad * p.C + ((pos >> 4) * 64 + ((pos >> 3) & 1) * 32) * 8 + (pos & 7)] =
+                (unsigned short)(pack2_kind(kv, 0.f, p.lp_kind) & 0xffffu);
+            reinterpret_cast<unsigned short*>(p.VTp)[(long)b * p.C * p.NkPad + (((c >> 5) * 4) * 64 + (c & 31)) * 8] = (unsigned short)(pack2_kind(vv, 0.f, p.lp_kind) & 0xffffu);
         }
     }
 }

@@ -413,9 +413,10 @@ void launch_tv_row0(const TvRow0P& p, hipStream_t st);
 //   out = mask * (x + linear(softmax((IN2d(x) W_q^T / sqrt(C)) K^T) V))   with the InstanceNorm folded into a per-utterance W_eff, b_eff
 // (launch_in_fold) - q projection, attention over the Ts + 1 style keys, output projection, residual, mask and the TIV adaptor's
 // InstanceNorm statistics of the result per 128-pixel workgroup; q and the attention output never exist in HBM.
-// TvKvPrepP: K / V (fp32 [B][Nk][C]) -> 16-bit operands in the layouts the chain's LDS tiles take as they are: Kp [B][NkPad][C] with the
-// channels of every 16-group in accumulator order, VTp [B][C][NkPad] transposed with the keys of every 16-group in accumulator order;
-// keys >= Nk are zeros.  C = 128.
+// TvKvPrepP: K / V (fp32 [B][Nk][C]) -> 16-bit operands in MFMA FRAGMENT order, as the chain's LDS-DMA ring takes them (per utterance and
+// 64-key tile sixteen 1-KB pieces each): Kp piece (st, ks), lane (i, hh) = key tile * 64 + st * 32 + i, positions ks * 16 + hh * 8 .. + 8 of
+// the key row with the channels of every 16-group in accumulator order; VTp piece (t, q), lane (i, hh), element e = channel t * 32 + i of key
+// tile * 64 + (q / 2) * 32 + (q % 2) * 16 + key_pos(hh * 8 + e); keys >= Nk are zeros.  C = 128.
 struct TvKvPrepP { const float* K; const float* V; long kvb; int Nk; int NkPad; void* Kp; void* VTp; int B; };
 struct TvChainP { const float* X; int ldx; int x_coff; long x_bstride; int npix; int Wm;
                   const float* mask; int mask_ws; long mask_bstride;
