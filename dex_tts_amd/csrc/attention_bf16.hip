@@ -780,9 +780,13 @@ __global__ __launch_bounds__(256, 2) void tv_chain_kernel(const TvChainP p) {
 // LDS: [K'0 | V'^T0 | K'1 | V'^T1], 4 x 16 KB; the x tile and the output stage alias the second half (+ 2.8 KB), so tile 0 lands under
 // the x rows.  The residual rows of the first output half are requested under the last tile, the second half's before the first is
 // processed (the registers the projection form spends on W_l's prefetch).
-static_assert(2 * TVC_FBUF + 128 * K_LD <= TVC_U16 && 2 * TVC_FBUF * 2 + 128 * TVC_SLD * 4 <= TVC_U16 * 2, "x tile / output stage fit behind ring half 0");
+static_assert(128 * TVC_SLD * 4 <= 128 * K_LD * 2, "the output stage fits the x tile's bytes");
 __global__ __launch_bounds__(256, 2) void tv_chain_fold_kernel(const TvChainP p) {
-    extern __shared__ __attribute__((aligned(16))) u16 smem_b[];
+    // The two ring halves are two DISTINCT static arrays and the tile loop is unrolled over them: hipcc puts an s_waitcnt vmcnt(0) in front
+    // of every LDS read that MAY alias an LDS-DMA piece in flight, and with one array (one underlying object) that was the first fragment
+    // read behind the next tile's requests - the ring prefetched nothing.  Reads of ring A provably do not alias pieces landing in ring B.
+    __shared__ __attribute__((aligned(16))) u16 ringA[2 * TVC_FBUF];                                   // tiles 0, 2, 4: [K' | V'^T]
+    __shared__ __attribute__((aligned(16))) u16 ringB[2 * TVC_FBUF > 128 * K_LD ? 2 * TVC_FBUF : 128 * K_LD];   // tiles 1, 3, 5; the x tile / output stage (34.8 KB) alias it
     __shared__ long long red[2 * AHD];
     typedef __attribute__((address_space(3))) void* lds_ptr;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -796,19 +800,16 @@ __global__ __launch_bounds__(256, 2) void tv_chain_fold_kernel(const TvChainP p)
     const u16* Kg = reinterpret_cast<const u16*>(p.Kp) + (long)b * p.NkPad * AHD;
     const u16* Vg = reinterpret_cast<const u16*>(p.VTp) + (long)b * AHD * p.NkPad;
     red[tid] = 0;
-    auto kv_dma = [&](int kt) __attribute__((always_inline)) {       // tile kt of the fragment-ordered operands -> ring half kt & 1
-        u16* dst = smem_b + (kt & 1) * 2 * TVC_FBUF;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int piece = 4 * wave + j;
-            __builtin_amdgcn_global_load_lds(Kg + (long)kt * TVC_FBUF + piece * 512 + lane * 8, (lds_ptr)(dst + piece * 512), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(Vg + (long)kt * TVC_FBUF + piece * 512 + lane * 8, (lds_ptr)(dst + TVC_FBUF + piece * 512), 16, 0, 0);
-        }
-    };
-    if (ntiles > 0) kv_dma(0);               // first K' / V'^T tile in flight under the x rows
+#define TVF_DMA(ring, kt)                                                                                           \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                \
+        const int piece = 4 * wave + j;                                                                             \
+        __builtin_amdgcn_global_load_lds(Kg + (long)(kt) * TVC_FBUF + piece * 512 + lane * 8, (lds_ptr)(&ring[piece * 512]), 16, 0, 0);              \
+        __builtin_amdgcn_global_load_lds(Vg + (long)(kt) * TVC_FBUF + piece * 512 + lane * 8, (lds_ptr)(&ring[TVC_FBUF + piece * 512]), 16, 0, 0);   \
+    }
+    if (ntiles > 0) { TVF_DMA(ringA, 0) }    // first K' / V'^T tile in flight under the x rows
 
     // ---- prologue: the 128 x rows, masked and centred (x * mask - mean: what IN2d subtracts; its 1 / std lives in K'), rounded once
-    u16* Xs = smem_b + 2 * TVC_FBUF;         // [128 pixels][K_LD]
+    u16* Xs = ringB;                         // [128 pixels][K_LD]
     Frag qf[8];
     {
         const float4 mu = *reinterpret_cast<const float4*>(p.xmean + (long)b * AHD + (tid & 31) * 4);
@@ -862,25 +863,34 @@ __global__ __launch_bounds__(256, 2) void tv_chain_fold_kernel(const TvChainP p)
             if (h == 0) { const float mv = mrow[(pc % p.Wm) * p.mask_ws]; mkp[j] = pix < p.npix ? mv : 0.f; }
         }
     };
-    for (int kt = 0; kt + 1 < ntiles; ++kt) {
-        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces of tile kt have landed
-        __syncthreads();                     // ... everybody's: tile kt visible; ring half (kt + 1) & 1 (and the x tile in it) free
-        kv_dma(kt + 1);
-        tvc_tile<true, false>(smem_b + (kt & 1) * 2 * TVC_FBUF, smem_b + (kt & 1) * 2 * TVC_FBUF + TVC_FBUF, qf, o, m_run, l_run, kt * TVC_KT, Nk, lane);
+    int kt = 0;
+    while (kt + 1 < ntiles) {                // (tile kt is not the last one; even tiles live in ring A)
+        __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): this wave's pieces of tile kt have landed (requested a whole tile ago)
+        __syncthreads();                     // ... everybody's: tile kt visible; ring B (tile kt - 1 / the x tile) free
+        TVF_DMA(ringB, kt + 1)
+        tvc_tile<true, false>(ringA, ringA + TVC_FBUF, qf, o, m_run, l_run, kt * TVC_KT, Nk, lane);
+        ++kt;
+        if (kt + 1 >= ntiles) break;
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+        TVF_DMA(ringA, kt + 1)
+        tvc_tile<true, false>(ringB, ringB + TVC_FBUF, qf, o, m_run, l_run, kt * TVC_KT, Nk, lane);
+        ++kt;
     }
+#undef TVF_DMA
     __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
     res_load(0);
     if (ntiles > 0) {
-        const int kt = ntiles - 1;
-        tvc_tile<true>(smem_b + (kt & 1) * 2 * TVC_FBUF, smem_b + (kt & 1) * 2 * TVC_FBUF + TVC_FBUF, qf, o, m_run, l_run, kt * TVC_KT, Nk, lane);
+        if (kt & 1) tvc_tile<true>(ringB, ringB + TVC_FBUF, qf, o, m_run, l_run, kt * TVC_KT, Nk, lane);
+        else tvc_tile<true>(ringA, ringA + TVC_FBUF, qf, o, m_run, l_run, kt * TVC_KT, Nk, lane);
     }
     l_run += __shfl_xor(l_run, 32);
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
     __syncthreads();                         // rings free
 
     // ---- result: O^T / l through the LDS stage as 256-byte row segments, + residual, * mask, the TIV statistics (as the projection form)
-    float* stage = reinterpret_cast<float*>(smem_b + 2 * TVC_FBUF);          // [128 pixels][TVC_SLD]
+    float* stage = reinterpret_cast<float*>(ringB);          // [128 pixels][TVC_SLD]
     float gs[2][4], gq[2][4];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -985,13 +995,12 @@ void launch_tv_chain(const TvChainP& p, hipStream_t st) {
     static bool attr = false;
     if (!attr) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&tv_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&tv_chain_fold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr = true;
     }
     const dim3 grid((p.npix + 127) / 128, p.B);
-    if (p.xmean) {                     // the folded form (kernels.h TvChainP)
+    if (p.xmean) {                     // the folded form (kernels.h TvChainP): static LDS (two ring arrays)
         g_last_symbol = "tv_chain_fold_kernel";
-        hipLaunchKernelGGL(tv_chain_fold_kernel, grid, dim3(256), lds, st, p);
+        hipLaunchKernelGGL(tv_chain_fold_kernel, grid, dim3(256), 0, st, p);
         return;
     }
     g_last_symbol = "tv_chain_kernel";
