@@ -63,5 +63,5 @@ for w in gedex_b1 gedex_b32 dex_b32; do
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES --output-format csv -d /tmp/pqx_$w -o pmc -- python $R/bench.py --workload $w --precision fp16x2 --steps 1 --warmup 0 --graph off $B > /dev/null 2>&1
   python $R/tools/pmc_mfma.py ${w}_fp16x2 0 $(find /tmp/pqx_$w -name "*counter_collection.csv" | head -1) $O/mfma_util.json > $O/${w}_fp16x2_mfma_util.txt 2>&1
 done
-python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
+python $R/bench.py > $O/bench_stdout_line.json 2> $O/bench_default.err; cp $R/gpurun_out/bench_full_gedex_b1_n1.json $O/bench_default.json   # (the FULL record: tests/test_bench_line.py reads profiles/round*_bench_default.json)
 ls -la $O
