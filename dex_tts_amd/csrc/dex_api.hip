@@ -1465,6 +1465,10 @@ struct Runner {
         const DexConfig& c = x->cfg;
         const int B = P.d.B, ns = c.n_stages;
         gn_idx = 0;
+        if (debug) {                          // (G1 checkpoints: this step's rows of the conditioning tables - the time MLP and the DiT's TimestepEmbedder)
+            tap("mlp", P.temb + (long)sp * c.dim, 1, c.dim, c.dim);
+            tap("vit.t_embedder", P.c_emb + (long)sp * c.dit_hidden, 1, c.dit_hidden, c.dit_hidden);
+        }
         if (!stats_other) zero_fill(stats_base, P.stats_bytes, st);   // single call (dex_denoise_once): clear in place
         TD cur{nullptr, 0, 0, 0};
         // Activations whose EVERY consumer rounds them to the MFMA operand type while staging (x * mask with a 0 / 1 mask) are
@@ -1499,6 +1503,10 @@ struct Runner {
             const bool defer = linattn_fused(s.C);
             resblock(x->down_res[i][1], s, r0, P.tadd_down[2 * i + 1], s.r1out, false, defer ? &tail : nullptr, defer0 ? &t0 : nullptr);
             TD r1{s.r1out, s.C, 0, s.C};
+            if (debug && !x->lp()) {          // module-level checkpoints (the reference's module paths): the exact-fp32 mode materialises them
+                char n0[24], n1[24]; snprintf(n0, sizeof n0, "downs.%d.0", i); snprintf(n1, sizeof n1, "downs.%d.1", i);
+                tap(n0, s.r0out, B * s.npix, s.C, s.C); tap(n1, s.r1out, B * s.npix, s.C, s.C);
+            }
             // the Downsample conv is this output's only reader at level 0 (the reference's hiddens.append of this level is never
             // popped; deeper levels live in the up path's concatenation buffer, which is read as fp32)
             const bool t1_lp = lp_inter && i == 0 && i < ns - 1 && linattn_fused(s.C) && linattn_out2_lp_out_supported((int)s.npix, B) && x->lp_of().count(x->down_ds_w[i]);
@@ -1530,6 +1538,7 @@ struct Runner {
                 } else
                 gemm("downsample", g);
                 cur = TD{s.ds_out, s.C, 0, s.C, t2_lp ? lpk : 0};
+                if (debug && !x->lp()) { char nd[24]; snprintf(nd, sizeof nd, "downs.%d.3", i); tap(nd, s.ds_out, (long)B * g.Ho * g.Wo, s.C, s.C); }
             }
         }
         const StageBuf& sm = P.down[ns - 1];
@@ -1559,6 +1568,10 @@ struct Runner {
             const bool defer = linattn_fused(s.C);
             resblock(x->up_res[j][1], s, r0, P.tadd_up[2 * j + 1], s.r1out, false, defer ? &tail : nullptr, defer0 ? &t0 : nullptr);
             TD r1{s.r1out, s.C, 0, s.C};
+            if (debug && !x->lp()) {
+                char n0[24], n1[24]; snprintf(n0, sizeof n0, "ups.%d.0", j); snprintf(n1, sizeof n1, "ups.%d.1", j);
+                tap(n0, s.r0out, B * s.npix, s.C, s.C); tap(n1, s.r1out, B * s.npix, s.C, s.C);
+            }
             const bool t5_lp = lp_inter && linattn_fused(s.C) && linattn_out2_lp_out_supported((int)s.npix, B) && x->lp_of().count(x->up_us_w[j]);
             linattn(x->up_lin[j], s, r1, s.attn_out, s.C, 0, defer ? &tail : nullptr, t5_lp);
             char nm[16]; snprintf(nm, sizeof nm, "up%d", j);

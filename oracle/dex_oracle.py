@@ -68,9 +68,11 @@ def block(W, p: str, x: Tensor, mask: Tensor, groups: int) -> Tensor:
     return mish(y) * mask
 
 
-def resnet_block(W, p: str, x: Tensor, mask: Tensor, temb: Tensor, groups: int) -> Tensor:
+def resnet_block(W, p: str, x: Tensor, mask: Tensor, temb: Tensor, groups: int, taps: Optional[dict] = None) -> Tensor:
     """ResnetBlock.forward — diffusion.py:66-71 (time bias added after the mask, result unmasked)."""
     h = block(W, f"{p}.block1", x, mask, groups)
+    if taps is not None:
+        taps[f"{p}.block1"] = h               # module-level checkpoints (tests/golden/modules_*.npz): Block (a6)
     h = h + linear(W, f"{p}.mlp.1", mish(temb))[:, :, None, None]
     h = block(W, f"{p}.block2", h, mask, groups)
     if f"{p}.res_conv.weight" in W:
@@ -127,7 +129,7 @@ def dit_block(W, p: str, x: Tensor, c: Tensor, heads: int) -> Tensor:
     return x + g2[:, None, :] * h
 
 
-def dit_patchify(W, cfg, x: Tensor):
+def dit_patchify(W, cfg, x: Tensor, taps: Optional[dict] = None):
     """DiTMask.patchify — dit.py:440-456 with PatchEmbed2D :57-59, make_conv_pos :81-96, SamePad :128-139."""
     t = cfg.dit
     w = x.shape[-1]
@@ -136,6 +138,8 @@ def dit_patchify(W, cfg, x: Tensor):
     e = F.conv2d(x, W["vit.x_embedder.proj.0.weight"], W["vit.x_embedder.proj.0.bias"],
                  stride=t.stride_size, padding=t.patch_size // 2, groups=x.shape[1])
     e = F.conv2d(F.silu(e), W["vit.x_embedder.proj.2.weight"], W["vit.x_embedder.proj.2.bias"])
+    if taps is not None:
+        taps["vit.x_embedder"] = e            # PatchEmbed2D (a10)
     pos = F.conv2d(e, W["vit.pos_conv.0.weight"], W["vit.pos_conv.0.bias"],
                    padding=t.conv_pos // 2, groups=t.conv_pos_groups)
     if t.conv_pos % 2 == 0:
@@ -149,10 +153,11 @@ def dit_patchify(W, cfg, x: Tensor):
 def dit_forward(W, cfg, x: Tensor, mask_mid: Tensor, t: Tensor, taps: Optional[dict] = None) -> Tensor:
     """DiTMask.forward, eval / mask_ratio=0 / use_decoder=False path — dit.py:485-525."""
     td = cfg.dit
-    tok, w_orig, hh, ww = dit_patchify(W, cfg, x)
+    tok, w_orig, hh, ww = dit_patchify(W, cfg, x, taps)
     c = linear(W, "vit.t_embedder.mlp.2", F.silu(linear(W, "vit.t_embedder.mlp.0", sinusoid_dit(t, 256))))
     if taps is not None:
         taps["tok_in"] = tok
+        taps["vit.t_embedder"] = c            # TimestepEmbedder (a11)
     for k in range(td.depth):
         tok = dit_block(W, f"vit.blocks.{k}", tok, c, td.num_heads)
         if taps is not None:
@@ -160,6 +165,8 @@ def dit_forward(W, cfg, x: Tensor, mask_mid: Tensor, t: Tensor, taps: Optional[d
     mod = linear(W, "vit.final_layer.adaLN_modulation.1", F.silu(c))
     shift, scale = mod.chunk(2, dim=1)
     tok = linear(W, "vit.final_layer.linear", modulate(layer_norm_noaffine(tok), shift, scale))
+    if taps is not None:
+        taps["vit.final_layer"] = tok         # FinalLayer before unpatchify (a13)
     # unpatchify 'B (h w) (p1 p2 C) -> B C (h p1) (w p2)' — dit.py:458-463
     B, N, _ = tok.shape
     s, C = td.stride_size, x.shape[1]
@@ -234,6 +241,8 @@ def denoiser_forward(W, cfg, x: Tensor, mask: Tensor, mu: Tensor, t: Tensor, spk
     h = torch.stack(planes, dim=1)
     t_init = sinusoid_unet(t, d, cfg.pe_scale)
     temb = linear(W, "mlp.2", mish(linear(W, "mlp.0", t_init)))
+    if taps is not None:
+        taps["mlp"] = temb                    # sinusoid + time MLP (a5)
     if cfg.variant == "dex":
         t_adap = linear(W, "mlp_adap.2", mish(linear(W, "mlp_adap.0", t_init)))            # [1|B, 2d]
         t_sty = linear(W, "mlp_adap_sty.2", mish(linear(W, "mlp_adap_sty.0", t_init)))
@@ -243,8 +252,12 @@ def denoiser_forward(W, cfg, x: Tensor, mask: Tensor, mu: Tensor, t: Tensor, spk
     n_stage = len(cfg.dim_mults)
     for i in range(n_stage):
         md = masks[-1]
-        h = resnet_block(W, f"downs.{i}.0", h, md, temb, g)
-        h = resnet_block(W, f"downs.{i}.1", h, md, temb, g)
+        h = resnet_block(W, f"downs.{i}.0", h, md, temb, g, taps)
+        if taps is not None:
+            taps[f"downs.{i}.0"] = h          # ResnetBlock (a7)
+        h = resnet_block(W, f"downs.{i}.1", h, md, temb, g, taps)
+        if taps is not None:
+            taps[f"downs.{i}.1"] = h
         h = linear_attention(W, f"downs.{i}.2", h, cfg.lin_heads, cfg.lin_dim_head)
         hiddens.append(h)
         if taps is not None:
@@ -252,6 +265,8 @@ def denoiser_forward(W, cfg, x: Tensor, mask: Tensor, mu: Tensor, t: Tensor, spk
         h = h * md
         if i < n_stage - 1:
             h = F.conv2d(h, W[f"downs.{i}.3.conv.weight"], W[f"downs.{i}.3.conv.bias"], stride=2, padding=1)
+            if taps is not None:
+                taps[f"downs.{i}.3"] = h      # Downsample (a9)
         masks.append(md[:, :, :, ::2])
     masks = masks[:-1]
     mm = masks[-1]
@@ -270,8 +285,12 @@ def denoiser_forward(W, cfg, x: Tensor, mask: Tensor, mu: Tensor, t: Tensor, spk
     for j in range(n_stage - 1):
         mu_ = masks.pop()
         h = torch.cat([h, hiddens.pop()], dim=1)
-        h = resnet_block(W, f"ups.{j}.0", h, mu_, temb, g)
-        h = resnet_block(W, f"ups.{j}.1", h, mu_, temb, g)
+        h = resnet_block(W, f"ups.{j}.0", h, mu_, temb, g, taps)
+        if taps is not None:
+            taps[f"ups.{j}.0"] = h
+        h = resnet_block(W, f"ups.{j}.1", h, mu_, temb, g, taps)
+        if taps is not None:
+            taps[f"ups.{j}.1"] = h
         h = linear_attention(W, f"ups.{j}.2", h, cfg.lin_heads, cfg.lin_dim_head)
         if taps is not None:
             taps[f"up{j}"] = h
@@ -281,6 +300,9 @@ def denoiser_forward(W, cfg, x: Tensor, mask: Tensor, mu: Tensor, t: Tensor, spk
         taps["up_out"] = h
     h = block(W, "final_block", h, m, g)
     out = F.conv2d(h * m, W["final_conv.weight"], W["final_conv.bias"])
+    if taps is not None:
+        taps["final_block"] = h               # final Block + 1x1 conv (a14)
+        taps["final_conv"] = out
     return (out * m).squeeze(1)
 
 
